@@ -1,0 +1,71 @@
+"""Deterministic scene generators for the headless bench and the parity tests.
+
+The reference only ships interactive demo scenes (ref: src/main.cpp:82-230).  `stack` keeps the
+box size / spacing of its scene 4 ("Stacks", main.cpp:154-168) without the taper so boxes rest
+exactly on each other; `falling` keeps the shape of scene 0 (main.cpp:97-110) but draws from
+splitmix64 instead of libc rand() so the scene is reproducible everywhere.  A scene is a dict of
+equal-length numpy arrays: px, py, angle, sx, sy (half sizes), static (bool).
+"""
+import numpy as np
+
+
+def _scene(px, py, angle, sx, sy, static):
+    return {
+        "px": np.asarray(px, dtype=np.float32), "py": np.asarray(py, dtype=np.float32),
+        "angle": np.asarray(angle, dtype=np.float32), "sx": np.asarray(sx, dtype=np.float32),
+        "sy": np.asarray(sy, dtype=np.float32), "static": np.asarray(static, dtype=bool),
+    }
+
+
+def stack(nx, ny, x_offset_columns=0):
+    """Ground (body 0, static, half-size (max(nx,1)*15, 10) at the origin) + nx columns of ny boxes of
+    half-size 5x5, column pitch 15, row pitch 10.  `x_offset_columns` shifts the
+    columns sideways (used to give each rank of a multi-GPU run its own slab of one wide world)."""
+    n = nx * ny
+    xs = np.repeat(np.arange(nx, dtype=np.int64), ny)
+    ys = np.tile(np.arange(ny, dtype=np.int64), nx)
+    px = np.concatenate([[0.0 + x_offset_columns * 15.0], (xs - nx // 2 + x_offset_columns) * 15.0]).astype(np.float32)
+    py = np.concatenate([[0.0], 15.0 + 10.0 * ys]).astype(np.float32)
+    sx = np.concatenate([[max(nx, 1) * 15.0], np.full(n, 5.0)]).astype(np.float32)
+    sy = np.concatenate([[10.0], np.full(n, 5.0)]).astype(np.float32)
+    static = np.zeros(n + 1, dtype=bool)
+    static[0] = True
+    return _scene(px, py, np.zeros(n + 1), sx, sy, static)
+
+
+def _splitmix64(state):
+    state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return state, z ^ (z >> 31)
+
+
+def falling(n, seed=1, half=4.0, width=500.0, ymin=50.0, ymax=1000.0, ground_half_width=10000.0):
+    """Ground + n boxes of half-size `half` scattered uniformly (reference scene 0 shape)."""
+    s = seed
+    px, py = [0.0], [0.0]
+    for _ in range(n):
+        s, a = _splitmix64(s)
+        s, b = _splitmix64(s)
+        u = (a >> 40) / float(1 << 24)
+        v = (b >> 40) / float(1 << 24)
+        px.append(-width + 2.0 * width * u)
+        py.append(ymin + (ymax - ymin) * v)
+    sx = [ground_half_width] + [half] * n
+    sy = [10.0] + [half] * n
+    static = [True] + [False] * n
+    return _scene(px, py, np.zeros(n + 1), sx, sy, static)
+
+
+def tilted(n, seed=7):
+    """Small scene of rotated boxes dropped on the ground — exercises the vertex/edge contact cases
+    (ref: Collider.cpp:94-209) that axis-aligned stacks never reach."""
+    sc = falling(n, seed=seed, half=6.0, width=60.0, ymin=20.0, ymax=200.0, ground_half_width=400.0)
+    s = seed * 977
+    ang = [0.0]
+    for _ in range(n):
+        s, a = _splitmix64(s)
+        ang.append(-1.5 + 3.0 * ((a >> 40) / float(1 << 24)))
+    sc["angle"] = np.asarray(ang, dtype=np.float32)
+    return sc
