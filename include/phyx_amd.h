@@ -1,0 +1,227 @@
+/*
+ * phyx_amd.h — C ABI of the MI355X-native contact solver + sweep-and-prune broadphase.
+ *
+ * The reference (zeux/phyx) has no plugin/FFI layer; its de-facto boundary is what World::Update
+ * calls (ref: src/World.cpp:19-37): Collider::UpdateBroadphase / UpdatePairs (src/Collider.h:28-29),
+ * Solver::SolveJoints (src/Solver.h:54) and the Configuration struct (src/Configuration.h:3-23),
+ * all operating on the public POD arrays RigidBody (src/RigidBody.h:12-57, 128 B), ContactPoint
+ * (src/Manifold.h:12-43, 32 B), Manifold (src/Manifold.h:45-67, 16 B) and ContactJoint
+ * (src/Joints.h:6-23, 20 B).  Every entry point below names the reference interface it replaces
+ * and takes those exact layouts, so buffers can cross the boundary unchanged.
+ *
+ * Conventions: plain pointers and sizes only; every function returns PHX_OK (0) or a negative
+ * phx_status (the reference's void/assert convention is the one deliberate deviation);
+ * phx_last_error() gives the message of the last failure on the calling thread.  A handle is not
+ * re-entrant (like the reference's member scratch, ref: src/Solver.h:108-128): one thread per
+ * handle at a time.  Pointers are borrowed for the duration of the call only.
+ *
+ * There is no CPU fallback: every compute entry point fails with PHX_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef PHYX_AMD_H
+#define PHYX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHX_ABI_VERSION 1
+
+typedef enum {
+    PHX_OK = 0,
+    PHX_ERR_INVALID = -1,     /* bad argument / size / enum value                         */
+    PHX_ERR_NO_DEVICE = -2,   /* no usable HIP device                                      */
+    PHX_ERR_HIP = -3,         /* a HIP runtime call failed (see phx_last_error)            */
+    PHX_ERR_CAPACITY = -4,    /* caller-provided output buffer too small                   */
+    PHX_ERR_STATE = -5        /* call order violated (e.g. query before first solve)       */
+} phx_status;
+
+/* ref: src/Configuration.h:5-18 — same numeric values */
+enum { PHX_SOLVE_SCALAR = 0, PHX_SOLVE_SSE2 = 1, PHX_SOLVE_AVX2 = 2 };
+enum { PHX_ISLAND_SINGLE = 0, PHX_ISLAND_MULTIPLE = 1, PHX_ISLAND_SINGLE_SLOPPY = 2, PHX_ISLAND_MULTIPLE_SLOPPY = 3 };
+
+/* ref: src/Configuration.h:20-23.  On this backend the wavefront is the SIMD unit, so solve_mode
+ * does not select a code path: every mode runs per-joint (scalar, N=1) skip semantics in the
+ * device's own colour order.  island_mode picks the schedule: Single* = one coupled system solved
+ * colour by colour out of HBM; Multiple* = islands split (GatherIslands semantics) and solved one
+ * island per workgroup out of LDS where they fit.  The Sloppy variants are accepted and run the
+ * same deterministic schedule (a legal outcome of the reference's racy modes). */
+typedef struct {
+    int32_t solve_mode;
+    int32_t island_mode;
+    int32_t contact_iterations;
+    int32_t penetration_iterations;
+} phx_config;
+
+/* byte-exact POD records (static_asserted in the implementation) */
+typedef struct { float x, y; } phx_vec2;
+typedef struct {                                  /* ref: src/RigidBody.h:12-57 */
+    uint32_t index;
+    phx_vec2 geom_size, geom_xvector, geom_yvector, geom_pos, aabb_min, aabb_max;
+    phx_vec2 velocity, acceleration, displacing_velocity;
+    float    angular_velocity, angular_acceleration, displacing_angular_velocity;
+    float    inv_mass, inv_inertia;
+    phx_vec2 xvector, yvector, pos;
+    int32_t  last_iteration, last_displacement_iteration;
+} phx_rigid_body;                                 /* 128 B */
+typedef struct {                                  /* ref: src/Manifold.h:12-43 */
+    phx_vec2 delta1, delta2, normal;
+    uint8_t  is_merged, is_newly_created, pad_[2];
+    int32_t  solver_index;
+} phx_contact_point;                              /* 32 B */
+typedef struct { int32_t body1, body2, point_count, point_index; } phx_manifold;   /* ref: src/Manifold.h:45-67, 16 B */
+typedef struct {                                  /* ref: src/Joints.h:6-23 */
+    int32_t contact_point_index, body1, body2;
+    float   normal_accumulated_impulse, friction_accumulated_impulse;
+} phx_contact_joint;                              /* 20 B */
+typedef struct { float minx, maxx, centery, extenty; uint32_t index; } phx_broadphase_entry; /* ref: src/Collider.h:45-50, 20 B */
+typedef struct { uint32_t value, index; } phx_sort_entry;                                     /* ref: src/Collider.h:52-56, 8 B  */
+
+/* ---------------------------------------------------------------------------------------------- */
+/* library                                                                                         */
+int          phx_abi_version(void);
+const char*  phx_last_error(void);
+int          phx_device_count(void);              /* >=0, or a negative phx_status */
+/* name / CU count / LDS per workgroup of `device`; name_cap bytes incl. NUL */
+int          phx_device_info(int device, char* name, int name_cap, int* compute_units, int* lds_bytes, int64_t* hbm_bytes);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Solver — replaces Solver::SolveJoints (ref: src/Solver.h:54, src/Solver.cpp:17-119)             */
+typedef struct phx_solver phx_solver;
+
+int  phx_solver_create(phx_solver** out, int device);
+void phx_solver_destroy(phx_solver* s);
+
+/* Drop-in for Solver::SolveJoints: HOST arrays in the reference's layouts.  Reads per body
+ * invMass/invInertia/coords.pos and the four velocity fields, per contact point delta1/delta2/
+ * normal, per joint indices + accumulated impulses; writes back bodies[i].velocity /
+ * angularVelocity / displacingVelocity / displacingAngularVelocity (ref: Solver.cpp:488-492) and
+ * the joints' two accumulated impulses (ref: Solver.cpp:543-544).  Uploads, solves on the device,
+ * downloads — the PCIe cost is part of this call. */
+int phx_solver_solve(phx_solver* s, phx_rigid_body* bodies, int32_t body_count,
+                     const phx_contact_point* contact_points, int32_t contact_point_count,
+                     phx_contact_joint* joints, int32_t joint_count, const phx_config* config);
+
+/* Same computation on DEVICE-resident arrays (same layouts, HBM pointers), asynchronous on the
+ * solver's stream; nothing crosses PCIe except the topology check word.  This is the entry point
+ * a device-resident World uses and the one bench.py times. */
+int phx_solver_solve_device(phx_solver* s, void* d_bodies, int32_t body_count,
+                            const void* d_contact_points, int32_t contact_point_count,
+                            void* d_joints, int32_t joint_count, const phx_config* config);
+int phx_solver_synchronize(phx_solver* s);
+
+/* results of the last solve (valid after a synchronizing call) — counterparts of
+ * Solver::islandCount / islandMaxSize (ref: src/Solver.h:105-106) plus executed sweep counts */
+typedef struct {
+    int32_t island_count, island_max_size;
+    int32_t colour_count;
+    int32_t impulse_iterations;        /* sweeps executed before the no-productive-joint exit (ref: Solver.cpp:189) */
+    int32_t displacement_iterations;   /* ref: Solver.cpp:210 */
+    int32_t lds_islands;               /* islands solved by the one-workgroup-per-island kernel */
+    int32_t recoloured;                /* 1 if the joint topology changed and the schedule was rebuilt */
+    int32_t reserved;
+    double  device_ms;                 /* HIP-event time of the device work of the last solve */
+} phx_solve_stats;
+int phx_solver_get_stats(phx_solver* s, phx_solve_stats* out);
+
+/* The schedule the device used: order[k] = index of the joint occupying slot k; colour c owns slots
+ * [colour_offsets[c], colour_offsets[c+1]).  Sweeping the slots front to back with the reference's
+ * scalar loop reproduces the device result bit for bit (tests/ feeds this to the oracle). */
+int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap,
+                            int32_t* colour_offsets, int32_t offsets_cap, int32_t* colour_count);
+
+/* RefreshJoints output for joint `joint_index` of the last solve (ref: Solver.cpp:592-695), expanded
+ * to the reference's 30-float ContactJointPacked<1> order: normal limiter 13, 0, dstVelocity,
+ * dstDisplacingVelocity, accumulatedDisplacingImpulse(after solve), friction limiter 13. */
+int phx_solver_get_refreshed(phx_solver* s, int32_t joint_index, float out30[30]);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Broadphase — replaces Collider::UpdateBroadphase + UpdatePairs                                   */
+/* (ref: src/Collider.h:28-29, src/Collider.cpp:251-366, src/base/RadixSort.h:19-95)               */
+typedef struct phx_broadphase phx_broadphase;
+
+int  phx_broadphase_create(phx_broadphase** out, int device);
+void phx_broadphase_destroy(phx_broadphase* b);
+/* forget every persistent pair (ref: main.cpp:88 manifoldMap.clear()) */
+int  phx_broadphase_clear(phx_broadphase* b);
+
+/* UpdateBroadphase + UpdatePairs on HOST bodies (reads geom.aabb only).  new_pairs receives the
+ * pairs that were not yet in the persistent pair set, as (index_i, index_j) in the reference's
+ * serial emission order (ref: Collider.cpp:296-318), and inserts them into the set.
+ * *new_pair_count always receives the full count (PHX_ERR_CAPACITY if it exceeds the cap). */
+int phx_broadphase_update(phx_broadphase* b, const phx_rigid_body* bodies, int32_t body_count,
+                          uint32_t* new_pairs, int32_t new_pairs_cap, int32_t* new_pair_count);
+int phx_broadphase_update_device(phx_broadphase* b, const void* d_bodies, int32_t body_count);
+/* after an update: broadphaseSort[1] and broadphase[] of the reference (ref: Collider.h:64-65) */
+int phx_broadphase_get_sorted(phx_broadphase* b, phx_sort_entry* sorted, phx_broadphase_entry* entries, int32_t cap);
+/* pairs emitted by the last update (device variant leaves them on the device until asked) */
+int phx_broadphase_get_new_pairs(phx_broadphase* b, uint32_t* new_pairs, int32_t cap, int32_t* count);
+/* remove pairs from the persistent set (ref: Collider.cpp:391 manifoldMap.erase) */
+int phx_broadphase_erase_pairs(phx_broadphase* b, const uint32_t* pairs, int32_t pair_count);
+typedef struct {
+    int64_t candidate_tests;      /* y-overlap tests executed by the sweep (20 B each) */
+    int64_t overlapping_pairs;    /* candidates that passed the y test                               */
+    int32_t new_pairs;
+    int32_t set_size;             /* persistent pairs after the update                               */
+    double  device_ms;
+} phx_broadphase_stats;
+int phx_broadphase_get_stats(phx_broadphase* b, phx_broadphase_stats* out);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* World — replaces World (ref: src/World.h:9-36, src/World.cpp:11-37)                              */
+typedef struct phx_world phx_world;
+
+int  phx_world_create(phx_world** out, int device);
+void phx_world_destroy(phx_world* w);
+/* World::AddBody (ref: World.cpp:11-17; RigidBody ctor RigidBody.h:15-36, density 1e-5); returns index */
+int  phx_world_add_body(phx_world* w, float px, float py, float angle, float half_x, float half_y);
+/* main.cpp:91-93 groundBody->invMass = invInertia = 0 */
+int  phx_world_set_body_static(phx_world* w, int32_t body);
+int  phx_world_set_gravity(phx_world* w, float gravity);            /* ref: World.h:35 */
+/* restrict the solve to islands whose index % shard_count == shard (multi-GPU island sharding; the
+ * default 0/1 solves everything).  Bodies of other shards keep their velocities. */
+int  phx_world_set_shard(phx_world* w, int32_t shard, int32_t shard_count);
+int  phx_world_update(phx_world* w, float dt, const phx_config* config);   /* ref: World.cpp:19-37 */
+int  phx_world_counts(phx_world* w, int32_t* bodies, int32_t* manifolds, int32_t* contact_points, int32_t* joints);
+int  phx_world_get_bodies(phx_world* w, phx_rigid_body* out, int32_t cap);
+int  phx_world_get_manifolds(phx_world* w, phx_manifold* out, int32_t cap);
+int  phx_world_get_contact_points(phx_world* w, phx_contact_point* out, int32_t cap);
+int  phx_world_get_joints(phx_world* w, phx_contact_joint* out, int32_t cap);
+int  phx_world_get_solve_stats(phx_world* w, phx_solve_stats* out);
+int  phx_world_get_broadphase_stats(phx_world* w, phx_broadphase_stats* out);
+/* handles owned by the world (for stage-level queries after an update) */
+phx_solver*     phx_world_solver(phx_world* w);
+phx_broadphase* phx_world_broadphase(phx_world* w);
+/* per-phase wall/device milliseconds of the last update, in World::Update order:
+ * 0 IntegrateVelocity 1 UpdateBroadphase 2 UpdatePairs 3 UpdateManifolds 4 PackManifolds
+ * 5 RefreshContactJoints 6 SolveJoints 7 IntegratePosition */
+int  phx_world_get_phase_ms(phx_world* w, double out8[8]);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* measurement helpers used by bench.py: HIP events on the handle's own stream                     */
+typedef struct {
+    double  total_ms;             /* events around the whole timed region                      */
+    double  impulse_kernel_ms;    /* sum of HIP-event brackets around the impulse sweeps        */
+    int64_t impulse_launches;     /* colour kernels launched in those brackets                  */
+    int64_t joint_visits;         /* joints swept by them (skipped joints count as visited)     */
+    int64_t impulse_iterations;   /* sweeps executed                                            */
+} phx_bench_result;
+/* runs `steps` solves of identical device-resident input (state restored before each step from a
+ * device-side snapshot, outside the event brackets) and reports event timings */
+int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_contact_points,
+                     int32_t contact_point_count, const void* d_joints, int32_t joint_count,
+                     const phx_config* config, int32_t warmup, int32_t steps, phx_bench_result* out);
+
+/* raw device memory helpers so callers without a HIP binding (ctypes) can stage resident inputs */
+int phx_device_malloc(int device, size_t bytes, void** out);
+int phx_device_free(int device, void* p);
+int phx_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
+int phx_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYX_AMD_H */

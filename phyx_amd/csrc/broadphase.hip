@@ -1,0 +1,603 @@
+// broadphase.hip — single-axis sweep-and-prune broadphase on gfx950.
+//
+// Replaces (ref = /root/reference/src): Collider::UpdateBroadphase (Collider.cpp:251-284) = key build with
+// radixFloat (base/RadixSort.h:19-26) + radixSort3 (base/RadixSort.h:28-95) + gather of sorted
+// BroadphaseEntry records; Collider::UpdatePairs* (Collider.cpp:286-366) = forward sweep with the y-overlap
+// test and the persistent pair set `manifoldMap` (Collider.h:58, base/DenseHash.h).
+//
+// Device layout:
+//   keys/idx      u32 key = radixFloat(aabb.min.x), u32 idx — two ping-pong pairs of SoA arrays
+//   entries       float4 {minx, maxx, centery, extenty} per sorted position + u32 body index (SoA)
+//   pair set      open-addressing table of u64 (index_i << 32 | index_j), linear probing, in HBM
+//   new pairs     uint2 list in the reference's serial emission order (row i ascending, then j)
+//
+// The sort is a stable LSD radix sort on the full 32-bit key.  The reference splits the key 11/11/10; a
+// stable sort's output permutation does not depend on the digit split, so 4 passes of 8 bits (256-bin
+// LDS histograms, one wave-private counter row per wave) give the identical sequence.
+#include "broadphase.h"
+
+#include <algorithm>
+
+namespace phx {
+
+static inline int grid_for(int n, int per_block = 256, int cap = 4096) { return std::max(1, std::min(div_up(n, per_block), cap)); }
+
+// ---- radixFloat (ref: base/RadixSort.h:19-26) -------------------------------------------------------
+__device__ __forceinline__ unsigned radix_float(float v)
+{
+    const int f = __float_as_int(v);
+    const unsigned mask = (unsigned)(f >> 31) | 0x80000000u;
+    return (unsigned)f ^ mask;
+}
+
+// ref: Collider.cpp:259-265
+__global__ void __launch_bounds__(256) k_build_keys(const phx_rigid_body* __restrict__ bodies, int n,
+                                                    unsigned* __restrict__ keys, unsigned* __restrict__ idx)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        keys[i] = radix_float(bodies[i].aabb_min.x);
+        idx[i] = (unsigned)i;
+    }
+}
+
+// ---- one radix pass = histogram -> scan -> scatter --------------------------------------------------
+constexpr int RS_THREADS = 256;                 // 4 waves
+constexpr int RS_ITEMS = 8;                     // keys per lane
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 keys per workgroup
+constexpr int RS_BINS = 256;
+
+// per-workgroup digit histogram -> hist[digit * nblocks + block]
+__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const unsigned* __restrict__ keys, int n, int shift, int nblocks,
+                                                           unsigned* __restrict__ hist)
+{
+    __shared__ unsigned h[RS_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int e = base + i * RS_THREADS + threadIdx.x;
+        if (e < n) atomicAdd(&h[(keys[e] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive prefix sum of `count` words in place, one workgroup of 1024 lanes
+__global__ void __launch_bounds__(1024) k_exclusive_scan(unsigned* __restrict__ data, int count, unsigned* __restrict__ total_out)
+{
+    __shared__ unsigned partial[1024];
+    const int seg = (count + 1023) / 1024;
+    const int b = threadIdx.x * seg, e = min(b + seg, count);
+    unsigned sum = 0;
+    for (int i = b; i < e; ++i) sum += data[i];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
+        unsigned v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = partial[threadIdx.x] - sum;
+    for (int i = b; i < e; ++i) { const unsigned c = data[i]; data[i] = run; run += c; }
+    if (total_out && threadIdx.x == 1023) *total_out = partial[1023];
+}
+
+// stable scatter of one 8-bit digit.  Element order inside the tile is (wave, item, lane) = index order,
+// so ranks are assigned in that order: per item a wave-wide match on the digit gives each lane the number
+// of equal digits in lower lanes; a wave-private LDS counter row carries the count across items; an
+// exclusive scan over the 4 waves' rows orders the waves.
+__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ idx_in,
+                                                              unsigned* __restrict__ keys_out, unsigned* __restrict__ idx_out,
+                                                              int n, int shift, int nblocks, const unsigned* __restrict__ hist)
+{
+    __shared__ unsigned cnt[4][RS_BINS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4 * RS_BINS; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const int base = blockIdx.x * RS_TILE + wave * (64 * RS_ITEMS);
+    unsigned key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    volatile unsigned* my = cnt[wave];
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int e = base + i * 64 + lane;
+        const bool live = e < n;
+        key[i] = live ? keys_in[e] : 0xFFFFFFFFu;
+        val[i] = live ? idx_in[e] : 0u;
+        const unsigned d = (key[i] >> shift) & 255u;
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned lower = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        const unsigned prior = live ? my[d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (live && lower == 0) my[d] = prior + (unsigned)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = prior + lower;
+    }
+    __syncthreads();
+    // exclusive scan over waves per digit, plus the workgroup's global base for that digit
+    {
+        const int d = threadIdx.x;
+        unsigned run = hist[d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const unsigned c = cnt[w][d]; cnt[w][d] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int e = base + i * 64 + lane;
+        if (e < n) {
+            const unsigned d = (key[i] >> shift) & 255u;
+            const unsigned dst = cnt[wave][d] + rank[i];
+            keys_out[dst] = key[i];
+            idx_out[dst] = val[i];
+        }
+    }
+}
+
+// ref: Collider.cpp:269-283
+__global__ void __launch_bounds__(256) k_gather_entries(const phx_rigid_body* __restrict__ bodies, const unsigned* __restrict__ idx, int n,
+                                                        float4* __restrict__ entries)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const phx_rigid_body& b = bodies[idx[i]];
+        const float minx = b.aabb_min.x, miny = b.aabb_min.y, maxx = b.aabb_max.x, maxy = b.aabb_max.y;
+        entries[i] = make_float4(minx, maxx, (miny + maxy) * 0.5f, (maxy - miny) * 0.5f);
+    }
+}
+
+// ---- persistent pair set ------------------------------------------------------------------------------
+constexpr unsigned long long PS_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned long long PS_TOMB = 0xFFFFFFFFFFFFFFFEull;
+
+__device__ __forceinline__ unsigned ps_hash(unsigned long long k)
+{
+    // same mixing idea as the reference's pair hash (ref: Collider.h:10-18), finished with a multiply
+    const unsigned lb = (unsigned)(k >> 32), rb = (unsigned)k;
+    return (lb ^ (rb + 0x9e3779b9u + (lb << 6) + (lb >> 2))) * 0x9E3779B1u;
+}
+
+__device__ __forceinline__ bool ps_contains(const unsigned long long* __restrict__ table, unsigned mask, unsigned long long k)
+{
+    unsigned p = ps_hash(k) & mask;
+    for (;;) {
+        const unsigned long long s = table[p];
+        if (s == k) return true;
+        if (s == PS_EMPTY) return false;
+        p = (p + 1) & mask;
+    }
+}
+
+// keys are distinct and known to be absent
+__global__ void __launch_bounds__(256) k_ps_insert(unsigned long long* table, unsigned mask, const uint2* __restrict__ pairs, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = ((unsigned long long)pairs[i].x << 32) | pairs[i].y;
+        unsigned p = ps_hash(k) & mask;
+        for (;;) {
+            const unsigned long long s = table[p];
+            if (s == PS_EMPTY || s == PS_TOMB) {
+                if (atomicCAS(&table[p], s, k) == s) break;
+                continue;      // lost the slot to another inserter: look at it again
+            }
+            p = (p + 1) & mask;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ps_erase(unsigned long long* table, unsigned mask, const uint2* __restrict__ pairs, int n, int* erased)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = ((unsigned long long)pairs[i].x << 32) | pairs[i].y;
+        unsigned p = ps_hash(k) & mask;
+        for (;;) {
+            const unsigned long long s = table[p];
+            if (s == k) { table[p] = PS_TOMB; atomicAdd(erased, 1); break; }
+            if (s == PS_EMPTY) break;
+            p = (p + 1) & mask;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ps_rehash(const unsigned long long* __restrict__ old_table, unsigned old_cap,
+                                                   unsigned long long* table, unsigned mask)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = old_table[i];
+        if (k == PS_EMPTY || k == PS_TOMB) continue;
+        unsigned p = ps_hash(k) & mask;
+        for (;;) {
+            if (table[p] == PS_EMPTY && atomicCAS(&table[p], PS_EMPTY, k) == PS_EMPTY) break;
+            p = (p + 1) & mask;
+        }
+    }
+}
+
+// ---- sweep (ref: Collider.cpp:296-318 serial order, :347-366 per-row body) ----------------------------
+// Rows with a short scan range are swept one row per lane: lane l of a wave owns sorted row i0+l and reads
+// entries[i0+l+1+t] in step t, so a wave's loads are contiguous.  Rows whose range exceeds HUB_LEN (the
+// ground box spans every column) are deferred to a workgroup-per-row kernel.
+constexpr int HUB_LEN = 4096;
+
+struct SweepView {
+    const float4* entries;
+    const unsigned* idx;
+    int n;
+    const unsigned long long* table;
+    unsigned mask;
+    unsigned* row_count;       // new pairs per row
+    int* hub_rows;             // rows deferred to the hub kernels
+    int* hub_count;
+    unsigned long long* counters;   // [0] candidate tests, [1] overlapping pairs
+};
+
+// first position j > i with minx[j] > maxx (entries sorted by minx)
+__device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int n, int i, float maxx)
+{
+    int lo = i + 1, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (entries[mid].x > maxx) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
+{
+    unsigned long long tests = 0, overlaps = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
+        const float4 a = v.entries[i];
+        const int end = scan_end(v.entries, v.n, i, a.y);
+        if (end - i - 1 > HUB_LEN) {
+            if (!EMIT) { v.row_count[i] = 0; v.hub_rows[atomicAdd(v.hub_count, 1)] = i; }
+            continue;
+        }
+        const unsigned ia = v.idx[i];
+        unsigned found = 0;
+        unsigned dst = EMIT ? row_offset[i] : 0u;
+        for (int j = i + 1; j < end; ++j) {
+            const float4 b = v.entries[j];
+            if (fabsf(b.z - a.z) <= a.w + b.w) {
+                const unsigned ib = v.idx[j];
+                if (!EMIT) ++overlaps;
+                if (!ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | ib)) {
+                    if (EMIT) out[dst + found] = make_uint2(ia, ib);
+                    ++found;
+                }
+            }
+        }
+        if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)(end - i - 1); }
+    }
+    if (!EMIT) {
+        for (int off = 32; off > 0; off >>= 1) { tests += __shfl_down(tests, off); overlaps += __shfl_down(overlaps, off); }
+        if ((threadIdx.x & 63) == 0) {
+            if (tests) atomicAdd(&v.counters[0], tests);
+            if (overlaps) atomicAdd(&v.counters[1], overlaps);
+        }
+    }
+}
+
+// one workgroup per hub row; tiles of 256 candidates in j order, running base keeps emission order
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_sweep_hubs(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
+{
+    __shared__ unsigned wave_cnt[4];
+    __shared__ unsigned running;
+    const int i = v.hub_rows[blockIdx.x];
+    const float4 a = v.entries[i];
+    const unsigned ia = v.idx[i];
+    const int end = scan_end(v.entries, v.n, i, a.y);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) running = EMIT ? row_offset[i] : 0u;
+    unsigned long long overlaps = 0;
+    __syncthreads();
+    for (int j0 = i + 1; j0 < end; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        bool hit = false;
+        unsigned ib = 0;
+        if (j < end) {
+            const float4 b = v.entries[j];
+            if (fabsf(b.z - a.z) <= a.w + b.w) {
+                ib = v.idx[j];
+                ++overlaps;
+                hit = !ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | ib);
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+        const unsigned base = running;
+        if (EMIT && hit) out[base + before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(ia, ib);
+        __syncthreads();
+        if (threadIdx.x == 0) running = base + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (!EMIT) {
+        if (threadIdx.x == 0) { v.row_count[i] = running; atomicAdd(&v.counters[0], (unsigned long long)(end - i - 1)); }
+        for (int off = 32; off > 0; off >>= 1) overlaps += __shfl_down(overlaps, off);
+        if (lane == 0 && overlaps) atomicAdd(&v.counters[1], overlaps);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_entries_to_aos(const float4* __restrict__ entries, const unsigned* __restrict__ keys,
+                                                        const unsigned* __restrict__ idx, int n,
+                                                        phx_broadphase_entry* __restrict__ out_entries, phx_sort_entry* __restrict__ out_sorted)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 e = entries[i];
+        out_entries[i].minx = e.x; out_entries[i].maxx = e.y; out_entries[i].centery = e.z; out_entries[i].extenty = e.w;
+        out_entries[i].index = idx[i];
+        out_sorted[i].value = keys[i]; out_sorted[i].index = idx[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+
+DeviceBroadphase::~DeviceBroadphase()
+{
+    if (hipSetDevice(device_) != hipSuccess) return;
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
+    hist_.release(); entries_.release(); table_.release(); row_count_.release(); hub_rows_.release(); small_.release();
+    new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release();
+    if (ev_begin_) (void)hipEventDestroy(ev_begin_);
+    if (ev_end_) (void)hipEventDestroy(ev_end_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int DeviceBroadphase::init()
+{
+    PHX_TRY(use_device(device_));
+    PHX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    PHX_HIP(hipEventCreate(&ev_begin_));
+    PHX_HIP(hipEventCreate(&ev_end_));
+    PHX_TRY(small_.reserve(16));
+    return clear();
+}
+
+int DeviceBroadphase::resize_table(unsigned want_cap)
+{
+    unsigned cap = 1024;
+    while (cap < want_cap) cap <<= 1;
+    DevBuf<unsigned long long> fresh;
+    PHX_TRY(fresh.reserve(cap));
+    PHX_HIP(hipMemsetAsync(fresh.p, 0xFF, (size_t)cap * sizeof(unsigned long long), stream_));
+    if (table_.p && table_cap_) {
+        hipLaunchKernelGGL(k_ps_rehash, dim3(grid_for((int)table_cap_)), dim3(256), 0, stream_, table_.p, table_cap_, fresh.p, cap - 1);
+        PHX_HIP(hipGetLastError());
+    }
+    PHX_HIP(hipStreamSynchronize(stream_));
+    table_.release();
+    table_ = fresh;
+    table_cap_ = cap;
+    tombstones_ = 0;
+    return PHX_OK;
+}
+
+int DeviceBroadphase::clear()
+{
+    PHX_TRY(use_device(device_));
+    table_.release();
+    table_cap_ = 0;
+    set_size_ = 0;
+    tombstones_ = 0;
+    return resize_table(1024);
+}
+
+int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(n >= 0 && (n == 0 || d_bodies), "bad body array");
+    n_ = n;
+    last_new_ = 0;
+    stats_ = phx_broadphase_stats{};
+    const int nblocks = std::max(1, div_up(n, RS_TILE));
+    for (int k = 0; k < 2; ++k) { PHX_TRY(keys_[k].reserve(std::max(n, 1))); PHX_TRY(idx_[k].reserve(std::max(n, 1))); }
+    PHX_TRY(hist_.reserve((size_t)RS_BINS * nblocks));
+    PHX_TRY(entries_.reserve(std::max(n, 1)));
+    PHX_TRY(row_count_.reserve(std::max(n, 1) + 1));
+    PHX_TRY(hub_rows_.reserve(std::max(n, 1)));
+    // keep the table at most half full counting tombstones, before anything reads it
+    if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max(2 * set_size_ * 2, 1024)));
+
+    PHX_HIP(hipEventRecord(ev_begin_, stream_));
+    PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
+    if (n == 0) { PHX_HIP(hipEventRecord(ev_end_, stream_)); PHX_HIP(hipStreamSynchronize(stream_)); return PHX_OK; }
+
+    hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p);
+    int src = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, stream_, keys_[src].p, n, shift, nblocks, hist_.p);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream_, hist_.p, RS_BINS * nblocks, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, stream_, keys_[src].p, idx_[src].p,
+                           keys_[src ^ 1].p, idx_[src ^ 1].p, n, shift, nblocks, hist_.p);
+        src ^= 1;
+    }
+    sorted_ = src;
+    hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, idx_[src].p, n, entries_.p);
+
+    // sweep: count -> scan -> emit
+    SweepView v{};
+    v.entries = entries_.p; v.idx = idx_[src].p; v.n = n; v.table = table_.p; v.mask = table_cap_ - 1;
+    v.row_count = row_count_.p; v.hub_rows = hub_rows_.p;
+    v.hub_count = reinterpret_cast<int*>(small_.p + 2);
+    v.counters = small_.p;
+    hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
+    PHX_HIP(hipGetLastError());
+    int hubs = 0;
+    PHX_HIP(hipMemcpyAsync(&hubs, small_.p + 2, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    if (hubs) hipLaunchKernelGGL((k_sweep_hubs<false>), dim3(hubs), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream_, row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3));
+    PHX_HIP(hipGetLastError());
+    unsigned long long host_small[4] = {0, 0, 0, 0};
+    PHX_HIP(hipMemcpyAsync(host_small, small_.p, sizeof host_small, hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    const unsigned total = (unsigned)host_small[3];
+    stats_.candidate_tests = (long long)host_small[0];
+    stats_.overlapping_pairs = (long long)host_small[1];
+    stats_.new_pairs = (int)total;
+    last_new_ = (int)total;
+    if (total) {
+        PHX_TRY(new_pairs_.reserve(total));
+        if ((unsigned long long)(set_size_ + tombstones_ + (long long)total) * 2 > table_cap_)
+            PHX_TRY(resize_table((unsigned)std::min<long long>(4ll * (set_size_ + (long long)total), 1ll << 30)));
+        v.table = table_.p; v.mask = table_cap_ - 1;
+        hipLaunchKernelGGL((k_sweep_rows<true>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
+        if (hubs) hipLaunchKernelGGL((k_sweep_hubs<true>), dim3(hubs), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
+        // ref: Collider.cpp:313 / :341 — the emitted pairs join the persistent set
+        hipLaunchKernelGGL(k_ps_insert, dim3(grid_for((int)total)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)new_pairs_.p, (int)total);
+        PHX_HIP(hipGetLastError());
+        set_size_ += total;
+    }
+    PHX_HIP(hipEventRecord(ev_end_, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    float ms = 0.f;
+    PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+    stats_.device_ms = ms;
+    stats_.set_size = (int)set_size_;
+    have_update_ = true;
+    return PHX_OK;
+}
+
+int DeviceBroadphase::update_host(const phx_rigid_body* bodies, int n, uint32_t* new_pairs, int cap, int* count)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(n >= 0 && (n == 0 || bodies), "bad body array");
+    PHX_TRY(st_bodies_.reserve(std::max(n, 1)));
+    if (n) PHX_HIP(hipMemcpyAsync(st_bodies_.p, bodies, (size_t)n * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
+    PHX_TRY(update_device(st_bodies_.p, n));
+    return get_new_pairs(new_pairs, cap, count);
+}
+
+int DeviceBroadphase::get_new_pairs(uint32_t* out, int cap, int* count)
+{
+    if (!have_update_) { set_error("no broadphase update has run yet"); return PHX_ERR_STATE; }
+    if (count) *count = last_new_;
+    if (!out) return PHX_OK;
+    if (cap < last_new_) { set_error("new-pair buffer too small: need %d", last_new_); return PHX_ERR_CAPACITY; }
+    PHX_TRY(use_device(device_));
+    if (last_new_) PHX_HIP(hipMemcpy(out, new_pairs_.p, (size_t)last_new_ * sizeof(uint2), hipMemcpyDeviceToHost));
+    return PHX_OK;
+}
+
+int DeviceBroadphase::get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* entries, int cap)
+{
+    if (!have_update_) { set_error("no broadphase update has run yet"); return PHX_ERR_STATE; }
+    if (cap < n_) { set_error("sorted buffers too small: need %d", n_); return PHX_ERR_CAPACITY; }
+    PHX_TRY(use_device(device_));
+    if (!n_) return PHX_OK;
+    DevBuf<phx_broadphase_entry> de;
+    DevBuf<phx_sort_entry> ds;
+    PHX_TRY(de.reserve(n_));
+    PHX_TRY(ds.reserve(n_));
+    hipLaunchKernelGGL(k_entries_to_aos, dim3(grid_for(n_)), dim3(256), 0, stream_, (const float4*)entries_.p, (const unsigned*)keys_[sorted_].p,
+                       (const unsigned*)idx_[sorted_].p, n_, de.p, ds.p);
+    PHX_HIP(hipGetLastError());
+    if (entries) PHX_HIP(hipMemcpyAsync(entries, de.p, (size_t)n_ * sizeof(phx_broadphase_entry), hipMemcpyDeviceToHost, stream_));
+    if (sorted) PHX_HIP(hipMemcpyAsync(sorted, ds.p, (size_t)n_ * sizeof(phx_sort_entry), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    de.release();
+    ds.release();
+    return PHX_OK;
+}
+
+int DeviceBroadphase::erase_pairs(const uint32_t* pairs, int count)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(count >= 0 && (count == 0 || pairs), "bad pair list");
+    if (!count) return PHX_OK;
+    PHX_TRY(scratch_pairs_.reserve(count));
+    PHX_HIP(hipMemcpyAsync(scratch_pairs_.p, pairs, (size_t)count * sizeof(uint2), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipMemsetAsync(small_.p + 8, 0, sizeof(unsigned long long), stream_));
+    hipLaunchKernelGGL(k_ps_erase, dim3(grid_for(count)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)scratch_pairs_.p, count,
+                       reinterpret_cast<int*>(small_.p + 8));
+    PHX_HIP(hipGetLastError());
+    int erased = 0;
+    PHX_HIP(hipMemcpyAsync(&erased, small_.p + 8, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    set_size_ -= erased;
+    tombstones_ += erased;
+    return PHX_OK;
+}
+
+int DeviceBroadphase::get_stats(phx_broadphase_stats* out)
+{
+    PHX_REQUIRE(out, "null out");
+    if (!have_update_) { set_error("no broadphase update has run yet"); return PHX_ERR_STATE; }
+    *out = stats_;
+    out->set_size = (int)set_size_;
+    return PHX_OK;
+}
+
+} // namespace phx
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+struct phx_broadphase { phx::DeviceBroadphase impl; explicit phx_broadphase(int d) : impl(d) {} };
+
+extern "C" {
+
+int phx_broadphase_create(phx_broadphase** out, int device)
+{
+    PHX_REQUIRE(out, "null out");
+    *out = nullptr;
+    PHX_TRY(phx::use_device(device));
+    phx_broadphase* b = new (std::nothrow) phx_broadphase(device);
+    PHX_REQUIRE(b, "out of host memory");
+    int st = b->impl.init();
+    if (st != PHX_OK) { delete b; return st; }
+    *out = b;
+    return PHX_OK;
+}
+
+void phx_broadphase_destroy(phx_broadphase* b) { delete b; }
+
+int phx_broadphase_clear(phx_broadphase* b) { PHX_REQUIRE(b, "null handle"); return b->impl.clear(); }
+
+int phx_broadphase_update(phx_broadphase* b, const phx_rigid_body* bodies, int32_t n, uint32_t* new_pairs, int32_t cap, int32_t* count)
+{
+    PHX_REQUIRE(b, "null handle");
+    return b->impl.update_host(bodies, n, new_pairs, cap, count);
+}
+
+int phx_broadphase_update_device(phx_broadphase* b, const void* d_bodies, int32_t n)
+{
+    PHX_REQUIRE(b, "null handle");
+    return b->impl.update_device(static_cast<const phx_rigid_body*>(d_bodies), n);
+}
+
+int phx_broadphase_get_sorted(phx_broadphase* b, phx_sort_entry* sorted, phx_broadphase_entry* entries, int32_t cap)
+{
+    PHX_REQUIRE(b, "null handle");
+    return b->impl.get_sorted(sorted, entries, cap);
+}
+
+int phx_broadphase_get_new_pairs(phx_broadphase* b, uint32_t* new_pairs, int32_t cap, int32_t* count)
+{
+    PHX_REQUIRE(b, "null handle");
+    return b->impl.get_new_pairs(new_pairs, cap, count);
+}
+
+int phx_broadphase_erase_pairs(phx_broadphase* b, const uint32_t* pairs, int32_t count)
+{
+    PHX_REQUIRE(b, "null handle");
+    return b->impl.erase_pairs(pairs, count);
+}
+
+int phx_broadphase_get_stats(phx_broadphase* b, phx_broadphase_stats* out)
+{
+    PHX_REQUIRE(b, "null handle");
+    return b->impl.get_stats(out);
+}
+
+} // extern "C"

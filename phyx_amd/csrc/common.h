@@ -1,0 +1,99 @@
+// common.h — shared plumbing of libphyx_amd: status codes, HIP error capture, POD checks.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/phyx_amd.h"
+
+static_assert(sizeof(phx_rigid_body) == 128, "RigidBody layout (ref: src/RigidBody.h:12-57)");
+static_assert(sizeof(phx_contact_point) == 32, "ContactPoint layout (ref: src/Manifold.h:12-43)");
+static_assert(sizeof(phx_manifold) == 16, "Manifold layout (ref: src/Manifold.h:45-67)");
+static_assert(sizeof(phx_contact_joint) == 20, "ContactJoint layout (ref: src/Joints.h:6-23)");
+static_assert(sizeof(phx_broadphase_entry) == 20, "BroadphaseEntry layout (ref: src/Collider.h:45-50)");
+static_assert(sizeof(phx_sort_entry) == 8, "BroadphaseSortEntry layout (ref: src/Collider.h:52-56)");
+static_assert(offsetof(phx_rigid_body, velocity) == 52 && offsetof(phx_rigid_body, inv_mass) == 88 &&
+              offsetof(phx_rigid_body, xvector) == 96 && offsetof(phx_rigid_body, pos) == 112, "RigidBody offsets");
+
+namespace phx {
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+// Evaluates a HIP call; on failure records file:line + hipGetErrorString and returns PHX_ERR_HIP
+// from the enclosing function.
+#define PHX_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            ::phx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return PHX_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define PHX_TRY(expr)            \
+    do {                         \
+        int st_ = (expr);        \
+        if (st_ != PHX_OK) return st_; \
+    } while (0)
+
+#define PHX_REQUIRE(cond, msg)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::phx::set_error("%s", msg);       \
+            return PHX_ERR_INVALID;            \
+        }                                      \
+    } while (0)
+
+// Selects `device` after checking that a usable gfx950-class device exists.
+int use_device(int device);
+
+// Growable device buffer; never shrinks (the reference's scratch also only grows, ref: AlignedArray.h).
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return PHX_OK;
+        size_t want = n + n / 4 + 64;
+        T* np = nullptr;
+        PHX_HIP(hipMalloc(reinterpret_cast<void**>(&np), want * sizeof(T)));
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = want;
+        return PHX_OK;
+    }
+    // like reserve() but keeps the first `keep` elements
+    int reserve_keep(size_t n, size_t keep, hipStream_t stream)
+    {
+        if (n <= cap) return PHX_OK;
+        size_t want = n + n / 2 + 64;
+        T* np = nullptr;
+        PHX_HIP(hipMalloc(reinterpret_cast<void**>(&np), want * sizeof(T)));
+        if (p && keep) {
+            PHX_HIP(hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            PHX_HIP(hipStreamSynchronize(stream));
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = want;
+        return PHX_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace phx

@@ -1,0 +1,94 @@
+// runtime.hip — error capture, device selection and the raw device-memory helpers of the C ABI.
+#include "common.h"
+
+namespace phx {
+
+static thread_local char g_error[1024] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+const char* last_error() { return g_error; }
+
+int use_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no usable HIP device (hipGetDeviceCount: %s, count %d) — libphyx_amd has no CPU fallback",
+                  e == hipSuccess ? "ok" : hipGetErrorString(e), count);
+        return PHX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (have %d)", device, count);
+        return PHX_ERR_INVALID;
+    }
+    PHX_HIP(hipSetDevice(device));
+    return PHX_OK;
+}
+
+} // namespace phx
+
+extern "C" {
+
+int phx_abi_version(void) { return PHX_ABI_VERSION; }
+const char* phx_last_error(void) { return phx::last_error(); }
+
+int phx_device_count(void)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) {
+        phx::set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return PHX_ERR_NO_DEVICE;
+    }
+    return count;
+}
+
+int phx_device_info(int device, char* name, int name_cap, int* compute_units, int* lds_bytes, int64_t* hbm_bytes)
+{
+    PHX_TRY(phx::use_device(device));
+    hipDeviceProp_t p;
+    PHX_HIP(hipGetDeviceProperties(&p, device));
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return PHX_OK;
+}
+
+int phx_device_malloc(int device, size_t bytes, void** out)
+{
+    PHX_REQUIRE(out, "null out");
+    PHX_TRY(phx::use_device(device));
+    PHX_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return PHX_OK;
+}
+
+int phx_device_free(int device, void* p)
+{
+    PHX_TRY(phx::use_device(device));
+    if (p) PHX_HIP(hipFree(p));
+    return PHX_OK;
+}
+
+int phx_memcpy_h2d(int device, void* dst, const void* src, size_t bytes)
+{
+    PHX_TRY(phx::use_device(device));
+    if (bytes) PHX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PHX_OK;
+}
+
+int phx_memcpy_d2h(int device, void* dst, const void* src, size_t bytes)
+{
+    PHX_TRY(phx::use_device(device));
+    if (bytes) PHX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return PHX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,104 @@
+// solver.h — host side of the device solver: schedule (colouring / islands), residency, launches.
+#pragma once
+
+#include "common.h"
+
+namespace phx {
+
+// device-side view of the solver state, passed by value to every kernel (layout: solver_kernels.h)
+struct SolverView {
+    int nb, nj, nstatic, ncolours;
+    float4* sb_imp;
+    float4* sb_disp;
+    float4* sb_par;
+    float4* q0;
+    float4* q1;
+    float4* q2;
+    int4* q3;
+    float2* acc;
+    float2* dd;
+    const int* order;      // slot -> joint index
+    const int2* crange;    // colour -> [begin, end) slots
+    unsigned* sw_imp;      // static-body productive words, [2][nstatic] (see static_word())
+    unsigned* sw_disp;
+    int* imp_active;       // [iter] 1 if any joint was productive in sweep `iter`
+    int* disp_active;
+};
+
+
+// Schedule = the order in which one sweep visits the joints, as colour classes of body-disjoint joints.
+// It plays the role of Solver::PrepareIndices (ref: Solver.cpp:217-273), which greedily packs runs of
+// N independent joints for N SIMD lanes; here a whole colour class is one "run" and the lanes are
+// wavefront lanes.  Static bodies are exempt from conflicts (they never move).
+struct Schedule {
+    std::vector<int> order;            // slot -> joint
+    std::vector<int> colour_offsets;   // ncolours + 1
+    int island_count = 1, island_max_size = 0;
+    unsigned long long fingerprint = 0;
+    bool valid = false;
+};
+
+// Greedy first-fit colouring in joint-index order; joints keep their relative order inside a colour.
+void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out);
+
+// Solver::GatherIslands semantics (ref: Solver.cpp:285-454): union-find over dynamic bodies, islands
+// numbered in body order, consecutive islands coalesced until >= 256 joints.  Returns per-joint island
+// id (-1 for static-static joints) and per-island joint counts.
+void gather_islands(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
+                    std::vector<int>& joint_island, std::vector<int>& island_size);
+
+class DeviceSolver {
+public:
+    explicit DeviceSolver(int device) : device_(device) {}
+    ~DeviceSolver();
+    int init();
+
+    int solve_host(phx_rigid_body* bodies, int nb, const phx_contact_point* cps, int ncp, phx_contact_joint* joints, int nj, const phx_config& cfg);
+    int solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg);
+    int synchronize();
+    int get_stats(phx_solve_stats* out);
+    int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
+    int get_refreshed(int joint, float out30[30]);
+    int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
+              const phx_config& cfg, int warmup, int steps, phx_bench_result* out);
+
+    hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
+
+private:
+    int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, const phx_config& cfg);
+    int enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg);
+    int collect_stats();
+    SolverView view() const;
+
+    int device_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
+
+    // device state
+    DevBuf<float4> sb_imp_, sb_disp_, sb_par_, q0_, q1_, q2_;
+    DevBuf<int4> q3_;
+    DevBuf<float2> acc_, dd_;
+    DevBuf<int> order_, static_slot_, flags_;
+    DevBuf<int2> crange_;
+    DevBuf<unsigned> sw_;
+    DevBuf<unsigned long long> hash_;
+    // staging for the host-pointer entry point
+    DevBuf<phx_rigid_body> st_bodies_;
+    DevBuf<phx_contact_point> st_cps_;
+    DevBuf<phx_contact_joint> st_joints_;
+    // bench snapshots
+    DevBuf<phx_rigid_body> snap_bodies_;
+    DevBuf<phx_contact_joint> snap_joints_;
+
+    Schedule sched_;
+    std::vector<int> h_static_slot_;
+    int nstatic_ = 0, nb_ = 0, nj_ = 0;
+    int max_iters_ = 0;
+    phx_solve_stats stats_{};
+    bool stats_pending_ = false, have_solve_ = false;
+    int last_ci_ = 0, last_pi_ = 0;
+    long long sweep_launches_ = 0;
+};
+
+} // namespace phx

@@ -1,0 +1,403 @@
+// solver.hip — DeviceSolver: schedule construction on the host, residency and launch sequence.
+#include "solver.h"
+#include "solver_kernels.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace phx {
+
+// ---------------------------------------------------------------------------------------------------
+// schedule
+
+void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out)
+{
+    std::vector<int> colour(nj, 0);
+    int words = 1, ncolours = 0;
+    for (;;) {
+        // used[b * words + w] bit c%64 set <=> a joint of colour w*64+c already touches dynamic body b
+        std::vector<unsigned long long> used((size_t)nb * words, 0ull);
+        bool overflow = false;
+        ncolours = 0;
+        for (int j = 0; j < nj && !overflow; ++j) {
+            const int a = body1[j], b = body2[j];
+            const bool da = !is_static[a], db = !is_static[b];
+            int c = -1;
+            for (int w = 0; w < words; ++w) {
+                unsigned long long m = 0;
+                if (da) m |= used[(size_t)a * words + w];
+                if (db) m |= used[(size_t)b * words + w];
+                if (~m) { c = w * 64 + __builtin_ctzll(~m); break; }
+            }
+            if (c < 0) { overflow = true; break; }
+            colour[j] = c;
+            if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
+            if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
+            ncolours = std::max(ncolours, c + 1);
+        }
+        if (!overflow) break;
+        words *= 2;
+    }
+    out.colour_offsets.assign(ncolours + 1, 0);
+    for (int j = 0; j < nj; ++j) out.colour_offsets[colour[j] + 1]++;
+    for (int c = 0; c < ncolours; ++c) out.colour_offsets[c + 1] += out.colour_offsets[c];
+    out.order.resize(nj);
+    std::vector<int> cursor(out.colour_offsets.begin(), out.colour_offsets.end() - 1);
+    for (int j = 0; j < nj; ++j) out.order[cursor[colour[j]]++] = j;       // stable inside a colour
+}
+
+static int uf_find(std::vector<int>& t, int i)
+{
+    int r = i;
+    while (r != t[r]) r = t[r];
+    while (t[i] != r) { int n = t[i]; t[i] = r; i = n; }
+    return r;
+}
+
+void gather_islands(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
+                    std::vector<int>& joint_island, std::vector<int>& island_size)
+{
+    std::vector<int> root(nb);
+    for (int i = 0; i < nb; ++i) root[i] = is_static[i] ? -1 : i;
+    for (int j = 0; j < nj; ++j) {
+        const int a = body1[j], b = body2[j];
+        if (is_static[a] || is_static[b]) continue;
+        const int ra = uf_find(root, a), rb = uf_find(root, b);
+        root[ra] = rb;
+    }
+    std::vector<int> number(nb, -1);
+    int count = 0;
+    for (int i = 0; i < nb; ++i) {
+        if (root[i] < 0) continue;
+        const int r = uf_find(root, i);
+        if (number[r] < 0) number[r] = count++;
+    }
+    std::vector<int> raw_size(count, 0);
+    auto island_of = [&](int j) {
+        const int a = body1[j], b = body2[j];
+        if (is_static[a] && is_static[b]) return -1;
+        return number[uf_find(root, is_static[a] ? b : a)];
+    };
+    for (int j = 0; j < nj; ++j) { const int i = island_of(j); if (i >= 0) raw_size[i]++; }
+    // coalesce consecutive islands until >= kIslandMinSize joints (ref: Solver.cpp:382-413)
+    std::vector<int> merged(count, 0);
+    island_size.clear();
+    int run = 0;
+    for (int i = 0; i < count; ++i) {
+        run += raw_size[i];
+        merged[i] = (int)island_size.size();
+        if (run >= 256 || (run > 0 && i == count - 1)) { island_size.push_back(run); run = 0; }
+    }
+    joint_island.resize(nj);
+    for (int j = 0; j < nj; ++j) { const int i = island_of(j); joint_island[j] = i < 0 ? -1 : merged[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small kernels private to this file
+
+__global__ void __launch_bounds__(256) k_extract_topology(const phx_contact_joint* __restrict__ joints, int nj,
+                                                          const phx_rigid_body* __restrict__ bodies, int nb,
+                                                          int2* __restrict__ pairs, unsigned char* __restrict__ is_static)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x)
+        pairs[i] = make_int2(joints[i].body1, joints[i].body2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
+        is_static[i] = (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) ? 1 : 0;
+}
+
+static inline int grid_for(int n) { return std::max(1, std::min(div_up(n, 256), 2048)); }
+
+// ---------------------------------------------------------------------------------------------------
+
+DeviceSolver::~DeviceSolver()
+{
+    if (hipSetDevice(device_) != hipSuccess) return;
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
+    acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); crange_.release(); sw_.release();
+    hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
+    if (ev_begin_) (void)hipEventDestroy(ev_begin_);
+    if (ev_end_) (void)hipEventDestroy(ev_end_);
+    if (ev_sweep_begin_) (void)hipEventDestroy(ev_sweep_begin_);
+    if (ev_sweep_end_) (void)hipEventDestroy(ev_sweep_end_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int DeviceSolver::init()
+{
+    PHX_TRY(use_device(device_));
+    PHX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    PHX_HIP(hipEventCreate(&ev_begin_));
+    PHX_HIP(hipEventCreate(&ev_end_));
+    PHX_HIP(hipEventCreate(&ev_sweep_begin_));
+    PHX_HIP(hipEventCreate(&ev_sweep_end_));
+    PHX_TRY(hash_.reserve(1));
+    return PHX_OK;
+}
+
+SolverView DeviceSolver::view() const
+{
+    SolverView v{};
+    v.nb = nb_; v.nj = nj_; v.nstatic = std::max(nstatic_, 1); v.ncolours = (int)sched_.colour_offsets.size() - 1;
+    v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = sb_par_.p;
+    v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p;
+    v.order = order_.p; v.crange = crange_.p;
+    v.sw_imp = sw_.p; v.sw_disp = sw_.p + 2 * (size_t)v.nstatic;
+    v.imp_active = flags_.p; v.disp_active = flags_.p + max_iters_;
+    return v;
+}
+
+int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, const phx_config& cfg)
+{
+    // 1. fingerprint of the joint topology (8 bytes over PCIe)
+    unsigned long long fp = 0;
+    PHX_HIP(hipMemsetAsync(hash_.p, 0, sizeof(unsigned long long), stream_));
+    hipLaunchKernelGGL(k_topology_hash, dim3(grid_for(std::max(nj, nb))), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, hash_.p);
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipMemcpyAsync(&fp, hash_.p, sizeof fp, hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
+    stats_.recoloured = 0;
+    if (sched_.valid && sched_.fingerprint == fp && nb == nb_ && nj == nj_) return PHX_OK;
+
+    // 2. topology changed: pull the body pairs + static flags, colour on the host, push the schedule
+    DevBuf<int2> d_pairs;
+    DevBuf<unsigned char> d_static;
+    PHX_TRY(d_pairs.reserve(std::max(nj, 1)));
+    PHX_TRY(d_static.reserve(std::max(nb, 1)));
+    hipLaunchKernelGGL(k_extract_topology, dim3(grid_for(std::max(nj, nb))), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, d_pairs.p, d_static.p);
+    PHX_HIP(hipGetLastError());
+    std::vector<int2> pairs(std::max(nj, 1));
+    std::vector<unsigned char> is_static(std::max(nb, 1));
+    PHX_HIP(hipMemcpyAsync(pairs.data(), d_pairs.p, (size_t)nj * sizeof(int2), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipMemcpyAsync(is_static.data(), d_static.p, (size_t)nb, hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    d_pairs.release();
+    d_static.release();
+
+    std::vector<int> b1(nj), b2(nj);
+    for (int j = 0; j < nj; ++j) {
+        b1[j] = pairs[j].x; b2[j] = pairs[j].y;
+        if ((unsigned)b1[j] >= (unsigned)nb || (unsigned)b2[j] >= (unsigned)nb) { set_error("joint %d references body out of range", j); return PHX_ERR_INVALID; }
+    }
+    build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
+    const int ncol = (int)sched_.colour_offsets.size() - 1;
+    if (ncol > 65000) { set_error("more than 65000 colours"); return PHX_ERR_INVALID; }
+    {
+        std::vector<int> joint_island, island_size;
+        gather_islands(b1.data(), b2.data(), nj, is_static.data(), nb, joint_island, island_size);
+        sched_.island_count = (int)island_size.size();
+        sched_.island_max_size = island_size.empty() ? 0 : *std::max_element(island_size.begin(), island_size.end());
+    }
+    h_static_slot_.assign(nb, -1);
+    nstatic_ = 0;
+    for (int i = 0; i < nb; ++i) if (is_static[i]) h_static_slot_[i] = nstatic_++;
+
+    nb_ = nb; nj_ = nj;
+    PHX_TRY(order_.reserve(std::max(nj, 1)));
+    PHX_TRY(static_slot_.reserve(std::max(nb, 1)));
+    PHX_TRY(crange_.reserve(std::max(ncol, 1)));
+    PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
+    PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb)); PHX_TRY(sb_par_.reserve(nb));
+    PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj));
+    PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
+    std::vector<int2> ranges(std::max(ncol, 1));
+    for (int c = 0; c < ncol; ++c) ranges[c] = make_int2(sched_.colour_offsets[c], sched_.colour_offsets[c + 1]);
+    if (nj) PHX_HIP(hipMemcpyAsync(order_.p, sched_.order.data(), (size_t)nj * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (nb) PHX_HIP(hipMemcpyAsync(static_slot_.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (ncol) PHX_HIP(hipMemcpyAsync(crange_.p, ranges.data(), (size_t)ncol * sizeof(int2), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    sched_.fingerprint = fp;
+    sched_.valid = true;
+    stats_.recoloured = 1;
+    (void)cfg;
+    return PHX_OK;
+}
+
+int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg)
+{
+    const int ci = cfg.contact_iterations, pi = cfg.penetration_iterations;
+    const int iters = std::max(ci, pi);
+    if (iters + 1 > max_iters_ || !flags_.p) {
+        max_iters_ = std::max(iters + 1, 64);
+        PHX_TRY(flags_.reserve(2 * (size_t)max_iters_));
+    }
+    const SolverView v = view();
+    const int ncol = v.ncolours;
+    PHX_HIP(hipEventRecord(ev_begin_, stream_));
+    PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
+    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)v.nstatic * sizeof(unsigned), stream_));
+    if (nb) hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, sb_imp_.p, sb_disp_.p, sb_par_.p);
+    if (nj) {
+        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints, d_cps, static_slot_.p);
+        for (int c = 0; c < ncol; ++c) {
+            const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
+            hipLaunchKernelGGL(k_prestep, dim3(grid_for(n)), dim3(256), 0, stream_, v, c);
+        }
+    }
+    PHX_HIP(hipEventRecord(ev_sweep_begin_, stream_));
+    sweep_launches_ = 0;
+    if (nj) {
+        for (int it = 0; it < iters; ++it) {
+            const bool imp = it < ci, disp = it < pi;
+            for (int c = 0; c < ncol; ++c) {
+                const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
+                const dim3 g(grid_for(n)), b(256);
+                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, c, it);
+                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, c, it);
+                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, c, it);
+                ++sweep_launches_;
+            }
+        }
+    }
+    PHX_HIP(hipEventRecord(ev_sweep_end_, stream_));
+    if (nj) hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints);
+    if (nb) hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, v, d_bodies);
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipEventRecord(ev_end_, stream_));
+    last_ci_ = ci; last_pi_ = pi;
+    stats_pending_ = true;
+    have_solve_ = true;
+    return PHX_OK;
+}
+
+int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(nb >= 0 && nj >= 0 && ncp >= 0, "negative count");
+    PHX_REQUIRE(cfg.contact_iterations >= 0 && cfg.penetration_iterations >= 0 && cfg.contact_iterations < 60000 && cfg.penetration_iterations < 60000, "iteration count out of range");
+    PHX_REQUIRE(cfg.solve_mode >= PHX_SOLVE_SCALAR && cfg.solve_mode <= PHX_SOLVE_AVX2, "unknown solve mode");
+    PHX_REQUIRE(cfg.island_mode >= PHX_ISLAND_SINGLE && cfg.island_mode <= PHX_ISLAND_MULTIPLE_SLOPPY, "unknown island mode");
+    PHX_REQUIRE(nb == 0 || d_bodies, "null bodies");
+    PHX_REQUIRE(nj == 0 || (d_joints && d_cps), "null joints / contact points");
+    PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, cfg));
+    const bool split = cfg.island_mode == PHX_ISLAND_MULTIPLE || cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
+    stats_.island_count = split ? sched_.island_count : 1;
+    stats_.island_max_size = split ? sched_.island_max_size : nj;
+    stats_.colour_count = (int)sched_.colour_offsets.size() - 1;
+    stats_.lds_islands = 0;
+    return enqueue(static_cast<phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_point*>(d_cps), static_cast<phx_contact_joint*>(d_joints), nj, cfg);
+}
+
+int DeviceSolver::solve_host(phx_rigid_body* bodies, int nb, const phx_contact_point* cps, int ncp, phx_contact_joint* joints, int nj, const phx_config& cfg)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(nb >= 0 && nj >= 0 && ncp >= 0, "negative count");
+    PHX_REQUIRE(nb == 0 || bodies, "null bodies");
+    PHX_REQUIRE(nj == 0 || (joints && cps), "null joints / contact points");
+    for (int j = 0; j < nj; ++j)
+        if ((unsigned)joints[j].contact_point_index >= (unsigned)ncp) { set_error("joint %d references contact point out of range", j); return PHX_ERR_INVALID; }
+    PHX_TRY(st_bodies_.reserve(std::max(nb, 1)));
+    PHX_TRY(st_cps_.reserve(std::max(ncp, 1)));
+    PHX_TRY(st_joints_.reserve(std::max(nj, 1)));
+    if (nb) PHX_HIP(hipMemcpyAsync(st_bodies_.p, bodies, (size_t)nb * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
+    if (ncp) PHX_HIP(hipMemcpyAsync(st_cps_.p, cps, (size_t)ncp * sizeof(phx_contact_point), hipMemcpyHostToDevice, stream_));
+    if (nj) PHX_HIP(hipMemcpyAsync(st_joints_.p, joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyHostToDevice, stream_));
+    PHX_TRY(solve_device(st_bodies_.p, nb, st_cps_.p, ncp, st_joints_.p, nj, cfg));
+    if (nb) PHX_HIP(hipMemcpyAsync(bodies, st_bodies_.p, (size_t)nb * sizeof(phx_rigid_body), hipMemcpyDeviceToHost, stream_));
+    if (nj) PHX_HIP(hipMemcpyAsync(joints, st_joints_.p, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToHost, stream_));
+    return synchronize();
+}
+
+int DeviceSolver::collect_stats()
+{
+    if (!stats_pending_) return PHX_OK;
+    std::vector<int> flags(2 * (size_t)max_iters_);
+    PHX_HIP(hipMemcpyAsync(flags.data(), flags_.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    auto executed = [&](const int* active, int limit) {
+        int n = 0;
+        for (int k = 0; k < limit; ++k) { ++n; if (!active[k]) break; }     // ref: Solver.cpp:175-190
+        return nj_ ? n : std::min(limit, 1);
+    };
+    stats_.impulse_iterations = executed(flags.data(), last_ci_);
+    stats_.displacement_iterations = executed(flags.data() + max_iters_, last_pi_);
+    float ms = 0.f;
+    PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+    stats_.device_ms = ms;
+    stats_pending_ = false;
+    return PHX_OK;
+}
+
+int DeviceSolver::synchronize()
+{
+    PHX_TRY(use_device(device_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    return collect_stats();
+}
+
+int DeviceSolver::get_stats(phx_solve_stats* out)
+{
+    PHX_REQUIRE(out, "null out");
+    if (!have_solve_) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(synchronize());
+    *out = stats_;
+    return PHX_OK;
+}
+
+int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours)
+{
+    if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    const int ncol = (int)sched_.colour_offsets.size() - 1;
+    if (ncolours) *ncolours = ncol;
+    if ((order && order_cap < nj_) || (offsets && offsets_cap < ncol + 1)) { set_error("schedule buffers too small"); return PHX_ERR_CAPACITY; }
+    if (order) std::copy(sched_.order.begin(), sched_.order.end(), order);
+    if (offsets) std::copy(sched_.colour_offsets.begin(), sched_.colour_offsets.end(), offsets);
+    return PHX_OK;
+}
+
+int DeviceSolver::get_refreshed(int joint, float out[30])
+{
+    if (!have_solve_) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_REQUIRE(joint >= 0 && joint < nj_ && out, "joint index out of range");
+    PHX_TRY(synchronize());
+    const int slot = (int)(std::find(sched_.order.begin(), sched_.order.end(), joint) - sched_.order.begin());
+    float4 a, f, c; int4 k; float2 acc, d;
+    PHX_HIP(hipMemcpy(&a, q0_.p + slot, sizeof a, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&f, q1_.p + slot, sizeof f, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&c, q2_.p + slot, sizeof c, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&k, q3_.p + slot, sizeof k, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&acc, acc_.p + slot, sizeof acc, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&d, dd_.p + slot, sizeof d, hipMemcpyDeviceToHost));
+    float ii2; std::memcpy(&ii2, &k.x, 4);
+    const float im1 = c.y, ii1 = c.z, im2 = c.w;
+    const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
+    // expand to ContactLimiterPacked order (ref: Solver.h:7-24): projectors, angular, compMass, compInvMass
+    float* o = out;
+    *o++ = nx; *o++ = ny; *o++ = -nx; *o++ = -ny; *o++ = a.z; *o++ = a.w;
+    *o++ = nx * im1; *o++ = ny * im1; *o++ = (-nx) * im2; *o++ = (-ny) * im2; *o++ = a.z * ii1; *o++ = a.w * ii2; *o++ = c.x;
+    *o++ = 0.f; *o++ = f.w; *o++ = d.x; *o++ = d.y;
+    *o++ = tx; *o++ = ty; *o++ = -tx; *o++ = -ty; *o++ = f.x; *o++ = f.y;
+    *o++ = tx * im1; *o++ = ty * im1; *o++ = (-tx) * im2; *o++ = (-ty) * im2; *o++ = f.x * ii1; *o++ = f.y * ii2; *o++ = f.z;
+    (void)acc;
+    return PHX_OK;
+}
+
+int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
+                        const phx_config& cfg, int warmup, int steps, phx_bench_result* out)
+{
+    PHX_REQUIRE(out && warmup >= 0 && steps >= 0, "bad bench arguments");
+    PHX_TRY(use_device(device_));
+    PHX_TRY(snap_bodies_.reserve(std::max(nb, 1)));
+    PHX_TRY(snap_joints_.reserve(std::max(nj, 1)));
+    std::memset(out, 0, sizeof *out);
+    for (int i = 0; i < warmup + steps; ++i) {
+        // every step solves the SAME input: restore a working copy from the caller's (untouched) arrays
+        if (nb) PHX_HIP(hipMemcpyAsync(snap_bodies_.p, d_bodies, (size_t)nb * sizeof(phx_rigid_body), hipMemcpyDeviceToDevice, stream_));
+        if (nj) PHX_HIP(hipMemcpyAsync(snap_joints_.p, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
+        PHX_TRY(solve_device(snap_bodies_.p, nb, d_cps, ncp, snap_joints_.p, nj, cfg));
+        PHX_TRY(synchronize());
+        if (i >= warmup) {
+            float sweep_ms = 0.f;
+            PHX_HIP(hipEventElapsedTime(&sweep_ms, ev_sweep_begin_, ev_sweep_end_));
+            out->total_ms += stats_.device_ms;
+            out->impulse_kernel_ms += sweep_ms;
+            out->impulse_launches += sweep_launches_;
+            out->impulse_iterations += stats_.impulse_iterations;
+            out->joint_visits += (long long)stats_.impulse_iterations * nj;
+        }
+    }
+    return PHX_OK;
+}
+
+} // namespace phx

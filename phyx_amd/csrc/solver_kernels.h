@@ -1,0 +1,285 @@
+// solver_kernels.h — device data layout + HIP kernels of the sequential-impulse solver (gfx950).
+//
+// What it replaces (ref = /root/reference/src): Solver::PrepareBodies/FinishBodies (Solver.cpp:456-494),
+// PrepareJoints/FinishJoints (:496-547), RefreshJoints (:592-695), PreStepJoints (:697-758),
+// SolveJointsImpulses (:760-914), SolveJointsDisplacement (:916-1018).
+//
+// Layout in HBM:
+//   bodies   sb_imp[b]  = {vx, vy, w, lastIteration}   float4   (ref SolveBody, Solver.h:95-101)
+//            sb_disp[b] = same for the displacing velocities
+//            sb_par[b]  = {invMass, invInertia, pos.x, pos.y}   (ref SolveBodyParams minus the unused frame)
+//            one body = one 16-B gather/scatter granule per array.
+//   joints   stored in SCHEDULE order (slot s), colour c owns the contiguous slot range crange[c]:
+//            q0[s] = {n.x, n.y, angN1, angN2}          normal projector + its angular projectors
+//            q1[s] = {angF1, angF2, invMassF, dstVelocity}
+//            q2[s] = {invMassN, invMass1, invInertia1, invMass2}
+//            q3[s] = {invInertia2 (bits), body1, body2, static slot or -1}
+//            acc[s] = {accumulated normal, accumulated friction}            (read+write each sweep)
+//            dd[s]  = {dstDisplacingVelocity, accumulatedDisplacingImpulse}
+//            A lane owns one slot, so every array is read as one coalesced 16-B (or 8-B) load per lane.
+//   The reference keeps 31 words per joint (ContactLimiterPacked, Solver.h:7-45); projector2 = -projector1,
+//   the friction projector is the rotated normal and compMass* = projector * invMass are single IEEE
+//   multiplies, so they are recomputed in registers from 16 stored words — bit-identical, 44 % fewer bytes.
+//
+// Arithmetic contract: every expression below is written in the reference's operation order and the
+// file is compiled with -ffp-contract=off, so results equal the strict-IEEE oracle bit for bit.
+#pragma once
+
+#include "solver.h"
+
+namespace phx {
+
+// ---- static-body tags ----------------------------------------------------------------------------
+// A static body (invMass == invInertia == 0, ref: Solver.cpp:304) never changes velocity, so it does
+// not serialise the joints that touch it; only its lastIteration tag is shared (ref: Solver.cpp:900-910
+// writes it, :793-797 reads it).  The tag lives in two words per static body, selected by sweep parity:
+//   word = (iter + 1) << 16 | (0xFFFF - colour)   written with atomicMax by productive joints.
+// A joint of (iter, colour) sees the body as productive iff some joint on it was productive in sweep
+// iter-1, or in sweep iter in an EARLIER colour — deterministic regardless of scheduling.
+__device__ __forceinline__ unsigned static_word(int iter, int colour) { return ((unsigned)(iter + 1) << 16) | (0xFFFFu - (unsigned)colour); }
+
+__device__ __forceinline__ bool static_productive(const unsigned* sw, int nstatic, int slot, int iter, int colour)
+{
+    if (iter == 0) return true;                                    // tags start at -1 > 0 - 2 (ref: Solver.cpp:474)
+    unsigned prev = __hip_atomic_load(&sw[((iter - 1) & 1) * nstatic + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 16) == (unsigned)iter) return true;               // productive in sweep iter-1
+    unsigned cur = __hip_atomic_load(&sw[(iter & 1) * nstatic + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
+}
+
+__device__ __forceinline__ float max_ref(float l, float r) { return l > r ? l : r; }      // ref: base/SIMD_Scalar.h:275-278
+
+// ---- PrepareBodies (ref: Solver.cpp:456-480) -----------------------------------------------------
+__global__ void __launch_bounds__(256) k_unpack_bodies(const phx_rigid_body* __restrict__ bodies, int nb,
+                                                       float4* __restrict__ sb_imp, float4* __restrict__ sb_disp, float4* __restrict__ sb_par)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const phx_rigid_body& b = bodies[i];
+        sb_imp[i] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
+        sb_disp[i] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
+        sb_par[i] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
+    }
+}
+
+// ---- topology fingerprint --------------------------------------------------------------------------
+// Order-sensitive 64-bit fingerprint of the joint list's body pairs and of which bodies are static: the
+// colouring is a pure function of exactly that, so an unchanged fingerprint lets the schedule be reused.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
+                                                       const phx_rigid_body* __restrict__ bodies, int nb, unsigned long long* out)
+{
+    unsigned long long h = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
+        unsigned long long k = ((unsigned long long)(unsigned)joints[i].body1 << 32) | (unsigned)joints[i].body2;
+        h += mix64(k + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1));
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        if (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) h += mix64(0xD1B54A32D192ED03ull * (unsigned long long)(i + 1));
+    }
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+
+// ---- PrepareJoints + RefreshJoints (ref: Solver.cpp:496-521, 549-695) ----------------------------
+struct Limiter { float a1, a2, cim; };
+
+// RefreshLimiter (ref: Solver.cpp:549-590) for projector (n1x,n1y) on body 1 and its negation on body 2
+__device__ __forceinline__ Limiter refresh_limiter(float n1x, float n1y, float w1x, float w1y, float w2x, float w2y,
+                                                   float im1, float ii1, float im2, float ii2)
+{
+    const float n2x = -n1x, n2y = -n1y;
+    Limiter L;
+    L.a1 = n1x * w1y - n1y * w1x;
+    L.a2 = n2x * w2y - n2y * w2x;
+    const float c1x = n1x * im1, c1y = n1y * im1, c1a = L.a1 * ii1;
+    const float c2x = n2x * im2, c2y = n2y * im2, c2a = L.a2 * ii2;
+    const float m1 = n1x * c1x + n1y * c1y + L.a1 * c1a;
+    const float m2 = n2x * c2x + n2y * c2y + L.a2 * c2a;
+    const float m = m1 + m2;
+    L.cim = fabsf(m) > 0.f ? 1.0f / m : 0.f;
+    return L;
+}
+
+__global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, const phx_contact_joint* __restrict__ joints,
+                                                      const phx_contact_point* __restrict__ cps, const int* __restrict__ static_slot)
+{
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < v.nj; s += gridDim.x * blockDim.x) {
+        const phx_contact_joint j = joints[v.order[s]];
+        const phx_contact_point& cp = cps[j.contact_point_index];
+        const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
+        const float nx = cp.normal.x, ny = cp.normal.y;
+        const float4 p1 = v.sb_par[j.body1], p2 = v.sb_par[j.body2];       // {im, ii, pos.x, pos.y}
+
+        const float pt1x = d1x + p1.z, pt1y = d1y + p1.w;
+        const float pt2x = d2x + p2.z, pt2y = d2y + p2.w;
+        const float w1x = d1x, w1y = d1y;
+        const float w2x = pt1x - p2.z, w2y = pt1y - p2.w;                  // ref: Solver.cpp:649-650 (body-1's point, sic)
+
+        const Limiter N = refresh_limiter(nx, ny, w1x, w1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
+        const Limiter F = refresh_limiter(-ny, nx, w1x, w1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
+
+        // ref: Solver.cpp:658-680.  bounce == 0 makes dv = -0 * (relV . n); max(dv - 1, 0) is then +0 for
+        // every finite or non-finite relV, so the velocity gathers of :619-625 are dead and dropped.
+        const float depth = (pt2x - pt1x) * nx + (pt2y - pt1y) * ny;
+        const float dst = 0.f;
+        const float n_dst = depth < 1.f ? dst - 0.1f : dst;
+        const float n_dst_disp = 0.1f * max_ref(0.f, depth - 2.0f * 1.f);
+
+        const int s1 = static_slot[j.body1], s2 = static_slot[j.body2];
+        v.q0[s] = make_float4(nx, ny, N.a1, N.a2);
+        v.q1[s] = make_float4(F.a1, F.a2, F.cim, n_dst);
+        v.q2[s] = make_float4(N.cim, p1.x, p1.y, p2.x);
+        v.q3[s] = make_int4(__float_as_int(p2.y), j.body1, j.body2, s1 >= 0 ? s1 : s2);
+        v.acc[s] = make_float2(j.normal_accumulated_impulse, j.friction_accumulated_impulse);
+        v.dd[s] = make_float2(n_dst_disp, 0.f);
+    }
+}
+
+// ---- PreStepJoints (ref: Solver.cpp:697-758), one colour ------------------------------------------
+__global__ void __launch_bounds__(256) k_prestep(SolverView v, int colour)
+{
+    const int2 r = v.crange[colour];
+    for (int s = r.x + blockIdx.x * blockDim.x + threadIdx.x; s < r.y; s += gridDim.x * blockDim.x) {
+        const float4 a = v.q0[s], b = v.q1[s], c = v.q2[s];
+        const int4 k = v.q3[s];
+        const float2 acc = v.acc[s];
+        const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
+        const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
+        const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
+        if (!st1) {
+            float4 B = v.sb_imp[k.y];
+            B.x += (nx * im1) * acc.x; B.y += (ny * im1) * acc.x; B.z += (a.z * ii1) * acc.x;
+            B.x += (tx * im1) * acc.y; B.y += (ty * im1) * acc.y; B.z += (b.x * ii1) * acc.y;
+            v.sb_imp[k.y] = B;
+        }
+        if (!st2) {
+            float4 B = v.sb_imp[k.z];
+            B.x += ((-nx) * im2) * acc.x; B.y += ((-ny) * im2) * acc.x; B.z += (a.w * ii2) * acc.x;
+            B.x += ((-tx) * im2) * acc.y; B.y += ((-ty) * im2) * acc.y; B.z += (b.y * ii2) * acc.y;
+            v.sb_imp[k.z] = B;
+        }
+    }
+}
+
+// ---- SolveJointsImpulses + SolveJointsDisplacement (ref: Solver.cpp:760-1018), one colour, one sweep
+template <bool DO_IMP, bool DO_DISP>
+__global__ void __launch_bounds__(256) k_solve_colour(SolverView v, int colour, int iter)
+{
+    // a sweep after an unproductive sweep skips every joint (all tags <= iter-2), which is why the
+    // reference may stop there (ref: Solver.cpp:189, 210); the launch is already queued, so it just returns
+    const bool imp_on = DO_IMP && (iter == 0 || v.imp_active[iter - 1] != 0);
+    const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
+    if (!imp_on && !disp_on) return;
+
+    const int2 r = v.crange[colour];
+    bool any_imp = false, any_disp = false;
+    for (int s = r.x + blockIdx.x * blockDim.x + threadIdx.x; s < r.y; s += gridDim.x * blockDim.x) {
+        const int4 k = v.q3[s];
+        const float4 c = v.q2[s];
+        const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
+        const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
+        const int b1 = k.y, b2 = k.z, ss = k.w;
+
+        if (imp_on) {
+            float4 B1 = v.sb_imp[b1], B2 = v.sb_imp[b2];
+            // ref: Solver.cpp:790-798
+            const bool p1 = st1 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
+            const bool p2 = st2 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
+            if (p1 || p2) {
+                const float4 a = v.q0[s], f = v.q1[s];
+                float2 acc = v.acc[s];
+                const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
+                // normal limiter (ref: :833-858)
+                float dv = f.w;
+                dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
+                dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
+                float dn = dv * c.x;
+                dn = max_ref(dn, -acc.x);
+                B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (a.z * ii1) * dn;
+                B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (a.w * ii2) * dn;
+                acc.x += dn;
+                // friction limiter (ref: :860-889)
+                float fv = 0.f;
+                fv -= tx * B1.x; fv -= ty * B1.y; fv -= f.x * B1.z;
+                fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= f.y * B2.z;
+                float df = fv * f.z;
+                const float force = acc.y + df;
+                const float limit = acc.x * 0.3f;
+                const float signed_limit = force < 0.f ? -limit : limit;          // scalar flipsign, ref: SIMD_Scalar.h:265-268
+                const float adjusted = signed_limit - acc.y;
+                if (fabsf(force) > limit) df = adjusted;
+                acc.y += df;
+                B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (f.x * ii1) * df;
+                B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (f.y * ii2) * df;
+                v.acc[s] = acc;
+                const bool productive = max_ref(fabsf(dn), fabsf(df)) > 1e-4f;      // ref: :894-896
+                if (productive) {
+                    B1.w = __int_as_float(iter); B2.w = __int_as_float(iter);
+                    any_imp = true;
+                    if ((st1 || st2) && ss >= 0) atomicMax(&v.sw_imp[(iter & 1) * v.nstatic + ss], static_word(iter, colour));
+                }
+                if (!st1) v.sb_imp[b1] = B1;
+                if (!st2) v.sb_imp[b2] = B2;
+            }
+        }
+        if (disp_on) {
+            float4 B1 = v.sb_disp[b1], B2 = v.sb_disp[b2];
+            const bool p1 = st1 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
+            const bool p2 = st2 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
+            if (p1 || p2) {
+                const float4 a = v.q0[s];
+                float2 d = v.dd[s];
+                const float nx = a.x, ny = a.y;
+                float dv = d.x;                                                      // ref: :973-981
+                dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
+                dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
+                float di = dv * c.x;
+                di = max_ref(di, -d.y);
+                B1.x += (nx * im1) * di; B1.y += (ny * im1) * di; B1.z += (a.z * ii1) * di;
+                B2.x += ((-nx) * im2) * di; B2.y += ((-ny) * im2) * di; B2.z += (a.w * ii2) * di;
+                d.y += di;
+                v.dd[s] = d;
+                const bool productive = fabsf(di) > 1e-4f;                           // ref: :999
+                if (productive) {
+                    B1.w = __int_as_float(iter); B2.w = __int_as_float(iter);
+                    any_disp = true;
+                    if ((st1 || st2) && ss >= 0) atomicMax(&v.sw_disp[(iter & 1) * v.nstatic + ss], static_word(iter, colour));
+                }
+                if (!st1) v.sb_disp[b1] = B1;
+                if (!st2) v.sb_disp[b2] = B2;
+            }
+        }
+    }
+    // any(productive) of the sweep (ref: Solver.cpp:913, 1017): one store per wave that saw one
+    if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
+    if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
+}
+
+// ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------
+__global__ void __launch_bounds__(256) k_finish_joints(SolverView v, phx_contact_joint* __restrict__ joints)
+{
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < v.nj; s += gridDim.x * blockDim.x) {
+        const float2 acc = v.acc[s];
+        phx_contact_joint& j = joints[v.order[s]];
+        j.normal_accumulated_impulse = acc.x;
+        j.friction_accumulated_impulse = acc.y;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, phx_rigid_body* __restrict__ bodies)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.nb; i += gridDim.x * blockDim.x) {
+        const float4 a = v.sb_imp[i], d = v.sb_disp[i];
+        phx_rigid_body& b = bodies[i];
+        b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
+        b.displacing_velocity.x = d.x; b.displacing_velocity.y = d.y; b.displacing_angular_velocity = d.z;
+    }
+}
+
+} // namespace phx
