@@ -138,6 +138,20 @@ int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap,
  * dstDisplacingVelocity, accumulatedDisplacingImpulse(after solve), friction limiter 13. */
 int phx_solver_get_refreshed(phx_solver* s, int32_t joint_index, float out30[30]);
 
+/* Host-only schedule builders (no device needed) — exposed so the ordering logic can be checked on
+ * its own.  phx_schedule_colours is this backend's counterpart of Solver::PrepareIndices
+ * (ref: src/Solver.cpp:217-273): it partitions the joints into colour classes of joints that share
+ * no dynamic body (is_static[b] != 0 exempts body b), first-fit in joint order, stable inside a
+ * colour.  phx_schedule_islands follows Solver::GatherIslands (ref: src/Solver.cpp:285-454):
+ * joint_island[j] = coalesced island of joint j (-1 if both bodies are static), island_size[i] =
+ * joints in island i; returns the island count. */
+int phx_schedule_colours(const int32_t* body1, const int32_t* body2, int32_t joint_count,
+                         const uint8_t* is_static, int32_t body_count,
+                         int32_t* order, int32_t* colour_offsets, int32_t offsets_cap, int32_t* colour_count);
+int phx_schedule_islands(const int32_t* body1, const int32_t* body2, int32_t joint_count,
+                         const uint8_t* is_static, int32_t body_count,
+                         int32_t* joint_island, int32_t* island_size, int32_t island_cap);
+
 /* ---------------------------------------------------------------------------------------------- */
 /* Broadphase — replaces Collider::UpdateBroadphase + UpdatePairs                                   */
 /* (ref: src/Collider.h:28-29, src/Collider.cpp:251-366, src/base/RadixSort.h:19-95)               */

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "phx_solver_get_schedule": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_get_refreshed": (C.c_int, [_vp, _i32, _vp]),
     "phx_solver_bench": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, C.POINTER(BenchResult)]),
+    "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "phx_schedule_islands": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32]),
     "phx_broadphase_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "phx_broadphase_destroy": (None, [_vp]),
     "phx_broadphase_clear": (C.c_int, [_vp]),

@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI.
+
+Names and argument meaning follow the reference (ref = /root/reference/src):
+  Configuration  <- Configuration.h:3-23      (solveMode, islandMode, contactIterationsCount, penetrationIterationsCount)
+  Solver         <- Solver.h:47-128           (SolveJoints, islandCount, islandMaxSize)
+  Collider       <- Collider.h:24-66          (UpdateBroadphase + UpdatePairs, broadphase[], broadphaseSort[1])
+  World          <- World.h:9-36              (AddBody, Update, bodies, gravity)
+Arrays are numpy structured arrays with the reference's exact POD layouts, so the same buffers can be
+handed to the oracle in tests/.  All compute happens inside libphyx_amd.so (HIP); nothing here
+falls back to numpy or the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, SolveStats, BroadphaseStats, BenchResult, check
+
+SOLVE_SCALAR, SOLVE_SSE2, SOLVE_AVX2 = 0, 1, 2
+ISLAND_SINGLE, ISLAND_MULTIPLE, ISLAND_SINGLE_SLOPPY, ISLAND_MULTIPLE_SLOPPY = 0, 1, 2, 3
+
+_vec2 = np.dtype([("x", "<f4"), ("y", "<f4")])
+rigid_body_dtype = np.dtype([
+    ("index", "<u4"), ("geom_size", _vec2), ("geom_xv", _vec2), ("geom_yv", _vec2), ("geom_pos", _vec2),
+    ("aabb_min", _vec2), ("aabb_max", _vec2), ("velocity", _vec2), ("acceleration", _vec2),
+    ("displacing_velocity", _vec2), ("angular_velocity", "<f4"), ("angular_acceleration", "<f4"),
+    ("displacing_angular_velocity", "<f4"), ("inv_mass", "<f4"), ("inv_inertia", "<f4"),
+    ("xv", _vec2), ("yv", _vec2), ("pos", _vec2), ("last_iteration", "<i4"), ("last_displacement_iteration", "<i4"),
+])
+contact_point_dtype = np.dtype([
+    ("delta1", _vec2), ("delta2", _vec2), ("normal", _vec2), ("is_merged", "u1"), ("is_newly_created", "u1"),
+    ("pad", "u1", (2,)), ("solver_index", "<i4"),
+])
+manifold_dtype = np.dtype([("body1", "<i4"), ("body2", "<i4"), ("point_count", "<i4"), ("point_index", "<i4")])
+contact_joint_dtype = np.dtype([("contact_point_index", "<i4"), ("body1", "<i4"), ("body2", "<i4"),
+                                ("normal_acc", "<f4"), ("friction_acc", "<f4")])
+broadphase_entry_dtype = np.dtype([("minx", "<f4"), ("maxx", "<f4"), ("centery", "<f4"), ("extenty", "<f4"), ("index", "<u4")])
+sort_entry_dtype = np.dtype([("value", "<u4"), ("index", "<u4")])
+assert rigid_body_dtype.itemsize == 128 and contact_point_dtype.itemsize == 32
+assert manifold_dtype.itemsize == 16 and contact_joint_dtype.itemsize == 20 and broadphase_entry_dtype.itemsize == 20
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _contig(a, dtype):
+    a = np.asarray(a)
+    if a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("expected a C-contiguous array of dtype %s" % (dtype,))
+    return a
+
+
+def device_count():
+    return check(_lib.load().phx_device_count())
+
+
+def device_info(device=0):
+    L = _lib.load()
+    name = C.create_string_buffer(256)
+    cu, lds, hbm = C.c_int(), C.c_int(), C.c_int64()
+    check(L.phx_device_info(device, name, 256, C.byref(cu), C.byref(lds), C.byref(hbm)))
+    return {"name": name.value.decode(), "compute_units": cu.value, "lds_bytes": lds.value, "hbm_bytes": hbm.value}
+
+
+def schedule_colours(body1, body2, is_static):
+    """Host-only: colour classes of body-disjoint joints (this backend's PrepareIndices, ref: Solver.cpp:217-273)."""
+    L = _lib.load()
+    b1 = np.ascontiguousarray(body1, dtype=np.int32)
+    b2 = np.ascontiguousarray(body2, dtype=np.int32)
+    st = np.ascontiguousarray(is_static, dtype=np.uint8)
+    order = np.zeros(max(len(b1), 1), dtype=np.int32)
+    offs = np.zeros(len(b1) + 2, dtype=np.int32)
+    nc = C.c_int32(0)
+    check(L.phx_schedule_colours(_ptr(b1), _ptr(b2), len(b1), _ptr(st), len(st), _ptr(order), _ptr(offs), len(offs), C.byref(nc)))
+    return order[:len(b1)], offs[:nc.value + 1]
+
+
+def schedule_islands(body1, body2, is_static):
+    """Host-only: GatherIslands semantics (ref: Solver.cpp:285-454) -> (joint_island, island_size)."""
+    L = _lib.load()
+    b1 = np.ascontiguousarray(body1, dtype=np.int32)
+    b2 = np.ascontiguousarray(body2, dtype=np.int32)
+    st = np.ascontiguousarray(is_static, dtype=np.uint8)
+    ji = np.zeros(max(len(b1), 1), dtype=np.int32)
+    sz = np.zeros(len(b1) + 1, dtype=np.int32)
+    n = check(L.phx_schedule_islands(_ptr(b1), _ptr(b2), len(b1), _ptr(st), len(st), _ptr(ji), _ptr(sz), len(sz)))
+    return ji[:len(b1)], sz[:n]
+
+
+class Configuration:
+    """ref: Configuration.h:20-23; defaults are the demo's (main.cpp:262-263,348) with the scalar mode."""
+
+    def __init__(self, solveMode=SOLVE_SCALAR, islandMode=ISLAND_SINGLE, contactIterationsCount=15, penetrationIterationsCount=15):
+        self.solveMode = solveMode
+        self.islandMode = islandMode
+        self.contactIterationsCount = contactIterationsCount
+        self.penetrationIterationsCount = penetrationIterationsCount
+
+    def _c(self):
+        return Config(self.solveMode, self.islandMode, self.contactIterationsCount, self.penetrationIterationsCount)
+
+
+class DeviceArray:
+    """A raw HBM allocation holding a copy of a host array (inputs resident before a timed region)."""
+
+    def __init__(self, host_array, device=0):
+        self.L = _lib.load()
+        self.device = device
+        self.dtype = host_array.dtype
+        self.count = len(host_array)
+        self.nbytes = int(host_array.nbytes)
+        p = C.c_void_p()
+        check(self.L.phx_device_malloc(device, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p
+        if self.nbytes:
+            check(self.L.phx_memcpy_h2d(device, self.ptr, _ptr(np.ascontiguousarray(host_array)), self.nbytes))
+
+    def to_host(self):
+        out = np.zeros(self.count, dtype=self.dtype)
+        if self.nbytes:
+            check(self.L.phx_memcpy_d2h(self.device, _ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.L.phx_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Solver:
+    """Device replacement of Solver (ref: Solver.h:47-128)."""
+
+    def __init__(self, device=0, _handle=None):
+        self.L = _lib.load()
+        self.device = device
+        self._owned = _handle is None
+        if _handle is None:
+            h = C.c_void_p()
+            check(self.L.phx_solver_create(C.byref(h), device))
+            self.h = h
+        else:
+            self.h = C.c_void_p(_handle)
+        self.islandCount = 0
+        self.islandMaxSize = 0
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "h", None):
+            self.L.phx_solver_destroy(self.h)
+            self.h = None
+
+    def SolveJoints(self, bodies, contactPoints, contactJoints, configuration):
+        """ref: Solver.h:54 — solves in place on the host arrays (velocities + accumulated impulses)."""
+        b = _contig(bodies, rigid_body_dtype)
+        cp = _contig(contactPoints, contact_point_dtype)
+        j = _contig(contactJoints, contact_joint_dtype)
+        cfg = configuration._c()
+        check(self.L.phx_solver_solve(self.h, _ptr(b), len(b), _ptr(cp), len(cp), _ptr(j), len(j), C.byref(cfg)))
+        st = self.stats()
+        self.islandCount, self.islandMaxSize = st.island_count, st.island_max_size
+        return st
+
+    def SolveJointsDevice(self, d_bodies, d_contact_points, d_joints, configuration):
+        cfg = configuration._c()
+        check(self.L.phx_solver_solve_device(self.h, d_bodies.ptr, d_bodies.count, d_contact_points.ptr, d_contact_points.count,
+                                             d_joints.ptr, d_joints.count, C.byref(cfg)))
+
+    def synchronize(self):
+        check(self.L.phx_solver_synchronize(self.h))
+
+    def stats(self):
+        st = SolveStats()
+        check(self.L.phx_solver_get_stats(self.h, C.byref(st)))
+        return st
+
+    def schedule(self):
+        """(order, colour_offsets) of the last solve: order[k] = joint in slot k."""
+        nc = C.c_int32(0)
+        check(self.L.phx_solver_get_schedule(self.h, None, 0, None, 0, C.byref(nc)))
+        offs = np.zeros(nc.value + 1, dtype=np.int32)
+        check(self.L.phx_solver_get_schedule(self.h, None, 0, _ptr(offs), len(offs), C.byref(nc)))
+        order = np.zeros(max(int(offs[-1]), 1), dtype=np.int32)
+        check(self.L.phx_solver_get_schedule(self.h, _ptr(order), len(order), _ptr(offs), len(offs), C.byref(nc)))
+        return order[:int(offs[-1])], offs
+
+    def refreshed(self, joint_index):
+        out = np.zeros(30, dtype=np.float32)
+        check(self.L.phx_solver_get_refreshed(self.h, joint_index, _ptr(out)))
+        return out
+
+    def bench(self, d_bodies, d_contact_points, d_joints, configuration, warmup, steps):
+        cfg = configuration._c()
+        res = BenchResult()
+        check(self.L.phx_solver_bench(self.h, d_bodies.ptr, d_bodies.count, d_contact_points.ptr, d_contact_points.count,
+                                      d_joints.ptr, d_joints.count, C.byref(cfg), warmup, steps, C.byref(res)))
+        return res
+
+
+class Collider:
+    """Device replacement of the broadphase half of Collider (ref: Collider.h:28-29, 58-66)."""
+
+    def __init__(self, device=0, _handle=None):
+        self.L = _lib.load()
+        self._owned = _handle is None
+        if _handle is None:
+            h = C.c_void_p()
+            check(self.L.phx_broadphase_create(C.byref(h), device))
+            self.h = h
+        else:
+            self.h = C.c_void_p(_handle)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "h", None):
+            self.L.phx_broadphase_destroy(self.h)
+            self.h = None
+
+    def clear(self):
+        check(self.L.phx_broadphase_clear(self.h))
+
+    def UpdateBroadphaseAndPairs(self, bodies):
+        """UpdateBroadphase + UpdatePairs; returns the pairs that were new this step, (n,2) uint32 in the
+        reference's serial emission order; they are now part of the persistent set."""
+        b = _contig(bodies, rigid_body_dtype)
+        n = C.c_int32(0)
+        check(self.L.phx_broadphase_update(self.h, _ptr(b), len(b), None, 0, C.byref(n)))
+        pairs = np.zeros((max(n.value, 1), 2), dtype=np.uint32)
+        check(self.L.phx_broadphase_get_new_pairs(self.h, _ptr(pairs), n.value, C.byref(n)))
+        return pairs[:n.value]
+
+    def sorted(self, n):
+        srt = np.zeros(n, dtype=sort_entry_dtype)
+        ent = np.zeros(n, dtype=broadphase_entry_dtype)
+        check(self.L.phx_broadphase_get_sorted(self.h, _ptr(srt), _ptr(ent), n))
+        return srt, ent
+
+    def erase(self, pairs):
+        p = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        check(self.L.phx_broadphase_erase_pairs(self.h, _ptr(p), len(p)))
+
+    def stats(self):
+        st = BroadphaseStats()
+        check(self.L.phx_broadphase_get_stats(self.h, C.byref(st)))
+        return st
+
+
+class World:
+    """Device-backed World (ref: World.h:9-36)."""
+
+    PHASES = ("IntegrateVelocity", "UpdateBroadphase", "UpdatePairs", "UpdateManifolds", "PackManifolds",
+              "RefreshContactJoints", "SolveJoints", "IntegratePosition")
+
+    def __init__(self, device=0, gravity=0.0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        check(self.L.phx_world_create(C.byref(h), device))
+        self.h = h
+        self.device = device
+        self.gravity = gravity
+        self.solver = Solver(device, _handle=self.L.phx_world_solver(self.h))
+        self.collider = Collider(device, _handle=self.L.phx_world_broadphase(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.phx_world_destroy(self.h)
+            self.h = None
+
+    @property
+    def gravity(self):
+        return self._gravity
+
+    @gravity.setter
+    def gravity(self, g):
+        self._gravity = float(g)
+        check(self.L.phx_world_set_gravity(self.h, self._gravity))
+
+    def AddBody(self, pos, angle, size, static=False):
+        """ref: World.cpp:11-17 — pos=(x,y), size = half extents; returns the body index."""
+        i = check(self.L.phx_world_add_body(self.h, pos[0], pos[1], angle, size[0], size[1]))
+        if static:
+            check(self.L.phx_world_set_body_static(self.h, i))
+        return i
+
+    def add_scene(self, scene):
+        for k in range(len(scene["px"])):
+            self.AddBody((float(scene["px"][k]), float(scene["py"][k])), float(scene["angle"][k]),
+                         (float(scene["sx"][k]), float(scene["sy"][k])), bool(scene["static"][k]))
+
+    def set_shard(self, shard, shard_count):
+        check(self.L.phx_world_set_shard(self.h, shard, shard_count))
+
+    def Update(self, dt, configuration):
+        cfg = configuration._c()
+        check(self.L.phx_world_update(self.h, dt, C.byref(cfg)))
+
+    def counts(self):
+        v = [C.c_int32() for _ in range(4)]
+        check(self.L.phx_world_counts(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def _get(self, fn, dtype, n):
+        out = np.zeros(n, dtype=dtype)
+        check(fn(self.h, _ptr(out), n))
+        return out
+
+    @property
+    def bodies(self):
+        return self._get(self.L.phx_world_get_bodies, rigid_body_dtype, self.counts()[0])
+
+    @property
+    def manifolds(self):
+        return self._get(self.L.phx_world_get_manifolds, manifold_dtype, self.counts()[1])
+
+    @property
+    def contactPoints(self):
+        return self._get(self.L.phx_world_get_contact_points, contact_point_dtype, self.counts()[2])
+
+    @property
+    def contactJoints(self):
+        return self._get(self.L.phx_world_get_joints, contact_joint_dtype, self.counts()[3])
+
+    def phase_ms(self):
+        out = np.zeros(8, dtype=np.float64)
+        check(self.L.phx_world_get_phase_ms(self.h, _ptr(out)))
+        return dict(zip(self.PHASES, out.tolist()))

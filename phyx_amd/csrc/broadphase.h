@@ -1,0 +1,42 @@
+// broadphase.h — host side of the device broadphase (kernels + layout notes: broadphase.hip).
+#pragma once
+
+#include "common.h"
+
+namespace phx {
+
+class DeviceBroadphase {
+public:
+    explicit DeviceBroadphase(int device) : device_(device) {}
+    ~DeviceBroadphase();
+    int init();
+    int clear();
+    int update_device(const phx_rigid_body* d_bodies, int n);
+    int update_host(const phx_rigid_body* bodies, int n, uint32_t* new_pairs, int cap, int* count);
+    int get_new_pairs(uint32_t* out, int cap, int* count);
+    int get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* entries, int cap);
+    int erase_pairs(const uint32_t* pairs, int count);
+    int get_stats(phx_broadphase_stats* out);
+    int new_pair_count() const { return last_new_; }
+    hipStream_t stream() const { return stream_; }
+
+private:
+    int resize_table(unsigned want_cap);
+
+    int device_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
+    DevBuf<unsigned> keys_[2], idx_[2], hist_, row_count_;
+    DevBuf<float4> entries_;
+    DevBuf<unsigned long long> table_, small_;
+    DevBuf<int> hub_rows_;
+    DevBuf<uint2> new_pairs_, scratch_pairs_;
+    DevBuf<phx_rigid_body> st_bodies_;
+    unsigned table_cap_ = 0;
+    long long set_size_ = 0, tombstones_ = 0;
+    int n_ = 0, sorted_ = 0, last_new_ = 0;
+    bool have_update_ = false;
+    phx_broadphase_stats stats_{};
+};
+
+} // namespace phx

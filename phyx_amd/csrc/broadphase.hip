@@ -14,7 +14,7 @@
 // The sort is a stable LSD radix sort on the full 32-bit key.  The reference splits the key 11/11/10; a
 // stable sort's output permutation does not depend on the digit split, so 4 passes of 8 bits (256-bin
 // LDS histograms, one wave-private counter row per wave) give the identical sequence.
-#include "broadphase.h"
+#include "handles.h"
 
 #include <algorithm>
 
@@ -407,7 +407,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     PHX_TRY(row_count_.reserve(std::max(n, 1) + 1));
     PHX_TRY(hub_rows_.reserve(std::max(n, 1)));
     // keep the table at most half full counting tombstones, before anything reads it
-    if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max(2 * set_size_ * 2, 1024)));
+    if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max<long long>(4 * set_size_, 1024)));
 
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
     PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
@@ -543,7 +543,6 @@ int DeviceBroadphase::get_stats(phx_broadphase_stats* out)
 } // namespace phx
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
-struct phx_broadphase { phx::DeviceBroadphase impl; explicit phx_broadphase(int d) : impl(d) {} };
 
 extern "C" {
 

@@ -1,7 +1,7 @@
 // c_api_solver.hip — extern "C" surface of the solver (see include/phyx_amd.h for the contract).
-#include "solver.h"
+#include "handles.h"
 
-struct phx_solver { phx::DeviceSolver impl; explicit phx_solver(int d) : impl(d) {} };
+#include <algorithm>
 
 extern "C" {
 
@@ -63,6 +63,33 @@ int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t nb, const void
 {
     PHX_REQUIRE(s && cfg, "null handle / config");
     return s->impl.bench(d_bodies, nb, d_cps, ncp, d_joints, nj, *cfg, warmup, steps, out);
+}
+
+int phx_schedule_colours(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb,
+                         int32_t* order, int32_t* offsets, int32_t offsets_cap, int32_t* ncolours)
+{
+    PHX_REQUIRE(nj >= 0 && nb >= 0 && (nj == 0 || (b1 && b2 && order)) && (nb == 0 || is_static) && offsets && ncolours, "bad arguments");
+    for (int j = 0; j < nj; ++j) PHX_REQUIRE((unsigned)b1[j] < (unsigned)nb && (unsigned)b2[j] < (unsigned)nb, "body index out of range");
+    phx::Schedule s;
+    phx::build_colour_schedule(b1, b2, nj, is_static, nb, s);
+    *ncolours = (int)s.colour_offsets.size() - 1;
+    if ((int)s.colour_offsets.size() > offsets_cap) { phx::set_error("colour_offsets too small"); return PHX_ERR_CAPACITY; }
+    std::copy(s.order.begin(), s.order.end(), order);
+    std::copy(s.colour_offsets.begin(), s.colour_offsets.end(), offsets);
+    return PHX_OK;
+}
+
+int phx_schedule_islands(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb,
+                         int32_t* joint_island, int32_t* island_size, int32_t island_cap)
+{
+    PHX_REQUIRE(nj >= 0 && nb >= 0 && (nj == 0 || (b1 && b2 && joint_island)) && (nb == 0 || is_static), "bad arguments");
+    for (int j = 0; j < nj; ++j) PHX_REQUIRE((unsigned)b1[j] < (unsigned)nb && (unsigned)b2[j] < (unsigned)nb, "body index out of range");
+    std::vector<int> ji, sz;
+    phx::gather_islands(b1, b2, nj, is_static, nb, ji, sz);
+    if ((int)sz.size() > island_cap) { phx::set_error("island_size too small"); return PHX_ERR_CAPACITY; }
+    std::copy(ji.begin(), ji.end(), joint_island);
+    if (island_size) std::copy(sz.begin(), sz.end(), island_size);
+    return (int)sz.size();
 }
 
 } // extern "C"

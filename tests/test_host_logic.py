@@ -1,0 +1,97 @@
+"""Host-side logic of the product that needs no GPU: scene generators, the colour schedule and the island
+partition (C++ code inside libphyx_amd.so, reached through its host-only C-ABI entry points)."""
+import numpy as np
+import pytest
+
+import phyx_amd
+from phyx_amd import scenes
+from helpers import SMALL_SCENES, presolve_state, is_static
+
+
+def test_stack_scene_shape():
+    s = scenes.stack(3, 4)
+    assert len(s["px"]) == 13 and s["static"][0] and not s["static"][1:].any()
+    assert s["sx"][0] == 45.0 and s["sy"][0] == 10.0
+    assert list(s["py"][1:5]) == [15.0, 25.0, 35.0, 45.0]
+    assert sorted(set(s["px"][1:].tolist())) == [-15.0, 0.0, 15.0]
+    shifted = scenes.stack(3, 4, x_offset_columns=10)
+    assert np.allclose(shifted["px"][1:] - s["px"][1:], 150.0)
+
+
+def test_falling_scene_is_reproducible():
+    a, b = scenes.falling(100, seed=3), scenes.falling(100, seed=3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    c = scenes.falling(100, seed=4)
+    assert not np.array_equal(a["px"], c["px"])
+    assert (np.abs(a["px"][1:]) <= 500).all() and (a["py"][1:] >= 50).all() and (a["py"][1:] <= 1000).all()
+
+
+@pytest.mark.parametrize("name", list(SMALL_SCENES))
+def test_colour_schedule_invariants(built_lib, name):
+    make, warm = SMALL_SCENES[name]
+    bodies, _, joints = presolve_state(make(), warm)
+    static = is_static(bodies)
+    order, offs = phyx_amd.schedule_colours(joints["body1"], joints["body2"], static)
+    nj = len(joints)
+    assert sorted(order.tolist()) == list(range(nj))                  # a permutation
+    assert offs[0] == 0 and offs[-1] == nj and (np.diff(offs) > 0).all()
+    for c in range(len(offs) - 1):
+        sl = order[offs[c]:offs[c + 1]]
+        assert (np.diff(sl) > 0).all()                                # stable: joint order kept inside a colour
+        b = np.concatenate([joints["body1"][sl], joints["body2"][sl]])
+        b = b[static[b] == 0]
+        assert len(np.unique(b)) == len(b), "colour %d touches a dynamic body twice" % c
+    # first-fit: a joint of colour c conflicts with some earlier joint in every colour < c
+    colour_of = np.zeros(nj, dtype=np.int64)
+    for c in range(len(offs) - 1):
+        colour_of[order[offs[c]:offs[c + 1]]] = c
+    rng = np.random.default_rng(0)
+    for j in rng.choice(nj, size=min(nj, 60), replace=False):
+        mine = {int(joints["body1"][j]), int(joints["body2"][j])}
+        mine = {b for b in mine if not static[b]}
+        for c in range(colour_of[j]):
+            sl = order[offs[c]:offs[c + 1]]
+            sl = sl[sl < j]
+            touched = set(joints["body1"][sl].tolist()) | set(joints["body2"][sl].tolist())
+            assert mine & touched
+
+
+@pytest.mark.parametrize("name", list(SMALL_SCENES))
+def test_island_partition_matches_oracle_gather(built_lib, oracle, name):
+    """Same island partition as the GatherIslands restatement (ref: Solver.cpp:285-454), incl. coalescing."""
+    import ctypes as C
+    make, warm = SMALL_SCENES[name]
+    bodies, _, joints = presolve_state(make(), warm)
+    ji, sz = phyx_amd.schedule_islands(joints["body1"], joints["body2"], is_static(bodies))
+    L = oracle.lib()
+    nb, nj = len(bodies), len(joints)
+    cap = nj + 64
+    jidx = np.full(cap, -1, dtype=np.int32)
+    off = np.zeros(nb + 1, dtype=np.int32)
+    siz = np.zeros(nb + 1, dtype=np.int32)
+    cnt, mx = C.c_int32(), C.c_int32()
+    L.phxo_gather_islands(bodies.ctypes.data, nb, joints.ctypes.data, nj, 1, jidx.ctypes.data, cap,
+                          off.ctypes.data, siz.ctypes.data, C.byref(cnt), C.byref(mx))
+    assert cnt.value == len(sz) and list(siz[:cnt.value]) == list(sz)
+    for i in range(cnt.value):
+        members = jidx[off[i]:off[i] + siz[i]]
+        assert (ji[members] == i).all()
+        assert (np.diff(members) > 0).all()
+
+
+def test_schedule_handles_hub_and_empty(built_lib):
+    # a dynamic hub touched by 200 joints needs 200 colours (> 64 exercises the multi-word masks)
+    n = 200
+    b1 = np.zeros(n, dtype=np.int32)
+    b2 = np.arange(1, n + 1, dtype=np.int32)
+    order, offs = phyx_amd.schedule_colours(b1, b2, np.zeros(n + 1, dtype=np.uint8))
+    assert len(offs) - 1 == n and list(order) == list(range(n))
+    # the same hub made static conflicts with nothing
+    st = np.zeros(n + 1, dtype=np.uint8)
+    st[0] = 1
+    order, offs = phyx_amd.schedule_colours(b1, b2, st)
+    assert len(offs) - 1 == 1
+    order, offs = phyx_amd.schedule_colours([], [], [0, 0])
+    assert len(order) == 0 and list(offs) == [0]
+    with pytest.raises(phyx_amd.PhxError):
+        phyx_amd.schedule_colours([0], [5], [0, 0])

@@ -1,0 +1,95 @@
+"""World::Update parity (MI355X): the product World (device broadphase + device solver, host narrowphase /
+contact cache / integrators) against the oracle World, step by step.  The oracle's solver is driven in the
+device's colour order (see test_solver_gpu.py); with that, every byte of every body, manifold, contact
+point and joint must agree after every step."""
+import numpy as np
+import pytest
+
+import phyx_amd
+from phyx_amd import scenes, Configuration
+from helpers import oracle_world
+
+pytestmark = pytest.mark.gpu
+
+
+def _lockstep(oracle, scene, steps, cfg, check_every=1):
+    pw = phyx_amd.World(0, gravity=-200.0)
+    pw.add_scene(scene)
+    ow = oracle_world(scene)
+    assert pw.bodies.tobytes() == ow.bodies().tobytes()                    # AddBody / RigidBody ctor
+    for step in range(steps):
+        pw.Update(1.0 / 60.0, cfg)
+        ow.pre_solve(1.0 / 60.0)
+        order, offs = pw.solver.schedule()
+        b, cp, j = ow.bodies(), ow.contact_points(), ow.joints()           # live views into the oracle world
+        assert len(order) == len(j)
+        oracle.solver_solve_ordered(b, cp, j, order, offs, cfg.contactIterationsCount, cfg.penetrationIterationsCount,
+                                    oracle.STAG_COLOUR_SYNC)
+        ow.integrate_position(1.0 / 60.0)
+        if step % check_every == 0 or step == steps - 1:
+            assert pw.counts() == (len(ow.bodies()), len(ow.manifolds()), len(ow.contact_points()), len(ow.joints())), "step %d" % step
+            assert pw.manifolds.tobytes() == ow.manifolds().tobytes(), "manifolds differ at step %d" % step
+            assert pw.contactJoints.tobytes() == ow.joints().tobytes(), "joints differ at step %d" % step
+            assert pw.bodies.tobytes() == ow.bodies().tobytes(), "bodies differ at step %d" % step
+            m = ow.manifolds()
+            live = np.concatenate([np.arange(int(x["point_index"]), int(x["point_index"]) + int(x["point_count"])) for x in m] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+            assert pw.contactPoints[live].tobytes() == ow.contact_points()[live].tobytes(), "contact points differ at step %d" % step
+    return pw, ow
+
+
+@pytest.mark.parametrize("name,steps", [("stack", 12), ("tilted", 60), ("falling", 50)])
+def test_world_lockstep_bit_exact(oracle, built_lib, name, steps):
+    scene = {"stack": lambda: scenes.stack(6, 40), "tilted": lambda: scenes.tilted(80),
+             "falling": lambda: scenes.falling(500, width=80.0, ymax=300.0)}[name]()
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_SINGLE, 15, 15)
+    pw, ow = _lockstep(oracle, scene, steps, cfg)
+    assert len(ow.joints()) > 0
+
+
+def test_island_shards_reproduce_the_unsharded_step(oracle, built_lib):
+    """Multi-GPU sharding is by island.  Emulated on one GPU: k worlds each solve the islands
+    of one shard; stitching their bodies' velocities together must give the unsharded result bit for bit,
+    because islands are body-disjoint."""
+    scene = scenes.stack(24, 30)                  # 24 columns -> several coalesced islands
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 15, 15)
+    full = phyx_amd.World(0, gravity=-200.0)
+    full.add_scene(scene)
+    for _ in range(3):
+        full.Update(1.0 / 60.0, cfg)
+    assert full.solver.stats().island_count >= 3
+    k = 3
+    shards = []
+    for r in range(k):
+        w = phyx_amd.World(0, gravity=-200.0)
+        w.add_scene(scene)
+        shards.append(w)
+    for _ in range(2):                             # identical history up to the step under test
+        for w in shards:
+            w.Update(1.0 / 60.0, cfg)
+    for r, w in enumerate(shards):
+        w.set_shard(r, k)
+        w.Update(1.0 / 60.0, cfg)
+    ref = full.bodies
+    joints = full.contactJoints
+    ji, sz = phyx_amd.schedule_islands(joints["body1"], joints["body2"], ((ref["inv_mass"] == 0) & (ref["inv_inertia"] == 0)).astype(np.uint8))
+    owner = np.full(len(ref), -1)
+    for j in range(len(joints)):
+        for body in (joints["body1"][j], joints["body2"][j]):
+            if ref["inv_mass"][body] != 0:
+                owner[body] = ji[j] % k
+    stitched = shards[0].bodies.copy()
+    for r in range(1, k):
+        mine = owner == r
+        stitched[mine] = shards[r].bodies[mine]
+    moved = owner >= 0
+    assert stitched[moved].tobytes() == ref[moved].tobytes()
+
+
+def test_world_api_errors(built_lib):
+    w = phyx_amd.World(0)
+    with pytest.raises(phyx_amd.PhxError):
+        w.AddBody((0, 0), 0.0, (0.0, 1.0))
+    with pytest.raises(phyx_amd.PhxError):
+        w.set_shard(3, 2)
+    w.Update(1.0 / 60.0, Configuration())          # empty world steps fine
+    assert w.counts() == (0, 0, 0, 0)
