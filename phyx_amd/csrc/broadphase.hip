@@ -411,7 +411,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
 
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
     PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
-    if (n == 0) { PHX_HIP(hipEventRecord(ev_end_, stream_)); PHX_HIP(hipStreamSynchronize(stream_)); return PHX_OK; }
+    if (n == 0) { PHX_HIP(hipEventRecord(ev_end_, stream_)); PHX_HIP(hipStreamSynchronize(stream_)); stats_.set_size = (int)set_size_; have_update_ = true; return PHX_OK; }
 
     hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p);
     int src = 0;
