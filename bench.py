@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X (contract: see the task brief / DESIGN.md §7).
+
+Metric (BASELINE.json): solver iterations/sec + contacts/sec on the 200k-box stack scene.  A "step" is one
+Solver::SolveJoints (ref: src/Solver.cpp:17-119) over the resident solver inputs of that scene: PrepareBodies,
+schedule check, PrepareJoints+RefreshJoints, PreStepJoints, `iters` impulse + displacement sweeps, FinishJoints,
+FinishBodies.  `value` = joint-visits per second (contacts/sec: joints swept, skipped ones included, SURVEY.md
+§8(d)) over the whole step wall time, summed over all ranks; solver iterations/sec is reported next to it.
+
+N=1: workload = BASELINE config 2 (stack(1000,200) = 200 001 bodies, Single Sloppy islands, 20+20 iterations).
+N>1: weak scaling — every rank owns its own slab of 1000 columns (= 1000 islands) of one world N*1000 columns
+wide, solves it on its GPU, and the ranks meet at a 4-byte RCCL all-reduce after every step; no body or joint
+data crosses ranks because islands are body-disjoint.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_IMPULSE_VISIT = 196        # algorithmic bytes per impulse joint-visit
+BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visit
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--columns", type=int, default=1000, help="stack columns per GPU (1000 x 200 = config 2)")
+    ap.add_argument("--rows", type=int, default=200)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--scene-steps", type=int, default=3, help="world steps run before the solver input is captured")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one rank")
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    from phyx_amd import dist as pdist
+    group = pdist.init(args.gpus, backend=args.backend, force=args.force_dist)
+    rank, world = group.rank, group.world_size
+    device = group.local_rank
+
+    import phyx_amd
+    from phyx_amd import scenes, Configuration
+
+    info = phyx_amd.device_info(device)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, args.iters, args.iters)
+
+    # ---- scene: this rank's slab of the wide world, brought to a settled contact state by the product World
+    first_col, ncols = pdist.shard_columns(args.columns * world, rank, world)
+    scene = scenes.stack(ncols, args.rows, x_offset_columns=first_col)
+    world_obj = phyx_amd.World(device, gravity=-200.0)
+    world_obj.add_scene(scene)
+    for _ in range(args.scene_steps):
+        world_obj.Update(1.0 / 60.0, cfg)
+    world_obj.PreSolve(1.0 / 60.0)
+    bodies, cps, joints = world_obj.bodies, world_obj.contactPoints, world_obj.contactJoints
+    nb, nj = len(bodies), len(joints)
+
+    solver = phyx_amd.Solver(device)
+    d_bodies, d_cps, d_joints = (phyx_amd.DeviceArray(a, device) for a in (bodies, cps, joints))
+
+    # ---- warmup (untimed): builds the schedule, touches every buffer
+    for _ in range(max(args.warmup, 1)):
+        solver.bench(d_bodies, d_cps, d_joints, cfg, 0, 1)
+        group.step_barrier()
+
+    # ---- timed region: exactly K steps, barrier + device sync on both sides
+    group.barrier()
+    solver.synchronize()
+    t0 = time.perf_counter()
+    tot = dict(total_ms=0.0, sweep_ms=0.0, launches=0, visits=0, iterations=0)
+    for _ in range(args.steps):
+        r = solver.bench(d_bodies, d_cps, d_joints, cfg, 0, 1)       # restore input + one full SolveJoints, synchronised
+        group.step_barrier()                                          # per-step RCCL barrier (no-op at N=1)
+        tot["total_ms"] += r.total_ms; tot["sweep_ms"] += r.impulse_kernel_ms; tot["launches"] += r.impulse_launches
+        tot["visits"] += r.joint_visits; tot["iterations"] += r.impulse_iterations
+    solver.synchronize()
+    group.barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = solver.stats()
+    elapsed_max = group.reduce_max(elapsed)
+    visits_all = group.reduce_sum(tot["visits"])
+    iters_all = group.reduce_sum(tot["iterations"])
+    joints_all = group.reduce_sum(nj)
+    bodies_all = group.reduce_sum(nb)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed_max / max(args.steps, 1)
+        # roofline of the dominant kernel (k_solve_colour<imp,disp>): algorithmic bytes / HIP-event time of the sweeps
+        disp_visits = st.displacement_iterations * nj * args.steps
+        alg_bytes = BYTES_IMPULSE_VISIT * tot["visits"] + BYTES_DISPLACEMENT_VISIT * disp_visits
+        sweep_s = tot["sweep_ms"] * 1e-3
+        achieved = alg_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "solver joint-visits/s (contacts/sec) on the 200k-box stack scene; solver iterations/s in extra",
+            "value": visits_all / elapsed_max,
+            "unit": "joint-visits/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: stack(%d,%d) per GPU = %d bodies / %d joints per GPU, Single Sloppy islands, %d+%d iterations, "
+                                   "full SolveJoints per step on HBM-resident inputs" % (args.columns, args.rows, nb, nj, args.iters, args.iters),
+                       "bodies_total": int(bodies_all), "joints_total": int(joints_all), "colours": st.colour_count,
+                       "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,
+                       "parallelism": "islands sharded by column slab, 1 rank per GPU, per-step 4-byte RCCL all-reduce" if world > 1 else "1 GPU",
+                       "device": info["name"], "compute_units": info["compute_units"]},
+            "extra": {"solver_iterations_per_sec": iters_all / world / elapsed_max,
+                      "contacts_resolved_per_sec": joints_all * args.steps / elapsed_max,
+                      "device_ms_per_step": tot["total_ms"] / max(args.steps, 1),
+                      "sweep_ms_per_step": tot["sweep_ms"] / max(args.steps, 1),
+                      "joint_visits_per_sec_sweeps_only": tot["visits"] / sweep_s if sweep_s > 0 else None},
+            "roofline": {"bound": "hbm", "kernel": "k_solve_colour<impulse,displacement>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "launches": tot["launches"], "avg_launch_us": 1e3 * tot["sweep_ms"] / max(tot["launches"], 1),
+                         "algorithmic_bytes_per_launch": alg_bytes / max(tot["launches"], 1),
+                         "note": "196 B per impulse joint-visit + 136 B per displacement joint-visit (SURVEY.md §8d) over the HIP-event "
+                                 "time of all sweep launches (inter-launch gaps and early-out launches included)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(bodies, cps, joints, args.iters, args.cpu_seconds)
+        print(json.dumps(out))
+    group.shutdown()
+
+
+def cpu_baseline(bodies, cps, joints, iters, budget_s):
+    """The oracle's impulse loop (restated ref: Solver.cpp:760-914) timed on this host over the same solver input,
+    Single-Sloppy style: persistent threads, 512-joint batches (ref: Solver.cpp:138-139).  The thread count is the
+    best of a short probe over {1, 4, 8, 16, 32, 64, all} — the racy sweep stops scaling long before 256 threads.
+    Reported beside the GPU number, not a target."""
+    from oracle import binding as ob
+    ncpu = os.cpu_count() or 1
+    b = bodies.view(ob.body_dtype); cp = cps.view(ob.contact_point_dtype); j = joints.view(ob.joint_dtype)
+    t_begin = time.perf_counter()
+    probe = {}
+    for t in sorted({1, 4, 8, 16, 32, 64, ncpu}):
+        if t > ncpu:
+            continue
+        sec, v = ob.time_impulse_loop(b, cp, j, iters, t)
+        probe[t] = v / sec
+    best = max(probe, key=probe.get)
+    used = time.perf_counter() - t_begin
+    one = len(j) * iters / probe[best]
+    reps = max(3, min(400, int(max(budget_s - used, 1.0) / max(one, 1e-6))))
+    tt = vv = 0.0
+    for _ in range(reps):
+        sec, v = ob.time_impulse_loop(b, cp, j, iters, best)
+        tt += sec; vv += v
+    return {"value": vv / tt, "unit": "joint-visits/s", "cores": best, "kind": "port",
+            "sample": "%d x (%d impulse sweeps over the same %d-joint solver input), impulse loop only, %d threads in 512-joint "
+                      "batches (best of probe %s; host has %d cores)" % (reps, iters, len(j), best,
+                                                                         {k: round(v / 1e6) for k, v in probe.items()}, ncpu),
+            "single_thread_value": probe.get(1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -122,7 +122,7 @@ typedef struct {
     int32_t displacement_iterations;   /* ref: Solver.cpp:210 */
     int32_t lds_islands;               /* islands solved by the one-workgroup-per-island kernel */
     int32_t recoloured;                /* 1 if the joint topology changed and the schedule was rebuilt */
-    int32_t reserved;
+    int32_t graph_replay;              /* 1 if the launch sequence was replayed from cached hipGraphs */
     double  device_ms;                 /* HIP-event time of the device work of the last solve */
 } phx_solve_stats;
 int phx_solver_get_stats(phx_solver* s, phx_solve_stats* out);
@@ -199,6 +199,11 @@ int  phx_world_set_gravity(phx_world* w, float gravity);            /* ref: Worl
  * default 0/1 solves everything).  Bodies of other shards keep their velocities. */
 int  phx_world_set_shard(phx_world* w, int32_t shard, int32_t shard_count);
 int  phx_world_update(phx_world* w, float dt, const phx_config* config);   /* ref: World.cpp:19-37 */
+/* World::Update split at the solver boundary: pre_solve = everything before Solver::SolveJoints
+ * (ref: World.cpp:25-32), after which bodies / contact points / joints are exactly the solver's inputs;
+ * finish_step = SolveJoints + IntegratePosition (ref: World.cpp:34-36).  pre_solve + finish_step == update. */
+int  phx_world_pre_solve(phx_world* w, float dt);
+int  phx_world_finish_step(phx_world* w, float dt, const phx_config* config);
 int  phx_world_counts(phx_world* w, int32_t* bodies, int32_t* manifolds, int32_t* contact_points, int32_t* joints);
 int  phx_world_get_bodies(phx_world* w, phx_rigid_body* out, int32_t cap);
 int  phx_world_get_manifolds(phx_world* w, phx_manifold* out, int32_t cap);

@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1149,22 +1150,51 @@ int phxo_world_point_overflows(phxo_world* w) { return w->point_overflows; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* multi-threaded timing harness (cpu_baseline leg of bench.py only)                           */
+/* Persistent worker threads meeting at a spin barrier once per sweep, 512-joint batches dealt  */
+/* round-robin — the shape of the reference's Single Sloppy mode (ref: Solver.cpp:138-139,      */
+/* 181-187; base/Parallel.h:27-103), including its data races on shared bodies.                 */
 
 typedef struct {
-    sctx* c; int begin, end, iter, tid, threads; volatile int* any;
-} tjob;
+    sctx* c;
+    int nj, iters, threads;
+    volatile int arrived, generation, stop_after;   /* barrier state; stop_after = sweeps actually run */
+    volatile int any[2];
+} tshared;
+
+typedef struct { tshared* sh; int tid; } tjob;
+
+static void spin_barrier(tshared* sh, int* local_gen)
+{
+    int gen = *local_gen;
+    if (__atomic_add_fetch(&sh->arrived, 1, __ATOMIC_ACQ_REL) == sh->threads) {
+        sh->arrived = 0;
+        __atomic_store_n(&sh->generation, gen + 1, __ATOMIC_RELEASE);
+    } else {
+        int spins = 0;
+        while (__atomic_load_n(&sh->generation, __ATOMIC_ACQUIRE) == gen)
+            if (++spins > 2000) { sched_yield(); spins = 0; }
+    }
+    *local_gen = gen + 1;
+}
 
 static void* tworker(void* p)
 {
     tjob* j = (tjob*)p;
-    /* 512-joint batches dealt round-robin to threads (ref: Solver.cpp:138-139,181-187 hands batches
-     * to whichever worker is free; both are unordered and racy by design) */
-    int any = 0;
-    for (int b = j->begin + j->tid * 512; b < j->end; b += j->threads * 512) {
-        int e = b + 512 < j->end ? b + 512 : j->end;
-        any |= sweep(j->c, b, e, j->iter, 1, 0);
+    tshared* sh = j->sh;
+    int gen = 0;
+    for (int it = 0; it < sh->iters; ++it) {
+        int any = 0;
+        for (int b = j->tid * 512; b < sh->nj; b += sh->threads * 512) {
+            int e = b + 512 < sh->nj ? b + 512 : sh->nj;
+            any |= sweep(sh->c, b, e, it, 1, 0);
+        }
+        if (any) sh->any[it & 1] = 1;
+        spin_barrier(sh, &gen);
+        int go = sh->any[it & 1];
+        spin_barrier(sh, &gen);
+        if (j->tid == 0) { sh->any[(it + 1) & 1] = 0; sh->stop_after = it + 1; }
+        if (!go) break;                                   /* ref: Solver.cpp:189 */
     }
-    if (any) *j->any = 1;
     return NULL;
 }
 
@@ -1180,28 +1210,18 @@ double phxo_time_impulse_loop(phxo_body* bodies, int nb, const phxo_contact_poin
     for (int s = 0; s < nj; ++s) refresh_one(&c.pj[s], c.imp, c.par, c.cps);
     for (int s = 0; s < nj; ++s) prestep_one(&c.pj[s], c.imp);
 
+    tshared sh; memset(&sh, 0, sizeof sh);
+    sh.c = &c; sh.nj = nj; sh.iters = iters; sh.threads = threads;
     pthread_t* th = (pthread_t*)malloc(threads * sizeof(pthread_t));
     tjob* jobs = (tjob*)malloc(threads * sizeof(tjob));
     struct timespec t0, t1;
-    int64_t visits = 0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int it = 0; it < iters; ++it) {
-        volatile int any = 0;
-        if (threads == 1) {
-            any = sweep(&c, 0, nj, it, 1, 0);
-        } else {
-            for (int t = 0; t < threads; ++t) {
-                tjob jb = {&c, 0, nj, it, t, threads, &any};
-                jobs[t] = jb;
-                pthread_create(&th[t], NULL, tworker, &jobs[t]);
-            }
-            for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
-        }
-        visits += nj;
-        if (!any) break;
-    }
+    for (int t = 1; t < threads; ++t) { jobs[t].sh = &sh; jobs[t].tid = t; pthread_create(&th[t], NULL, tworker, &jobs[t]); }
+    jobs[0].sh = &sh; jobs[0].tid = 0;
+    tworker(&jobs[0]);                                     /* the caller works too (ref: base/Parallel.h:94) */
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    if (joint_visits) *joint_visits = visits;
+    if (joint_visits) *joint_visits = (int64_t)sh.stop_after * nj;
     free(th); free(jobs);
     ctx_free(&c);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);

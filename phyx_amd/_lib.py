@@ -27,7 +27,7 @@ class Config(C.Structure):
 class SolveStats(C.Structure):
     _fields_ = [("island_count", C.c_int32), ("island_max_size", C.c_int32), ("colour_count", C.c_int32),
                 ("impulse_iterations", C.c_int32), ("displacement_iterations", C.c_int32),
-                ("lds_islands", C.c_int32), ("recoloured", C.c_int32), ("reserved", C.c_int32),
+                ("lds_islands", C.c_int32), ("recoloured", C.c_int32), ("graph_replay", C.c_int32),
                 ("device_ms", C.c_double)]
 
 
@@ -80,6 +80,8 @@ _SIGNATURES = {
     "phx_world_set_gravity": (C.c_int, [_vp, _f32]),
     "phx_world_set_shard": (C.c_int, [_vp, _i32, _i32]),
     "phx_world_update": (C.c_int, [_vp, _f32, C.POINTER(Config)]),
+    "phx_world_pre_solve": (C.c_int, [_vp, _f32]),
+    "phx_world_finish_step": (C.c_int, [_vp, _f32, C.POINTER(Config)]),
     "phx_world_counts": (C.c_int, [_vp] + [C.POINTER(_i32)] * 4),
     "phx_world_get_bodies": (C.c_int, [_vp, _vp, _i32]),
     "phx_world_get_manifolds": (C.c_int, [_vp, _vp, _i32]),

@@ -298,6 +298,15 @@ class World:
         cfg = configuration._c()
         check(self.L.phx_world_update(self.h, dt, C.byref(cfg)))
 
+    def PreSolve(self, dt):
+        """Everything of World::Update that precedes Solver::SolveJoints (ref: World.cpp:25-32)."""
+        check(self.L.phx_world_pre_solve(self.h, dt))
+
+    def FinishStep(self, dt, configuration):
+        """Solver::SolveJoints + IntegratePosition (ref: World.cpp:34-36)."""
+        cfg = configuration._c()
+        check(self.L.phx_world_finish_step(self.h, dt, C.byref(cfg)))
+
     def counts(self):
         v = [C.c_int32() for _ in range(4)]
         check(self.L.phx_world_counts(self.h, *[C.byref(x) for x in v]))

@@ -67,7 +67,23 @@ public:
 
 private:
     int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, const phx_config& cfg);
+    struct GraphKey {
+        const void *bodies = nullptr, *cps = nullptr, *joints = nullptr;
+        int nb = 0, nj = 0, ci = 0, pi = 0;
+        long long schedule_version = -1;
+        bool valid = false;
+        bool operator==(const GraphKey& o) const
+        {
+            return bodies == o.bodies && cps == o.cps && joints == o.joints && nb == o.nb && nj == o.nj && ci == o.ci && pi == o.pi &&
+                   schedule_version == o.schedule_version;
+        }
+    };
     int enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg);
+    int enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj);
+    int enqueue_sweeps(int nj, int ci, int pi);
+    int enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj);
+    int capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
+    void drop_graphs();
     int collect_stats();
     SolverView view() const;
 
@@ -98,7 +114,10 @@ private:
     phx_solve_stats stats_{};
     bool stats_pending_ = false, have_solve_ = false;
     int last_ci_ = 0, last_pi_ = 0;
-    long long sweep_launches_ = 0;
+    long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
+    hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
+    GraphKey graph_key_, last_key_;
+    bool use_graphs_ = true;
 };
 
 } // namespace phx

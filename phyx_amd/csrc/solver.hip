@@ -3,6 +3,7 @@
 #include "solver_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace phx {
@@ -113,6 +114,7 @@ DeviceSolver::~DeviceSolver()
 {
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
+    drop_graphs();
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); crange_.release(); sw_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
@@ -132,6 +134,8 @@ int DeviceSolver::init()
     PHX_HIP(hipEventCreate(&ev_sweep_begin_));
     PHX_HIP(hipEventCreate(&ev_sweep_end_));
     PHX_TRY(hash_.reserve(1));
+    const char* g = getenv("PHX_NO_GRAPHS");
+    use_graphs_ = !(g && g[0] == '1');
     return PHX_OK;
 }
 
@@ -152,7 +156,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     // 1. fingerprint of the joint topology (8 bytes over PCIe)
     unsigned long long fp = 0;
     PHX_HIP(hipMemsetAsync(hash_.p, 0, sizeof(unsigned long long), stream_));
-    hipLaunchKernelGGL(k_topology_hash, dim3(grid_for(std::max(nj, nb))), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, hash_.p);
+    hipLaunchKernelGGL(k_topology_hash, dim3(std::min(grid_for(std::max(nj, nb)), 512)), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, hash_.p);
     PHX_HIP(hipGetLastError());
     PHX_HIP(hipMemcpyAsync(&fp, hash_.p, sizeof fp, hipMemcpyDeviceToHost, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
@@ -209,8 +213,93 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_HIP(hipStreamSynchronize(stream_));
     sched_.fingerprint = fp;
     sched_.valid = true;
+    ++schedule_version_;
+    drop_graphs();
     stats_.recoloured = 1;
     (void)cfg;
+    return PHX_OK;
+}
+
+// The launch sequence of one SolveJoints, in three capturable segments (no sync, no allocation inside):
+//   pre    PrepareBodies, PrepareJoints+RefreshJoints, PreStepJoints colour by colour
+//   sweeps `iters` x colours fused impulse+displacement launches
+//   post   FinishJoints, FinishBodies
+int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj)
+{
+    const SolverView v = view();
+    PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
+    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)v.nstatic * sizeof(unsigned), stream_));
+    if (nb) hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, sb_imp_.p, sb_disp_.p, sb_par_.p);
+    if (nj) {
+        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints, d_cps, static_slot_.p);
+        for (int c = 0; c < v.ncolours; ++c) {
+            const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
+            hipLaunchKernelGGL(k_prestep, dim3(grid_for(n)), dim3(256), 0, stream_, v, c);
+        }
+    }
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
+int DeviceSolver::enqueue_sweeps(int nj, int ci, int pi)
+{
+    const SolverView v = view();
+    const int iters = std::max(ci, pi);
+    sweep_launches_ = 0;
+    if (!nj) return PHX_OK;
+    for (int it = 0; it < iters; ++it) {
+        const bool imp = it < ci, disp = it < pi;
+        for (int c = 0; c < v.ncolours; ++c) {
+            const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
+            const dim3 g(std::max(1, std::min(div_up(n, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
+            const int cb = sched_.colour_offsets[c], ce = sched_.colour_offsets[c + 1];
+            if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, ce, c, it);
+            else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, ce, c, it);
+            else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, ce, c, it);
+            ++sweep_launches_;
+        }
+    }
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
+int DeviceSolver::enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj)
+{
+    const SolverView v = view();
+    if (nj) hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints);
+    if (nb) hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, v, d_bodies);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
+void DeviceSolver::drop_graphs()
+{
+    for (hipGraphExec_t& g : graph_) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
+    graph_key_ = GraphKey{};
+}
+
+// Capture the three segments into hipGraphs.  A solve of the 200k-box scene is ~230 launches of 1-4 us
+// kernels; launched eagerly the host (~4 us per launch) is the bottleneck, replayed from a graph it is not.
+int DeviceSolver::capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints)
+{
+    drop_graphs();
+    for (int seg = 0; seg < 3; ++seg) {
+        hipGraph_t graph = nullptr;
+        PHX_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        int st = seg == 0 ? enqueue_pre(d_bodies, key.nb, d_cps, d_joints, key.nj)
+               : seg == 1 ? enqueue_sweeps(key.nj, key.ci, key.pi)
+                          : enqueue_post(d_bodies, key.nb, d_joints, key.nj);
+        hipError_t e = hipStreamEndCapture(stream_, &graph);
+        if (st != PHX_OK) { if (graph) (void)hipGraphDestroy(graph); drop_graphs(); return st; }
+        if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); drop_graphs(); return PHX_ERR_HIP; }
+        if (graph) {
+            e = hipGraphInstantiate(&graph_[seg], graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); drop_graphs(); return PHX_ERR_HIP; }
+        }
+    }
+    graph_key_ = key;
+    graph_sweep_launches_ = sweep_launches_;
     return PHX_OK;
 }
 
@@ -221,43 +310,31 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     if (iters + 1 > max_iters_ || !flags_.p) {
         max_iters_ = std::max(iters + 1, 64);
         PHX_TRY(flags_.reserve(2 * (size_t)max_iters_));
+        drop_graphs();
     }
-    const SolverView v = view();
-    const int ncol = v.ncolours;
+    GraphKey key;
+    key.bodies = d_bodies; key.cps = d_cps; key.joints = d_joints; key.nb = nb; key.nj = nj; key.ci = ci; key.pi = pi;
+    key.schedule_version = schedule_version_; key.valid = true;
+    // graphs pay off from the second solve of an unchanged (schedule, buffers, iteration counts) tuple on
+    const bool have = graph_key_.valid && graph_key_ == key;
+    if (!have && use_graphs_ && last_key_.valid && last_key_ == key) PHX_TRY(capture_graphs(key, d_bodies, d_cps, d_joints));
+    last_key_ = key;
+    const bool replay = graph_key_.valid && graph_key_ == key;
+
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
-    PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
-    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)v.nstatic * sizeof(unsigned), stream_));
-    if (nb) hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, sb_imp_.p, sb_disp_.p, sb_par_.p);
-    if (nj) {
-        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints, d_cps, static_slot_.p);
-        for (int c = 0; c < ncol; ++c) {
-            const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
-            hipLaunchKernelGGL(k_prestep, dim3(grid_for(n)), dim3(256), 0, stream_, v, c);
-        }
-    }
+    if (replay) { if (graph_[0]) PHX_HIP(hipGraphLaunch(graph_[0], stream_)); }
+    else PHX_TRY(enqueue_pre(d_bodies, nb, d_cps, d_joints, nj));
     PHX_HIP(hipEventRecord(ev_sweep_begin_, stream_));
-    sweep_launches_ = 0;
-    if (nj) {
-        for (int it = 0; it < iters; ++it) {
-            const bool imp = it < ci, disp = it < pi;
-            for (int c = 0; c < ncol; ++c) {
-                const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
-                const dim3 g(grid_for(n)), b(256);
-                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, c, it);
-                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, c, it);
-                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, c, it);
-                ++sweep_launches_;
-            }
-        }
-    }
+    if (replay) { if (graph_[1]) PHX_HIP(hipGraphLaunch(graph_[1], stream_)); sweep_launches_ = graph_sweep_launches_; }
+    else PHX_TRY(enqueue_sweeps(nj, ci, pi));
     PHX_HIP(hipEventRecord(ev_sweep_end_, stream_));
-    if (nj) hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints);
-    if (nb) hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, v, d_bodies);
-    PHX_HIP(hipGetLastError());
+    if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
+    else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
     PHX_HIP(hipEventRecord(ev_end_, stream_));
     last_ci_ = ci; last_pi_ = pi;
     stats_pending_ = true;
     have_solve_ = true;
+    stats_.graph_replay = replay ? 1 : 0;
     return PHX_OK;
 }
 

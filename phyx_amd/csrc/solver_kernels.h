@@ -74,6 +74,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
 __global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
                                                        const phx_rigid_body* __restrict__ bodies, int nb, unsigned long long* out)
 {
+    __shared__ unsigned long long part[4];
     unsigned long long h = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
         unsigned long long k = ((unsigned long long)(unsigned)joints[i].body1 << 32) | (unsigned)joints[i].body2;
@@ -83,7 +84,12 @@ __global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* 
         if (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) h += mix64(0xD1B54A32D192ED03ull * (unsigned long long)(i + 1));
     }
     for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
-    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                        // one device-scope atomic per workgroup
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 // ---- PrepareJoints + RefreshJoints (ref: Solver.cpp:496-521, 549-695) ----------------------------
@@ -168,33 +174,47 @@ __global__ void __launch_bounds__(256) k_prestep(SolverView v, int colour)
 }
 
 // ---- SolveJointsImpulses + SolveJointsDisplacement (ref: Solver.cpp:760-1018), one colour, one sweep
-template <bool DO_IMP, bool DO_DISP>
-__global__ void __launch_bounds__(256) k_solve_colour(SolverView v, int colour, int iter)
-{
-    // a sweep after an unproductive sweep skips every joint (all tags <= iter-2), which is why the
-    // reference may stop there (ref: Solver.cpp:189, 210); the launch is already queued, so it just returns
-    const bool imp_on = DO_IMP && (iter == 0 || v.imp_active[iter - 1] != 0);
-    const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
-    if (!imp_on && !disp_on) return;
+// Launch shape: one wavefront per workgroup (64 lanes, one joint per lane).  A colour of the 200k-box scene has
+// only 2e4-1e5 joints, i.e. a few waves per CU: the kernel is bound by the dependent-load chain
+// (slot -> body index -> body state), not by bandwidth, so (1) single-wave workgroups spread the joints over all
+// 256 CUs and (2) every load that does not depend on the body index is issued up front, before the skip test —
+// the reference loads the joint constants only after the test (ref: Solver.cpp:798-831), which on this machine
+// would add a third dependent round trip to save bytes that are not the bottleneck.
+constexpr int SOLVE_BLOCK = 64;
 
-    const int2 r = v.crange[colour];
+template <bool DO_IMP, bool DO_DISP>
+__global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int begin, int end, int colour, int iter)
+{
+    // A sweep after an unproductive sweep skips every joint (all tags <= iter-2), which is why the reference may
+    // stop there (ref: Solver.cpp:189, 210).  The impulse half needs no flag for that — each joint's own skip
+    // test does it — so its loads are issued unconditionally; the displacement half (dead after the first sweep
+    // on a resting scene) is gated by its flag, whose scalar load overlaps the vector loads below.
+    const bool imp_on = DO_IMP;
+    const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
+
     bool any_imp = false, any_disp = false;
-    for (int s = r.x + blockIdx.x * blockDim.x + threadIdx.x; s < r.y; s += gridDim.x * blockDim.x) {
+    for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
         const int4 k = v.q3[s];
         const float4 c = v.q2[s];
+        const float4 a = v.q0[s];
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 acc = make_float2(0.f, 0.f), d = make_float2(0.f, 0.f);
+        if (imp_on) { f = v.q1[s]; acc = v.acc[s]; }
+        if (disp_on) d = v.dd[s];
+        const int b1 = k.y, b2 = k.z, ss = k.w;
+        float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
+        if (imp_on) { B1 = v.sb_imp[b1]; B2 = v.sb_imp[b2]; }
+        if (disp_on) { D1 = v.sb_disp[b1]; D2 = v.sb_disp[b2]; }
+
         const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
         const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
-        const int b1 = k.y, b2 = k.z, ss = k.w;
+        const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
 
         if (imp_on) {
-            float4 B1 = v.sb_imp[b1], B2 = v.sb_imp[b2];
             // ref: Solver.cpp:790-798
             const bool p1 = st1 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
             const bool p2 = st2 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
             if (p1 || p2) {
-                const float4 a = v.q0[s], f = v.q1[s];
-                float2 acc = v.acc[s];
-                const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
                 // normal limiter (ref: :833-858)
                 float dv = f.w;
                 dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
@@ -229,30 +249,26 @@ __global__ void __launch_bounds__(256) k_solve_colour(SolverView v, int colour, 
             }
         }
         if (disp_on) {
-            float4 B1 = v.sb_disp[b1], B2 = v.sb_disp[b2];
-            const bool p1 = st1 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
-            const bool p2 = st2 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
+            const bool p1 = st1 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D1.w) > iter - 2);
+            const bool p2 = st2 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D2.w) > iter - 2);
             if (p1 || p2) {
-                const float4 a = v.q0[s];
-                float2 d = v.dd[s];
-                const float nx = a.x, ny = a.y;
                 float dv = d.x;                                                      // ref: :973-981
-                dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
-                dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
+                dv -= nx * D1.x; dv -= ny * D1.y; dv -= a.z * D1.z;
+                dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= a.w * D2.z;
                 float di = dv * c.x;
                 di = max_ref(di, -d.y);
-                B1.x += (nx * im1) * di; B1.y += (ny * im1) * di; B1.z += (a.z * ii1) * di;
-                B2.x += ((-nx) * im2) * di; B2.y += ((-ny) * im2) * di; B2.z += (a.w * ii2) * di;
+                D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (a.z * ii1) * di;
+                D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (a.w * ii2) * di;
                 d.y += di;
                 v.dd[s] = d;
                 const bool productive = fabsf(di) > 1e-4f;                           // ref: :999
                 if (productive) {
-                    B1.w = __int_as_float(iter); B2.w = __int_as_float(iter);
+                    D1.w = __int_as_float(iter); D2.w = __int_as_float(iter);
                     any_disp = true;
                     if ((st1 || st2) && ss >= 0) atomicMax(&v.sw_disp[(iter & 1) * v.nstatic + ss], static_word(iter, colour));
                 }
-                if (!st1) v.sb_disp[b1] = B1;
-                if (!st2) v.sb_disp[b2] = B2;
+                if (!st1) v.sb_disp[b1] = D1;
+                if (!st2) v.sb_disp[b2] = D2;
             }
         }
     }

@@ -37,6 +37,8 @@ public:
 
     int add_body(float px, float py, float angle, float sx, float sy);
     int update(float dt, const phx_config& cfg);
+    int pre_solve(float dt);
+    int finish_step(float dt, const phx_config& cfg);
 
     std::vector<phx_rigid_body> bodies;
     std::vector<phx_manifold> manifolds;
@@ -221,23 +223,36 @@ int World::solve(const phx_config& cfg)                                     // r
     return PHX_OK;
 }
 
-int World::update(float dt, const phx_config& cfg)
+int World::pre_solve(float dt)
 {
     using clk = std::chrono::steady_clock;
     auto t = clk::now();
     auto lap = [&](int phase) { auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
     integrate_velocity(dt); lap(0);
+    // the device runs sort and sweep back to back; the host clock cannot split them, so the whole device
+    // broadphase is booked under UpdatePairs and UpdateBroadphase reads 0 (phx_broadphase_stats has device_ms)
+    phase_ms[1] = 0.0;
     PHX_TRY(update_pairs()); lap(2);
-    {   // split the device time of the broadphase into sort (UpdateBroadphase) and sweep (UpdatePairs) shares is not
-        // possible from the host clock; report the whole device update under UpdatePairs and 0 under UpdateBroadphase
-        phase_ms[1] = 0.0;
-    }
     update_manifolds(); lap(3);
     PHX_TRY(pack_manifolds()); lap(4);
     refresh_contact_joints(); lap(5);
+    return PHX_OK;
+}
+
+int World::finish_step(float dt, const phx_config& cfg)
+{
+    using clk = std::chrono::steady_clock;
+    auto t = clk::now();
+    auto lap = [&](int phase) { auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
     PHX_TRY(solve(cfg)); lap(6);
     integrate_position(dt); lap(7);
     return PHX_OK;
+}
+
+int World::update(float dt, const phx_config& cfg)
+{
+    PHX_TRY(pre_solve(dt));
+    return finish_step(dt, cfg);
 }
 
 } // namespace phx
@@ -295,6 +310,18 @@ int phx_world_update(phx_world* w, float dt, const phx_config* cfg)
 {
     PHX_REQUIRE(w && cfg, "null handle / config");
     return w->impl.update(dt, *cfg);
+}
+
+int phx_world_pre_solve(phx_world* w, float dt)
+{
+    PHX_REQUIRE(w, "null handle");
+    return w->impl.pre_solve(dt);
+}
+
+int phx_world_finish_step(phx_world* w, float dt, const phx_config* cfg)
+{
+    PHX_REQUIRE(w && cfg, "null handle / config");
+    return w->impl.finish_step(dt, *cfg);
 }
 
 int phx_world_counts(phx_world* w, int32_t* nb, int32_t* nm, int32_t* ncp, int32_t* nj)
