@@ -124,6 +124,7 @@ typedef struct {
     int32_t recoloured;                /* 1 if the joint topology changed and the schedule was rebuilt */
     int32_t graph_replay;              /* 1 if the launch sequence was replayed from cached hipGraphs */
     double  device_ms;                 /* HIP-event time of the device work of the last solve */
+    int64_t joint_visits;              /* joints swept by the impulse loop, skipped ones included; per-island early exits honoured */
 } phx_solve_stats;
 int phx_solver_get_stats(phx_solver* s, phx_solve_stats* out);
 
@@ -132,6 +133,12 @@ int phx_solver_get_stats(phx_solver* s, phx_solve_stats* out);
  * scalar loop reproduces the device result bit for bit (tests/ feeds this to the oracle). */
 int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap,
                             int32_t* colour_offsets, int32_t offsets_cap, int32_t* colour_count);
+/* Groups of the schedule: group g owns slots [group_offsets[g], group_offsets[g+1]) and is an independent
+ * Gauss-Seidel problem (body-disjoint from every other group, static bodies aside) with its own early exit and
+ * its own copy of the static bodies' lastIteration tags — the counterpart of the reference's islands
+ * (ref: Solver.cpp:86-91).  The first *lds_group_count groups ran one-workgroup-per-group out of LDS, the rest
+ * (at most one) colour by colour out of HBM.  Single island mode always reports one group. */
+int phx_solver_get_groups(phx_solver* s, int32_t* group_offsets, int32_t offsets_cap, int32_t* group_count, int32_t* lds_group_count);
 
 /* RefreshJoints output for joint `joint_index` of the last solve (ref: Solver.cpp:592-695), expanded
  * to the reference's 30-float ContactJointPacked<1> order: normal limiter 13, 0, dstVelocity,

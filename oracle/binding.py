@@ -86,6 +86,8 @@ def lib():
                                         C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.phxo_solver_solve_ordered.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.phxo_solver_solve_grouped.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.phxo_refresh_joint.argtypes = [C.c_void_p] * 4
         L.phxo_gather_islands.restype = C.c_int
         L.phxo_gather_islands.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -256,6 +258,19 @@ def solver_solve_ordered(bodies, cps, joints, order, colour_offsets, contact_ite
     L.phxo_solver_solve_ordered(_p(bodies), len(bodies), _p(cps), _p(joints), len(joints), _p(order),
                                 _p(co) if co is not None else None, 0 if co is None else len(co) - 1,
                                 contact_iters, penetration_iters, stag_mode, C.byref(st))
+    return st
+
+
+def solver_solve_grouped(bodies, cps, joints, order, colour_offsets, group_offsets, contact_iters, penetration_iters,
+                         stag_mode=STAG_COLOUR_SYNC):
+    """The HIP path's island-aware schedule replayed sequentially: groups are independent islands."""
+    L = lib()
+    st = SolveStats()
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    co = np.ascontiguousarray(colour_offsets, dtype=np.int32)
+    go = np.ascontiguousarray(group_offsets, dtype=np.int32)
+    L.phxo_solver_solve_grouped(_p(bodies), len(bodies), _p(cps), _p(joints), len(joints), _p(order), _p(co), len(co) - 1,
+                                _p(go), len(go) - 1, contact_iters, penetration_iters, stag_mode, C.byref(st))
     return st
 
 

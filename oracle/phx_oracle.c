@@ -808,6 +808,45 @@ void phxo_solver_solve_ordered(phxo_body* bodies, int nb, const phxo_contact_poi
     ctx_free(&c);
 }
 
+/* The schedule form the HIP path uses in the island-aware modes: `order` is cut into GROUPS of consecutive
+ * slots; each group is an independent SolveJointIsland (Refresh, PreStep, sweeps with its own early exit —
+ * ref: Solver.cpp:130-215) and observes its OWN copy of every static body's lastIteration tag, i.e. the tags
+ * are reset at each group start.  (In the reference a static body's tag is one shared word that a later island
+ * inherits from the previous one, an artefact its own TODO at Solver.cpp:244 files under races; giving each
+ * island a private copy is the deterministic reading.)  Inside a group the scalar (N=1) loop runs in slot
+ * order, colours only matter for PHXO_STAG_COLOUR_SYNC. */
+void phxo_solver_solve_grouped(phxo_body* bodies, int nb, const phxo_contact_point* cps, phxo_contact_joint* joints, int nj,
+                               const int32_t* order, const int32_t* colour_offsets, int ncolours,
+                               const int32_t* group_offsets, int ngroups,
+                               int contact_iters, int pen_iters, int stag_mode, phxo_solve_stats* stats)
+{
+    phxo_solve_stats local; if (!stats) stats = &local;
+    memset(stats, 0, sizeof *stats);
+    sctx c; ctx_alloc(&c, nb, nj);
+    c.cps = cps; c.joints = joints; c.nj = nj; c.st = stats; c.stag_mode = stag_mode;
+    prepare_bodies(&c, bodies);
+    for (int i = 0; i < nj; ++i) c.joint_index[i] = order ? order[i] : i;
+    int32_t* colour = NULL;
+    if (colour_offsets && ncolours > 0) {
+        colour = (int32_t*)malloc((nj + 1) * sizeof(int32_t));
+        for (int k = 0; k < ncolours; ++k)
+            for (int s = colour_offsets[k]; s < colour_offsets[k + 1]; ++s) colour[s] = k;
+        c.slot_colour = colour;
+    }
+    stats->island_count = ngroups; stats->group_offset = nj;
+    copy_joints_in(&c, 0, nj);
+    for (int g = 0; g < ngroups; ++g) {
+        int b = group_offsets[g], e = group_offsets[g + 1];
+        if (e - b > stats->island_max_size) stats->island_max_size = e - b;
+        for (int i = 0; i < nb; ++i) if (c.is_static[i]) { c.imp[i].tag = -1; c.disp[i].tag = -1; }
+        solve_island(&c, b, e, e, 1, contact_iters, pen_iters);
+    }
+    copy_joints_out(&c, 0, nj);
+    finish_bodies(&c, bodies);
+    free(colour);
+    ctx_free(&c);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* narrowphase (ref: Collider.cpp:8-245) — the step between the two hot halves                  */
 

@@ -130,6 +130,16 @@ void phxo_solver_solve_ordered(phxo_body* bodies, int nb, const phxo_contact_poi
                                int contact_iters, int penetration_iters, int stag_mode,
                                phxo_solve_stats* stats);
 
+/* Grouped form of the above (what the HIP path does in the island-aware modes): group g = slots
+ * [group_offsets[g], group_offsets[g+1]) is solved as an independent island with its own early exit and
+ * its own copy of the static bodies' lastIteration tags.  See the comment at the definition. */
+void phxo_solver_solve_grouped(phxo_body* bodies, int nb, const phxo_contact_point* cps,
+                               phxo_contact_joint* joints, int nj,
+                               const int32_t* order, const int32_t* colour_offsets, int ncolours,
+                               const int32_t* group_offsets, int ngroups,
+                               int contact_iters, int penetration_iters, int stag_mode,
+                               phxo_solve_stats* stats);
+
 /* RefreshJoints only (Solver.cpp:592-695): 29 floats per joint in the field order of
  * ContactJointPacked<1> minus indices: normal limiter 13, normalLimiter_compInvMass(unused, 0),
  * dstVelocity, dstDisplacingVelocity, accumulatedDisplacingImpulse, friction limiter 13. */

@@ -28,7 +28,7 @@ class SolveStats(C.Structure):
     _fields_ = [("island_count", C.c_int32), ("island_max_size", C.c_int32), ("colour_count", C.c_int32),
                 ("impulse_iterations", C.c_int32), ("displacement_iterations", C.c_int32),
                 ("lds_islands", C.c_int32), ("recoloured", C.c_int32), ("graph_replay", C.c_int32),
-                ("device_ms", C.c_double)]
+                ("device_ms", C.c_double), ("joint_visits", C.c_int64)]
 
 
 class BroadphaseStats(C.Structure):
@@ -60,6 +60,7 @@ _SIGNATURES = {
     "phx_solver_synchronize": (C.c_int, [_vp]),
     "phx_solver_get_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),
     "phx_solver_get_schedule": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
+    "phx_solver_get_groups": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "phx_solver_get_refreshed": (C.c_int, [_vp, _i32, _vp]),
     "phx_solver_bench": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, C.POINTER(BenchResult)]),
     "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, C.POINTER(_i32)]),

@@ -189,6 +189,14 @@ class Solver:
         check(self.L.phx_solver_get_schedule(self.h, _ptr(order), len(order), _ptr(offs), len(offs), C.byref(nc)))
         return order[:int(offs[-1])], offs
 
+    def groups(self):
+        """(group_offsets, lds_group_count) of the last solve's schedule."""
+        n, lds = C.c_int32(0), C.c_int32(0)
+        check(self.L.phx_solver_get_groups(self.h, None, 0, C.byref(n), C.byref(lds)))
+        offs = np.zeros(n.value + 1, dtype=np.int32)
+        check(self.L.phx_solver_get_groups(self.h, _ptr(offs), len(offs), C.byref(n), C.byref(lds)))
+        return offs, lds.value
+
     def refreshed(self, joint_index):
         out = np.zeros(30, dtype=np.float32)
         check(self.L.phx_solver_get_refreshed(self.h, joint_index, _ptr(out)))

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libphyx_amd.so")
-SOURCES = ["runtime.hip", "solver.hip", "c_api_solver.hip", "broadphase.hip", "world.hip"]
+SOURCES = ["runtime.hip", "schedule.hip", "solver.hip", "c_api_solver.hip", "broadphase.hip", "world.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-shared"]
 

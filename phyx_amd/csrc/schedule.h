@@ -1,0 +1,54 @@
+// schedule.h — host-side construction of the solve schedule (which joint is swept when, and where).
+//
+// A schedule is the device's answer to Solver::PrepareIndices + Solver::GatherIslands
+// (ref: src/Solver.cpp:217-273, 285-454): it fixes ONE sequential sweep order of the joints and marks the
+// places where that order may be executed in parallel without changing its result:
+//   * a COLOUR is a run of consecutive slots whose joints share no dynamic body (PrepareIndices' idea of an
+//     N-independent group, with N = the whole class instead of 4 or 8) — its joints run in parallel lanes;
+//   * a GROUP is a run of consecutive colours whose joints share no dynamic body with any other group
+//     (GatherIslands' islands, coalesced into workgroup-sized bins) — groups run in parallel workgroups,
+//     each keeping its bodies in LDS for the whole solve.  The last group may be an "HBM group": whatever does
+//     not fit a workgroup (one huge island) is solved colour by colour out of HBM.
+// Static bodies (invMass == invInertia == 0, ref: Solver.cpp:304) never conflict; each group keeps a private
+// copy of their lastIteration tag.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace phx {
+
+struct Schedule {
+    std::vector<int> order;               // slot -> joint
+    std::vector<int> colour_offsets;      // ncolours + 1, over all groups
+    std::vector<int> group_offsets;       // ngroups + 1 (slots)
+    std::vector<int> group_first_colour;  // ngroups + 1 (indices into colour_offsets)
+    int lds_groups = 0;                   // leading groups solved out of LDS; the rest (0 or 1 group) out of HBM
+    // per LDS group g: its bodies = group_bodies[group_body_offsets[g] .. group_body_offsets[g+1])
+    std::vector<int> group_body_offsets;
+    std::vector<int> group_bodies;
+    std::vector<uint32_t> slot_local;     // per slot of an LDS group: local body1 | local body2 << 16
+    std::vector<uint8_t> slot_colour;     // per slot of an LDS group: colour index inside the group
+    int island_count = 1, island_max_size = 0;   // GatherIslands' published numbers (ref: Solver.h:105-106)
+    unsigned long long fingerprint = 0;
+    bool valid = false, islands = false;
+    int ngroups() const { return (int)group_offsets.size() - 1; }
+    int ncolours() const { return (int)colour_offsets.size() - 1; }
+};
+
+struct LdsCaps { int max_joints = 512, max_bodies = 768, max_colours = 64; };
+
+// One HBM group holding every joint: greedy first-fit colouring in joint-index order, stable inside a colour.
+void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out);
+
+// Island-aware schedule: connected components binned into LDS groups where they fit `caps`, the rest in one
+// trailing HBM group.
+void build_island_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
+                           const LdsCaps& caps, Schedule& out);
+
+// Solver::GatherIslands semantics (ref: Solver.cpp:285-454): per-joint coalesced island id (-1 for
+// static-static joints) and per-island joint counts.
+void gather_islands(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
+                    std::vector<int>& joint_island, std::vector<int>& island_size);
+
+} // namespace phx

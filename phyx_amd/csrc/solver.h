@@ -2,6 +2,7 @@
 #pragma once
 
 #include "common.h"
+#include "schedule.h"
 
 namespace phx {
 
@@ -18,34 +19,12 @@ struct SolverView {
     float2* acc;
     float2* dd;
     const int* order;      // slot -> joint index
-    const int2* crange;    // colour -> [begin, end) slots
     unsigned* sw_imp;      // static-body productive words, [2][nstatic] (see static_word())
     unsigned* sw_disp;
     int* imp_active;       // [iter] 1 if any joint was productive in sweep `iter`
     int* disp_active;
 };
 
-
-// Schedule = the order in which one sweep visits the joints, as colour classes of body-disjoint joints.
-// It plays the role of Solver::PrepareIndices (ref: Solver.cpp:217-273), which greedily packs runs of
-// N independent joints for N SIMD lanes; here a whole colour class is one "run" and the lanes are
-// wavefront lanes.  Static bodies are exempt from conflicts (they never move).
-struct Schedule {
-    std::vector<int> order;            // slot -> joint
-    std::vector<int> colour_offsets;   // ncolours + 1
-    int island_count = 1, island_max_size = 0;
-    unsigned long long fingerprint = 0;
-    bool valid = false;
-};
-
-// Greedy first-fit colouring in joint-index order; joints keep their relative order inside a colour.
-void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out);
-
-// Solver::GatherIslands semantics (ref: Solver.cpp:285-454): union-find over dynamic bodies, islands
-// numbered in body order, consecutive islands coalesced until >= 256 joints.  Returns per-joint island
-// id (-1 for static-static joints) and per-island joint counts.
-void gather_islands(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
-                    std::vector<int>& joint_island, std::vector<int>& island_size);
 
 class DeviceSolver {
 public:
@@ -58,6 +37,7 @@ public:
     int synchronize();
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
+    int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
               const phx_config& cfg, int warmup, int steps, phx_bench_result* out);
@@ -80,7 +60,7 @@ private:
     };
     int enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg);
     int enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj);
-    int enqueue_sweeps(int nj, int ci, int pi);
+    int enqueue_sweeps(const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi);
     int enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj);
     int capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
     void drop_graphs();
@@ -96,7 +76,11 @@ private:
     DevBuf<int4> q3_;
     DevBuf<float2> acc_, dd_;
     DevBuf<int> order_, static_slot_, flags_;
-    DevBuf<int2> crange_;
+    DevBuf<int4> grp_desc_;
+    DevBuf<int> grp_ncol_, grp_bodies_, isl_stats_;
+    DevBuf<unsigned> slot_local_;
+    DevBuf<unsigned char> slot_colour_;
+    DevBuf<unsigned long long> isl_visits_;
     DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;
     // staging for the host-pointer entry point

@@ -9,91 +9,6 @@
 namespace phx {
 
 // ---------------------------------------------------------------------------------------------------
-// schedule
-
-void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out)
-{
-    std::vector<int> colour(nj, 0);
-    int words = 1, ncolours = 0;
-    for (;;) {
-        // used[b * words + w] bit c%64 set <=> a joint of colour w*64+c already touches dynamic body b
-        std::vector<unsigned long long> used((size_t)nb * words, 0ull);
-        bool overflow = false;
-        ncolours = 0;
-        for (int j = 0; j < nj && !overflow; ++j) {
-            const int a = body1[j], b = body2[j];
-            const bool da = !is_static[a], db = !is_static[b];
-            int c = -1;
-            for (int w = 0; w < words; ++w) {
-                unsigned long long m = 0;
-                if (da) m |= used[(size_t)a * words + w];
-                if (db) m |= used[(size_t)b * words + w];
-                if (~m) { c = w * 64 + __builtin_ctzll(~m); break; }
-            }
-            if (c < 0) { overflow = true; break; }
-            colour[j] = c;
-            if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
-            if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
-            ncolours = std::max(ncolours, c + 1);
-        }
-        if (!overflow) break;
-        words *= 2;
-    }
-    out.colour_offsets.assign(ncolours + 1, 0);
-    for (int j = 0; j < nj; ++j) out.colour_offsets[colour[j] + 1]++;
-    for (int c = 0; c < ncolours; ++c) out.colour_offsets[c + 1] += out.colour_offsets[c];
-    out.order.resize(nj);
-    std::vector<int> cursor(out.colour_offsets.begin(), out.colour_offsets.end() - 1);
-    for (int j = 0; j < nj; ++j) out.order[cursor[colour[j]]++] = j;       // stable inside a colour
-}
-
-static int uf_find(std::vector<int>& t, int i)
-{
-    int r = i;
-    while (r != t[r]) r = t[r];
-    while (t[i] != r) { int n = t[i]; t[i] = r; i = n; }
-    return r;
-}
-
-void gather_islands(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
-                    std::vector<int>& joint_island, std::vector<int>& island_size)
-{
-    std::vector<int> root(nb);
-    for (int i = 0; i < nb; ++i) root[i] = is_static[i] ? -1 : i;
-    for (int j = 0; j < nj; ++j) {
-        const int a = body1[j], b = body2[j];
-        if (is_static[a] || is_static[b]) continue;
-        const int ra = uf_find(root, a), rb = uf_find(root, b);
-        root[ra] = rb;
-    }
-    std::vector<int> number(nb, -1);
-    int count = 0;
-    for (int i = 0; i < nb; ++i) {
-        if (root[i] < 0) continue;
-        const int r = uf_find(root, i);
-        if (number[r] < 0) number[r] = count++;
-    }
-    std::vector<int> raw_size(count, 0);
-    auto island_of = [&](int j) {
-        const int a = body1[j], b = body2[j];
-        if (is_static[a] && is_static[b]) return -1;
-        return number[uf_find(root, is_static[a] ? b : a)];
-    };
-    for (int j = 0; j < nj; ++j) { const int i = island_of(j); if (i >= 0) raw_size[i]++; }
-    // coalesce consecutive islands until >= kIslandMinSize joints (ref: Solver.cpp:382-413)
-    std::vector<int> merged(count, 0);
-    island_size.clear();
-    int run = 0;
-    for (int i = 0; i < count; ++i) {
-        run += raw_size[i];
-        merged[i] = (int)island_size.size();
-        if (run >= 256 || (run > 0 && i == count - 1)) { island_size.push_back(run); run = 0; }
-    }
-    joint_island.resize(nj);
-    for (int j = 0; j < nj; ++j) { const int i = island_of(j); joint_island[j] = i < 0 ? -1 : merged[i]; }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // small kernels private to this file
 
 __global__ void __launch_bounds__(256) k_extract_topology(const phx_contact_joint* __restrict__ joints, int nj,
@@ -116,7 +31,8 @@ DeviceSolver::~DeviceSolver()
     if (stream_) (void)hipStreamSynchronize(stream_);
     drop_graphs();
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
-    acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); crange_.release(); sw_.release();
+    acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
+    grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -134,6 +50,8 @@ int DeviceSolver::init()
     PHX_HIP(hipEventCreate(&ev_sweep_begin_));
     PHX_HIP(hipEventCreate(&ev_sweep_end_));
     PHX_TRY(hash_.reserve(1));
+    PHX_TRY(isl_stats_.reserve(2));
+    PHX_TRY(isl_visits_.reserve(1));
     const char* g = getenv("PHX_NO_GRAPHS");
     use_graphs_ = !(g && g[0] == '1');
     return PHX_OK;
@@ -142,10 +60,10 @@ int DeviceSolver::init()
 SolverView DeviceSolver::view() const
 {
     SolverView v{};
-    v.nb = nb_; v.nj = nj_; v.nstatic = std::max(nstatic_, 1); v.ncolours = (int)sched_.colour_offsets.size() - 1;
+    v.nb = nb_; v.nj = nj_; v.nstatic = std::max(nstatic_, 1); v.ncolours = sched_.ncolours();
     v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = sb_par_.p;
     v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p;
-    v.order = order_.p; v.crange = crange_.p;
+    v.order = order_.p;
     v.sw_imp = sw_.p; v.sw_disp = sw_.p + 2 * (size_t)v.nstatic;
     v.imp_active = flags_.p; v.disp_active = flags_.p + max_iters_;
     return v;
@@ -162,9 +80,12 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_HIP(hipStreamSynchronize(stream_));
     fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
     stats_.recoloured = 0;
-    if (sched_.valid && sched_.fingerprint == fp && nb == nb_ && nj == nj_) return PHX_OK;
+    // Single = one coupled system swept colour by colour out of HBM; every other island mode lets the schedule
+    // exploit body-disjoint islands (groups solved out of LDS)
+    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !(getenv("PHX_NO_ISLANDS") && getenv("PHX_NO_ISLANDS")[0] == '1');
+    if (sched_.valid && sched_.fingerprint == fp && nb == nb_ && nj == nj_ && sched_.islands == want_islands) return PHX_OK;
 
-    // 2. topology changed: pull the body pairs + static flags, colour on the host, push the schedule
+    // 2. topology changed: pull the body pairs + static flags, build the schedule on the host, push it
     DevBuf<int2> d_pairs;
     DevBuf<unsigned char> d_static;
     PHX_TRY(d_pairs.reserve(std::max(nj, 1)));
@@ -184,9 +105,14 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         b1[j] = pairs[j].x; b2[j] = pairs[j].y;
         if ((unsigned)b1[j] >= (unsigned)nb || (unsigned)b2[j] >= (unsigned)nb) { set_error("joint %d references body out of range", j); return PHX_ERR_INVALID; }
     }
-    build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
-    const int ncol = (int)sched_.colour_offsets.size() - 1;
-    if (ncol > 65000) { set_error("more than 65000 colours"); return PHX_ERR_INVALID; }
+    if (want_islands) {
+        LdsCaps caps;
+        caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
+        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_);
+    } else {
+        build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
+    }
+    if (sched_.ncolours() > 65000) { set_error("more than 65000 colours"); return PHX_ERR_INVALID; }
     {
         std::vector<int> joint_island, island_size;
         gather_islands(b1.data(), b2.data(), nj, is_static.data(), nb, joint_island, island_size);
@@ -200,23 +126,36 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     nb_ = nb; nj_ = nj;
     PHX_TRY(order_.reserve(std::max(nj, 1)));
     PHX_TRY(static_slot_.reserve(std::max(nb, 1)));
-    PHX_TRY(crange_.reserve(std::max(ncol, 1)));
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
     PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb)); PHX_TRY(sb_par_.reserve(nb));
     PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj));
     PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
-    std::vector<int2> ranges(std::max(ncol, 1));
-    for (int c = 0; c < ncol; ++c) ranges[c] = make_int2(sched_.colour_offsets[c], sched_.colour_offsets[c + 1]);
     if (nj) PHX_HIP(hipMemcpyAsync(order_.p, sched_.order.data(), (size_t)nj * sizeof(int), hipMemcpyHostToDevice, stream_));
     if (nb) PHX_HIP(hipMemcpyAsync(static_slot_.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
-    if (ncol) PHX_HIP(hipMemcpyAsync(crange_.p, ranges.data(), (size_t)ncol * sizeof(int2), hipMemcpyHostToDevice, stream_));
+    const int ng = sched_.lds_groups;
+    std::vector<int4> desc(std::max(ng, 1));
+    std::vector<int> ncol(std::max(ng, 1));
+    if (ng) {
+        for (int g = 0; g < ng; ++g) {
+            desc[g] = make_int4(sched_.group_offsets[g], sched_.group_offsets[g + 1] - sched_.group_offsets[g],
+                                sched_.group_body_offsets[g], sched_.group_body_offsets[g + 1] - sched_.group_body_offsets[g]);
+            ncol[g] = sched_.group_first_colour[g + 1] - sched_.group_first_colour[g];
+        }
+        const size_t lds_slots = (size_t)sched_.group_offsets[ng];
+        PHX_TRY(grp_desc_.reserve(ng)); PHX_TRY(grp_ncol_.reserve(ng));
+        PHX_TRY(grp_bodies_.reserve(sched_.group_bodies.size())); PHX_TRY(slot_local_.reserve(lds_slots)); PHX_TRY(slot_colour_.reserve(lds_slots));
+        PHX_HIP(hipMemcpyAsync(grp_desc_.p, desc.data(), (size_t)ng * sizeof(int4), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(grp_ncol_.p, ncol.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(grp_bodies_.p, sched_.group_bodies.data(), sched_.group_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(slot_local_.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(slot_colour_.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
+    }
     PHX_HIP(hipStreamSynchronize(stream_));
     sched_.fingerprint = fp;
     sched_.valid = true;
     ++schedule_version_;
     drop_graphs();
     stats_.recoloured = 1;
-    (void)cfg;
     return PHX_OK;
 }
 
@@ -229,34 +168,49 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     const SolverView v = view();
     PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
     PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)v.nstatic * sizeof(unsigned), stream_));
+    PHX_HIP(hipMemsetAsync(isl_stats_.p, 0, 2 * sizeof(int), stream_));
+    PHX_HIP(hipMemsetAsync(isl_visits_.p, 0, sizeof(unsigned long long), stream_));
     if (nb) hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, sb_imp_.p, sb_disp_.p, sb_par_.p);
-    if (nj) {
-        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints, d_cps, static_slot_.p);
-        for (int c = 0; c < v.ncolours; ++c) {
-            const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
-            hipLaunchKernelGGL(k_prestep, dim3(grid_for(n)), dim3(256), 0, stream_, v, c);
+    // the HBM group (if any): PrepareJoints + RefreshJoints over its slots, PreStep colour by colour
+    const int ng = sched_.ngroups(), lg = sched_.lds_groups;
+    if (nj && ng > lg) {
+        const int hb = sched_.group_offsets[lg], he = sched_.group_offsets[lg + 1];
+        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
+        for (int c = sched_.group_first_colour[lg]; c < sched_.group_first_colour[lg + 1]; ++c) {
+            const int cb = sched_.colour_offsets[c], ce = sched_.colour_offsets[c + 1];
+            hipLaunchKernelGGL(k_prestep, dim3(grid_for(ce - cb)), dim3(256), 0, stream_, v, cb, ce);
         }
     }
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
 
-int DeviceSolver::enqueue_sweeps(int nj, int ci, int pi)
+int DeviceSolver::enqueue_sweeps(const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi)
 {
     const SolverView v = view();
     const int iters = std::max(ci, pi);
     sweep_launches_ = 0;
     if (!nj) return PHX_OK;
-    for (int it = 0; it < iters; ++it) {
-        const bool imp = it < ci, disp = it < pi;
-        for (int c = 0; c < v.ncolours; ++c) {
-            const int n = sched_.colour_offsets[c + 1] - sched_.colour_offsets[c];
-            const dim3 g(std::max(1, std::min(div_up(n, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
-            const int cb = sched_.colour_offsets[c], ce = sched_.colour_offsets[c + 1];
-            if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, ce, c, it);
-            else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, ce, c, it);
-            else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, ce, c, it);
-            ++sweep_launches_;
+    const int ng = sched_.ngroups(), lg = sched_.lds_groups;
+    if (lg) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
+        IslandView iv{};
+        iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
+        iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
+        hipLaunchKernelGGL(k_solve_islands, dim3(lg), dim3(ISL_T), 0, stream_, v, iv, (const phx_contact_joint*)d_joints, d_cps, ci, pi);
+        ++sweep_launches_;
+    }
+    if (ng > lg) {
+        const int c0 = sched_.group_first_colour[lg], c1 = sched_.group_first_colour[lg + 1];
+        for (int it = 0; it < iters; ++it) {
+            const bool imp = it < ci, disp = it < pi;
+            for (int c = c0; c < c1; ++c) {
+                const int cb = sched_.colour_offsets[c], ce = sched_.colour_offsets[c + 1];
+                const dim3 g(std::max(1, std::min(div_up(ce - cb, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
+                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, ce, c - c0, it);
+                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, ce, c - c0, it);
+                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, ce, c - c0, it);
+                ++sweep_launches_;
+            }
         }
     }
     PHX_HIP(hipGetLastError());
@@ -287,7 +241,7 @@ int DeviceSolver::capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, 
         hipGraph_t graph = nullptr;
         PHX_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         int st = seg == 0 ? enqueue_pre(d_bodies, key.nb, d_cps, d_joints, key.nj)
-               : seg == 1 ? enqueue_sweeps(key.nj, key.ci, key.pi)
+               : seg == 1 ? enqueue_sweeps(d_cps, d_joints, key.nj, key.ci, key.pi)
                           : enqueue_post(d_bodies, key.nb, d_joints, key.nj);
         hipError_t e = hipStreamEndCapture(stream_, &graph);
         if (st != PHX_OK) { if (graph) (void)hipGraphDestroy(graph); drop_graphs(); return st; }
@@ -326,7 +280,7 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     else PHX_TRY(enqueue_pre(d_bodies, nb, d_cps, d_joints, nj));
     PHX_HIP(hipEventRecord(ev_sweep_begin_, stream_));
     if (replay) { if (graph_[1]) PHX_HIP(hipGraphLaunch(graph_[1], stream_)); sweep_launches_ = graph_sweep_launches_; }
-    else PHX_TRY(enqueue_sweeps(nj, ci, pi));
+    else PHX_TRY(enqueue_sweeps(d_cps, d_joints, nj, ci, pi));
     PHX_HIP(hipEventRecord(ev_sweep_end_, stream_));
     if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
     else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
@@ -351,8 +305,8 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     const bool split = cfg.island_mode == PHX_ISLAND_MULTIPLE || cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
     stats_.island_count = split ? sched_.island_count : 1;
     stats_.island_max_size = split ? sched_.island_max_size : nj;
-    stats_.colour_count = (int)sched_.colour_offsets.size() - 1;
-    stats_.lds_islands = 0;
+    stats_.colour_count = sched_.ncolours();
+    stats_.lds_islands = sched_.lds_groups;
     return enqueue(static_cast<phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_point*>(d_cps), static_cast<phx_contact_joint*>(d_joints), nj, cfg);
 }
 
@@ -380,15 +334,26 @@ int DeviceSolver::collect_stats()
 {
     if (!stats_pending_) return PHX_OK;
     std::vector<int> flags(2 * (size_t)max_iters_);
+    int isl[2] = {0, 0};
+    unsigned long long isl_visits = 0;
     PHX_HIP(hipMemcpyAsync(flags.data(), flags_.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipMemcpyAsync(isl, isl_stats_.p, sizeof isl, hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipMemcpyAsync(&isl_visits, isl_visits_.p, sizeof isl_visits, hipMemcpyDeviceToHost, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
     auto executed = [&](const int* active, int limit) {
         int n = 0;
         for (int k = 0; k < limit; ++k) { ++n; if (!active[k]) break; }     // ref: Solver.cpp:175-190
-        return nj_ ? n : std::min(limit, 1);
+        return n;
     };
-    stats_.impulse_iterations = executed(flags.data(), last_ci_);
-    stats_.displacement_iterations = executed(flags.data() + max_iters_, last_pi_);
+    const int lg = sched_.lds_groups;
+    const bool hbm = sched_.ngroups() > lg;
+    const int hbm_joints = hbm ? sched_.group_offsets[lg + 1] - sched_.group_offsets[lg] : 0;
+    const int h_imp = hbm_joints ? executed(flags.data(), last_ci_) : 0;
+    const int h_disp = hbm_joints ? executed(flags.data() + max_iters_, last_pi_) : 0;
+    // like the reference's per-island loops, report the longest-running island (ref: Solver.cpp:175-190 per island)
+    stats_.impulse_iterations = nj_ ? std::max(h_imp, isl[0]) : std::min(last_ci_, 1);
+    stats_.displacement_iterations = nj_ ? std::max(h_disp, isl[1]) : std::min(last_pi_, 1);
+    stats_.joint_visits = (long long)isl_visits + (long long)h_imp * hbm_joints;
     float ms = 0.f;
     PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
     stats_.device_ms = ms;
@@ -415,11 +380,23 @@ int DeviceSolver::get_stats(phx_solve_stats* out)
 int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours)
 {
     if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
-    const int ncol = (int)sched_.colour_offsets.size() - 1;
+    const int ncol = sched_.ncolours();
     if (ncolours) *ncolours = ncol;
     if ((order && order_cap < nj_) || (offsets && offsets_cap < ncol + 1)) { set_error("schedule buffers too small"); return PHX_ERR_CAPACITY; }
     if (order) std::copy(sched_.order.begin(), sched_.order.end(), order);
     if (offsets) std::copy(sched_.colour_offsets.begin(), sched_.colour_offsets.end(), offsets);
+    return PHX_OK;
+}
+
+int DeviceSolver::get_groups(int* offsets, int cap, int* count, int* lds_count)
+{
+    if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    if (count) *count = sched_.ngroups();
+    if (lds_count) *lds_count = sched_.lds_groups;
+    if (offsets) {
+        if (cap < (int)sched_.group_offsets.size()) { set_error("group_offsets too small"); return PHX_ERR_CAPACITY; }
+        std::copy(sched_.group_offsets.begin(), sched_.group_offsets.end(), offsets);
+    }
     return PHX_OK;
 }
 
@@ -471,7 +448,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
             out->impulse_kernel_ms += sweep_ms;
             out->impulse_launches += sweep_launches_;
             out->impulse_iterations += stats_.impulse_iterations;
-            out->joint_visits += (long long)stats_.impulse_iterations * nj;
+            out->joint_visits += stats_.joint_visits;
         }
     }
     return PHX_OK;

@@ -112,10 +112,10 @@ __device__ __forceinline__ Limiter refresh_limiter(float n1x, float n1y, float w
     return L;
 }
 
-__global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, const phx_contact_joint* __restrict__ joints,
+__global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int begin, int end, const phx_contact_joint* __restrict__ joints,
                                                       const phx_contact_point* __restrict__ cps, const int* __restrict__ static_slot)
 {
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < v.nj; s += gridDim.x * blockDim.x) {
+    for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
         const phx_contact_joint j = joints[v.order[s]];
         const phx_contact_point& cp = cps[j.contact_point_index];
         const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
@@ -148,10 +148,9 @@ __global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, const phx_co
 }
 
 // ---- PreStepJoints (ref: Solver.cpp:697-758), one colour ------------------------------------------
-__global__ void __launch_bounds__(256) k_prestep(SolverView v, int colour)
+__global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int end)
 {
-    const int2 r = v.crange[colour];
-    for (int s = r.x + blockIdx.x * blockDim.x + threadIdx.x; s < r.y; s += gridDim.x * blockDim.x) {
+    for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
         const float4 a = v.q0[s], b = v.q1[s], c = v.q2[s];
         const int4 k = v.q3[s];
         const float2 acc = v.acc[s];
@@ -275,6 +274,207 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
     // any(productive) of the sweep (ref: Solver.cpp:913, 1017): one store per wave that saw one
     if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
     if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
+}
+
+// ---- island kernel: one workgroup solves one GROUP of the schedule entirely out of LDS -----------------
+// (Refresh, PreStep and every impulse / displacement sweep of ref: Solver.cpp:130-215 SolveJointIsland.)
+// A lane owns one joint for the whole solve: its 16 refreshed constants and 3 accumulators live in registers,
+// the group's body velocities live in LDS, colours are separated by workgroup barriers instead of kernel
+// launches, and HBM is touched once on the way in and once on the way out.  The early exit of ref: Solver.cpp:189
+// / :210 is per group, exactly like the reference's per-island loop.
+constexpr int ISL_T = 512;     // lanes = joint capacity of a group
+constexpr int ISL_B = 768;     // body capacity of a group (dynamic + the static ones it touches)
+
+struct IslandView {
+    const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
+    const int* ncol;                  // per group: colours
+    const int* bodies;                // global body ids, group-local order
+    const unsigned* slot_local;       // per slot: local body1 | local body2 << 16
+    const unsigned char* slot_colour; // per slot: colour inside the group
+    int* executed;                    // [0] max impulse sweeps run by any group, [1] same for displacement
+    unsigned long long* visits;       // sum over groups of impulse sweeps * joints
+};
+
+__device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[ISL_B], int body, int iter, int colour)
+{
+    if (iter == 0) return true;
+    if ((sw[(iter - 1) & 1][body] >> 16) == (unsigned)iter) return true;
+    const unsigned cur = sw[iter & 1][body];
+    return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
+}
+
+__global__ void __launch_bounds__(ISL_T) k_solve_islands(SolverView v, IslandView iv, const phx_contact_joint* __restrict__ joints,
+                                                         const phx_contact_point* __restrict__ cps, int ci, int pi)
+{
+    __shared__ float4 imp[ISL_B];
+    __shared__ float4 disp[ISL_B];
+    __shared__ unsigned swi[2][ISL_B];
+    __shared__ unsigned swd[2][ISL_B];
+    __shared__ unsigned char is_st[ISL_B];
+    __shared__ int flag_imp[2], flag_disp[2];
+
+    const int4 d = iv.desc[blockIdx.x];
+    const int ncol = iv.ncol[blockIdx.x];
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < d.w; i += ISL_T) {
+        const int gb = iv.bodies[d.z + i];
+        const float4 par = v.sb_par[gb];
+        imp[i] = v.sb_imp[gb];
+        disp[i] = v.sb_disp[gb];
+        is_st[i] = (par.x == 0.f && par.y == 0.f) ? 1 : 0;
+        swi[0][i] = 0; swi[1][i] = 0; swd[0][i] = 0; swd[1][i] = 0;
+    }
+    if (tid < 2) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
+
+    const bool live = tid < d.y;
+    const int s = d.x + tid;
+    float nx = 0.f, ny = 0.f, aN1 = 0.f, aN2 = 0.f, aF1 = 0.f, aF2 = 0.f, cimN = 0.f, cimF = 0.f, dstV = 0.f, dstD = 0.f;
+    float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f, accN = 0.f, accF = 0.f, accD = 0.f;
+    int l1 = 0, l2 = 0, col = -1, gb1 = 0, gb2 = 0;
+    if (live) {
+        const phx_contact_joint j = joints[v.order[s]];
+        const phx_contact_point& cp = cps[j.contact_point_index];
+        const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
+        nx = cp.normal.x; ny = cp.normal.y;
+        gb1 = j.body1; gb2 = j.body2;
+        const float4 p1 = v.sb_par[gb1], p2 = v.sb_par[gb2];
+        // RefreshJoints (ref: Solver.cpp:642-693) — same expressions as k_pack_refresh
+        const float pt1x = d1x + p1.z, pt1y = d1y + p1.w;
+        const float pt2x = d2x + p2.z, pt2y = d2y + p2.w;
+        const float w2x = pt1x - p2.z, w2y = pt1y - p2.w;
+        const Limiter N = refresh_limiter(nx, ny, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
+        const Limiter F = refresh_limiter(-ny, nx, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
+        const float depth = (pt2x - pt1x) * nx + (pt2y - pt1y) * ny;
+        const float dst = 0.f;
+        dstV = depth < 1.f ? dst - 0.1f : dst;
+        dstD = 0.1f * max_ref(0.f, depth - 2.0f * 1.f);
+        aN1 = N.a1; aN2 = N.a2; cimN = N.cim; aF1 = F.a1; aF2 = F.a2; cimF = F.cim;
+        im1 = p1.x; ii1 = p1.y; im2 = p2.x; ii2 = p2.y;
+        accN = j.normal_accumulated_impulse; accF = j.friction_accumulated_impulse;
+        const unsigned loc = iv.slot_local[s];
+        l1 = (int)(loc & 0xFFFFu); l2 = (int)(loc >> 16);
+        col = iv.slot_colour[s];
+    }
+    const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
+    const float tx = -ny, ty = nx;
+    __syncthreads();
+
+    // PreStepJoints (ref: Solver.cpp:736-750), colour by colour
+    for (int c = 0; c < ncol; ++c) {
+        if (col == c) {
+            if (!st1) {
+                float4 B = imp[l1];
+                B.x += (nx * im1) * accN; B.y += (ny * im1) * accN; B.z += (aN1 * ii1) * accN;
+                B.x += (tx * im1) * accF; B.y += (ty * im1) * accF; B.z += (aF1 * ii1) * accF;
+                imp[l1] = B;
+            }
+            if (!st2) {
+                float4 B = imp[l2];
+                B.x += ((-nx) * im2) * accN; B.y += ((-ny) * im2) * accN; B.z += (aN2 * ii2) * accN;
+                B.x += ((-tx) * im2) * accF; B.y += ((-ty) * im2) * accF; B.z += (aF2 * ii2) * accF;
+                imp[l2] = B;
+            }
+        }
+        __syncthreads();
+    }
+
+    int done_imp = 0, done_disp = 0;
+    bool imp_alive = ci > 0, disp_alive = pi > 0;
+    const int iters = ci > pi ? ci : pi;
+    for (int it = 0; it < iters; ++it) {
+        const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
+        if (!imp_on && !disp_on) break;
+        if (tid == 0) { flag_imp[(it + 1) & 1] = 0; flag_disp[(it + 1) & 1] = 0; }   // read last at the end of sweep it-1
+        for (int c = 0; c < ncol; ++c) {
+            if (col == c) {
+                if (imp_on) {
+                    float4 B1 = imp[l1], B2 = imp[l2];
+                    const bool p1 = st1 ? static_productive_lds(swi, l1, it, c) : (__float_as_int(B1.w) > it - 2);
+                    const bool p2 = st2 ? static_productive_lds(swi, l2, it, c) : (__float_as_int(B2.w) > it - 2);
+                    if (p1 || p2) {
+                        float dv = dstV;
+                        dv -= nx * B1.x; dv -= ny * B1.y; dv -= aN1 * B1.z;
+                        dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= aN2 * B2.z;
+                        float dn = dv * cimN;
+                        dn = max_ref(dn, -accN);
+                        B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (aN1 * ii1) * dn;
+                        B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (aN2 * ii2) * dn;
+                        accN += dn;
+                        float fv = 0.f;
+                        fv -= tx * B1.x; fv -= ty * B1.y; fv -= aF1 * B1.z;
+                        fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= aF2 * B2.z;
+                        float df = fv * cimF;
+                        const float force = accF + df;
+                        const float limit = accN * 0.3f;
+                        const float signed_limit = force < 0.f ? -limit : limit;
+                        const float adjusted = signed_limit - accF;
+                        if (fabsf(force) > limit) df = adjusted;
+                        accF += df;
+                        B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (aF1 * ii1) * df;
+                        B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (aF2 * ii2) * df;
+                        if (max_ref(fabsf(dn), fabsf(df)) > 1e-4f) {
+                            B1.w = __int_as_float(it); B2.w = __int_as_float(it);
+                            flag_imp[it & 1] = 1;
+                            if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
+                            if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+                        }
+                        if (!st1) imp[l1] = B1;
+                        if (!st2) imp[l2] = B2;
+                    }
+                }
+                if (disp_on) {
+                    float4 D1 = disp[l1], D2 = disp[l2];
+                    const bool p1 = st1 ? static_productive_lds(swd, l1, it, c) : (__float_as_int(D1.w) > it - 2);
+                    const bool p2 = st2 ? static_productive_lds(swd, l2, it, c) : (__float_as_int(D2.w) > it - 2);
+                    if (p1 || p2) {
+                        float dv = dstD;
+                        dv -= nx * D1.x; dv -= ny * D1.y; dv -= aN1 * D1.z;
+                        dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= aN2 * D2.z;
+                        float di = dv * cimN;
+                        di = max_ref(di, -accD);
+                        D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (aN1 * ii1) * di;
+                        D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (aN2 * ii2) * di;
+                        accD += di;
+                        if (fabsf(di) > 1e-4f) {
+                            D1.w = __int_as_float(it); D2.w = __int_as_float(it);
+                            flag_disp[it & 1] = 1;
+                            if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
+                            if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
+                        }
+                        if (!st1) disp[l1] = D1;
+                        if (!st2) disp[l2] = D2;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[it & 1] != 0; }
+        if (disp_on) { done_disp = it + 1; disp_alive = flag_disp[it & 1] != 0; }
+        __syncthreads();
+    }
+
+    // results: joints' accumulators (FinishJoints reads them from acc[]), the refreshed constants (query API) and
+    // the dynamic bodies' velocities back to the HBM solver arrays (FinishBodies reads those)
+    if (live) {
+        v.acc[s] = make_float2(accN, accF);
+        v.dd[s] = make_float2(dstD, accD);
+        v.q0[s] = make_float4(nx, ny, aN1, aN2);
+        v.q1[s] = make_float4(aF1, aF2, cimF, dstV);
+        v.q2[s] = make_float4(cimN, im1, ii1, im2);
+        v.q3[s] = make_int4(__float_as_int(ii2), gb1, gb2, -1);
+    }
+    for (int i = tid; i < d.w; i += ISL_T) {
+        if (is_st[i]) continue;
+        const int gb = iv.bodies[d.z + i];
+        v.sb_imp[gb] = imp[i];
+        v.sb_disp[gb] = disp[i];
+    }
+    if (tid == 0) {
+        atomicMax(&iv.executed[0], done_imp);
+        atomicMax(&iv.executed[1], done_disp);
+        atomicAdd(iv.visits, (unsigned long long)done_imp * (unsigned long long)d.y);
+    }
 }
 
 // ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------

@@ -21,9 +21,10 @@ def _lockstep(oracle, scene, steps, cfg, check_every=1):
         pw.Update(1.0 / 60.0, cfg)
         ow.pre_solve(1.0 / 60.0)
         order, offs = pw.solver.schedule()
+        groups, _ = pw.solver.groups()
         b, cp, j = ow.bodies(), ow.contact_points(), ow.joints()           # live views into the oracle world
         assert len(order) == len(j)
-        oracle.solver_solve_ordered(b, cp, j, order, offs, cfg.contactIterationsCount, cfg.penetrationIterationsCount,
+        oracle.solver_solve_grouped(b, cp, j, order, offs, groups, cfg.contactIterationsCount, cfg.penetrationIterationsCount,
                                     oracle.STAG_COLOUR_SYNC)
         ow.integrate_position(1.0 / 60.0)
         if step % check_every == 0 or step == steps - 1:
@@ -38,10 +39,11 @@ def _lockstep(oracle, scene, steps, cfg, check_every=1):
 
 
 @pytest.mark.parametrize("name,steps", [("stack", 12), ("tilted", 60), ("falling", 50)])
-def test_world_lockstep_bit_exact(oracle, built_lib, name, steps):
+@pytest.mark.parametrize("island_mode", [0, 3])
+def test_world_lockstep_bit_exact(oracle, built_lib, name, steps, island_mode):
     scene = {"stack": lambda: scenes.stack(6, 40), "tilted": lambda: scenes.tilted(80),
              "falling": lambda: scenes.falling(500, width=80.0, ymax=300.0)}[name]()
-    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_SINGLE, 15, 15)
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, island_mode, 15, 15)
     pw, ow = _lockstep(oracle, scene, steps, cfg)
     assert len(ow.joints()) > 0
 
