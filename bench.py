@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--scene-steps", type=int, default=3, help="world steps run before the solver input is captured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed Single-mode comparison run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one rank")
     ap.add_argument("--backend", default="nccl")
@@ -70,46 +71,69 @@ def main():
     solver = phyx_amd.Solver(device)
     d_bodies, d_cps, d_joints = (phyx_amd.DeviceArray(a, device) for a in (bodies, cps, joints))
 
-    # ---- warmup (untimed): builds the schedule, touches every buffer
-    for _ in range(max(args.warmup, 1)):
-        solver.bench(d_bodies, d_cps, d_joints, cfg, 0, 1)
-        group.step_barrier()
+    def run(config, warmup, steps):
+        """`steps` timed solves of the resident input under `config`; returns wall seconds + HIP-event totals."""
+        for _ in range(max(warmup, 1)):                               # untimed: builds the schedule, captures graphs
+            solver.bench(d_bodies, d_cps, d_joints, config, 0, 1)
+            group.step_barrier()
+        group.barrier()
+        solver.synchronize()
+        t0 = time.perf_counter()
+        tot = dict(total_ms=0.0, sweep_ms=0.0, launches=0, visits=0, iterations=0)
+        for _ in range(steps):
+            r = solver.bench(d_bodies, d_cps, d_joints, config, 0, 1)   # restore input + one full SolveJoints, synchronised
+            group.step_barrier()                                        # per-step RCCL barrier (no-op at N=1)
+            tot["total_ms"] += r.total_ms; tot["sweep_ms"] += r.impulse_kernel_ms; tot["launches"] += r.impulse_launches
+            tot["visits"] += r.joint_visits; tot["iterations"] += r.impulse_iterations
+        solver.synchronize()
+        group.barrier()
+        tot["elapsed"] = time.perf_counter() - t0
+        tot["stats"] = solver.stats()
+        return tot
 
-    # ---- timed region: exactly K steps, barrier + device sync on both sides
-    group.barrier()
-    solver.synchronize()
-    t0 = time.perf_counter()
-    tot = dict(total_ms=0.0, sweep_ms=0.0, launches=0, visits=0, iterations=0)
-    for _ in range(args.steps):
-        r = solver.bench(d_bodies, d_cps, d_joints, cfg, 0, 1)       # restore input + one full SolveJoints, synchronised
-        group.step_barrier()                                          # per-step RCCL barrier (no-op at N=1)
-        tot["total_ms"] += r.total_ms; tot["sweep_ms"] += r.impulse_kernel_ms; tot["launches"] += r.impulse_launches
-        tot["visits"] += r.joint_visits; tot["iterations"] += r.impulse_iterations
-    solver.synchronize()
-    group.barrier()
-    elapsed = time.perf_counter() - t0
-
-    st = solver.stats()
-    elapsed_max = group.reduce_max(elapsed)
-    visits_all = group.reduce_sum(tot["visits"])
-    iters_all = group.reduce_sum(tot["iterations"])
-    joints_all = group.reduce_sum(nj)
-    bodies_all = group.reduce_sum(nb)
-
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed_max / max(args.steps, 1)
-        # roofline of the dominant kernel (k_solve_colour<imp,disp>): algorithmic bytes / HIP-event time of the sweeps
-        disp_visits = st.displacement_iterations * nj * args.steps
+    def roofline(tot, steps, kernel):
+        st = tot["stats"]
+        disp_visits = st.displacement_iterations * nj * steps           # upper bound: every group runs the longest count
         alg_bytes = BYTES_IMPULSE_VISIT * tot["visits"] + BYTES_DISPLACEMENT_VISIT * disp_visits
         sweep_s = tot["sweep_ms"] * 1e-3
         achieved = alg_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
-        traffic = None
+        return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches": tot["launches"], "avg_launch_us": 1e3 * tot["sweep_ms"] / max(tot["launches"], 1),
+                "algorithmic_bytes_per_launch": alg_bytes / max(tot["launches"], 1)}
+
+    # ---- timed region: exactly K steps of config 2, barrier + device sync on both sides (inside run())
+    main_tot = run(cfg, args.warmup, args.steps)
+    st = main_tot["stats"]
+    elapsed_max = group.reduce_max(main_tot["elapsed"])
+    visits_all = group.reduce_sum(main_tot["visits"])
+    iters_all = group.reduce_sum(main_tot["iterations"])
+    joints_all = group.reduce_sum(nj)
+    bodies_all = group.reduce_sum(nb)
+
+    # ---- secondary (N=1 only, untimed by the driver): strict Single island mode = the HBM colour path
+    single_tot = None
+    if world == 1 and not args.no_secondary:
+        single_cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE, args.iters, args.iters)
+        single_tot = run(single_cfg, 2, max(5, args.steps // 2))
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed_max / max(args.steps, 1)
+        lds = st.lds_islands > 0
+        roof = roofline(main_tot, args.steps, "k_solve_islands (one workgroup per island, all sweeps in LDS)" if lds
+                        else "k_solve_colour<impulse,displacement>")
+        roof["note"] = ("achieved = ALGORITHMIC bytes (196 B per impulse joint-visit + 136 B per displacement joint-visit, SURVEY.md §8d) "
+                        "over the HIP-event time of the sweep launches. " +
+                        ("The island kernel keeps body state in LDS and joint constants in registers for all sweeps, so its real HBM "
+                         "traffic (`traffic`, PMC) is a small fraction of the algorithmic bytes and `frac` can exceed 1: the kernel is "
+                         "bound by LDS latency + workgroup barriers, not by HBM. The HBM-streaming form of the same sweeps is "
+                         "`extra.single_mode.roofline`." if lds else ""))
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "solver joint-visits/s (contacts/sec) on the 200k-box stack scene; solver iterations/s in extra",
             "value": visits_all / elapsed_max,
@@ -121,22 +145,25 @@ def main():
             "config": {"workload": "cfg2: stack(%d,%d) per GPU = %d bodies / %d joints per GPU, Single Sloppy islands, %d+%d iterations, "
                                    "full SolveJoints per step on HBM-resident inputs" % (args.columns, args.rows, nb, nj, args.iters, args.iters),
                        "bodies_total": int(bodies_all), "joints_total": int(joints_all), "colours": st.colour_count,
+                       "lds_islands": st.lds_islands, "graph_replay": st.graph_replay,
                        "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,
                        "parallelism": "islands sharded by column slab, 1 rank per GPU, per-step 4-byte RCCL all-reduce" if world > 1 else "1 GPU",
                        "device": info["name"], "compute_units": info["compute_units"]},
             "extra": {"solver_iterations_per_sec": iters_all / world / elapsed_max,
                       "contacts_resolved_per_sec": joints_all * args.steps / elapsed_max,
-                      "device_ms_per_step": tot["total_ms"] / max(args.steps, 1),
-                      "sweep_ms_per_step": tot["sweep_ms"] / max(args.steps, 1),
-                      "joint_visits_per_sec_sweeps_only": tot["visits"] / sweep_s if sweep_s > 0 else None},
-            "roofline": {"bound": "hbm", "kernel": "k_solve_colour<impulse,displacement>",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "launches": tot["launches"], "avg_launch_us": 1e3 * tot["sweep_ms"] / max(tot["launches"], 1),
-                         "algorithmic_bytes_per_launch": alg_bytes / max(tot["launches"], 1),
-                         "note": "196 B per impulse joint-visit + 136 B per displacement joint-visit (SURVEY.md §8d) over the HIP-event "
-                                 "time of all sweep launches (inter-launch gaps and early-out launches included)"},
+                      "device_ms_per_step": main_tot["total_ms"] / max(args.steps, 1),
+                      "sweep_ms_per_step": main_tot["sweep_ms"] / max(args.steps, 1),
+                      "joint_visits_per_sec_sweeps_only": main_tot["visits"] / (main_tot["sweep_ms"] * 1e-3) if main_tot["sweep_ms"] > 0 else None},
+            "roofline": roof,
         }
+        if single_tot is not None:
+            k = max(5, args.steps // 2)
+            sst = single_tot["stats"]
+            out["extra"]["single_mode"] = {
+                "what": "same input, island_mode = Single (no island split): colour-by-colour sweeps out of HBM",
+                "ms_per_step": 1e3 * single_tot["elapsed"] / k, "joint_visits_per_sec": single_tot["visits"] / single_tot["elapsed"],
+                "colours": sst.colour_count, "impulse_sweeps_per_step": sst.impulse_iterations,
+                "roofline": roofline(single_tot, k, "k_solve_colour<impulse,displacement>")}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bodies, cps, joints, args.iters, args.cpu_seconds)
         print(json.dumps(out))

@@ -406,6 +406,10 @@ int DeviceSolver::get_refreshed(int joint, float out[30])
     PHX_REQUIRE(joint >= 0 && joint < nj_ && out, "joint index out of range");
     PHX_TRY(synchronize());
     const int slot = (int)(std::find(sched_.order.begin(), sched_.order.end(), joint) - sched_.order.begin());
+    if (sched_.lds_groups && slot < sched_.group_offsets[sched_.lds_groups]) {
+        set_error("joint %d was solved by the island kernel, whose refreshed constants live only in registers; query it under island mode Single", joint);
+        return PHX_ERR_STATE;
+    }
     float4 a, f, c; int4 k; float2 acc, d;
     PHX_HIP(hipMemcpy(&a, q0_.p + slot, sizeof a, hipMemcpyDeviceToHost));
     PHX_HIP(hipMemcpy(&f, q1_.p + slot, sizeof f, hipMemcpyDeviceToHost));

@@ -303,7 +303,7 @@ __device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[ISL_B
     return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
 }
 
-__global__ void __launch_bounds__(ISL_T) k_solve_islands(SolverView v, IslandView iv, const phx_contact_joint* __restrict__ joints,
+__global__ void __launch_bounds__(ISL_T, 8) k_solve_islands(SolverView v, IslandView iv, const phx_contact_joint* __restrict__ joints,
                                                          const phx_contact_point* __restrict__ cps, int ci, int pi)
 {
     __shared__ float4 imp[ISL_B];
@@ -331,14 +331,13 @@ __global__ void __launch_bounds__(ISL_T) k_solve_islands(SolverView v, IslandVie
     const int s = d.x + tid;
     float nx = 0.f, ny = 0.f, aN1 = 0.f, aN2 = 0.f, aF1 = 0.f, aF2 = 0.f, cimN = 0.f, cimF = 0.f, dstV = 0.f, dstD = 0.f;
     float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f, accN = 0.f, accF = 0.f, accD = 0.f;
-    int l1 = 0, l2 = 0, col = -1, gb1 = 0, gb2 = 0;
+    int l1 = 0, l2 = 0, col = -1;
     if (live) {
         const phx_contact_joint j = joints[v.order[s]];
         const phx_contact_point& cp = cps[j.contact_point_index];
         const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
         nx = cp.normal.x; ny = cp.normal.y;
-        gb1 = j.body1; gb2 = j.body2;
-        const float4 p1 = v.sb_par[gb1], p2 = v.sb_par[gb2];
+        const float4 p1 = v.sb_par[j.body1], p2 = v.sb_par[j.body2];
         // RefreshJoints (ref: Solver.cpp:642-693) — same expressions as k_pack_refresh
         const float pt1x = d1x + p1.z, pt1y = d1y + p1.w;
         const float pt2x = d2x + p2.z, pt2y = d2y + p2.w;
@@ -454,15 +453,11 @@ __global__ void __launch_bounds__(ISL_T) k_solve_islands(SolverView v, IslandVie
         __syncthreads();
     }
 
-    // results: joints' accumulators (FinishJoints reads them from acc[]), the refreshed constants (query API) and
-    // the dynamic bodies' velocities back to the HBM solver arrays (FinishBodies reads those)
+    // results: joints' accumulators (FinishJoints reads them from acc[]) and the dynamic bodies' velocities back to
+    // the HBM solver arrays (FinishBodies reads those); the refreshed constants never leave the registers
     if (live) {
         v.acc[s] = make_float2(accN, accF);
         v.dd[s] = make_float2(dstD, accD);
-        v.q0[s] = make_float4(nx, ny, aN1, aN2);
-        v.q1[s] = make_float4(aF1, aF2, cimF, dstV);
-        v.q2[s] = make_float4(cimN, im1, ii1, im2);
-        v.q3[s] = make_int4(__float_as_int(ii2), gb1, gb2, -1);
     }
     for (int i = tid; i < d.w; i += ISL_T) {
         if (is_st[i]) continue;
