@@ -1,0 +1,72 @@
+"""The N>1 plumbing of bench.py on CPU: two processes over gloo (the GPU box only ever runs world_size 1 here;
+the 8-GPU run belongs to the driver).  Covers rendezvous on 127.0.0.1, the per-step barrier, max/sum reductions
+and the slab partition each rank derives for itself."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    from phyx_amd import dist as pdist
+    g = pdist.init(2, backend="gloo")
+    first, n = pdist.shard_columns(2001, g.rank, g.world_size)
+    g.barrier()
+    flags = [g.step_barrier() for _ in range(3)]           # the per-step 4-byte all-reduce
+    t = g.reduce_max(1.0 + g.rank)                          # max over ranks (timing)
+    units = g.reduce_sum(float(n))                          # whole-job units
+    print(json.dumps({"rank": g.rank, "world": g.world_size, "first": first, "n": n, "t": t, "units": units, "flags": flags}))
+    g.shutdown()
+""") % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(180)
+def test_two_ranks_over_gloo():
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=150)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert [o["world"] for o in outs] == [2, 2]
+    assert (outs[0]["first"], outs[0]["n"]) == (0, 1001) and (outs[1]["first"], outs[1]["n"]) == (1001, 1000)
+    assert all(o["t"] == 2.0 and o["units"] == 2001.0 and o["flags"] == [0, 0, 0] for o in outs)
+
+
+def test_shard_columns_partition():
+    from phyx_amd.dist import shard_columns
+    for total in (1, 7, 8, 1000, 8003):
+        for ws in (1, 2, 3, 8):
+            parts = [shard_columns(total, r, ws) for r in range(ws)]
+            assert sum(n for _, n in parts) == total
+            nxt = 0
+            for first, n in parts:
+                assert first == nxt and n >= total // ws
+                nxt = first + n
+
+
+def test_single_process_group_is_torch_free():
+    code = "import sys; sys.path.insert(0, %r); from phyx_amd import dist; g = dist.init(1); g.barrier(); g.step_barrier(); assert g.reduce_sum(3) == 3.0; assert 'torch' not in sys.modules" % ROOT
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    subprocess.check_call([sys.executable, "-c", code], env=env)
