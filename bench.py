@@ -80,9 +80,11 @@ def main():
         solver.synchronize()
         t0 = time.perf_counter()
         tot = dict(total_ms=0.0, sweep_ms=0.0, launches=0, visits=0, iterations=0)
-        for _ in range(steps):
-            r = solver.bench(d_bodies, d_cps, d_joints, config, 0, 1)   # restore input + one full SolveJoints, synchronised
-            group.step_barrier()                                        # per-step RCCL barrier (no-op at N=1)
+        # each step: restore the input, one full SolveJoints, synchronise, then the per-step RCCL barrier.  With one
+        # rank there is no barrier, so the K steps run back to back inside one library call.
+        for _ in range(1 if world == 1 else steps):
+            r = solver.bench(d_bodies, d_cps, d_joints, config, 0, steps if world == 1 else 1)
+            group.step_barrier()
             tot["total_ms"] += r.total_ms; tot["sweep_ms"] += r.impulse_kernel_ms; tot["launches"] += r.impulse_launches
             tot["visits"] += r.joint_visits; tot["iterations"] += r.impulse_iterations
         solver.synchronize()

@@ -29,6 +29,7 @@ struct Schedule {
     std::vector<int> group_bodies;
     std::vector<uint32_t> slot_local;     // per slot of an LDS group: local body1 | local body2 << 16
     std::vector<uint8_t> slot_colour;     // per slot of an LDS group: colour index inside the group
+    std::vector<int> hbm_bodies;          // bodies touched by the HBM group (the only ones it stages / writes back)
     int island_count = 1, island_max_size = 0;   // GatherIslands' published numbers (ref: Solver.h:105-106)
     unsigned long long fingerprint = 0;
     bool valid = false, islands = false;
@@ -36,7 +37,9 @@ struct Schedule {
     int ncolours() const { return (int)colour_offsets.size() - 1; }
 };
 
-struct LdsCaps { int max_joints = 512, max_bodies = 768, max_colours = 64; };
+struct LdsCaps { int max_joints = 512, max_bodies = 768, max_colours = 64, max_static = 1 << 30; };
+// (an LDS group's local body table lists its static bodies first, so a static body's local index is also its
+//  slot in the group's small static-tag table)
 
 // One HBM group holding every joint: greedy first-fit colouring in joint-index order, stable inside a colour.
 void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out);

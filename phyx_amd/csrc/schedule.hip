@@ -70,6 +70,10 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
     if (nj) append_group(out, all, colour, ncol);
     out.lds_groups = 0;
     out.islands = false;
+    std::vector<unsigned char> seen(nb, 0);
+    for (int j = 0; j < nj; ++j)
+        for (int b : {body1[j], body2[j]})
+            if (!seen[b]) { seen[b] = 1; out.hbm_bodies.push_back(b); }
 }
 
 static int uf_find(std::vector<int>& t, int i)
@@ -156,12 +160,15 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         if (bin.empty()) return;
         std::sort(bin.begin(), bin.end());       // joint-index order inside the bin
         // local body table
-        std::vector<int> bodies;
+        std::vector<int> bodies, dynamic;
         for (int j : bin)
             for (int b : {body1[j], body2[j]})
-                if (stamp[b] != bin_id) { stamp[b] = bin_id; local[b] = (int)bodies.size(); bodies.push_back(b); }
+                if (stamp[b] != bin_id) { stamp[b] = bin_id; (is_static[b] ? bodies : dynamic).push_back(b); }
+        const int nstatic = (int)bodies.size();
+        bodies.insert(bodies.end(), dynamic.begin(), dynamic.end());      // static bodies first
+        for (size_t i = 0; i < bodies.size(); ++i) local[bodies[i]] = (int)i;
         const int ncol = colour_joints(bin, body1, body2, is_static, nb, colour);
-        if ((int)bodies.size() > caps.max_bodies || ncol > caps.max_colours || (int)bodies.size() > 65535) {
+        if ((int)bodies.size() > caps.max_bodies || ncol > caps.max_colours || (int)bodies.size() > 65535 || nstatic > caps.max_static) {
             rest.insert(rest.end(), bin.begin(), bin.end());
         } else {
             const int base = (int)out.order.size();
@@ -200,6 +207,10 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         std::sort(rest.begin(), rest.end());
         const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour);
         append_group(out, rest, colour, ncol);
+        std::vector<unsigned char> seen(nb, 0);
+        for (int j : rest)
+            for (int b : {body1[j], body2[j]})
+                if (!seen[b]) { seen[b] = 1; out.hbm_bodies.push_back(b); }
     }
 }
 

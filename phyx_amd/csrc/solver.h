@@ -60,7 +60,7 @@ private:
     };
     int enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg);
     int enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj);
-    int enqueue_sweeps(const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi);
+    int enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi);
     int enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj);
     int capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
     void drop_graphs();
@@ -77,7 +77,9 @@ private:
     DevBuf<float2> acc_, dd_;
     DevBuf<int> order_, static_slot_, flags_;
     DevBuf<int4> grp_desc_;
-    DevBuf<int> grp_ncol_, grp_bodies_, isl_stats_;
+    DevBuf<int2> grp_colours_;
+    DevBuf<int> colour_offsets_;
+    DevBuf<int> grp_ncol_, grp_bodies_, isl_stats_, hbm_body_list_;
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;
     DevBuf<unsigned long long> isl_visits_;
@@ -101,7 +103,7 @@ private:
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
-    bool use_graphs_ = true;
+    bool use_graphs_ = true, wave_islands_ = false;
 };
 
 } // namespace phx

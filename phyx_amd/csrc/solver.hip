@@ -32,7 +32,7 @@ DeviceSolver::~DeviceSolver()
     drop_graphs();
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
-    grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
+    hbm_body_list_.release(); grp_colours_.release(); colour_offsets_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -54,6 +54,8 @@ int DeviceSolver::init()
     PHX_TRY(isl_visits_.reserve(1));
     const char* g = getenv("PHX_NO_GRAPHS");
     use_graphs_ = !(g && g[0] == '1');
+    const char* wv = getenv("PHX_ISLAND_KERNEL");      // "wave" = one wavefront per island (measured 5x slower: a lone wave exposes every instruction latency); default = one 512-lane workgroup per island
+    wave_islands_ = (wv && wv[0] == 'w');
     return PHX_OK;
 }
 
@@ -107,7 +109,8 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     }
     if (want_islands) {
         LdsCaps caps;
-        caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
+        if (wave_islands_) { caps.max_joints = ISW_J; caps.max_bodies = ISW_B; caps.max_colours = 4096; caps.max_static = ISW_S; }
+        else { caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64; }
         build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_);
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
@@ -146,10 +149,18 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         PHX_TRY(grp_bodies_.reserve(sched_.group_bodies.size())); PHX_TRY(slot_local_.reserve(lds_slots)); PHX_TRY(slot_colour_.reserve(lds_slots));
         PHX_HIP(hipMemcpyAsync(grp_desc_.p, desc.data(), (size_t)ng * sizeof(int4), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(grp_ncol_.p, ncol.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
+        std::vector<int2> gcol(ng);
+        for (int g = 0; g < ng; ++g) gcol[g] = make_int2(sched_.group_first_colour[g], ncol[g]);
+        PHX_TRY(grp_colours_.reserve(ng)); PHX_TRY(colour_offsets_.reserve(sched_.colour_offsets.size()));
+        PHX_HIP(hipMemcpyAsync(grp_colours_.p, gcol.data(), (size_t)ng * sizeof(int2), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(colour_offsets_.p, sched_.colour_offsets.data(), sched_.colour_offsets.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(grp_bodies_.p, sched_.group_bodies.data(), sched_.group_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_local_.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_colour_.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
     }
+    PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sched_.hbm_bodies.size(), 1)));
+    if (!sched_.hbm_bodies.empty())
+        PHX_HIP(hipMemcpyAsync(hbm_body_list_.p, sched_.hbm_bodies.data(), sched_.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
     sched_.fingerprint = fp;
     sched_.valid = true;
@@ -170,10 +181,13 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)v.nstatic * sizeof(unsigned), stream_));
     PHX_HIP(hipMemsetAsync(isl_stats_.p, 0, 2 * sizeof(int), stream_));
     PHX_HIP(hipMemsetAsync(isl_visits_.p, 0, sizeof(unsigned long long), stream_));
-    if (nb) hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, sb_imp_.p, sb_disp_.p, sb_par_.p);
-    // the HBM group (if any): PrepareJoints + RefreshJoints over its slots, PreStep colour by colour
+    // the HBM group (if any): PrepareBodies for the bodies it touches, PrepareJoints + RefreshJoints over its slots,
+    // PreStep colour by colour.  Groups solved in LDS read and write the caller's records directly.
     const int ng = sched_.ngroups(), lg = sched_.lds_groups;
+    const int hbm_bodies = (int)sched_.hbm_bodies.size();
     if (nj && ng > lg) {
+        hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies, (const int*)hbm_body_list_.p,
+                           hbm_bodies, sb_imp_.p, sb_disp_.p, sb_par_.p);
         const int hb = sched_.group_offsets[lg], he = sched_.group_offsets[lg + 1];
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
         for (int c = sched_.group_first_colour[lg]; c < sched_.group_first_colour[lg + 1]; ++c) {
@@ -185,7 +199,7 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     return PHX_OK;
 }
 
-int DeviceSolver::enqueue_sweeps(const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi)
+int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi)
 {
     const SolverView v = view();
     const int iters = std::max(ci, pi);
@@ -196,7 +210,14 @@ int DeviceSolver::enqueue_sweeps(const phx_contact_point* d_cps, phx_contact_joi
         IslandView iv{};
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
-        hipLaunchKernelGGL(k_solve_islands, dim3(lg), dim3(ISL_T), 0, stream_, v, iv, (const phx_contact_joint*)d_joints, d_cps, ci, pi);
+        if (wave_islands_) {
+            IslandWaveView wv{};
+            wv.desc = grp_desc_.p; wv.colours = grp_colours_.p; wv.colour_offsets = colour_offsets_.p; wv.bodies = grp_bodies_.p;
+            wv.slot_local = slot_local_.p; wv.executed = isl_stats_.p; wv.visits = isl_visits_.p;
+            hipLaunchKernelGGL(k_solve_islands_wave, dim3(lg), dim3(64), 0, stream_, v, wv, d_bodies, d_joints, d_cps, ci, pi);
+        } else {
+            hipLaunchKernelGGL(k_solve_islands, dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        }
         ++sweep_launches_;
     }
     if (ng > lg) {
@@ -220,8 +241,14 @@ int DeviceSolver::enqueue_sweeps(const phx_contact_point* d_cps, phx_contact_joi
 int DeviceSolver::enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
-    if (nj) hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(nj)), dim3(256), 0, stream_, v, d_joints);
-    if (nb) hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, v, d_bodies);
+    const int ng = sched_.ngroups(), lg = sched_.lds_groups;
+    if (nj && ng > lg) {      // only the HBM group has results parked in the solver arrays
+        const int hb = sched_.group_offsets[lg], he = sched_.group_offsets[lg + 1];
+        const int hbm_bodies = (int)sched_.hbm_bodies.size();
+        hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints);
+        hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, v, (const int*)hbm_body_list_.p, hbm_bodies, d_bodies);
+    }
+    (void)nb;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -241,7 +268,7 @@ int DeviceSolver::capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, 
         hipGraph_t graph = nullptr;
         PHX_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         int st = seg == 0 ? enqueue_pre(d_bodies, key.nb, d_cps, d_joints, key.nj)
-               : seg == 1 ? enqueue_sweeps(d_cps, d_joints, key.nj, key.ci, key.pi)
+               : seg == 1 ? enqueue_sweeps(d_bodies, d_cps, d_joints, key.nj, key.ci, key.pi)
                           : enqueue_post(d_bodies, key.nb, d_joints, key.nj);
         hipError_t e = hipStreamEndCapture(stream_, &graph);
         if (st != PHX_OK) { if (graph) (void)hipGraphDestroy(graph); drop_graphs(); return st; }
@@ -280,7 +307,7 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     else PHX_TRY(enqueue_pre(d_bodies, nb, d_cps, d_joints, nj));
     PHX_HIP(hipEventRecord(ev_sweep_begin_, stream_));
     if (replay) { if (graph_[1]) PHX_HIP(hipGraphLaunch(graph_[1], stream_)); sweep_launches_ = graph_sweep_launches_; }
-    else PHX_TRY(enqueue_sweeps(d_cps, d_joints, nj, ci, pi));
+    else PHX_TRY(enqueue_sweeps(d_bodies, d_cps, d_joints, nj, ci, pi));
     PHX_HIP(hipEventRecord(ev_sweep_end_, stream_));
     if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
     else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
