@@ -22,6 +22,7 @@ public:
 
 private:
     int resize_table(unsigned want_cap);
+    int exclusive_scan(unsigned* data, int count, unsigned* total_out);
 
     int device_;
     hipStream_t stream_ = nullptr;
@@ -29,7 +30,8 @@ private:
     DevBuf<unsigned> keys_[2], idx_[2], hist_, row_count_;
     DevBuf<float4> entries_;
     DevBuf<unsigned long long> table_, small_;
-    DevBuf<int> hub_rows_;
+    DevBuf<int4> chunks_;
+    DevBuf<unsigned> chunk_count_, scan_tiles_;
     DevBuf<uint2> new_pairs_, scratch_pairs_;
     DevBuf<phx_rigid_body> st_bodies_;
     unsigned table_cap_ = 0;

@@ -63,25 +63,70 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const unsigned* __res
     hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive prefix sum of `count` words in place, one workgroup of 1024 lanes
-__global__ void __launch_bounds__(1024) k_exclusive_scan(unsigned* __restrict__ data, int count, unsigned* __restrict__ total_out)
+// ---- exclusive prefix sum over `count` words, in place: three small launches ---------------------------
+//   k_scan_tiles   each 1024-lane workgroup scans a 4096-word tile in LDS and records the tile total
+//   k_scan_totals  one workgroup scans the (<= 4096) tile totals
+//   k_scan_add     adds each tile's base
+constexpr int SCAN_TILE = 4096;
+
+__device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsigned* lds, unsigned* total)
 {
-    __shared__ unsigned partial[1024];
-    const int seg = (count + 1023) / 1024;
-    const int b = threadIdx.x * seg, e = min(b + seg, count);
-    unsigned sum = 0;
-    for (int i = b; i < e; ++i) sum += data[i];
-    partial[threadIdx.x] = sum;
+    // wave-level inclusive scan, then a 16-entry scan of the wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned x = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) lds[wave] = x;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
-        unsigned v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+    if (wave == 0) {
+        unsigned t = lane < 16 ? lds[lane] : 0u;
+        for (int off = 1; off < 16; off <<= 1) { const unsigned y = __shfl_up(t, off); if (lane >= off) t += y; }
+        if (lane < 16) lds[lane] = t;            // inclusive totals of waves 0..lane
+    }
+    __syncthreads();
+    const unsigned before = wave ? lds[wave - 1] : 0u;
+    if (total) *total = lds[15];
+    return before + x - v;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tiles(unsigned* __restrict__ data, int count, unsigned* __restrict__ tile_total)
+{
+    __shared__ unsigned lds[16];
+    __shared__ unsigned tot;
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    unsigned v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (base + k < count) ? data[base + k] : 0u;
+    const unsigned mine = v[0] + v[1] + v[2] + v[3];
+    unsigned run = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < count) data[base + k] = run; run += v[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_totals(unsigned* __restrict__ tile_total, int tiles, unsigned* __restrict__ grand_total)
+{
+    __shared__ unsigned lds[16];
+    __shared__ unsigned tot;
+    unsigned carry = 0;
+    for (int b = 0; b < tiles; b += 1024) {                     // tiles <= 1024 in practice (4M words)
+        const int i = b + threadIdx.x;
+        const unsigned v = i < tiles ? tile_total[i] : 0u;
+        const unsigned ex = block_exclusive_scan_1024(v, lds, threadIdx.x == 0 ? &tot : nullptr);
+        if (i < tiles) tile_total[i] = carry + ex;
         __syncthreads();
-        partial[threadIdx.x] += v;
+        carry += tot;
         __syncthreads();
     }
-    unsigned run = partial[threadIdx.x] - sum;
-    for (int i = b; i < e; ++i) { const unsigned c = data[i]; data[i] = run; run += c; }
-    if (total_out && threadIdx.x == 1023) *total_out = partial[1023];
+    if (grand_total && threadIdx.x == 0) *grand_total = carry;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_add(unsigned* __restrict__ data, int count, const unsigned* __restrict__ tile_base)
+{
+    const unsigned add = tile_base[blockIdx.x];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
 }
 
 // stable scatter of one 8-bit digit.  Element order inside the tile is (wave, item, lane) = index order,
@@ -223,7 +268,8 @@ __global__ void __launch_bounds__(256) k_ps_rehash(const unsigned long long* __r
 // Rows with a short scan range are swept one row per lane: lane l of a wave owns sorted row i0+l and reads
 // entries[i0+l+1+t] in step t, so a wave's loads are contiguous.  Rows whose range exceeds HUB_LEN (the
 // ground box spans every column) are deferred to a workgroup-per-row kernel.
-constexpr int HUB_LEN = 4096;
+constexpr int HUB_LEN = 2048;      // rows scanning more candidates than this are cut into chunks
+constexpr int HUB_CHUNK = 2048;    // candidates per chunk = one 256-lane workgroup x 8 tiles
 
 struct SweepView {
     const float4* entries;
@@ -232,8 +278,10 @@ struct SweepView {
     const unsigned long long* table;
     unsigned mask;
     unsigned* row_count;       // new pairs per row
-    int* hub_rows;             // rows deferred to the hub kernels
-    int* hub_count;
+    int4* chunks;              // hub chunks {row, j_begin, j_end, index of the row's first chunk}
+    unsigned* chunk_count;     // new pairs per chunk, later: the chunk's base inside its row
+    int* n_chunks;
+    int chunk_cap;
     unsigned long long* counters;   // [0] candidate tests, [1] overlapping pairs
 };
 
@@ -255,8 +303,17 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
         const float4 a = v.entries[i];
         const int end = scan_end(v.entries, v.n, i, a.y);
-        if (end - i - 1 > HUB_LEN) {
-            if (!EMIT) { v.row_count[i] = 0; v.hub_rows[atomicAdd(v.hub_count, 1)] = i; }
+        const int len = end - i - 1;
+        if (len > HUB_LEN) {
+            if (!EMIT) {
+                // hand the row to the chunk kernels: its chunks sit contiguously and in j order in the list
+                const int nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
+                const int first = atomicAdd(v.n_chunks, nc);
+                for (int k = 0; k < nc && first + k < v.chunk_cap; ++k)
+                    v.chunks[first + k] = make_int4(i, i + 1 + k * HUB_CHUNK, min(end, i + 1 + (k + 1) * HUB_CHUNK), first);
+                v.row_count[i] = 0;
+                tests += (unsigned long long)len;
+            }
             continue;
         }
         const unsigned ia = v.idx[i];
@@ -273,7 +330,7 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
                 }
             }
         }
-        if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)(end - i - 1); }
+        if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; }
     }
     if (!EMIT) {
         for (int off = 32; off > 0; off >>= 1) { tests += __shfl_down(tests, off); overlaps += __shfl_down(overlaps, off); }
@@ -284,47 +341,64 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
     }
 }
 
-// one workgroup per hub row; tiles of 256 candidates in j order, running base keeps emission order
+// one workgroup per hub chunk; tiles of 256 candidates in j order, a running base keeps the emission order
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_sweep_hubs(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
+__global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
 {
     __shared__ unsigned wave_cnt[4];
     __shared__ unsigned running;
-    const int i = v.hub_rows[blockIdx.x];
-    const float4 a = v.entries[i];
-    const unsigned ia = v.idx[i];
-    const int end = scan_end(v.entries, v.n, i, a.y);
+    const int total = min(*v.n_chunks, v.chunk_cap);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) running = EMIT ? row_offset[i] : 0u;
-    unsigned long long overlaps = 0;
-    __syncthreads();
-    for (int j0 = i + 1; j0 < end; j0 += 256) {
-        const int j = j0 + threadIdx.x;
-        bool hit = false;
-        unsigned ib = 0;
-        if (j < end) {
-            const float4 b = v.entries[j];
-            if (fabsf(b.z - a.z) <= a.w + b.w) {
-                ib = v.idx[j];
-                ++overlaps;
-                hit = !ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | ib);
+    for (int c = blockIdx.x; c < total; c += gridDim.x) {
+        const int4 ch = v.chunks[c];
+        const float4 a = v.entries[ch.x];
+        const unsigned ia = v.idx[ch.x];
+        if (threadIdx.x == 0) running = EMIT ? row_offset[ch.x] + v.chunk_count[c] : 0u;
+        unsigned long long overlaps = 0;
+        __syncthreads();
+        for (int j0 = ch.y; j0 < ch.z; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            bool hit = false;
+            unsigned ib = 0;
+            if (j < ch.z) {
+                const float4 b = v.entries[j];
+                if (fabsf(b.z - a.z) <= a.w + b.w) {
+                    ib = v.idx[j];
+                    ++overlaps;
+                    hit = !ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | ib);
+                }
             }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned before = 0;
+            for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+            const unsigned base = running;
+            if (EMIT && hit) out[base + before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(ia, ib);
+            __syncthreads();
+            if (threadIdx.x == 0) running = base + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
         }
-        const unsigned long long bal = __ballot(hit);
-        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned before = 0;
-        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-        const unsigned base = running;
-        if (EMIT && hit) out[base + before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(ia, ib);
-        __syncthreads();
-        if (threadIdx.x == 0) running = base + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (!EMIT) {
+            if (threadIdx.x == 0) v.chunk_count[c] = running;
+            for (int off = 32; off > 0; off >>= 1) overlaps += __shfl_down(overlaps, off);
+            if (lane == 0 && overlaps) atomicAdd(&v.counters[1], overlaps);
+        }
         __syncthreads();
     }
-    if (!EMIT) {
-        if (threadIdx.x == 0) { v.row_count[i] = running; atomicAdd(&v.counters[0], (unsigned long long)(end - i - 1)); }
-        for (int off = 32; off > 0; off >>= 1) overlaps += __shfl_down(overlaps, off);
-        if (lane == 0 && overlaps) atomicAdd(&v.counters[1], overlaps);
+}
+
+// per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  One lane per chunk that is
+// the first of its row walks the row's chunks (a row has len/2048 of them — tens, not thousands).
+__global__ void __launch_bounds__(256) k_chunk_bases(SweepView v)
+{
+    const int total = min(*v.n_chunks, v.chunk_cap);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+        const int4 ch = v.chunks[c];
+        if (ch.w != c) continue;
+        unsigned run = 0;
+        for (int k = c; k < total && v.chunks[k].x == ch.x; ++k) { const unsigned n = v.chunk_count[k]; v.chunk_count[k] = run; run += n; }
+        v.row_count[ch.x] = run;
     }
 }
 
@@ -347,7 +421,7 @@ DeviceBroadphase::~DeviceBroadphase()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
-    hist_.release(); entries_.release(); table_.release(); row_count_.release(); hub_rows_.release(); small_.release();
+    hist_.release(); entries_.release(); table_.release(); row_count_.release(); chunks_.release(); chunk_count_.release(); scan_tiles_.release(); small_.release();
     new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -362,6 +436,17 @@ int DeviceBroadphase::init()
     PHX_HIP(hipEventCreate(&ev_end_));
     PHX_TRY(small_.reserve(16));
     return clear();
+}
+
+int DeviceBroadphase::exclusive_scan(unsigned* data, int count, unsigned* total_out)
+{
+    if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream_)); return PHX_OK; }
+    const int tiles = div_up(count, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, stream_, data, count, scan_tiles_.p);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream_, scan_tiles_.p, tiles, total_out);
+    if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(1024), 0, stream_, data, count, (const unsigned*)scan_tiles_.p);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
 }
 
 int DeviceBroadphase::resize_table(unsigned want_cap)
@@ -403,9 +488,12 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     const int nblocks = std::max(1, div_up(n, RS_TILE));
     for (int k = 0; k < 2; ++k) { PHX_TRY(keys_[k].reserve(std::max(n, 1))); PHX_TRY(idx_[k].reserve(std::max(n, 1))); }
     PHX_TRY(hist_.reserve((size_t)RS_BINS * nblocks));
+    PHX_TRY(scan_tiles_.reserve((size_t)std::max(div_up(std::max(RS_BINS * nblocks, n), SCAN_TILE), 1)));
+    int chunk_cap = std::max<int>((int)chunks_.cap, div_up(std::max(n, 1), HUB_CHUNK) * 8 + 64);   // grows on demand below
+    PHX_TRY(chunks_.reserve(chunk_cap));
+    PHX_TRY(chunk_count_.reserve(chunk_cap));
     PHX_TRY(entries_.reserve(std::max(n, 1)));
     PHX_TRY(row_count_.reserve(std::max(n, 1) + 1));
-    PHX_TRY(hub_rows_.reserve(std::max(n, 1)));
     // keep the table at most half full counting tombstones, before anything reads it
     if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max<long long>(4 * set_size_, 1024)));
 
@@ -418,7 +506,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = pass * 8;
         hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, stream_, keys_[src].p, n, shift, nblocks, hist_.p);
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream_, hist_.p, RS_BINS * nblocks, (unsigned*)nullptr);
+        PHX_TRY(exclusive_scan(hist_.p, RS_BINS * nblocks, nullptr));
         hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, stream_, keys_[src].p, idx_[src].p,
                            keys_[src ^ 1].p, idx_[src ^ 1].p, n, shift, nblocks, hist_.p);
         src ^= 1;
@@ -429,20 +517,31 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     // sweep: count -> scan -> emit
     SweepView v{};
     v.entries = entries_.p; v.idx = idx_[src].p; v.n = n; v.table = table_.p; v.mask = table_cap_ - 1;
-    v.row_count = row_count_.p; v.hub_rows = hub_rows_.p;
-    v.hub_count = reinterpret_cast<int*>(small_.p + 2);
+    v.row_count = row_count_.p;
+    v.n_chunks = reinterpret_cast<int*>(small_.p + 2);
     v.counters = small_.p;
-    hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
-    PHX_HIP(hipGetLastError());
-    int hubs = 0;
-    PHX_HIP(hipMemcpyAsync(&hubs, small_.p + 2, sizeof(int), hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
-    if (hubs) hipLaunchKernelGGL((k_sweep_hubs<false>), dim3(hubs), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream_, row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3));
-    PHX_HIP(hipGetLastError());
     unsigned long long host_small[4] = {0, 0, 0, 0};
-    PHX_HIP(hipMemcpyAsync(host_small, small_.p, sizeof host_small, hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    int chunk_grid = 1;
+    for (int attempt = 0;; ++attempt) {
+        v.chunks = chunks_.p; v.chunk_count = chunk_count_.p; v.chunk_cap = chunk_cap;
+        chunk_grid = std::min(chunk_cap, 2048);
+        hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
+        hipLaunchKernelGGL((k_sweep_chunks<false>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
+        hipLaunchKernelGGL(k_chunk_bases, dim3(grid_for(chunk_cap)), dim3(256), 0, stream_, v);
+        PHX_TRY(exclusive_scan(row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3)));
+        PHX_HIP(hipGetLastError());
+        PHX_HIP(hipMemcpyAsync(host_small, small_.p, sizeof host_small, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
+        if (needed <= chunk_cap) break;
+        // pathological overlap (many rows each spanning thousands of candidates): the chunk list was too short.
+        // Its exact length is now known; grow it and redo the count pass.
+        if (attempt) { set_error("broadphase: hub chunk list overflow twice (%d chunks)", needed); return PHX_ERR_CAPACITY; }
+        chunk_cap = needed + 64;
+        PHX_TRY(chunks_.reserve(chunk_cap));
+        PHX_TRY(chunk_count_.reserve(chunk_cap));
+        PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
+    }
     const unsigned total = (unsigned)host_small[3];
     stats_.candidate_tests = (long long)host_small[0];
     stats_.overlapping_pairs = (long long)host_small[1];
@@ -454,7 +553,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
             PHX_TRY(resize_table((unsigned)std::min<long long>(4ll * (set_size_ + (long long)total), 1ll << 30)));
         v.table = table_.p; v.mask = table_cap_ - 1;
         hipLaunchKernelGGL((k_sweep_rows<true>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
-        if (hubs) hipLaunchKernelGGL((k_sweep_hubs<true>), dim3(hubs), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
+        if (host_small[2] & 0xFFFFFFFFull) hipLaunchKernelGGL((k_sweep_chunks<true>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
         // ref: Collider.cpp:313 / :341 — the emitted pairs join the persistent set
         hipLaunchKernelGGL(k_ps_insert, dim3(grid_for((int)total)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)new_pairs_.p, (int)total);
         PHX_HIP(hipGetLastError());

@@ -5,18 +5,27 @@
 
 namespace phx {
 
-// first-fit colouring of `joints` (indices into body1/body2) in the given order; returns colour per entry
+// first-fit colouring of `joints` (indices into body1/body2) in the given order; returns colour per entry.
+// `used` is caller-owned scratch (nb * words 64-bit masks, all zero on entry and on exit) so that colouring a
+// thousand small bins does not allocate or clear a world-sized array a thousand times.
+struct ColourScratch {
+    std::vector<unsigned long long> used;
+    int words = 1;
+    void ensure(int nb) { if (used.size() < (size_t)nb * words) used.assign((size_t)nb * words, 0ull); }
+};
+
 static int colour_joints(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-                         int nb, std::vector<int>& colour)
+                         int nb, std::vector<int>& colour, ColourScratch& sc)
 {
     colour.assign(joints.size(), 0);
-    int words = 1, ncolours = 0;
     for (;;) {
-        // used[b * words + w] bit c%64 <=> a joint of colour w*64+c already touches dynamic body b
-        std::vector<unsigned long long> used((size_t)nb * words, 0ull);
+        sc.ensure(nb);
+        const int words = sc.words;
+        unsigned long long* used = sc.used.data();
         bool overflow = false;
-        ncolours = 0;
-        for (size_t k = 0; k < joints.size() && !overflow; ++k) {
+        int ncolours = 0;
+        size_t done = 0;
+        for (size_t k = 0; k < joints.size(); ++k) {
             const int a = body1[joints[k]], b = body2[joints[k]];
             const bool da = !is_static[a], db = !is_static[b];
             int c = -1;
@@ -31,9 +40,14 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
             if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
             if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
             ncolours = std::max(ncolours, c + 1);
+            done = k + 1;
         }
+        for (size_t k = 0; k < done; ++k)                      // leave the scratch clean for the next caller
+            for (int body : {body1[joints[k]], body2[joints[k]]})
+                for (int w = 0; w < words; ++w) used[(size_t)body * words + w] = 0ull;
         if (!overflow) return ncolours;
-        words *= 2;
+        sc.words *= 2;                                         // > 64 * words colours needed: widen the masks and redo
+        sc.used.clear();
     }
 }
 
@@ -66,7 +80,8 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
     reset(out);
     std::vector<int> all(nj), colour;
     for (int j = 0; j < nj; ++j) all[j] = j;
-    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour);
+    ColourScratch scratch;
+    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch);
     if (nj) append_group(out, all, colour, ncol);
     out.lds_groups = 0;
     out.islands = false;
@@ -155,6 +170,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
     std::vector<int> rest;                       // joints left to the HBM group
     std::vector<int> stamp(nb, -1), local(nb, 0);
     std::vector<int> bin, colour;
+    ColourScratch scratch;
     int bin_id = 0;
     auto flush = [&]() {
         if (bin.empty()) return;
@@ -167,7 +183,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         const int nstatic = (int)bodies.size();
         bodies.insert(bodies.end(), dynamic.begin(), dynamic.end());      // static bodies first
         for (size_t i = 0; i < bodies.size(); ++i) local[bodies[i]] = (int)i;
-        const int ncol = colour_joints(bin, body1, body2, is_static, nb, colour);
+        const int ncol = colour_joints(bin, body1, body2, is_static, nb, colour, scratch);
         if ((int)bodies.size() > caps.max_bodies || ncol > caps.max_colours || (int)bodies.size() > 65535 || nstatic > caps.max_static) {
             rest.insert(rest.end(), bin.begin(), bin.end());
         } else {
@@ -205,7 +221,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
     for (int j = 0; j < nj; ++j) if (comp_of[j] < 0) rest.push_back(j);
     if (!rest.empty()) {
         std::sort(rest.begin(), rest.end());
-        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour);
+        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch);
         append_group(out, rest, colour, ncol);
         std::vector<unsigned char> seen(nb, 0);
         for (int j : rest)
