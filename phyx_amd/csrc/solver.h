@@ -8,7 +8,9 @@ namespace phx {
 
 // device-side view of the solver state, passed by value to every kernel (layout: solver_kernels.h)
 struct SolverView {
-    int nb, nj, nstatic, ncolours;
+    int nb, nj, ncp, nstatic, ncolours;
+    const unsigned long long* fingerprint;       // topology fingerprint computed for this call (device word)
+    unsigned long long expected_fingerprint;     // the one the schedule in use was built for
     float4* sb_imp;
     float4* sb_disp;
     float4* sb_par;
@@ -46,15 +48,16 @@ public:
     int device() const { return device_; }
 
 private:
-    int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, const phx_config& cfg);
+    int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild);
+    int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     struct GraphKey {
         const void *bodies = nullptr, *cps = nullptr, *joints = nullptr;
-        int nb = 0, nj = 0, ci = 0, pi = 0;
+        int nb = 0, nj = 0, ncp = 0, ci = 0, pi = 0;
         long long schedule_version = -1;
         bool valid = false;
         bool operator==(const GraphKey& o) const
         {
-            return bodies == o.bodies && cps == o.cps && joints == o.joints && nb == o.nb && nj == o.nj && ci == o.ci && pi == o.pi &&
+            return bodies == o.bodies && cps == o.cps && joints == o.joints && nb == o.nb && nj == o.nj && ncp == o.ncp && ci == o.ci && pi == o.pi &&
                    schedule_version == o.schedule_version;
         }
     };
@@ -103,7 +106,12 @@ private:
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
-    bool use_graphs_ = true, wave_islands_ = false;
+    bool use_graphs_ = true, wave_islands_ = false, speculate_ = true;
+    // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()
+    struct Pending { bool active = false; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
+    int ncp_ = 0;
+    unsigned long long raw_fingerprint_ = 0;
+    std::vector<hipEvent_t> bench_events_;
 };
 
 } // namespace phx

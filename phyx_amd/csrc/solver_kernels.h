@@ -49,6 +49,8 @@ __device__ __forceinline__ bool static_productive(const unsigned* sw, int nstati
 
 __device__ __forceinline__ float max_ref(float l, float r) { return l > r ? l : r; }      // ref: base/SIMD_Scalar.h:275-278
 
+__device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i >= n ? (n > 0 ? n - 1 : 0) : i); }
+
 // ---- PrepareBodies (ref: Solver.cpp:456-480) -----------------------------------------------------
 // `list` = the bodies the HBM group touches (islands solved in LDS read the records directly)
 __global__ void __launch_bounds__(256) k_unpack_bodies(const phx_rigid_body* __restrict__ bodies, const int* __restrict__ list, int count,
@@ -74,13 +76,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
 }
 
 __global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
-                                                       const phx_rigid_body* __restrict__ bodies, int nb, unsigned long long* out)
+                                                       const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out)
 {
     __shared__ unsigned long long part[4];
     unsigned long long h = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
-        unsigned long long k = ((unsigned long long)(unsigned)joints[i].body1 << 32) | (unsigned)joints[i].body2;
+        const phx_contact_joint j = joints[i];
+        unsigned long long k = ((unsigned long long)(unsigned)j.body1 << 32) | (unsigned)j.body2;
         h += mix64(k + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1));
+        // an out-of-range index can never belong to the topology a schedule was built (and validated) for
+        if ((unsigned)j.body1 >= (unsigned)nb || (unsigned)j.body2 >= (unsigned)nb || (unsigned)j.contact_point_index >= (unsigned)ncp)
+            h += 0xBADBADBADBADBAD1ull + (unsigned long long)i;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         if (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) h += mix64(0xD1B54A32D192ED03ull * (unsigned long long)(i + 1));
@@ -118,8 +124,11 @@ __global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int begin, i
                                                       const phx_contact_point* __restrict__ cps, const int* __restrict__ static_slot)
 {
     for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
-        const phx_contact_joint j = joints[v.order[s]];
-        const phx_contact_point& cp = cps[j.contact_point_index];
+        phx_contact_joint j = joints[v.order[s]];
+        // indices come from the caller's arrays; clamp so that a bad or stale record cannot fault (the host
+        // validates them whenever it rebuilds the schedule and the fingerprint kernel poisons itself on a bad one)
+        j.body1 = clamp_index(j.body1, v.nb); j.body2 = clamp_index(j.body2, v.nb);
+        const phx_contact_point& cp = cps[clamp_index(j.contact_point_index, v.ncp)];
         const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
         const float nx = cp.normal.x, ny = cp.normal.y;
         const float4 p1 = v.sb_par[j.body1], p2 = v.sb_par[j.body2];       // {im, ii, pos.x, pos.y}
@@ -342,7 +351,7 @@ __global__ void __launch_bounds__(ISL_T, 8) k_solve_islands(SolverView v, Island
     int l1 = 0, l2 = 0, col = -1;
     if (live) {                                            // PrepareJoints (ref: Solver.cpp:509-521)
         j = joints[v.order[s]];
-        const float4* cp4 = reinterpret_cast<const float4*>(&cps[j.contact_point_index]);   // 32-byte records
+        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);   // 32-byte records
         const float4 da = cp4[0];                          // delta1, delta2
         const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
         d1x = da.x; d1y = da.y; d2x = da.z; d2y = da.w; nx = nn.x; ny = nn.y;
@@ -467,7 +476,9 @@ __global__ void __launch_bounds__(ISL_T, 8) k_solve_islands(SolverView v, Island
         __syncthreads();
     }
 
-    // results go straight back into the caller's records; the refreshed constants never leave the registers
+    // results go straight back into the caller's records (commit-gated like k_finish_*); the refreshed constants
+    // never leave the registers
+    if (*v.fingerprint != v.expected_fingerprint) return;
     if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
         phx_contact_joint& j = joints[v.order[s]];
         j.normal_accumulated_impulse = accN;
@@ -550,11 +561,11 @@ __global__ void __launch_bounds__(64) k_solve_islands_wave(SolverView v, IslandW
     for (int t = lane; t < d.y; t += 64) {                 // PrepareJoints + RefreshJoints (ref: Solver.cpp:509-521, 642-693)
         const int s = d.x + t;
         const phx_contact_joint j = joints[v.order[s]];
-        const phx_contact_point& cp = cps[j.contact_point_index];
+        const phx_contact_point& cp = cps[clamp_index(j.contact_point_index, v.ncp)];
         const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
         const float nx = cp.normal.x, ny = cp.normal.y;
-        const phx_rigid_body& r1 = bodies[j.body1];
-        const phx_rigid_body& r2 = bodies[j.body2];
+        const phx_rigid_body& r1 = bodies[clamp_index(j.body1, v.nb)];
+        const phx_rigid_body& r2 = bodies[clamp_index(j.body2, v.nb)];
         const float pt1x = d1x + r1.pos.x, pt1y = d1y + r1.pos.y;
         const float pt2x = d2x + r2.pos.x, pt2y = d2y + r2.pos.y;
         const float w2x = pt1x - r2.pos.x, w2y = pt1y - r2.pos.y;
@@ -684,6 +695,7 @@ __global__ void __launch_bounds__(64) k_solve_islands_wave(SolverView v, IslandW
         if (disp_on) { done_disp = it + 1; disp_alive = __any(any_disp); }
     }
 
+    if (*v.fingerprint != v.expected_fingerprint) return;
     for (int t = lane; t < d.y; t += 64) {                 // FinishJoints (ref: Solver.cpp:543-544)
         phx_contact_joint& j = joints[v.order[d.x + t]];
         const float4 acc = ac[t];
@@ -706,8 +718,12 @@ __global__ void __launch_bounds__(64) k_solve_islands_wave(SolverView v, IslandW
 }
 
 // ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------
+// The two finish kernels (and the island kernel's epilogue) are the only places that write to the caller's
+// arrays.  They commit only if the topology fingerprint computed for THIS call equals the one the schedule was
+// built for; otherwise the solve ran on a stale schedule, nothing is written, and the host rebuilds and repeats.
 __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int begin, int end, phx_contact_joint* __restrict__ joints)
 {
+    if (*v.fingerprint != v.expected_fingerprint) return;
     for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
         const float2 acc = v.acc[s];
         phx_contact_joint& j = joints[v.order[s]];
@@ -718,6 +734,7 @@ __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int begin, 
 
 __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, phx_rigid_body* __restrict__ bodies)
 {
+    if (*v.fingerprint != v.expected_fingerprint) return;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int i = list[k];
         const float4 a = v.sb_imp[i], d = v.sb_disp[i];

@@ -219,3 +219,26 @@ def test_full_size_200k_boxes(solver, oracle):
     oracle.solver_solve(rb, cp, rj, oracle.SOLVE_AVX2, oracle.ISLAND_SINGLE, 20, 20)
     dv = np.abs(gb["velocity"]["y"] - rb["velocity"]["y"])
     assert np.isfinite(dv).all() and np.median(dv) < 1.0
+
+
+def test_speculative_schedule_is_verified(solver, oracle):
+    """Solves on the same array sizes reuse the cached schedule without waiting for the topology fingerprint; the
+    device refuses to commit if it differs and the host then rebuilds and repeats.  Same joint count, different
+    wiring: the result must still be the right one for the NEW joint list."""
+    a = presolve_state(scenes.stack(6, 40), 3)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 15, 15)
+    _device_solve(solver, a, cfg)                                   # builds the schedule for `a`
+    perm = np.random.default_rng(3).permutation(len(a[2]))
+    b = (a[0], a[1], a[2][perm].copy())                              # same sizes, joints re-ordered => other topology fingerprint
+    gb, gj, sched, _, st = _device_solve(solver, b, cfg)
+    assert st.recoloured == 1
+    ob_, oj, _ = _oracle_in_device_order(oracle, b, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+    # and a corrupted body index is reported, not dereferenced, even on the speculative path
+    bad = b[2].copy()
+    bad["body1"][5] = 10 ** 6
+    with pytest.raises(phyx_amd.PhxError):
+        solver.SolveJoints(b[0].copy(), b[1], bad, cfg)
+    gb2, gj2, sched2, _, _ = _device_solve(solver, a, cfg)          # the solver still works afterwards
+    ob2, oj2, _ = _oracle_in_device_order(oracle, a, sched2, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb2.tobytes() == ob2.tobytes() and gj2.tobytes() == oj2.tobytes()
