@@ -16,6 +16,8 @@ public:
     int get_new_pairs(uint32_t* out, int cap, int* count);
     int get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* entries, int cap);
     int erase_pairs(const uint32_t* pairs, int count);
+    int erase_pairs_device(const uint2* d_pairs, int count);      // pairs already in HBM
+    const uint2* new_pairs_device() const { return new_pairs_.p; }   // pairs emitted by the last update, in HBM
     int get_stats(phx_broadphase_stats* out);
     int new_pair_count() const { return last_new_; }
     hipStream_t stream() const { return stream_; }

@@ -15,6 +15,7 @@
 // stable sort's output permutation does not depend on the digit split, so 4 passes of 8 bits (256-bin
 // LDS histograms, one wave-private counter row per wave) give the identical sequence.
 #include "handles.h"
+#include "device_scan.h"
 
 #include <algorithm>
 
@@ -61,72 +62,6 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const unsigned* __res
     }
     __syncthreads();
     hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
-}
-
-// ---- exclusive prefix sum over `count` words, in place: three small launches ---------------------------
-//   k_scan_tiles   each 1024-lane workgroup scans a 4096-word tile in LDS and records the tile total
-//   k_scan_totals  one workgroup scans the (<= 4096) tile totals
-//   k_scan_add     adds each tile's base
-constexpr int SCAN_TILE = 4096;
-
-__device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsigned* lds, unsigned* total)
-{
-    // wave-level inclusive scan, then a 16-entry scan of the wave totals
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned x = v;
-    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
-    if (lane == 63) lds[wave] = x;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned t = lane < 16 ? lds[lane] : 0u;
-        for (int off = 1; off < 16; off <<= 1) { const unsigned y = __shfl_up(t, off); if (lane >= off) t += y; }
-        if (lane < 16) lds[lane] = t;            // inclusive totals of waves 0..lane
-    }
-    __syncthreads();
-    const unsigned before = wave ? lds[wave - 1] : 0u;
-    if (total) *total = lds[15];
-    return before + x - v;
-}
-
-__global__ void __launch_bounds__(1024) k_scan_tiles(unsigned* __restrict__ data, int count, unsigned* __restrict__ tile_total)
-{
-    __shared__ unsigned lds[16];
-    __shared__ unsigned tot;
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-    unsigned v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (base + k < count) ? data[base + k] : 0u;
-    const unsigned mine = v[0] + v[1] + v[2] + v[3];
-    unsigned run = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < count) data[base + k] = run; run += v[k]; }
-    __syncthreads();
-    if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(1024) k_scan_totals(unsigned* __restrict__ tile_total, int tiles, unsigned* __restrict__ grand_total)
-{
-    __shared__ unsigned lds[16];
-    __shared__ unsigned tot;
-    unsigned carry = 0;
-    for (int b = 0; b < tiles; b += 1024) {                     // tiles <= 1024 in practice (4M words)
-        const int i = b + threadIdx.x;
-        const unsigned v = i < tiles ? tile_total[i] : 0u;
-        const unsigned ex = block_exclusive_scan_1024(v, lds, threadIdx.x == 0 ? &tot : nullptr);
-        if (i < tiles) tile_total[i] = carry + ex;
-        __syncthreads();
-        carry += tot;
-        __syncthreads();
-    }
-    if (grand_total && threadIdx.x == 0) *grand_total = carry;
-}
-
-__global__ void __launch_bounds__(1024) k_scan_add(unsigned* __restrict__ data, int count, const unsigned* __restrict__ tile_base)
-{
-    const unsigned add = tile_base[blockIdx.x];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
 }
 
 // stable scatter of one 8-bit digit.  Element order inside the tile is (wave, item, lane) = index order,
@@ -440,13 +375,7 @@ int DeviceBroadphase::init()
 
 int DeviceBroadphase::exclusive_scan(unsigned* data, int count, unsigned* total_out)
 {
-    if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream_)); return PHX_OK; }
-    const int tiles = div_up(count, SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, stream_, data, count, scan_tiles_.p);
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream_, scan_tiles_.p, tiles, total_out);
-    if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(1024), 0, stream_, data, count, (const unsigned*)scan_tiles_.p);
-    PHX_HIP(hipGetLastError());
-    return PHX_OK;
+    return device_exclusive_scan(data, count, total_out, scan_tiles_.p, stream_);
 }
 
 int DeviceBroadphase::resize_table(unsigned want_cap)
@@ -611,15 +540,13 @@ int DeviceBroadphase::get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* e
     return PHX_OK;
 }
 
-int DeviceBroadphase::erase_pairs(const uint32_t* pairs, int count)
+int DeviceBroadphase::erase_pairs_device(const uint2* d_pairs, int count)
 {
     PHX_TRY(use_device(device_));
-    PHX_REQUIRE(count >= 0 && (count == 0 || pairs), "bad pair list");
+    PHX_REQUIRE(count >= 0 && (count == 0 || d_pairs), "bad pair list");
     if (!count) return PHX_OK;
-    PHX_TRY(scratch_pairs_.reserve(count));
-    PHX_HIP(hipMemcpyAsync(scratch_pairs_.p, pairs, (size_t)count * sizeof(uint2), hipMemcpyHostToDevice, stream_));
     PHX_HIP(hipMemsetAsync(small_.p + 8, 0, sizeof(unsigned long long), stream_));
-    hipLaunchKernelGGL(k_ps_erase, dim3(grid_for(count)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)scratch_pairs_.p, count,
+    hipLaunchKernelGGL(k_ps_erase, dim3(grid_for(count)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, d_pairs, count,
                        reinterpret_cast<int*>(small_.p + 8));
     PHX_HIP(hipGetLastError());
     int erased = 0;
@@ -628,6 +555,16 @@ int DeviceBroadphase::erase_pairs(const uint32_t* pairs, int count)
     set_size_ -= erased;
     tombstones_ += erased;
     return PHX_OK;
+}
+
+int DeviceBroadphase::erase_pairs(const uint32_t* pairs, int count)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(count >= 0 && (count == 0 || pairs), "bad pair list");
+    if (!count) return PHX_OK;
+    PHX_TRY(scratch_pairs_.reserve(count));
+    PHX_HIP(hipMemcpyAsync(scratch_pairs_.p, pairs, (size_t)count * sizeof(uint2), hipMemcpyHostToDevice, stream_));
+    return erase_pairs_device(scratch_pairs_.p, count);
 }
 
 int DeviceBroadphase::get_stats(phx_broadphase_stats* out)

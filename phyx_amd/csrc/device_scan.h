@@ -1,0 +1,87 @@
+// device_scan.h — exclusive prefix sum over u32 words on the device (shared by the broadphase and the world step).
+#pragma once
+
+#include "common.h"
+
+namespace phx {
+
+// ---- exclusive prefix sum over `count` words, in place: three small launches ---------------------------
+//   k_scan_tiles   each 1024-lane workgroup scans a 4096-word tile in LDS and records the tile total
+//   k_scan_totals  one workgroup scans the (<= 4096) tile totals
+//   k_scan_add     adds each tile's base
+constexpr int SCAN_TILE = 4096;
+
+__device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsigned* lds, unsigned* total)
+{
+    // wave-level inclusive scan, then a 16-entry scan of the wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned x = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned t = lane < 16 ? lds[lane] : 0u;
+        for (int off = 1; off < 16; off <<= 1) { const unsigned y = __shfl_up(t, off); if (lane >= off) t += y; }
+        if (lane < 16) lds[lane] = t;            // inclusive totals of waves 0..lane
+    }
+    __syncthreads();
+    const unsigned before = wave ? lds[wave - 1] : 0u;
+    if (total) *total = lds[15];
+    return before + x - v;
+}
+
+static __global__ void __launch_bounds__(1024) k_scan_tiles(unsigned* __restrict__ data, int count, unsigned* __restrict__ tile_total)
+{
+    __shared__ unsigned lds[16];
+    __shared__ unsigned tot;
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    unsigned v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (base + k < count) ? data[base + k] : 0u;
+    const unsigned mine = v[0] + v[1] + v[2] + v[3];
+    unsigned run = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < count) data[base + k] = run; run += v[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
+}
+
+static __global__ void __launch_bounds__(1024) k_scan_totals(unsigned* __restrict__ tile_total, int tiles, unsigned* __restrict__ grand_total)
+{
+    __shared__ unsigned lds[16];
+    __shared__ unsigned tot;
+    unsigned carry = 0;
+    for (int b = 0; b < tiles; b += 1024) {                     // tiles <= 1024 in practice (4M words)
+        const int i = b + threadIdx.x;
+        const unsigned v = i < tiles ? tile_total[i] : 0u;
+        const unsigned ex = block_exclusive_scan_1024(v, lds, threadIdx.x == 0 ? &tot : nullptr);
+        if (i < tiles) tile_total[i] = carry + ex;
+        __syncthreads();
+        carry += tot;
+        __syncthreads();
+    }
+    if (grand_total && threadIdx.x == 0) *grand_total = carry;
+}
+
+static __global__ void __launch_bounds__(1024) k_scan_add(unsigned* __restrict__ data, int count, const unsigned* __restrict__ tile_base)
+{
+    const unsigned add = tile_base[blockIdx.x];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
+}
+
+
+// scratch must hold div_up(count, SCAN_TILE) words.  total_out (device pointer, may be null) receives the sum.
+static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, unsigned* scratch, hipStream_t stream)
+{
+    if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream)); return PHX_OK; }
+    const int tiles = div_up(count, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, stream, data, count, scratch);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream, scratch, tiles, total_out);
+    if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(1024), 0, stream, data, count, (const unsigned*)scratch);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
+} // namespace phx

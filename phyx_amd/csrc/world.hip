@@ -1,49 +1,41 @@
-// world.hip — World: step orchestration in the reference's order (ref: src/World.cpp:19-37).
+// world.hip — World: the whole step of ref: src/World.cpp:19-37 on HBM-resident arrays.
 //
-// The two hot halves run on the device (DeviceBroadphase, DeviceSolver).  The stages between them —
-// narrowphase + manifold cache (ref: Collider.cpp:368-416), joint matching (ref: World.cpp:72-149) and
-// the integrators (ref: World.cpp:39-70) — are host C++ in this round (SURVEY.md §8(f) rows 1-3 are the
-// next ones to move to HIP); they run on all host cores where the reference uses parallelFor.
+// bodies / manifolds / contact points / joints live on the device in the reference's POD layouts; the host keeps
+// only their counts.  Per step: IntegrateVelocity (kernel) -> UpdateBroadphase + UpdatePairs (DeviceBroadphase) ->
+// manifold creation + UpdateManifolds (narrowphase kernel) -> PackManifolds -> RefreshContactJoints (scan-based,
+// order-preserving, world_kernels.h) -> SolveJoints (DeviceSolver) -> IntegratePosition (kernel).  What crosses
+// PCIe per step is a handful of counters (new pairs, dead manifolds, new / dead joints) and, only when the joint
+// topology changed, the body-pair list the host schedule builder needs.
 #include "handles.h"
-#include "narrowphase.h"
+#include "device_scan.h"
+#include "world_kernels.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
-#include <thread>
 
 namespace phx {
 
-template <typename F>
-static void parallel_for(int count, int grain, F&& fn)
-{
-    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-    const int workers = std::max(1, std::min(hw, count / std::max(grain, 1)));
-    if (workers <= 1) { fn(0, count); return; }
-    std::vector<std::thread> pool;
-    const int chunk = div_up(count, workers);
-    for (int w = 0; w < workers; ++w) {
-        const int b = w * chunk, e = std::min(count, b + chunk);
-        if (b >= e) break;
-        pool.emplace_back([&fn, b, e] { fn(b, e); });
-    }
-    for (auto& t : pool) t.join();
-}
+static inline int wgrid(int n) { return std::max(1, std::min(div_up(n, 256), 4096)); }
 
 class World {
 public:
-    explicit World(int device) : broadphase_h(device), solver_h(device), broadphase_(broadphase_h.impl), solver_(solver_h.impl) {}
-    int init() { PHX_TRY(broadphase_.init()); return solver_.init(); }
+    explicit World(int device) : broadphase_h(device), solver_h(device), device_(device), broadphase_(broadphase_h.impl), solver_(solver_h.impl) {}
+    ~World();
+    int init();
 
     int add_body(float px, float py, float angle, float sx, float sy);
+    int set_static(int body);
     int update(float dt, const phx_config& cfg);
     int pre_solve(float dt);
     int finish_step(float dt, const phx_config& cfg);
+    int download_bodies(phx_rigid_body* out, int cap);
+    int download_manifolds(phx_manifold* out, int cap);
+    int download_contact_points(phx_contact_point* out, int cap);
+    int download_joints(phx_contact_joint* out, int cap);
 
-    std::vector<phx_rigid_body> bodies;
-    std::vector<phx_manifold> manifolds;
-    std::vector<phx_contact_point> contact_points;
-    std::vector<phx_contact_joint> joints;
+    int nb() const { return (int)host_bodies_.size(); }
+    int nm = 0, nj = 0;
     float gravity = 0.f;
     int shard = 0, shard_count = 1;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -54,22 +46,51 @@ public:
     DeviceSolver& solver() { return solver_; }
 
 private:
-    void integrate_velocity(float dt);
-    void integrate_position(float dt);
+    int sync_bodies_to_device();
     int update_pairs();
-    void update_manifolds();
+    int update_manifolds();
     int pack_manifolds();
-    void refresh_contact_joints();
+    int refresh_contact_joints();
     int solve(const phx_config& cfg);
+    int scratch_for(int n);
 
+    int device_;
     DeviceBroadphase& broadphase_;
     DeviceSolver& solver_;
-    std::vector<uint32_t> pair_scratch_;
+    hipStream_t stream_ = nullptr;
+    std::vector<phx_rigid_body> host_bodies_;     // construction-time staging; the device copy is authoritative after upload
+    bool bodies_dirty_ = false;
+    DevBuf<phx_rigid_body> d_bodies_;
+    DevBuf<phx_manifold> d_manifolds_;
+    DevBuf<phx_contact_point> d_cps_;
+    DevBuf<phx_contact_joint> d_joints_;
+    DevBuf<unsigned> flags_, scan_tiles_, counters_;     // counters_: [0] dead/new total, [1] dropped points
+    DevBuf<int> mover_pos_;
+    DevBuf<uint2> erased_;
 };
+
+World::~World()
+{
+    if (hipSetDevice(device_) != hipSuccess) return;
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
+    flags_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int World::init()
+{
+    PHX_TRY(broadphase_.init());
+    PHX_TRY(solver_.init());
+    PHX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    PHX_TRY(counters_.reserve(4));
+    return PHX_OK;
+}
 
 // ref: World.cpp:11-17, RigidBody.h:15-36, Coords2.h:10-17 (cos/sin resolve to the double overloads)
 int World::add_body(float px, float py, float angle, float sx, float sy)
 {
+    if (!bodies_dirty_ && !host_bodies_.empty() && d_bodies_.p) PHX_TRY(download_bodies(host_bodies_.data(), (int)host_bodies_.size()));
     phx_rigid_body b;
     std::memset(&b, 0, sizeof b);
     const float pi = 3.141592f;
@@ -84,168 +105,188 @@ int World::add_body(float px, float py, float angle, float sx, float sy)
     b.inv_mass = 1.0f / mass;
     b.inv_inertia = 1.0f / inertia;
     update_geom(b);
-    b.index = (uint32_t)bodies.size();
-    bodies.push_back(b);
-    return (int)bodies.size() - 1;
+    b.index = (uint32_t)host_bodies_.size();
+    host_bodies_.push_back(b);
+    bodies_dirty_ = true;
+    return (int)host_bodies_.size() - 1;
 }
 
-void World::integrate_velocity(float dt)                                   // ref: World.cpp:39-55
+int World::set_static(int body)
 {
-    const float g = gravity;
-    parallel_for((int)bodies.size(), 16384, [&](int b, int e) {
-        for (int i = b; i < e; ++i) {
-            phx_rigid_body& body = bodies[i];
-            if (body.inv_mass > 0.0f) body.acceleration.y += g;
-            body.velocity.x += body.acceleration.x * dt; body.velocity.y += body.acceleration.y * dt;
-            body.acceleration.x = 0.f; body.acceleration.y = 0.f;
-            body.angular_velocity += body.angular_acceleration * dt;
-            body.angular_acceleration = 0.f;
-        }
-    });
+    if (!bodies_dirty_ && d_bodies_.p) PHX_TRY(download_bodies(host_bodies_.data(), (int)host_bodies_.size()));
+    host_bodies_[body].inv_mass = 0.f;
+    host_bodies_[body].inv_inertia = 0.f;
+    bodies_dirty_ = true;
+    return PHX_OK;
 }
 
-static inline void rotate(phx_vec2& v, float c, float s)                   // ref: Vector2.h:48-56
+int World::sync_bodies_to_device()
 {
-    const V2 x = v2(v), y = perp(x);
-    const V2 delta = (x * c + y * s) - x;
-    v.x = v.x + delta.x; v.y = v.y + delta.y;
+    if (!bodies_dirty_) return PHX_OK;
+    PHX_TRY(use_device(device_));
+    PHX_TRY(d_bodies_.reserve(std::max<size_t>(host_bodies_.size(), 1)));
+    if (!host_bodies_.empty())
+        PHX_HIP(hipMemcpyAsync(d_bodies_.p, host_bodies_.data(), host_bodies_.size() * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    bodies_dirty_ = false;
+    return PHX_OK;
 }
 
-void World::integrate_position(float dt)                                   // ref: World.cpp:57-70
+int World::scratch_for(int n)
 {
-    parallel_for((int)bodies.size(), 8192, [&](int b, int e) {
-        for (int i = b; i < e; ++i) {
-            phx_rigid_body& body = bodies[i];
-            body.pos.x += body.displacing_velocity.x + body.velocity.x * dt;
-            body.pos.y += body.displacing_velocity.y + body.velocity.y * dt;
-            const float ang = -(body.displacing_angular_velocity + body.angular_velocity * dt);
-            const float c = (float)std::cos((double)ang), s = (float)std::sin((double)ang);
-            rotate(body.xvector, c, s);
-            rotate(body.yvector, c, s);
-            body.displacing_velocity.x = 0.f; body.displacing_velocity.y = 0.f;
-            body.displacing_angular_velocity = 0.f;
-            update_geom(body);
-        }
-    });
+    PHX_TRY(flags_.reserve((size_t)n + 2));
+    PHX_TRY(mover_pos_.reserve((size_t)n + 2));
+    PHX_TRY(scan_tiles_.reserve((size_t)div_up(n + 1, SCAN_TILE) + 1));
+    return PHX_OK;
 }
 
 int World::update_pairs()                                                   // ref: Collider.cpp:251-345
 {
-    int count = 0;
-    PHX_TRY(broadphase_.update_host(bodies.data(), (int)bodies.size(), nullptr, 0, &count));
-    pair_scratch_.resize(2 * (size_t)std::max(count, 1));
-    PHX_TRY(broadphase_.get_new_pairs(pair_scratch_.data(), count, &count));
-    for (int k = 0; k < count; ++k) {                                       // ref: Collider.cpp:313-316
-        phx_manifold m;
-        m.body1 = (int)pair_scratch_[2 * k]; m.body2 = (int)pair_scratch_[2 * k + 1];
-        m.point_count = 0; m.point_index = (int)manifolds.size() * 2;
-        manifolds.push_back(m);
-    }
+    PHX_TRY(broadphase_.update_device(d_bodies_.p, nb()));                  // synchronises its own stream
+    const int fresh = broadphase_.new_pair_count();
+    if (!fresh) return PHX_OK;
+    PHX_TRY(d_manifolds_.reserve_keep((size_t)nm + fresh, nm, stream_));
+    PHX_TRY(d_cps_.reserve_keep(2 * ((size_t)nm + fresh), 2 * (size_t)nm, stream_));
+    hipLaunchKernelGGL(k_append_manifolds, dim3(wgrid(fresh)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, broadphase_.new_pairs_device(), fresh);
+    PHX_HIP(hipGetLastError());
+    nm += fresh;
     return PHX_OK;
 }
 
-void World::update_manifolds()                                              // ref: Collider.cpp:368-377
+int World::update_manifolds()                                               // ref: Collider.cpp:368-377
 {
-    const size_t old = contact_points.size();
-    contact_points.resize(manifolds.size() * 2);
-    for (size_t k = old; k < contact_points.size(); ++k) { std::memset(&contact_points[k], 0, sizeof(phx_contact_point)); contact_points[k].solver_index = -1; }
-    std::vector<int> dropped(64, 0);
-    parallel_for((int)manifolds.size(), 2048, [&](int b, int e) {
-        int d = 0;
-        for (int i = b; i < e; ++i) d += update_manifold(manifolds[i], bodies.data(), contact_points.data() + manifolds[i].point_index) ? 1 : 0;
-        if (d) __atomic_fetch_add(&dropped[0], d, __ATOMIC_RELAXED);
-    });
-    dropped_points += dropped[0];
+    if (!nm) return PHX_OK;
+    PHX_TRY(scratch_for(nm));
+    PHX_HIP(hipMemsetAsync(counters_.p, 0, 4 * sizeof(unsigned), stream_));
+    hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, (const phx_rigid_body*)d_bodies_.p, d_cps_.p,
+                       flags_.p, reinterpret_cast<int*>(counters_.p + 1));
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
 }
 
 int World::pack_manifolds()                                                 // ref: Collider.cpp:379-416
 {
-    std::vector<uint32_t> erased;
-    for (size_t i = 0; i < manifolds.size();) {
-        phx_manifold& m = manifolds[i];
-        if (m.point_count == 0 && !aabb_intersects(bodies[m.body1], bodies[m.body2])) {
-            erased.push_back((uint32_t)m.body1); erased.push_back((uint32_t)m.body2);
-            const phx_manifold last = manifolds.back();
-            const int slot = m.point_index;
-            for (int k = 0; k < last.point_count; ++k) contact_points[slot + k] = contact_points[last.point_index + k];
-            m = last;
-            m.point_index = slot;
-            manifolds.pop_back();
-        } else ++i;
-    }
-    contact_points.resize(manifolds.size() * 2);
-    if (!erased.empty()) PHX_TRY(broadphase_.erase_pairs(erased.data(), (int)erased.size() / 2));
-    return PHX_OK;
+    if (!nm) return PHX_OK;
+    PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
+    unsigned host[2] = {0, 0};
+    PHX_HIP(hipMemcpyAsync(host, counters_.p, sizeof host, hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    dropped_points += (int)host[1];
+    const int dead = (int)host[0];
+    if (!dead) return PHX_OK;
+    PHX_TRY(erased_.reserve(dead));
+    hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, nm, mover_pos_.p);
+    hipLaunchKernelGGL(k_pack_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, (const unsigned*)flags_.p,
+                       (const unsigned*)counters_.p, (const int*)mover_pos_.p, erased_.p);
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipStreamSynchronize(stream_));
+    nm -= dead;
+    return broadphase_.erase_pairs_device(erased_.p, dead);                 // ref: Collider.cpp:391 manifoldMap.erase
 }
 
-void World::refresh_contact_joints()                                        // ref: World.cpp:72-149
+int World::refresh_contact_joints()                                         // ref: World.cpp:72-149
 {
-    for (auto& j : joints) j.contact_point_index = -1;
-    for (const phx_manifold& m : manifolds)
-        for (int k = 0; k < m.point_count; ++k) {
-            const int cpi = m.point_index + k;
-            phx_contact_point& cp = contact_points[cpi];
-            if (cp.solver_index < 0) {
-                cp.solver_index = (int)joints.size();
-                phx_contact_joint j;
-                j.contact_point_index = cpi; j.body1 = m.body1; j.body2 = m.body2;
-                j.normal_accumulated_impulse = 0.f; j.friction_accumulated_impulse = 0.f;
-                joints.push_back(j);
-            } else {
-                joints[cp.solver_index].contact_point_index = cpi;
-            }
+    PHX_TRY(scratch_for(std::max(nm, nj + 2 * nm)));
+    if (nj) hipLaunchKernelGGL(k_joints_reset, dim3(wgrid(nj)), dim3(256), 0, stream_, d_joints_.p, nj);
+    int fresh = 0;
+    if (nm) {
+        hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
+                           d_joints_.p, flags_.p);
+        PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
+        unsigned host = 0;
+        PHX_HIP(hipMemcpyAsync(&host, counters_.p, sizeof host, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        fresh = (int)host;
+        if (fresh) {
+            PHX_TRY(d_joints_.reserve_keep((size_t)nj + fresh, nj, stream_));
+            hipLaunchKernelGGL(k_joints_create, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, d_cps_.p, d_joints_.p, nj,
+                               (const unsigned*)flags_.p);
         }
-    for (size_t k = 0; k < joints.size();) {
-        if (joints[k].contact_point_index < 0) { joints[k] = joints.back(); joints.pop_back(); }
-        else { contact_points[joints[k].contact_point_index].solver_index = (int)k; ++k; }
     }
+    const int total = nj + fresh;
+    if (total) {
+        hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(total)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, total, flags_.p);
+        PHX_TRY(device_exclusive_scan(flags_.p, total, counters_.p, scan_tiles_.p, stream_));
+        unsigned host = 0;
+        PHX_HIP(hipMemcpyAsync(&host, counters_.p, sizeof host, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        const int dead = (int)host;
+        if (dead) {
+            hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, total, mover_pos_.p);
+            hipLaunchKernelGGL(k_joints_fill, dim3(wgrid(total)), dim3(256), 0, stream_, d_joints_.p, total, (const unsigned*)flags_.p, (const unsigned*)counters_.p,
+                               (const int*)mover_pos_.p);
+        }
+        nj = total - dead;
+        if (nj) hipLaunchKernelGGL(k_joints_publish, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, d_cps_.p);
+    } else nj = 0;
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipStreamSynchronize(stream_));
+    return PHX_OK;
 }
 
 int World::solve(const phx_config& cfg)                                     // ref: World.cpp:34
 {
-    if (shard_count <= 1)
-        return solver_.solve_host(bodies.data(), (int)bodies.size(), contact_points.data(), (int)contact_points.size(),
-                                  joints.data(), (int)joints.size(), cfg);
+    if (shard_count <= 1) {
+        PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg));
+        return solver_.synchronize();
+    }
     // island sharding: this rank solves the joints of islands whose index % shard_count == shard; islands are
-    // body-disjoint (static bodies aside), so the other shards' bodies simply keep their velocities here
-    const int nj = (int)joints.size(), nb = (int)bodies.size();
+    // body-disjoint (static bodies aside), so the other shards' bodies simply keep their velocities here.  The island
+    // partition is host logic (GatherIslands semantics), so this path stages through the host.
+    std::vector<phx_rigid_body> hb(std::max(nb(), 1));
+    std::vector<phx_contact_point> hc(std::max(2 * nm, 1));
+    std::vector<phx_contact_joint> hj(std::max(nj, 1));
+    PHX_TRY(download_bodies(hb.data(), nb()));
+    PHX_TRY(download_contact_points(hc.data(), 2 * nm));
+    PHX_TRY(download_joints(hj.data(), nj));
     std::vector<int> b1(nj), b2(nj), joint_island, island_size;
-    std::vector<unsigned char> is_static(nb);
-    for (int j = 0; j < nj; ++j) { b1[j] = joints[j].body1; b2[j] = joints[j].body2; }
-    for (int i = 0; i < nb; ++i) is_static[i] = (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f);
-    gather_islands(b1.data(), b2.data(), nj, is_static.data(), nb, joint_island, island_size);
+    std::vector<unsigned char> is_static(std::max(nb(), 1));
+    for (int j = 0; j < nj; ++j) { b1[j] = hj[j].body1; b2[j] = hj[j].body2; }
+    for (int i = 0; i < nb(); ++i) is_static[i] = (hb[i].inv_mass == 0.f && hb[i].inv_inertia == 0.f);
+    gather_islands(b1.data(), b2.data(), nj, is_static.data(), nb(), joint_island, island_size);
     std::vector<phx_contact_joint> mine;
     std::vector<int> where;
     for (int j = 0; j < nj; ++j)
-        if (joint_island[j] >= 0 && joint_island[j] % shard_count == shard) { mine.push_back(joints[j]); where.push_back(j); }
-    PHX_TRY(solver_.solve_host(bodies.data(), nb, contact_points.data(), (int)contact_points.size(), mine.data(), (int)mine.size(), cfg));
-    for (size_t k = 0; k < mine.size(); ++k) joints[where[k]] = mine[k];
+        if (joint_island[j] >= 0 && joint_island[j] % shard_count == shard) { mine.push_back(hj[j]); where.push_back(j); }
+    PHX_TRY(solver_.solve_host(hb.data(), nb(), hc.data(), 2 * nm, mine.data(), (int)mine.size(), cfg));
+    for (size_t k = 0; k < mine.size(); ++k) hj[where[k]] = mine[k];
+    if (nb()) PHX_HIP(hipMemcpyAsync(d_bodies_.p, hb.data(), (size_t)nb() * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
+    if (nj) PHX_HIP(hipMemcpyAsync(d_joints_.p, hj.data(), (size_t)nj * sizeof(phx_contact_joint), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
     return PHX_OK;
 }
 
 int World::pre_solve(float dt)
 {
     using clk = std::chrono::steady_clock;
+    PHX_TRY(use_device(device_));
+    PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
-    auto lap = [&](int phase) { auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
-    integrate_velocity(dt); lap(0);
-    // the device runs sort and sweep back to back; the host clock cannot split them, so the whole device
-    // broadphase is booked under UpdatePairs and UpdateBroadphase reads 0 (phx_broadphase_stats has device_ms)
+    auto lap = [&](int phase) { (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
+    if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt);   // ref: World.cpp:39-55
+    PHX_HIP(hipGetLastError());
+    lap(0);
+    // the device runs sort and sweep back to back; the host clock cannot split them, so the whole device broadphase
+    // is booked under UpdatePairs and UpdateBroadphase reads 0 (phx_broadphase_stats has the device time)
     phase_ms[1] = 0.0;
     PHX_TRY(update_pairs()); lap(2);
-    update_manifolds(); lap(3);
+    PHX_TRY(update_manifolds()); lap(3);
     PHX_TRY(pack_manifolds()); lap(4);
-    refresh_contact_joints(); lap(5);
+    PHX_TRY(refresh_contact_joints()); lap(5);
     return PHX_OK;
 }
 
 int World::finish_step(float dt, const phx_config& cfg)
 {
     using clk = std::chrono::steady_clock;
+    PHX_TRY(use_device(device_));
+    PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
-    auto lap = [&](int phase) { auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
+    auto lap = [&](int phase) { (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
     PHX_TRY(solve(cfg)); lap(6);
-    integrate_position(dt); lap(7);
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
+    PHX_HIP(hipGetLastError());
+    lap(7);
     return PHX_OK;
 }
 
@@ -253,6 +294,29 @@ int World::update(float dt, const phx_config& cfg)
 {
     PHX_TRY(pre_solve(dt));
     return finish_step(dt, cfg);
+}
+
+#define PHX_DOWNLOAD(fn, type, buf, count_expr)                                                                    \
+    int World::fn(type* out, int cap)                                                                                \
+    {                                                                                                                \
+        const int n = (count_expr);                                                                                  \
+        if (cap < n) { set_error(#fn ": buffer too small"); return PHX_ERR_CAPACITY; }                             \
+        PHX_TRY(use_device(device_));                                                                                \
+        if (n) PHX_HIP(hipMemcpy(out, buf.p, (size_t)n * sizeof(type), hipMemcpyDeviceToHost));                     \
+        return PHX_OK;                                                                                               \
+    }
+PHX_DOWNLOAD(download_manifolds, phx_manifold, d_manifolds_, nm)
+PHX_DOWNLOAD(download_contact_points, phx_contact_point, d_cps_, 2 * nm)
+PHX_DOWNLOAD(download_joints, phx_contact_joint, d_joints_, nj)
+
+int World::download_bodies(phx_rigid_body* out, int cap)
+{
+    const int n = nb();
+    if (cap < n) { set_error("download_bodies: buffer too small"); return PHX_ERR_CAPACITY; }
+    if (bodies_dirty_ || !d_bodies_.p) { if (n && out != host_bodies_.data()) std::memcpy(out, host_bodies_.data(), (size_t)n * sizeof(phx_rigid_body)); return PHX_OK; }
+    PHX_TRY(use_device(device_));
+    if (n) PHX_HIP(hipMemcpy(out, d_bodies_.p, (size_t)n * sizeof(phx_rigid_body), hipMemcpyDeviceToHost));
+    return PHX_OK;
 }
 
 } // namespace phx
@@ -290,10 +354,8 @@ int phx_world_add_body(phx_world* w, float px, float py, float angle, float hx, 
 int phx_world_set_body_static(phx_world* w, int32_t body)
 {
     PHX_REQUIRE(w, "null handle");
-    PHX_REQUIRE(body >= 0 && body < (int)w->impl.bodies.size(), "body index out of range");
-    w->impl.bodies[body].inv_mass = 0.f;
-    w->impl.bodies[body].inv_inertia = 0.f;
-    return PHX_OK;
+    PHX_REQUIRE(body >= 0 && body < w->impl.nb(), "body index out of range");
+    return w->impl.set_static(body);
 }
 
 int phx_world_set_gravity(phx_world* w, float g) { PHX_REQUIRE(w, "null handle"); w->impl.gravity = g; return PHX_OK; }
@@ -327,26 +389,17 @@ int phx_world_finish_step(phx_world* w, float dt, const phx_config* cfg)
 int phx_world_counts(phx_world* w, int32_t* nb, int32_t* nm, int32_t* ncp, int32_t* nj)
 {
     PHX_REQUIRE(w, "null handle");
-    if (nb) *nb = (int)w->impl.bodies.size();
-    if (nm) *nm = (int)w->impl.manifolds.size();
-    if (ncp) *ncp = (int)w->impl.contact_points.size();
-    if (nj) *nj = (int)w->impl.joints.size();
+    if (nb) *nb = w->impl.nb();
+    if (nm) *nm = w->impl.nm;
+    if (ncp) *ncp = 2 * w->impl.nm;
+    if (nj) *nj = w->impl.nj;
     return PHX_OK;
 }
 
-#define PHX_WORLD_GETTER(name, member, type)                                                         \
-    int name(phx_world* w, type* out, int32_t cap)                                                   \
-    {                                                                                                \
-        PHX_REQUIRE(w && out, "null handle / buffer");                                               \
-        const size_t n = w->impl.member.size();                                                      \
-        if ((size_t)cap < n) { phx::set_error(#name ": buffer too small"); return PHX_ERR_CAPACITY; } \
-        if (n) std::memcpy(out, w->impl.member.data(), n * sizeof(type));                            \
-        return PHX_OK;                                                                               \
-    }
-PHX_WORLD_GETTER(phx_world_get_bodies, bodies, phx_rigid_body)
-PHX_WORLD_GETTER(phx_world_get_manifolds, manifolds, phx_manifold)
-PHX_WORLD_GETTER(phx_world_get_contact_points, contact_points, phx_contact_point)
-PHX_WORLD_GETTER(phx_world_get_joints, joints, phx_contact_joint)
+int phx_world_get_bodies(phx_world* w, phx_rigid_body* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_bodies(out, cap); }
+int phx_world_get_manifolds(phx_world* w, phx_manifold* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_manifolds(out, cap); }
+int phx_world_get_contact_points(phx_world* w, phx_contact_point* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_contact_points(out, cap); }
+int phx_world_get_joints(phx_world* w, phx_contact_joint* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_joints(out, cap); }
 
 int phx_world_get_solve_stats(phx_world* w, phx_solve_stats* out) { PHX_REQUIRE(w, "null handle"); return w->impl.solver().get_stats(out); }
 int phx_world_get_broadphase_stats(phx_world* w, phx_broadphase_stats* out) { PHX_REQUIRE(w, "null handle"); return w->impl.broadphase().get_stats(out); }

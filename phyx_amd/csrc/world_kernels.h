@@ -1,0 +1,188 @@
+// world_kernels.h — the stages of World::Update that sit around the two hot halves, as HIP kernels, so that the
+// whole step runs on HBM-resident arrays.
+//
+//   IntegrateVelocity / IntegratePosition        ref: src/World.cpp:39-70
+//   manifold creation for new pairs              ref: src/Collider.cpp:313-316
+//   UpdateManifolds (SAT + contact generation)   ref: src/Collider.cpp:368-377 -> narrowphase.h
+//   PackManifolds                                ref: src/Collider.cpp:379-416
+//   RefreshContactJoints                         ref: src/World.cpp:72-149
+//
+// The last two are written sequentially in the reference (swap-remove while scanning forward), and the ORDER they
+// leave behind is semantics: joint order is solve order.  The parallel form reproduces that order exactly.  Scanning
+// i upward and replacing every dead a[i] by the current last element (re-examining i) ends with: survivors count
+// n' = n - dead; every dead position below n' (a "hole"), taken in ascending order, receives the live elements that
+// sat at positions >= n' (the "movers"), taken in DESCENDING order; everything else stays where it was.
+#pragma once
+
+#include "common.h"
+#include "narrowphase.h"
+
+namespace phx {
+
+static __global__ void __launch_bounds__(256) k_integrate_velocity(phx_rigid_body* __restrict__ bodies, int n, float gravity, float dt)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        phx_rigid_body& b = bodies[i];
+        float ax = b.acceleration.x, ay = b.acceleration.y;
+        if (b.inv_mass > 0.0f) ay += gravity;
+        b.velocity.x += ax * dt; b.velocity.y += ay * dt;
+        b.acceleration.x = 0.f; b.acceleration.y = 0.f;
+        b.angular_velocity += b.angular_acceleration * dt;
+        b.angular_acceleration = 0.f;
+    }
+}
+
+// Vector2::Rotate (ref: Vector2.h:48-56); the reference's unqualified cos/sin resolve to the double overloads
+__device__ __forceinline__ void rotate_vec(phx_vec2& v, float c, float s)
+{
+    const V2 x = v2(v), y = perp(x);
+    const V2 delta = (x * c + y * s) - x;
+    v.x = v.x + delta.x; v.y = v.y + delta.y;
+}
+
+static __global__ void __launch_bounds__(256) k_integrate_position(phx_rigid_body* __restrict__ bodies, int n, float dt)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        phx_rigid_body b = bodies[i];
+        b.pos.x += b.displacing_velocity.x + b.velocity.x * dt;
+        b.pos.y += b.displacing_velocity.y + b.velocity.y * dt;
+        const float ang = -(b.displacing_angular_velocity + b.angular_velocity * dt);
+        const float c = (float)cos((double)ang), s = (float)sin((double)ang);
+        rotate_vec(b.xvector, c, s);
+        rotate_vec(b.yvector, c, s);
+        b.displacing_velocity.x = 0.f; b.displacing_velocity.y = 0.f;
+        b.displacing_angular_velocity = 0.f;
+        update_geom(b);
+        bodies[i] = b;
+    }
+}
+
+// ref: Collider.cpp:313-316 — Manifold(index_i, index_j, manifolds.size * kMaxContactPoints), contact slots blank
+static __global__ void __launch_bounds__(256) k_append_manifolds(phx_manifold* __restrict__ manifolds, phx_contact_point* __restrict__ cps,
+                                                                 int nm_old, const uint2* __restrict__ pairs, int count)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const int m = nm_old + k;
+        phx_manifold mm;
+        mm.body1 = (int)pairs[k].x; mm.body2 = (int)pairs[k].y; mm.point_count = 0; mm.point_index = 2 * m;
+        manifolds[m] = mm;
+        phx_contact_point blank;
+        blank.delta1.x = blank.delta1.y = blank.delta2.x = blank.delta2.y = blank.normal.x = blank.normal.y = 0.f;
+        blank.is_merged = 0; blank.is_newly_created = 0; blank.pad_[0] = 0; blank.pad_[1] = 0; blank.solver_index = -1;
+        cps[2 * m] = blank; cps[2 * m + 1] = blank;
+    }
+}
+
+// ref: Collider.cpp:368-377; also flags the manifolds PackManifolds will drop (ref: Collider.cpp:387)
+static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, const phx_rigid_body* __restrict__ bodies,
+                                                                 phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+        phx_manifold m = manifolds[i];
+        if (update_manifold(m, bodies, cps + m.point_index)) atomicAdd(dropped, 1);
+        manifolds[i] = m;
+        dead[i] = (m.point_count == 0 && !aabb_intersects(bodies[m.body1], bodies[m.body2])) ? 1u : 0u;
+    }
+}
+
+// ---- hole-filling compaction ---------------------------------------------------------------------------
+// dead_before = exclusive scan of the dead flags; D = total dead; n' = n - D.
+// mover_pos[r] = position of the r-th live element counted from the end (only those at positions >= n').
+static __global__ void __launch_bounds__(256) k_compact_movers(const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
+                                                               int n, int* __restrict__ mover_pos)
+{
+    const int D = (int)*dead_total, live = n - D;
+    for (int p = live + blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int next = (p + 1 < n) ? (int)dead_before[p + 1] : D;
+        if (next != (int)dead_before[p]) continue;                       // p itself is dead
+        const int dead_after = D - (int)dead_before[p];
+        mover_pos[(n - 1 - p) - dead_after] = p;
+    }
+}
+
+// ref: Collider.cpp:385-410.  Every dead manifold's pair is listed for removal from the pair set; holes take movers.
+static __global__ void __launch_bounds__(256) k_pack_manifolds(phx_manifold* __restrict__ manifolds, phx_contact_point* __restrict__ cps, int nm,
+                                                               const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
+                                                               const int* __restrict__ mover_pos, uint2* __restrict__ erased)
+{
+    const int D = (int)*dead_total, live = nm - D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+        const int h = (int)dead_before[i];
+        const int next = (i + 1 < nm) ? (int)dead_before[i + 1] : D;
+        if (next == h) continue;                                          // live: stays
+        const phx_manifold gone = manifolds[i];
+        erased[h] = make_uint2((unsigned)gone.body1, (unsigned)gone.body2);
+        if (i >= live) continue;                                          // dead in the tail: just dropped
+        const phx_manifold me = manifolds[mover_pos[h]];
+        for (int k = 0; k < me.point_count; ++k) cps[2 * i + k] = cps[me.point_index + k];
+        phx_manifold m = me;
+        m.point_index = 2 * i;
+        manifolds[i] = m;
+    }
+}
+
+// ---- RefreshContactJoints (ref: World.cpp:72-149) -----------------------------------------------------------
+static __global__ void __launch_bounds__(256) k_joints_reset(phx_contact_joint* __restrict__ joints, int nj)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) joints[i].contact_point_index = -1;
+}
+
+// Match, pass 1: matched points re-attach their joint; count the points that need a new joint
+static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold* __restrict__ manifolds, int nm, const phx_contact_point* __restrict__ cps,
+                                                             phx_contact_joint* __restrict__ joints, unsigned* __restrict__ new_count)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+        const phx_manifold m = manifolds[i];
+        unsigned fresh = 0;
+        for (int k = 0; k < m.point_count; ++k) {
+            const int si = cps[m.point_index + k].solver_index;
+            if (si < 0) ++fresh;
+            else joints[si].contact_point_index = m.point_index + k;
+        }
+        new_count[i] = fresh;
+    }
+}
+
+// Match, pass 2: new joints appended in manifold order, then point order (ref: World.cpp:108-114)
+static __global__ void __launch_bounds__(256) k_joints_create(const phx_manifold* __restrict__ manifolds, int nm, phx_contact_point* __restrict__ cps,
+                                                              phx_contact_joint* __restrict__ joints, int nj_old, const unsigned* __restrict__ new_before)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+        const phx_manifold m = manifolds[i];
+        int at = nj_old + (int)new_before[i];
+        for (int k = 0; k < m.point_count; ++k) {
+            phx_contact_point& cp = cps[m.point_index + k];
+            if (cp.solver_index >= 0) continue;
+            cp.solver_index = at;
+            phx_contact_joint j;
+            j.contact_point_index = m.point_index + k; j.body1 = m.body1; j.body2 = m.body2;
+            j.normal_accumulated_impulse = 0.f; j.friction_accumulated_impulse = 0.f;
+            joints[at++] = j;
+        }
+    }
+}
+
+static __global__ void __launch_bounds__(256) k_joints_flag_dead(const phx_contact_joint* __restrict__ joints, int nj, unsigned* __restrict__ dead)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) dead[i] = joints[i].contact_point_index < 0 ? 1u : 0u;
+}
+
+// Cleanup (ref: World.cpp:125-143): holes take movers
+static __global__ void __launch_bounds__(256) k_joints_fill(phx_contact_joint* __restrict__ joints, int nj, const unsigned* __restrict__ dead_before,
+                                                            const unsigned* __restrict__ dead_total, const int* __restrict__ mover_pos)
+{
+    const int D = (int)*dead_total, live = nj - D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < live; i += gridDim.x * blockDim.x) {
+        const int h = (int)dead_before[i];
+        const int next = (i + 1 < nj) ? (int)dead_before[i + 1] : D;
+        if (next == h) continue;
+        joints[i] = joints[mover_pos[h]];
+    }
+}
+
+static __global__ void __launch_bounds__(256) k_joints_publish(const phx_contact_joint* __restrict__ joints, int nj, phx_contact_point* __restrict__ cps)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) cps[joints[i].contact_point_index].solver_index = i;
+}
+
+} // namespace phx
