@@ -3,6 +3,7 @@
 #include "solver_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <numeric>
 
@@ -100,6 +101,9 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     if (!force_rebuild && sched_.valid && sched_.fingerprint == fp && nb == nb_ && nj == nj_ && sched_.islands == want_islands) { raw_fingerprint_ = raw; return PHX_OK; }
 
     // 2. topology changed: pull the body pairs + static flags, build the schedule on the host, push it
+    const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     DevBuf<int2> d_pairs;
     DevBuf<unsigned char> d_static;
     PHX_TRY(d_pairs.reserve(std::max(nj, 1)));
@@ -113,6 +117,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_HIP(hipStreamSynchronize(stream_));
     d_pairs.release();
     d_static.release();
+    lap("download");
 
     std::vector<int> b1(nj), b2(nj);
     for (int j = 0; j < nj; ++j) {
@@ -127,13 +132,15 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
     }
+    lap("build");
     if (sched_.ncolours() > 65000) { set_error("more than 65000 colours"); return PHX_ERR_INVALID; }
-    {
+    if (!want_islands) {       // the island-aware builder publishes GatherIslands' numbers itself
         std::vector<int> joint_island, island_size;
         gather_islands(b1.data(), b2.data(), nj, is_static.data(), nb, joint_island, island_size);
         sched_.island_count = (int)island_size.size();
         sched_.island_max_size = island_size.empty() ? 0 : *std::max_element(island_size.begin(), island_size.end());
     }
+    lap("gather_islands");
     h_static_slot_.assign(nb, -1);
     nstatic_ = 0;
     for (int i = 0; i < nb; ++i) if (is_static[i]) h_static_slot_[i] = nstatic_++;
@@ -174,6 +181,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     if (!sched_.hbm_bodies.empty())
         PHX_HIP(hipMemcpyAsync(hbm_body_list_.p, sched_.hbm_bodies.data(), sched_.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
+    lap("upload");
     sched_.fingerprint = fp;
     raw_fingerprint_ = raw;
     sched_.valid = true;
