@@ -24,6 +24,7 @@ struct Schedule {
     std::vector<int> group_offsets;       // ngroups + 1 (slots)
     std::vector<int> group_first_colour;  // ngroups + 1 (indices into colour_offsets)
     int lds_groups = 0;                   // leading groups solved out of LDS; the rest (0 or 1 group) out of HBM
+    int lds_lanes = 0;                    // joint capacity the LDS groups were binned for (selects the kernel shape)
     // per LDS group g: its bodies = group_bodies[group_body_offsets[g] .. group_body_offsets[g+1])
     std::vector<int> group_body_offsets;
     std::vector<int> group_bodies;
@@ -46,8 +47,9 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
 
 // Island-aware schedule: connected components binned into LDS groups where they fit `caps`, the rest in one
 // trailing HBM group.
+// `big` (optional) is a roomier shape used for ALL groups when some component fits it but not `caps`.
 void build_island_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
-                           const LdsCaps& caps, Schedule& out);
+                           const LdsCaps& caps, Schedule& out, const LdsCaps* big = nullptr);
 
 // Solver::GatherIslands semantics (ref: Solver.cpp:285-454): per-joint coalesced island id (-1 for
 // static-static joints) and per-island joint counts.

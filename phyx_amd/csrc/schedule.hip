@@ -257,7 +257,7 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
 } // namespace
 
 void build_island_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
-                           const LdsCaps& caps, Schedule& out)
+                           const LdsCaps& small_caps, Schedule& out, const LdsCaps* big)
 {
     reset(out);
     out.islands = true;
@@ -285,6 +285,14 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         }
         out.island_count = count; out.island_max_size = mx;
     }
+    // pick the workgroup shape: the roomier one only if some component needs it and fits it
+    LdsCaps caps = small_caps;
+    if (big) {
+        int need = 0;
+        for (int c = 0; c < ncomp; ++c) { const int n = comp_count[c + 1] - comp_count[c]; if (n > small_caps.max_joints && n <= big->max_joints) need = std::max(need, n); }
+        if (need) caps = *big;
+    }
+    out.lds_lanes = caps.max_joints;
     // greedy binning of consecutive components (serial, one pass); oversized components go to the HBM group whole
     std::vector<int> rest;
     std::vector<std::pair<int, int>> bins;       // [first component, last component)

@@ -128,7 +128,9 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         LdsCaps caps;
         if (wave_islands_) { caps.max_joints = ISW_J; caps.max_bodies = ISW_B; caps.max_colours = 4096; caps.max_static = ISW_S; }
         else { caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64; }
-        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_);
+        LdsCaps big;
+        big.max_joints = ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
+        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, wave_islands_ ? nullptr : &big);
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
     }
@@ -237,7 +239,10 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
             wv.slot_local = slot_local_.p; wv.executed = isl_stats_.p; wv.visits = isl_visits_.p;
             hipLaunchKernelGGL(k_solve_islands_wave, dim3(lg), dim3(64), 0, stream_, v, wv, d_bodies, d_joints, d_cps, ci, pi);
         } else {
-            hipLaunchKernelGGL(k_solve_islands, dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            if (sched_.lds_lanes > ISL_T)
+                hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG>), dim3(lg), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else
+                hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B>), dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         }
         ++sweep_launches_;
     }

@@ -293,8 +293,10 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
 // the group's body velocities live in LDS, colours are separated by workgroup barriers instead of kernel
 // launches, and HBM is touched once on the way in and once on the way out.  The early exit of ref: Solver.cpp:189
 // / :210 is per group, exactly like the reference's per-island loop.
-constexpr int ISL_T = 512;     // lanes = joint capacity of a group
-constexpr int ISL_B = 768;     // body capacity of a group (dynamic + the static ones it touches)
+// Two shapes: 512 lanes / 768 bodies (4 workgroups per CU — the 200-box columns of cfg 2 are 410 joints each) and
+// 1024 lanes / 1024 bodies (2 per CU — the 500-box columns of cfg 5 are ~1020 joints each).
+constexpr int ISL_T = 512, ISL_B = 768;        // lanes = joint capacity of a group; body capacity (dynamic + touched static)
+constexpr int ISL_T_BIG = 1024, ISL_B_BIG = 1024;
 
 struct IslandView {
     const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
@@ -306,7 +308,8 @@ struct IslandView {
     unsigned long long* visits;       // sum over groups of impulse sweeps * joints
 };
 
-__device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[ISL_B], int body, int iter, int colour)
+template <int B>
+__device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[B], int body, int iter, int colour)
 {
     if (iter == 0) return true;
     if ((sw[(iter - 1) & 1][body] >> 16) == (unsigned)iter) return true;
@@ -314,25 +317,26 @@ __device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[ISL_B
     return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
 }
 
-__global__ void __launch_bounds__(ISL_T, 8) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
+template <int T, int NB>
+__global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
                                                             phx_contact_joint* __restrict__ joints,
                                                             const phx_contact_point* __restrict__ cps, int ci, int pi)
 {
-    __shared__ float4 imp[ISL_B];
-    __shared__ float4 disp[ISL_B];
+    __shared__ float4 imp[NB];
+    __shared__ float4 disp[NB];
     // static-tag words [imp|disp][parity][body]; during set-up the same 12 KB hold {invMass, invInertia, pos} per body
-    __shared__ __attribute__((aligned(16))) unsigned sw_raw[4 * ISL_B];
-    __shared__ unsigned char is_st[ISL_B];
+    __shared__ __attribute__((aligned(16))) unsigned sw_raw[4 * NB];
+    __shared__ unsigned char is_st[NB];
     __shared__ int flag_imp[2], flag_disp[2];
-    unsigned (*swi)[ISL_B] = reinterpret_cast<unsigned (*)[ISL_B]>(sw_raw);
-    unsigned (*swd)[ISL_B] = reinterpret_cast<unsigned (*)[ISL_B]>(sw_raw + 2 * ISL_B);
+    unsigned (*swi)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw);
+    unsigned (*swd)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw + 2 * NB);
     float4* par = reinterpret_cast<float4*>(sw_raw);
 
     const int4 d = iv.desc[blockIdx.x];
     const int ncol = iv.ncol[blockIdx.x];
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < d.w; i += ISL_T) {
+    for (int i = tid; i < d.w; i += T) {
         // PrepareBodies (ref: Solver.cpp:456-480) straight from the 128-byte records
         const phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
         imp[i] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(ISL_T, 8) k_solve_islands(SolverView v, Island
         im1 = p1.x; ii1 = p1.y; im2 = p2.x; ii2 = p2.y;
     }
     __syncthreads();
-    for (int i = tid; i < 4 * ISL_B; i += ISL_T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
+    for (int i = tid; i < 4 * NB; i += T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
     const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
     const float tx = -ny, ty = nx;
     __syncthreads();
@@ -484,7 +488,7 @@ __global__ void __launch_bounds__(ISL_T, 8) k_solve_islands(SolverView v, Island
         j.normal_accumulated_impulse = accN;
         j.friction_accumulated_impulse = accF;
     }
-    for (int i = tid; i < d.w; i += ISL_T) {               // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
+    for (int i = tid; i < d.w; i += T) {               // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
         if (is_st[i]) continue;
         phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
         const float4 a = imp[i], e = disp[i];

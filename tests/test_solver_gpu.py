@@ -242,3 +242,27 @@ def test_speculative_schedule_is_verified(solver, oracle):
     gb2, gj2, sched2, _, _ = _device_solve(solver, a, cfg)          # the solver still works afterwards
     ob2, oj2, _ = _oracle_in_device_order(oracle, a, sched2, None, cfg, oracle.STAG_COLOUR_SYNC)
     assert gb2.tobytes() == ob2.tobytes() and gj2.tobytes() == oj2.tobytes()
+
+
+def test_tall_columns_use_the_1024_lane_island_shape(solver, oracle):
+    """Columns of 500 boxes are ~1020 joints each: too big for the 512-lane workgroup, they take the 1024-lane
+    shape instead of falling back to HBM (BASELINE config 5 geometry, 50 iterations)."""
+    state = presolve_state(scenes.stack(6, 500), 3, iters=50)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, 50, 50)
+    gb, gj, sched, _, st = _device_solve(solver, state, cfg)
+    sizes = np.diff(sched.groups)
+    assert sched.lds_groups == len(sizes) and sizes.max() > 512 and sizes.max() <= 1024
+    ob_, oj, ost = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+    assert st.impulse_iterations == ost.impulse_iterations and st.joint_visits == ost.joint_visits
+
+
+def test_full_size_500k_boxes_50_iterations(solver, oracle):
+    """BASELINE config 5 size: stack(1000,500) = 500 001 bodies, ~1e6 joints, 50+50 iterations (fp32 body state)."""
+    state = presolve_state(scenes.stack(1000, 500), 2, iters=50)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, 50, 50)
+    gb, gj, sched, _, st = _device_solve(solver, state, cfg)
+    assert len(state[2]) > 900000 and st.lds_islands >= 900
+    ob_, oj, ost = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+    assert (gj["normal_acc"] >= 0).all()
