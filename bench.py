@@ -166,10 +166,55 @@ def main():
                 "ms_per_step": 1e3 * single_tot["elapsed"] / k, "joint_visits_per_sec": single_tot["visits"] / single_tot["elapsed"],
                 "colours": sst.colour_count, "impulse_sweeps_per_step": sst.impulse_iterations,
                 "roofline": roofline(single_tot, k, "k_solve_colour<impulse,displacement>")}
+        if world == 1 and not args.no_secondary:
+            out["extra"]["other_configs"] = other_configs(phyx_amd, scenes, Configuration, device, world_obj, cfg)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bodies, cps, joints, args.iters, args.cpu_seconds)
         print(json.dumps(out))
     group.shutdown()
+
+
+def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
+    """Untimed-by-the-driver side measurements of the other BASELINE.json configs (N=1): the whole device-resident
+    World::Update at cfg 2 size, the broadphase at cfg 4 size (1M boxes) and the solver at cfg 5 size (500k boxes,
+    50 iterations).  They are parity-test cases first (tests/test_*_gpu.py); the numbers here are informational."""
+    res = {}
+    # cfg 2, whole step (ref: World.cpp:19-37), topology still changing (new contacts every step)
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter(); cfg2_world.FinishStep(1.0 / 60.0, cfg2); cfg2_world.PreSolve(1.0 / 60.0); t.append(time.perf_counter() - t0)
+    ph = cfg2_world.phase_ms()
+    res["cfg2_world_step"] = {"ms_per_step": 1e3 * float(np.median(t)), "phases_ms": {k: round(v, 3) for k, v in ph.items()},
+                              "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), cfg2_world.counts()))}
+    # cfg 4: 1M boxes, broadphase-heavy
+    w4 = phyx_amd.World(device, gravity=-200.0)
+    w4.add_scene(scenes.stack(10000, 100))
+    for _ in range(3):
+        w4.Update(1.0 / 60.0, cfg2)
+    bs = w4.collider.stats()
+    t0 = time.perf_counter(); w4.Update(1.0 / 60.0, cfg2); step4 = time.perf_counter() - t0
+    bs = w4.collider.stats()
+    # algorithmic bytes (SURVEY.md §8d): 112 B per body for key build + radix sort + gather, 20 B per candidate test
+    alg = 112.0 * w4.counts()[0] + 20.0 * bs.candidate_tests
+    res["cfg4_broadphase_1M"] = {"device_ms": bs.device_ms, "candidate_tests": bs.candidate_tests, "new_pairs": bs.new_pairs,
+                                 "algorithmic_GBps": alg / (bs.device_ms * 1e-3) / 1e9, "world_step_ms": 1e3 * step4,
+                                 "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), w4.counts()))}
+    del w4
+    # cfg 5: 500k boxes tall stack, 50 iterations, fp32 body state
+    cfg5 = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, 50, 50)
+    w5 = phyx_amd.World(device, gravity=-200.0)
+    w5.add_scene(scenes.stack(1000, 500))
+    for _ in range(3):
+        w5.Update(1.0 / 60.0, cfg5)
+    w5.PreSolve(1.0 / 60.0)
+    arrs = [phyx_amd.DeviceArray(a, device) for a in (w5.bodies, w5.contactPoints, w5.contactJoints)]
+    s5 = phyx_amd.Solver(device)
+    s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 2, 0)
+    t0 = time.perf_counter(); r = s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 0, 10); el = time.perf_counter() - t0
+    st = s5.stats()
+    res["cfg5_500k_tall_50it_fp32"] = {"ms_per_step": 1e3 * el / 10, "joint_visits_per_sec": r.joint_visits / el, "joints": arrs[2].count,
+                                       "impulse_sweeps": st.impulse_iterations, "lds_islands": st.lds_islands, "sweep_ms_per_step": r.impulse_kernel_ms / 10}
+    return res
 
 
 def cpu_baseline(bodies, cps, joints, iters, budget_s):
