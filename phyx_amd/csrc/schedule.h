@@ -13,6 +13,7 @@
 // copy of their lastIteration tag.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
@@ -31,11 +32,19 @@ struct Schedule {
     std::vector<uint32_t> slot_local;     // per slot of an LDS group: local body1 | local body2 << 16
     std::vector<uint8_t> slot_colour;     // per slot of an LDS group: colour index inside the group
     std::vector<int> hbm_bodies;          // bodies touched by the HBM group (the only ones it stages / writes back)
+    std::vector<int> hbm_colour_offsets;  // slots of the HBM group's colours (absolute), empty if there is no HBM group
+    // A schedule built on the device keeps the LDS groups' order / colours in HBM only; `lds_on_host` says whether
+    // order[], colour_offsets[], group_first_colour[] above already cover the LDS groups (DeviceSolver::materialise).
+    bool lds_on_host = true;
+    int lds_colours = 0;                  // sum of the LDS groups' colour counts
     int island_count = 1, island_max_size = 0;   // GatherIslands' published numbers (ref: Solver.h:105-106)
     unsigned long long fingerprint = 0;
     bool valid = false, islands = false;
     int ngroups() const { return (int)group_offsets.size() - 1; }
-    int ncolours() const { return (int)colour_offsets.size() - 1; }
+    int ncolours() const { return lds_on_host ? (int)colour_offsets.size() - 1 : lds_colours + std::max(0, (int)hbm_colour_offsets.size() - 1); }
+    bool has_hbm_group() const { return hbm_colour_offsets.size() > 1; }
+    int hbm_begin() const { return has_hbm_group() ? hbm_colour_offsets.front() : 0; }
+    int hbm_end() const { return has_hbm_group() ? hbm_colour_offsets.back() : 0; }
 };
 
 struct LdsCaps { int max_joints = 512, max_bodies = 768, max_colours = 64, max_static = 1 << 30; };

@@ -100,7 +100,10 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
     for (int j = 0; j < nj; ++j) all[j] = j;
     ColourScratch scratch;
     const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch);
-    if (nj) append_group(out, all, colour, ncol);
+    if (nj) {
+        append_group(out, all, colour, ncol);
+        out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
+    }
     out.lds_groups = 0;
     out.islands = false;
     std::vector<unsigned char> seen(nb, 0);
@@ -343,13 +346,16 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         out.group_body_offsets.push_back((int)out.group_bodies.size());
         out.lds_groups++;
     }
+    out.lds_colours = (int)out.colour_offsets.size() - 1;
     for (int j = 0; j < nj; ++j) if (comp_of[j] < 0) rest.push_back(j);
     if (!rest.empty()) {
         std::sort(rest.begin(), rest.end());
         std::vector<int> colour;
         ColourScratch scratch;
         const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch);
+        const size_t first = out.colour_offsets.size() - 1;
         append_group(out, rest, colour, ncol);
+        out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
         std::vector<unsigned char> seen(nb, 0);
         for (int j : rest)
             for (int b : {body1[j], body2[j]})

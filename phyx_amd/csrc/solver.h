@@ -49,6 +49,8 @@ public:
 
 private:
     int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild);
+    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool* fallback);
+    int materialise_schedule();
     int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     struct GraphKey {
         const void *bodies = nullptr, *cps = nullptr, *joints = nullptr;
@@ -86,6 +88,13 @@ private:
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;
     DevBuf<unsigned long long> isl_visits_;
+    // device schedule builder scratch
+    DevBuf<int> cc_parent_, joint_comp_, bin_of_comp_, grp_goff_, sb_small_;
+    DevBuf<unsigned char> cc_static_;
+    DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_, sort_scan_;
+    DevBuf<int2> rest_pairs_;
+    std::vector<int> rest_order_;      // HBM group's slots (joint ids), kept on the host for materialise_schedule()
+    bool gpu_builder_ = true;
     DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;
     // staging for the host-pointer entry point

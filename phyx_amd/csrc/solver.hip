@@ -1,6 +1,8 @@
 // solver.hip — DeviceSolver: schedule construction on the host, residency and launch sequence.
 #include "solver.h"
 #include "solver_kernels.h"
+#include "schedule_kernels.h"
+#include "device_radix.h"
 
 #include <algorithm>
 #include <chrono>
@@ -34,6 +36,9 @@ DeviceSolver::~DeviceSolver()
     for (hipEvent_t e : bench_events_) (void)hipEventDestroy(e);
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
+    cc_parent_.release(); joint_comp_.release(); bin_of_comp_.release(); grp_goff_.release(); sb_small_.release(); cc_static_.release();
+    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); rest_pairs_.release();
+    for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_colours_.release(); colour_offsets_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -56,6 +61,8 @@ int DeviceSolver::init()
     PHX_TRY(isl_visits_.reserve(1));
     const char* g = getenv("PHX_NO_GRAPHS");
     use_graphs_ = !(g && g[0] == '1');
+    const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
+    gpu_builder_ = !(sb && sb[0] == 'h');
     const char* sp = getenv("PHX_NO_SPECULATION");
     speculate_ = !(sp && sp[0] == '1');
     const char* wv = getenv("PHX_ISLAND_KERNEL");      // "wave" = one wavefront per island (measured 5x slower: a lone wave exposes every instruction latency); default = one 512-lane workgroup per island
@@ -100,7 +107,23 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !(getenv("PHX_NO_ISLANDS") && getenv("PHX_NO_ISLANDS")[0] == '1');
     if (!force_rebuild && sched_.valid && sched_.fingerprint == fp && nb == nb_ && nj == nj_ && sched_.islands == want_islands) { raw_fingerprint_ = raw; return PHX_OK; }
 
-    // 2. topology changed: pull the body pairs + static flags, build the schedule on the host, push it
+    // 2. topology changed.  Island-aware schedules are built on the device (only component sizes cross PCIe);
+    //    the host builder below is the specification and the fallback (Single mode, bins that exceed the caps, ...).
+    if (want_islands && gpu_builder_ && !wave_islands_) {
+        bool fallback = false;
+        nb_ = nb; nj_ = nj;
+        PHX_TRY(build_schedule_device(d_bodies, nb, d_joints, nj, &fallback));
+        if (!fallback) {
+            sched_.fingerprint = fp;
+            raw_fingerprint_ = raw;
+            sched_.valid = true;
+            ++schedule_version_;
+            drop_graphs();
+            stats_.recoloured = 1;
+            return PHX_OK;
+        }
+        sched_.valid = false;
+    }
     const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
@@ -193,6 +216,211 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     return PHX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// device schedule builder (kernels: schedule_kernels.h)
+
+__global__ void __launch_bounds__(256) k_extract_pairs(const phx_contact_joint* __restrict__ joints, const unsigned* __restrict__ ids, int n, int2* __restrict__ pairs)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const phx_contact_joint& j = joints[ids[i]];
+        pairs[i] = make_int2(j.body1, j.body2);
+    }
+}
+
+int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool* fallback)
+{
+    *fallback = false;
+    const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
+    const int nbs = std::max(nb, 1), njs = std::max(nj, 1);
+    PHX_TRY(cc_parent_.reserve(nbs)); PHX_TRY(cc_static_.reserve(nbs)); PHX_TRY(cc_flags_.reserve(nbs + 1)); PHX_TRY(comp_size_.reserve(nbs + 1));
+    PHX_TRY(joint_comp_.reserve(njs)); PHX_TRY(sb_small_.reserve(8));
+    for (int k = 0; k < 2; ++k) { PHX_TRY(sort_keys_[k].reserve(njs)); PHX_TRY(sort_vals_[k].reserve(njs)); }
+    PHX_TRY(sort_hist_.reserve((size_t)RS_BINS * std::max(1, div_up(nj, RS_TILE))));
+    PHX_TRY(sort_scan_.reserve((size_t)div_up(std::max(std::max(nb, nj), RS_BINS * div_up(njs, RS_TILE)), SCAN_TILE) + 2));
+    PHX_TRY(order_.reserve(njs));
+
+    // 1. connected components
+    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p);
+    for (int round = 0;; ++round) {
+        if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
+        int changed = 0;
+        PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));
+        hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
+        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb);
+        PHX_HIP(hipMemcpyAsync(&changed, sb_small_.p, sizeof changed, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        if (!changed) break;
+    }
+    lap("components");
+    // 2. number the components in body order, count their joints
+    hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
+    PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
+    unsigned ncomp_u = 0;
+    PHX_HIP(hipMemcpyAsync(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    const int ncomp = (int)ncomp_u;
+    PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)std::max(ncomp, 1) * sizeof(unsigned), stream_));
+    hipLaunchKernelGGL(k_joint_components, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p, (const unsigned*)cc_flags_.p,
+                       joint_comp_.p, comp_size_.p);
+    std::vector<unsigned> comp_size(std::max(ncomp, 1));
+    PHX_HIP(hipMemcpyAsync(comp_size.data(), comp_size_.p, (size_t)ncomp * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    lap("count");
+
+    // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
+    //    (identical to schedule.hip::build_island_schedule — ncomp integers of work)
+    Schedule sc;
+    sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
+    sc.islands = true; sc.lds_on_host = false;
+    {
+        int run = 0, count = 0, mx = 0;
+        for (int c = 0; c < ncomp; ++c) {
+            run += (int)comp_size[c];
+            if (run >= 256 || (run > 0 && c == ncomp - 1)) { ++count; mx = std::max(mx, run); run = 0; }
+        }
+        sc.island_count = count; sc.island_max_size = mx;
+    }
+    int cap_joints = ISL_T, cap_bodies = ISL_B;
+    for (int c = 0; c < ncomp; ++c) if ((int)comp_size[c] > ISL_T && (int)comp_size[c] <= ISL_T_BIG) { cap_joints = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
+    sc.lds_lanes = cap_joints;
+    std::vector<int> bin_of(std::max(ncomp, 1), -1);
+    int nbins = 0;
+    {
+        int size = 0;
+        bool open = false;
+        for (int c = 0; c < ncomp; ++c) {
+            const int n = (int)comp_size[c];
+            if (n == 0) continue;
+            if (n > cap_joints) { open = false; size = 0; continue; }            // -> HBM group
+            if (!open || size + n > cap_joints) { sc.group_offsets.push_back(sc.group_offsets.back()); ++nbins; open = true; size = 0; }
+            bin_of[c] = nbins - 1;
+            size += n;
+            sc.group_offsets.back() += n;
+        }
+    }
+    const int lds_slots = sc.group_offsets.back();
+    const int rest = nj - lds_slots;
+    for (int c = 0; c < ncomp; ++c) if (bin_of[c] < 0) bin_of[c] = nbins;
+    sc.lds_groups = nbins;
+    PHX_TRY(bin_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(grp_goff_.reserve(nbins + 2));
+    if (ncomp) PHX_HIP(hipMemcpyAsync(bin_of_comp_.p, bin_of.data(), (size_t)ncomp * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipMemcpyAsync(grp_goff_.p, sc.group_offsets.data(), (size_t)(nbins + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
+    lap("bin");
+
+    // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
+    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)bin_of_comp_.p, nj, nbins,
+                       sort_keys_[0].p, sort_vals_[0].p);
+    int bits = 1;
+    while ((1 << bits) <= nbins) ++bits;
+    int where = 0;
+    PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_.p, stream_, &where));
+    lap("sort");
+
+    // 5. one workgroup per bin: body table, colouring, slot arrays
+    PHX_TRY(grp_desc_.reserve(std::max(nbins, 1))); PHX_TRY(grp_ncol_.reserve(std::max(nbins, 1)));
+    PHX_TRY(grp_bodies_.reserve((size_t)std::max(nbins, 1) * cap_bodies));
+    PHX_TRY(slot_local_.reserve(std::max(lds_slots, 1))); PHX_TRY(slot_colour_.reserve(std::max(lds_slots, 1)));
+    PHX_HIP(hipMemsetAsync(sb_small_.p + 2, 0, sizeof(int), stream_));
+    if (nbins) {
+        BinBuildView bv{};
+        bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff_.p; bv.joints = d_joints; bv.is_static = cc_static_.p;
+        bv.nb = nb; bv.max_static = 1 << 30;
+        bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
+        bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2;
+        if (cap_joints > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(ISL_T_BIG), 0, stream_, bv);
+        else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(ISL_T), 0, stream_, bv);
+    }
+    PHX_HIP(hipGetLastError());
+    int rejected = 0;
+    std::vector<int> ncol(std::max(nbins, 1), 0);
+    PHX_HIP(hipMemcpyAsync(&rejected, sb_small_.p + 2, sizeof rejected, hipMemcpyDeviceToHost, stream_));
+    if (nbins) PHX_HIP(hipMemcpyAsync(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    lap("bins");
+    if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
+    sc.lds_colours = 0;
+    for (int g = 0; g < nbins; ++g) sc.lds_colours += ncol[g];
+
+    // 6. the HBM group (components too big for a workgroup, static-static joints): coloured on the host from its own
+    //    body pairs only
+    rest_order_.clear();
+    nstatic_ = 0;
+    if (rest > 0) {
+        PHX_TRY(rest_pairs_.reserve(rest));
+        hipLaunchKernelGGL(k_extract_pairs, dim3(grid_for(rest)), dim3(256), 0, stream_, d_joints, (const unsigned*)(sort_vals_[where].p + lds_slots), rest, rest_pairs_.p);
+        std::vector<int2> pairs(rest);
+        std::vector<unsigned> ids(rest);
+        std::vector<unsigned char> is_static(nbs);
+        PHX_HIP(hipMemcpyAsync(pairs.data(), rest_pairs_.p, (size_t)rest * sizeof(int2), hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipMemcpyAsync(ids.data(), sort_vals_[where].p + lds_slots, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipMemcpyAsync(is_static.data(), cc_static_.p, (size_t)nb, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        std::vector<int> b1(rest), b2(rest);
+        for (int k = 0; k < rest; ++k) {
+            b1[k] = pairs[k].x; b2[k] = pairs[k].y;
+            if ((unsigned)b1[k] >= (unsigned)nb || (unsigned)b2[k] >= (unsigned)nb) { set_error("joint %u references body out of range", ids[k]); return PHX_ERR_INVALID; }
+        }
+        Schedule hs;
+        build_colour_schedule(b1.data(), b2.data(), rest, is_static.data(), nb, hs);      // ids[] is ascending, so this is joint order
+        rest_order_.resize(rest);
+        for (int k = 0; k < rest; ++k) rest_order_[k] = (int)ids[hs.order[k]];
+        sc.hbm_colour_offsets.resize(hs.colour_offsets.size());
+        for (size_t c = 0; c < hs.colour_offsets.size(); ++c) sc.hbm_colour_offsets[c] = lds_slots + hs.colour_offsets[c];
+        sc.hbm_bodies = hs.hbm_bodies;
+        sc.group_offsets.push_back(nj);
+        PHX_HIP(hipMemcpyAsync(order_.p + lds_slots, rest_order_.data(), (size_t)rest * sizeof(int), hipMemcpyHostToDevice, stream_));
+        h_static_slot_.assign(nb, -1);
+        for (int i = 0; i < nb; ++i) if (is_static[i]) h_static_slot_[i] = nstatic_++;
+        PHX_TRY(static_slot_.reserve(nbs)); PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sc.hbm_bodies.size(), 1)));
+        PHX_HIP(hipMemcpyAsync(static_slot_.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(hbm_body_list_.p, sc.hbm_bodies.data(), sc.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs)); PHX_TRY(sb_par_.reserve(nbs));
+        PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs));
+        PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
+        PHX_HIP(hipStreamSynchronize(stream_));
+    }
+    PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
+    lap("rest");
+    sched_ = std::move(sc);
+    return PHX_OK;
+}
+
+// The LDS groups of a device-built schedule live in HBM; the query API (and the parity tests that replay the
+// schedule through the oracle) need them on the host.
+int DeviceSolver::materialise_schedule()
+{
+    if (sched_.lds_on_host) return PHX_OK;
+    const int lg = sched_.lds_groups;
+    const int lds_slots = lg ? sched_.group_offsets[lg] : 0;
+    std::vector<int> order(std::max(lds_slots, 1)), ncol(std::max(lg, 1));
+    std::vector<unsigned char> colour(std::max(lds_slots, 1));
+    PHX_TRY(use_device(device_));
+    if (lds_slots) {
+        PHX_HIP(hipMemcpy(order.data(), order_.p, (size_t)lds_slots * sizeof(int), hipMemcpyDeviceToHost));
+        PHX_HIP(hipMemcpy(colour.data(), slot_colour_.p, (size_t)lds_slots, hipMemcpyDeviceToHost));
+        PHX_HIP(hipMemcpy(ncol.data(), grp_ncol_.p, (size_t)lg * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    sched_.order.assign(order.begin(), order.begin() + lds_slots);
+    sched_.order.insert(sched_.order.end(), rest_order_.begin(), rest_order_.end());
+    sched_.colour_offsets.assign(1, 0);
+    sched_.group_first_colour.assign(1, 0);
+    for (int g = 0; g < lg; ++g) {
+        std::vector<int> count(ncol[g], 0);
+        for (int s = sched_.group_offsets[g]; s < sched_.group_offsets[g + 1]; ++s) count[colour[s]]++;
+        int at = sched_.group_offsets[g];
+        for (int c = 0; c < ncol[g]; ++c) { at += count[c]; sched_.colour_offsets.push_back(at); }
+        sched_.group_first_colour.push_back((int)sched_.colour_offsets.size() - 1);
+    }
+    if (sched_.has_hbm_group()) {
+        for (size_t c = 1; c < sched_.hbm_colour_offsets.size(); ++c) sched_.colour_offsets.push_back(sched_.hbm_colour_offsets[c]);
+        sched_.group_first_colour.push_back((int)sched_.colour_offsets.size() - 1);
+    }
+    sched_.lds_on_host = true;
+    return PHX_OK;
+}
+
 // The launch sequence of one SolveJoints, in three capturable segments (no sync, no allocation inside):
 //   pre    PrepareBodies, PrepareJoints+RefreshJoints, PreStepJoints colour by colour
 //   sweeps `iters` x colours fused impulse+displacement launches
@@ -206,15 +434,14 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     PHX_HIP(hipMemsetAsync(isl_visits_.p, 0, sizeof(unsigned long long), stream_));
     // the HBM group (if any): PrepareBodies for the bodies it touches, PrepareJoints + RefreshJoints over its slots,
     // PreStep colour by colour.  Groups solved in LDS read and write the caller's records directly.
-    const int ng = sched_.ngroups(), lg = sched_.lds_groups;
     const int hbm_bodies = (int)sched_.hbm_bodies.size();
-    if (nj && ng > lg) {
+    if (nj && sched_.has_hbm_group()) {
         hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies, (const int*)hbm_body_list_.p,
                            hbm_bodies, sb_imp_.p, sb_disp_.p, sb_par_.p);
-        const int hb = sched_.group_offsets[lg], he = sched_.group_offsets[lg + 1];
+        const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
-        for (int c = sched_.group_first_colour[lg]; c < sched_.group_first_colour[lg + 1]; ++c) {
-            const int cb = sched_.colour_offsets[c], ce = sched_.colour_offsets[c + 1];
+        for (size_t c = 0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
+            const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1];
             hipLaunchKernelGGL(k_prestep, dim3(grid_for(ce - cb)), dim3(256), 0, stream_, v, cb, ce);
         }
     }
@@ -228,7 +455,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
     const int iters = std::max(ci, pi);
     sweep_launches_ = 0;
     if (!nj) return PHX_OK;
-    const int ng = sched_.ngroups(), lg = sched_.lds_groups;
+    const int lg = sched_.lds_groups;
     if (lg) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
@@ -246,16 +473,16 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         }
         ++sweep_launches_;
     }
-    if (ng > lg) {
-        const int c0 = sched_.group_first_colour[lg], c1 = sched_.group_first_colour[lg + 1];
+    if (sched_.has_hbm_group()) {
+        const int ncol = (int)sched_.hbm_colour_offsets.size() - 1;
         for (int it = 0; it < iters; ++it) {
             const bool imp = it < ci, disp = it < pi;
-            for (int c = c0; c < c1; ++c) {
-                const int cb = sched_.colour_offsets[c], ce = sched_.colour_offsets[c + 1];
+            for (int c = 0; c < ncol; ++c) {
+                const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1];
                 const dim3 g(std::max(1, std::min(div_up(ce - cb, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
-                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, ce, c - c0, it);
-                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, ce, c - c0, it);
-                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, ce, c - c0, it);
+                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, ce, c, it);
+                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, ce, c, it);
+                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, ce, c, it);
                 ++sweep_launches_;
             }
         }
@@ -267,9 +494,8 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
 int DeviceSolver::enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
-    const int ng = sched_.ngroups(), lg = sched_.lds_groups;
-    if (nj && ng > lg) {      // only the HBM group has results parked in the solver arrays
-        const int hb = sched_.group_offsets[lg], he = sched_.group_offsets[lg + 1];
+    if (nj && sched_.has_hbm_group()) {      // only the HBM group has results parked in the solver arrays
+        const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         const int hbm_bodies = (int)sched_.hbm_bodies.size();
         hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints);
         hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, v, (const int*)hbm_body_list_.p, hbm_bodies, d_bodies);
@@ -416,9 +642,7 @@ int DeviceSolver::collect_stats()
         for (int k = 0; k < limit; ++k) { ++n; if (!active[k]) break; }     // ref: Solver.cpp:175-190
         return n;
     };
-    const int lg = sched_.lds_groups;
-    const bool hbm = sched_.ngroups() > lg;
-    const int hbm_joints = hbm ? sched_.group_offsets[lg + 1] - sched_.group_offsets[lg] : 0;
+    const int hbm_joints = sched_.hbm_end() - sched_.hbm_begin();
     const int h_imp = hbm_joints ? executed(flags.data(), last_ci_) : 0;
     const int h_disp = hbm_joints ? executed(flags.data() + max_iters_, last_pi_) : 0;
     // like the reference's per-island loops, report the longest-running island (ref: Solver.cpp:175-190 per island)
@@ -468,6 +692,7 @@ int DeviceSolver::get_stats(phx_solve_stats* out)
 int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours)
 {
     if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(materialise_schedule());
     const int ncol = sched_.ncolours();
     if (ncolours) *ncolours = ncol;
     if ((order && order_cap < nj_) || (offsets && offsets_cap < ncol + 1)) { set_error("schedule buffers too small"); return PHX_ERR_CAPACITY; }
@@ -479,6 +704,7 @@ int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offs
 int DeviceSolver::get_groups(int* offsets, int cap, int* count, int* lds_count)
 {
     if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(materialise_schedule());
     if (count) *count = sched_.ngroups();
     if (lds_count) *lds_count = sched_.lds_groups;
     if (offsets) {
@@ -493,6 +719,7 @@ int DeviceSolver::get_refreshed(int joint, float out[30])
     if (!have_solve_) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
     PHX_REQUIRE(joint >= 0 && joint < nj_ && out, "joint index out of range");
     PHX_TRY(synchronize());
+    PHX_TRY(materialise_schedule());
     const int slot = (int)(std::find(sched_.order.begin(), sched_.order.end(), joint) - sched_.order.begin());
     if (sched_.lds_groups && slot < sched_.group_offsets[sched_.lds_groups]) {
         set_error("joint %d was solved by the island kernel, whose refreshed constants live only in registers; query it under island mode Single", joint);

@@ -266,3 +266,28 @@ def test_full_size_500k_boxes_50_iterations(solver, oracle):
     ob_, oj, ost = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
     assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
     assert (gj["normal_acc"] >= 0).all()
+
+
+def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
+    """The island-aware schedule is built on the device (connected components by label hooking, per-bin colouring in
+    LDS); the host builder is the specification.  Both must produce the very same schedule."""
+    import os
+    os.environ["PHX_SCHEDULE_BUILDER"] = "host"
+    try:
+        host_solver = phyx_amd.Solver(0)
+    finally:
+        del os.environ["PHX_SCHEDULE_BUILDER"]
+    dev_solver = phyx_amd.Solver(0)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 15, 15)
+    cases = [presolve_state(SMALL_SCENES[n][0](), SMALL_SCENES[n][1]) for n in SMALL_SCENES]
+    cases.append(presolve_state(scenes.stack(40, 60), 4))                       # many bins of several components each
+    cases.append(presolve_state(scenes.stack(5, 500), 3, iters=30))             # 1024-lane shape
+    cases.append(presolve_state(scenes.falling(2500, width=100.0, ymax=400.0), 50))   # one huge island + loose boxes -> HBM group
+    for state in cases:
+        hb, hj, hs, _, hst = _device_solve(host_solver, state, cfg)
+        db, dj, ds, _, dst = _device_solve(dev_solver, state, cfg)
+        assert np.array_equal(hs.order, ds.order)
+        assert np.array_equal(hs.colours, ds.colours)
+        assert np.array_equal(hs.groups, ds.groups) and hs.lds_groups == ds.lds_groups
+        assert (hst.island_count, hst.island_max_size, hst.colour_count) == (dst.island_count, dst.island_max_size, dst.colour_count)
+        assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
