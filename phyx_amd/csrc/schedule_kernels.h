@@ -72,7 +72,16 @@ static __global__ void __launch_bounds__(256) k_joint_components(const phx_conta
             if (r >= 0) comp = (int)root_number[r];
         }
         joint_comp[j] = comp;
-        if (comp >= 0) atomicAdd(&comp_size[comp], 1u);
+        // neighbouring joints mostly share a component: one atomic per distinct component per wave
+        unsigned long long todo = __ballot(comp >= 0);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int key = __shfl(comp, leader);
+            const unsigned long long same = __ballot(comp == key) & todo;
+            if (lane == leader) atomicAdd(&comp_size[key], (unsigned)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
@@ -112,12 +121,14 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     __shared__ unsigned long long used[NB];
     __shared__ unsigned short col[T], pos[T];
     __shared__ unsigned scan_lds[T / 64];
+    __shared__ unsigned hist[64];                         // per-colour counts, then cursors (LDS: a private array would live in scratch)
     __shared__ int n_static, n_bodies, n_col, bad;
 
     const int g = blockIdx.x, tid = threadIdx.x;
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
     for (int i = tid; i < HT; i += T) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
     for (int i = tid; i < NB; i += T) used[i] = 0ull;
+    if (tid < 64) hist[tid] = 0;
     if (tid == 0) { bad = 0; n_col = 0; }
     __syncthreads();
 
@@ -174,8 +185,6 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     __syncthreads();
     // greedy first-fit colouring in joint order (one lane; the masks live in LDS), then stable positions by colour
     if (tid == 0 && fits) {
-        unsigned hist[64];
-        for (int c = 0; c < 64; ++c) hist[c] = 0;
         int ncol = 0;
         for (int k = 0; k < count; ++k) {
             const int a = jb[0][k], c2 = jb[1][k];
