@@ -55,7 +55,9 @@ def main():
     from phyx_amd import scenes, Configuration
 
     info = phyx_amd.device_info(device)
-    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, args.iters, args.iters)
+    # N=1: BASELINE config 2 (Single Sloppy).  N>1: config 3 (Multiple island mode, islands sharded across the GPUs).
+    island_mode = phyx_amd.ISLAND_SINGLE_SLOPPY if world == 1 else phyx_amd.ISLAND_MULTIPLE
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, island_mode, args.iters, args.iters)
 
     # ---- scene: this rank's slab of the wide world, brought to a settled contact state by the product World
     first_col, ncols = pdist.shard_columns(args.columns * world, rank, world)
@@ -144,8 +146,11 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: stack(%d,%d) per GPU = %d bodies / %d joints per GPU, Single Sloppy islands, %d+%d iterations, "
-                                   "full SolveJoints per step on HBM-resident inputs" % (args.columns, args.rows, nb, nj, args.iters, args.iters),
+            "config": {"workload": ("cfg2: stack(%d,%d) = %d bodies / %d joints, Single Sloppy island mode, %d+%d iterations, full SolveJoints "
+                                    "per step on HBM-resident inputs" % (args.columns, args.rows, nb, nj, args.iters, args.iters)) if world == 1 else
+                                   ("cfg3 (weak-scaled): Multiple island mode, islands sharded across %d GPUs as slabs of stack(%d,%d) = %d bodies / "
+                                    "%d joints per GPU, %d+%d iterations, full SolveJoints per step on HBM-resident inputs, 4-byte RCCL all-reduce "
+                                    "per step" % (world, args.columns, args.rows, nb, nj, args.iters, args.iters)),
                        "bodies_total": int(bodies_all), "joints_total": int(joints_all), "colours": st.colour_count,
                        "lds_islands": st.lds_islands, "graph_replay": st.graph_replay,
                        "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,

@@ -152,6 +152,9 @@ __device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int 
     return lo;
 }
 
+// One sorted row per lane: lane l of a wave owns row i0+l and reads entries[i0+l+1+t] in step t, so a wave's loads are
+// contiguous and L1/L2-resident.  Candidates are fetched four at a time so that four loads are in flight per lane (the
+// loop is latency-bound, not bandwidth-bound: staging the window through LDS was measured and bought nothing).
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
 {
@@ -174,9 +177,8 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
         }
         const unsigned ia = v.idx[i];
         unsigned found = 0;
-        unsigned dst = EMIT ? row_offset[i] : 0u;
-        for (int j = i + 1; j < end; ++j) {
-            const float4 b = v.entries[j];
+        const unsigned dst = EMIT ? row_offset[i] : 0u;
+        auto test = [&](int j, const float4& b) {
             if (fabsf(b.z - a.z) <= a.w + b.w) {
                 const unsigned ib = v.idx[j];
                 if (!EMIT) ++overlaps;
@@ -185,7 +187,13 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
                     ++found;
                 }
             }
+        };
+        int j = i + 1;
+        for (; j + 4 <= end; j += 4) {
+            const float4 b0 = v.entries[j], b1 = v.entries[j + 1], b2 = v.entries[j + 2], b3 = v.entries[j + 3];
+            test(j, b0); test(j + 1, b1); test(j + 2, b2); test(j + 3, b3);
         }
+        for (; j < end; ++j) test(j, v.entries[j]);
         if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; }
     }
     if (!EMIT) {
@@ -244,17 +252,16 @@ __global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigne
     }
 }
 
-// per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  One lane per chunk that is
-// the first of its row walks the row's chunks (a row has len/2048 of them — tens, not thousands).
-__global__ void __launch_bounds__(256) k_chunk_bases(SweepView v)
+// per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  `scanned` is the exclusive scan of the
+// chunk counts over the whole chunk list; a row's chunks are contiguous, so differences of that scan give both.
+__global__ void __launch_bounds__(256) k_chunk_bases(SweepView v, const unsigned* __restrict__ scanned, const unsigned* __restrict__ counts)
 {
     const int total = min(*v.n_chunks, v.chunk_cap);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
         const int4 ch = v.chunks[c];
-        if (ch.w != c) continue;
-        unsigned run = 0;
-        for (int k = c; k < total && v.chunks[k].x == ch.x; ++k) { const unsigned n = v.chunk_count[k]; v.chunk_count[k] = run; run += n; }
-        v.row_count[ch.x] = run;
+        v.chunk_count[c] = scanned[c] - scanned[ch.w];                      // base of this chunk inside its row
+        const bool last = (c + 1 == total) || v.chunks[c + 1].x != ch.x;
+        if (last) v.row_count[ch.x] = scanned[c] + counts[c] - scanned[ch.w];
     }
 }
 
@@ -277,7 +284,7 @@ DeviceBroadphase::~DeviceBroadphase()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
-    hist_.release(); entries_.release(); table_.release(); row_count_.release(); chunks_.release(); chunk_count_.release(); scan_tiles_.release(); small_.release();
+    hist_.release(); entries_.release(); table_.release(); row_count_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); chunk_raw_.release(); scan_tiles_.release(); small_.release();
     new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -349,6 +356,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
 
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
     PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
+    PHX_HIP(hipMemsetAsync(chunk_count_.p, 0, (size_t)chunk_cap * sizeof(unsigned), stream_));
     if (n == 0) { PHX_HIP(hipEventRecord(ev_end_, stream_)); PHX_HIP(hipStreamSynchronize(stream_)); stats_.set_size = (int)set_size_; have_update_ = true; return PHX_OK; }
 
     hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p);
@@ -370,7 +378,15 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         chunk_grid = std::min(chunk_cap, 2048);
         hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
         hipLaunchKernelGGL((k_sweep_chunks<false>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
-        hipLaunchKernelGGL(k_chunk_bases, dim3(grid_for(chunk_cap)), dim3(256), 0, stream_, v);
+        {   // chunk counts -> per-row bases: scan a copy of the counts, then take differences
+            PHX_TRY(scan_tiles_.reserve((size_t)div_up(chunk_cap, SCAN_TILE) + 1));
+            PHX_TRY(chunk_scan_.reserve(chunk_cap + 1));
+            PHX_TRY(chunk_raw_.reserve(chunk_cap + 1));
+            PHX_HIP(hipMemcpyAsync(chunk_raw_.p, chunk_count_.p, (size_t)chunk_cap * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
+            PHX_HIP(hipMemcpyAsync(chunk_scan_.p, chunk_count_.p, (size_t)chunk_cap * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
+            PHX_TRY(exclusive_scan(chunk_scan_.p, chunk_cap, nullptr));
+            hipLaunchKernelGGL(k_chunk_bases, dim3(grid_for(chunk_cap)), dim3(256), 0, stream_, v, (const unsigned*)chunk_scan_.p, (const unsigned*)chunk_raw_.p);
+        }
         PHX_TRY(exclusive_scan(row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3)));
         PHX_HIP(hipGetLastError());
         PHX_HIP(hipMemcpyAsync(host_small, small_.p, sizeof host_small, hipMemcpyDeviceToHost, stream_));
@@ -384,6 +400,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         PHX_TRY(chunks_.reserve(chunk_cap));
         PHX_TRY(chunk_count_.reserve(chunk_cap));
         PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
+        PHX_HIP(hipMemsetAsync(chunk_count_.p, 0, (size_t)chunk_cap * sizeof(unsigned), stream_));
     }
     const unsigned total = (unsigned)host_small[3];
     stats_.candidate_tests = (long long)host_small[0];
