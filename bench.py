@@ -219,6 +219,23 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     st = s5.stats()
     res["cfg5_500k_tall_50it_fp32"] = {"ms_per_step": 1e3 * el / 10, "joint_visits_per_sec": r.joint_visits / el, "joints": arrs[2].count,
                                        "impulse_sweeps": st.impulse_iterations, "lds_islands": st.lds_islands, "sweep_ms_per_step": r.impulse_kernel_ms / 10}
+    # the ablation of config 5: solver-side body state in fp16 (fp32 arithmetic, every store rounds to nearest even)
+    def solved(solver):
+        b, j = phyx_amd.DeviceArray(w5.bodies, device), phyx_amd.DeviceArray(w5.contactJoints, device)
+        solver.SolveJointsDevice(b, arrs[1], j, cfg5); solver.synchronize()
+        return b.to_host(), j.to_host()
+    b32, j32 = solved(s5)
+    s5.set_body_state_bits(16)
+    s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 2, 0)
+    t0 = time.perf_counter(); r16 = s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 0, 10); el16 = time.perf_counter() - t0
+    st16 = s5.stats()
+    b16, j16 = solved(s5)
+    res["cfg5_500k_tall_50it_fp16_body_state"] = {
+        "ms_per_step": 1e3 * el16 / 10, "joint_visits_per_sec": r16.joint_visits / el16, "impulse_sweeps": st16.impulse_iterations,
+        "sweep_ms_per_step": r16.impulse_kernel_ms / 10,
+        "max_abs_velocity_diff_vs_fp32": float(max(np.abs(b16["velocity"]["x"] - b32["velocity"]["x"]).max(), np.abs(b16["velocity"]["y"] - b32["velocity"]["y"]).max())),
+        "mean_abs_velocity_diff_vs_fp32": float(np.abs(b16["velocity"]["y"] - b32["velocity"]["y"]).mean()),
+        "max_abs_impulse_diff_vs_fp32": float(np.abs(j16["normal_acc"] - j32["normal_acc"]).max())}
     return res
 
 

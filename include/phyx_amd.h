@@ -113,6 +113,12 @@ int phx_solver_solve_device(phx_solver* s, void* d_bodies, int32_t body_count,
                             void* d_joints, int32_t joint_count, const phx_config* config);
 int phx_solver_synchronize(phx_solver* s);
 
+/* Precision ablation (BASELINE config 5): 32 (default) keeps the solver-side body state {velocity, angular velocity}
+ * in fp32 like the reference's SolveBody (ref: src/Solver.h:95-101); 16 stores it as IEEE half between joint updates
+ * (arithmetic stays fp32, every store rounds to nearest-even) in the groups solved out of LDS.  Not a drop-in mode:
+ * results differ from the reference's by the rounding; tests compare against an oracle that rounds the same way. */
+int phx_solver_set_body_state_bits(phx_solver* s, int32_t bits);
+
 /* results of the last solve (valid after a synchronizing call) — counterparts of
  * Solver::islandCount / islandMaxSize (ref: src/Solver.h:105-106) plus executed sweep counts */
 typedef struct {

@@ -88,6 +88,8 @@ def lib():
                                                 C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.phxo_solver_solve_grouped.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.phxo_solver_solve_grouped_fp16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.phxo_refresh_joint.argtypes = [C.c_void_p] * 4
         L.phxo_gather_islands.restype = C.c_int
         L.phxo_gather_islands.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -262,15 +264,16 @@ def solver_solve_ordered(bodies, cps, joints, order, colour_offsets, contact_ite
 
 
 def solver_solve_grouped(bodies, cps, joints, order, colour_offsets, group_offsets, contact_iters, penetration_iters,
-                         stag_mode=STAG_COLOUR_SYNC):
-    """The HIP path's island-aware schedule replayed sequentially: groups are independent islands."""
+                         stag_mode=STAG_COLOUR_SYNC, fp16_groups=0):
+    """The HIP path's island-aware schedule replayed sequentially: groups are independent islands.
+    fp16_groups > 0 models the fp16 body-state ablation for the first that many groups."""
     L = lib()
     st = SolveStats()
     order = np.ascontiguousarray(order, dtype=np.int32)
     co = np.ascontiguousarray(colour_offsets, dtype=np.int32)
     go = np.ascontiguousarray(group_offsets, dtype=np.int32)
-    L.phxo_solver_solve_grouped(_p(bodies), len(bodies), _p(cps), _p(joints), len(joints), _p(order), _p(co), len(co) - 1,
-                                _p(go), len(go) - 1, contact_iters, penetration_iters, stag_mode, C.byref(st))
+    L.phxo_solver_solve_grouped_fp16(_p(bodies), len(bodies), _p(cps), _p(joints), len(joints), _p(order), _p(co), len(co) - 1,
+                                     _p(go), len(go) - 1, contact_iters, penetration_iters, stag_mode, fp16_groups, C.byref(st))
     return st
 
 

@@ -32,6 +32,40 @@ static inline phxo_vec2 perp2(phxo_vec2 a) { phxo_vec2 r = {-a.y, a.x}; return r
 static inline float sqlen2(phxo_vec2 a) { return a.x * a.x + a.y * a.y; }
 static inline float maxf_ref(float l, float r) { return l > r ? l : r; }                         /* ref: base/SIMD_Scalar.h:275-278 */
 
+/* IEEE binary16 round trip (round to nearest even), for the fp16 body-state ablation of BASELINE config 5.
+ * Not part of the reference: it models what the HIP island kernel does when asked to keep body velocities in half. */
+static uint16_t f32_to_f16(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u, a = x & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (a < 0x33000001u) return (uint16_t)sign;
+    if (a < 0x38800000u) {
+        int e = (int)(a >> 23);
+        uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        int shift = 126 - e;
+        uint32_t r = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (a - 0x38000000u) >> 13, rem = a & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+}
+static float f16_to_f32(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; ++sh; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - sh) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+static inline float qh(int half, float x) { return half ? f16_to_f32(f32_to_f16(x)) : x; }
+float phxo_round_f16(float x) { return f16_to_f32(f32_to_f16(x)); }
+
 #define GROW(ptr, cap, need, type)                                           \
     do {                                                                     \
         if ((size_t)(need) > (size_t)(cap)) {                                \
@@ -305,6 +339,7 @@ typedef struct {
     phxo_contact_joint* joints;
     /* static-tag bookkeeping for PHXO_STAG_COLOUR_SYNC / event counting */
     int stag_mode;
+    int fp16;                     /* body velocities are rounded to binary16 on every store (ablation) */
     const int32_t* slot_colour;   /* slot -> colour or NULL */
     uint8_t* is_static;
     /* colour-sync bookkeeping for static bodies, two words per body selected by iteration parity:
@@ -400,13 +435,17 @@ void phxo_refresh_joint(const phxo_body* bodies, const phxo_contact_point* cps, 
 }
 
 /* ref: Solver.cpp:697-758 PreStepJoints<1,1> body */
-static void prestep_one(const pjoint* J, sbody* imp)
+static void prestep_one(const pjoint* J, sbody* imp, int half, const uint8_t* is_static)
 {
     sbody *b1 = &imp[J->b1], *b2 = &imp[J->b2];
-    b1->vx += J->n.c1x * J->n_acc; b1->vy += J->n.c1y * J->n_acc; b1->w += J->n.c1a * J->n_acc;
-    b2->vx += J->n.c2x * J->n_acc; b2->vy += J->n.c2y * J->n_acc; b2->w += J->n.c2a * J->n_acc;
-    b1->vx += J->f.c1x * J->f_acc; b1->vy += J->f.c1y * J->f_acc; b1->w += J->f.c1a * J->f_acc;
-    b2->vx += J->f.c2x * J->f_acc; b2->vy += J->f.c2y * J->f_acc; b2->w += J->f.c2a * J->f_acc;
+    float v1x = b1->vx, v1y = b1->vy, w1 = b1->w, v2x = b2->vx, v2y = b2->vy, w2 = b2->w;
+    v1x += J->n.c1x * J->n_acc; v1y += J->n.c1y * J->n_acc; w1 += J->n.c1a * J->n_acc;
+    v2x += J->n.c2x * J->n_acc; v2y += J->n.c2y * J->n_acc; w2 += J->n.c2a * J->n_acc;
+    v1x += J->f.c1x * J->f_acc; v1y += J->f.c1y * J->f_acc; w1 += J->f.c1a * J->f_acc;
+    v2x += J->f.c2x * J->f_acc; v2y += J->f.c2y * J->f_acc; w2 += J->f.c2a * J->f_acc;
+    /* a static body's compMass is 0, so its velocity is unchanged; the fp16 form (like the device) does not store it */
+    if (!(half && is_static[J->b1])) { b1->vx = qh(half, v1x); b1->vy = qh(half, v1y); b1->w = qh(half, w1); }
+    if (!(half && is_static[J->b2])) { b2->vx = qh(half, v2x); b2->vy = qh(half, v2y); b2->w = qh(half, w2); }
 }
 
 static inline float flipsign_scalar(float x, float y) { return y < 0.f ? -x : x; }             /* ref: base/SIMD_Scalar.h:265-268 */
@@ -447,7 +486,7 @@ static void reset_static_words(sctx* c)
 }
 
 /* one joint of ref: Solver.cpp:800-911; returns productive */
-static int impulse_one(pjoint* J, sbody* imp, int simd_flipsign, float* out_dn, float* out_df)
+static int impulse_one(pjoint* J, sbody* imp, int simd_flipsign, float* out_dn, float* out_df, int half, const uint8_t* is_static)
 {
     sbody *b1 = &imp[J->b1], *b2 = &imp[J->b2];
     float v1x = b1->vx, v1y = b1->vy, w1 = b1->w, v2x = b2->vx, v2y = b2->vy, w2 = b2->w;
@@ -476,25 +515,28 @@ static int impulse_one(pjoint* J, sbody* imp, int simd_flipsign, float* out_dn, 
     v1x += F->c1x * df; v1y += F->c1y * df; w1 += F->c1a * df;
     v2x += F->c2x * df; v2y += F->c2y * df; w2 += F->c2a * df;
 
-    b1->vx = v1x; b1->vy = v1y; b1->w = w1;
-    b2->vx = v2x; b2->vy = v2y; b2->w = w2;
+    if (!(half && is_static[J->b1])) { b1->vx = qh(half, v1x); b1->vy = qh(half, v1y); b1->w = qh(half, w1); }
+    if (!(half && is_static[J->b2])) { b2->vx = qh(half, v2x); b2->vy = qh(half, v2y); b2->w = qh(half, w2); }
     *out_dn = dn; *out_df = df;
     return maxf_ref(fabsf(dn), fabsf(df)) > 1e-4f;                  /* kProductiveImpulse, ref: Solver.cpp:8 */
 }
 
 /* one joint of ref: Solver.cpp:973-1015 */
-static int displacement_one(pjoint* J, sbody* disp)
+static int displacement_one(pjoint* J, sbody* disp, int half, const uint8_t* is_static)
 {
     sbody *b1 = &disp[J->b1], *b2 = &disp[J->b2];
     const limiter* N = &J->n;
+    float v1x = b1->vx, v1y = b1->vy, w1 = b1->w, v2x = b2->vx, v2y = b2->vy, w2 = b2->w;
     float dv = J->n_dst_disp;
-    dv -= N->p1x * b1->vx; dv -= N->p1y * b1->vy; dv -= N->a1 * b1->w;
-    dv -= N->p2x * b2->vx; dv -= N->p2y * b2->vy; dv -= N->a2 * b2->w;
+    dv -= N->p1x * v1x; dv -= N->p1y * v1y; dv -= N->a1 * w1;
+    dv -= N->p2x * v2x; dv -= N->p2y * v2y; dv -= N->a2 * w2;
     float di = dv * N->cim;
     di = maxf_ref(di, -J->n_acc_disp);
-    b1->vx += N->c1x * di; b1->vy += N->c1y * di; b1->w += N->c1a * di;
-    b2->vx += N->c2x * di; b2->vy += N->c2y * di; b2->w += N->c2a * di;
+    v1x += N->c1x * di; v1y += N->c1y * di; w1 += N->c1a * di;
+    v2x += N->c2x * di; v2y += N->c2y * di; w2 += N->c2a * di;
     J->n_acc_disp += di;
+    if (!(half && is_static[J->b1])) { b1->vx = qh(half, v1x); b1->vy = qh(half, v1y); b1->w = qh(half, w1); }
+    if (!(half && is_static[J->b2])) { b2->vx = qh(half, v2x); b2->vy = qh(half, v2y); b2->w = qh(half, w2); }
     return fabsf(di) > 1e-4f;
 }
 
@@ -522,8 +564,8 @@ static int sweep(sctx* c, int begin, int end, int iter, int vn, int which)
             if (c->joint_index[s] < 0) continue;
             pjoint* J = &c->pj[s];
             int productive;
-            if (which) productive = displacement_one(J, arr);
-            else { float dn, df; productive = impulse_one(J, arr, vn > 1, &dn, &df); if (c->st) c->st->joints_computed++; }
+            if (which) productive = displacement_one(J, arr, c->fp16, c->is_static);
+            else { float dn, df; productive = impulse_one(J, arr, vn > 1, &dn, &df, c->fp16, c->is_static); if (c->st) c->st->joints_computed++; }
             if (productive) {
                 mark_productive(c, arr, J->b1, s, iter);
                 mark_productive(c, arr, J->b2, s, iter);
@@ -699,7 +741,7 @@ static void solve_island(sctx* c, int begin, int end, int group_offset, int n, i
     int tail_begin = group_offset > begin ? group_offset : begin;
 
     for (int s = begin; s < end; ++s) if (c->joint_index[s] >= 0) refresh_one(&c->pj[s], c->imp, c->par, c->cps);
-    for (int s = begin; s < end; ++s) if (c->joint_index[s] >= 0) prestep_one(&c->pj[s], c->imp);
+    for (int s = begin; s < end; ++s) if (c->joint_index[s] >= 0) prestep_one(&c->pj[s], c->imp, c->fp16, c->is_static);
 
     int it;
     reset_static_words(c);
@@ -820,6 +862,17 @@ void phxo_solver_solve_grouped(phxo_body* bodies, int nb, const phxo_contact_poi
                                const int32_t* group_offsets, int ngroups,
                                int contact_iters, int pen_iters, int stag_mode, phxo_solve_stats* stats)
 {
+    phxo_solver_solve_grouped_fp16(bodies, nb, cps, joints, nj, order, colour_offsets, ncolours, group_offsets, ngroups,
+                                   contact_iters, pen_iters, stag_mode, 0, stats);
+}
+
+/* Same, with the first `fp16_groups` groups keeping their body velocities in binary16 between joint updates (what the
+ * device's island kernel does under phx_solver_set_body_state_bits(16)); arithmetic stays fp32. */
+void phxo_solver_solve_grouped_fp16(phxo_body* bodies, int nb, const phxo_contact_point* cps, phxo_contact_joint* joints, int nj,
+                                    const int32_t* order, const int32_t* colour_offsets, int ncolours,
+                                    const int32_t* group_offsets, int ngroups,
+                                    int contact_iters, int pen_iters, int stag_mode, int fp16_groups, phxo_solve_stats* stats)
+{
     phxo_solve_stats local; if (!stats) stats = &local;
     memset(stats, 0, sizeof *stats);
     sctx c; ctx_alloc(&c, nb, nj);
@@ -839,7 +892,30 @@ void phxo_solver_solve_grouped(phxo_body* bodies, int nb, const phxo_contact_poi
         int b = group_offsets[g], e = group_offsets[g + 1];
         if (e - b > stats->island_max_size) stats->island_max_size = e - b;
         for (int i = 0; i < nb; ++i) if (c.is_static[i]) { c.imp[i].tag = -1; c.disp[i].tag = -1; }
-        solve_island(&c, b, e, e, 1, contact_iters, pen_iters);
+        c.fp16 = g < fp16_groups;
+        if (c.fp16) {       /* the group's working copy of its bodies is binary16 from the start (the statics' copy is private) */
+            for (int s = b; s < e; ++s)
+                for (int side = 0; side < 2; ++side) {
+                    int body = side ? c.pj[s].b2 : c.pj[s].b1;
+                    if (c.is_static[body]) continue;
+                    c.imp[body].vx = qh(1, c.imp[body].vx); c.imp[body].vy = qh(1, c.imp[body].vy); c.imp[body].w = qh(1, c.imp[body].w);
+                    c.disp[body].vx = qh(1, c.disp[body].vx); c.disp[body].vy = qh(1, c.disp[body].vy); c.disp[body].w = qh(1, c.disp[body].w);
+                }
+            /* static bodies: rounded copies for the duration of the group, originals restored afterwards */
+            sbody* keep_i = (sbody*)malloc((nb + 1) * sizeof(sbody));
+            sbody* keep_d = (sbody*)malloc((nb + 1) * sizeof(sbody));
+            memcpy(keep_i, c.imp, nb * sizeof(sbody)); memcpy(keep_d, c.disp, nb * sizeof(sbody));
+            for (int i = 0; i < nb; ++i) if (c.is_static[i]) {
+                c.imp[i].vx = qh(1, c.imp[i].vx); c.imp[i].vy = qh(1, c.imp[i].vy); c.imp[i].w = qh(1, c.imp[i].w);
+                c.disp[i].vx = qh(1, c.disp[i].vx); c.disp[i].vy = qh(1, c.disp[i].vy); c.disp[i].w = qh(1, c.disp[i].w);
+            }
+            solve_island(&c, b, e, e, 1, contact_iters, pen_iters);
+            for (int i = 0; i < nb; ++i) if (c.is_static[i]) { c.imp[i] = keep_i[i]; c.disp[i] = keep_d[i]; }
+            free(keep_i); free(keep_d);
+        } else {
+            solve_island(&c, b, e, e, 1, contact_iters, pen_iters);
+        }
+        c.fp16 = 0;
     }
     copy_joints_out(&c, 0, nj);
     finish_bodies(&c, bodies);
@@ -1247,7 +1323,7 @@ double phxo_time_impulse_loop(phxo_body* bodies, int nb, const phxo_contact_poin
     for (int i = 0; i < nj; ++i) c.joint_index[i] = i;
     copy_joints_in(&c, 0, nj);
     for (int s = 0; s < nj; ++s) refresh_one(&c.pj[s], c.imp, c.par, c.cps);
-    for (int s = 0; s < nj; ++s) prestep_one(&c.pj[s], c.imp);
+    for (int s = 0; s < nj; ++s) prestep_one(&c.pj[s], c.imp, 0, c.is_static);
 
     tshared sh; memset(&sh, 0, sizeof sh);
     sh.c = &c; sh.nj = nj; sh.iters = iters; sh.threads = threads;

@@ -140,6 +140,17 @@ void phxo_solver_solve_grouped(phxo_body* bodies, int nb, const phxo_contact_poi
                                int contact_iters, int penetration_iters, int stag_mode,
                                phxo_solve_stats* stats);
 
+float phxo_round_f16(float x);   /* float -> IEEE binary16 (nearest even) -> float */
+
+/* Ablation, not reference behaviour: the first `fp16_groups` groups keep body velocities in IEEE binary16 between
+ * joint updates (round to nearest even on every store, fp32 arithmetic) — the model of phx_solver_set_body_state_bits(16). */
+void phxo_solver_solve_grouped_fp16(phxo_body* bodies, int nb, const phxo_contact_point* cps,
+                                    phxo_contact_joint* joints, int nj,
+                                    const int32_t* order, const int32_t* colour_offsets, int ncolours,
+                                    const int32_t* group_offsets, int ngroups,
+                                    int contact_iters, int penetration_iters, int stag_mode, int fp16_groups,
+                                    phxo_solve_stats* stats);
+
 /* RefreshJoints only (Solver.cpp:592-695): 29 floats per joint in the field order of
  * ContactJointPacked<1> minus indices: normal limiter 13, normalLimiter_compInvMass(unused, 0),
  * dstVelocity, dstDisplacingVelocity, accumulatedDisplacingImpulse, friction limiter 13. */

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "phx_solver_solve": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
     "phx_solver_solve_device": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
     "phx_solver_synchronize": (C.c_int, [_vp]),
+    "phx_solver_set_body_state_bits": (C.c_int, [_vp, _i32]),
     "phx_solver_get_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),
     "phx_solver_get_schedule": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_get_groups": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),

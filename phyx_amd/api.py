@@ -174,6 +174,10 @@ class Solver:
     def synchronize(self):
         check(self.L.phx_solver_synchronize(self.h))
 
+    def set_body_state_bits(self, bits):
+        """32 = fp32 solver-side body state (default, the reference's); 16 = the fp16 ablation of BASELINE config 5."""
+        check(self.L.phx_solver_set_body_state_bits(self.h, bits))
+
     def stats(self):
         st = SolveStats()
         check(self.L.phx_solver_get_stats(self.h, C.byref(st)))

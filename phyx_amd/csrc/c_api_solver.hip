@@ -52,6 +52,12 @@ int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap, in
     return s->impl.get_schedule(order, order_cap, offsets, offsets_cap, ncolours);
 }
 
+int phx_solver_set_body_state_bits(phx_solver* s, int32_t bits)
+{
+    PHX_REQUIRE(s, "null handle");
+    return s->impl.set_body_state_bits(bits);
+}
+
 int phx_solver_get_groups(phx_solver* s, int32_t* offsets, int32_t cap, int32_t* count, int32_t* lds_count)
 {
     PHX_REQUIRE(s, "null handle");

@@ -39,6 +39,7 @@ public:
     int synchronize();
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
+    int set_body_state_bits(int bits);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
@@ -115,7 +116,7 @@ private:
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
-    bool use_graphs_ = true, wave_islands_ = false, speculate_ = true;
+    bool use_graphs_ = true, wave_islands_ = false, speculate_ = true, half_state_ = false;
     // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()
     struct Pending { bool active = false; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
     int ncp_ = 0;

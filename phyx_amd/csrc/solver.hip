@@ -466,10 +466,11 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
             wv.slot_local = slot_local_.p; wv.executed = isl_stats_.p; wv.visits = isl_visits_.p;
             hipLaunchKernelGGL(k_solve_islands_wave, dim3(lg), dim3(64), 0, stream_, v, wv, d_bodies, d_joints, d_cps, ci, pi);
         } else {
-            if (sched_.lds_lanes > ISL_T)
-                hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG>), dim3(lg), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else
-                hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B>), dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            const bool big = sched_.lds_lanes > ISL_T;
+            if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(lg), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(lg), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         }
         ++sweep_launches_;
     }
@@ -576,6 +577,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(nb >= 0 && nj >= 0 && ncp >= 0, "negative count");
     PHX_REQUIRE(cfg.contact_iterations >= 0 && cfg.penetration_iterations >= 0 && cfg.contact_iterations < 60000 && cfg.penetration_iterations < 60000, "iteration count out of range");
+    PHX_REQUIRE(!half_state_ || (cfg.contact_iterations < 32000 && cfg.penetration_iterations < 32000), "fp16 body state keeps the iteration tag in 16 bits");
     PHX_REQUIRE(cfg.solve_mode >= PHX_SOLVE_SCALAR && cfg.solve_mode <= PHX_SOLVE_AVX2, "unknown solve mode");
     PHX_REQUIRE(cfg.island_mode >= PHX_ISLAND_SINGLE && cfg.island_mode <= PHX_ISLAND_MULTIPLE_SLOPPY, "unknown island mode");
     PHX_REQUIRE(nb == 0 || d_bodies, "null bodies");
@@ -698,6 +700,13 @@ int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offs
     if ((order && order_cap < nj_) || (offsets && offsets_cap < ncol + 1)) { set_error("schedule buffers too small"); return PHX_ERR_CAPACITY; }
     if (order) std::copy(sched_.order.begin(), sched_.order.end(), order);
     if (offsets) std::copy(sched_.colour_offsets.begin(), sched_.colour_offsets.end(), offsets);
+    return PHX_OK;
+}
+
+int DeviceSolver::set_body_state_bits(int bits)
+{
+    PHX_REQUIRE(bits == 16 || bits == 32, "body state precision must be 16 or 32 bits");
+    if ((bits == 16) != half_state_) { half_state_ = bits == 16; drop_graphs(); }
     return PHX_OK;
 }
 

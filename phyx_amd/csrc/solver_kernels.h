@@ -27,6 +27,8 @@
 
 #include "solver.h"
 
+#include <hip/hip_fp16.h>
+
 namespace phx {
 
 // ---- static-body tags ----------------------------------------------------------------------------
@@ -317,13 +319,34 @@ __device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[B], i
     return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
 }
 
-template <int T, int NB>
+// ---- body-state storage of the island kernel: fp32 (default) or the fp16 ablation ------------------------------
+template <bool HALF> struct BodyStore { using type = float4; };
+template <> struct BodyStore<true> { using type = uint2; };
+
+__device__ __forceinline__ float4 body_load(const float4* p, int i) { return p[i]; }
+__device__ __forceinline__ void body_store(float4* p, int i, float4 v) { p[i] = v; }
+__device__ __forceinline__ unsigned f2h_bits(float f) { return (unsigned)__half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ float h2f_bits(unsigned h) { return __half2float(__ushort_as_half((unsigned short)h)); }
+__device__ __forceinline__ float4 body_load(const uint2* p, int i)
+{
+    const uint2 r = p[i];
+    return make_float4(h2f_bits(r.x & 0xFFFFu), h2f_bits(r.x >> 16), h2f_bits(r.y & 0xFFFFu), __int_as_float((int)(short)(r.y >> 16)));
+}
+__device__ __forceinline__ void body_store(uint2* p, int i, float4 v)
+{
+    p[i] = make_uint2(f2h_bits(v.x) | (f2h_bits(v.y) << 16), f2h_bits(v.z) | ((unsigned)(unsigned short)(short)__float_as_int(v.w) << 16));
+}
+
+template <int T, int NB, bool HALF>
 __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
                                                             phx_contact_joint* __restrict__ joints,
                                                             const phx_contact_point* __restrict__ cps, int ci, int pi)
 {
-    __shared__ float4 imp[NB];
-    __shared__ float4 disp[NB];
+    // body velocities in LDS: float4 {vx, vy, w, tag}, or — fp16 body-state ablation (BASELINE config 5) — four 16-bit
+    // words {half vx, half vy, half w, int16 tag}; arithmetic is fp32 either way, HALF rounds on every store
+    using BodyT = typename BodyStore<HALF>::type;
+    __shared__ BodyT imp[NB];
+    __shared__ BodyT disp[NB];
     // static-tag words [imp|disp][parity][body]; during set-up the same 12 KB hold {invMass, invInertia, pos} per body
     __shared__ __attribute__((aligned(16))) unsigned sw_raw[4 * NB];
     __shared__ unsigned char is_st[NB];
@@ -339,8 +362,8 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     for (int i = tid; i < d.w; i += T) {
         // PrepareBodies (ref: Solver.cpp:456-480) straight from the 128-byte records
         const phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
-        imp[i] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
-        disp[i] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
+        body_store(imp, i, make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1)));
+        body_store(disp, i, make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1)));
         par[i] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
         is_st[i] = (b.inv_mass == 0.f && b.inv_inertia == 0.f) ? 1 : 0;
     }
@@ -390,16 +413,16 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     for (int c = 0; c < ncol; ++c) {
         if (col == c) {
             if (!st1) {
-                float4 B = imp[l1];
+                float4 B = body_load(imp, l1);
                 B.x += (nx * im1) * accN; B.y += (ny * im1) * accN; B.z += (aN1 * ii1) * accN;
                 B.x += (tx * im1) * accF; B.y += (ty * im1) * accF; B.z += (aF1 * ii1) * accF;
-                imp[l1] = B;
+                body_store(imp, l1, B);
             }
             if (!st2) {
-                float4 B = imp[l2];
+                float4 B = body_load(imp, l2);
                 B.x += ((-nx) * im2) * accN; B.y += ((-ny) * im2) * accN; B.z += (aN2 * ii2) * accN;
                 B.x += ((-tx) * im2) * accF; B.y += ((-ty) * im2) * accF; B.z += (aF2 * ii2) * accF;
-                imp[l2] = B;
+                body_store(imp, l2, B);
             }
         }
         __syncthreads();
@@ -415,7 +438,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         for (int c = 0; c < ncol; ++c) {
             if (col == c) {
                 if (imp_on) {
-                    float4 B1 = imp[l1], B2 = imp[l2];
+                    float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
                     const bool p1 = st1 ? static_productive_lds(swi, l1, it, c) : (__float_as_int(B1.w) > it - 2);
                     const bool p2 = st2 ? static_productive_lds(swi, l2, it, c) : (__float_as_int(B2.w) > it - 2);
                     if (p1 || p2) {
@@ -445,12 +468,12 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
                             if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
                             if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
                         }
-                        if (!st1) imp[l1] = B1;
-                        if (!st2) imp[l2] = B2;
+                        if (!st1) body_store(imp, l1, B1);
+                        if (!st2) body_store(imp, l2, B2);
                     }
                 }
                 if (disp_on) {
-                    float4 D1 = disp[l1], D2 = disp[l2];
+                    float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
                     const bool p1 = st1 ? static_productive_lds(swd, l1, it, c) : (__float_as_int(D1.w) > it - 2);
                     const bool p2 = st2 ? static_productive_lds(swd, l2, it, c) : (__float_as_int(D2.w) > it - 2);
                     if (p1 || p2) {
@@ -468,8 +491,8 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
                             if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
                             if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
                         }
-                        if (!st1) disp[l1] = D1;
-                        if (!st2) disp[l2] = D2;
+                        if (!st1) body_store(disp, l1, D1);
+                        if (!st2) body_store(disp, l2, D2);
                     }
                 }
             }
@@ -491,7 +514,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     for (int i = tid; i < d.w; i += T) {               // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
         if (is_st[i]) continue;
         phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
-        const float4 a = imp[i], e = disp[i];
+        const float4 a = body_load(imp, i), e = body_load(disp, i);
         b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
         b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
     }

@@ -231,3 +231,20 @@ def test_regression_fixture(oracle):
         oracle.solver_solve(b, cp, j, mode, oracle.ISLAND_SINGLE, 15, 15)
         assert b.tobytes() == g["bodies_out_" + name].tobytes()
         assert j.tobytes() == g["joints_out_" + name].tobytes()
+
+
+def test_binary16_rounding_model(oracle):
+    """The fp16 ablation's rounding (float -> binary16 nearest-even -> float) against numpy's float16."""
+    import ctypes as C
+    L = oracle.lib()
+    L.phxo_round_f16.restype = C.c_float
+    L.phxo_round_f16.argtypes = [C.c_float]
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([
+        (rng.standard_normal(20000) * 10.0 ** rng.integers(-9, 6, 20000)).astype(np.float32),
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 6.1035156e-05, 6.0975552e-05, 5.9604645e-08, 2.9802322e-08,
+                  2.9802326e-08, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, np.inf, -np.inf], dtype=np.float32)])
+    got = np.array([L.phxo_round_f16(float(v)) for v in vals], dtype=np.float32)
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).astype(np.float32)
+    assert got.tobytes() == want.tobytes()

@@ -291,3 +291,25 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
         assert np.array_equal(hs.groups, ds.groups) and hs.lds_groups == ds.lds_groups
         assert (hst.island_count, hst.island_max_size, hst.colour_count) == (dst.island_count, dst.island_max_size, dst.colour_count)
         assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
+
+
+def test_fp16_body_state_ablation(oracle, built_lib):
+    """BASELINE config 5's ablation: body velocities kept in IEEE half between joint updates (fp32 arithmetic).  The device
+    must agree bit for bit with the oracle's model of that rounding, and stay close to the fp32 result."""
+    s16 = phyx_amd.Solver(0)
+    s16.set_body_state_bits(16)
+    s32 = phyx_amd.Solver(0)
+    for state, iters in ((presolve_state(scenes.stack(6, 60), 3), 20), (presolve_state(scenes.stack(3, 500), 3, iters=50), 50),
+                         (presolve_state(scenes.tilted(60), 25), 15)):
+        cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, iters, iters)
+        hb, hj, sched, _, st = _device_solve(s16, state, cfg)
+        b, cp, j = (a.copy() for a in state)
+        oracle.solver_solve_grouped(b, cp, j, sched.order, sched.colours, sched.groups, iters, iters, oracle.STAG_COLOUR_SYNC,
+                                    fp16_groups=sched.lds_groups)
+        assert hb.tobytes() == b.tobytes() and hj.tobytes() == j.tobytes()
+        fb, fj, _, _, _ = _device_solve(s32, state, cfg)
+        dv = np.abs(hb["velocity"]["y"] - fb["velocity"]["y"])
+        assert np.isfinite(hb["velocity"]["y"]).all() and hb.tobytes() != fb.tobytes()
+        assert dv.max() < 2.0          # half has ~3 decimal digits; velocities here are O(1..10)
+    with pytest.raises(phyx_amd.PhxError):
+        s16.set_body_state_bits(8)
