@@ -79,6 +79,12 @@ def lib():
         L.phxo_rotate_vec.argtypes = [C.c_void_p, C.c_float]
         L.phxo_support_points.restype = C.c_int
         L.phxo_support_points.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.phxo_contact_equals.restype = C.c_int
+        L.phxo_contact_equals.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.phxo_contact_point_make.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]
+        L.phxo_project_point_to_line.argtypes = [C.c_float] * 8 + [C.c_void_p]
+        L.phxo_aabb_intersects.restype = C.c_int
+        L.phxo_aabb_intersects.argtypes = [C.c_void_p, C.c_void_p]
         L.phxo_broadphase_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.phxo_sweep_candidates.restype = C.c_size_t
         L.phxo_sweep_candidates.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]

@@ -971,6 +971,15 @@ static phxo_contact_point make_point(phxo_vec2 p1, phxo_vec2 p2, phxo_vec2 n, co
     return c;
 }
 
+/* exported forms of the header-resident narrowphase leaves, so tests can pin them against oracle/_ref */
+int phxo_contact_equals(const phxo_contact_point* a, const phxo_contact_point* o, float tol) { return cp_equals(a, o, tol); }
+void phxo_contact_point_make(phxo_contact_point* out, float p1x, float p1y, float p2x, float p2y, float nx, float ny,
+                             const phxo_body* b1, const phxo_body* b2)
+{
+    phxo_vec2 p1 = {p1x, p1y}, p2 = {p2x, p2y}, n = {nx, ny};
+    *out = make_point(p1, p2, n, b1, b2);
+}
+
 /* ref: Collider.cpp:58-92 */
 static void add_point(phxo_contact_point* pts, int* count, phxo_contact_point* nb)
 {
@@ -998,6 +1007,13 @@ static phxo_vec2 project_to_line(phxo_vec2 point, phxo_vec2 plane_point, phxo_ve
     float mult = 1.0f / dot2(dir, plane_normal);
     float s = dot2(plane_point, plane_normal) - dot2(point, plane_normal);
     return add2(point, mul2(mul2(dir, s), mult));
+}
+
+void phxo_project_point_to_line(float px, float py, float qx, float qy, float nx, float ny, float dx, float dy, float out[2])
+{
+    phxo_vec2 p = {px, py}, q = {qx, qy}, n = {nx, ny}, d = {dx, dy};
+    phxo_vec2 r = project_to_line(p, q, n, d);
+    out[0] = r.x; out[1] = r.y;
 }
 
 static int within_segment(phxo_vec2 p, phxo_vec2 a, phxo_vec2 b)
@@ -1178,6 +1194,8 @@ static int aabb_intersects(const phxo_body* a, const phxo_body* b) /* ref: AABB2
     if (a->aabb_min.y > b->aabb_max.y || b->aabb_min.y > a->aabb_max.y) return 0;
     return 1;
 }
+
+int phxo_aabb_intersects(const phxo_body* a, const phxo_body* b) { return aabb_intersects(a, b); }
 
 static void pack_manifolds(phxo_world* w) /* ref: Collider.cpp:379-416 */
 {

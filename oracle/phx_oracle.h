@@ -10,7 +10,8 @@
  *             oracle/Makefile into oracle/_ref/, vectors in tests/golden/):
  *             radixFloat, radixSort3, std::hash<pair<u32,u32>>, RigidBody construction
  *             (mass/inertia/frame/AABB), Geom::RecomputeAABB, Geom::GetSupportPointSet,
- *             Vector2::Rotate, ContactPoint::Equals, DenseHashSet insert/contains (set
+ *             Vector2::Rotate, the ContactPoint constructor and ContactPoint::Equals, the plane form
+ *             of ProjectPointToLine, AABB2::Intersects, DenseHashSet insert/contains (set
  *             semantics on tombstone-free sequences).
  *   UNPINNED ("parity unpinned"): everything that lives in the reference's .cpp files —
  *             Solver.cpp, Collider.cpp, World.cpp.  Those translation units include
@@ -94,6 +95,11 @@ void     phxo_body_init(phxo_body* b, float px, float py, float angle, float sx,
 void     phxo_recompute_aabb(phxo_body* b);                                /* Geom.h:79-85 */
 void     phxo_rotate_vec(phxo_vec2* v, float angle);                       /* Vector2.h:48-56 */
 int      phxo_support_points(const phxo_body* b, float ax, float ay, phxo_vec2 out[2]); /* Geom.h:66-77 */
+int      phxo_contact_equals(const phxo_contact_point* a, const phxo_contact_point* o, float tol); /* Manifold.h:28-36 */
+void     phxo_contact_point_make(phxo_contact_point* out, float p1x, float p1y, float p2x, float p2y, float nx, float ny,
+                                 const phxo_body* b1, const phxo_body* b2);  /* Manifold.h:18-26 */
+void     phxo_project_point_to_line(float px, float py, float qx, float qy, float nx, float ny, float dx, float dy, float out[2]); /* Vector2.h ProjectPointToLine */
+int      phxo_aabb_intersects(const phxo_body* a, const phxo_body* b);      /* AABB2.h:18-24 */
 
 /* ---- broadphase stages on raw arrays (Collider.cpp:251-366) ---- */
 void   phxo_broadphase_build(const phxo_body* bodies, size_t n, phxo_sort_entry* keys_unsorted /*n, may be NULL*/,

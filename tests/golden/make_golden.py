@@ -91,6 +91,52 @@ def main():
     out["support_n"] = sup_n
     out["support_pts"] = sup_pts
 
+    # narrowphase leaves that live in headers: ContactPoint ctor + Equals (ref: Manifold.h:18-36), the plane form of
+    # ProjectPointToLine (ref: Vector2.h:277-285), AABB2::Intersects (ref: AABB2.h:18-24)
+    q = 1200
+    ia, ib = rng.integers(0, m, q), rng.integers(0, m, q)
+    cp_args = rng.uniform(-50, 50, (q, 6)).astype(np.float32)
+    cp_args[:, 0:2] += np.stack([bodies["pos"]["x"][ia], bodies["pos"]["y"][ia]], axis=1)
+    cp_args[:, 2:4] += np.stack([bodies["pos"]["x"][ib], bodies["pos"]["y"][ib]], axis=1)
+    made = np.zeros(q, dtype=ob.contact_point_dtype)
+    for k in range(q):
+        one = np.zeros(1, dtype=ob.contact_point_dtype)
+        R.ref_contact_point_make(one.ctypes.data, *[float(x) for x in cp_args[k]], bodies[ia[k]:ia[k] + 1].ctypes.data, bodies[ib[k]:ib[k] + 1].ctypes.data)
+        made[k] = one[0]
+    out["cp_args"], out["cp_b1"], out["cp_b2"], out["cp_made"] = cp_args, ia.astype(np.int32), ib.astype(np.int32), made
+    # Equals: pairs at distances straddling the tolerance on either delta
+    ea = made.copy()
+    eb = made.copy()
+    jitter = rng.uniform(-3.0, 3.0, (q, 4)).astype(np.float32)
+    jitter[: q // 3, 2:] = 0.0                      # only delta1 differs
+    jitter[q // 3: 2 * q // 3, :2] = 0.0            # only delta2 differs
+    eb["delta1"]["x"] += jitter[:, 0]; eb["delta1"]["y"] += jitter[:, 1]; eb["delta2"]["x"] += jitter[:, 2]; eb["delta2"]["y"] += jitter[:, 3]
+    tol = np.where(np.arange(q) % 2 == 0, 2.0, 0.75).astype(np.float32)
+    out["eq_a"], out["eq_b"], out["eq_tol"] = ea, eb, tol
+    out["eq_out"] = np.array([R.ref_contact_equals(ea[k:k + 1].ctypes.data, eb[k:k + 1].ctypes.data, float(tol[k])) for k in range(q)], dtype=np.int32)
+    pl = rng.uniform(-100, 100, (q, 8)).astype(np.float32)
+    pl[:, 4:6] /= np.linalg.norm(pl[:, 4:6], axis=1, keepdims=True)
+    pl[:, 6:8] = pl[:, 4:6] * rng.choice([-1.0, 1.0], (q, 1)).astype(np.float32)   # narrowphase projects along +-normal
+    pl[: q // 4, 6:8] = rng.standard_normal((q // 4, 2)).astype(np.float32)         # and a general direction
+    pr = np.zeros((q, 2), dtype=np.float32)
+    for k in range(q):
+        tmp = np.zeros(2, dtype=np.float32)
+        R.ref_project_point_to_line(*[float(x) for x in pl[k]], tmp.ctypes.data)
+        pr[k] = tmp
+    out["proj_in"], out["proj_out"] = pl, pr
+    # AABB overlap, including touching boxes (shared edges are overlaps: the tests are strict '>')
+    ta, tb = rng.integers(0, m, q), rng.integers(0, m, q)
+    touch = bodies.copy()
+    out["aabb_a"], out["aabb_b"] = ta.astype(np.int32), tb.astype(np.int32)
+    out["aabb_out"] = np.array([R.ref_aabb_intersects(touch[a:a + 1].ctypes.data, touch[b:b + 1].ctypes.data) for a, b in zip(ta, tb)], dtype=np.int32)
+    edge = np.zeros(4, dtype=ob.body_dtype)
+    for k, (x, y) in enumerate([(0, 0), (20, 0), (0, 20), (20.5, 0)]):
+        one = np.zeros(1, dtype=ob.body_dtype)
+        R.ref_body_init(one.ctypes.data, float(x), float(y), 0.0, 10.0, 10.0, 1e-5)
+        edge[k] = one[0]
+    out["aabb_edge_bodies"] = edge
+    out["aabb_edge_out"] = np.array([[R.ref_aabb_intersects(edge[a:a + 1].ctypes.data, edge[b:b + 1].ctypes.data) for b in range(4)] for a in range(4)], dtype=np.int32)
+
     # DenseHashSet insert-only behaviour == set semantics (ref: base/DenseHash.h:208-236)
     ps = rng.integers(0, 300, (5000, 2), dtype=np.uint64).astype(np.uint32)
     res = np.zeros(len(ps), dtype=np.uint8)
