@@ -119,6 +119,12 @@ int phx_solver_synchronize(phx_solver* s);
  * results differ from the reference's by the rounding; tests compare against an oracle that rounds the same way. */
 int phx_solver_set_body_state_bits(phx_solver* s, int32_t bits);
 
+/* Island sharding across ranks: the schedule's groups (phx_solver_get_groups) are body-disjoint, so rank `shard` of
+ * `shard_count` sweeps only groups g with g % shard_count == shard (the trailing HBM group counts as group
+ * lds_count) and leaves every other body and joint untouched.  All ranks must be given the same joints; the union of
+ * their results is the unsharded result, bit for bit.  Default 0 / 1 = everything. */
+int phx_solver_set_shard(phx_solver* s, int32_t shard, int32_t shard_count);
+
 /* results of the last solve (valid after a synchronizing call) — counterparts of
  * Solver::islandCount / islandMaxSize (ref: src/Solver.h:105-106) plus executed sweep counts */
 typedef struct {
@@ -154,16 +160,22 @@ int phx_solver_get_refreshed(phx_solver* s, int32_t joint_index, float out30[30]
 /* Host-only schedule builders (no device needed) — exposed so the ordering logic can be checked on
  * its own.  phx_schedule_colours is this backend's counterpart of Solver::PrepareIndices
  * (ref: src/Solver.cpp:217-273): it partitions the joints into colour classes of joints that share
- * no dynamic body (is_static[b] != 0 exempts body b), first-fit in joint order, stable inside a
- * colour.  phx_schedule_islands follows Solver::GatherIslands (ref: src/Solver.cpp:285-454):
+ * no dynamic body (is_static[b] != 0 exempts body b): joints take the first free colour in order of
+ * DECREASING phx_schedule_priority(priority_ids[j], j) — a fixed pseudo-random order, chosen because
+ * the device reaches the same colours with ~log n Jones-Plassmann rounds, whereas joint-index order
+ * needs one round per box of a stacked column; inside a colour the slots keep joint-index order.
+ * priority_ids may be NULL (the joint index is used); the solver passes each joint's
+ * contactPointIndex, which survives compaction of the joint list (island sharding).
+ * phx_schedule_islands follows Solver::GatherIslands (ref: src/Solver.cpp:285-454):
  * joint_island[j] = coalesced island of joint j (-1 if both bodies are static), island_size[i] =
  * joints in island i; returns the island count. */
 int phx_schedule_colours(const int32_t* body1, const int32_t* body2, int32_t joint_count,
-                         const uint8_t* is_static, int32_t body_count,
+                         const uint8_t* is_static, int32_t body_count, const int32_t* priority_ids,
                          int32_t* order, int32_t* colour_offsets, int32_t offsets_cap, int32_t* colour_count);
 int phx_schedule_islands(const int32_t* body1, const int32_t* body2, int32_t joint_count,
                          const uint8_t* is_static, int32_t body_count,
                          int32_t* joint_island, int32_t* island_size, int32_t island_cap);
+uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Broadphase — replaces Collider::UpdateBroadphase + UpdatePairs                                   */
@@ -208,8 +220,8 @@ int  phx_world_add_body(phx_world* w, float px, float py, float angle, float hal
 /* main.cpp:91-93 groundBody->invMass = invInertia = 0 */
 int  phx_world_set_body_static(phx_world* w, int32_t body);
 int  phx_world_set_gravity(phx_world* w, float gravity);            /* ref: World.h:35 */
-/* restrict the solve to islands whose index % shard_count == shard (multi-GPU island sharding; the
- * default 0/1 solves everything).  Bodies of other shards keep their velocities. */
+/* restrict the solve to the schedule groups g with g % shard_count == shard (phx_solver_set_shard; multi-GPU
+ * island sharding; the default 0/1 solves everything).  Bodies of other shards keep their velocities. */
 int  phx_world_set_shard(phx_world* w, int32_t shard, int32_t shard_count);
 int  phx_world_update(phx_world* w, float dt, const phx_config* config);   /* ref: World.cpp:19-37 */
 /* World::Update split at the solver boundary: pre_solve = everything before Solver::SolveJoints

@@ -58,13 +58,15 @@ _SIGNATURES = {
     "phx_solver_solve": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
     "phx_solver_solve_device": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
     "phx_solver_synchronize": (C.c_int, [_vp]),
+    "phx_solver_set_shard": (C.c_int, [_vp, _i32, _i32]),
     "phx_solver_set_body_state_bits": (C.c_int, [_vp, _i32]),
     "phx_solver_get_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),
     "phx_solver_get_schedule": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_get_groups": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "phx_solver_get_refreshed": (C.c_int, [_vp, _i32, _vp]),
     "phx_solver_bench": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, C.POINTER(BenchResult)]),
-    "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "phx_schedule_priority": (C.c_uint64, [C.c_uint32, C.c_uint32]),
+    "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_schedule_islands": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32]),
     "phx_broadphase_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "phx_broadphase_destroy": (None, [_vp]),

@@ -63,16 +63,23 @@ def device_info(device=0):
     return {"name": name.value.decode(), "compute_units": cu.value, "lds_bytes": lds.value, "hbm_bytes": hbm.value}
 
 
-def schedule_colours(body1, body2, is_static):
-    """Host-only: colour classes of body-disjoint joints (this backend's PrepareIndices, ref: Solver.cpp:217-273)."""
+def schedule_priority(priority_id, joint_index):
+    """Colouring priority of a joint (higher = coloured earlier); see include/phyx_amd.h."""
+    return int(_lib.load().phx_schedule_priority(int(priority_id), int(joint_index)))
+
+
+def schedule_colours(body1, body2, is_static, priority_ids=None):
+    """Host-only: colour classes of body-disjoint joints (this backend's PrepareIndices, ref: Solver.cpp:217-273).
+    priority_ids: per-joint priority id (the solver uses contactPointIndex); the joint index if None."""
     L = _lib.load()
+    pid = None if priority_ids is None else np.ascontiguousarray(priority_ids, dtype=np.int32)
     b1 = np.ascontiguousarray(body1, dtype=np.int32)
     b2 = np.ascontiguousarray(body2, dtype=np.int32)
     st = np.ascontiguousarray(is_static, dtype=np.uint8)
     order = np.zeros(max(len(b1), 1), dtype=np.int32)
     offs = np.zeros(len(b1) + 2, dtype=np.int32)
     nc = C.c_int32(0)
-    check(L.phx_schedule_colours(_ptr(b1), _ptr(b2), len(b1), _ptr(st), len(st), _ptr(order), _ptr(offs), len(offs), C.byref(nc)))
+    check(L.phx_schedule_colours(_ptr(b1), _ptr(b2), len(b1), _ptr(st), len(st), None if pid is None else _ptr(pid), _ptr(order), _ptr(offs), len(offs), C.byref(nc)))
     return order[:len(b1)], offs[:nc.value + 1]
 
 
@@ -177,6 +184,10 @@ class Solver:
     def set_body_state_bits(self, bits):
         """32 = fp32 solver-side body state (default, the reference's); 16 = the fp16 ablation of BASELINE config 5."""
         check(self.L.phx_solver_set_body_state_bits(self.h, bits))
+
+    def set_shard(self, shard, shard_count):
+        """Sweep only the schedule groups g with g % shard_count == shard (multi-GPU island sharding)."""
+        check(self.L.phx_solver_set_shard(self.h, shard, shard_count))
 
     def stats(self):
         st = SolveStats()

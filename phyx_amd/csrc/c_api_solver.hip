@@ -58,6 +58,12 @@ int phx_solver_set_body_state_bits(phx_solver* s, int32_t bits)
     return s->impl.set_body_state_bits(bits);
 }
 
+int phx_solver_set_shard(phx_solver* s, int32_t shard, int32_t count)
+{
+    PHX_REQUIRE(s, "null handle");
+    return s->impl.set_shard(shard, count);
+}
+
 int phx_solver_get_groups(phx_solver* s, int32_t* offsets, int32_t cap, int32_t* count, int32_t* lds_count)
 {
     PHX_REQUIRE(s, "null handle");
@@ -77,13 +83,15 @@ int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t nb, const void
     return s->impl.bench(d_bodies, nb, d_cps, ncp, d_joints, nj, *cfg, warmup, steps, out);
 }
 
-int phx_schedule_colours(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb,
+uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index) { return phx::colour_priority(priority_id, joint_index); }
+
+int phx_schedule_colours(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb, const int32_t* priority_ids,
                          int32_t* order, int32_t* offsets, int32_t offsets_cap, int32_t* ncolours)
 {
     PHX_REQUIRE(nj >= 0 && nb >= 0 && (nj == 0 || (b1 && b2 && order)) && (nb == 0 || is_static) && offsets && ncolours, "bad arguments");
     for (int j = 0; j < nj; ++j) PHX_REQUIRE((unsigned)b1[j] < (unsigned)nb && (unsigned)b2[j] < (unsigned)nb, "body index out of range");
     phx::Schedule s;
-    phx::build_colour_schedule(b1, b2, nj, is_static, nb, s);
+    phx::build_colour_schedule(b1, b2, nj, is_static, nb, s, priority_ids);
     *ncolours = (int)s.colour_offsets.size() - 1;
     if ((int)s.colour_offsets.size() > offsets_cap) { phx::set_error("colour_offsets too small"); return PHX_ERR_CAPACITY; }
     std::copy(s.order.begin(), s.order.end(), order);

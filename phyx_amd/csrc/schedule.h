@@ -19,6 +19,17 @@
 
 namespace phx {
 
+// Colouring priority of joint j whose priority id is `id` (the colouring rule is stated below).  The solver uses the
+// joint's contactPointIndex as the id: unlike the joint's position it survives compacting the joint list (island
+// sharding solves a subset of the joints and must reach the same colours).  The joint index only breaks ties between
+// equal ids, so keys are unique; they are never zero (zero means "nobody" in the builders' tables).
+__host__ __device__ inline unsigned long long colour_priority(unsigned id, unsigned j)
+{
+    unsigned x = id * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    return (((unsigned long long)x << 32) | j) + 1ull;
+}
+
 struct Schedule {
     std::vector<int> order;               // slot -> joint
     std::vector<int> colour_offsets;      // ncolours + 1, over all groups
@@ -31,7 +42,8 @@ struct Schedule {
     std::vector<int> group_bodies;
     std::vector<uint32_t> slot_local;     // per slot of an LDS group: local body1 | local body2 << 16
     std::vector<uint8_t> slot_colour;     // per slot of an LDS group: colour index inside the group
-    std::vector<int> hbm_bodies;          // bodies touched by the HBM group (the only ones it stages / writes back)
+    std::vector<int> hbm_bodies;          // bodies touched by the HBM group, ascending (the only ones it stages / writes back)
+    int hbm_body_count = 0;               // = hbm_bodies.size() when the list is on the host; a device-built list lives in HBM only
     std::vector<int> hbm_colour_offsets;  // slots of the HBM group's colours (absolute), empty if there is no HBM group
     // A schedule built on the device keeps the LDS groups' order / colours in HBM only; `lds_on_host` says whether
     // order[], colour_offsets[], group_first_colour[] above already cover the LDS groups (DeviceSolver::materialise).
@@ -51,14 +63,21 @@ struct LdsCaps { int max_joints = 512, max_bodies = 768, max_colours = 64, max_s
 // (an LDS group's local body table lists its static bodies first, so a static body's local index is also its
 //  slot in the group's small static-tag table)
 
-// One HBM group holding every joint: greedy first-fit colouring in joint-index order, stable inside a colour.
-void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out);
+// Colouring rule (every group, host and device builders alike): joints take their colour FIRST-FIT IN ORDER OF DECREASING
+// colour_priority(id, joint index) — a fixed pseudo-random order.  Sequentially that is one pass over the sorted
+// joints; in parallel it is what Jones-Plassmann rounds compute (a joint colours itself once it has the highest
+// priority among the uncoloured joints on both of its dynamic bodies), which needs ~log n rounds where joint-index order
+// would need one round per body of a stacked column.  Inside a colour the slots keep joint-index order.
+
+// One HBM group holding every joint.  `prio_id` (optional, per joint): priority ids; the joint index itself if null.
+void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out,
+                           const int* prio_id = nullptr);
 
 // Island-aware schedule: connected components binned into LDS groups where they fit `caps`, the rest in one
 // trailing HBM group.
 // `big` (optional) is a roomier shape used for ALL groups when some component fits it but not `caps`.
 void build_island_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
-                           const LdsCaps& caps, Schedule& out, const LdsCaps* big = nullptr);
+                           const LdsCaps& caps, Schedule& out, const LdsCaps* big = nullptr, const int* prio_id = nullptr);
 
 // Solver::GatherIslands semantics (ref: Solver.cpp:285-454): per-joint coalesced island id (-1 for
 // static-static joints) and per-island joint counts.

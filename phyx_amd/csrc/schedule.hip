@@ -23,7 +23,21 @@ static void parallel_chunks(int count, int min_per_thread, F&& fn)
     for (auto& t : pool) t.join();
 }
 
-// first-fit colouring of `joints` (indices into body1/body2) in the given order; returns colour per entry.
+// positions of `joints` in colouring order: decreasing colour_priority (schedule.h)
+static void priority_order(const std::vector<int>& joints, const int* prio_id, std::vector<int>& perm)
+{
+    std::vector<std::pair<unsigned long long, int>> keyed(joints.size());
+    for (size_t k = 0; k < joints.size(); ++k)
+        keyed[k] = {colour_priority((unsigned)(prio_id ? prio_id[joints[k]] : joints[k]), (unsigned)joints[k]), (int)k};
+    std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    perm.resize(joints.size());
+    for (size_t k = 0; k < joints.size(); ++k) perm[k] = keyed[k].second;
+}
+
+// first-fit colouring of `joints` (indices into body1/body2), taken in priority order; returns colour per entry.
+// Colouring in decreasing-priority order is what Jones-Plassmann rounds compute in parallel (a joint takes its colour
+// once it holds the highest priority among the uncoloured joints on both its dynamic bodies) — that is how the device
+// builder reaches the same colours in ~log n rounds instead of one serial pass (schedule_kernels.h).
 // `used` is caller-owned scratch (nb * words 64-bit masks, all zero on entry and on exit) so that colouring a
 // thousand small bins does not allocate or clear a world-sized array a thousand times.
 struct ColourScratch {
@@ -33,9 +47,11 @@ struct ColourScratch {
 };
 
 static int colour_joints(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-                         int nb, std::vector<int>& colour, ColourScratch& sc)
+                         int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id)
 {
     colour.assign(joints.size(), 0);
+    std::vector<int> perm;
+    priority_order(joints, prio_id, perm);
     for (;;) {
         sc.ensure(nb);
         const int words = sc.words;
@@ -43,7 +59,8 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
         bool overflow = false;
         int ncolours = 0;
         size_t done = 0;
-        for (size_t k = 0; k < joints.size(); ++k) {
+        for (size_t i = 0; i < joints.size(); ++i) {
+            const size_t k = (size_t)perm[i];
             const int a = body1[joints[k]], b = body2[joints[k]];
             const bool da = !is_static[a], db = !is_static[b];
             int c = -1;
@@ -58,10 +75,10 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
             if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
             if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
             ncolours = std::max(ncolours, c + 1);
-            done = k + 1;
+            done = i + 1;
         }
-        for (size_t k = 0; k < done; ++k)                      // leave the scratch clean for the next caller
-            for (int body : {body1[joints[k]], body2[joints[k]]})
+        for (size_t i = 0; i < done; ++i)                      // leave the scratch clean for the next caller
+            for (int body : {body1[joints[perm[i]]], body2[joints[perm[i]]]})
                 for (int w = 0; w < words; ++w) used[(size_t)body * words + w] = 0ull;
         if (!overflow) return ncolours;
         sc.words *= 2;                                         // > 64 * words colours needed: widen the masks and redo
@@ -93,23 +110,30 @@ static void reset(Schedule& out)
     out.group_body_offsets.assign(1, 0);
 }
 
-void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out)
+// bodies touched by `joints`, ascending
+static void touched_bodies(const std::vector<int>& joints, const int* body1, const int* body2, int nb, std::vector<int>& out)
+{
+    std::vector<unsigned char> seen(nb, 0);
+    for (int j : joints) { seen[body1[j]] = 1; seen[body2[j]] = 1; }
+    out.clear();
+    for (int b = 0; b < nb; ++b) if (seen[b]) out.push_back(b);
+}
+
+void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out, const int* prio_id)
 {
     reset(out);
     std::vector<int> all(nj), colour;
     for (int j = 0; j < nj; ++j) all[j] = j;
     ColourScratch scratch;
-    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch);
+    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch, prio_id);
     if (nj) {
         append_group(out, all, colour, ncol);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
     }
     out.lds_groups = 0;
     out.islands = false;
-    std::vector<unsigned char> seen(nb, 0);
-    for (int j = 0; j < nj; ++j)
-        for (int b : {body1[j], body2[j]})
-            if (!seen[b]) { seen[b] = 1; out.hbm_bodies.push_back(b); }
+    touched_bodies(all, body1, body2, nb, out.hbm_bodies);
+    out.hbm_body_count = (int)out.hbm_bodies.size();
 }
 
 static int uf_find(std::vector<int>& t, int i)
@@ -204,7 +228,7 @@ struct LocalMap {
 };
 
 void build_bin(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-               const LdsCaps& caps, LocalMap& map, BinOut& out)
+               const LdsCaps& caps, LocalMap& map, BinOut& out, const int* prio_id)
 {
     out = BinOut{};
     map.reset((unsigned)joints.size() * 2u + 8u);
@@ -221,13 +245,16 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
     int nstatic = 0;
     for (int b : out.bodies) nstatic += is_static[b] ? 1 : 0;
     if ((int)out.bodies.size() > caps.max_bodies || (int)out.bodies.size() > 65535 || nstatic > caps.max_static) { out.rejected = true; return; }
-    // greedy first-fit colouring in joint order on per-local-body masks
+    // first-fit colouring in priority order on per-local-body masks
     const int words = (caps.max_colours + 63) / 64;
     std::vector<unsigned long long> used(out.bodies.size() * (size_t)words, 0ull);
     std::vector<int> colour(joints.size());
     std::vector<uint32_t> local(joints.size());
+    std::vector<int> perm;
+    priority_order(joints, prio_id, perm);
     int ncol = 0;
-    for (size_t k = 0; k < joints.size(); ++k) {
+    for (size_t i = 0; i < joints.size(); ++i) {
+        const size_t k = (size_t)perm[i];
         bool fresh;
         const int a = *map.find_or_insert(body1[joints[k]], fresh), b = *map.find_or_insert(body2[joints[k]], fresh);
         const bool da = !is_static[body1[joints[k]]], db = !is_static[body2[joints[k]]];
@@ -260,7 +287,7 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
 } // namespace
 
 void build_island_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
-                           const LdsCaps& small_caps, Schedule& out, const LdsCaps* big)
+                           const LdsCaps& small_caps, Schedule& out, const LdsCaps* big, const int* prio_id)
 {
     reset(out);
     out.islands = true;
@@ -324,7 +351,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         for (int b = b0; b < b1; ++b) {
             joints.assign(comp_joints.begin() + comp_count[bins[b].first], comp_joints.begin() + comp_count[bins[b].second]);
             if (bins[b].second - bins[b].first > 1) std::sort(joints.begin(), joints.end());      // joint-index order inside the bin
-            build_bin(joints, body1, body2, is_static, caps, map, built[b]);
+            build_bin(joints, body1, body2, is_static, caps, map, built[b], prio_id);
             if (built[b].rejected) built[b].order = joints;
         }
     });
@@ -352,14 +379,12 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         std::sort(rest.begin(), rest.end());
         std::vector<int> colour;
         ColourScratch scratch;
-        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch);
+        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch, prio_id);
         const size_t first = out.colour_offsets.size() - 1;
         append_group(out, rest, colour, ncol);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
-        std::vector<unsigned char> seen(nb, 0);
-        for (int j : rest)
-            for (int b : {body1[j], body2[j]})
-                if (!seen[b]) { seen[b] = 1; out.hbm_bodies.push_back(b); }
+        touched_bodies(rest, body1, body2, nb, out.hbm_bodies);
+        out.hbm_body_count = (int)out.hbm_bodies.size();
     }
 }
 

@@ -8,11 +8,12 @@
 //   numbering              components numbered by their smallest body index (= body order, ref: Solver.cpp:344-356)
 //   binning                greedy over consecutive components — ncomp integers, done on the host
 //   joint order            stable radix sort of the joints by bin (device_radix.h)
-//   per bin                one workgroup: local body table (static first), first-fit colouring in joint order,
-//                          stable counting sort by colour -> slot arrays
+//   per bin                one workgroup: local body table (static first), first-fit colouring in priority order
+//                          (Jones-Plassmann rounds in LDS), stable placement by colour -> slot arrays
 #pragma once
 
 #include "common.h"
+#include "schedule.h"
 
 namespace phx {
 
@@ -115,13 +116,13 @@ template <int T, int NB>
 static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
 {
     constexpr int HT = 4 * T;                           // open-addressing table, <= 2T distinct bodies
-    __shared__ int ht_key[HT];
+    __shared__ __align__(8) int ht_key[HT];              // later reused as the per-body priority table of the colouring
+    static_assert((size_t)NB * 8 <= (size_t)HT * 4, "priority table must fit the hash table");
     __shared__ int ht_val[HT];                          // first occurrence position, later the local index
-    __shared__ int jb[2][T];
     __shared__ unsigned long long used[NB];
-    __shared__ unsigned short col[T], pos[T];
     __shared__ unsigned scan_lds[T / 64];
-    __shared__ unsigned hist[64];                         // per-colour counts, then cursors (LDS: a private array would live in scratch)
+    __shared__ unsigned hist[64];                         // first slot of each colour
+    __shared__ unsigned short wave_count[(T / 64) * 64];   // joints of colour c in wave w, then the exclusive sum over waves
     __shared__ int n_static, n_bodies, n_col, bad;
 
     const int g = blockIdx.x, tid = threadIdx.x;
@@ -137,7 +138,6 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     if (live) {
         j = (int)v.sorted_joints[begin + tid];
         b[0] = v.joints[j].body1; b[1] = v.joints[j].body2;
-        jb[0][tid] = b[0]; jb[1][tid] = b[1];
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s
             unsigned p = ((unsigned)b[s] * 2654435761u) & (HT - 1);
             for (;;) {
@@ -181,41 +181,163 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     }
     __syncthreads();
     int loc[2] = {0, 0};
-    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; jb[0][tid] = loc[0]; jb[1][tid] = loc[1]; }
+    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; }
     __syncthreads();
-    // greedy first-fit colouring in joint order (one lane; the masks live in LDS), then stable positions by colour
-    if (tid == 0 && fits) {
-        int ncol = 0;
-        for (int k = 0; k < count; ++k) {
-            const int a = jb[0][k], c2 = jb[1][k];
-            const bool da = a >= n_static, db = c2 >= n_static;          // static bodies sit first in the table
+    // First-fit colouring in priority order by Jones-Plassmann rounds (schedule.h): every round, an uncoloured joint
+    // that holds the highest priority on both its dynamic bodies takes the smallest colour free on them.  One winner
+    // per body per round, so the mask updates do not race.  ~log(count) rounds of three barriers each.
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(ht_key);        // the hash table is dead by now (NB * 8 <= HT * 4)
+    for (int i = tid; i < NB; i += T) best[i] = 0ull;
+    __syncthreads();
+    const bool dyn0 = loc[0] >= n_static, dyn1 = loc[1] >= n_static;                  // static bodies sit first in the table
+    const unsigned long long key = live ? colour_priority((unsigned)v.joints[j].contact_point_index, (unsigned)j) : 0ull;
+    bool pending = live && fits;
+    int mycol = 0;
+    for (;;) {
+        if (pending) { if (dyn0) atomicMax(&best[loc[0]], key); if (dyn1) atomicMax(&best[loc[1]], key); }
+        __syncthreads();
+        const bool win = pending && (!dyn0 || best[loc[0]] == key) && (!dyn1 || best[loc[1]] == key);
+        __syncthreads();
+        if (win) {
             unsigned long long m = 0;
-            if (da) m |= used[a];
-            if (db) m |= used[c2];
-            if (!~m) { bad = 1; break; }
-            const int c = __builtin_ctzll(~m);
-            if (da) used[a] |= 1ull << c;
-            if (db) used[c2] |= 1ull << c;
-            col[k] = (unsigned short)c;
-            hist[c]++;
-            if (c + 1 > ncol) ncol = c + 1;
+            if (dyn0) m |= used[loc[0]];
+            if (dyn1) m |= used[loc[1]];
+            if (!~m) bad = 1;
+            else {
+                mycol = __builtin_ctzll(~m);
+                if (dyn0) used[loc[0]] |= 1ull << mycol;
+                if (dyn1) used[loc[1]] |= 1ull << mycol;
+            }
+            if (dyn0) best[loc[0]] = 0ull;
+            if (dyn1) best[loc[1]] = 0ull;
+            pending = false;
         }
-        if (!bad) {
-            unsigned run = 0;
-            for (int c = 0; c < ncol; ++c) { const unsigned n = hist[c]; hist[c] = run; run += n; }
-            for (int k = 0; k < count; ++k) pos[k] = (unsigned short)hist[col[k]]++;
-            n_col = ncol;
+        if (!__syncthreads_or(pending ? 1 : 0)) break;
+    }
+    // stable placement: slot = first slot of my colour + joints of my colour in earlier waves + earlier lanes of my wave
+    for (int i = tid; i < (T / 64) * 64; i += T) wave_count[i] = 0;
+    __syncthreads();
+    const bool placed = live && fits && !bad;
+    int rank = 0;
+    {
+        unsigned long long todo = __ballot(placed);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int k = __shfl(mycol, leader);
+            const unsigned long long same = __ballot(placed && mycol == k);
+            if (placed && mycol == k) rank = __popcll(same & ((1ull << lane) - 1ull));
+            if (lane == leader) wave_count[wave * 64 + k] = (unsigned short)__popcll(same);
+            todo &= ~same;
         }
     }
     __syncthreads();
+    if (tid < 64) {                                      // lane c: joints of colour c per wave -> exclusive over waves; colour starts
+        unsigned run = 0;
+        for (int w = 0; w < T / 64; ++w) { const unsigned t = wave_count[w * 64 + tid]; wave_count[w * 64 + tid] = (unsigned short)run; run += t; }
+        unsigned x2 = run;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x2, off); if (lane >= off) x2 += y; }
+        hist[tid] = x2 - run;
+        const unsigned long long nonempty = __ballot(run != 0);
+        if (tid == 0) n_col = nonempty ? 64 - __builtin_clzll(nonempty) : 0;
+    }
+    __syncthreads();
+    const int at = placed ? (int)(hist[mycol] + wave_count[wave * 64 + mycol]) + rank : 0;
     if (!fits || bad) { if (tid == 0) *v.rejected = 1; return; }
     if (live) {
-        const int slot = begin + pos[tid];
+        const int slot = begin + at;
         v.order[slot] = j;
         v.slot_local[slot] = (unsigned)loc[0] | ((unsigned)loc[1] << 16);
-        v.slot_colour[slot] = (unsigned char)col[tid];
+        v.slot_colour[slot] = (unsigned char)mycol;
     }
     if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; }
+}
+
+// ---- the HBM group (islands too big for a workgroup, or everything in Single mode): the same colouring in HBM ----------
+// One launch per Jones-Plassmann round.  Three per-body priority tables rotate: `cur` was filled by the previous round
+// (highest priority among the joints still uncoloured on each dynamic body), `next` is filled for the following round by
+// the joints that stay uncoloured, `zero` is cleared for the round after that.  A body has at most one winner per round,
+// so the colour-mask updates do not race.
+constexpr unsigned JP_NONE = 0xFFFFFFFFu;
+constexpr int JP_MAX_COLOURS = 64;
+
+struct JpView {
+    const unsigned* ids;              // the group's joints, ascending joint index
+    int count;
+    const phx_contact_joint* joints;
+    const unsigned char* is_static;
+    int nb;
+    unsigned long long* used;         // per body: colours taken
+    unsigned* colour;                 // per entry: JP_NONE until coloured
+    unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
+    int* remaining;                   // per round: nonzero if some joint is still uncoloured after it
+    int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours
+};
+
+static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigned long long* __restrict__ cur, unsigned long long* next,
+                                                         unsigned long long* zero, int round)
+{
+    bool left = false;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
+        if (v.colour[k] != JP_NONE) continue;
+        const unsigned j = v.ids[k];
+        const phx_contact_joint jt = v.joints[j];
+        const unsigned a = (unsigned)jt.body1, b = (unsigned)jt.body2;
+        if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) { atomicOr(v.flags, 1); v.colour[k] = 0; continue; }
+        const bool da = !v.is_static[a], db = !v.is_static[b];
+        const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
+        if (round == 0) { v.touched[a] = 1u; v.touched[b] = 1u; }
+        else if ((!da || cur[a] == key) && (!db || cur[b] == key)) {
+            unsigned long long m = 0;
+            if (da) m |= v.used[a];
+            if (db) m |= v.used[b];
+            int c = 0;
+            if (!~m) atomicOr(v.flags, 2);
+            else {
+                c = __builtin_ctzll(~m);
+                if (da) v.used[a] |= 1ull << c;
+                if (db) v.used[b] |= 1ull << c;
+            }
+            v.colour[k] = (unsigned)c;
+            continue;
+        }
+        if (da) { atomicMax(&next[a], key); zero[a] = 0ull; }
+        if (db) { atomicMax(&next[b], key); zero[b] = 0ull; }
+        left = true;
+    }
+    if (__any(left) && (threadIdx.x & 63) == 0) v.remaining[round] = 1;      // a flag, not a count: same-address atomics would serialise
+}
+
+static __global__ void __launch_bounds__(256) k_jp_hist(const unsigned* __restrict__ colour, int count, unsigned* __restrict__ hist)
+{
+    __shared__ unsigned h[JP_MAX_COLOURS];
+    if (threadIdx.x < JP_MAX_COLOURS) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) atomicAdd(&h[colour[k] & (JP_MAX_COLOURS - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < JP_MAX_COLOURS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// bodies flagged in `scan` (already exclusive-scanned, nb + 1 entries) -> ascending list
+static __global__ void __launch_bounds__(256) k_compact_flagged(const unsigned* __restrict__ scan, int nb, int* __restrict__ list)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
+        if (scan[i + 1] != scan[i]) list[scan[i]] = i;
+}
+
+static __global__ void __launch_bounds__(256) k_static_flags(const unsigned char* __restrict__ is_static, int nb, unsigned* __restrict__ flags)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) flags[i] = (i < nb && is_static[i]) ? 1u : 0u;
+}
+
+// static body -> its slot in the static-tag tables (rank among static bodies), dynamic body -> -1
+static __global__ void __launch_bounds__(256) k_static_slots(const unsigned char* __restrict__ is_static, const unsigned* __restrict__ scan, int nb, int* __restrict__ slot)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) slot[i] = is_static[i] ? (int)scan[i] : -1;
+}
+
+static __global__ void __launch_bounds__(256) k_iota(unsigned* __restrict__ out, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (unsigned)i;
 }
 
 } // namespace phx

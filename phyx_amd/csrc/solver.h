@@ -40,6 +40,7 @@ public:
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
     int set_body_state_bits(int bits);
+    int set_shard(int shard, int count);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
@@ -50,7 +51,7 @@ public:
 
 private:
     int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild);
-    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool* fallback);
+    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
     int materialise_schedule();
     int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     struct GraphKey {
@@ -93,8 +94,9 @@ private:
     DevBuf<int> cc_parent_, joint_comp_, bin_of_comp_, grp_goff_, sb_small_;
     DevBuf<unsigned char> cc_static_;
     DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_, sort_scan_;
-    DevBuf<int2> rest_pairs_;
-    std::vector<int> rest_order_;      // HBM group's slots (joint ids), kept on the host for materialise_schedule()
+    DevBuf<unsigned long long> jp_best_[3], jp_used_;      // colouring of the HBM group on the device (schedule_kernels.h)
+    DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2];
+    DevBuf<int> jp_small_;
     bool gpu_builder_ = true;
     DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;
@@ -117,6 +119,8 @@ private:
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
     bool use_graphs_ = true, wave_islands_ = false, speculate_ = true, half_state_ = false;
+    int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
+    bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }
     // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()
     struct Pending { bool active = false; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
     int ncp_ = 0;

@@ -16,10 +16,12 @@ namespace phx {
 
 __global__ void __launch_bounds__(256) k_extract_topology(const phx_contact_joint* __restrict__ joints, int nj,
                                                           const phx_rigid_body* __restrict__ bodies, int nb,
-                                                          int2* __restrict__ pairs, unsigned char* __restrict__ is_static)
+                                                          int2* __restrict__ pairs, int* __restrict__ prio_id, unsigned char* __restrict__ is_static)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
         pairs[i] = make_int2(joints[i].body1, joints[i].body2);
+        prio_id[i] = joints[i].contact_point_index;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
         is_static[i] = (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) ? 1 : 0;
 }
@@ -37,7 +39,8 @@ DeviceSolver::~DeviceSolver()
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
     cc_parent_.release(); joint_comp_.release(); bin_of_comp_.release(); grp_goff_.release(); sb_small_.release(); cc_static_.release();
-    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); rest_pairs_.release();
+    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); for (int k = 0; k < 3; ++k) jp_best_[k].release();
+    jp_used_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_colours_.release(); colour_offsets_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
@@ -109,10 +112,10 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
 
     // 2. topology changed.  Island-aware schedules are built on the device (only component sizes cross PCIe);
     //    the host builder below is the specification and the fallback (Single mode, bins that exceed the caps, ...).
-    if (want_islands && gpu_builder_ && !wave_islands_) {
+    if (gpu_builder_ && !(want_islands && wave_islands_)) {
         bool fallback = false;
         nb_ = nb; nj_ = nj;
-        PHX_TRY(build_schedule_device(d_bodies, nb, d_joints, nj, &fallback));
+        PHX_TRY(build_schedule_device(d_bodies, nb, d_joints, nj, want_islands, &fallback));
         if (!fallback) {
             sched_.fingerprint = fp;
             raw_fingerprint_ = raw;
@@ -128,17 +131,22 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     DevBuf<int2> d_pairs;
+    DevBuf<int> d_prio;
     DevBuf<unsigned char> d_static;
     PHX_TRY(d_pairs.reserve(std::max(nj, 1)));
+    PHX_TRY(d_prio.reserve(std::max(nj, 1)));
     PHX_TRY(d_static.reserve(std::max(nb, 1)));
-    hipLaunchKernelGGL(k_extract_topology, dim3(grid_for(std::max(nj, nb))), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, d_pairs.p, d_static.p);
+    hipLaunchKernelGGL(k_extract_topology, dim3(grid_for(std::max(nj, nb))), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, d_pairs.p, d_prio.p, d_static.p);
     PHX_HIP(hipGetLastError());
     std::vector<int2> pairs(std::max(nj, 1));
+    std::vector<int> prio_id(std::max(nj, 1));
     std::vector<unsigned char> is_static(std::max(nb, 1));
     PHX_HIP(hipMemcpyAsync(pairs.data(), d_pairs.p, (size_t)nj * sizeof(int2), hipMemcpyDeviceToHost, stream_));
+    PHX_HIP(hipMemcpyAsync(prio_id.data(), d_prio.p, (size_t)nj * sizeof(int), hipMemcpyDeviceToHost, stream_));
     PHX_HIP(hipMemcpyAsync(is_static.data(), d_static.p, (size_t)nb, hipMemcpyDeviceToHost, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
     d_pairs.release();
+    d_prio.release();
     d_static.release();
     lap("download");
 
@@ -153,9 +161,9 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         else { caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64; }
         LdsCaps big;
         big.max_joints = ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
-        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, wave_islands_ ? nullptr : &big);
+        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, wave_islands_ ? nullptr : &big, prio_id.data());
     } else {
-        build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_);
+        build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_, prio_id.data());
     }
     lap("build");
     if (sched_.ncolours() > 65000) { set_error("more than 65000 colours"); return PHX_ERR_INVALID; }
@@ -219,15 +227,10 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
 // ---------------------------------------------------------------------------------------------------
 // device schedule builder (kernels: schedule_kernels.h)
 
-__global__ void __launch_bounds__(256) k_extract_pairs(const phx_contact_joint* __restrict__ joints, const unsigned* __restrict__ ids, int n, int2* __restrict__ pairs)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const phx_contact_joint& j = joints[ids[i]];
-        pairs[i] = make_int2(j.body1, j.body2);
-    }
-}
+constexpr int JP_BATCH = 8;          // Jones-Plassmann rounds queued between two looks at the 'joints left' counter
+constexpr int JP_ROUNDS_MAX = 512;
 
-int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool* fallback)
+int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
 {
     *fallback = false;
     const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
@@ -241,8 +244,16 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(sort_scan_.reserve((size_t)div_up(std::max(std::max(nb, nj), RS_BINS * div_up(njs, RS_TILE)), SCAN_TILE) + 2));
     PHX_TRY(order_.reserve(njs));
 
-    // 1. connected components
     hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p);
+    Schedule sc;
+    sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
+    sc.islands = want_islands; sc.lds_on_host = false;
+    int nbins = 0, lds_slots = 0, where = 0;
+    if (!want_islands) {
+        // Single mode: one coupled system, every joint goes to the HBM group in joint order
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
+    } else {
+    // 1. connected components
     for (int round = 0;; ++round) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
         int changed = 0;
@@ -271,9 +282,6 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
 
     // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
     //    (identical to schedule.hip::build_island_schedule — ncomp integers of work)
-    Schedule sc;
-    sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
-    sc.islands = true; sc.lds_on_host = false;
     {
         int run = 0, count = 0, mx = 0;
         for (int c = 0; c < ncomp; ++c) {
@@ -286,7 +294,6 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     for (int c = 0; c < ncomp; ++c) if ((int)comp_size[c] > ISL_T && (int)comp_size[c] <= ISL_T_BIG) { cap_joints = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
     sc.lds_lanes = cap_joints;
     std::vector<int> bin_of(std::max(ncomp, 1), -1);
-    int nbins = 0;
     {
         int size = 0;
         bool open = false;
@@ -300,8 +307,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
             sc.group_offsets.back() += n;
         }
     }
-    const int lds_slots = sc.group_offsets.back();
-    const int rest = nj - lds_slots;
+    lds_slots = sc.group_offsets.back();
     for (int c = 0; c < ncomp; ++c) if (bin_of[c] < 0) bin_of[c] = nbins;
     sc.lds_groups = nbins;
     PHX_TRY(bin_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(grp_goff_.reserve(nbins + 2));
@@ -314,7 +320,6 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
                        sort_keys_[0].p, sort_vals_[0].p);
     int bits = 1;
     while ((1 << bits) <= nbins) ++bits;
-    int where = 0;
     PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_.p, stream_, &where));
     lap("sort");
 
@@ -342,44 +347,72 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
     sc.lds_colours = 0;
     for (int g = 0; g < nbins; ++g) sc.lds_colours += ncol[g];
+    }
+    const int rest = nj - lds_slots;
 
-    // 6. the HBM group (components too big for a workgroup, static-static joints): coloured on the host from its own
-    //    body pairs only
-    rest_order_.clear();
+    // 6. the HBM group (components too big for a workgroup, static-static joints; every joint in Single mode): the same
+    //    first-fit-by-priority colouring, one launch per Jones-Plassmann round, then a stable sort by colour
     nstatic_ = 0;
+    sc.hbm_body_count = 0;
     if (rest > 0) {
-        PHX_TRY(rest_pairs_.reserve(rest));
-        hipLaunchKernelGGL(k_extract_pairs, dim3(grid_for(rest)), dim3(256), 0, stream_, d_joints, (const unsigned*)(sort_vals_[where].p + lds_slots), rest, rest_pairs_.p);
-        std::vector<int2> pairs(rest);
-        std::vector<unsigned> ids(rest);
-        std::vector<unsigned char> is_static(nbs);
-        PHX_HIP(hipMemcpyAsync(pairs.data(), rest_pairs_.p, (size_t)rest * sizeof(int2), hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipMemcpyAsync(ids.data(), sort_vals_[where].p + lds_slots, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipMemcpyAsync(is_static.data(), cc_static_.p, (size_t)nb, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipStreamSynchronize(stream_));
-        std::vector<int> b1(rest), b2(rest);
-        for (int k = 0; k < rest; ++k) {
-            b1[k] = pairs[k].x; b2[k] = pairs[k].y;
-            if ((unsigned)b1[k] >= (unsigned)nb || (unsigned)b2[k] >= (unsigned)nb) { set_error("joint %u references body out of range", ids[k]); return PHX_ERR_INVALID; }
+        const unsigned* ids = sort_vals_[where].p + lds_slots;
+        for (int k = 0; k < 3; ++k) { PHX_TRY(jp_best_[k].reserve(nbs)); PHX_HIP(hipMemsetAsync(jp_best_[k].p, 0, (size_t)nbs * sizeof(unsigned long long), stream_)); }
+        PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_small_.reserve(JP_ROUNDS_MAX + JP_MAX_COLOURS + 8));
+        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); }
+        PHX_HIP(hipMemsetAsync(jp_used_.p, 0, (size_t)nbs * sizeof(unsigned long long), stream_));
+        PHX_HIP(hipMemsetAsync(jp_touched_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
+        PHX_HIP(hipMemsetAsync(jp_small_.p, 0, (size_t)(JP_ROUNDS_MAX + JP_MAX_COLOURS + 8) * sizeof(int), stream_));
+        PHX_HIP(hipMemsetAsync(jp_keys_[0].p, 0xFF, (size_t)rest * sizeof(unsigned), stream_));
+        JpView jv{};
+        jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = cc_static_.p; jv.nb = nb;
+        jv.used = jp_used_.p; jv.colour = jp_keys_[0].p; jv.touched = jp_touched_.p;
+        jv.remaining = jp_small_.p; jv.flags = jp_small_.p + JP_ROUNDS_MAX;
+        int round = 0;
+        for (bool done = false; !done;) {
+            if (round + JP_BATCH > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }       // pathological dependency chain: host builder
+            for (int k = 0; k < JP_BATCH; ++k, ++round)
+                hipLaunchKernelGGL(k_jp_round, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned long long*)jp_best_[round % 3].p,
+                                   jp_best_[(round + 1) % 3].p, jp_best_[(round + 2) % 3].p, round);
+            int tail[2] = {0, 0};
+            PHX_HIP(hipMemcpyAsync(&tail[0], jp_small_.p + round - 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+            PHX_HIP(hipMemcpyAsync(&tail[1], jp_small_.p + JP_ROUNDS_MAX, sizeof(int), hipMemcpyDeviceToHost, stream_));
+            PHX_HIP(hipStreamSynchronize(stream_));
+            if (tail[1] & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
+            if (tail[1] & 2) { *fallback = true; return PHX_OK; }                             // > 64 colours: host builder (wider masks)
+            done = tail[0] == 0;
         }
-        Schedule hs;
-        build_colour_schedule(b1.data(), b2.data(), rest, is_static.data(), nb, hs);      // ids[] is ascending, so this is joint order
-        rest_order_.resize(rest);
-        for (int k = 0; k < rest; ++k) rest_order_[k] = (int)ids[hs.order[k]];
-        sc.hbm_colour_offsets.resize(hs.colour_offsets.size());
-        for (size_t c = 0; c < hs.colour_offsets.size(); ++c) sc.hbm_colour_offsets[c] = lds_slots + hs.colour_offsets[c];
-        sc.hbm_bodies = hs.hbm_bodies;
+        if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d Jones-Plassmann rounds\n", rest, round);
+        lap("rest/colour");
+        // colour sizes, bodies touched, static slots: three small scans, one readback
+        unsigned* hist = reinterpret_cast<unsigned*>(jp_small_.p + JP_ROUNDS_MAX + 4);
+        hipLaunchKernelGGL(k_jp_hist, dim3(std::min(grid_for(rest), 256)), dim3(256), 0, stream_, (const unsigned*)jp_keys_[0].p, rest, hist);
+        PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_.p, stream_));
+        PHX_TRY(hbm_body_list_.reserve(nbs));
+        hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned*)jp_touched_.p, nb, hbm_body_list_.p);
+        int where2 = 0;
+        PHX_HIP(hipMemcpyAsync(jp_vals_[0].p, ids, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
+        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 6, sort_hist_.p, sort_scan_.p, stream_, &where2));
+        PHX_HIP(hipMemcpyAsync(order_.p + lds_slots, jp_vals_[where2].p, (size_t)rest * sizeof(int), hipMemcpyDeviceToDevice, stream_));
+        unsigned h_hist[JP_MAX_COLOURS], h_touched = 0;
+        PHX_HIP(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipMemcpyAsync(&h_touched, jp_touched_.p + nb, sizeof h_touched, hipMemcpyDeviceToHost, stream_));
+        // static slots (only the HBM path indexes the global static-tag tables)
+        PHX_TRY(static_slot_.reserve(nbs));
+        hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, nb, jp_touched_.p);
+        PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_.p, stream_));
+        hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)jp_touched_.p, nb, static_slot_.p);
+        unsigned h_nstatic = 0;
+        PHX_HIP(hipMemcpyAsync(&h_nstatic, jp_touched_.p + nb, sizeof h_nstatic, hipMemcpyDeviceToHost, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        nstatic_ = (int)h_nstatic;
+        sc.hbm_body_count = (int)h_touched;
+        sc.hbm_colour_offsets.assign(1, lds_slots);
+        for (int c = 0; c < JP_MAX_COLOURS; ++c) if (h_hist[c]) sc.hbm_colour_offsets.push_back(sc.hbm_colour_offsets.back() + (int)h_hist[c]);
+        if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
-        PHX_HIP(hipMemcpyAsync(order_.p + lds_slots, rest_order_.data(), (size_t)rest * sizeof(int), hipMemcpyHostToDevice, stream_));
-        h_static_slot_.assign(nb, -1);
-        for (int i = 0; i < nb; ++i) if (is_static[i]) h_static_slot_[i] = nstatic_++;
-        PHX_TRY(static_slot_.reserve(nbs)); PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sc.hbm_bodies.size(), 1)));
-        PHX_HIP(hipMemcpyAsync(static_slot_.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(hbm_body_list_.p, sc.hbm_bodies.data(), sc.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs)); PHX_TRY(sb_par_.reserve(nbs));
         PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs));
         PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
-        PHX_HIP(hipStreamSynchronize(stream_));
     }
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
     lap("rest");
@@ -394,16 +427,15 @@ int DeviceSolver::materialise_schedule()
     if (sched_.lds_on_host) return PHX_OK;
     const int lg = sched_.lds_groups;
     const int lds_slots = lg ? sched_.group_offsets[lg] : 0;
-    std::vector<int> order(std::max(lds_slots, 1)), ncol(std::max(lg, 1));
+    std::vector<int> order(std::max(nj_, 1)), ncol(std::max(lg, 1));
     std::vector<unsigned char> colour(std::max(lds_slots, 1));
     PHX_TRY(use_device(device_));
+    if (nj_) PHX_HIP(hipMemcpy(order.data(), order_.p, (size_t)nj_ * sizeof(int), hipMemcpyDeviceToHost));
     if (lds_slots) {
-        PHX_HIP(hipMemcpy(order.data(), order_.p, (size_t)lds_slots * sizeof(int), hipMemcpyDeviceToHost));
         PHX_HIP(hipMemcpy(colour.data(), slot_colour_.p, (size_t)lds_slots, hipMemcpyDeviceToHost));
         PHX_HIP(hipMemcpy(ncol.data(), grp_ncol_.p, (size_t)lg * sizeof(int), hipMemcpyDeviceToHost));
     }
-    sched_.order.assign(order.begin(), order.begin() + lds_slots);
-    sched_.order.insert(sched_.order.end(), rest_order_.begin(), rest_order_.end());
+    sched_.order.assign(order.begin(), order.begin() + nj_);
     sched_.colour_offsets.assign(1, 0);
     sched_.group_first_colour.assign(1, 0);
     for (int g = 0; g < lg; ++g) {
@@ -434,8 +466,8 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     PHX_HIP(hipMemsetAsync(isl_visits_.p, 0, sizeof(unsigned long long), stream_));
     // the HBM group (if any): PrepareBodies for the bodies it touches, PrepareJoints + RefreshJoints over its slots,
     // PreStep colour by colour.  Groups solved in LDS read and write the caller's records directly.
-    const int hbm_bodies = (int)sched_.hbm_bodies.size();
-    if (nj && sched_.has_hbm_group()) {
+    const int hbm_bodies = sched_.hbm_body_count;
+    if (nj && owns_hbm_group()) {
         hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies, (const int*)hbm_body_list_.p,
                            hbm_bodies, sb_imp_.p, sb_disp_.p, sb_par_.p);
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
@@ -456,25 +488,27 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
     sweep_launches_ = 0;
     if (!nj) return PHX_OK;
     const int lg = sched_.lds_groups;
-    if (lg) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
+    const int mine = lg > shard_ ? (lg - shard_ + shard_count_ - 1) / shard_count_ : 0;      // groups shard_, shard_ + count, ...
+    if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
+        iv.first = shard_; iv.stride = shard_count_;
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
         if (wave_islands_) {
             IslandWaveView wv{};
             wv.desc = grp_desc_.p; wv.colours = grp_colours_.p; wv.colour_offsets = colour_offsets_.p; wv.bodies = grp_bodies_.p;
             wv.slot_local = slot_local_.p; wv.executed = isl_stats_.p; wv.visits = isl_visits_.p;
-            hipLaunchKernelGGL(k_solve_islands_wave, dim3(lg), dim3(64), 0, stream_, v, wv, d_bodies, d_joints, d_cps, ci, pi);
+            hipLaunchKernelGGL(k_solve_islands_wave, dim3(mine), dim3(64), 0, stream_, v, wv, d_bodies, d_joints, d_cps, ci, pi);
         } else {
             const bool big = sched_.lds_lanes > ISL_T;
-            if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(lg), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(lg), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(lg), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+            else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         }
         ++sweep_launches_;
     }
-    if (sched_.has_hbm_group()) {
+    if (owns_hbm_group()) {
         const int ncol = (int)sched_.hbm_colour_offsets.size() - 1;
         for (int it = 0; it < iters; ++it) {
             const bool imp = it < ci, disp = it < pi;
@@ -495,9 +529,9 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
 int DeviceSolver::enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
-    if (nj && sched_.has_hbm_group()) {      // only the HBM group has results parked in the solver arrays
+    if (nj && owns_hbm_group()) {      // only the HBM group has results parked in the solver arrays
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
-        const int hbm_bodies = (int)sched_.hbm_bodies.size();
+        const int hbm_bodies = sched_.hbm_body_count;
         hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints);
         hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, v, (const int*)hbm_body_list_.p, hbm_bodies, d_bodies);
     }
@@ -707,6 +741,16 @@ int DeviceSolver::set_body_state_bits(int bits)
 {
     PHX_REQUIRE(bits == 16 || bits == 32, "body state precision must be 16 or 32 bits");
     if ((bits == 16) != half_state_) { half_state_ = bits == 16; drop_graphs(); }
+    return PHX_OK;
+}
+
+// Island sharding: every rank builds the same schedule from the same joints and sweeps only the groups
+// g with g % count == shard.  Groups are body-disjoint, so the other ranks' bodies and joints are simply left untouched;
+// stitching the ranks' results together reproduces the unsharded solve bit for bit.
+int DeviceSolver::set_shard(int shard, int count)
+{
+    PHX_REQUIRE(count >= 1 && shard >= 0 && shard < count, "bad shard");
+    if (shard != shard_ || count != shard_count_) { shard_ = shard; shard_count_ = count; drop_graphs(); }
     return PHX_OK;
 }
 

@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* 
         const phx_contact_joint j = joints[i];
         unsigned long long k = ((unsigned long long)(unsigned)j.body1 << 32) | (unsigned)j.body2;
         h += mix64(k + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1));
+        h += mix64(0xA24BAED4963EE407ull * (unsigned long long)(unsigned)j.contact_point_index + (unsigned long long)i);   // the colouring priority id
         // an out-of-range index can never belong to the topology a schedule was built (and validated) for
         if ((unsigned)j.body1 >= (unsigned)nb || (unsigned)j.body2 >= (unsigned)nb || (unsigned)j.contact_point_index >= (unsigned)ncp)
             h += 0xBADBADBADBADBAD1ull + (unsigned long long)i;
@@ -308,6 +309,7 @@ struct IslandView {
     const unsigned char* slot_colour; // per slot: colour inside the group
     int* executed;                    // [0] max impulse sweeps run by any group, [1] same for displacement
     unsigned long long* visits;       // sum over groups of impulse sweeps * joints
+    int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
 };
 
 template <int B>
@@ -355,8 +357,9 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     unsigned (*swd)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw + 2 * NB);
     float4* par = reinterpret_cast<float4*>(sw_raw);
 
-    const int4 d = iv.desc[blockIdx.x];
-    const int ncol = iv.ncol[blockIdx.x];
+    const int group = iv.first + (int)blockIdx.x * iv.stride;
+    const int4 d = iv.desc[group];
+    const int ncol = iv.ncol[group];
     const int tid = threadIdx.x;
 
     for (int i = tid; i < d.w; i += T) {

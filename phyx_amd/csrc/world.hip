@@ -226,34 +226,10 @@ int World::refresh_contact_joints()                                         // r
 
 int World::solve(const phx_config& cfg)                                     // ref: World.cpp:34
 {
-    if (shard_count <= 1) {
-        PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg));
-        return solver_.synchronize();
-    }
-    // island sharding: this rank solves the joints of islands whose index % shard_count == shard; islands are
-    // body-disjoint (static bodies aside), so the other shards' bodies simply keep their velocities here.  The island
-    // partition is host logic (GatherIslands semantics), so this path stages through the host.
-    std::vector<phx_rigid_body> hb(std::max(nb(), 1));
-    std::vector<phx_contact_point> hc(std::max(2 * nm, 1));
-    std::vector<phx_contact_joint> hj(std::max(nj, 1));
-    PHX_TRY(download_bodies(hb.data(), nb()));
-    PHX_TRY(download_contact_points(hc.data(), 2 * nm));
-    PHX_TRY(download_joints(hj.data(), nj));
-    std::vector<int> b1(nj), b2(nj), joint_island, island_size;
-    std::vector<unsigned char> is_static(std::max(nb(), 1));
-    for (int j = 0; j < nj; ++j) { b1[j] = hj[j].body1; b2[j] = hj[j].body2; }
-    for (int i = 0; i < nb(); ++i) is_static[i] = (hb[i].inv_mass == 0.f && hb[i].inv_inertia == 0.f);
-    gather_islands(b1.data(), b2.data(), nj, is_static.data(), nb(), joint_island, island_size);
-    std::vector<phx_contact_joint> mine;
-    std::vector<int> where;
-    for (int j = 0; j < nj; ++j)
-        if (joint_island[j] >= 0 && joint_island[j] % shard_count == shard) { mine.push_back(hj[j]); where.push_back(j); }
-    PHX_TRY(solver_.solve_host(hb.data(), nb(), hc.data(), 2 * nm, mine.data(), (int)mine.size(), cfg));
-    for (size_t k = 0; k < mine.size(); ++k) hj[where[k]] = mine[k];
-    if (nb()) PHX_HIP(hipMemcpyAsync(d_bodies_.p, hb.data(), (size_t)nb() * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
-    if (nj) PHX_HIP(hipMemcpyAsync(d_joints_.p, hj.data(), (size_t)nj * sizeof(phx_contact_joint), hipMemcpyHostToDevice, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
-    return PHX_OK;
+    // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
+    // keep their velocities here
+    PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg));
+    return solver_.synchronize();
 }
 
 int World::pre_solve(float dt)
@@ -365,6 +341,7 @@ int phx_world_set_shard(phx_world* w, int32_t shard, int32_t count)
     PHX_REQUIRE(w, "null handle");
     PHX_REQUIRE(count >= 1 && shard >= 0 && shard < count, "bad shard");
     w->impl.shard = shard; w->impl.shard_count = count;
+    PHX_TRY(w->impl.solver().set_shard(shard, count));
     return PHX_OK;
 }
 

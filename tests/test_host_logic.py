@@ -41,7 +41,9 @@ def test_colour_schedule_invariants(built_lib, name):
         b = np.concatenate([joints["body1"][sl], joints["body2"][sl]])
         b = b[static[b] == 0]
         assert len(np.unique(b)) == len(b), "colour %d touches a dynamic body twice" % c
-    # first-fit: a joint of colour c conflicts with some earlier joint in every colour < c
+    # first-fit in priority order: a joint of colour c conflicts with some higher-priority joint in every colour < c
+    prio = np.array([phyx_amd.schedule_priority(j, j) for j in range(nj)], dtype=np.uint64)
+    assert len(np.unique(prio)) == nj and (prio > 0).all()
     colour_of = np.zeros(nj, dtype=np.int64)
     for c in range(len(offs) - 1):
         colour_of[order[offs[c]:offs[c + 1]]] = c
@@ -51,7 +53,7 @@ def test_colour_schedule_invariants(built_lib, name):
         mine = {b for b in mine if not static[b]}
         for c in range(colour_of[j]):
             sl = order[offs[c]:offs[c + 1]]
-            sl = sl[sl < j]
+            sl = sl[prio[sl] > prio[j]]
             touched = set(joints["body1"][sl].tolist()) | set(joints["body2"][sl].tolist())
             assert mine & touched
 
@@ -79,13 +81,34 @@ def test_island_partition_matches_oracle_gather(built_lib, oracle, name):
         assert (np.diff(members) > 0).all()
 
 
+def test_colouring_survives_compaction_of_the_joint_list(built_lib):
+    """Island sharding solves a compacted subset of the joints.  With contactPointIndex as the priority id, a
+    component's joints get the same colours whether or not other components' joints are in the list."""
+    bodies, _, joints = presolve_state(scenes.stack(6, 30), 4)
+    static = is_static(bodies)
+    ji, _ = phyx_amd.schedule_islands(joints["body1"], joints["body2"], static)
+    comp = np.where(static[joints["body1"]] == 0, joints["body1"], joints["body2"]) // 30      # column of the joint's dynamic body
+    def colours(sel):
+        sub = joints[sel]
+        order, offs = phyx_amd.schedule_colours(sub["body1"], sub["body2"], static, sub["contact_point_index"])
+        col = np.zeros(len(sub), dtype=np.int64)
+        for c in range(len(offs) - 1):
+            col[order[offs[c]:offs[c + 1]]] = c
+        return col
+    everything = colours(np.arange(len(joints)))
+    keep = np.flatnonzero(comp % 2 == 0)                       # every other column
+    assert 0 < len(keep) < len(joints)
+    assert np.array_equal(colours(keep), everything[keep])
+
+
 def test_schedule_handles_hub_and_empty(built_lib):
     # a dynamic hub touched by 200 joints needs 200 colours (> 64 exercises the multi-word masks)
     n = 200
     b1 = np.zeros(n, dtype=np.int32)
     b2 = np.arange(1, n + 1, dtype=np.int32)
     order, offs = phyx_amd.schedule_colours(b1, b2, np.zeros(n + 1, dtype=np.uint8))
-    assert len(offs) - 1 == n and list(order) == list(range(n))
+    prio = [phyx_amd.schedule_priority(j, j) for j in range(n)]
+    assert len(offs) - 1 == n and list(order) == sorted(range(n), key=lambda j: -prio[j])      # one joint per colour, highest priority first
     # the same hub made static conflicts with nothing
     st = np.zeros(n + 1, dtype=np.uint8)
     st[0] = 1

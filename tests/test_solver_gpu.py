@@ -269,8 +269,9 @@ def test_full_size_500k_boxes_50_iterations(solver, oracle):
 
 
 def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
-    """The island-aware schedule is built on the device (connected components by label hooking, per-bin colouring in
-    LDS); the host builder is the specification.  Both must produce the very same schedule."""
+    """Schedules are built on the device (connected components by label hooking, per-bin colouring in LDS, the HBM
+    group coloured by Jones-Plassmann rounds in HBM); the host builder is the specification.  Both must produce the
+    very same schedule, in the island modes and in Single mode."""
     import os
     os.environ["PHX_SCHEDULE_BUILDER"] = "host"
     try:
@@ -283,7 +284,8 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
     cases.append(presolve_state(scenes.stack(40, 60), 4))                       # many bins of several components each
     cases.append(presolve_state(scenes.stack(5, 500), 3, iters=30))             # 1024-lane shape
     cases.append(presolve_state(scenes.falling(2500, width=100.0, ymax=400.0), 50))   # one huge island + loose boxes -> HBM group
-    for state in cases:
+    single = Configuration(0, phyx_amd.ISLAND_SINGLE, 15, 15)
+    for state, cfg in [(st, cfg) for st in cases] + [(st, single) for st in cases]:
         hb, hj, hs, _, hst = _device_solve(host_solver, state, cfg)
         db, dj, ds, _, dst = _device_solve(dev_solver, state, cfg)
         assert np.array_equal(hs.order, ds.order)
@@ -310,6 +312,6 @@ def test_fp16_body_state_ablation(oracle, built_lib):
         fb, fj, _, _, _ = _device_solve(s32, state, cfg)
         dv = np.abs(hb["velocity"]["y"] - fb["velocity"]["y"])
         assert np.isfinite(hb["velocity"]["y"]).all() and hb.tobytes() != fb.tobytes()
-        assert dv.max() < 2.0          # half has ~3 decimal digits; velocities here are O(1..10)
+        assert dv.max() < 2.0, dv.max()          # half has ~3 decimal digits; velocities here are O(1..10)
     with pytest.raises(phyx_amd.PhxError):
         s16.set_body_state_bits(8)

@@ -49,9 +49,9 @@ def test_world_lockstep_bit_exact(oracle, built_lib, name, steps, island_mode):
 
 
 def test_island_shards_reproduce_the_unsharded_step(oracle, built_lib):
-    """Multi-GPU sharding is by island.  Emulated on one GPU: k worlds each solve the islands
-    of one shard; stitching their bodies' velocities together must give the unsharded result bit for bit,
-    because islands are body-disjoint."""
+    """Multi-GPU sharding is by island: every rank builds the same schedule and sweeps the groups
+    g with g % k == rank.  Emulated on one GPU: k worlds each solve one shard; stitching their bodies together must
+    give the unsharded result bit for bit, because groups are body-disjoint."""
     scene = scenes.stack(24, 30)                  # 24 columns -> several coalesced islands
     cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 15, 15)
     full = phyx_amd.World(0, gravity=-200.0)
@@ -73,12 +73,15 @@ def test_island_shards_reproduce_the_unsharded_step(oracle, built_lib):
         w.Update(1.0 / 60.0, cfg)
     ref = full.bodies
     joints = full.contactJoints
-    ji, sz = phyx_amd.schedule_islands(joints["body1"], joints["body2"], ((ref["inv_mass"] == 0) & (ref["inv_inertia"] == 0)).astype(np.uint8))
+    order, _ = full.solver.schedule()              # groups are the unit of sharding: rank = group index % k
+    groups, _ = full.solver.groups()
+    assert len(groups) - 1 >= k
     owner = np.full(len(ref), -1)
-    for j in range(len(joints)):
-        for body in (joints["body1"][j], joints["body2"][j]):
-            if ref["inv_mass"][body] != 0:
-                owner[body] = ji[j] % k
+    for g in range(len(groups) - 1):
+        for j in order[groups[g]:groups[g + 1]]:
+            for body in (joints["body1"][j], joints["body2"][j]):
+                if ref["inv_mass"][body] != 0:
+                    owner[body] = g % k
     stitched = shards[0].bodies.copy()
     for r in range(1, k):
         mine = owner == r

@@ -1,0 +1,15 @@
+"""Per-phase times of a running World over many steps (the topology keeps changing while a stack settles).
+usage: steady.py [steps] ; PHX_TRACE_SCHEDULE=1 prints the schedule builder's laps to stderr."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import phyx_amd
+from phyx_amd import scenes, Configuration
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+w = phyx_amd.World(0, gravity=-200.0); w.add_scene(scenes.stack(1000, 200))
+cfg = Configuration(2, 2, 20, 20)
+for step in range(steps):
+    t = time.time(); w.Update(1/60, cfg); dt = time.time() - t
+    ss = w.solver.stats(); bs = w.collider.stats()
+    if step % 4 == 0 or step > steps - 5:
+        print(step, "step %.2f ms" % (dt*1e3), {k: round(v, 3) for k, v in w.phase_ms().items()}, "recol", ss.recoloured, "lds groups", ss.lds_islands, "colours", ss.colour_count,
+              "solve dev %.3f" % ss.device_ms, "new", bs.new_pairs, "joints", w.counts()[3], flush=True)
