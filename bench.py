@@ -73,22 +73,21 @@ def main():
     solver = phyx_amd.Solver(device)
     d_bodies, d_cps, d_joints = (phyx_amd.DeviceArray(a, device) for a in (bodies, cps, joints))
 
+    hook = group.stream_hook(solver.stream_ptr())
+
     def run(config, warmup, steps):
         """`steps` timed solves of the resident input under `config`; returns wall seconds + HIP-event totals."""
         for _ in range(max(warmup, 1)):                               # untimed: builds the schedule, captures graphs
-            solver.bench(d_bodies, d_cps, d_joints, config, 0, 1)
-            group.step_barrier()
+            solver.bench(d_bodies, d_cps, d_joints, config, 0, 1, hook=hook)
         group.barrier()
         solver.synchronize()
         t0 = time.perf_counter()
-        tot = dict(total_ms=0.0, sweep_ms=0.0, launches=0, visits=0, iterations=0)
-        # each step: restore the input, one full SolveJoints, synchronise, then the per-step RCCL barrier.  With one
-        # rank there is no barrier, so the K steps run back to back inside one library call.
-        for _ in range(1 if world == 1 else steps):
-            r = solver.bench(d_bodies, d_cps, d_joints, config, 0, steps if world == 1 else 1)
-            group.step_barrier()
-            tot["total_ms"] += r.total_ms; tot["sweep_ms"] += r.impulse_kernel_ms; tot["launches"] += r.impulse_launches
-            tot["visits"] += r.joint_visits; tot["iterations"] += r.impulse_iterations
+        # each step: restore the input, one full SolveJoints, then (N > 1) the per-step 4-byte RCCL all-reduce, enqueued on the
+        # solver's stream so that step s+1 of every rank starts only after step s of all ranks — ordered on the device, the
+        # host queues the K steps back to back inside one library call
+        r = solver.bench(d_bodies, d_cps, d_joints, config, 0, steps, hook=hook)
+        tot = dict(total_ms=r.total_ms, sweep_ms=r.impulse_kernel_ms, launches=r.impulse_launches, visits=r.joint_visits,
+                   iterations=r.impulse_iterations)
         solver.synchronize()
         group.barrier()
         tot["elapsed"] = time.perf_counter() - t0

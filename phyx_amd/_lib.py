@@ -44,6 +44,7 @@ class BenchResult(C.Structure):
 _lib = None
 
 _vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
+STEP_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)      # phx_step_hook
 _SIGNATURES = {
     "phx_abi_version": (C.c_int, []),
     "phx_last_error": (C.c_char_p, []),
@@ -65,6 +66,8 @@ _SIGNATURES = {
     "phx_solver_get_groups": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "phx_solver_get_refreshed": (C.c_int, [_vp, _i32, _vp]),
     "phx_solver_bench": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, C.POINTER(BenchResult)]),
+    "phx_solver_bench_hooked": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, STEP_HOOK, _vp, C.POINTER(BenchResult)]),
+    "phx_solver_stream": (C.c_void_p, [_vp]),
     "phx_schedule_priority": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_schedule_islands": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32]),

@@ -217,12 +217,35 @@ class Solver:
         check(self.L.phx_solver_get_refreshed(self.h, joint_index, _ptr(out)))
         return out
 
-    def bench(self, d_bodies, d_contact_points, d_joints, configuration, warmup, steps):
+    def bench(self, d_bodies, d_contact_points, d_joints, configuration, warmup, steps, hook=None):
+        """`steps` solves of the same resident input, queued back to back.  hook(step) (optional) runs on the host after
+        each step has been queued — where a multi-GPU caller enqueues its per-step exchange on stream_ptr()."""
         cfg = configuration._c()
         res = BenchResult()
-        check(self.L.phx_solver_bench(self.h, d_bodies.ptr, d_bodies.count, d_contact_points.ptr, d_contact_points.count,
-                                      d_joints.ptr, d_joints.count, C.byref(cfg), warmup, steps, C.byref(res)))
+        if hook is None:
+            check(self.L.phx_solver_bench(self.h, d_bodies.ptr, d_bodies.count, d_contact_points.ptr, d_contact_points.count,
+                                          d_joints.ptr, d_joints.count, C.byref(cfg), warmup, steps, C.byref(res)))
+            return res
+        failure = []
+
+        def _trampoline(_user, step):
+            try:
+                hook(int(step))
+                return 0
+            except BaseException as e:          # an exception must not unwind through the C frames
+                failure.append(e)
+                return 1
+        cb = _lib.STEP_HOOK(_trampoline)
+        st = self.L.phx_solver_bench_hooked(self.h, d_bodies.ptr, d_bodies.count, d_contact_points.ptr, d_contact_points.count,
+                                            d_joints.ptr, d_joints.count, C.byref(cfg), warmup, steps, cb, None, C.byref(res))
+        if failure:
+            raise failure[0]
+        check(st)
         return res
+
+    def stream_ptr(self):
+        """The hipStream_t (as an int) all of this handle's work is queued on."""
+        return int(self.L.phx_solver_stream(self.h) or 0)
 
 
 class Collider:

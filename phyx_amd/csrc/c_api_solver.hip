@@ -83,6 +83,15 @@ int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t nb, const void
     return s->impl.bench(d_bodies, nb, d_cps, ncp, d_joints, nj, *cfg, warmup, steps, out);
 }
 
+int phx_solver_bench_hooked(phx_solver* s, const void* d_bodies, int32_t nb, const void* d_cps, int32_t ncp, const void* d_joints, int32_t nj,
+                            const phx_config* cfg, int32_t warmup, int32_t steps, phx_step_hook hook, void* user, phx_bench_result* out)
+{
+    PHX_REQUIRE(s && cfg, "null handle / config");
+    return s->impl.bench(d_bodies, nb, d_cps, ncp, d_joints, nj, *cfg, warmup, steps, out, hook, user);
+}
+
+void* phx_solver_stream(phx_solver* s) { return s ? (void*)s->impl.stream() : nullptr; }
+
 uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index) { return phx::colour_priority(priority_id, joint_index); }
 
 int phx_schedule_colours(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb, const int32_t* priority_ids,

@@ -44,7 +44,7 @@ public:
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
-              const phx_config& cfg, int warmup, int steps, phx_bench_result* out);
+              const phx_config& cfg, int warmup, int steps, phx_bench_result* out, phx_step_hook hook = nullptr, void* user = nullptr);
 
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }

@@ -800,7 +800,7 @@ int DeviceSolver::get_refreshed(int joint, float out[30])
 }
 
 int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
-                        const phx_config& cfg, int warmup, int steps, phx_bench_result* out)
+                        const phx_config& cfg, int warmup, int steps, phx_bench_result* out, phx_step_hook hook, void* user)
 {
     PHX_REQUIRE(out && warmup >= 0 && steps >= 0 && steps <= 4096, "bad bench arguments");
     PHX_TRY(use_device(device_));
@@ -814,7 +814,11 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
         if (nj) PHX_HIP(hipMemcpyAsync(snap_joints_.p, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
         return solve_device(snap_bodies_.p, nb, d_cps, ncp, snap_joints_.p, nj, cfg);
     };
-    for (int i = 0; i < warmup; ++i) { PHX_TRY(one_step()); PHX_TRY(synchronize()); }
+    for (int i = 0; i < warmup; ++i) {
+        PHX_TRY(one_step());
+        if (hook && hook(user, i - warmup)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
+        PHX_TRY(synchronize());
+    }
     if (!steps) return PHX_OK;
     // timed steps are queued back to back; the device never waits for the host between them
     hipEvent_t keep_b = ev_sweep_begin_, keep_e = ev_sweep_end_;
@@ -823,6 +827,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     for (int i = 0; i < steps && st == PHX_OK; ++i) {
         ev_sweep_begin_ = bench_events_[2 * i]; ev_sweep_end_ = bench_events_[2 * i + 1];
         st = one_step();
+        if (st == PHX_OK && hook && hook(user, i)) { set_error("bench: step hook failed"); st = PHX_ERR_STATE; }
     }
     ev_sweep_begin_ = keep_b; ev_sweep_end_ = keep_e;
     PHX_TRY(st);

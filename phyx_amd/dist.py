@@ -24,6 +24,9 @@ class Single:
     def reduce_sum(self, x):
         return float(x)
 
+    def stream_hook(self, stream_ptr):
+        return None
+
     def shutdown(self):
         pass
 
@@ -61,6 +64,22 @@ class Group:
         self.dist.all_reduce(self._flag, op=self.dist.ReduceOp.MAX)
         self._sync()
         return int(self._flag.item())
+
+    def stream_hook(self, stream_ptr):
+        """hook(step) that enqueues the per-step exchange ON THE SOLVER'S OWN STREAM: the 4-byte all-reduce waits for the
+        step queued before it and the next step waits for the all-reduce — on the device; the host never blocks.
+        (gloo has no streams: there the hook is the blocking all-reduce.)"""
+        if self.backend != "nccl":
+            return lambda step: self.step_barrier()
+        ext = self.torch.cuda.ExternalStream(stream_ptr, device=self.device)
+        flag = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
+        self.torch.cuda.synchronize(self.device)
+
+        def hook(step):
+            with self.torch.cuda.stream(ext):
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        self._hook_keep = (ext, flag)
+        return hook
 
     def _reduce(self, x, op):
         t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)

@@ -19,6 +19,8 @@ WORKER = textwrap.dedent("""
     first, n = pdist.shard_columns(2001, g.rank, g.world_size)
     g.barrier()
     flags = [g.step_barrier() for _ in range(3)]           # the per-step 4-byte all-reduce
+    hook = g.stream_hook(0)                                 # bench.py's per-step hook (gloo: the blocking all-reduce)
+    for step in range(3): hook(step)
     t = g.reduce_max(1.0 + g.rank)                          # max over ranks (timing)
     units = g.reduce_sum(float(n))                          # whole-job units
     print(json.dumps({"rank": g.rank, "world": g.world_size, "first": first, "n": n, "t": t, "units": units, "flags": flags}))
@@ -66,7 +68,7 @@ def test_shard_columns_partition():
 
 
 def test_single_process_group_is_torch_free():
-    code = "import sys; sys.path.insert(0, %r); from phyx_amd import dist; g = dist.init(1); g.barrier(); g.step_barrier(); assert g.reduce_sum(3) == 3.0; assert 'torch' not in sys.modules" % ROOT
+    code = "import sys; sys.path.insert(0, %r); from phyx_amd import dist; g = dist.init(1); g.barrier(); g.step_barrier(); assert g.stream_hook(0) is None; assert g.reduce_sum(3) == 3.0; assert 'torch' not in sys.modules" % ROOT
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     subprocess.check_call([sys.executable, "-c", code], env=env)
