@@ -295,6 +295,68 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
         assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
 
 
+def _random_state(rng, nb, nj, static_frac, dup_ids=False, hub=0):
+    """A synthetic solver input with an arbitrary contact graph: random pairs over nb bodies (a few static), plausible
+    small offsets and unit normals, so that the arithmetic stays finite while the topology is nothing like a stack."""
+    bodies = np.zeros(nb, dtype=phyx_amd.rigid_body_dtype)
+    bodies["index"] = np.arange(nb)
+    bodies["inv_mass"] = rng.uniform(0.5, 2.0, nb)
+    bodies["inv_inertia"] = rng.uniform(0.01, 0.1, nb)
+    static = rng.random(nb) < static_frac
+    bodies["inv_mass"][static] = 0
+    bodies["inv_inertia"][static] = 0
+    bodies["pos"]["x"] = rng.uniform(-100, 100, nb)
+    bodies["pos"]["y"] = rng.uniform(-100, 100, nb)
+    bodies["velocity"]["x"] = np.where(static, 0.0, rng.uniform(-1, 1, nb))      # (+0.0 exactly: see DESIGN §4.3 on -0.0 statics)
+    bodies["velocity"]["y"] = np.where(static, 0.0, rng.uniform(-1, 1, nb))
+    b1 = rng.integers(0, nb, nj)
+    b2 = (b1 + rng.integers(1, nb, nj)) % nb                           # never the same body twice
+    if hub:
+        b1[:hub] = 0                                                   # body 0 made a hub touched by `hub` joints
+        bodies["inv_mass"][0], bodies["inv_inertia"][0] = 1.0, 0.05
+    cps = np.zeros(nj, dtype=phyx_amd.contact_point_dtype)
+    ang = rng.uniform(0, 2 * np.pi, nj)
+    cps["normal"]["x"], cps["normal"]["y"] = np.cos(ang), np.sin(ang)
+    for d in ("delta1", "delta2"):
+        cps[d]["x"] = rng.uniform(-5, 5, nj)
+        cps[d]["y"] = rng.uniform(-5, 5, nj)
+    joints = np.zeros(nj, dtype=phyx_amd.contact_joint_dtype)
+    joints["body1"], joints["body2"] = b1, b2
+    joints["contact_point_index"] = rng.permutation(nj) if not dup_ids else rng.integers(0, max(nj // 4, 1), nj)
+    joints["normal_acc"] = rng.uniform(0, 0.1, nj)
+    return bodies, cps, joints
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense", "dup_ids", "mostly_static", "hub_over_64_colours"])
+def test_random_contact_graphs_both_builders_and_oracle(oracle, built_lib, case):
+    """Arbitrary contact graphs (not stacks): the device builder must reproduce the host builder's schedule — including
+    duplicated priority ids (ties broken by joint index) and a hub that needs more than 64 colours (device falls back to
+    the host builder) — and the solve must match the oracle's replay of that schedule bit for bit."""
+    import os
+    rng = np.random.default_rng({"sparse": 1, "dense": 2, "dup_ids": 3, "mostly_static": 4, "hub_over_64_colours": 5}[case])
+    nb, nj, sf, dup, hub = {"sparse": (4000, 3000, 0.05, False, 0), "dense": (600, 6000, 0.05, False, 0), "dup_ids": (2000, 5000, 0.1, True, 0),
+                            "mostly_static": (3000, 4000, 0.7, False, 0), "hub_over_64_colours": (1500, 2500, 0.05, False, 90)}[case]
+    state = _random_state(rng, nb, nj, sf, dup, hub)
+    os.environ["PHX_SCHEDULE_BUILDER"] = "host"
+    try:
+        host_solver = phyx_amd.Solver(0)
+    finally:
+        del os.environ["PHX_SCHEDULE_BUILDER"]
+    dev_solver = phyx_amd.Solver(0)
+    for island_mode in (phyx_amd.ISLAND_SINGLE, phyx_amd.ISLAND_MULTIPLE):
+        cfg = Configuration(0, island_mode, 4, 3)
+        hb, hj, hs, _, hst = _device_solve(host_solver, state, cfg)
+        db, dj, ds, _, dst = _device_solve(dev_solver, state, cfg)
+        assert np.array_equal(hs.order, ds.order) and np.array_equal(hs.colours, ds.colours) and np.array_equal(hs.groups, ds.groups)
+        assert sorted(ds.order.tolist()) == list(range(nj))
+        if case == "hub_over_64_colours":
+            assert dst.colour_count >= 90
+        ob_, oj, _ = _oracle_in_device_order(oracle, state, ds, None, cfg, oracle.STAG_COLOUR_SYNC)
+        assert np.isfinite(db["velocity"]["x"]).all()
+        assert db.tobytes() == ob_.tobytes() and dj.tobytes() == oj.tobytes()
+        assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
+
+
 def test_fp16_body_state_ablation(oracle, built_lib):
     """BASELINE config 5's ablation: body velocities kept in IEEE half between joint updates (fp32 arithmetic).  The device
     must agree bit for bit with the oracle's model of that rounding, and stay close to the fp32 result."""
