@@ -88,7 +88,10 @@ SolverView DeviceSolver::view() const
 
 int DeviceSolver::launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp)
 {
-    PHX_HIP(hipMemsetAsync(hash_.p, 0, sizeof(unsigned long long), stream_));
+    // one dispatch clears the fingerprint accumulator and every control word of the solve that follows
+    const int nflags = flags_.p ? 2 * max_iters_ : 0, nsw = sw_.p ? 4 * std::max(nstatic_, 1) : 0;
+    hipLaunchKernelGGL(k_clear_control, dim3(std::max(1, std::min(div_up(std::max(nflags, nsw), 256), 64))), dim3(256), 0, stream_,
+                       hash_.p, flags_.p, nflags, sw_.p, nsw, isl_stats_.p, isl_visits_.p);
     hipLaunchKernelGGL(k_topology_hash, dim3(std::min(grid_for(std::max(nj, nb)), 512)), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, ncp, hash_.p);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
@@ -182,6 +185,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_TRY(order_.reserve(std::max(nj, 1)));
     PHX_TRY(static_slot_.reserve(std::max(nb, 1)));
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
+    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));      // new table for this solve
     PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb)); PHX_TRY(sb_par_.reserve(nb));
     PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj));
     PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
@@ -415,6 +419,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
     }
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
+    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));      // new table for this solve
     lap("rest");
     sched_ = std::move(sc);
     return PHX_OK;
@@ -460,10 +465,8 @@ int DeviceSolver::materialise_schedule()
 int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
-    PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
-    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)v.nstatic * sizeof(unsigned), stream_));
-    PHX_HIP(hipMemsetAsync(isl_stats_.p, 0, 2 * sizeof(int), stream_));
-    PHX_HIP(hipMemsetAsync(isl_visits_.p, 0, sizeof(unsigned long long), stream_));
+    // (the control words — productive flags, static tags, island counters — were cleared by launch_fingerprint's
+    //  k_clear_control, which every solve runs first)
     // the HBM group (if any): PrepareBodies for the bodies it touches, PrepareJoints + RefreshJoints over its slots,
     // PreStep colour by colour.  Groups solved in LDS read and write the caller's records directly.
     const int hbm_bodies = sched_.hbm_body_count;
@@ -578,6 +581,7 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     if (iters + 1 > max_iters_ || !flags_.p) {
         max_iters_ = std::max(iters + 1, 64);
         PHX_TRY(flags_.reserve(2 * (size_t)max_iters_));
+        PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
         drop_graphs();
     }
     GraphKey key;

@@ -77,6 +77,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
     return z ^ (z >> 31);
 }
 
+// Every per-solve control word in one dispatch (five memsets would be five dispatches on a 0.18 ms step): the fingerprint
+// accumulator, the HBM path's per-sweep 'productive' flags and static-tag words, the island kernel's counters.
+__global__ void __launch_bounds__(256) k_clear_control(unsigned long long* hash, int* flags, int nflags, unsigned* sw, int nsw,
+                                                       int* isl_stats, unsigned long long* isl_visits)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    if (i == 0) { *hash = 0ull; *isl_visits = 0ull; isl_stats[0] = 0; isl_stats[1] = 0; }
+    for (int k = i; k < nflags; k += n) flags[k] = 0;
+    for (int k = i; k < nsw; k += n) sw[k] = 0u;
+}
+
 __global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
                                                        const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out)
 {
@@ -362,33 +373,51 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     const int ncol = iv.ncol[group];
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < d.w; i += T) {
-        // PrepareBodies (ref: Solver.cpp:456-480) straight from the 128-byte records
-        const phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
-        body_store(imp, i, make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1)));
-        body_store(disp, i, make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1)));
-        par[i] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
-        is_st[i] = (b.inv_mass == 0.f && b.inv_inertia == 0.f) ? 1 : 0;
-    }
-    if (tid < 2) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
-
+    // Set-up is a chain of dependent HBM round trips (index -> record -> contact point); the body chain and the joint
+    // chain are independent, so their loads are issued level by level, both chains in flight together.
+    constexpr int BI = (NB + T - 1) / T;                   // body records per lane
     const bool live = tid < d.y;
     const int s = d.x + tid;
+    int body_id[BI];
+#pragma unroll
+    for (int k = 0; k < BI; ++k) body_id[k] = tid + k * T < d.w ? iv.bodies[d.z + tid + k * T] : -1;      // level 1
+    const int joint_id = live ? v.order[s] : 0;
+    unsigned loc = 0;
+    int col = -1;
+    if (live) { loc = iv.slot_local[s]; col = iv.slot_colour[s]; }
+    if (tid < 2) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
+
+    float4 rec_imp[BI], rec_disp[BI], rec_par[BI];
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {                         // level 2: PrepareBodies (ref: Solver.cpp:456-480) straight from
+        if (body_id[k] < 0) continue;                      //          the 128-byte records
+        const phx_rigid_body& b = bodies[body_id[k]];
+        rec_imp[k] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
+        rec_disp[k] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
+        rec_par[k] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
+    }
     phx_contact_joint j;
     float d1x = 0.f, d1y = 0.f, d2x = 0.f, d2y = 0.f;
     float nx = 0.f, ny = 0.f, aN1 = 0.f, aN2 = 0.f, aF1 = 0.f, aF2 = 0.f, cimN = 0.f, cimF = 0.f, dstV = 0.f, dstD = 0.f;
     float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f, accN = 0.f, accF = 0.f, accD = 0.f;
-    int l1 = 0, l2 = 0, col = -1;
+    int l1 = 0, l2 = 0;
     if (live) {                                            // PrepareJoints (ref: Solver.cpp:509-521)
-        j = joints[v.order[s]];
-        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);   // 32-byte records
+        j = joints[joint_id];
+        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);   // level 3, 32-byte records
         const float4 da = cp4[0];                          // delta1, delta2
         const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
         d1x = da.x; d1y = da.y; d2x = da.z; d2y = da.w; nx = nn.x; ny = nn.y;
-        const unsigned loc = iv.slot_local[s];
         l1 = (int)(loc & 0xFFFFu); l2 = (int)(loc >> 16);
-        col = iv.slot_colour[s];
         accN = j.normal_accumulated_impulse; accF = j.friction_accumulated_impulse;
+    }
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+        if (body_id[k] < 0) continue;
+        const int i = tid + k * T;
+        body_store(imp, i, rec_imp[k]);
+        body_store(disp, i, rec_disp[k]);
+        par[i] = rec_par[k];
+        is_st[i] = (rec_par[k].x == 0.f && rec_par[k].y == 0.f) ? 1 : 0;
     }
     __syncthreads();
     if (live) {
@@ -510,13 +539,15 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     // never leave the registers
     if (*v.fingerprint != v.expected_fingerprint) return;
     if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
-        phx_contact_joint& j = joints[v.order[s]];
-        j.normal_accumulated_impulse = accN;
-        j.friction_accumulated_impulse = accF;
+        phx_contact_joint& out = joints[joint_id];
+        out.normal_accumulated_impulse = accN;
+        out.friction_accumulated_impulse = accF;
     }
-    for (int i = tid; i < d.w; i += T) {               // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
-        if (is_st[i]) continue;
-        phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {                         // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
+        const int i = tid + k * T;
+        if (body_id[k] < 0 || is_st[i]) continue;
+        phx_rigid_body& b = bodies[body_id[k]];
         const float4 a = body_load(imp, i), e = body_load(disp, i);
         b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
         b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
