@@ -41,6 +41,7 @@ private:
     int n_ = 0, sorted_ = 0, last_new_ = 0;
     bool have_update_ = false;
     phx_broadphase_stats stats_{};
+    Readback rb_;
 };
 
 } // namespace phx

@@ -389,8 +389,8 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         }
         PHX_TRY(exclusive_scan(row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3)));
         PHX_HIP(hipGetLastError());
-        PHX_HIP(hipMemcpyAsync(host_small, small_.p, sizeof host_small, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipStreamSynchronize(stream_));
+        PHX_TRY(rb_.add(host_small, small_.p, sizeof host_small, stream_));
+        PHX_TRY(rb_.wait(stream_));
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
         if (needed <= chunk_cap) break;
         // pathological overlap (many rows each spanning thousands of candidates): the chunk list was too short.
@@ -481,8 +481,8 @@ int DeviceBroadphase::erase_pairs_device(const uint2* d_pairs, int count)
                        reinterpret_cast<int*>(small_.p + 8));
     PHX_HIP(hipGetLastError());
     int erased = 0;
-    PHX_HIP(hipMemcpyAsync(&erased, small_.p + 8, sizeof(int), hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    PHX_TRY(rb_.add(&erased, small_.p + 8, sizeof(int), stream_));
+    PHX_TRY(rb_.wait(stream_));
     set_size_ -= erased;
     tombstones_ += erased;
     return PHX_OK;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -95,5 +96,50 @@ struct DevBuf {
 };
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Small device->host readbacks (counts, flags, fingerprints) through one pinned staging buffer: asynchronous DMAs into
+// pinned memory and ONE stream synchronisation per batch, instead of one blocking staged copy per value into pageable
+// memory (measured: ~25 us of idle GPU per pageable readback, ~16 of them per world step).
+class Readback {
+public:
+    Readback() = default;
+    Readback(const Readback&) = delete;
+    Readback& operator=(const Readback&) = delete;
+    ~Readback() { if (pin_) (void)hipHostFree(pin_); }
+    // queue a copy of `bytes` from device memory `src` on `stream`; the value is delivered to `dst` by wait()
+    int add(void* dst, const void* src, size_t bytes, hipStream_t stream)
+    {
+        if (!bytes) return PHX_OK;
+        if (!pin_) {
+            cap_ = std::max<size_t>(want_, 1u << 20);
+            PHX_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin_), cap_, hipHostMallocDefault));
+        }
+        const size_t off = (used_ + 15) & ~size_t(15);
+        if (off + bytes > cap_ || count_ == MAX_ITEMS) {   // does not fit while DMAs are pending: plain copy now, bigger buffer next time
+            if (off + bytes > cap_) want_ = std::max(want_, 2 * (off + bytes));
+            PHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+            return PHX_OK;
+        }
+        PHX_HIP(hipMemcpyAsync(pin_ + off, src, bytes, hipMemcpyDeviceToHost, stream));
+        items_[count_++] = Item{dst, off, bytes};
+        used_ = off + bytes;
+        return PHX_OK;
+    }
+    int wait(hipStream_t stream)
+    {
+        PHX_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i < count_; ++i) std::memcpy(items_[i].dst, pin_ + items_[i].off, items_[i].bytes);
+        count_ = 0; used_ = 0;
+        if (want_ > cap_) { (void)hipHostFree(pin_); pin_ = nullptr; }      // reallocated by the next add()
+        return PHX_OK;
+    }
+private:
+    static constexpr int MAX_ITEMS = 16;
+    struct Item { void* dst; size_t off, bytes; };
+    char* pin_ = nullptr;
+    size_t cap_ = 0, used_ = 0, want_ = 0;
+    int count_ = 0;
+    Item items_[MAX_ITEMS];
+};
 
 } // namespace phx

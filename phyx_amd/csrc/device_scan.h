@@ -5,10 +5,11 @@
 
 namespace phx {
 
-// ---- exclusive prefix sum over `count` words, in place: three small launches ---------------------------
-//   k_scan_tiles   each 1024-lane workgroup scans a 4096-word tile in LDS and records the tile total
-//   k_scan_totals  one workgroup scans the (<= 4096) tile totals
-//   k_scan_add     adds each tile's base
+// ---- exclusive prefix sum over `count` words, in place ---------------------------------------------------
+//   <= 64k words   k_scan_single: one workgroup, one launch
+//   <= 4M words    k_scan_tiles (each 1024-lane workgroup scans a 4096-word tile in LDS and records the tile total)
+//                  + k_scan_add_totals (each workgroup sums the totals before its tile and adds them): two launches
+//   beyond         k_scan_tiles, k_scan_totals (one workgroup scans the tile totals), k_scan_add
 constexpr int SCAN_TILE = 4096;
 
 __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsigned* lds, unsigned* total)
@@ -71,13 +72,66 @@ static __global__ void __launch_bounds__(1024) k_scan_add(unsigned* __restrict__
     for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
 }
 
+// second launch of the two-launch form (<= 1024 tiles): every workgroup sums the totals of the tiles before its own
+// (at most 1024 words, one per lane) instead of waiting for a separate scan-of-totals launch
+static __global__ void __launch_bounds__(1024) k_scan_add_totals(unsigned* __restrict__ data, int count, const unsigned* __restrict__ tile_total, int tiles,
+                                                                 unsigned* __restrict__ grand_total)
+{
+    __shared__ unsigned part[16];
+    unsigned x = ((int)threadIdx.x < (int)blockIdx.x) ? tile_total[threadIdx.x] : 0u;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned add = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) add += part[w];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
+    if (grand_total && (int)blockIdx.x == tiles - 1 && threadIdx.x == 0) *grand_total = add + tile_total[tiles - 1];
+}
+
+// Short inputs (radix histograms, per-bin tables: a few thousand words) are launch-latency bound, not bandwidth bound:
+// one workgroup walks them tile by tile with a running carry — one launch instead of three.
+constexpr int SCAN_SINGLE_MAX = 32 * 1024;      // 32 words per lane
+
+static __global__ void __launch_bounds__(1024) k_scan_single(unsigned* __restrict__ data, int count, unsigned* __restrict__ grand_total)
+{
+    __shared__ unsigned lds[16];
+    __shared__ unsigned tot;
+    // lane t owns words [t * per, (t + 1) * per): every load is issued before any is used — one memory round trip
+    constexpr int PER_MAX = SCAN_SINGLE_MAX / 1024;
+    const int per = (count + 1023) / 1024;
+    const int base = threadIdx.x * per;
+    unsigned v[PER_MAX];
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) { v[k] = (k < per && base + k < count) ? data[base + k] : 0u; }
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) mine += v[k];
+    unsigned run = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) { if (k < per && base + k < count) data[base + k] = run; run += v[k]; }
+    __syncthreads();
+    if (grand_total && threadIdx.x == 0) *grand_total = tot;
+}
 
 // scratch must hold div_up(count, SCAN_TILE) words.  total_out (device pointer, may be null) receives the sum.
 static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, unsigned* scratch, hipStream_t stream)
 {
     if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream)); return PHX_OK; }
+    if (count <= SCAN_SINGLE_MAX) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, data, count, total_out);
+        PHX_HIP(hipGetLastError());
+        return PHX_OK;
+    }
     const int tiles = div_up(count, SCAN_TILE);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, stream, data, count, scratch);
+    if (tiles <= 1024) {
+        hipLaunchKernelGGL(k_scan_add_totals, dim3(tiles), dim3(1024), 0, stream, data, count, (const unsigned*)scratch, tiles, total_out);
+        PHX_HIP(hipGetLastError());
+        return PHX_OK;
+    }
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream, scratch, tiles, total_out);
     if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(1024), 0, stream, data, count, (const unsigned*)scratch);
     PHX_HIP(hipGetLastError());

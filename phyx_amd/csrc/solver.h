@@ -71,7 +71,7 @@ private:
     int enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj);
     int capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
     void drop_graphs();
-    int collect_stats();
+    int collect_stats(unsigned long long* extra = nullptr, const unsigned long long* extra_src = nullptr);
     SolverView view() const;
 
     int device_;
@@ -100,6 +100,7 @@ private:
     bool gpu_builder_ = true;
     DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;
+    Readback rb_;                        // pinned staging for every small device->host readback of this handle
     // staging for the host-pointer entry point
     DevBuf<phx_rigid_body> st_bodies_;
     DevBuf<phx_contact_point> st_cps_;

@@ -102,8 +102,8 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     // 1. fingerprint of the joint topology (8 bytes over PCIe)
     unsigned long long fp = 0;
     PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
-    PHX_HIP(hipMemcpyAsync(&fp, hash_.p, sizeof fp, hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
+    PHX_TRY(rb_.wait(stream_));
     const unsigned long long raw = fp;
     fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
     stats_.recoloured = 0;
@@ -264,8 +264,8 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));
         hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb);
-        PHX_HIP(hipMemcpyAsync(&changed, sb_small_.p, sizeof changed, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipStreamSynchronize(stream_));
+        PHX_TRY(rb_.add(&changed, sb_small_.p, sizeof changed, stream_));
+        PHX_TRY(rb_.wait(stream_));
         if (!changed) break;
     }
     lap("components");
@@ -273,15 +273,15 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
     PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
     unsigned ncomp_u = 0;
-    PHX_HIP(hipMemcpyAsync(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    PHX_TRY(rb_.add(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, stream_));
+    PHX_TRY(rb_.wait(stream_));
     const int ncomp = (int)ncomp_u;
     PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)std::max(ncomp, 1) * sizeof(unsigned), stream_));
     hipLaunchKernelGGL(k_joint_components, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p, (const unsigned*)cc_flags_.p,
                        joint_comp_.p, comp_size_.p);
     std::vector<unsigned> comp_size(std::max(ncomp, 1));
-    PHX_HIP(hipMemcpyAsync(comp_size.data(), comp_size_.p, (size_t)ncomp * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)ncomp * sizeof(unsigned), stream_));
+    PHX_TRY(rb_.wait(stream_));
     lap("count");
 
     // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
@@ -344,9 +344,9 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_HIP(hipGetLastError());
     int rejected = 0;
     std::vector<int> ncol(std::max(nbins, 1), 0);
-    PHX_HIP(hipMemcpyAsync(&rejected, sb_small_.p + 2, sizeof rejected, hipMemcpyDeviceToHost, stream_));
-    if (nbins) PHX_HIP(hipMemcpyAsync(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    PHX_TRY(rb_.add(&rejected, sb_small_.p + 2, sizeof rejected, stream_));
+    if (nbins) PHX_TRY(rb_.add(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), stream_));
+    PHX_TRY(rb_.wait(stream_));
     lap("bins");
     if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
     sc.lds_colours = 0;
@@ -378,9 +378,9 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
                 hipLaunchKernelGGL(k_jp_round, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned long long*)jp_best_[round % 3].p,
                                    jp_best_[(round + 1) % 3].p, jp_best_[(round + 2) % 3].p, round);
             int tail[2] = {0, 0};
-            PHX_HIP(hipMemcpyAsync(&tail[0], jp_small_.p + round - 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
-            PHX_HIP(hipMemcpyAsync(&tail[1], jp_small_.p + JP_ROUNDS_MAX, sizeof(int), hipMemcpyDeviceToHost, stream_));
-            PHX_HIP(hipStreamSynchronize(stream_));
+            PHX_TRY(rb_.add(&tail[0], jp_small_.p + round - 1, sizeof(int), stream_));
+            PHX_TRY(rb_.add(&tail[1], jp_small_.p + JP_ROUNDS_MAX, sizeof(int), stream_));
+            PHX_TRY(rb_.wait(stream_));
             if (tail[1] & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
             if (tail[1] & 2) { *fallback = true; return PHX_OK; }                             // > 64 colours: host builder (wider masks)
             done = tail[0] == 0;
@@ -398,16 +398,16 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 6, sort_hist_.p, sort_scan_.p, stream_, &where2));
         PHX_HIP(hipMemcpyAsync(order_.p + lds_slots, jp_vals_[where2].p, (size_t)rest * sizeof(int), hipMemcpyDeviceToDevice, stream_));
         unsigned h_hist[JP_MAX_COLOURS], h_touched = 0;
-        PHX_HIP(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipMemcpyAsync(&h_touched, jp_touched_.p + nb, sizeof h_touched, hipMemcpyDeviceToHost, stream_));
+        PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
+        PHX_TRY(rb_.add(&h_touched, jp_touched_.p + nb, sizeof h_touched, stream_));
         // static slots (only the HBM path indexes the global static-tag tables)
         PHX_TRY(static_slot_.reserve(nbs));
         hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, nb, jp_touched_.p);
         PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_.p, stream_));
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)jp_touched_.p, nb, static_slot_.p);
         unsigned h_nstatic = 0;
-        PHX_HIP(hipMemcpyAsync(&h_nstatic, jp_touched_.p + nb, sizeof h_nstatic, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipStreamSynchronize(stream_));
+        PHX_TRY(rb_.add(&h_nstatic, jp_touched_.p + nb, sizeof h_nstatic, stream_));
+        PHX_TRY(rb_.wait(stream_));
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
         sc.hbm_colour_offsets.assign(1, lds_slots);
@@ -667,16 +667,21 @@ int DeviceSolver::solve_host(phx_rigid_body* bodies, int nb, const phx_contact_p
     return PHX_OK;
 }
 
-int DeviceSolver::collect_stats()
+// `extra`/`extra_src`: one more 8-byte value to fetch in the same round trip (the fingerprint of a speculative solve)
+int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long long* extra_src)
 {
-    if (!stats_pending_) return PHX_OK;
+    if (!stats_pending_) {
+        if (extra) { PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_)); }
+        return rb_.wait(stream_);
+    }
     std::vector<int> flags(2 * (size_t)max_iters_);
     int isl[2] = {0, 0};
     unsigned long long isl_visits = 0;
-    PHX_HIP(hipMemcpyAsync(flags.data(), flags_.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipMemcpyAsync(isl, isl_stats_.p, sizeof isl, hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipMemcpyAsync(&isl_visits, isl_visits_.p, sizeof isl_visits, hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    if (extra) PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_));
+    PHX_TRY(rb_.add(flags.data(), flags_.p, flags.size() * sizeof(int), stream_));
+    PHX_TRY(rb_.add(isl, isl_stats_.p, sizeof isl, stream_));
+    PHX_TRY(rb_.add(&isl_visits, isl_visits_.p, sizeof isl_visits, stream_));
+    PHX_TRY(rb_.wait(stream_));
     auto executed = [&](const int* active, int limit) {
         int n = 0;
         for (int k = 0; k < limit; ++k) { ++n; if (!active[k]) break; }     // ref: Solver.cpp:175-190
@@ -699,13 +704,14 @@ int DeviceSolver::collect_stats()
 int DeviceSolver::synchronize()
 {
     PHX_TRY(use_device(device_));
-    PHX_HIP(hipStreamSynchronize(stream_));
     if (pending_.active) {
+        // one round trip: the speculative solve's fingerprint and its counters together
         unsigned long long fp = 0;
-        PHX_HIP(hipMemcpy(&fp, hash_.p, sizeof fp, hipMemcpyDeviceToHost));
+        PHX_TRY(collect_stats(&fp, hash_.p));
         const Pending p = pending_;
         pending_.active = false;
         if (fp != raw_fingerprint_) {
+            stats_pending_ = true;                     // those counters belong to a solve that committed nothing
             // the joint topology changed under the cached schedule: nothing was committed; rebuild and solve again
             PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp, p.cfg, true));
             stats_.colour_count = sched_.ncolours();

@@ -65,6 +65,7 @@ private:
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
     DevBuf<unsigned> flags_, scan_tiles_, counters_;     // counters_: [0] dead/new total, [1] dropped points
+    Readback rb_;
     DevBuf<int> mover_pos_;
     DevBuf<uint2> erased_;
 };
@@ -169,8 +170,8 @@ int World::pack_manifolds()                                                 // r
     if (!nm) return PHX_OK;
     PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
     unsigned host[2] = {0, 0};
-    PHX_HIP(hipMemcpyAsync(host, counters_.p, sizeof host, hipMemcpyDeviceToHost, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
+    PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
+    PHX_TRY(rb_.wait(stream_));
     dropped_points += (int)host[1];
     const int dead = (int)host[0];
     if (!dead) return PHX_OK;
@@ -194,8 +195,8 @@ int World::refresh_contact_joints()                                         // r
                            d_joints_.p, flags_.p);
         PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
         unsigned host = 0;
-        PHX_HIP(hipMemcpyAsync(&host, counters_.p, sizeof host, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipStreamSynchronize(stream_));
+        PHX_TRY(rb_.add(&host, counters_.p, sizeof host, stream_));
+        PHX_TRY(rb_.wait(stream_));
         fresh = (int)host;
         if (fresh) {
             PHX_TRY(d_joints_.reserve_keep((size_t)nj + fresh, nj, stream_));
@@ -208,8 +209,8 @@ int World::refresh_contact_joints()                                         // r
         hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(total)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, total, flags_.p);
         PHX_TRY(device_exclusive_scan(flags_.p, total, counters_.p, scan_tiles_.p, stream_));
         unsigned host = 0;
-        PHX_HIP(hipMemcpyAsync(&host, counters_.p, sizeof host, hipMemcpyDeviceToHost, stream_));
-        PHX_HIP(hipStreamSynchronize(stream_));
+        PHX_TRY(rb_.add(&host, counters_.p, sizeof host, stream_));
+        PHX_TRY(rb_.wait(stream_));
         const int dead = (int)host;
         if (dead) {
             hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, total, mover_pos_.p);
