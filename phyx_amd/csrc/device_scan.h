@@ -93,34 +93,65 @@ static __global__ void __launch_bounds__(1024) k_scan_add_totals(unsigned* __res
 
 // Short inputs (radix histograms, per-bin tables: a few thousand words) are launch-latency bound, not bandwidth bound:
 // one workgroup walks them tile by tile with a running carry — one launch instead of three.
-constexpr int SCAN_SINGLE_MAX = 32 * 1024;      // 32 words per lane
+constexpr int SCAN_SINGLE_MAX = 8 * SCAN_TILE;      // 32 words per lane
 
 static __global__ void __launch_bounds__(1024) k_scan_single(unsigned* __restrict__ data, int count, unsigned* __restrict__ grand_total)
 {
-    __shared__ unsigned lds[16];
-    __shared__ unsigned tot;
-    // lane t owns words [t * per, (t + 1) * per): every load is issued before any is used — one memory round trip
-    constexpr int PER_MAX = SCAN_SINGLE_MAX / 1024;
-    const int per = (count + 1023) / 1024;
-    const int base = threadIdx.x * per;
-    unsigned v[PER_MAX];
-    unsigned mine = 0;
+    // word i belongs to tile i / 4096, lane (i % 4096) / 4: every lane reads one 16-byte vector per tile (coalesced), all
+    // tiles' loads in flight together; the tiles' block scans run side by side on one pair of barriers
+    constexpr int TILES_MAX = SCAN_SINGLE_MAX / SCAN_TILE;
+    __shared__ unsigned wave_total[TILES_MAX][16];
+    const int tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4 v[TILES_MAX];
+    unsigned incl[TILES_MAX];
 #pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) { v[k] = (k < per && base + k < count) ? data[base + k] : 0u; }
+    for (int t = 0; t < TILES_MAX; ++t) {
+        const int base = t * SCAN_TILE + threadIdx.x * 4;
+        v[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (t < tiles) {
+            if (base + 3 < count) v[t] = *reinterpret_cast<const uint4*>(data + base);
+            else {
+                if (base < count) v[t].x = data[base];
+                if (base + 1 < count) v[t].y = data[base + 1];
+                if (base + 2 < count) v[t].z = data[base + 2];
+            }
+        }
+    }
 #pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) mine += v[k];
-    unsigned run = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
-#pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) { if (k < per && base + k < count) data[base + k] = run; run += v[k]; }
+    for (int t = 0; t < TILES_MAX; ++t) {
+        unsigned x = v[t].x + v[t].y + v[t].z + v[t].w;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+        incl[t] = x;
+        if (lane == 63) wave_total[t][wave] = x;
+    }
     __syncthreads();
-    if (grand_total && threadIdx.x == 0) *grand_total = tot;
+    unsigned carry = 0;                                    // everything before the current tile
+#pragma unroll
+    for (int t = 0; t < TILES_MAX; ++t) {
+        if (t >= tiles) break;
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const unsigned x = wave_total[t][w]; if (w < wave) before += x; total += x; }
+        unsigned run = carry + before + incl[t] - (v[t].x + v[t].y + v[t].z + v[t].w);
+        const int base = t * SCAN_TILE + threadIdx.x * 4;
+        const uint4 o = make_uint4(run, run + v[t].x, run + v[t].x + v[t].y, run + v[t].x + v[t].y + v[t].z);
+        if (base + 3 < count) *reinterpret_cast<uint4*>(data + base) = o;
+        else {
+            if (base < count) data[base] = o.x;
+            if (base + 1 < count) data[base + 1] = o.y;
+            if (base + 2 < count) data[base + 2] = o.z;
+        }
+        carry += total;
+    }
+    if (grand_total && threadIdx.x == 0) *grand_total = carry;
 }
 
 // scratch must hold div_up(count, SCAN_TILE) words.  total_out (device pointer, may be null) receives the sum.
 static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, unsigned* scratch, hipStream_t stream)
 {
     if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream)); return PHX_OK; }
-    if (count <= SCAN_SINGLE_MAX) {
+    if (count <= SCAN_SINGLE_MAX && (reinterpret_cast<uintptr_t>(data) & 15u) == 0) {
         hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, data, count, total_out);
         PHX_HIP(hipGetLastError());
         return PHX_OK;
