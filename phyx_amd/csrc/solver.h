@@ -35,7 +35,8 @@ public:
     int init();
 
     int solve_host(phx_rigid_body* bodies, int nb, const phx_contact_point* cps, int ncp, phx_contact_joint* joints, int nj, const phx_config& cfg);
-    int solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg);
+    // topology_changed: the caller knows the joint list differs from the previous solve's (skips one host round trip)
+    int solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
     int synchronize();
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
@@ -50,8 +51,10 @@ public:
     int device() const { return device_; }
 
 private:
-    int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild);
-    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
+    int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
+                        bool known_changed = false);
+    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback,
+                              unsigned long long* fp_out = nullptr);
     int materialise_schedule();
     int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     struct GraphKey {
@@ -98,6 +101,7 @@ private:
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2];
     DevBuf<int> jp_small_;
     bool gpu_builder_ = true;
+    int ncomp_guess_ = 0;               // component count of the previous device build (sizes its readback)
     DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;
     Readback rb_;                        // pinned staging for every small device->host readback of this handle

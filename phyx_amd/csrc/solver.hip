@@ -97,31 +97,46 @@ int DeviceSolver::launch_fingerprint(const phx_rigid_body* d_bodies, int nb, con
     return PHX_OK;
 }
 
-int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild)
+int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
+                                  bool known_changed)
 {
-    // 1. fingerprint of the joint topology (8 bytes over PCIe)
+    // 1. fingerprint of the joint topology (8 bytes over PCIe).  A caller that KNOWS the topology changed (the World, when
+    //    joints were created or destroyed this step) does not wait for it: the value rides along with the builder's first
+    //    readback.
     unsigned long long fp = 0;
+    bool have_fp = false;
     PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
-    PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
-    PHX_TRY(rb_.wait(stream_));
-    const unsigned long long raw = fp;
-    fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
     stats_.recoloured = 0;
     ncp_ = ncp;
     // Single = one coupled system swept colour by colour out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !(getenv("PHX_NO_ISLANDS") && getenv("PHX_NO_ISLANDS")[0] == '1');
-    if (!force_rebuild && sched_.valid && sched_.fingerprint == fp && nb == nb_ && nj == nj_ && sched_.islands == want_islands) { raw_fingerprint_ = raw; return PHX_OK; }
+    const bool device_builder = gpu_builder_ && !(want_islands && wave_islands_);
+    if (!(known_changed && device_builder)) {
+        PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
+        PHX_TRY(rb_.wait(stream_));
+        have_fp = true;
+        const unsigned long long mixed = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
+        if (!force_rebuild && !known_changed && sched_.valid && sched_.fingerprint == mixed && nb == nb_ && nj == nj_ && sched_.islands == want_islands) {
+            raw_fingerprint_ = fp;
+            return PHX_OK;
+        }
+    }
 
-    // 2. topology changed.  Island-aware schedules are built on the device (only component sizes cross PCIe);
-    //    the host builder below is the specification and the fallback (Single mode, bins that exceed the caps, ...).
-    if (gpu_builder_ && !(want_islands && wave_islands_)) {
+    // 2. topology changed.  Schedules are built on the device (only component sizes cross PCIe); the host builder below is
+    //    the specification and the fallback (bins that exceed the caps, more than 64 colours, ...).
+    if (device_builder) {
         bool fallback = false;
         nb_ = nb; nj_ = nj;
-        PHX_TRY(build_schedule_device(d_bodies, nb, d_joints, nj, want_islands, &fallback));
+        PHX_TRY(build_schedule_device(d_bodies, nb, d_joints, nj, want_islands, &fallback, have_fp ? nullptr : &fp));
+        if (!have_fp && fallback) {                    // the builder bailed out before its first readback
+            PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
+            PHX_TRY(rb_.wait(stream_));
+        }
+        have_fp = true;
         if (!fallback) {
-            sched_.fingerprint = fp;
-            raw_fingerprint_ = raw;
+            sched_.fingerprint = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
+            raw_fingerprint_ = fp;
             sched_.valid = true;
             ++schedule_version_;
             drop_graphs();
@@ -130,6 +145,8 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         }
         sched_.valid = false;
     }
+    const unsigned long long raw = fp;
+    fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
     const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
@@ -234,9 +251,12 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
 constexpr int JP_BATCH = 8;          // Jones-Plassmann rounds queued between two looks at the 'joints left' counter
 constexpr int JP_ROUNDS_MAX = 512;
 
-int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
+int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback,
+                                        unsigned long long* fp_out)
 {
     *fallback = false;
+    // the topology fingerprint (already queued on the stream) rides along with the first readback of the build
+    auto with_fingerprint = [&]() -> int { if (fp_out) { PHX_TRY(rb_.add(fp_out, hash_.p, sizeof *fp_out, stream_)); fp_out = nullptr; } return PHX_OK; };
     const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
@@ -258,13 +278,17 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
     } else {
     // 1. connected components
-    for (int round = 0;; ++round) {
+    // (two hook + compress rounds per host round trip: stacks converge in two, the second one only confirms it)
+    for (int round = 0;; round += 2) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
         int changed = 0;
-        PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));
-        hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
-        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb);
-        PHX_TRY(rb_.add(&changed, sb_small_.p, sizeof changed, stream_));
+        for (int k = 0; k < 2; ++k) {
+            PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));
+            hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
+            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb);
+        }
+        PHX_TRY(with_fingerprint());
+        PHX_TRY(rb_.add(&changed, sb_small_.p, sizeof changed, stream_));      // did the LAST round still hook anything?
         PHX_TRY(rb_.wait(stream_));
         if (!changed) break;
     }
@@ -272,16 +296,24 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     // 2. number the components in body order, count their joints
     hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
     PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
-    unsigned ncomp_u = 0;
-    PHX_TRY(rb_.add(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, stream_));
-    PHX_TRY(rb_.wait(stream_));
-    const int ncomp = (int)ncomp_u;
-    PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)std::max(ncomp, 1) * sizeof(unsigned), stream_));
+    PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
     hipLaunchKernelGGL(k_joint_components, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p, (const unsigned*)cc_flags_.p,
                        joint_comp_.p, comp_size_.p);
-    std::vector<unsigned> comp_size(std::max(ncomp, 1));
-    PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)ncomp * sizeof(unsigned), stream_));
+    // one round trip for the component count AND the sizes: fetch as many sizes as the previous build needed (+25 %)
+    unsigned ncomp_u = 0;
+    const int guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
+    std::vector<unsigned> comp_size(std::max(guess, 1));
+    PHX_TRY(rb_.add(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, stream_));
+    PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)guess * sizeof(unsigned), stream_));
     PHX_TRY(rb_.wait(stream_));
+    const int ncomp = (int)ncomp_u;
+    if (ncomp > guess) {
+        comp_size.resize(ncomp);
+        PHX_TRY(rb_.add(comp_size.data() + guess, comp_size_.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.wait(stream_));
+    }
+    comp_size.resize(std::max(ncomp, 1));
+    ncomp_guess_ = ncomp;
     lap("count");
 
     // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
@@ -378,6 +410,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
                 hipLaunchKernelGGL(k_jp_round, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned long long*)jp_best_[round % 3].p,
                                    jp_best_[(round + 1) % 3].p, jp_best_[(round + 2) % 3].p, round);
             int tail[2] = {0, 0};
+            PHX_TRY(with_fingerprint());
             PHX_TRY(rb_.add(&tail[0], jp_small_.p + round - 1, sizeof(int), stream_));
             PHX_TRY(rb_.add(&tail[1], jp_small_.p + JP_ROUNDS_MAX, sizeof(int), stream_));
             PHX_TRY(rb_.wait(stream_));
@@ -610,7 +643,7 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     return PHX_OK;
 }
 
-int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg)
+int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(nb >= 0 && nj >= 0 && ncp >= 0, "negative count");
@@ -626,7 +659,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
                              pending_.nj == nj && pending_.ncp == ncp && std::memcmp(&pending_.cfg, &cfg, sizeof cfg) == 0))
         PHX_TRY(synchronize());
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !(getenv("PHX_NO_ISLANDS") && getenv("PHX_NO_ISLANDS")[0] == '1');
-    if (speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
+    if (!topology_changed && speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
         // Same sizes as the schedule in hand: run on it without waiting for the fingerprint.  The fingerprint kernel is
         // queued first; every kernel that writes to the caller's arrays compares it on the device and commits nothing on
         // a mismatch; synchronize() reads it back and, if it differs, rebuilds the schedule and repeats the solve.
@@ -635,7 +668,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
         pending_.nb = nb; pending_.ncp = ncp; pending_.nj = nj; pending_.cfg = cfg;
         stats_.recoloured = 0;
     } else {
-        PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp, cfg, false));
+        PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp, cfg, false, topology_changed));
     }
     const bool split = cfg.island_mode == PHX_ISLAND_MULTIPLE || cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
     stats_.island_count = split ? sched_.island_count : 1;

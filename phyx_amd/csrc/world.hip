@@ -66,6 +66,7 @@ private:
     DevBuf<phx_contact_joint> d_joints_;
     DevBuf<unsigned> flags_, scan_tiles_, counters_;     // counters_: [0] dead/new total, [1] dropped points
     Readback rb_;
+    bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
     DevBuf<int> mover_pos_;
     DevBuf<uint2> erased_;
 };
@@ -199,6 +200,7 @@ int World::refresh_contact_joints()                                         // r
         PHX_TRY(rb_.wait(stream_));
         fresh = (int)host;
         if (fresh) {
+            joints_changed_ = true;
             PHX_TRY(d_joints_.reserve_keep((size_t)nj + fresh, nj, stream_));
             hipLaunchKernelGGL(k_joints_create, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, d_cps_.p, d_joints_.p, nj,
                                (const unsigned*)flags_.p);
@@ -213,6 +215,7 @@ int World::refresh_contact_joints()                                         // r
         PHX_TRY(rb_.wait(stream_));
         const int dead = (int)host;
         if (dead) {
+            joints_changed_ = true;
             hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, total, mover_pos_.p);
             hipLaunchKernelGGL(k_joints_fill, dim3(wgrid(total)), dim3(256), 0, stream_, d_joints_.p, total, (const unsigned*)flags_.p, (const unsigned*)counters_.p,
                                (const int*)mover_pos_.p);
@@ -229,7 +232,8 @@ int World::solve(const phx_config& cfg)                                     // r
 {
     // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
     // keep their velocities here
-    PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg));
+    PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
+    joints_changed_ = false;
     return solver_.synchronize();
 }
 
