@@ -224,6 +224,9 @@ int  phx_world_set_gravity(phx_world* w, float gravity);            /* ref: Worl
  * island sharding; the default 0/1 solves everything).  Bodies of other shards keep their velocities. */
 int  phx_world_set_shard(phx_world* w, int32_t shard, int32_t shard_count);
 int  phx_world_update(phx_world* w, float dt, const phx_config* config);   /* ref: World.cpp:19-37 */
+/* phx_world_update returns once the step is QUEUED on the world's stream (the host waits only where it needs a count
+ * to size a launch); every getter synchronises before it reads.  This waits for the device explicitly. */
+int  phx_world_synchronize(phx_world* w);
 /* World::Update split at the solver boundary: pre_solve = everything before Solver::SolveJoints
  * (ref: World.cpp:25-32), after which bodies / contact points / joints are exactly the solver's inputs;
  * finish_step = SolveJoints + IntegratePosition (ref: World.cpp:34-36).  pre_solve + finish_step == update. */
@@ -243,6 +246,9 @@ phx_broadphase* phx_world_broadphase(phx_world* w);
  * 0 IntegrateVelocity 1 UpdateBroadphase 2 UpdatePairs 3 UpdateManifolds 4 PackManifolds
  * 5 RefreshContactJoints 6 SolveJoints 7 IntegratePosition */
 int  phx_world_get_phase_ms(phx_world* w, double out8[8]);
+/* per-phase host timers cost one stream synchronisation per phase; off by default (get_phase_ms then returns the last
+ * values measured while it was on) */
+int  phx_world_set_phase_timing(phx_world* w, int32_t on);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* measurement helpers used by bench.py: HIP events on the handle's own stream                     */

@@ -379,6 +379,14 @@ class World:
     def contactJoints(self):
         return self._get(self.L.phx_world_get_joints, contact_joint_dtype, self.counts()[3])
 
+    def sync(self):
+        """Wait for the queued step (Update returns once the step is queued; getters synchronise on their own)."""
+        check(self.L.phx_world_synchronize(self.h))
+
+    def set_phase_timing(self, on=True):
+        """Per-phase host timers (phase_ms) cost one stream synchronisation per phase; off by default."""
+        check(self.L.phx_world_set_phase_timing(self.h, 1 if on else 0))
+
     def phase_ms(self):
         out = np.zeros(8, dtype=np.float64)
         check(self.L.phx_world_get_phase_ms(self.h, _ptr(out)))

@@ -39,7 +39,7 @@ private:
     unsigned table_cap_ = 0;
     long long set_size_ = 0, tombstones_ = 0;
     int n_ = 0, sorted_ = 0, last_new_ = 0;
-    bool have_update_ = false;
+    bool have_update_ = false, ms_pending_ = false;
     phx_broadphase_stats stats_{};
     Readback rb_;
 };

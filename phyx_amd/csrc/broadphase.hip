@@ -420,12 +420,11 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         set_size_ += total;
     }
     PHX_HIP(hipEventRecord(ev_end_, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));
-    float ms = 0.f;
-    PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
-    stats_.device_ms = ms;
+    // (not synchronised here: what follows on this stream — insertions' consumers, the next phase of a World — is ordered
+    //  behind it; get_stats / get_new_pairs / get_sorted synchronise before they read)
     stats_.set_size = (int)set_size_;
     have_update_ = true;
+    ms_pending_ = true;
     return PHX_OK;
 }
 
@@ -436,6 +435,7 @@ int DeviceBroadphase::update_host(const phx_rigid_body* bodies, int n, uint32_t*
     PHX_TRY(st_bodies_.reserve(std::max(n, 1)));
     if (n) PHX_HIP(hipMemcpyAsync(st_bodies_.p, bodies, (size_t)n * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
     PHX_TRY(update_device(st_bodies_.p, n));
+    PHX_HIP(hipStreamSynchronize(stream_));
     return get_new_pairs(new_pairs, cap, count);
 }
 
@@ -446,6 +446,7 @@ int DeviceBroadphase::get_new_pairs(uint32_t* out, int cap, int* count)
     if (!out) return PHX_OK;
     if (cap < last_new_) { set_error("new-pair buffer too small: need %d", last_new_); return PHX_ERR_CAPACITY; }
     PHX_TRY(use_device(device_));
+    PHX_HIP(hipStreamSynchronize(stream_));
     if (last_new_) PHX_HIP(hipMemcpy(out, new_pairs_.p, (size_t)last_new_ * sizeof(uint2), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
@@ -502,6 +503,14 @@ int DeviceBroadphase::get_stats(phx_broadphase_stats* out)
 {
     PHX_REQUIRE(out, "null out");
     if (!have_update_) { set_error("no broadphase update has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(use_device(device_));
+    if (ms_pending_) {
+        PHX_HIP(hipStreamSynchronize(stream_));
+        float ms = 0.f;
+        PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+        stats_.device_ms = ms;
+        ms_pending_ = false;
+    }
     *out = stats_;
     out->set_size = (int)set_size_;
     return PHX_OK;

@@ -48,6 +48,10 @@ public:
               const phx_config& cfg, int warmup, int steps, phx_bench_result* out, phx_step_hook hook = nullptr, void* user = nullptr);
 
     hipStream_t stream() const { return stream_; }
+    // run on a caller-owned stream from now on (the World puts broadphase, step kernels and solver on one stream so that
+    // consecutive phases need no host synchronisation)
+    int adopt_stream(hipStream_t s);
+    bool has_pending() const { return pending_.active; }
     int device() const { return device_; }
 
 private:
@@ -124,6 +128,7 @@ private:
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
     bool use_graphs_ = true, wave_islands_ = false, speculate_ = true, half_state_ = false;
+    bool owns_stream_ = true;
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
     bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }
     // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()

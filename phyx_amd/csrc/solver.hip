@@ -48,7 +48,18 @@ DeviceSolver::~DeviceSolver()
     if (ev_end_) (void)hipEventDestroy(ev_end_);
     if (ev_sweep_begin_) (void)hipEventDestroy(ev_sweep_begin_);
     if (ev_sweep_end_) (void)hipEventDestroy(ev_sweep_end_);
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_ && owns_stream_) (void)hipStreamDestroy(stream_);
+}
+
+int DeviceSolver::adopt_stream(hipStream_t s)
+{
+    PHX_TRY(use_device(device_));
+    PHX_TRY(synchronize());
+    drop_graphs();
+    if (stream_ && owns_stream_) PHX_HIP(hipStreamDestroy(stream_));
+    stream_ = s;
+    owns_stream_ = false;
+    return PHX_OK;
 }
 
 int DeviceSolver::init()

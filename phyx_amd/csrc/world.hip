@@ -26,6 +26,7 @@ public:
 
     int add_body(float px, float py, float angle, float sx, float sy);
     int set_static(int body);
+    int synchronize();
     int update(float dt, const phx_config& cfg);
     int pre_solve(float dt);
     int finish_step(float dt, const phx_config& cfg);
@@ -39,6 +40,7 @@ public:
     float gravity = 0.f;
     int shard = 0, shard_count = 1;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool phase_timing = false;          // per-phase host timers: one stream synchronisation per phase, off by default
     int dropped_points = 0;
     phx_broadphase broadphase_h;     // world-owned handles, also reachable through phx_world_broadphase()/phx_world_solver()
     phx_solver solver_h;
@@ -77,14 +79,17 @@ World::~World()
     if (stream_) (void)hipStreamSynchronize(stream_);
     d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
     flags_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
-    if (stream_) (void)hipStreamDestroy(stream_);
+    // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
 
 int World::init()
 {
     PHX_TRY(broadphase_.init());
     PHX_TRY(solver_.init());
-    PHX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // one stream for the whole step: broadphase, narrowphase, contact cache, solver and integrators are ordered by it, the
+    // host waits only where it needs a count to size the next launch
+    stream_ = broadphase_.stream();
+    PHX_TRY(solver_.adopt_stream(stream_));
     PHX_TRY(counters_.reserve(4));
     return PHX_OK;
 }
@@ -144,7 +149,7 @@ int World::scratch_for(int n)
 
 int World::update_pairs()                                                   // ref: Collider.cpp:251-345
 {
-    PHX_TRY(broadphase_.update_device(d_bodies_.p, nb()));                  // synchronises its own stream
+    PHX_TRY(broadphase_.update_device(d_bodies_.p, nb()));                  // same stream; returns once the new-pair count is known
     const int fresh = broadphase_.new_pair_count();
     if (!fresh) return PHX_OK;
     PHX_TRY(d_manifolds_.reserve_keep((size_t)nm + fresh, nm, stream_));
@@ -181,7 +186,6 @@ int World::pack_manifolds()                                                 // r
     hipLaunchKernelGGL(k_pack_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, (const unsigned*)flags_.p,
                        (const unsigned*)counters_.p, (const int*)mover_pos_.p, erased_.p);
     PHX_HIP(hipGetLastError());
-    PHX_HIP(hipStreamSynchronize(stream_));
     nm -= dead;
     return broadphase_.erase_pairs_device(erased_.p, dead);                 // ref: Collider.cpp:391 manifoldMap.erase
 }
@@ -224,7 +228,6 @@ int World::refresh_contact_joints()                                         // r
         if (nj) hipLaunchKernelGGL(k_joints_publish, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, d_cps_.p);
     } else nj = 0;
     PHX_HIP(hipGetLastError());
-    PHX_HIP(hipStreamSynchronize(stream_));
     return PHX_OK;
 }
 
@@ -234,7 +237,9 @@ int World::solve(const phx_config& cfg)                                     // r
     // keep their velocities here
     PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
     joints_changed_ = false;
-    return solver_.synchronize();
+    // a speculative solve (unchanged joint list, cached schedule) must be verified before the integrator consumes its
+    // result; a solve on a freshly built schedule needs no host wait at all (its counters are fetched by the first getter)
+    return solver_.has_pending() ? solver_.synchronize() : PHX_OK;
 }
 
 int World::pre_solve(float dt)
@@ -243,7 +248,7 @@ int World::pre_solve(float dt)
     PHX_TRY(use_device(device_));
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
-    auto lap = [&](int phase) { (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
+    auto lap = [&](int phase) { if (!phase_timing) return; (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
     if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt);   // ref: World.cpp:39-55
     PHX_HIP(hipGetLastError());
     lap(0);
@@ -263,11 +268,19 @@ int World::finish_step(float dt, const phx_config& cfg)
     PHX_TRY(use_device(device_));
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
-    auto lap = [&](int phase) { (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
+    auto lap = [&](int phase) { if (!phase_timing) return; (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
     PHX_TRY(solve(cfg)); lap(6);
     if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
     PHX_HIP(hipGetLastError());
     lap(7);
+    return PHX_OK;
+}
+
+int World::synchronize()
+{
+    PHX_TRY(use_device(device_));
+    PHX_TRY(solver_.synchronize());
+    PHX_HIP(hipStreamSynchronize(stream_));
     return PHX_OK;
 }
 
@@ -283,6 +296,7 @@ int World::update(float dt, const phx_config& cfg)
         const int n = (count_expr);                                                                                  \
         if (cap < n) { set_error(#fn ": buffer too small"); return PHX_ERR_CAPACITY; }                             \
         PHX_TRY(use_device(device_));                                                                                \
+        PHX_HIP(hipStreamSynchronize(stream_));                                                                      \
         if (n) PHX_HIP(hipMemcpy(out, buf.p, (size_t)n * sizeof(type), hipMemcpyDeviceToHost));                     \
         return PHX_OK;                                                                                               \
     }
@@ -296,6 +310,7 @@ int World::download_bodies(phx_rigid_body* out, int cap)
     if (cap < n) { set_error("download_bodies: buffer too small"); return PHX_ERR_CAPACITY; }
     if (bodies_dirty_ || !d_bodies_.p) { if (n && out != host_bodies_.data()) std::memcpy(out, host_bodies_.data(), (size_t)n * sizeof(phx_rigid_body)); return PHX_OK; }
     PHX_TRY(use_device(device_));
+    PHX_HIP(hipStreamSynchronize(stream_));
     if (n) PHX_HIP(hipMemcpy(out, d_bodies_.p, (size_t)n * sizeof(phx_rigid_body), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
@@ -388,6 +403,19 @@ int phx_world_get_broadphase_stats(phx_world* w, phx_broadphase_stats* out) { PH
 
 phx_solver* phx_world_solver(phx_world* w) { return w ? &w->impl.solver_h : nullptr; }
 phx_broadphase* phx_world_broadphase(phx_world* w) { return w ? &w->impl.broadphase_h : nullptr; }
+
+int phx_world_synchronize(phx_world* w)
+{
+    PHX_REQUIRE(w, "null handle");
+    return w->impl.synchronize();
+}
+
+int phx_world_set_phase_timing(phx_world* w, int32_t on)
+{
+    PHX_REQUIRE(w, "null handle");
+    w->impl.phase_timing = on != 0;
+    return PHX_OK;
+}
 
 int phx_world_get_phase_ms(phx_world* w, double out8[8])
 {

@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import phyx_amd
 from phyx_amd import scenes, Configuration
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-w = phyx_amd.World(0, gravity=-200.0); w.add_scene(scenes.stack(1000, 200))
+w = phyx_amd.World(0, gravity=-200.0); w.set_phase_timing(True); w.add_scene(scenes.stack(1000, 200))
 cfg = Configuration(2, 2, 20, 20)
 for step in range(steps):
-    t = time.time(); w.Update(1/60, cfg); dt = time.time() - t
+    t = time.time(); w.Update(1/60, cfg); w.sync(); dt = time.time() - t
     ss = w.solver.stats(); bs = w.collider.stats()
     if step % 4 == 0 or step > steps - 5:
         print(step, "step %.2f ms" % (dt*1e3), {k: round(v, 3) for k, v in w.phase_ms().items()}, "recol", ss.recoloured, "lds groups", ss.lds_islands, "colours", ss.colour_count,
