@@ -327,6 +327,35 @@ def _random_state(rng, nb, nj, static_frac, dup_ids=False, hub=0):
     return bodies, cps, joints
 
 
+def _priority_chain_state(n):
+    """A chain of n joints whose colouring priorities decrease monotonically along the chain: every Jones-Plassmann round
+    can colour exactly one joint, so the device needs n rounds — more than it allows itself before handing the HBM group
+    to the host builder."""
+    rng = np.random.default_rng(11)
+    bodies, cps, joints = _random_state(rng, n + 1, n, 0.0)
+    joints["body1"] = np.arange(n)
+    joints["body2"] = np.arange(1, n + 1)
+    hi = np.array([phyx_amd.schedule_priority(i, 0) >> 32 for i in range(n)])
+    joints["contact_point_index"] = np.argsort(-hi, kind="stable")                  # a permutation of the n contact points
+    return bodies, cps, joints
+
+
+def test_pathological_priority_chain_falls_back_to_the_host_builder(oracle, built_lib):
+    state = _priority_chain_state(700)
+    solver = phyx_amd.Solver(0)
+    cfg = Configuration(0, phyx_amd.ISLAND_SINGLE, 3, 3)
+    gb, gj, sched, _, st = _device_solve(solver, state, cfg)
+    assert sorted(sched.order.tolist()) == list(range(700)) and st.colour_count == 2      # a path needs two colours
+    ob_, oj, _ = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+    # the island-aware mode colours the same chain inside one 1024-lane workgroup (no round limit there)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 3, 3)
+    gb, gj, sched, _, st = _device_solve(solver, state, cfg)
+    assert st.lds_islands == 1 and st.colour_count == 2
+    ob_, oj, _ = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+
+
 @pytest.mark.parametrize("case", ["sparse", "dense", "dup_ids", "mostly_static", "hub_over_64_colours"])
 def test_random_contact_graphs_both_builders_and_oracle(oracle, built_lib, case):
     """Arbitrary contact graphs (not stacks): the device builder must reproduce the host builder's schedule — including
