@@ -31,4 +31,7 @@ ok = True
 ok &= run("falling3000/multiple", scenes.falling(3000, width=120.0, ymax=500.0), 240, 1)
 ok &= run("tilted300/single", scenes.tilted(300), 300, 0)
 ok &= run("stack12x80/sloppy", scenes.stack(12, 80), 150, 3)
+if "--long" in sys.argv:      # tall columns that lean into each other: islands merge past the LDS caps, the HBM group is coloured on the device
+    ok &= run("stack30x200/multiple", scenes.stack(30, 200), 60, 1, every=5)
+    ok &= run("stack30x200/single", scenes.stack(30, 200), 40, 0, every=5)
 print("SOAK", "OK" if ok else "FAILED")
