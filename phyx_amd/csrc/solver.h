@@ -57,8 +57,7 @@ public:
 private:
     int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
                         bool known_changed = false);
-    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback,
-                              unsigned long long* fp_out = nullptr);
+    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
     int materialise_schedule();
     int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     struct GraphKey {
@@ -105,6 +104,7 @@ private:
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2];
     DevBuf<int> jp_small_;
     bool gpu_builder_ = true;
+    unsigned long long* fp_wanted_ = nullptr;   // set by ensure_schedule: deliver the fingerprint with the builder's first readback
     int ncomp_guess_ = 0;               // component count of the previous device build (sizes its readback)
     DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;

@@ -139,8 +139,11 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     if (device_builder) {
         bool fallback = false;
         nb_ = nb; nj_ = nj;
-        PHX_TRY(build_schedule_device(d_bodies, nb, d_joints, nj, want_islands, &fallback, have_fp ? nullptr : &fp));
-        if (!have_fp && fallback) {                    // the builder bailed out before its first readback
+        fp_wanted_ = have_fp ? nullptr : &fp;
+        const int st = build_schedule_device(d_bodies, nb, d_joints, nj, want_islands, &fallback);
+        if (st != PHX_OK) { fp_wanted_ = nullptr; return st; }
+        if (fp_wanted_) {                              // the builder had nothing to read back (no joints) or bailed out early
+            fp_wanted_ = nullptr;
             PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
             PHX_TRY(rb_.wait(stream_));
         }
@@ -262,12 +265,11 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
 constexpr int JP_BATCH = 8;          // Jones-Plassmann rounds queued between two looks at the 'joints left' counter
 constexpr int JP_ROUNDS_MAX = 512;
 
-int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback,
-                                        unsigned long long* fp_out)
+int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
 {
     *fallback = false;
     // the topology fingerprint (already queued on the stream) rides along with the first readback of the build
-    auto with_fingerprint = [&]() -> int { if (fp_out) { PHX_TRY(rb_.add(fp_out, hash_.p, sizeof *fp_out, stream_)); fp_out = nullptr; } return PHX_OK; };
+    auto with_fingerprint = [&]() -> int { if (fp_wanted_) { PHX_TRY(rb_.add(fp_wanted_, hash_.p, sizeof *fp_wanted_, stream_)); fp_wanted_ = nullptr; } return PHX_OK; };
     const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
