@@ -79,6 +79,9 @@ int DeviceSolver::init()
     gpu_builder_ = !(sb && sb[0] == 'h');
     const char* sp = getenv("PHX_NO_SPECULATION");
     speculate_ = !(sp && sp[0] == '1');
+    const char* ni = getenv("PHX_NO_ISLANDS");           // "1": ignore island modes, always the HBM colour path (A/B measurements)
+    no_islands_ = ni && ni[0] == '1';
+    trace_schedule_ = getenv("PHX_TRACE_SCHEDULE") != nullptr;      // print the schedule builders' laps to stderr
     const char* wv = getenv("PHX_ISLAND_KERNEL");      // "wave" = one wavefront per island (measured 5x slower: a lone wave exposes every instruction latency); default = one 512-lane workgroup per island
     wave_islands_ = (wv && wv[0] == 'w');
     return PHX_OK;
@@ -121,7 +124,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     ncp_ = ncp;
     // Single = one coupled system swept colour by colour out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
-    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !(getenv("PHX_NO_ISLANDS") && getenv("PHX_NO_ISLANDS")[0] == '1');
+    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     const bool device_builder = gpu_builder_ && !(want_islands && wave_islands_);
     if (!(known_changed && device_builder)) {
         PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
@@ -161,7 +164,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     }
     const unsigned long long raw = fp;
     fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
-    const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
+    const bool trace = trace_schedule_;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     DevBuf<int2> d_pairs;
@@ -270,7 +273,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     *fallback = false;
     // the topology fingerprint (already queued on the stream) rides along with the first readback of the build
     auto with_fingerprint = [&]() -> int { if (fp_wanted_) { PHX_TRY(rb_.add(fp_wanted_, hash_.p, sizeof *fp_wanted_, stream_)); fp_wanted_ = nullptr; } return PHX_OK; };
-    const bool trace = getenv("PHX_TRACE_SCHEDULE") != nullptr;
+    const bool trace = trace_schedule_;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     const int nbs = std::max(nb, 1), njs = std::max(nj, 1);
@@ -671,7 +674,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     if (pending_.active && !(pending_.bodies == d_bodies && pending_.cps == d_cps && pending_.joints == d_joints && pending_.nb == nb &&
                              pending_.nj == nj && pending_.ncp == ncp && std::memcmp(&pending_.cfg, &cfg, sizeof cfg) == 0))
         PHX_TRY(synchronize());
-    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !(getenv("PHX_NO_ISLANDS") && getenv("PHX_NO_ISLANDS")[0] == '1');
+    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     if (!topology_changed && speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
         // Same sizes as the schedule in hand: run on it without waiting for the fingerprint.  The fingerprint kernel is
         // queued first; every kernel that writes to the caller's arrays compares it on the device and commits nothing on
