@@ -20,7 +20,9 @@ static_assert(sizeof(phx_contact_joint) == 20, "ContactJoint layout (ref: src/Jo
 static_assert(sizeof(phx_broadphase_entry) == 20, "BroadphaseEntry layout (ref: src/Collider.h:45-50)");
 static_assert(sizeof(phx_sort_entry) == 8, "BroadphaseSortEntry layout (ref: src/Collider.h:52-56)");
 static_assert(offsetof(phx_rigid_body, velocity) == 52 && offsetof(phx_rigid_body, inv_mass) == 88 &&
-              offsetof(phx_rigid_body, xvector) == 96 && offsetof(phx_rigid_body, pos) == 112, "RigidBody offsets");
+              offsetof(phx_rigid_body, xvector) == 96 && offsetof(phx_rigid_body, pos) == 112 &&
+              offsetof(phx_rigid_body, displacing_velocity) == 68 && offsetof(phx_rigid_body, angular_velocity) == 76 &&
+              offsetof(phx_rigid_body, displacing_angular_velocity) == 84, "RigidBody offsets");
 
 namespace phx {
 

@@ -669,6 +669,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     PHX_REQUIRE(cfg.island_mode >= PHX_ISLAND_SINGLE && cfg.island_mode <= PHX_ISLAND_MULTIPLE_SLOPPY, "unknown island mode");
     PHX_REQUIRE(nb == 0 || d_bodies, "null bodies");
     PHX_REQUIRE(nj == 0 || (d_joints && d_cps), "null joints / contact points");
+    PHX_REQUIRE((reinterpret_cast<uintptr_t>(d_bodies) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_cps) & 15u) == 0, "device arrays must be 16-byte aligned");
     // an unverified solve on OTHER arrays is still in flight: settle it first (a repeat on the same arrays simply
     // supersedes it — each solve is gated by the fingerprint computed for itself)
     if (pending_.active && !(pending_.bodies == d_bodies && pending_.cps == d_cps && pending_.joints == d_joints && pending_.nb == nb &&
