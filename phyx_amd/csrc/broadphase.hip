@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(256) k_ps_rehash(const unsigned long long* __r
 // Rows with a short scan range are swept one row per lane: lane l of a wave owns sorted row i0+l and reads
 // entries[i0+l+1+t] in step t, so a wave's loads are contiguous.  Rows whose range exceeds HUB_LEN (the
 // ground box spans every column) are deferred to a workgroup-per-row kernel.
+constexpr int STAT_SLOTS = 64;     // same-address atomics serialise (~10 ns each): 31k of them cost 0.3 ms of a 0.4 ms kernel
 constexpr int HUB_LEN = 2048;      // rows scanning more candidates than this are cut into chunks
 constexpr int HUB_CHUNK = 2048;    // candidates per chunk = one 256-lane workgroup x 8 tiles
 
@@ -138,7 +139,7 @@ struct SweepView {
     unsigned* chunk_count;     // new pairs per chunk, later: the chunk's base inside its row
     int* n_chunks;
     int chunk_cap;
-    unsigned long long* counters;   // [0] candidate tests, [1] overlapping pairs
+    unsigned long long* counters;   // statistics, spread over STAT_SLOTS slots to keep the atomics apart: [2 * slot] candidate tests, [2 * slot + 1] overlapping pairs
 };
 
 // first position j > i with minx[j] > maxx (entries sorted by minx)
@@ -161,11 +162,15 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
     unsigned long long tests = 0, overlaps = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
         const float4 a = v.entries[i];
-        const int end = scan_end(v.entries, v.n, i, a.y);
-        const int len = end - i - 1;
-        if (len > HUB_LEN) {
+        // a hub row (more than HUB_LEN candidates) is recognised by one probe: entries are sorted by minx, so the row is a
+        // hub iff the candidate HUB_LEN places ahead still starts at or before this row's maxx.  Only hub rows pay the
+        // binary search for their end; every other row finds it by scanning (ref: Collider.cpp:300-303 breaks the same way).
+        const bool hub = i + 1 + HUB_LEN < v.n && !(v.entries[i + 1 + HUB_LEN].x > a.y);
+        if (hub) {
             if (!EMIT) {
                 // hand the row to the chunk kernels: its chunks sit contiguously and in j order in the list
+                const int end = scan_end(v.entries, v.n, i, a.y);
+                const int len = end - i - 1;
                 const int nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
                 const int first = atomicAdd(v.n_chunks, nc);
                 for (int k = 0; k < nc && first + k < v.chunk_cap; ++k)
@@ -188,19 +193,36 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
                 }
             }
         };
+        // candidates four at a time (four loads in flight), in j order, until the first one that starts beyond maxx
         int j = i + 1;
-        for (; j + 4 <= end; j += 4) {
-            const float4 b0 = v.entries[j], b1 = v.entries[j + 1], b2 = v.entries[j + 2], b3 = v.entries[j + 3];
-            test(j, b0); test(j + 1, b1); test(j + 2, b2); test(j + 3, b3);
+        for (;;) {
+            if (j + 4 <= v.n) {
+                const float4 b0 = v.entries[j], b1 = v.entries[j + 1], b2 = v.entries[j + 2], b3 = v.entries[j + 3];
+                if (b0.x > a.y) break;
+                test(j, b0);
+                if (b1.x > a.y) { j += 1; break; }
+                test(j + 1, b1);
+                if (b2.x > a.y) { j += 2; break; }
+                test(j + 2, b2);
+                if (b3.x > a.y) { j += 3; break; }
+                test(j + 3, b3);
+                j += 4;
+            } else {
+                for (; j < v.n; ++j) { const float4 b = v.entries[j]; if (b.x > a.y) break; test(j, b); }
+                break;
+            }
         }
-        for (; j < end; ++j) test(j, v.entries[j]);
+        const int len = j - i - 1;
         if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; }
     }
     if (!EMIT) {
         for (int off = 32; off > 0; off >>= 1) { tests += __shfl_down(tests, off); overlaps += __shfl_down(overlaps, off); }
-        if ((threadIdx.x & 63) == 0) {
-            if (tests) atomicAdd(&v.counters[0], tests);
-            if (overlaps) atomicAdd(&v.counters[1], overlaps);
+        __shared__ unsigned long long part[2][4];
+        if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = tests; part[1][threadIdx.x >> 6] = overlaps; }
+        __syncthreads();
+        if (threadIdx.x < 2) {                             // one atomic per workgroup per counter, 64 slots
+            const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+            if (t) atomicAdd(&v.counters[2 * (blockIdx.x % STAT_SLOTS) + threadIdx.x], t);
         }
     }
 }
@@ -246,7 +268,7 @@ __global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigne
         if (!EMIT) {
             if (threadIdx.x == 0) v.chunk_count[c] = running;
             for (int off = 32; off > 0; off >>= 1) overlaps += __shfl_down(overlaps, off);
-            if (lane == 0 && overlaps) atomicAdd(&v.counters[1], overlaps);
+            if (lane == 0 && overlaps) atomicAdd(&v.counters[2 * ((blockIdx.x * 4 + wave) % STAT_SLOTS) + 1], overlaps);
         }
         __syncthreads();
     }
@@ -297,7 +319,7 @@ int DeviceBroadphase::init()
     PHX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     PHX_HIP(hipEventCreate(&ev_begin_));
     PHX_HIP(hipEventCreate(&ev_end_));
-    PHX_TRY(small_.reserve(16));
+    PHX_TRY(small_.reserve(16 + 2 * STAT_SLOTS));
     return clear();
 }
 
@@ -355,7 +377,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max<long long>(4 * set_size_, 1024)));
 
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
-    PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
+    PHX_HIP(hipMemsetAsync(small_.p, 0, (16 + 2 * STAT_SLOTS) * sizeof(unsigned long long), stream_));
     PHX_HIP(hipMemsetAsync(chunk_count_.p, 0, (size_t)chunk_cap * sizeof(unsigned), stream_));
     if (n == 0) { PHX_HIP(hipEventRecord(ev_end_, stream_)); PHX_HIP(hipStreamSynchronize(stream_)); stats_.set_size = (int)set_size_; have_update_ = true; return PHX_OK; }
 
@@ -370,8 +392,8 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     v.entries = entries_.p; v.idx = idx_[src].p; v.n = n; v.table = table_.p; v.mask = table_cap_ - 1;
     v.row_count = row_count_.p;
     v.n_chunks = reinterpret_cast<int*>(small_.p + 2);
-    v.counters = small_.p;
-    unsigned long long host_small[4] = {0, 0, 0, 0};
+    v.counters = small_.p + 16;
+    unsigned long long host_small[16 + 2 * STAT_SLOTS] = {0};      // [2] chunks needed, [3] new pairs, [16..] statistics slots
     int chunk_grid = 1;
     for (int attempt = 0;; ++attempt) {
         v.chunks = chunks_.p; v.chunk_count = chunk_count_.p; v.chunk_cap = chunk_cap;
@@ -399,12 +421,12 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         chunk_cap = needed + 64;
         PHX_TRY(chunks_.reserve(chunk_cap));
         PHX_TRY(chunk_count_.reserve(chunk_cap));
-        PHX_HIP(hipMemsetAsync(small_.p, 0, 16 * sizeof(unsigned long long), stream_));
+        PHX_HIP(hipMemsetAsync(small_.p, 0, (16 + 2 * STAT_SLOTS) * sizeof(unsigned long long), stream_));
         PHX_HIP(hipMemsetAsync(chunk_count_.p, 0, (size_t)chunk_cap * sizeof(unsigned), stream_));
     }
     const unsigned total = (unsigned)host_small[3];
-    stats_.candidate_tests = (long long)host_small[0];
-    stats_.overlapping_pairs = (long long)host_small[1];
+    stats_.candidate_tests = 0; stats_.overlapping_pairs = 0;
+    for (int k = 0; k < STAT_SLOTS; ++k) { stats_.candidate_tests += (long long)host_small[16 + 2 * k]; stats_.overlapping_pairs += (long long)host_small[17 + 2 * k]; }
     stats_.new_pairs = (int)total;
     last_new_ = (int)total;
     if (total) {

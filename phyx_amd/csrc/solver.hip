@@ -71,8 +71,8 @@ int DeviceSolver::init()
     PHX_HIP(hipEventCreate(&ev_sweep_begin_));
     PHX_HIP(hipEventCreate(&ev_sweep_end_));
     PHX_TRY(hash_.reserve(1));
-    PHX_TRY(isl_stats_.reserve(2));
-    PHX_TRY(isl_visits_.reserve(1));
+    PHX_TRY(isl_stats_.reserve(2 * ISL_STAT_SLOTS));
+    PHX_TRY(isl_visits_.reserve(ISL_STAT_SLOTS));
     const char* g = getenv("PHX_NO_GRAPHS");
     use_graphs_ = !(g && g[0] == '1');
     const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
@@ -725,13 +725,16 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
         return rb_.wait(stream_);
     }
     std::vector<int> flags(2 * (size_t)max_iters_);
-    int isl[2] = {0, 0};
-    unsigned long long isl_visits = 0;
+    int isl_slots[2 * ISL_STAT_SLOTS] = {0};
+    unsigned long long visit_slots[ISL_STAT_SLOTS] = {0};
     if (extra) PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_));
     PHX_TRY(rb_.add(flags.data(), flags_.p, flags.size() * sizeof(int), stream_));
-    PHX_TRY(rb_.add(isl, isl_stats_.p, sizeof isl, stream_));
-    PHX_TRY(rb_.add(&isl_visits, isl_visits_.p, sizeof isl_visits, stream_));
+    PHX_TRY(rb_.add(isl_slots, isl_stats_.p, sizeof isl_slots, stream_));
+    PHX_TRY(rb_.add(visit_slots, isl_visits_.p, sizeof visit_slots, stream_));
     PHX_TRY(rb_.wait(stream_));
+    int isl[2] = {0, 0};
+    unsigned long long isl_visits = 0;
+    for (int k = 0; k < ISL_STAT_SLOTS; ++k) { isl[0] = std::max(isl[0], isl_slots[2 * k]); isl[1] = std::max(isl[1], isl_slots[2 * k + 1]); isl_visits += visit_slots[k]; }
     auto executed = [&](const int* active, int limit) {
         int n = 0;
         for (int k = 0; k < limit; ++k) { ++n; if (!active[k]) break; }     // ref: Solver.cpp:175-190

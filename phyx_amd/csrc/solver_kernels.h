@@ -77,13 +77,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
     return z ^ (z >> 31);
 }
 
+// the island kernel's per-group statistics go to ISL_STAT_SLOTS slots: thousands of same-address atomics would serialise at the L2
+constexpr int ISL_STAT_SLOTS = 64;
+
 // Every per-solve control word in one dispatch (five memsets would be five dispatches on a 0.18 ms step): the fingerprint
 // accumulator, the HBM path's per-sweep 'productive' flags and static-tag words, the island kernel's counters.
 __global__ void __launch_bounds__(256) k_clear_control(unsigned long long* hash, int* flags, int nflags, unsigned* sw, int nsw,
                                                        int* isl_stats, unsigned long long* isl_visits)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
-    if (i == 0) { *hash = 0ull; *isl_visits = 0ull; isl_stats[0] = 0; isl_stats[1] = 0; }
+    if (i == 0) *hash = 0ull;
+    if (i < ISL_STAT_SLOTS) { isl_visits[i] = 0ull; isl_stats[2 * i] = 0; isl_stats[2 * i + 1] = 0; }
     for (int k = i; k < nflags; k += n) flags[k] = 0;
     for (int k = i; k < nsw; k += n) sw[k] = 0u;
 }
@@ -206,6 +210,20 @@ __global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int en
 // would add a third dependent round trip to save bytes that are not the bottleneck.
 constexpr int SOLVE_BLOCK = 64;
 
+// atomicMax(&words[slot], word) for every lane with `want`, issued once per distinct slot in the wave
+__device__ __forceinline__ void wave_tag_update(unsigned* words, bool want, int slot, unsigned word)
+{
+    unsigned long long todo = __ballot(want);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int key = __shfl(slot, leader);
+        const unsigned long long same = __ballot(want && slot == key);
+        if (lane == leader) atomicMax(&words[key], word);
+        todo &= ~same;
+    }
+}
+
 template <bool DO_IMP, bool DO_DISP>
 __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int begin, int end, int colour, int iter)
 {
@@ -226,6 +244,7 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
         if (imp_on) { f = v.q1[s]; acc = v.acc[s]; }
         if (disp_on) d = v.dd[s];
         const int b1 = k.y, b2 = k.z, ss = k.w;
+        bool tag_imp = false, tag_disp = false;
         float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
         if (imp_on) { B1 = v.sb_imp[b1]; B2 = v.sb_imp[b2]; }
         if (disp_on) { D1 = v.sb_disp[b1]; D2 = v.sb_disp[b2]; }
@@ -266,7 +285,7 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
                 if (productive) {
                     B1.w = __int_as_float(iter); B2.w = __int_as_float(iter);
                     any_imp = true;
-                    if ((st1 || st2) && ss >= 0) atomicMax(&v.sw_imp[(iter & 1) * v.nstatic + ss], static_word(iter, colour));
+                    tag_imp = (st1 || st2) && ss >= 0;
                 }
                 if (!st1) v.sb_imp[b1] = B1;
                 if (!st2) v.sb_imp[b2] = B2;
@@ -289,12 +308,16 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
                 if (productive) {
                     D1.w = __int_as_float(iter); D2.w = __int_as_float(iter);
                     any_disp = true;
-                    if ((st1 || st2) && ss >= 0) atomicMax(&v.sw_disp[(iter & 1) * v.nstatic + ss], static_word(iter, colour));
+                    tag_disp = (st1 || st2) && ss >= 0;
                 }
                 if (!st1) v.sb_disp[b1] = D1;
                 if (!st2) v.sb_disp[b2] = D2;
             }
         }
+        // static-tag updates of this wave, one atomic per distinct static body: every joint on the ground raises the
+        // same word to the same value, and same-address atomics serialise at the L2 (thousands per colour otherwise)
+        if (DO_IMP) wave_tag_update(v.sw_imp + (iter & 1) * v.nstatic, tag_imp, ss, static_word(iter, colour));
+        if (DO_DISP) wave_tag_update(v.sw_disp + (iter & 1) * v.nstatic, tag_disp, ss, static_word(iter, colour));
     }
     // any(productive) of the sweep (ref: Solver.cpp:913, 1017): one store per wave that saw one
     if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
@@ -318,8 +341,8 @@ struct IslandView {
     const int* bodies;                // global body ids, group-local order
     const unsigned* slot_local;       // per slot: local body1 | local body2 << 16
     const unsigned char* slot_colour; // per slot: colour inside the group
-    int* executed;                    // [0] max impulse sweeps run by any group, [1] same for displacement
-    unsigned long long* visits;       // sum over groups of impulse sweeps * joints
+    int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
+    unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
 };
 
@@ -553,9 +576,10 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
     }
     if (tid == 0) {
-        atomicMax(&iv.executed[0], done_imp);
-        atomicMax(&iv.executed[1], done_disp);
-        atomicAdd(iv.visits, (unsigned long long)done_imp * (unsigned long long)d.y);
+        const int slot = group % ISL_STAT_SLOTS;
+        atomicMax(&iv.executed[2 * slot], done_imp);
+        atomicMax(&iv.executed[2 * slot + 1], done_disp);
+        atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
     }
 }
 
@@ -772,9 +796,10 @@ __global__ void __launch_bounds__(64) k_solve_islands_wave(SolverView v, IslandW
         b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
     }
     if (lane == 0) {
-        atomicMax(&iv.executed[0], done_imp);
-        atomicMax(&iv.executed[1], done_disp);
-        atomicAdd(iv.visits, (unsigned long long)done_imp * (unsigned long long)d.y);
+        const int slot = (int)blockIdx.x % ISL_STAT_SLOTS;
+        atomicMax(&iv.executed[2 * slot], done_imp);
+        atomicMax(&iv.executed[2 * slot + 1], done_disp);
+        atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
     }
 }
 
