@@ -106,7 +106,7 @@ int DeviceSolver::launch_fingerprint(const phx_rigid_body* d_bodies, int nb, con
     const int nflags = flags_.p ? 2 * max_iters_ : 0, nsw = sw_.p ? 4 * std::max(nstatic_, 1) : 0;
     hipLaunchKernelGGL(k_clear_control, dim3(std::max(1, std::min(div_up(std::max(nflags, nsw), 256), 64))), dim3(256), 0, stream_,
                        hash_.p, flags_.p, nflags, sw_.p, nsw, isl_stats_.p, isl_visits_.p);
-    hipLaunchKernelGGL(k_topology_hash, dim3(std::min(grid_for(std::max(nj, nb)), 512)), dim3(256), 0, stream_, d_joints, nj, d_bodies, nb, ncp, hash_.p);
+    hipLaunchKernelGGL(k_topology_hash, dim3(std::max(1, std::min(div_up(std::max(nj, nb), HASH_T), HASH_BLOCKS))), dim3(HASH_T), 0, stream_, d_joints, nj, d_bodies, nb, ncp, hash_.p);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }

@@ -92,10 +92,13 @@ __global__ void __launch_bounds__(256) k_clear_control(unsigned long long* hash,
     for (int k = i; k < nsw; k += n) sw[k] = 0u;
 }
 
-__global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
+constexpr int HASH_T = 1024;          // few, fat workgroups: the final same-address atomics serialise (~10 ns each)
+constexpr int HASH_BLOCKS = 128;
+
+__global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
                                                        const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out)
 {
-    __shared__ unsigned long long part[4];
+    __shared__ unsigned long long part[HASH_T / 64];
     unsigned long long h = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
         const phx_contact_joint j = joints[i];
@@ -113,7 +116,8 @@ __global__ void __launch_bounds__(256) k_topology_hash(const phx_contact_joint* 
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
     __syncthreads();
     if (threadIdx.x == 0) {                                        // one device-scope atomic per workgroup
-        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        unsigned long long t = 0;
+        for (int w = 0; w < HASH_T / 64; ++w) t += part[w];
         if (t) atomicAdd(out, t);
     }
 }
