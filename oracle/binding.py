@@ -83,6 +83,10 @@ def lib():
         L.phxo_contact_equals.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         L.phxo_contact_point_make.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]
         L.phxo_project_point_to_line.argtypes = [C.c_float] * 8 + [C.c_void_p]
+        L.phxo_flipsign.restype = C.c_float
+        L.phxo_flipsign.argtypes = [C.c_float, C.c_float, C.c_int]
+        L.phxo_max.restype = C.c_float
+        L.phxo_max.argtypes = [C.c_float, C.c_float]
         L.phxo_aabb_intersects.restype = C.c_int
         L.phxo_aabb_intersects.argtypes = [C.c_void_p, C.c_void_p]
         L.phxo_broadphase_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -163,6 +167,10 @@ def ref_lib():
         R.ref_flipsign1.argtypes = [C.c_float, C.c_float]
         R.ref_max1.restype = C.c_float
         R.ref_max1.argtypes = [C.c_float, C.c_float]
+        for name in ("ref_simd4_lane0", "ref_simd8_lane0"):
+            if hasattr(R, name):
+                getattr(R, name).restype = C.c_float
+                getattr(R, name).argtypes = [C.c_int, C.c_float, C.c_float]
         _ref = R
     return _ref
 

@@ -455,6 +455,10 @@ static inline float flipsign_simd(float x, float y)                             
     xb ^= yb & 0x80000000u; memcpy(&x, &xb, 4); return x;
 }
 
+/* exported so tests can pin the two flipsign forms and max against the reference's scalar / SSE2 / AVX2 wrappers */
+float phxo_flipsign(float x, float y, int simd) { return simd ? flipsign_simd(x, y) : flipsign_scalar(x, y); }
+float phxo_max(float l, float r) { return maxf_ref(l, r); }
+
 /* ref: Solver.cpp:790-798 skip test for one body: lastIteration > iterationIndex - 2.
  * PHXO_STAG_COLOUR_SYNC changes only how a STATIC body's tag is observed: a productive joint of the
  * current iteration is visible only to joints of later colours.  Tags start at -1

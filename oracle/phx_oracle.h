@@ -11,7 +11,8 @@
  *             radixFloat, radixSort3, std::hash<pair<u32,u32>>, RigidBody construction
  *             (mass/inertia/frame/AABB), Geom::RecomputeAABB, Geom::GetSupportPointSet,
  *             Vector2::Rotate, the ContactPoint constructor and ContactPoint::Equals, the plane form
- *             of ProjectPointToLine, AABB2::Intersects, DenseHashSet insert/contains (set
+ *             of ProjectPointToLine, AABB2::Intersects, the scalar / SSE2 / AVX2 flipsign, max and abs wrappers the
+ *             solve loops use, DenseHashSet insert/contains (set
  *             semantics on tombstone-free sequences).
  *   UNPINNED ("parity unpinned"): everything that lives in the reference's .cpp files —
  *             Solver.cpp, Collider.cpp, World.cpp.  Those translation units include
@@ -100,6 +101,8 @@ void     phxo_contact_point_make(phxo_contact_point* out, float p1x, float p1y, 
                                  const phxo_body* b1, const phxo_body* b2);  /* Manifold.h:18-26 */
 void     phxo_project_point_to_line(float px, float py, float qx, float qy, float nx, float ny, float dx, float dy, float out[2]); /* Vector2.h ProjectPointToLine */
 int      phxo_aabb_intersects(const phxo_body* a, const phxo_body* b);      /* AABB2.h:18-24 */
+float    phxo_flipsign(float x, float y, int simd);   /* simd = 0: SIMD_Scalar.h:265-268; 1: SIMD_SSE2.h / SIMD_AVX2.h:272-275 (sign-bit xor) */
+float    phxo_max(float l, float r);                  /* SIMD_Scalar.h:275-278 = the SSE2 / AVX2 max on non-NaN inputs */
 
 /* ---- broadphase stages on raw arrays (Collider.cpp:251-366) ---- */
 void   phxo_broadphase_build(const phxo_body* bodies, size_t n, phxo_sort_entry* keys_unsorted /*n, may be NULL*/,

@@ -143,10 +143,21 @@ void ref_pairset_insert_run(const unsigned* pairs, size_t n, unsigned char* resu
 // scalar SIMD wrapper semantics used by the solve loops (base/SIMD_Scalar.h)
 float ref_flipsign1(float x, float y) { return simd::flipsign(simd::V1f(x), simd::V1f(y)).v; }
 float ref_max1(float l, float r) { return simd::max(simd::V1f(l), simd::V1f(r)).v; }
-#ifdef __AVX2__
-float ref_flipsign8_lane0(float x, float y)
+// the SSE2 / AVX2 wrappers of the same three operations (base/SIMD_SSE2.h, base/SIMD_AVX2.h), lane 0 of a splat:
+// op 0 flipsign(x, y), 1 max(x, y), 2 abs(x)
+float ref_simd4_lane0(int op, float x, float y)
 {
-    simd::V8f r = simd::flipsign(simd::V8f::one(x), simd::V8f::one(y));
+    simd::V4f a = simd::V4f::one(x), b = simd::V4f::one(y);
+    simd::V4f r = op == 0 ? simd::flipsign(a, b) : op == 1 ? simd::max(a, b) : simd::abs(a);
+    float out[4];
+    _mm_storeu_ps(out, r.v);
+    return out[0];
+}
+#ifdef __AVX2__
+float ref_simd8_lane0(int op, float x, float y)
+{
+    simd::V8f a = simd::V8f::one(x), b = simd::V8f::one(y);
+    simd::V8f r = op == 0 ? simd::flipsign(a, b) : op == 1 ? simd::max(a, b) : simd::abs(a);
     float out[8];
     _mm256_storeu_ps(out, r.v);
     return out[0];

@@ -150,6 +150,14 @@ def main():
     out["flipsign_x"], out["flipsign_y"] = fx, fy
     out["flipsign_out"] = np.array([R.ref_flipsign1(float(a), float(b)) for a, b in zip(fx, fy)], dtype=np.float32)
     out["max_out"] = np.array([R.ref_max1(float(a), float(b)) for a, b in zip(fx, fy)], dtype=np.float32)
+    # the SSE2 / AVX2 wrappers of flipsign / max / abs (ref: base/SIMD_SSE2.h, base/SIMD_AVX2.h:260-285): signed zeros,
+    # denormals, infinities; no NaNs (the solve loops never feed one to max)
+    sx = np.array([1.5, -2.0, 0.0, -0.0, 3.0, 1e-4, 1e-40, -1e-40, np.inf, -np.inf, 0.3, -0.3, 7.0, -7.0], dtype=np.float32)
+    sy = np.array([-1.0, 2.0, -0.0, 0.0, -0.0, -1e-9, -1e-45, 1e-45, -np.inf, 2.0, 0.0, -0.0, 7.0, -8.0], dtype=np.float32)
+    out["simd_x"], out["simd_y"] = sx, sy
+    for width, fn in ((4, R.ref_simd4_lane0), (8, R.ref_simd8_lane0)):
+        for op, name in enumerate(("flipsign", "max", "abs")):
+            out["simd%d_%s" % (width, name)] = np.array([fn(op, float(a), float(b)) for a, b in zip(sx, sy)], dtype=np.float32)
 
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "leaf_vectors.npz")
     np.savez_compressed(path, **out)
