@@ -295,6 +295,28 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
         assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
 
 
+def test_bench_step_hook(solver):
+    """phx_solver_bench_hooked calls back once per queued step (bench.py enqueues the per-step all-reduce there); an
+    exception raised in the hook aborts the run and reaches the caller, and the handle stays usable."""
+    state = presolve_state(scenes.stack(8, 30), 3)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, 10, 10)
+    d = [phyx_amd.DeviceArray(a) for a in state]
+    assert solver.stream_ptr() != 0
+    seen = []
+    plain = solver.bench(*d, cfg, 1, 5)
+    hooked = solver.bench(*d, cfg, 1, 5, hook=seen.append)
+    assert seen == [-1, 0, 1, 2, 3, 4]                                  # one warm-up step, then the five timed ones
+    assert hooked.joint_visits == plain.joint_visits and hooked.impulse_iterations == plain.impulse_iterations
+
+    def boom(step):
+        if step == 2:
+            raise RuntimeError("hook failed on purpose")
+    with pytest.raises(RuntimeError, match="on purpose"):
+        solver.bench(*d, cfg, 0, 5, hook=boom)
+    again = solver.bench(*d, cfg, 0, 3)
+    assert again.joint_visits * 5 == plain.joint_visits * 3
+
+
 def _random_state(rng, nb, nj, static_frac, dup_ids=False, hub=0):
     """A synthetic solver input with an arbitrary contact graph: random pairs over nb bodies (a few static), plausible
     small offsets and unit normals, so that the arithmetic stays finite while the topology is nothing like a stack."""

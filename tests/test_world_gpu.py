@@ -90,6 +90,30 @@ def test_island_shards_reproduce_the_unsharded_step(oracle, built_lib):
     assert stitched[moved].tobytes() == ref[moved].tobytes()
 
 
+def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
+    """phx_world_update returns once the step is queued on the world's stream; every getter waits for it.  Two worlds, one
+    read after every step, one only at the end (with an explicit synchronize), must agree bit for bit; the per-phase timers
+    are off unless asked for."""
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 10, 10)
+    eager, lazy = phyx_amd.World(0, gravity=-200.0), phyx_amd.World(0, gravity=-200.0)
+    for w in (eager, lazy):
+        w.add_scene(scenes.stack(12, 40))
+    for _ in range(12):
+        eager.Update(1.0 / 60.0, cfg)
+        _ = eager.bodies, eager.contactJoints, eager.solver.stats()
+        lazy.Update(1.0 / 60.0, cfg)
+    lazy.sync()
+    assert eager.bodies.tobytes() == lazy.bodies.tobytes() and eager.contactJoints.tobytes() == lazy.contactJoints.tobytes()
+    assert eager.counts() == lazy.counts() and eager.counts()[3] > 0
+    assert sum(lazy.phase_ms().values()) == 0.0                       # timers never switched on
+    lazy.set_phase_timing(True)
+    lazy.Update(1.0 / 60.0, cfg)
+    ph = lazy.phase_ms()
+    assert ph["SolveJoints"] > 0.0 and ph["UpdatePairs"] > 0.0
+    eager.Update(1.0 / 60.0, cfg)
+    assert eager.bodies.tobytes() == lazy.bodies.tobytes()            # timing changes nothing but the waits
+
+
 def test_world_api_errors(built_lib):
     w = phyx_amd.World(0)
     with pytest.raises(phyx_amd.PhxError):
