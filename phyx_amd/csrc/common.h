@@ -65,7 +65,7 @@ struct DevBuf {
     int reserve(size_t n)
     {
         if (n <= cap) return PHX_OK;
-        size_t want = n + n / 4 + 64;
+        size_t want = n + n / 2 + 64;      // hipMalloc + hipFree cost ~0.2 ms each and synchronise the device: grow generously
         T* np = nullptr;
         PHX_HIP(hipMalloc(reinterpret_cast<void**>(&np), want * sizeof(T)));
         if (p) (void)hipFree(p);

@@ -313,7 +313,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
     PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
     PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
-    hipLaunchKernelGGL(k_joint_components, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p, (const unsigned*)cc_flags_.p,
+    hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p, (const unsigned*)cc_flags_.p,
                        joint_comp_.p, comp_size_.p);
     // one round trip for the component count AND the sizes: fetch as many sizes as the previous build needed (+25 %)
     unsigned ncomp_u = 0;
