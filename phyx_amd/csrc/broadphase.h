@@ -25,6 +25,8 @@ public:
 private:
     int resize_table(unsigned want_cap);
     int exclusive_scan(unsigned* data, int count, unsigned* total_out);
+    int queue_erase_check(int* erased);
+    int settle_erase_check(int erased);
 
     int device_;
     hipStream_t stream_ = nullptr;
@@ -36,8 +38,9 @@ private:
     DevBuf<unsigned> chunk_count_, chunk_scan_, chunk_raw_, scan_tiles_;
     DevBuf<uint2> new_pairs_, scratch_pairs_;
     DevBuf<phx_rigid_body> st_bodies_;
+    DevBuf<int> erase_count_;                 // pairs really tombstoned since the last settle_erase_check()
     unsigned table_cap_ = 0;
-    long long set_size_ = 0, tombstones_ = 0;
+    long long set_size_ = 0, tombstones_ = 0, erase_unchecked_ = 0;
     int n_ = 0, sorted_ = 0, last_new_ = 0;
     bool have_update_ = false, ms_pending_ = false;
     phx_broadphase_stats stats_{};

@@ -94,16 +94,19 @@ __global__ void __launch_bounds__(256) k_ps_insert(unsigned long long* table, un
 
 __global__ void __launch_bounds__(256) k_ps_erase(unsigned long long* table, unsigned mask, const uint2* __restrict__ pairs, int n, int* erased)
 {
+    int mine = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long k = ((unsigned long long)pairs[i].x << 32) | pairs[i].y;
         unsigned p = ps_hash(k) & mask;
         for (;;) {
             const unsigned long long s = table[p];
-            if (s == k) { table[p] = PS_TOMB; atomicAdd(erased, 1); break; }
+            if (s == k) { table[p] = PS_TOMB; ++mine; break; }
             if (s == PS_EMPTY) break;
             p = (p + 1) & mask;
         }
     }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);      // one atomic per wave
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(erased, mine);
 }
 
 __global__ void __launch_bounds__(256) k_ps_rehash(const unsigned long long* __restrict__ old_table, unsigned old_cap,
@@ -307,7 +310,7 @@ DeviceBroadphase::~DeviceBroadphase()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
     hist_.release(); entries_.release(); table_.release(); row_count_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); chunk_raw_.release(); scan_tiles_.release(); small_.release();
-    new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release();
+    new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release(); erase_count_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -320,6 +323,8 @@ int DeviceBroadphase::init()
     PHX_HIP(hipEventCreate(&ev_begin_));
     PHX_HIP(hipEventCreate(&ev_end_));
     PHX_TRY(small_.reserve(16 + 2 * STAT_SLOTS));
+    PHX_TRY(erase_count_.reserve(1));
+    PHX_HIP(hipMemsetAsync(erase_count_.p, 0, sizeof(int), stream_));
     return clear();
 }
 
@@ -354,6 +359,7 @@ int DeviceBroadphase::clear()
     table_cap_ = 0;
     set_size_ = 0;
     tombstones_ = 0;
+    if (erase_unchecked_) { erase_unchecked_ = 0; PHX_HIP(hipMemsetAsync(erase_count_.p, 0, sizeof(int), stream_)); }
     return resize_table(1024);
 }
 
@@ -411,8 +417,11 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         }
         PHX_TRY(exclusive_scan(row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3)));
         PHX_HIP(hipGetLastError());
+        int erased = 0;
+        PHX_TRY(queue_erase_check(&erased));
         PHX_TRY(rb_.add(host_small, small_.p, sizeof host_small, stream_));
         PHX_TRY(rb_.wait(stream_));
+        PHX_TRY(settle_erase_check(erased));
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
         if (needed <= chunk_cap) break;
         // pathological overlap (many rows each spanning thousands of candidates): the chunk list was too short.
@@ -499,15 +508,34 @@ int DeviceBroadphase::erase_pairs_device(const uint2* d_pairs, int count)
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(count >= 0 && (count == 0 || d_pairs), "bad pair list");
     if (!count) return PHX_OK;
-    PHX_HIP(hipMemsetAsync(small_.p + 8, 0, sizeof(unsigned long long), stream_));
-    hipLaunchKernelGGL(k_ps_erase, dim3(grid_for(count)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, d_pairs, count,
-                       reinterpret_cast<int*>(small_.p + 8));
+    hipLaunchKernelGGL(k_ps_erase, dim3(grid_for(count)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, d_pairs, count, erase_count_.p);
     PHX_HIP(hipGetLastError());
-    int erased = 0;
-    PHX_TRY(rb_.add(&erased, small_.p + 8, sizeof(int), stream_));
-    PHX_TRY(rb_.wait(stream_));
-    set_size_ -= erased;
-    tombstones_ += erased;
+    // Booked as if every pair was found (a World only erases pairs it inserted); the device counter says how many really
+    // were, and the difference is settled with the next readback this handle makes anyway (reconcile_erases) — an erase
+    // costs no host round trip of its own.  set_size_ + tombstones_, which sizes the table, is right either way.
+    set_size_ -= count;
+    tombstones_ += count;
+    erase_unchecked_ += count;
+    return PHX_OK;
+}
+
+// queue the read of the device's erase counter with a batch the caller is about to wait for ...
+int DeviceBroadphase::queue_erase_check(int* erased)
+{
+    *erased = 0;
+    if (!erase_unchecked_) return PHX_OK;
+    return rb_.add(erased, erase_count_.p, sizeof(int), stream_);
+}
+
+// ... and settle the books afterwards
+int DeviceBroadphase::settle_erase_check(int erased)
+{
+    if (!erase_unchecked_) return PHX_OK;
+    const long long missing = erase_unchecked_ - erased;             // requested pairs that were not in the set
+    set_size_ += missing;
+    tombstones_ = std::max<long long>(0, tombstones_ - missing);
+    erase_unchecked_ = 0;
+    PHX_HIP(hipMemsetAsync(erase_count_.p, 0, sizeof(int), stream_));
     return PHX_OK;
 }
 
@@ -532,6 +560,12 @@ int DeviceBroadphase::get_stats(phx_broadphase_stats* out)
         PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
         stats_.device_ms = ms;
         ms_pending_ = false;
+    }
+    if (erase_unchecked_) {
+        int erased = 0;
+        PHX_TRY(queue_erase_check(&erased));
+        PHX_TRY(rb_.wait(stream_));
+        PHX_TRY(settle_erase_check(erased));
     }
     *out = stats_;
     out->set_size = (int)set_size_;
