@@ -33,6 +33,19 @@ def stack(nx, ny, x_offset_columns=0):
     return _scene(px, py, np.zeros(n + 1), sx, sy, static)
 
 
+def clique(n, pitch=0.01):
+    """Ground + n boxes of half-size 5x5 dropped almost on top of each other: every box overlaps every other one, so each
+    body carries ~2n joints.  More than 64 colours are needed — the case where the device schedule builder hands over to
+    the host builder — and the narrowphase merges contact points all the time."""
+    px = np.concatenate([[0.0], pitch * np.arange(n)]).astype(np.float32)
+    py = np.concatenate([[0.0], np.full(n, 14.0)]).astype(np.float32)
+    sx = np.concatenate([[100.0], np.full(n, 5.0)]).astype(np.float32)
+    sy = np.concatenate([[10.0], np.full(n, 5.0)]).astype(np.float32)
+    static = np.zeros(n + 1, dtype=bool)
+    static[0] = True
+    return _scene(px, py, np.zeros(n + 1), sx, sy, static)
+
+
 def _splitmix64(state):
     state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
     z = state

@@ -1,5 +1,5 @@
-"""World::Update parity (MI355X): the product World (device broadphase + device solver, host narrowphase /
-contact cache / integrators) against the oracle World, step by step.  The oracle's solver is driven in the
+"""World::Update parity (MI355X): the device-resident World (every stage of the step a HIP kernel) against the oracle
+World, step by step.  The oracle's solver is driven in the
 device's colour order (see test_solver_gpu.py); with that, every byte of every body, manifold, contact
 point and joint must agree after every step."""
 import numpy as np
@@ -38,11 +38,12 @@ def _lockstep(oracle, scene, steps, cfg, check_every=1):
     return pw, ow
 
 
-@pytest.mark.parametrize("name,steps", [("stack", 12), ("tilted", 60), ("falling", 50)])
+@pytest.mark.parametrize("name,steps", [("stack", 12), ("tilted", 60), ("falling", 50), ("clique", 5)])
 @pytest.mark.parametrize("island_mode", [0, 3])
 def test_world_lockstep_bit_exact(oracle, built_lib, name, steps, island_mode):
     scene = {"stack": lambda: scenes.stack(6, 40), "tilted": lambda: scenes.tilted(80),
-             "falling": lambda: scenes.falling(500, width=80.0, ymax=300.0)}[name]()
+             "falling": lambda: scenes.falling(500, width=80.0, ymax=300.0),
+             "clique": lambda: scenes.clique(90)}[name]()                  # > 64 colours: host-builder fallback inside a World
     cfg = Configuration(phyx_amd.SOLVE_SCALAR, island_mode, 15, 15)
     pw, ow = _lockstep(oracle, scene, steps, cfg)
     assert len(ow.joints()) > 0
