@@ -90,3 +90,33 @@ def test_device_world_is_within_the_reference_cross_mode_band(oracle, built_lib,
             b = w.bodies
             dev[k] = (b["pos"].copy(), b["velocity"].copy())
     _check(dev, scalar, avx2)
+
+
+@pytest.mark.gpu
+def test_full_size_200k_boxes_within_the_cross_mode_band(oracle, built_lib):
+    """The same statement at BASELINE config 2's size (200 001 bodies, Single Sloppy, 20 iterations), K = 1..3 steps."""
+    scene = scenes.stack(1000, 200)
+    steps = (1, 2, 3)
+
+    def reference(mode):
+        w = oracle.OracleWorld(-200.0)
+        w.add_scene(scene)
+        out = {}
+        for k in range(1, max(steps) + 1):
+            w.update(DT, mode, oracle.ISLAND_SINGLE, ITERS, ITERS)
+            b = w.bodies()
+            out[k] = (b["pos"].copy(), b["velocity"].copy())
+        return out
+    scalar, avx2 = reference(oracle.SOLVE_SCALAR), reference(oracle.SOLVE_AVX2)
+    w = phyx_amd.World(0, gravity=-200.0)
+    w.add_scene(scene)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, ITERS, ITERS)
+    for k in range(1, max(steps) + 1):
+        w.Update(DT, cfg)
+        b = w.bodies
+        dev = (b["pos"], b["velocity"])
+        band, got = _diff(scalar[k], avx2[k]), _diff(dev, avx2[k])
+        assert np.isfinite(dev[0]["x"]).all() and np.isfinite(dev[1]["y"]).all()
+        assert got[0] <= 2.0 * band[0] + 1e-6 and got[2] <= 2.0 * band[2] + 1e-6, (k, got, band)
+        if k == 1:
+            assert got[0] <= 1e-3 and got[1] <= 0.1 and got[2] <= 0.05, got
