@@ -1,5 +1,5 @@
 """Differential fuzz: random worlds (random sizes, angles, overlaps, several static boxes) stepped in lockstep on the device
-and in the oracle; every byte of bodies / manifolds / joints compared after every step.   usage: fuzz.py [first_seed [count]]"""
+and in the oracle; every byte of bodies / manifolds / joints compared after every step.   usage: fuzz.py [first_seed [count]] [--big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,9 +8,12 @@ from phyx_amd import Configuration
 from oracle import binding as ob
 
 
+BIG = "--big" in sys.argv        # thousands of bodies: many bins, 1024-lane groups, an HBM group once piles form
+
+
 def scene(rng):
-    n = int(rng.integers(20, 700))
-    width = float(rng.uniform(40, 400))
+    n = int(rng.integers(3000, 20000)) if BIG else int(rng.integers(20, 700))
+    width = float(rng.uniform(400, 3000)) if BIG else float(rng.uniform(40, 400))
     px, py, ang, sx, sy, st = [0.0], [0.0], [0.0], [width * 1.5], [10.0], [True]
     for _ in range(int(rng.integers(0, 3))):                  # walls / shelves
         px.append(float(rng.uniform(-width, width))); py.append(float(rng.uniform(20, 200))); ang.append(float(rng.uniform(-0.5, 0.5)))
@@ -25,7 +28,7 @@ def scene(rng):
 def run(seed):
     rng = np.random.default_rng(seed)
     sc = scene(rng)
-    mode = int(rng.integers(0, 4)); iters = int(rng.integers(1, 25)); steps = int(rng.integers(10, 70))
+    mode = int(rng.integers(0, 4)); iters = int(rng.integers(1, 25)); steps = int(rng.integers(10, 40 if BIG else 70))
     cfg = Configuration(int(rng.integers(0, 3)), mode, iters, int(rng.integers(0, 25)))
     pw = phyx_amd.World(0, gravity=-200.0); pw.add_scene(sc)
     ow = ob.OracleWorld(); ow.add_scene(sc)
@@ -40,8 +43,9 @@ def run(seed):
     return True
 
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+first = int(args[0]) if len(args) > 0 else 0
+count = int(args[1]) if len(args) > 1 else 40
 t0 = time.time(); bad = [s for s in range(first, first + count) if not run(s)]
 print("fuzz: %d seeds, %d diverged %s, %.0f s" % (count, len(bad), bad, time.time() - t0))
 sys.exit(1 if bad else 0)
