@@ -73,8 +73,8 @@ int DeviceSolver::init()
     PHX_TRY(hash_.reserve(1));
     PHX_TRY(isl_stats_.reserve(2 * ISL_STAT_SLOTS));
     PHX_TRY(isl_visits_.reserve(ISL_STAT_SLOTS));
-    const char* g = getenv("PHX_NO_GRAPHS");
-    use_graphs_ = !(g && g[0] == '1');
+    const char* g = getenv("PHX_GRAPHS");               // "1": replay the launch sequence from hipGraphs (measured: no gain on the
+    use_graphs_ = g && g[0] == '1';                      // HBM path, 7 us slower per solve on the island path) — off by default
     const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
     gpu_builder_ = !(sb && sb[0] == 'h');
     const char* sp = getenv("PHX_NO_SPECULATION");

@@ -144,7 +144,13 @@ def test_edge_inputs(solver, oracle):
     assert st.colour_count >= 20                                          # the hub serialises its contacts
 
 
-def test_schedule_reuse_and_device_resident_path(solver, oracle):
+def test_schedule_reuse_and_device_resident_path(oracle, built_lib):
+    import os
+    os.environ["PHX_GRAPHS"] = "1"                     # also exercise the optional hipGraph replay of the launch sequence
+    try:
+        solver = phyx_amd.Solver(0)
+    finally:
+        del os.environ["PHX_GRAPHS"]
     state = presolve_state(scenes.stack(10, 100), 3)
     cfg = Configuration(0, 0, 20, 20)
     gb, gj, order, offs, st1 = _device_solve(solver, state, cfg)
