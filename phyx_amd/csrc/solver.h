@@ -104,6 +104,7 @@ private:
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2];
     DevBuf<int> jp_small_;
     bool gpu_builder_ = true;
+    int hash_slot_ = 1;                  // which of the two fingerprint accumulators the solve in flight uses
     unsigned long long* fp_wanted_ = nullptr;   // set by ensure_schedule: deliver the fingerprint with the builder's first readback
     int ncomp_guess_ = 0;               // component count of the previous device build (sizes its readback)
     DevBuf<unsigned> sw_;

@@ -70,7 +70,8 @@ int DeviceSolver::init()
     PHX_HIP(hipEventCreate(&ev_end_));
     PHX_HIP(hipEventCreate(&ev_sweep_begin_));
     PHX_HIP(hipEventCreate(&ev_sweep_end_));
-    PHX_TRY(hash_.reserve(1));
+    PHX_TRY(hash_.reserve(2));
+    PHX_HIP(hipMemsetAsync(hash_.p, 0, 2 * sizeof(unsigned long long), stream_));
     PHX_TRY(isl_stats_.reserve(2 * ISL_STAT_SLOTS));
     PHX_TRY(isl_visits_.reserve(ISL_STAT_SLOTS));
     const char* g = getenv("PHX_GRAPHS");               // "1": replay the launch sequence from hipGraphs (measured: no gain on the
@@ -91,7 +92,7 @@ SolverView DeviceSolver::view() const
 {
     SolverView v{};
     v.nb = nb_; v.nj = nj_; v.ncp = ncp_; v.nstatic = std::max(nstatic_, 1); v.ncolours = sched_.ncolours();
-    v.fingerprint = hash_.p; v.expected_fingerprint = raw_fingerprint_;
+    v.fingerprint = hash_.p + hash_slot_; v.expected_fingerprint = raw_fingerprint_;
     v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = sb_par_.p;
     v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p;
     v.order = order_.p;
@@ -102,11 +103,20 @@ SolverView DeviceSolver::view() const
 
 int DeviceSolver::launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp)
 {
-    // one dispatch clears the fingerprint accumulator and every control word of the solve that follows
-    const int nflags = flags_.p ? 2 * max_iters_ : 0, nsw = sw_.p ? 4 * std::max(nstatic_, 1) : 0;
-    hipLaunchKernelGGL(k_clear_control, dim3(std::max(1, std::min(div_up(std::max(nflags, nsw), 256), 64))), dim3(256), 0, stream_,
-                       hash_.p, flags_.p, nflags, sw_.p, nsw, isl_stats_.p, isl_visits_.p);
-    hipLaunchKernelGGL(k_topology_hash, dim3(std::max(1, std::min(div_up(std::max(nj, nb), HASH_T), HASH_BLOCKS))), dim3(HASH_T), 0, stream_, d_joints, nj, d_bodies, nb, ncp, hash_.p);
+    // the fingerprint kernel is the first kernel of every solve: it also clears the solve's control words and the accumulator
+    // of the next solve's fingerprint (the two accumulators alternate)
+    ControlWords cw{};
+    cw.flags = flags_.p; cw.nflags = flags_.p ? 2 * max_iters_ : 0;
+    cw.sw = sw_.p; cw.nsw = sw_.p ? 4 * std::max(nstatic_, 1) : 0;
+    cw.isl_stats = isl_stats_.p; cw.isl_visits = isl_visits_.p;
+    int slot = hash_slot_ ^ 1;
+    if (use_graphs_) {        // captured graphs have the accumulator's address baked in: one fixed slot, cleared by a memset
+        slot = 0; hash_slot_ = 1;
+        PHX_HIP(hipMemsetAsync(hash_.p, 0, sizeof(unsigned long long), stream_));
+    }
+    hipLaunchKernelGGL(k_topology_hash, dim3(std::max(1, std::min(div_up(std::max(nj, nb), HASH_T), HASH_BLOCKS))), dim3(HASH_T), 0, stream_, d_joints, nj, d_bodies, nb, ncp,
+                       hash_.p + slot, hash_.p + hash_slot_, cw);
+    hash_slot_ = slot;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -127,7 +137,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     const bool device_builder = gpu_builder_ && !(want_islands && wave_islands_);
     if (!(known_changed && device_builder)) {
-        PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
+        PHX_TRY(rb_.add(&fp, hash_.p + hash_slot_, sizeof fp, stream_));
         PHX_TRY(rb_.wait(stream_));
         have_fp = true;
         const unsigned long long mixed = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
@@ -147,7 +157,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         if (st != PHX_OK) { fp_wanted_ = nullptr; return st; }
         if (fp_wanted_) {                              // the builder had nothing to read back (no joints) or bailed out early
             fp_wanted_ = nullptr;
-            PHX_TRY(rb_.add(&fp, hash_.p, sizeof fp, stream_));
+            PHX_TRY(rb_.add(&fp, hash_.p + hash_slot_, sizeof fp, stream_));
             PHX_TRY(rb_.wait(stream_));
         }
         have_fp = true;
@@ -272,7 +282,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
 {
     *fallback = false;
     // the topology fingerprint (already queued on the stream) rides along with the first readback of the build
-    auto with_fingerprint = [&]() -> int { if (fp_wanted_) { PHX_TRY(rb_.add(fp_wanted_, hash_.p, sizeof *fp_wanted_, stream_)); fp_wanted_ = nullptr; } return PHX_OK; };
+    auto with_fingerprint = [&]() -> int { if (fp_wanted_) { PHX_TRY(rb_.add(fp_wanted_, hash_.p + hash_slot_, sizeof *fp_wanted_, stream_)); fp_wanted_ = nullptr; } return PHX_OK; };
     const bool trace = trace_schedule_;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
@@ -515,7 +525,7 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
 {
     const SolverView v = view();
     // (the control words — productive flags, static tags, island counters — were cleared by launch_fingerprint's
-    //  k_clear_control, which every solve runs first)
+    //  fingerprint kernel, which every solve runs first)
     // the HBM group (if any): PrepareBodies for the bodies it touches, PrepareJoints + RefreshJoints over its slots,
     // PreStep colour by colour.  Groups solved in LDS read and write the caller's records directly.
     const int hbm_bodies = sched_.hbm_body_count;
@@ -760,7 +770,7 @@ int DeviceSolver::synchronize()
     if (pending_.active) {
         // one round trip: the speculative solve's fingerprint and its counters together
         unsigned long long fp = 0;
-        PHX_TRY(collect_stats(&fp, hash_.p));
+        PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_));
         const Pending p = pending_;
         pending_.active = false;
         if (fp != raw_fingerprint_) {

@@ -80,24 +80,30 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
 // the island kernel's per-group statistics go to ISL_STAT_SLOTS slots: thousands of same-address atomics would serialise at the L2
 constexpr int ISL_STAT_SLOTS = 64;
 
-// Every per-solve control word in one dispatch (five memsets would be five dispatches on a 0.18 ms step): the fingerprint
-// accumulator, the HBM path's per-sweep 'productive' flags and static-tag words, the island kernel's counters.
-__global__ void __launch_bounds__(256) k_clear_control(unsigned long long* hash, int* flags, int nflags, unsigned* sw, int nsw,
-                                                       int* isl_stats, unsigned long long* isl_visits)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
-    if (i == 0) *hash = 0ull;
-    if (i < ISL_STAT_SLOTS) { isl_visits[i] = 0ull; isl_stats[2 * i] = 0; isl_stats[2 * i + 1] = 0; }
-    for (int k = i; k < nflags; k += n) flags[k] = 0;
-    for (int k = i; k < nsw; k += n) sw[k] = 0u;
-}
+// the per-solve control words: the HBM path's per-sweep 'productive' flags and static-tag words, the island kernel's counters
+struct ControlWords {
+    int* flags; int nflags;
+    unsigned* sw; int nsw;
+    int* isl_stats;
+    unsigned long long* isl_visits;
+};
 
 constexpr int HASH_T = 1024;          // few, fat workgroups: the final same-address atomics serialise (~10 ns each)
 constexpr int HASH_BLOCKS = 128;
 
 __global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
-                                                       const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out)
+                                                       const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out,
+                                                       unsigned long long* next_out, ControlWords cw)
 {
+    // First kernel of every solve, so it also clears that solve's control words and the accumulator the NEXT solve's
+    // fingerprint will use (two accumulators alternate): one dispatch where there used to be five memsets.
+    {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+        if (i == 0) *next_out = 0ull;
+        if (i < ISL_STAT_SLOTS) { cw.isl_visits[i] = 0ull; cw.isl_stats[2 * i] = 0; cw.isl_stats[2 * i + 1] = 0; }
+        for (int k = i; k < cw.nflags; k += n) cw.flags[k] = 0;
+        for (int k = i; k < cw.nsw; k += n) cw.sw[k] = 0u;
+    }
     __shared__ unsigned long long part[HASH_T / 64];
     unsigned long long h = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
