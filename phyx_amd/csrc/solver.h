@@ -90,8 +90,6 @@ private:
     DevBuf<float2> acc_, dd_;
     DevBuf<int> order_, static_slot_, flags_;
     DevBuf<int4> grp_desc_;
-    DevBuf<int2> grp_colours_;
-    DevBuf<int> colour_offsets_;
     DevBuf<int> grp_ncol_, grp_bodies_, isl_stats_, hbm_body_list_;
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;
@@ -128,7 +126,7 @@ private:
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
-    bool use_graphs_ = false, wave_islands_ = false, speculate_ = true, half_state_ = false;
+    bool use_graphs_ = false, speculate_ = true, half_state_ = false;
     bool owns_stream_ = true, no_islands_ = false, trace_schedule_ = false;      // environment knobs, read once in init()
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
     bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }

@@ -42,7 +42,7 @@ DeviceSolver::~DeviceSolver()
     cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); for (int k = 0; k < 3; ++k) jp_best_[k].release();
     jp_used_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
-    hbm_body_list_.release(); grp_colours_.release(); colour_offsets_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
+    hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -83,8 +83,6 @@ int DeviceSolver::init()
     const char* ni = getenv("PHX_NO_ISLANDS");           // "1": ignore island modes, always the HBM colour path (A/B measurements)
     no_islands_ = ni && ni[0] == '1';
     trace_schedule_ = getenv("PHX_TRACE_SCHEDULE") != nullptr;      // print the schedule builders' laps to stderr
-    const char* wv = getenv("PHX_ISLAND_KERNEL");      // "wave" = one wavefront per island (measured 5x slower: a lone wave exposes every instruction latency); default = one 512-lane workgroup per island
-    wave_islands_ = (wv && wv[0] == 'w');
     return PHX_OK;
 }
 
@@ -135,7 +133,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     // Single = one coupled system swept colour by colour out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
-    const bool device_builder = gpu_builder_ && !(want_islands && wave_islands_);
+    const bool device_builder = gpu_builder_;
     if (!(known_changed && device_builder)) {
         PHX_TRY(rb_.add(&fp, hash_.p + hash_slot_, sizeof fp, stream_));
         PHX_TRY(rb_.wait(stream_));
@@ -204,11 +202,10 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     }
     if (want_islands) {
         LdsCaps caps;
-        if (wave_islands_) { caps.max_joints = ISW_J; caps.max_bodies = ISW_B; caps.max_colours = 4096; caps.max_static = ISW_S; }
-        else { caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64; }
+        caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
         LdsCaps big;
         big.max_joints = ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
-        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, wave_islands_ ? nullptr : &big, prio_id.data());
+        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, &big, prio_id.data());
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_, prio_id.data());
     }
@@ -249,11 +246,6 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         PHX_TRY(grp_bodies_.reserve(sched_.group_bodies.size())); PHX_TRY(slot_local_.reserve(lds_slots)); PHX_TRY(slot_colour_.reserve(lds_slots));
         PHX_HIP(hipMemcpyAsync(grp_desc_.p, desc.data(), (size_t)ng * sizeof(int4), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(grp_ncol_.p, ncol.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
-        std::vector<int2> gcol(ng);
-        for (int g = 0; g < ng; ++g) gcol[g] = make_int2(sched_.group_first_colour[g], ncol[g]);
-        PHX_TRY(grp_colours_.reserve(ng)); PHX_TRY(colour_offsets_.reserve(sched_.colour_offsets.size()));
-        PHX_HIP(hipMemcpyAsync(grp_colours_.p, gcol.data(), (size_t)ng * sizeof(int2), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(colour_offsets_.p, sched_.colour_offsets.data(), sched_.colour_offsets.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(grp_bodies_.p, sched_.group_bodies.data(), sched_.group_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_local_.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_colour_.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
@@ -556,18 +548,11 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         iv.first = shard_; iv.stride = shard_count_;
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
-        if (wave_islands_) {
-            IslandWaveView wv{};
-            wv.desc = grp_desc_.p; wv.colours = grp_colours_.p; wv.colour_offsets = colour_offsets_.p; wv.bodies = grp_bodies_.p;
-            wv.slot_local = slot_local_.p; wv.executed = isl_stats_.p; wv.visits = isl_visits_.p;
-            hipLaunchKernelGGL(k_solve_islands_wave, dim3(mine), dim3(64), 0, stream_, v, wv, d_bodies, d_joints, d_cps, ci, pi);
-        } else {
-            const bool big = sched_.lds_lanes > ISL_T;
-            if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-            else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-        }
+        const bool big = sched_.lds_lanes > ISL_T;
+        if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         ++sweep_launches_;
     }
     if (owns_hbm_group()) {

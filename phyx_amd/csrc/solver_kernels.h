@@ -593,226 +593,6 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     }
 }
 
-// ---- island kernel, wave form: ONE WAVEFRONT solves one group, no workgroup barriers -------------------------
-// Same arithmetic and the same schedule as k_solve_islands, different mapping: a group's joints are spread over the
-// 64 lanes colour by colour (lane l takes the l-th joint of the colour, a colour with more than 64 joints takes
-// several passes), the refreshed constants and accumulators live in LDS next to the body velocities, and because the
-// whole group is one wave, consecutive colours are ordered by the wave's in-order LDS pipeline — no s_barrier, no
-// idle waves parked at a barrier.  Four groups per CU (one per SIMD) => 1024 groups in flight on the chip.
-constexpr int ISW_J = 448;     // joints per group
-constexpr int ISW_B = 256;     // bodies per group (static ones first)
-constexpr int ISW_S = 16;      // static bodies per group
-
-__device__ __forceinline__ bool static_productive_w(const unsigned (*sw)[ISW_S], int body, int iter, int colour)
-{
-    if (iter == 0) return true;
-    if ((sw[(iter - 1) & 1][body] >> 16) == (unsigned)iter) return true;
-    const unsigned cur = sw[iter & 1][body];
-    return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
-}
-
-__device__ __forceinline__ void wave_lds_order()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct IslandWaveView {
-    const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
-    const int2* colours;              // per group {first colour index, colour count} into colour_offsets
-    const int* colour_offsets;        // global slot offsets of every colour
-    const int* bodies;                // global body ids, group-local order (static first)
-    const unsigned* slot_local;       // per slot: local body1 | local body2 << 16
-    int* executed;
-    unsigned long long* visits;
-};
-
-__global__ void __launch_bounds__(64) k_solve_islands_wave(SolverView v, IslandWaveView iv, phx_rigid_body* __restrict__ bodies,
-                                                              phx_contact_joint* __restrict__ joints,
-                                                              const phx_contact_point* __restrict__ cps, int ci, int pi)
-{
-    __shared__ float4 c0[ISW_J];          // {n.x, n.y, angN1, angN2}
-    __shared__ float4 c1[ISW_J];          // {angF1, angF2, invMassF, dstVelocity}
-    __shared__ float4 c2[ISW_J];          // {invMassN, dstDisplacingVelocity, local bodies (bits), -}
-    __shared__ float4 ac[ISW_J];          // {accN, accF, accDisplacing, -}
-    __shared__ float4 imp[ISW_B];
-    __shared__ float4 disp[ISW_B];
-    __shared__ float2 par[ISW_B];         // {invMass, invInertia}
-    __shared__ unsigned swi[2][ISW_S];
-    __shared__ unsigned swd[2][ISW_S];
-
-    const int4 d = iv.desc[blockIdx.x];
-    const int2 cr = iv.colours[blockIdx.x];
-    const int lane = threadIdx.x;
-
-    for (int i = lane; i < d.w; i += 64) {                 // PrepareBodies (ref: Solver.cpp:456-480)
-        const phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
-        imp[i] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
-        disp[i] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
-        par[i] = make_float2(b.inv_mass, b.inv_inertia);
-    }
-    if (lane < ISW_S) { swi[0][lane] = 0; swi[1][lane] = 0; swd[0][lane] = 0; swd[1][lane] = 0; }
-    for (int t = lane; t < d.y; t += 64) {                 // PrepareJoints + RefreshJoints (ref: Solver.cpp:509-521, 642-693)
-        const int s = d.x + t;
-        const phx_contact_joint j = joints[v.order[s]];
-        const phx_contact_point& cp = cps[clamp_index(j.contact_point_index, v.ncp)];
-        const float d1x = cp.delta1.x, d1y = cp.delta1.y, d2x = cp.delta2.x, d2y = cp.delta2.y;
-        const float nx = cp.normal.x, ny = cp.normal.y;
-        const phx_rigid_body& r1 = bodies[clamp_index(j.body1, v.nb)];
-        const phx_rigid_body& r2 = bodies[clamp_index(j.body2, v.nb)];
-        const float pt1x = d1x + r1.pos.x, pt1y = d1y + r1.pos.y;
-        const float pt2x = d2x + r2.pos.x, pt2y = d2y + r2.pos.y;
-        const float w2x = pt1x - r2.pos.x, w2y = pt1y - r2.pos.y;
-        const Limiter N = refresh_limiter(nx, ny, d1x, d1y, w2x, w2y, r1.inv_mass, r1.inv_inertia, r2.inv_mass, r2.inv_inertia);
-        const Limiter F = refresh_limiter(-ny, nx, d1x, d1y, w2x, w2y, r1.inv_mass, r1.inv_inertia, r2.inv_mass, r2.inv_inertia);
-        const float depth = (pt2x - pt1x) * nx + (pt2y - pt1y) * ny;
-        const float dst = 0.f;
-        const float dstV = depth < 1.f ? dst - 0.1f : dst;
-        const float dstD = 0.1f * max_ref(0.f, depth - 2.0f * 1.f);
-        c0[t] = make_float4(nx, ny, N.a1, N.a2);
-        c1[t] = make_float4(F.a1, F.a2, F.cim, dstV);
-        c2[t] = make_float4(N.cim, dstD, __uint_as_float(iv.slot_local[s]), 0.f);
-        ac[t] = make_float4(j.normal_accumulated_impulse, j.friction_accumulated_impulse, 0.f, 0.f);
-    }
-    wave_lds_order();
-
-    // PreStepJoints (ref: Solver.cpp:736-750), colour by colour
-    for (int c = 0; c < cr.y; ++c) {
-        const int cb = iv.colour_offsets[cr.x + c] - d.x, ce = iv.colour_offsets[cr.x + c + 1] - d.x;
-        for (int t = cb + lane; t < ce; t += 64) {
-            const float4 a = c0[t], f = c1[t], k = c2[t], acc = ac[t];
-            const unsigned loc = __float_as_uint(k.z);
-            const int l1 = (int)(loc & 0xFFFFu), l2 = (int)(loc >> 16);
-            const float2 q1 = par[l1], q2 = par[l2];
-            const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
-            if (!(q1.x == 0.f && q1.y == 0.f)) {
-                float4 B = imp[l1];
-                B.x += (nx * q1.x) * acc.x; B.y += (ny * q1.x) * acc.x; B.z += (a.z * q1.y) * acc.x;
-                B.x += (tx * q1.x) * acc.y; B.y += (ty * q1.x) * acc.y; B.z += (f.x * q1.y) * acc.y;
-                imp[l1] = B;
-            }
-            if (!(q2.x == 0.f && q2.y == 0.f)) {
-                float4 B = imp[l2];
-                B.x += ((-nx) * q2.x) * acc.x; B.y += ((-ny) * q2.x) * acc.x; B.z += (a.w * q2.y) * acc.x;
-                B.x += ((-tx) * q2.x) * acc.y; B.y += ((-ty) * q2.x) * acc.y; B.z += (f.y * q2.y) * acc.y;
-                imp[l2] = B;
-            }
-        }
-        wave_lds_order();
-    }
-
-    int done_imp = 0, done_disp = 0;
-    bool imp_alive = ci > 0, disp_alive = pi > 0;
-    const int iters = ci > pi ? ci : pi;
-    for (int it = 0; it < iters; ++it) {
-        const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
-        if (!imp_on && !disp_on) break;
-        bool any_imp = false, any_disp = false;
-        for (int c = 0; c < cr.y; ++c) {
-            const int cb = iv.colour_offsets[cr.x + c] - d.x, ce = iv.colour_offsets[cr.x + c + 1] - d.x;
-            for (int t = cb + lane; t < ce; t += 64) {
-                const float4 a = c0[t], k = c2[t];
-                float4 acc = ac[t];
-                const unsigned loc = __float_as_uint(k.z);
-                const int l1 = (int)(loc & 0xFFFFu), l2 = (int)(loc >> 16);
-                const float2 q1 = par[l1], q2 = par[l2];
-                const float im1 = q1.x, ii1 = q1.y, im2 = q2.x, ii2 = q2.y;
-                const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
-                const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
-                bool dirty = false;
-                if (imp_on) {
-                    float4 B1 = imp[l1], B2 = imp[l2];
-                    const bool p1 = st1 ? static_productive_w(swi, l1, it, c) : (__float_as_int(B1.w) > it - 2);
-                    const bool p2 = st2 ? static_productive_w(swi, l2, it, c) : (__float_as_int(B2.w) > it - 2);
-                    if (p1 || p2) {
-                        const float4 f = c1[t];
-                        float dv = f.w;
-                        dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
-                        dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
-                        float dn = dv * k.x;
-                        dn = max_ref(dn, -acc.x);
-                        B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (a.z * ii1) * dn;
-                        B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (a.w * ii2) * dn;
-                        acc.x += dn;
-                        float fv = 0.f;
-                        fv -= tx * B1.x; fv -= ty * B1.y; fv -= f.x * B1.z;
-                        fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= f.y * B2.z;
-                        float df = fv * f.z;
-                        const float force = acc.y + df;
-                        const float limit = acc.x * 0.3f;
-                        const float signed_limit = force < 0.f ? -limit : limit;
-                        const float adjusted = signed_limit - acc.y;
-                        if (fabsf(force) > limit) df = adjusted;
-                        acc.y += df;
-                        B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (f.x * ii1) * df;
-                        B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (f.y * ii2) * df;
-                        dirty = true;
-                        if (max_ref(fabsf(dn), fabsf(df)) > 1e-4f) {
-                            B1.w = __int_as_float(it); B2.w = __int_as_float(it);
-                            any_imp = true;
-                            if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                            if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
-                        }
-                        if (!st1) imp[l1] = B1;
-                        if (!st2) imp[l2] = B2;
-                    }
-                }
-                if (disp_on) {
-                    float4 D1 = disp[l1], D2 = disp[l2];
-                    const bool p1 = st1 ? static_productive_w(swd, l1, it, c) : (__float_as_int(D1.w) > it - 2);
-                    const bool p2 = st2 ? static_productive_w(swd, l2, it, c) : (__float_as_int(D2.w) > it - 2);
-                    if (p1 || p2) {
-                        float dv = k.y;
-                        dv -= nx * D1.x; dv -= ny * D1.y; dv -= a.z * D1.z;
-                        dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= a.w * D2.z;
-                        float di = dv * k.x;
-                        di = max_ref(di, -acc.z);
-                        D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (a.z * ii1) * di;
-                        D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (a.w * ii2) * di;
-                        acc.z += di;
-                        dirty = true;
-                        if (fabsf(di) > 1e-4f) {
-                            D1.w = __int_as_float(it); D2.w = __int_as_float(it);
-                            any_disp = true;
-                            if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
-                            if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
-                        }
-                        if (!st1) disp[l1] = D1;
-                        if (!st2) disp[l2] = D2;
-                    }
-                }
-                if (dirty) ac[t] = acc;
-            }
-            wave_lds_order();
-        }
-        if (imp_on) { done_imp = it + 1; imp_alive = __any(any_imp); }
-        if (disp_on) { done_disp = it + 1; disp_alive = __any(any_disp); }
-    }
-
-    if (*v.fingerprint != v.expected_fingerprint) return;
-    for (int t = lane; t < d.y; t += 64) {                 // FinishJoints (ref: Solver.cpp:543-544)
-        phx_contact_joint& j = joints[v.order[d.x + t]];
-        const float4 acc = ac[t];
-        j.normal_accumulated_impulse = acc.x;
-        j.friction_accumulated_impulse = acc.y;
-    }
-    for (int i = lane; i < d.w; i += 64) {                 // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
-        const float2 q = par[i];
-        if (q.x == 0.f && q.y == 0.f) continue;
-        phx_rigid_body& b = bodies[iv.bodies[d.z + i]];
-        const float4 a = imp[i], e = disp[i];
-        b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
-        b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
-    }
-    if (lane == 0) {
-        const int slot = (int)blockIdx.x % ISL_STAT_SLOTS;
-        atomicMax(&iv.executed[2 * slot], done_imp);
-        atomicMax(&iv.executed[2 * slot + 1], done_disp);
-        atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
-    }
-}
-
 // ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------
 // The two finish kernels (and the island kernel's epilogue) are the only places that write to the caller's
 // arrays.  They commit only if the topology fingerprint computed for THIS call equals the one the schedule was

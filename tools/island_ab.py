@@ -14,4 +14,4 @@ for iters in (0, 1, 2, 5, 20):
     c = Configuration(2, 2, iters, iters)
     r = s.bench(db, dc, dj, c, 3, 10)
     st = s.stats()
-    print(os.environ.get("PHX_ISLAND_KERNEL","wave"), "iters", iters, "sweep_ms/step %.4f"%(r.impulse_kernel_ms/10), "total %.4f"%(r.total_ms/10), "groups", st.lds_islands, "colours", st.colour_count, "imp sweeps", st.impulse_iterations)
+    print("iters", iters, "sweep_ms/step %.4f"%(r.impulse_kernel_ms/10), "total %.4f"%(r.total_ms/10), "groups", st.lds_islands, "colours", st.colour_count, "imp sweeps", st.impulse_iterations)
