@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(256) k_ps_rehash(const unsigned long long* __r
 // entries[i0+l+1+t] in step t, so a wave's loads are contiguous.  Rows whose range exceeds HUB_LEN (the
 // ground box spans every column) are deferred to a workgroup-per-row kernel.
 constexpr int STAT_SLOTS = 64;     // same-address atomics serialise (~10 ns each): 31k of them cost 0.3 ms of a 0.4 ms kernel
+constexpr int ROW_CACHE = 4;        // new pairs remembered per row by the count pass (rows with more are rescanned by the emit pass)
 constexpr int HUB_LEN = 2048;      // rows scanning more candidates than this are cut into chunks
 constexpr int HUB_CHUNK = 2048;    // candidates per chunk = one 256-lane workgroup x 8 tiles
 
@@ -138,6 +139,8 @@ struct SweepView {
     const unsigned long long* table;
     unsigned mask;
     unsigned* row_count;       // new pairs per row
+    unsigned* row_cache;       // count pass: the first ROW_CACHE new partners of every row (index_j)
+    int* cache_overflow;       // set by the count pass if some row found more than ROW_CACHE new pairs
     int4* chunks;              // hub chunks {row, j_begin, j_end, index of the row's first chunk}
     unsigned* chunk_count;     // new pairs per chunk, later: the chunk's base inside its row
     int* n_chunks;
@@ -160,8 +163,11 @@ __device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int 
 // contiguous and L1/L2-resident.  Candidates are fetched four at a time so that four loads are in flight per lane (the
 // loop is latency-bound, not bandwidth-bound: staging the window through LDS was measured and bought nothing).
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
+__global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total)
 {
+    // EMIT = false: the count pass (also remembers each row's first ROW_CACHE new partners).
+    // EMIT = true : rescans ONLY the rows that found more than ROW_CACHE new pairs; all other rows are emitted from the
+    //               cache by k_emit_cached without touching the entries or the pair set again.
     unsigned long long tests = 0, overlaps = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
         const float4 a = v.entries[i];
@@ -183,15 +189,20 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
             }
             continue;
         }
+        const unsigned dst = EMIT ? row_offset[i] : 0u;
+        if (EMIT) {
+            const unsigned next = i + 1 < v.n ? row_offset[i + 1] : total;
+            if (next - dst <= (unsigned)ROW_CACHE) continue;             // emitted from the cache
+        }
         const unsigned ia = v.idx[i];
         unsigned found = 0;
-        const unsigned dst = EMIT ? row_offset[i] : 0u;
         auto test = [&](int j, const float4& b) {
             if (fabsf(b.z - a.z) <= a.w + b.w) {
                 const unsigned ib = v.idx[j];
                 if (!EMIT) ++overlaps;
                 if (!ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | ib)) {
                     if (EMIT) out[dst + found] = make_uint2(ia, ib);
+                    else if (found < (unsigned)ROW_CACHE) v.row_cache[(size_t)i * ROW_CACHE + found] = ib;
                     ++found;
                 }
             }
@@ -216,7 +227,7 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
             }
         }
         const int len = j - i - 1;
-        if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; }
+        if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; if (found > (unsigned)ROW_CACHE) *v.cache_overflow = 1; }
     }
     if (!EMIT) {
         for (int off = 32; off > 0; off >>= 1) { tests += __shfl_down(tests, off); overlaps += __shfl_down(overlaps, off); }
@@ -227,6 +238,18 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
             const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
             if (t) atomicAdd(&v.counters[2 * (blockIdx.x % STAT_SLOTS) + threadIdx.x], t);
         }
+    }
+}
+
+// emit pass for every row with at most ROW_CACHE new pairs: straight from what the count pass remembered
+__global__ void __launch_bounds__(256) k_emit_cached(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
+        const unsigned dst = row_offset[i];
+        const unsigned count = (i + 1 < v.n ? row_offset[i + 1] : total) - dst;
+        if (count == 0 || count > (unsigned)ROW_CACHE) continue;     // nothing new, a hub row (its chunks emit), or a rescanned row
+        const unsigned ia = v.idx[i];
+        for (unsigned k = 0; k < count; ++k) out[dst + k] = make_uint2(ia, v.row_cache[(size_t)i * ROW_CACHE + k]);
     }
 }
 
@@ -309,7 +332,7 @@ DeviceBroadphase::~DeviceBroadphase()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
-    hist_.release(); entries_.release(); table_.release(); row_count_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); chunk_raw_.release(); scan_tiles_.release(); small_.release();
+    hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); chunk_raw_.release(); scan_tiles_.release(); small_.release();
     new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release(); erase_count_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -379,6 +402,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     PHX_TRY(chunk_count_.reserve(chunk_cap));
     PHX_TRY(entries_.reserve(std::max(n, 1)));
     PHX_TRY(row_count_.reserve(std::max(n, 1) + 1));
+    PHX_TRY(row_cache_.reserve((size_t)std::max(n, 1) * ROW_CACHE));
     // keep the table at most half full counting tombstones, before anything reads it
     if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max<long long>(4 * set_size_, 1024)));
 
@@ -396,7 +420,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     // sweep: count -> scan -> emit
     SweepView v{};
     v.entries = entries_.p; v.idx = idx_[src].p; v.n = n; v.table = table_.p; v.mask = table_cap_ - 1;
-    v.row_count = row_count_.p;
+    v.row_count = row_count_.p; v.row_cache = row_cache_.p; v.cache_overflow = reinterpret_cast<int*>(small_.p + 4);
     v.n_chunks = reinterpret_cast<int*>(small_.p + 2);
     v.counters = small_.p + 16;
     unsigned long long host_small[16 + 2 * STAT_SLOTS] = {0};      // [2] chunks needed, [3] new pairs, [16..] statistics slots
@@ -404,7 +428,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     for (int attempt = 0;; ++attempt) {
         v.chunks = chunks_.p; v.chunk_count = chunk_count_.p; v.chunk_cap = chunk_cap;
         chunk_grid = std::min(chunk_cap, 2048);
-        hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
+        hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr, 0u);
         hipLaunchKernelGGL((k_sweep_chunks<false>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
         {   // chunk counts -> per-row bases: scan a copy of the counts, then take differences
             PHX_TRY(scan_tiles_.reserve((size_t)div_up(chunk_cap, SCAN_TILE) + 1));
@@ -443,7 +467,9 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         if ((unsigned long long)(set_size_ + tombstones_ + (long long)total) * 2 > table_cap_)
             PHX_TRY(resize_table((unsigned)std::min<long long>(4ll * (set_size_ + (long long)total), 1ll << 30)));
         v.table = table_.p; v.mask = table_cap_ - 1;
-        hipLaunchKernelGGL((k_sweep_rows<true>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
+        hipLaunchKernelGGL(k_emit_cached, dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p, total);
+        if (host_small[4] & 0xFFFFFFFFull)      // some row found more than ROW_CACHE new pairs: those rows are rescanned
+            hipLaunchKernelGGL((k_sweep_rows<true>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p, total);
         if (host_small[2] & 0xFFFFFFFFull) hipLaunchKernelGGL((k_sweep_chunks<true>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
         // ref: Collider.cpp:313 / :341 — the emitted pairs join the persistent set
         hipLaunchKernelGGL(k_ps_insert, dim3(grid_for((int)total)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)new_pairs_.p, (int)total);
