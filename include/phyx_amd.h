@@ -264,14 +264,18 @@ typedef struct {
 int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_contact_points,
                      int32_t contact_point_count, const void* d_joints, int32_t joint_count,
                      const phx_config* config, int32_t warmup, int32_t steps, phx_bench_result* out);
-/* Same, calling `between_steps(user, step)` on the host right after step `step`'s work has been queued on the handle's
- * stream (phx_solver_stream) and before the next step is queued.  A multi-GPU caller enqueues its per-step exchange
- * there — e.g. an RCCL all-reduce ordered on that stream — so that the steps of all ranks stay in lock step without the
- * host ever waiting inside the timed region.  A nonzero return aborts the run with PHX_ERR_STATE. */
-typedef int (*phx_step_hook)(void* user, int32_t step);
+/* Same, with a host callback around every step so that a multi-GPU caller can keep its ranks in lock step without the host
+ * ever waiting inside the timed region.  hook(user, step, phase) is called
+ *   phase 0  right after step `step` has been queued on the handle's stream (phx_solver_stream): start the per-step
+ *            exchange here, ordered behind the step on that stream (e.g. an asynchronous RCCL all-reduce);
+ *   phase 1  when the rank-local preparation of step `step` (input restore, topology fingerprint) is queued and its sweeps
+ *            are not: make the stream wait for the exchange started after step - 1 here, so the exchange overlaps the
+ *            preparation.  Called once more with step = `steps` after the last step, to drain the last exchange.
+ * Warm-up steps are numbered -warmup .. -1.  A nonzero return aborts the run with PHX_ERR_STATE. */
+typedef int (*phx_step_hook)(void* user, int32_t step, int32_t phase);
 int phx_solver_bench_hooked(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_contact_points,
                             int32_t contact_point_count, const void* d_joints, int32_t joint_count,
-                            const phx_config* config, int32_t warmup, int32_t steps, phx_step_hook between_steps, void* user,
+                            const phx_config* config, int32_t warmup, int32_t steps, phx_step_hook hook, void* user,
                             phx_bench_result* out);
 /* the hipStream_t every launch of this handle goes to (as void*), for callers that order their own work against it */
 void* phx_solver_stream(phx_solver* s);

@@ -44,7 +44,7 @@ class BenchResult(C.Structure):
 _lib = None
 
 _vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
-STEP_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)      # phx_step_hook
+STEP_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32)      # phx_step_hook(user, step, phase)
 _SIGNATURES = {
     "phx_abi_version": (C.c_int, []),
     "phx_last_error": (C.c_char_p, []),

@@ -218,8 +218,9 @@ class Solver:
         return out
 
     def bench(self, d_bodies, d_contact_points, d_joints, configuration, warmup, steps, hook=None):
-        """`steps` solves of the same resident input, queued back to back.  hook(step) (optional) runs on the host after
-        each step has been queued — where a multi-GPU caller enqueues its per-step exchange on stream_ptr()."""
+        """`steps` solves of the same resident input, queued back to back.  hook(step, phase) (optional) runs on the host:
+        phase 0 after step `step` has been queued (start the per-step exchange on stream_ptr()), phase 1 when the local
+        preparation of step `step` is queued and its sweeps are not (make the stream wait for the previous exchange)."""
         cfg = configuration._c()
         res = BenchResult()
         if hook is None:
@@ -228,9 +229,9 @@ class Solver:
             return res
         failure = []
 
-        def _trampoline(_user, step):
+        def _trampoline(_user, step, phase):
             try:
-                hook(int(step))
+                hook(int(step), int(phase))
                 return 0
             except BaseException as e:          # an exception must not unwind through the C frames
                 failure.append(e)

@@ -102,6 +102,9 @@ private:
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2];
     DevBuf<int> jp_small_;
     bool gpu_builder_ = true;
+    phx_step_hook step_hook_ = nullptr;  // bench(): called with phase 1 between a step's local preparation and its sweeps
+    void* step_hook_user_ = nullptr;
+    int step_hook_step_ = 0;
     int hash_slot_ = 1;                  // which of the two fingerprint accumulators the solve in flight uses
     unsigned long long* fp_wanted_ = nullptr;   // set by ensure_schedule: deliver the fingerprint with the builder's first readback
     int ncomp_guess_ = 0;               // component count of the previous device build (sizes its readback)

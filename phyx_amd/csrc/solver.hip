@@ -687,6 +687,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     stats_.island_max_size = split ? sched_.island_max_size : nj;
     stats_.colour_count = sched_.ncolours();
     stats_.lds_islands = sched_.lds_groups;
+    if (step_hook_ && step_hook_(step_hook_user_, step_hook_step_, 1)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
     return enqueue(static_cast<phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_point*>(d_cps), static_cast<phx_contact_joint*>(d_joints), nj, cfg);
 }
 
@@ -872,21 +873,30 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
         if (nj) PHX_HIP(hipMemcpyAsync(snap_joints_.p, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
         return solve_device(snap_bodies_.p, nb, d_cps, ncp, snap_joints_.p, nj, cfg);
     };
+    // the hook's phase 1 fires inside solve_device, between the step's fingerprint and its sweeps
+    struct HookScope {
+        DeviceSolver& s;
+        HookScope(DeviceSolver& s_, phx_step_hook h, void* u) : s(s_) { s.step_hook_ = h; s.step_hook_user_ = u; }
+        ~HookScope() { s.step_hook_ = nullptr; s.step_hook_user_ = nullptr; }
+    } scope(*this, hook, user);
     for (int i = 0; i < warmup; ++i) {
+        step_hook_step_ = i - warmup;
         PHX_TRY(one_step());
-        if (hook && hook(user, i - warmup)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
+        if (hook && hook(user, i - warmup, 0)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
         PHX_TRY(synchronize());
     }
-    if (!steps) return PHX_OK;
+    if (!steps) { if (hook && warmup && hook(user, 0, 1)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; } return PHX_OK; }
     // timed steps are queued back to back; the device never waits for the host between them
     hipEvent_t keep_b = ev_sweep_begin_, keep_e = ev_sweep_end_;
     int st = PHX_OK;
     PHX_HIP(hipEventRecord(bench_events_[2 * steps], stream_));
     for (int i = 0; i < steps && st == PHX_OK; ++i) {
         ev_sweep_begin_ = bench_events_[2 * i]; ev_sweep_end_ = bench_events_[2 * i + 1];
+        step_hook_step_ = i;
         st = one_step();
-        if (st == PHX_OK && hook && hook(user, i)) { set_error("bench: step hook failed"); st = PHX_ERR_STATE; }
+        if (st == PHX_OK && hook && hook(user, i, 0)) { set_error("bench: step hook failed"); st = PHX_ERR_STATE; }
     }
+    if (st == PHX_OK && hook && hook(user, steps, 1)) { set_error("bench: step hook failed"); st = PHX_ERR_STATE; }      // drain the last exchange
     ev_sweep_begin_ = keep_b; ev_sweep_end_ = keep_e;
     PHX_TRY(st);
     PHX_HIP(hipEventRecord(bench_events_[2 * steps + 1], stream_));

@@ -66,19 +66,26 @@ class Group:
         return int(self._flag.item())
 
     def stream_hook(self, stream_ptr):
-        """hook(step) that enqueues the per-step exchange ON THE SOLVER'S OWN STREAM: the 4-byte all-reduce waits for the
-        step queued before it and the next step waits for the all-reduce — on the device; the host never blocks.
-        (gloo has no streams: there the hook is the blocking all-reduce.)"""
+        """hook(step, phase) for Solver.bench: the per-step exchange (a 4-byte all-reduce) lives ON THE SOLVER'S OWN STREAM.
+        Phase 0 (step queued) starts it asynchronously behind the step; phase 1 (the next step's local preparation is
+        queued, its sweeps are not) makes the stream wait for it — so the exchange overlaps the preparation, the sweeps
+        of step s+1 start only after step s of every rank, and the host never blocks.
+        (gloo has no streams: there phase 0 is the blocking all-reduce.)"""
         if self.backend != "nccl":
-            return lambda step: self.step_barrier()
+            return lambda step, phase: self.step_barrier() if phase == 0 else None
         ext = self.torch.cuda.ExternalStream(stream_ptr, device=self.device)
         flag = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
         self.torch.cuda.synchronize(self.device)
+        pending = []
 
-        def hook(step):
+        def hook(step, phase):
             with self.torch.cuda.stream(ext):
-                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
-        self._hook_keep = (ext, flag)
+                if phase == 0:
+                    pending.append(self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, async_op=True))
+                else:
+                    while pending:
+                        pending.pop(0).wait()          # the solver's stream waits for the exchange; the host does not
+        self._hook_keep = (ext, flag, pending)
         return hook
 
     def _reduce(self, x, op):

@@ -20,7 +20,8 @@ WORKER = textwrap.dedent("""
     g.barrier()
     flags = [g.step_barrier() for _ in range(3)]           # the per-step 4-byte all-reduce
     hook = g.stream_hook(0)                                 # bench.py's per-step hook (gloo: the blocking all-reduce)
-    for step in range(3): hook(step)
+    for step in range(3):
+        hook(step, 1); hook(step, 0)
     t = g.reduce_max(1.0 + g.rank)                          # max over ranks (timing)
     units = g.reduce_sum(float(n))                          # whole-job units
     print(json.dumps({"rank": g.rank, "world": g.world_size, "first": first, "n": n, "t": t, "units": units, "flags": flags}))

@@ -310,12 +310,13 @@ def test_bench_step_hook(solver):
     assert solver.stream_ptr() != 0
     seen = []
     plain = solver.bench(*d, cfg, 1, 5)
-    hooked = solver.bench(*d, cfg, 1, 5, hook=seen.append)
-    assert seen == [-1, 0, 1, 2, 3, 4]                                  # one warm-up step, then the five timed ones
+    hooked = solver.bench(*d, cfg, 1, 5, hook=lambda step, phase: seen.append((step, phase)))
+    # every step: phase 1 before its sweeps, phase 0 once it is queued; one warm-up step (-1), five timed ones, a final drain
+    assert seen == [(-1, 1), (-1, 0)] + [(k, p) for k in range(5) for p in (1, 0)] + [(5, 1)]
     assert hooked.joint_visits == plain.joint_visits and hooked.impulse_iterations == plain.impulse_iterations
 
-    def boom(step):
-        if step == 2:
+    def boom(step, phase):
+        if step == 2 and phase == 0:
             raise RuntimeError("hook failed on purpose")
     with pytest.raises(RuntimeError, match="on purpose"):
         solver.bench(*d, cfg, 0, 5, hook=boom)
