@@ -66,7 +66,7 @@ private:
     DevBuf<phx_manifold> d_manifolds_;
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
-    DevBuf<unsigned> flags_, scan_tiles_, counters_;     // counters_: [0] dead/new total, [1] dropped points
+    DevBuf<unsigned> flags_, dead_flags_, scan_tiles_, counters_;     // counters_: [0] dead/new total, [1] dropped points
     Readback rb_;
     bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
     DevBuf<int> mover_pos_;
@@ -78,7 +78,7 @@ World::~World()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
-    flags_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
+    flags_.release(); dead_flags_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
     // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
 
@@ -182,7 +182,7 @@ int World::pack_manifolds()                                                 // r
     const int dead = (int)host[0];
     if (!dead) return PHX_OK;
     PHX_TRY(erased_.reserve(dead));
-    hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, nm, mover_pos_.p);
+    hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, nm, nm, mover_pos_.p);
     hipLaunchKernelGGL(k_pack_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, (const unsigned*)flags_.p,
                        (const unsigned*)counters_.p, (const int*)mover_pos_.p, erased_.p);
     PHX_HIP(hipGetLastError());
@@ -193,40 +193,41 @@ int World::pack_manifolds()                                                 // r
 int World::refresh_contact_joints()                                         // ref: World.cpp:72-149
 {
     PHX_TRY(scratch_for(std::max(nm, nj + 2 * nm)));
+    PHX_TRY(dead_flags_.reserve((size_t)nj + 2));
     if (nj) hipLaunchKernelGGL(k_joints_reset, dim3(wgrid(nj)), dim3(256), 0, stream_, d_joints_.p, nj);
-    int fresh = 0;
+    // One host round trip for both counts.  A joint is dead iff no contact point re-attached it (k_joints_match), which is
+    // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
+    unsigned host[2] = {0, 0};                                              // [0] new joints, [1] dead joints
     if (nm) {
         hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
                            d_joints_.p, flags_.p);
         PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
-        unsigned host = 0;
-        PHX_TRY(rb_.add(&host, counters_.p, sizeof host, stream_));
-        PHX_TRY(rb_.wait(stream_));
-        fresh = (int)host;
-        if (fresh) {
-            joints_changed_ = true;
-            PHX_TRY(d_joints_.reserve_keep((size_t)nj + fresh, nj, stream_));
-            hipLaunchKernelGGL(k_joints_create, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, d_cps_.p, d_joints_.p, nj,
-                               (const unsigned*)flags_.p);
-        }
+        PHX_TRY(rb_.add(&host[0], counters_.p, sizeof(unsigned), stream_));
+    }
+    if (nj) {
+        hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, dead_flags_.p);
+        PHX_TRY(device_exclusive_scan(dead_flags_.p, nj, counters_.p + 1, scan_tiles_.p, stream_));
+        PHX_TRY(rb_.add(&host[1], counters_.p + 1, sizeof(unsigned), stream_));
+    }
+    if (nm || nj) PHX_TRY(rb_.wait(stream_));
+    const int fresh = (int)host[0], dead = (int)host[1], old = nj;
+    if (fresh) {
+        joints_changed_ = true;
+        PHX_TRY(d_joints_.reserve_keep((size_t)nj + fresh, nj, stream_));
+        hipLaunchKernelGGL(k_joints_create, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, d_cps_.p, d_joints_.p, nj,
+                           (const unsigned*)flags_.p);
     }
     const int total = nj + fresh;
-    if (total) {
-        hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(total)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, total, flags_.p);
-        PHX_TRY(device_exclusive_scan(flags_.p, total, counters_.p, scan_tiles_.p, stream_));
-        unsigned host = 0;
-        PHX_TRY(rb_.add(&host, counters_.p, sizeof host, stream_));
-        PHX_TRY(rb_.wait(stream_));
-        const int dead = (int)host;
-        if (dead) {
-            joints_changed_ = true;
-            hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, total, mover_pos_.p);
-            hipLaunchKernelGGL(k_joints_fill, dim3(wgrid(total)), dim3(256), 0, stream_, d_joints_.p, total, (const unsigned*)flags_.p, (const unsigned*)counters_.p,
-                               (const int*)mover_pos_.p);
-        }
-        nj = total - dead;
-        if (nj) hipLaunchKernelGGL(k_joints_publish, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, d_cps_.p);
-    } else nj = 0;
+    if (dead) {                                                             // cleanup (ref: World.cpp:125-143): holes take movers from the tail
+        joints_changed_ = true;
+        PHX_TRY(mover_pos_.reserve((size_t)total + 2));
+        hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)dead_flags_.p, (const unsigned*)(counters_.p + 1), total, old,
+                           mover_pos_.p);
+        hipLaunchKernelGGL(k_joints_fill, dim3(wgrid(total)), dim3(256), 0, stream_, d_joints_.p, total, old, (const unsigned*)dead_flags_.p,
+                           (const unsigned*)(counters_.p + 1), (const int*)mover_pos_.p);
+    }
+    nj = total - dead;
+    if (nj) hipLaunchKernelGGL(k_joints_publish, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, d_cps_.p);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }

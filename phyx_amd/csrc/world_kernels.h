@@ -88,14 +88,17 @@ static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* _
 // ---- hole-filling compaction ---------------------------------------------------------------------------
 // dead_before = exclusive scan of the dead flags; D = total dead; n' = n - D.
 // mover_pos[r] = position of the r-th live element counted from the end (only those at positions >= n').
+// (`n_flagged`: dead_before[] covers positions [0, n_flagged); positions beyond it were appended after the flags were
+//  taken — new joints — and are alive, with every dead element before them)
 static __global__ void __launch_bounds__(256) k_compact_movers(const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
-                                                               int n, int* __restrict__ mover_pos)
+                                                               int n, int n_flagged, int* __restrict__ mover_pos)
 {
     const int D = (int)*dead_total, live = n - D;
     for (int p = live + blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-        const int next = (p + 1 < n) ? (int)dead_before[p + 1] : D;
-        if (next != (int)dead_before[p]) continue;                       // p itself is dead
-        const int dead_after = D - (int)dead_before[p];
+        const int here = p < n_flagged ? (int)dead_before[p] : D;
+        const int next = (p + 1 < n_flagged) ? (int)dead_before[p + 1] : D;
+        if (next != here) continue;                                      // p itself is dead
+        const int dead_after = D - here;
         mover_pos[(n - 1 - p) - dead_after] = p;
     }
 }
@@ -168,13 +171,14 @@ static __global__ void __launch_bounds__(256) k_joints_flag_dead(const phx_conta
 }
 
 // Cleanup (ref: World.cpp:125-143): holes take movers
-static __global__ void __launch_bounds__(256) k_joints_fill(phx_contact_joint* __restrict__ joints, int nj, const unsigned* __restrict__ dead_before,
+static __global__ void __launch_bounds__(256) k_joints_fill(phx_contact_joint* __restrict__ joints, int nj, int n_flagged, const unsigned* __restrict__ dead_before,
                                                             const unsigned* __restrict__ dead_total, const int* __restrict__ mover_pos)
 {
     const int D = (int)*dead_total, live = nj - D;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < live; i += gridDim.x * blockDim.x) {
+        if (i >= n_flagged) continue;                                     // appended after the flags were taken: alive
         const int h = (int)dead_before[i];
-        const int next = (i + 1 < nj) ? (int)dead_before[i + 1] : D;
+        const int next = (i + 1 < n_flagged) ? (int)dead_before[i + 1] : D;
         if (next == h) continue;
         joints[i] = joints[mover_pos[h]];
     }
