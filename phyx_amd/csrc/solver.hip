@@ -295,8 +295,13 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         // Single mode: one coupled system, every joint goes to the HBM group in joint order
         hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
     } else {
-    // 1. connected components
-    // (two hook + compress rounds per host round trip: stacks converge in two, the second one only confirms it)
+    // 1. connected components: two hook + compress rounds (stacks converge in two, the second one only confirms it), and
+    // 2. the components numbered in body order with their joints counted — queued behind them OPTIMISTICALLY: the 'did the
+    //    last round still hook anything' flag comes back in the same round trip as the component count and sizes, and only
+    //    if it is set (deep island graphs) are more rounds run and the numbering redone.
+    unsigned ncomp_u = 0;
+    std::vector<unsigned> comp_size;
+    int guess = 0;
     for (int round = 0;; round += 2) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
         int changed = 0;
@@ -305,25 +310,22 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
             hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
             hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb);
         }
+        hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
+        PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
+        PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
+        hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
+                           (const unsigned*)cc_flags_.p, joint_comp_.p, comp_size_.p);
+        // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
+        guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
+        comp_size.assign(std::max(guess, 1), 0u);
         PHX_TRY(with_fingerprint());
-        PHX_TRY(rb_.add(&changed, sb_small_.p, sizeof changed, stream_));      // did the LAST round still hook anything?
+        PHX_TRY(rb_.add(&changed, sb_small_.p, sizeof changed, stream_));
+        PHX_TRY(rb_.add(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, stream_));
+        PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
         if (!changed) break;
     }
-    lap("components");
-    // 2. number the components in body order, count their joints
-    hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
-    PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
-    PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
-    hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p, (const unsigned*)cc_flags_.p,
-                       joint_comp_.p, comp_size_.p);
-    // one round trip for the component count AND the sizes: fetch as many sizes as the previous build needed (+25 %)
-    unsigned ncomp_u = 0;
-    const int guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
-    std::vector<unsigned> comp_size(std::max(guess, 1));
-    PHX_TRY(rb_.add(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, stream_));
-    PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)guess * sizeof(unsigned), stream_));
-    PHX_TRY(rb_.wait(stream_));
+    lap("components+count");
     const int ncomp = (int)ncomp_u;
     if (ncomp > guess) {
         comp_size.resize(ncomp);
@@ -332,7 +334,6 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     }
     comp_size.resize(std::max(ncomp, 1));
     ncomp_guess_ = ncomp;
-    lap("count");
 
     // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
     //    (identical to schedule.hip::build_island_schedule — ncomp integers of work)
