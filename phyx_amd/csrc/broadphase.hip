@@ -33,9 +33,13 @@ __device__ __forceinline__ unsigned radix_float(float v)
 }
 
 // ref: Collider.cpp:259-265
+// (first kernel of an update: it also clears the update's counters and the hub-chunk counts — two dispatches fewer)
 __global__ void __launch_bounds__(256) k_build_keys(const phx_rigid_body* __restrict__ bodies, int n,
-                                                    unsigned* __restrict__ keys, unsigned* __restrict__ idx)
+                                                    unsigned* __restrict__ keys, unsigned* __restrict__ idx,
+                                                    unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks)
 {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nsmall; i += gridDim.x * blockDim.x) small[i] = 0ull;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) chunk_count[i] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         keys[i] = radix_float(bodies[i].aabb_min.x);
         idx[i] = (unsigned)i;
@@ -407,11 +411,15 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max<long long>(4 * set_size_, 1024)));
 
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
-    PHX_HIP(hipMemsetAsync(small_.p, 0, (16 + 2 * STAT_SLOTS) * sizeof(unsigned long long), stream_));
-    PHX_HIP(hipMemsetAsync(chunk_count_.p, 0, (size_t)chunk_cap * sizeof(unsigned), stream_));
-    if (n == 0) { PHX_HIP(hipEventRecord(ev_end_, stream_)); PHX_HIP(hipStreamSynchronize(stream_)); stats_.set_size = (int)set_size_; have_update_ = true; return PHX_OK; }
+    if (n == 0) {
+        PHX_HIP(hipEventRecord(ev_end_, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+        stats_.candidate_tests = 0; stats_.overlapping_pairs = 0; stats_.new_pairs = 0; last_new_ = 0;
+        stats_.set_size = (int)set_size_; have_update_ = true; ms_pending_ = true;
+        return PHX_OK;
+    }
 
-    hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p);
+    hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap);
     int src = 0;
     PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_.p, stream_, &src));
     sorted_ = src;

@@ -18,9 +18,11 @@
 namespace phx {
 
 // ---- connected components over dynamic bodies --------------------------------------------------------------
+// (`clear`: a word to zero on the way — the 'hooked anything' flag of the first round; saves a memset dispatch)
 static __global__ void __launch_bounds__(256) k_cc_init(const phx_rigid_body* __restrict__ bodies, int nb, int* __restrict__ parent,
-                                                        unsigned char* __restrict__ is_static)
+                                                        unsigned char* __restrict__ is_static, int* __restrict__ clear)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         const bool st = bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f;      // ref: Solver.cpp:304
         is_static[i] = st ? 1 : 0;
@@ -44,8 +46,10 @@ static __global__ void __launch_bounds__(256) k_cc_hook(const phx_contact_joint*
 }
 
 // full path compression: afterwards parent[b] is the representative (smallest label reached so far)
-static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb)
+// (`clear`, if not null: the 'hooked anything' flag, zeroed for the NEXT round's hook — this round's hook has run)
+static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb, int* __restrict__ clear)
 {
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         int p = parent[i];
         if (p < 0) continue;
@@ -54,9 +58,13 @@ static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb)
     }
 }
 
-static __global__ void __launch_bounds__(256) k_cc_root_flags(const int* __restrict__ parent, int nb, unsigned* __restrict__ flags)
+// (also zeroes the per-component joint counters that k_joint_components fills next: nb + 1 words)
+static __global__ void __launch_bounds__(256) k_cc_root_flags(const int* __restrict__ parent, int nb, unsigned* __restrict__ flags, unsigned* __restrict__ comp_size)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) flags[i] = parent[i] == i ? 1u : 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) {
+        if (i < nb) flags[i] = parent[i] == i ? 1u : 0u;
+        comp_size[i] = 0u;
+    }
 }
 
 // joint -> component number (-1 if both bodies are static), and joints per component.
@@ -99,9 +107,11 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
     }
 }
 
+// (also clears the 'a bin was rejected' flag that k_build_bin may raise)
 static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __restrict__ joint_comp, const int* __restrict__ bin_of_comp, int nj, int rest_key,
-                                                               unsigned* __restrict__ keys, unsigned* __restrict__ vals)
+                                                               unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ rejected)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         const int c = joint_comp[j];
         keys[j] = (unsigned)(c < 0 ? rest_key : bin_of_comp[c]);

@@ -286,7 +286,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(sort_scan_.reserve((size_t)div_up(std::max(std::max(nb, nj), RS_BINS * div_up(njs, RS_TILE)), SCAN_TILE) + 2));
     PHX_TRY(order_.reserve(njs));
 
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p);
+    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -305,14 +305,13 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     for (int round = 0;; round += 2) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
         int changed = 0;
+        if (round) PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));        // (the first pair's flag was cleared by k_cc_init)
         for (int k = 0; k < 2; ++k) {
-            PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));
             hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
-            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb);
+            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == 0 ? sb_small_.p : (int*)nullptr);
         }
-        hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p);
+        hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p, comp_size_.p);
         PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
-        PHX_HIP(hipMemsetAsync(comp_size_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
                            (const unsigned*)cc_flags_.p, joint_comp_.p, comp_size_.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
@@ -372,7 +371,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
 
     // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
     hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)bin_of_comp_.p, nj, nbins,
-                       sort_keys_[0].p, sort_vals_[0].p);
+                       sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2);
     int bits = 1;
     while ((1 << bits) <= nbins) ++bits;
     PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_.p, stream_, &where));
@@ -382,7 +381,6 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(grp_desc_.reserve(std::max(nbins, 1))); PHX_TRY(grp_ncol_.reserve(std::max(nbins, 1)));
     PHX_TRY(grp_bodies_.reserve((size_t)std::max(nbins, 1) * cap_bodies));
     PHX_TRY(slot_local_.reserve(std::max(lds_slots, 1))); PHX_TRY(slot_colour_.reserve(std::max(lds_slots, 1)));
-    PHX_HIP(hipMemsetAsync(sb_small_.p + 2, 0, sizeof(int), stream_));
     if (nbins) {
         BinBuildView bv{};
         bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff_.p; bv.joints = d_joints; bv.is_static = cc_static_.p;

@@ -164,7 +164,6 @@ int World::update_manifolds()                                               // r
 {
     if (!nm) return PHX_OK;
     PHX_TRY(scratch_for(nm));
-    PHX_HIP(hipMemsetAsync(counters_.p, 0, 4 * sizeof(unsigned), stream_));
     hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, (const phx_rigid_body*)d_bodies_.p, d_cps_.p,
                        flags_.p, reinterpret_cast<int*>(counters_.p + 1));
     PHX_HIP(hipGetLastError());
@@ -250,7 +249,7 @@ int World::pre_solve(float dt)
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
     auto lap = [&](int phase) { if (!phase_timing) return; (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
-    if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt);   // ref: World.cpp:39-55
+    if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt, counters_.p);   // ref: World.cpp:39-55
     PHX_HIP(hipGetLastError());
     lap(0);
     // the device runs sort and sweep back to back; the host clock cannot split them, so the whole device broadphase

@@ -19,8 +19,10 @@
 
 namespace phx {
 
-static __global__ void __launch_bounds__(256) k_integrate_velocity(phx_rigid_body* __restrict__ bodies, int n, float gravity, float dt)
+// (first kernel of a step: it also clears the step's four counters)
+static __global__ void __launch_bounds__(256) k_integrate_velocity(phx_rigid_body* __restrict__ bodies, int n, float gravity, float dt, unsigned* __restrict__ counters)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         phx_rigid_body& b = bodies[i];
         float ax = b.acceleration.x, ay = b.acceleration.y;
