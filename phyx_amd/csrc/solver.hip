@@ -318,10 +318,11 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
         comp_size.assign(std::max(guess, 1), 0u);
         PHX_TRY(with_fingerprint());
-        PHX_TRY(rb_.add(&changed, sb_small_.p, sizeof changed, stream_));
-        PHX_TRY(rb_.add(&ncomp_u, sb_small_.p + 1, sizeof ncomp_u, stream_));
+        int pair[2] = {0, 0};                              // {changed, component count}: adjacent words, one copy
+        PHX_TRY(rb_.add(pair, sb_small_.p, sizeof pair, stream_));
         PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
+        changed = pair[0]; ncomp_u = (unsigned)pair[1];
         if (!changed) break;
     }
     lap("components+count");

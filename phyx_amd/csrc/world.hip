@@ -201,14 +201,17 @@ int World::refresh_contact_joints()                                         // r
         hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
                            d_joints_.p, flags_.p);
         PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
-        PHX_TRY(rb_.add(&host[0], counters_.p, sizeof(unsigned), stream_));
     }
     if (nj) {
         hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, dead_flags_.p);
         PHX_TRY(device_exclusive_scan(dead_flags_.p, nj, counters_.p + 1, scan_tiles_.p, stream_));
-        PHX_TRY(rb_.add(&host[1], counters_.p + 1, sizeof(unsigned), stream_));
     }
-    if (nm || nj) PHX_TRY(rb_.wait(stream_));
+    if (nm || nj) {                                                         // counters_[0], [1]: adjacent words, one copy
+        PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
+        PHX_TRY(rb_.wait(stream_));
+        if (!nm) host[0] = 0;                                               // (not written this step)
+        if (!nj) host[1] = 0;
+    }
     const int fresh = (int)host[0], dead = (int)host[1], old = nj;
     if (fresh) {
         joints_changed_ = true;
