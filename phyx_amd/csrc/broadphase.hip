@@ -304,17 +304,35 @@ __global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigne
     }
 }
 
-// per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  `scanned` is the exclusive scan of the
-// chunk counts over the whole chunk list; a row's chunks are contiguous, so differences of that scan give both.
-__global__ void __launch_bounds__(256) k_chunk_bases(SweepView v, const unsigned* __restrict__ scanned, const unsigned* __restrict__ counts)
+// per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  A row's chunks are contiguous in the
+// list, so differences of the exclusive scan of the counts give both.  The list is short (the ground row of the 200k-box
+// scene is 98 chunks), so ONE workgroup scans it tile by tile with a running carry and then takes the differences — one
+// dispatch where a copy, a second copy, a scan and a difference kernel used to be four.
+__global__ void __launch_bounds__(1024) k_chunk_bases(SweepView v, unsigned* __restrict__ scanned)
 {
+    __shared__ unsigned lds[16];
+    __shared__ unsigned tot;
     const int total = min(*v.n_chunks, v.chunk_cap);
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
-        const int4 ch = v.chunks[c];
-        v.chunk_count[c] = scanned[c] - scanned[ch.w];                      // base of this chunk inside its row
-        const bool last = (c + 1 == total) || v.chunks[c + 1].x != ch.x;
-        if (last) v.row_count[ch.x] = scanned[c] + counts[c] - scanned[ch.w];
+    unsigned carry = 0;
+    for (int tile = 0; tile < total; tile += 1024) {
+        const int c = tile + (int)threadIdx.x;
+        const unsigned mine = c < total ? v.chunk_count[c] : 0u;
+        const unsigned ex = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
+        if (c < total) scanned[c] = carry + ex;
+        __syncthreads();
+        carry += tot;
+        __syncthreads();
     }
+    __threadfence_block();
+    __syncthreads();
+    for (int c = threadIdx.x; c < total; c += 1024) {
+        const int4 ch = v.chunks[c];
+        const unsigned count = v.chunk_count[c];
+        const bool last = (c + 1 == total) || v.chunks[c + 1].x != ch.x;
+        if (last) v.row_count[ch.x] = scanned[c] + count - scanned[ch.w];
+    }
+    __syncthreads();                                                        // every count has been read: now overwrite them with the bases
+    for (int c = threadIdx.x; c < total; c += 1024) v.chunk_count[c] = scanned[c] - scanned[v.chunks[c].w];
 }
 
 __global__ void __launch_bounds__(256) k_entries_to_aos(const float4* __restrict__ entries, const unsigned* __restrict__ keys,
@@ -336,7 +354,7 @@ DeviceBroadphase::~DeviceBroadphase()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
-    hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); chunk_raw_.release(); scan_tiles_.release(); small_.release();
+    hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); scan_tiles_.release(); small_.release();
     new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release(); erase_count_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -438,15 +456,9 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         chunk_grid = std::min(chunk_cap, 2048);
         hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr, 0u);
         hipLaunchKernelGGL((k_sweep_chunks<false>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
-        {   // chunk counts -> per-row bases: scan a copy of the counts, then take differences
-            PHX_TRY(scan_tiles_.reserve((size_t)div_up(chunk_cap, SCAN_TILE) + 1));
-            PHX_TRY(chunk_scan_.reserve(chunk_cap + 1));
-            PHX_TRY(chunk_raw_.reserve(chunk_cap + 1));
-            PHX_HIP(hipMemcpyAsync(chunk_raw_.p, chunk_count_.p, (size_t)chunk_cap * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-            PHX_HIP(hipMemcpyAsync(chunk_scan_.p, chunk_count_.p, (size_t)chunk_cap * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-            PHX_TRY(exclusive_scan(chunk_scan_.p, chunk_cap, nullptr));
-            hipLaunchKernelGGL(k_chunk_bases, dim3(grid_for(chunk_cap)), dim3(256), 0, stream_, v, (const unsigned*)chunk_scan_.p, (const unsigned*)chunk_raw_.p);
-        }
+        // chunk counts -> per-row bases and the hub rows' totals (one small workgroup)
+        PHX_TRY(chunk_scan_.reserve(chunk_cap + 1));
+        hipLaunchKernelGGL(k_chunk_bases, dim3(1), dim3(1024), 0, stream_, v, chunk_scan_.p);
         PHX_TRY(exclusive_scan(row_count_.p, n, reinterpret_cast<unsigned*>(small_.p + 3)));
         PHX_HIP(hipGetLastError());
         int erased = 0;
