@@ -8,9 +8,14 @@ FinishBodies.  `value` = joint-visits per second (contacts/sec: joints swept, sk
 §8(d)) over the whole step wall time, summed over all ranks; solver iterations/sec is reported next to it.
 
 N=1: workload = BASELINE config 2 (stack(1000,200) = 200 001 bodies, Single Sloppy islands, 20+20 iterations).
-N>1: weak scaling — every rank owns its own slab of 1000 columns (= 1000 islands) of one world N*1000 columns
-wide, solves it on its GPU, and the ranks meet at a 4-byte RCCL all-reduce after every step; no body or joint
-data crosses ranks because islands are body-disjoint.
+N>1: workload = BASELINE config 3 — the SAME 200 001-body world on every rank, Multiple island mode, the schedule's
+groups (islands binned per workgroup) sharded g % N over the ranks; after its solve every rank packs its results,
+ONE all-gather per step (RCCL over xGMI, on the solver's stream) carries them to every other rank, and every rank
+scatters them into its replica (csrc/exchange.h) — so after each step all N replicas hold the whole solved world.
+Strong scaling: total work is fixed.
+
+The K-step timed block (barrier + device sync on both sides) is repeated `--repeats` times and the MEDIAN block is
+reported (20 steps of 0.15 ms are 3 ms: one scheduler hiccup would move a single block by several per cent).
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,8 +31,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHADER_CLOCK_HZ = 2.4e9          # same guide: max clock; cycle figures below are seconds x this
 BYTES_IMPULSE_VISIT = 196        # algorithmic bytes per impulse joint-visit
 BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visit
+# Latency floor of one colour step of the island kernel: LDS read of the two bodies (issue -> use ~64 cycles),
+# the dependent fp32 chain of one joint update that strict operation order leaves (6 subtractions, multiply, max, 2-op body
+# update, 6 subtractions, multiply, add, compare + select, 2-op body update = ~26 dependent ops x ~4 cycles), the LDS
+# write-back (~13 cycles issue for 16 bytes) and one workgroup barrier (~40 cycles)
+COLOUR_STEP_FLOOR_CYCLES = 64 + 26 * 4 + 13 + 40
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the solve kernels from the committed PMC passes (tools/gpu_prof.sh -> tools/pmc_summary.py):
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same script, read side corrected x2 as MI355X_MICROARCH.md §HBM says."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                out = {"file": "profiles/%s_pmc_traffic.json" % tag}
+                for name, k in d.get("kernels", {}).items():
+                    if "k_solve_islands<512" in name:
+                        out["k_solve_islands"] = k["hbm_bytes_per_launch_corrected"]
+                    if "k_solve_colour<true, true>" in name:
+                        out["k_solve_colour"] = k["hbm_bytes_per_launch_corrected"]
+                    if "k_solve_dataflow" in name:
+                        out["k_solve_dataflow"] = k["hbm_bytes_per_launch_corrected"]
+                return out
+            except Exception:
+                pass
+    return {}
 
 
 def main():
@@ -35,12 +68,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--columns", type=int, default=1000, help="stack columns per GPU (1000 x 200 = config 2)")
+    ap.add_argument("--repeats", type=int, default=11, help="timed K-step blocks; the median block is reported")
+    ap.add_argument("--columns", type=int, default=1000, help="stack columns (1000 x 200 = configs 2 and 3)")
     ap.add_argument("--rows", type=int, default=200)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--scene-steps", type=int, default=3, help="world steps run before the solver input is captured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed Single-mode comparison run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed side measurements (Single mode, live topology, other configs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one rank")
     ap.add_argument("--backend", default="nccl")
@@ -49,7 +83,7 @@ def main():
     from phyx_amd import dist as pdist
     group = pdist.init(args.gpus, backend=args.backend, force=args.force_dist)
     rank, world = group.rank, group.world_size
-    device = group.local_rank
+    device = group.local_rank if getattr(group, "backend", "nccl") == "nccl" else 0
 
     import phyx_amd
     from phyx_amd import scenes, Configuration
@@ -59,9 +93,8 @@ def main():
     island_mode = phyx_amd.ISLAND_SINGLE_SLOPPY if world == 1 else phyx_amd.ISLAND_MULTIPLE
     cfg = Configuration(phyx_amd.SOLVE_AVX2, island_mode, args.iters, args.iters)
 
-    # ---- scene: this rank's slab of the wide world, brought to a settled contact state by the product World
-    first_col, ncols = pdist.shard_columns(args.columns * world, rank, world)
-    scene = scenes.stack(ncols, args.rows, x_offset_columns=first_col)
+    # ---- scene: the same world on every rank, brought to a settled contact state by the product World
+    scene = scenes.stack(args.columns, args.rows)
     world_obj = phyx_amd.World(device, gravity=-200.0)
     world_obj.add_scene(scene)
     for _ in range(args.scene_steps):
@@ -72,110 +105,200 @@ def main():
 
     solver = phyx_amd.Solver(device)
     d_bodies, d_cps, d_joints = (phyx_amd.DeviceArray(a, device) for a in (bodies, cps, joints))
+    xch = None
+    if world > 1:
+        solver.set_shard(rank, world)
+        xch = group.exchange(solver, pdist.Exchange.capacity_for(nb, nj) // 2)
+    hook = xch.hook() if xch else None
 
-    hook = group.stream_hook(solver.stream_ptr())
-
-    def run(config, warmup, steps):
-        """`steps` timed solves of the resident input under `config`; returns wall seconds + HIP-event totals."""
-        for _ in range(max(warmup, 1)):                               # untimed: builds the schedule, captures graphs
-            solver.bench(d_bodies, d_cps, d_joints, config, 0, 1, hook=hook)
-        group.barrier()
-        solver.synchronize()
-        t0 = time.perf_counter()
-        # each step: restore the input, one full SolveJoints, then (N > 1) the per-step 4-byte RCCL all-reduce, enqueued on the
-        # solver's stream so that step s+1 of every rank starts only after step s of all ranks — ordered on the device, the
-        # host queues the K steps back to back inside one library call
-        r = solver.bench(d_bodies, d_cps, d_joints, config, 0, steps, hook=hook)
-        tot = dict(total_ms=r.total_ms, sweep_ms=r.impulse_kernel_ms, launches=r.impulse_launches, visits=r.joint_visits,
-                   iterations=r.impulse_iterations)
-        solver.synchronize()
-        group.barrier()
-        tot["elapsed"] = time.perf_counter() - t0
-        tot["stats"] = solver.stats()
+    def run(config, warmup, steps, repeats, slv=solver, hk=hook):
+        """`repeats` timed blocks of `steps` solves of the resident input under `config`; returns the median block."""
+        for _ in range(max(warmup, 1)):                               # untimed: builds the schedule
+            slv.bench(d_bodies, d_cps, d_joints, config, 0, 1, hook=hk)
+        blocks = []
+        for _ in range(max(repeats, 1)):
+            group.barrier()
+            slv.synchronize()
+            t0 = time.perf_counter()
+            # each step: restore the input, one full SolveJoints of this rank's groups, then (N > 1) pack -> all-gather ->
+            # unpack, all queued on the solver's stream; the host queues the K steps back to back inside one library call
+            r = slv.bench(d_bodies, d_cps, d_joints, config, 0, steps, hook=hk)
+            slv.synchronize()
+            group.barrier()
+            el = time.perf_counter() - t0
+            blocks.append(dict(elapsed=el, total_ms=r.total_ms, sweep_ms=r.impulse_kernel_ms, launches=r.impulse_launches,
+                               visits=r.joint_visits, iterations=r.impulse_iterations))
+        # the block every rank reports must be the same one: rank by the max-over-ranks time
+        times = [group.reduce_max(b["elapsed"]) for b in blocks]
+        mid = int(np.argsort(times)[len(times) // 2])
+        tot = dict(blocks[mid])
+        tot["elapsed_max"] = times[mid]
+        tot["all_blocks_ms_per_step"] = [1e3 * t / max(steps, 1) for t in times]
+        tot["stats"] = slv.stats()
         return tot
 
-    def roofline(tot, steps, kernel):
+    def algorithmic_bytes(tot, steps):
         st = tot["stats"]
         disp_visits = st.displacement_iterations * nj * steps           # upper bound: every group runs the longest count
-        alg_bytes = BYTES_IMPULSE_VISIT * tot["visits"] + BYTES_DISPLACEMENT_VISIT * disp_visits
-        sweep_s = tot["sweep_ms"] * 1e-3
-        achieved = alg_bytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
-        return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "launches": tot["launches"], "avg_launch_us": 1e3 * tot["sweep_ms"] / max(tot["launches"], 1),
-                "algorithmic_bytes_per_launch": alg_bytes / max(tot["launches"], 1)}
+        return BYTES_IMPULSE_VISIT * tot["visits"] + BYTES_DISPLACEMENT_VISIT * disp_visits
 
-    # ---- timed region: exactly K steps of config 2, barrier + device sync on both sides (inside run())
-    main_tot = run(cfg, args.warmup, args.steps)
+    # ---- timed region: K steps, barrier + device sync on both sides (inside run()), median of `repeats` blocks
+    main_tot = run(cfg, args.warmup, args.steps, args.repeats)
     st = main_tot["stats"]
-    elapsed_max = group.reduce_max(main_tot["elapsed"])
+    elapsed_max = main_tot["elapsed_max"]
     visits_all = group.reduce_sum(main_tot["visits"])
-    iters_all = group.reduce_sum(main_tot["iterations"])
-    joints_all = group.reduce_sum(nj)
-    bodies_all = group.reduce_sum(nb)
+    iters_max = group.reduce_max(main_tot["iterations"])
+    exchange_status = 0
+    if xch:
+        exchange_status = int(group.reduce_max(solver.exchange_status()))
 
-    # ---- secondary (N=1 only, untimed by the driver): strict Single island mode = the HBM colour path
-    single_tot = None
+    traffic = pmc_traffic()
+    extra = {}
+    lds = st.lds_islands > 0
+
+    # ---- the island kernel's phases, measured live: a 0-iteration solve is set-up + PreStep + write-back only
+    phases = None
+    if world == 1 and lds and not args.no_secondary:
+        zero = run(Configuration(phyx_amd.SOLVE_AVX2, island_mode, 0, 0), 2, 10, 3)
+        phases = {"setup_prestep_writeback_us": 1e3 * zero["sweep_ms"] / max(zero["launches"], 1)}
+
+    # ---- secondary (N=1 only, untimed by the driver): strict Single island mode = the general-case (big island) path
+    single_tot = live_tot = None
     if world == 1 and not args.no_secondary:
         single_cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE, args.iters, args.iters)
-        single_tot = run(single_cfg, 2, max(5, args.steps // 2))
+        single_tot = run(single_cfg, 2, max(5, args.steps // 2), 3)
+        # live topology: the schedule is rebuilt inside the timed region on every solve, like the reference rebuilds
+        # PrepareIndices / GatherIslands on every call (ref: Solver.cpp:77, 135)
+        solver.set_schedule_reuse(False)
+        live_tot = run(cfg, 2, args.steps, 3)
+        solver.set_schedule_reuse(True)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed_max / max(args.steps, 1)
-        lds = st.lds_islands > 0
-        roof = roofline(main_tot, args.steps, "k_solve_islands (one workgroup per island, all sweeps in LDS)" if lds
-                        else "k_solve_colour<impulse,displacement>")
-        roof["note"] = ("achieved = ALGORITHMIC bytes (196 B per impulse joint-visit + 136 B per displacement joint-visit, SURVEY.md §8d) "
-                        "over the HIP-event time of the sweep launches. " +
-                        ("The island kernel keeps body state in LDS and joint constants in registers for all sweeps, so its real HBM "
-                         "traffic (`traffic`, PMC) is a small fraction of the algorithmic bytes and `frac` can exceed 1: the kernel is "
-                         "bound by LDS latency + workgroup barriers, not by HBM. The HBM-streaming form of the same sweeps is "
-                         "`extra.single_mode.roofline`." if lds else ""))
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                roof["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+        launches = max(main_tot["launches"], 1)
+        launch_us = 1e3 * main_tot["sweep_ms"] / launches
+        alg = algorithmic_bytes(main_tot, args.steps) / launches
+        kname = "k_solve_islands" if lds else "k_solve_colour"
+        tbytes = traffic.get(kname)
+        roof = {"bound": "hbm",
+                "kernel": "k_solve_islands<512,768> (one workgroup per island group, all sweeps in LDS)" if lds else "k_solve_colour<impulse,displacement>",
+                "achieved": (tbytes / (launch_us * 1e-6) / 1e9) if tbytes else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (tbytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tbytes else None,
+                "traffic": tbytes, "traffic_source": traffic.get("file"),
+                "launches": main_tot["launches"], "avg_launch_us": launch_us,
+                "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / (launch_us * 1e-6) / 1e9,
+                "note": ("achieved / frac = HBM bytes the kernel really moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, `traffic`) over its "
+                         "live HIP-event launch time.  algorithmic_GBps = SURVEY.md §8(d) bytes (196 B per impulse joint-visit, 136 B per "
+                         "displacement joint-visit, no reuse assumed) over the same time; it exceeds the HBM peak because the kernel keeps "
+                         "body state in LDS and joint constants in registers across all sweeps — it is a statement about avoided traffic, "
+                         "not a bandwidth claim.  The kernel is latency-bound: see latency_model.")}
+        if lds:
+            # colour steps on the critical path: the slowest group runs (iterations + PreStep) x its colour count
+            ncol_max = int(world_groups_max_colours(solver))
+            steps_crit = ncol_max * (st.impulse_iterations + 1)
+            model = {"colour_steps_on_critical_path": steps_crit, "colours_of_the_slowest_group": ncol_max,
+                     "floor_cycles_per_colour_step": COLOUR_STEP_FLOOR_CYCLES,
+                     "floor_what": "LDS read 64 + 26 dependent fp32 ops x 4 + LDS write 13 + barrier 40 cycles"}
+            if phases:
+                sweep_us = max(launch_us - phases["setup_prestep_writeback_us"], 0.0)
+                cyc = sweep_us * 1e-6 * SHADER_CLOCK_HZ / max(ncol_max * st.impulse_iterations, 1)
+                model.update({"sweeps_us": sweep_us, "setup_prestep_writeback_us": phases["setup_prestep_writeback_us"],
+                              "achieved_cycles_per_colour_step": cyc, "frac_of_latency_floor": COLOUR_STEP_FLOOR_CYCLES / cyc if cyc > 0 else None,
+                              "setup_writeback_GBps": (tbytes / (phases["setup_prestep_writeback_us"] * 1e-6) / 1e9) if tbytes else None})
+            roof["latency_model"] = model
         out = {
             "metric": "solver joint-visits/s (contacts/sec) on the 200k-box stack scene; solver iterations/s in extra",
             "value": visits_all / elapsed_max,
             "unit": "joint-visits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("cfg2: stack(%d,%d) = %d bodies / %d joints, Single Sloppy island mode, %d+%d iterations, full SolveJoints "
                                     "per step on HBM-resident inputs" % (args.columns, args.rows, nb, nj, args.iters, args.iters)) if world == 1 else
-                                   ("cfg3 (weak-scaled): Multiple island mode, islands sharded across %d GPUs as slabs of stack(%d,%d) = %d bodies / "
-                                    "%d joints per GPU, %d+%d iterations, full SolveJoints per step on HBM-resident inputs, 4-byte RCCL all-reduce "
-                                    "per step" % (world, args.columns, args.rows, nb, nj, args.iters, args.iters)),
-                       "bodies_total": int(bodies_all), "joints_total": int(joints_all), "colours": st.colour_count,
+                                   ("cfg3: the same stack(%d,%d) = %d bodies / %d joints world on every rank, Multiple island mode, the schedule's "
+                                    "groups sharded g %% %d over the GPUs, %d+%d iterations, full SolveJoints per step on HBM-resident inputs + "
+                                    "pack / all-gather (RCCL) / unpack of the solved bodies and joint impulses every step"
+                                    % (args.columns, args.rows, nb, nj, world, args.iters, args.iters)),
+                       "bodies_total": int(nb), "joints_total": int(nj), "colours": st.colour_count,
                        "lds_islands": st.lds_islands, "graph_replay": st.graph_replay,
                        "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,
-                       "parallelism": "islands sharded by column slab, 1 rank per GPU, per-step 4-byte RCCL all-reduce" if world > 1 else "1 GPU",
+                       "parallelism": ("islands sharded by schedule group, 1 rank per GPU, one all-gather of %d bytes per rank per step"
+                                       % solver.exchange_segment_bytes()) if world > 1 else "1 GPU",
+                       "timed_blocks": args.repeats, "reported_block": "median",
                        "device": info["name"], "compute_units": info["compute_units"]},
-            "extra": {"solver_iterations_per_sec": iters_all / world / elapsed_max,
-                      "contacts_resolved_per_sec": joints_all * args.steps / elapsed_max,
+            "extra": {"solver_iterations_per_sec": iters_max / elapsed_max,
+                      "contacts_resolved_per_sec": nj * args.steps / elapsed_max,
                       "device_ms_per_step": main_tot["total_ms"] / max(args.steps, 1),
                       "sweep_ms_per_step": main_tot["sweep_ms"] / max(args.steps, 1),
+                      "all_blocks_ms_per_step": [round(x, 5) for x in main_tot["all_blocks_ms_per_step"]],
                       "joint_visits_per_sec_sweeps_only": main_tot["visits"] / (main_tot["sweep_ms"] * 1e-3) if main_tot["sweep_ms"] > 0 else None},
             "roofline": roof,
         }
+        if world > 1:
+            out["extra"]["exchange"] = {"segment_bytes_per_rank": solver.exchange_segment_bytes(), "status": exchange_status,
+                                        "what": "6 floats per body + 2 per joint of the rank's groups behind a 32-byte header {serial, status, "
+                                                "topology fingerprint}; status 0 = every rank saw consistent peers in every step"}
+        if live_tot is not None:
+            out["extra"]["live_topology"] = {
+                "what": "same workload, the schedule (connected components, binning, colouring) rebuilt inside the timed region on EVERY "
+                        "solve, as the reference rebuilds PrepareIndices / GatherIslands every call — what a world whose contact graph "
+                        "changes every step pays",
+                "ms_per_step": 1e3 * live_tot["elapsed_max"] / max(args.steps, 1),
+                "joint_visits_per_sec": live_tot["visits"] / live_tot["elapsed_max"]}
         if single_tot is not None:
             k = max(5, args.steps // 2)
             sst = single_tot["stats"]
+            sl = max(single_tot["launches"], 1)
+            s_us = 1e3 * single_tot["sweep_ms"] / sl
+            s_alg = algorithmic_bytes(single_tot, k) / sl
+            skey = "k_solve_dataflow" if sl <= 2 * k else "k_solve_colour"
+            s_tr = traffic.get(skey)
             out["extra"]["single_mode"] = {
-                "what": "same input, island_mode = Single (no island split): colour-by-colour sweeps out of HBM",
-                "ms_per_step": 1e3 * single_tot["elapsed"] / k, "joint_visits_per_sec": single_tot["visits"] / single_tot["elapsed"],
+                "what": "same input, island_mode = Single (no island split: one coupled system, the path every island too big for a workgroup takes)",
+                "ms_per_step": 1e3 * single_tot["elapsed_max"] / k, "joint_visits_per_sec": single_tot["visits"] / single_tot["elapsed_max"],
                 "colours": sst.colour_count, "impulse_sweeps_per_step": sst.impulse_iterations,
-                "roofline": roofline(single_tot, k, "k_solve_colour<impulse,displacement>")}
+                "roofline": {"bound": "hbm", "kernel": skey, "launches": single_tot["launches"], "avg_launch_us": s_us,
+                             "achieved": s_alg / (s_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": s_alg / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": s_alg,
+                             "traffic": s_tr, "traffic_frac": (s_tr / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if s_tr else None}}
         if world == 1 and not args.no_secondary:
+            out["extra"]["cfg3_one_rank_of_n"] = one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run)
             out["extra"]["other_configs"] = other_configs(phyx_amd, scenes, Configuration, device, world_obj, cfg)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bodies, cps, joints, args.iters, args.cpu_seconds)
         print(json.dumps(out))
     group.shutdown()
+
+
+def world_groups_max_colours(solver):
+    """Colours of the schedule group with the most colours (the critical path of the island launch)."""
+    _, offs = solver.schedule()
+    groups, lds = solver.groups()
+    offs = np.asarray(offs)
+    # colour_offsets are slot offsets; a group's colours = the colour boundaries that fall inside its slot range
+    best = 0
+    idx = np.searchsorted(offs, np.asarray(groups))
+    for g in range(lds):
+        best = max(best, int(idx[g + 1] - idx[g]))
+    return best
+
+
+def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run):
+    """What ONE rank of an n-GPU config-3 run spends per step, measured on this GPU: shard 0 of n of the Multiple-mode
+    schedule + pack + (the all-gather replaced by a local copy of the rank's own segment) + unpack.  The RCCL time is not in
+    it; it bounds the strong scaling the driver's multi-GPU run can show."""
+    from phyx_amd import dist as pdist
+    cfg3 = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, args.iters, args.iters)
+    res = {}
+    slv = phyx_amd.Solver(solver.device)
+    xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj) // 2, solver.device)
+    for n in (1, 2, 4, 8):
+        slv.set_shard(0, n)
+        tot = run(cfg3, 2, 10, 3, slv=slv, hk=xch.hook())
+        res["n=%d" % n] = {"ms_per_step": 1e3 * tot["elapsed_max"] / 10, "island_launch_us": 1e3 * tot["sweep_ms"] / max(tot["launches"], 1),
+                           "segment_bytes": slv.exchange_segment_bytes(), "groups": (tot["stats"].lds_islands + n - 1) // n}
+    return res
 
 
 def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
@@ -203,10 +326,12 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     w4.sync()
     t0 = time.perf_counter(); w4.Update(1.0 / 60.0, cfg2); w4.sync(); step4 = time.perf_counter() - t0
     bs = w4.collider.stats()
-    # algorithmic bytes: 112 B per body for key build + radix sort + gather, 20 B per candidate test
+    # algorithmic bytes: 112 B per body for key build + radix sort + gather, 20 B per candidate test.  The sweep
+    # is an L1-resident latency loop (PMC: ~6 % of its algorithmic bytes reach HBM), so this is NOT quoted against the HBM peak.
     alg = 112.0 * w4.counts()[0] + 20.0 * bs.candidate_tests
     res["cfg4_broadphase_1M"] = {"device_ms": bs.device_ms, "candidate_tests": bs.candidate_tests, "new_pairs": bs.new_pairs,
-                                 "algorithmic_GBps": alg / (bs.device_ms * 1e-3) / 1e9, "world_step_ms": 1e3 * step4,
+                                 "candidate_tests_per_sec": bs.candidate_tests / (bs.device_ms * 1e-3),
+                                 "algorithmic_GBps_cache_resident": alg / (bs.device_ms * 1e-3) / 1e9, "world_step_ms": 1e3 * step4,
                                  "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), w4.counts()))}
     del w4
     # cfg 5: 500k boxes tall stack, 50 iterations, fp32 body state

@@ -45,10 +45,15 @@ enum { PHX_ISLAND_SINGLE = 0, PHX_ISLAND_MULTIPLE = 1, PHX_ISLAND_SINGLE_SLOPPY 
 
 /* ref: src/Configuration.h:20-23.  On this backend the wavefront is the SIMD unit, so solve_mode
  * does not select a code path: every mode runs per-joint (scalar, N=1) skip semantics in the
- * device's own colour order.  island_mode picks the schedule: Single* = one coupled system solved
- * colour by colour out of HBM; Multiple* = islands split (GatherIslands semantics) and solved one
- * island per workgroup out of LDS where they fit.  The Sloppy variants are accepted and run the
- * same deterministic schedule (a legal outcome of the reference's racy modes). */
+ * device's own colour order.  island_mode picks the schedule:
+ *   Single                      one coupled system (one group), solved colour by colour out of HBM;
+ *   Multiple, Single Sloppy,    the island-aware schedule: connected components (GatherIslands semantics) binned
+ *   Multiple Sloppy             into workgroup-sized groups solved out of LDS, each with its own early exit and its
+ *                               own copy of the static bodies' tags; components too big for a workgroup go to one
+ *                               trailing group solved out of HBM.
+ * The reference's Sloppy modes promise no order (racy 512-joint batches, ref: src/Solver.cpp:138-139); here
+ * they run that deterministic island-aware schedule — a legal outcome of those modes.  islandCount /
+ * islandMaxSize are published only by the two Multiple modes (1 / joint count otherwise), like the reference. */
 typedef struct {
     int32_t solve_mode;
     int32_t island_mode;
@@ -124,6 +129,37 @@ int phx_solver_set_body_state_bits(phx_solver* s, int32_t bits);
  * lds_count) and leaves every other body and joint untouched.  All ranks must be given the same joints; the union of
  * their results is the unsharded result, bit for bit.  Default 0 / 1 = everything. */
 int phx_solver_set_shard(phx_solver* s, int32_t shard, int32_t shard_count);
+
+/* 1 (default): a solve whose joint topology fingerprint matches the cached schedule reuses it (checked on the device,
+ * see DESIGN.md §4.1).  0: every solve rebuilds its schedule, like the reference rebuilds PrepareIndices / GatherIslands on
+ * every call (ref: src/Solver.cpp:77, 135) — the cost a world whose contact graph changes every step pays. */
+int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on);
+
+/* Post-solve exchange of an island-sharded solve (BASELINE config 3; counterpart of the reference merging every island's
+ * bodies back after its parallel island loop, ref: src/Solver.cpp:86-91, 482-494, 527-547).  Every rank holds a replica
+ * of the inputs and solves only its own groups; afterwards
+ *   phx_solver_exchange_pack     queues kernels that pack this rank's results (6 floats per body, 2 per joint of its
+ *                                groups, behind a 32-byte header) into the send buffer and returns the segment size —
+ *                                the same on every rank, because the layout is a pure function of the schedule;
+ *   the CALLER all-gathers       segment_bytes from every rank's send buffer into the recv buffer (rank r at byte offset
+ *                                r * segment_bytes) on phx_solver_stream() — RCCL over xGMI on a GPU node;
+ *   phx_solver_exchange_unpack   queues kernels that scatter the other ranks' results into this rank's arrays and check
+ *                                every peer's header (step serial, status word, topology fingerprint).
+ * After the unpack all replicas are bit-identical to the unsharded solve.  Buffers are caller-owned device memory
+ * (16-byte aligned; recv holds shard_count segments of segment_capacity_bytes, a multiple of 256).  status_word != 0 in
+ * pack tells the peers that this rank failed earlier in the step.  phx_solver_exchange_status synchronises and returns
+ * the OR of PHX_XCH_* bits seen by the unpacks so far (0 = every exchange was consistent). */
+enum { PHX_XCH_PEER_ERROR = 1, PHX_XCH_SERIAL_MISMATCH = 2, PHX_XCH_TOPOLOGY_MISMATCH = 4, PHX_XCH_BAD_SEGMENT = 8 };
+int    phx_solver_set_exchange_buffers(phx_solver* s, void* d_send, void* d_recv, size_t segment_capacity_bytes);
+int    phx_solver_exchange_pack(phx_solver* s, const void* d_bodies, const void* d_joints, int32_t status_word, size_t* segment_bytes);
+int    phx_solver_exchange_unpack(phx_solver* s, void* d_bodies, void* d_joints);
+int    phx_solver_exchange_status(phx_solver* s, int32_t* status);
+size_t phx_solver_exchange_segment_bytes(phx_solver* s);      /* of the last pack */
+/* Host-only: the segment layout.  group g (body table of group_bodies[g] entries, group_slots[g] joints) belongs to rank
+ * g % shard_count; group_offset_words[g] = 32-bit word offset of its block inside its owner's segment, rank_words[r] = words
+ * rank r actually fills (both optional), *segment_words = the common padded segment length. */
+int    phx_exchange_layout(const int32_t* group_bodies, const int32_t* group_slots, int32_t group_count, int32_t shard_count,
+                           int64_t* group_offset_words, int64_t* rank_words, int64_t* segment_words);
 
 /* results of the last solve (valid after a synchronizing call) — counterparts of
  * Solver::islandCount / islandMaxSize (ref: src/Solver.h:105-106) plus executed sweep counts */
@@ -220,9 +256,19 @@ int  phx_world_add_body(phx_world* w, float px, float py, float angle, float hal
 /* main.cpp:91-93 groundBody->invMass = invInertia = 0 */
 int  phx_world_set_body_static(phx_world* w, int32_t body);
 int  phx_world_set_gravity(phx_world* w, float gravity);            /* ref: World.h:35 */
-/* restrict the solve to the schedule groups g with g % shard_count == shard (phx_solver_set_shard; multi-GPU
- * island sharding; the default 0/1 solves everything).  Bodies of other shards keep their velocities. */
+/* Multi-GPU island sharding: every rank steps a replica of the same world and solves only the schedule groups g with
+ * g % shard_count == shard (phx_solver_set_shard; the default 0/1 solves everything).  A sharded world (shard_count > 1)
+ * steps in two halves around the caller's all-gather (see phx_solver_exchange_pack; the buffers are set on
+ * phx_world_solver(w) with phx_solver_set_exchange_buffers):
+ *   phx_world_step_begin   World::Update up to and including SolveJoints of this rank's groups, then the pack;
+ *   all-gather             of *segment_bytes per rank, send buffer -> recv buffer, on phx_world_stream(w);
+ *   phx_world_step_end     scatter of the other ranks' results, then IntegratePosition.
+ * phx_world_update / phx_world_finish_step refuse to run on a sharded world (PHX_ERR_STATE): without the exchange they
+ * would integrate the other ranks' bodies with unsolved velocities. */
 int  phx_world_set_shard(phx_world* w, int32_t shard, int32_t shard_count);
+int  phx_world_step_begin(phx_world* w, float dt, const phx_config* config, size_t* segment_bytes);
+int  phx_world_step_end(phx_world* w, float dt);
+void* phx_world_stream(phx_world* w);       /* the hipStream_t all of the world's work is queued on */
 int  phx_world_update(phx_world* w, float dt, const phx_config* config);   /* ref: World.cpp:19-37 */
 /* phx_world_update returns once the step is QUEUED on the world's stream (the host waits only where it needs a count
  * to size a launch); every getter synchronises before it reads.  This waits for the device explicitly. */
@@ -271,6 +317,9 @@ int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t body_count, co
  *   phase 1  when the rank-local preparation of step `step` (input restore, topology fingerprint) is queued and its sweeps
  *            are not: make the stream wait for the exchange started after step - 1 here, so the exchange overlaps the
  *            preparation.  Called once more with step = `steps` after the last step, to drain the last exchange.
+ *   phase 2  only when exchange buffers are set (phx_solver_set_exchange_buffers): step `step` is solved and its results
+ *            are packed; run the all-gather of phx_solver_exchange_segment_bytes() on the stream now — the unpack is
+ *            queued right after the hook returns.
  * Warm-up steps are numbered -warmup .. -1.  A nonzero return aborts the run with PHX_ERR_STATE. */
 typedef int (*phx_step_hook)(void* user, int32_t step, int32_t phase);
 int phx_solver_bench_hooked(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_contact_points,
@@ -285,6 +334,12 @@ int phx_device_malloc(int device, size_t bytes, void** out);
 int phx_device_free(int device, void* p);
 int phx_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
 int phx_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
+int phx_memcpy_d2d(int device, void* dst, const void* src, size_t bytes);
+/* the same, ordered on `stream` (a hipStream_t such as phx_solver_stream / phx_world_stream): the host-touching copies
+ * return when the data has arrived, the device-to-device copy returns when it is queued */
+int phx_memcpy_d2h_on(int device, void* dst, const void* src, size_t bytes, void* stream);
+int phx_memcpy_h2d_on(int device, void* dst, const void* src, size_t bytes, void* stream);
+int phx_memcpy_d2d_on(int device, void* dst, const void* src, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,11 +54,25 @@ _SIGNATURES = {
     "phx_device_free": (C.c_int, [C.c_int, _vp]),
     "phx_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t]),
     "phx_memcpy_d2h": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t]),
+    "phx_memcpy_d2d": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t]),
+    "phx_memcpy_d2h_on": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "phx_memcpy_h2d_on": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "phx_memcpy_d2d_on": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "phx_exchange_layout": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(C.c_int64)]),
+    "phx_solver_set_exchange_buffers": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "phx_solver_exchange_pack": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(C.c_size_t)]),
+    "phx_solver_exchange_unpack": (C.c_int, [_vp, _vp, _vp]),
+    "phx_solver_exchange_status": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "phx_solver_exchange_segment_bytes": (C.c_size_t, [_vp]),
+    "phx_world_step_begin": (C.c_int, [_vp, _f32, C.POINTER(Config), C.POINTER(C.c_size_t)]),
+    "phx_world_step_end": (C.c_int, [_vp, _f32]),
+    "phx_world_stream": (C.c_void_p, [_vp]),
     "phx_solver_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "phx_solver_destroy": (None, [_vp]),
     "phx_solver_solve": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
     "phx_solver_solve_device": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
     "phx_solver_synchronize": (C.c_int, [_vp]),
+    "phx_solver_set_schedule_reuse": (C.c_int, [_vp, _i32]),
     "phx_solver_set_shard": (C.c_int, [_vp, _i32, _i32]),
     "phx_solver_set_body_state_bits": (C.c_int, [_vp, _i32]),
     "phx_solver_get_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),

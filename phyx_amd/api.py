@@ -63,6 +63,23 @@ def device_info(device=0):
     return {"name": name.value.decode(), "compute_units": cu.value, "lds_bytes": lds.value, "hbm_bytes": hbm.value}
 
 
+XCH_PEER_ERROR, XCH_SERIAL_MISMATCH, XCH_TOPOLOGY_MISMATCH, XCH_BAD_SEGMENT = 1, 2, 4, 8
+XCH_HEADER_BYTES = 32
+
+
+def exchange_layout(group_bodies, group_slots, shard_count):
+    """Host-only: segment layout of the island-sharded exchange (include/phyx_amd.h: phx_exchange_layout) ->
+    (group_offset_words, rank_words, segment_words)."""
+    L = _lib.load()
+    gb = np.ascontiguousarray(group_bodies, dtype=np.int32)
+    gs = np.ascontiguousarray(group_slots, dtype=np.int32)
+    off = np.zeros(max(len(gb), 1), dtype=np.int64)
+    rw = np.zeros(shard_count, dtype=np.int64)
+    seg = C.c_int64(0)
+    check(L.phx_exchange_layout(_ptr(gb), _ptr(gs), len(gb), shard_count, _ptr(off), _ptr(rw), C.byref(seg)))
+    return off[:len(gb)], rw, seg.value
+
+
 def schedule_priority(priority_id, joint_index):
     """Colouring priority of a joint (higher = coloured earlier); see include/phyx_amd.h."""
     return int(_lib.load().phx_schedule_priority(int(priority_id), int(joint_index)))
@@ -106,6 +123,53 @@ class Configuration:
 
     def _c(self):
         return Config(self.solveMode, self.islandMode, self.contactIterationsCount, self.penetrationIterationsCount)
+
+
+class DeviceBuffer:
+    """A raw HBM allocation of `nbytes` (exchange buffers of a sharded solve when the caller has no torch tensors)."""
+
+    def __init__(self, nbytes, device=0):
+        self.L = _lib.load()
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(self.L.phx_device_malloc(device, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p
+
+    def address(self, offset=0):
+        return C.c_void_p(self.ptr.value + int(offset))
+
+    def to_host(self, nbytes=None, offset=0):
+        n = self.nbytes - offset if nbytes is None else int(nbytes)
+        out = np.zeros(n, dtype=np.uint8)
+        if n:
+            check(self.L.phx_memcpy_d2h(self.device, _ptr(out), self.address(offset), n))
+        return out
+
+    def from_host(self, data, offset=0):
+        a = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        if len(a):
+            check(self.L.phx_memcpy_h2d(self.device, self.address(offset), _ptr(a), len(a)))
+
+    def copy_from(self, other, nbytes, dst_offset=0, src_offset=0, stream=None):
+        """Device-to-device copy; with `stream` (a hipStream_t address) it is queued on that stream instead of blocking."""
+        if not nbytes:
+            return
+        if stream is None:
+            check(self.L.phx_memcpy_d2d(self.device, self.address(dst_offset), other.address(src_offset), int(nbytes)))
+        else:
+            check(self.L.phx_memcpy_d2d_on(self.device, self.address(dst_offset), other.address(src_offset), int(nbytes), C.c_void_p(int(stream))))
+
+    def free(self):
+        if self.ptr:
+            self.L.phx_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceArray:
@@ -185,9 +249,34 @@ class Solver:
         """32 = fp32 solver-side body state (default, the reference's); 16 = the fp16 ablation of BASELINE config 5."""
         check(self.L.phx_solver_set_body_state_bits(self.h, bits))
 
+    def set_schedule_reuse(self, on):
+        """False: rebuild the schedule on every solve (the reference rebuilds its grouping every call)."""
+        check(self.L.phx_solver_set_schedule_reuse(self.h, 1 if on else 0))
+
     def set_shard(self, shard, shard_count):
         """Sweep only the schedule groups g with g % shard_count == shard (multi-GPU island sharding)."""
         check(self.L.phx_solver_set_shard(self.h, shard, shard_count))
+
+    # ---- island-sharded solves: the post-solve exchange (include/phyx_amd.h: phx_solver_exchange_pack) ----
+    def set_exchange_buffers(self, send_ptr, recv_ptr, segment_capacity_bytes):
+        """Caller-owned device buffers (raw addresses): one segment to send, shard_count segments to receive."""
+        check(self.L.phx_solver_set_exchange_buffers(self.h, C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr)), int(segment_capacity_bytes)))
+
+    def exchange_pack(self, d_bodies, d_joints, status_word=0):
+        seg = C.c_size_t(0)
+        check(self.L.phx_solver_exchange_pack(self.h, d_bodies.ptr, d_joints.ptr, int(status_word), C.byref(seg)))
+        return seg.value
+
+    def exchange_unpack(self, d_bodies, d_joints):
+        check(self.L.phx_solver_exchange_unpack(self.h, d_bodies.ptr, d_joints.ptr))
+
+    def exchange_status(self):
+        v = C.c_int32(0)
+        check(self.L.phx_solver_exchange_status(self.h, C.byref(v)))
+        return v.value
+
+    def exchange_segment_bytes(self):
+        return int(self.L.phx_solver_exchange_segment_bytes(self.h))
 
     def stats(self):
         st = SolveStats()
@@ -344,6 +433,21 @@ class World:
     def Update(self, dt, configuration):
         cfg = configuration._c()
         check(self.L.phx_world_update(self.h, dt, C.byref(cfg)))
+
+    def StepBegin(self, dt, configuration):
+        """First half of a SHARDED world's step: everything up to and including SolveJoints of this rank's groups, then
+        the pack.  Returns the segment size in bytes every rank must all-gather (send buffer -> recv buffer)."""
+        cfg = configuration._c()
+        seg = C.c_size_t(0)
+        check(self.L.phx_world_step_begin(self.h, dt, C.byref(cfg), C.byref(seg)))
+        return seg.value
+
+    def StepEnd(self, dt):
+        """Second half: scatter the other ranks' results, IntegratePosition."""
+        check(self.L.phx_world_step_end(self.h, dt))
+
+    def stream_ptr(self):
+        return int(self.L.phx_world_stream(self.h) or 0)
 
     def PreSolve(self, dt):
         """Everything of World::Update that precedes Solver::SolveJoints (ref: World.cpp:25-32)."""

@@ -2,17 +2,23 @@
 
 No CUDA shims, no multi-arch fat binary, one code path.  -ffp-contract=off is part of the numerical
 contract (the kernels must round exactly like the strict-IEEE oracle), not a tuning choice.
+
+Each translation unit is compiled to its own object (in parallel, only when it or a header changed), then linked.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libphyx_amd.so")
-SOURCES = ["runtime.hip", "schedule.hip", "solver.hip", "c_api_solver.hip", "broadphase.hip", "world.hip"]
+SOURCES = ["runtime.hip", "schedule.hip", "solver.hip", "exchange.hip", "dataflow.hip", "c_api_solver.hip", "broadphase.hip", "world.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-result", "-shared"]
+         "-Wall", "-Wno-unused-result"]
+# roctx ranges (phase names of the reference's MICROPROFILE scopes) are resolved at run time with dlopen: no link dependency
+LINK = ["-shared", "-ldl"]
 
 
 def hipcc():
@@ -22,27 +28,55 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _header_time():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(HERE, "..", "include", "phyx_amd.h"), __file__]
+    return max(os.path.getmtime(d) for d in deps)
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "phyx_amd.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _header_time() > t or any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in _sources())
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc()] + FLAGS + ["-o", OUT] + srcs
+def _compile(src, force, verbose):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _header_time()):
+        return obj, ""
+    cmd = [hipcc()] + FLAGS + ["-c", "-o", obj, path]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout)
-        raise RuntimeError("hipcc failed building libphyx_amd.so")
-    if verbose and res.stdout.strip():
-        print(res.stdout)
+        raise RuntimeError("hipcc failed compiling %s" % src)
+    return obj, res.stdout
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(lambda s: _compile(s, force, verbose), _sources()))
+    objs = [o for o, _ in results]
+    log = "".join(t for _, t in results)
+    cmd = [hipcc(), "--offload-arch=gfx950"] + LINK + ["-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout)
+        raise RuntimeError("hipcc failed linking libphyx_amd.so")
+    if verbose and (log + res.stdout).strip():
+        print(log + res.stdout)
     return OUT
 
 

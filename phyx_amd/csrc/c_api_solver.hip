@@ -64,6 +64,13 @@ int phx_solver_set_shard(phx_solver* s, int32_t shard, int32_t count)
     return s->impl.set_shard(shard, count);
 }
 
+int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on)
+{
+    PHX_REQUIRE(s, "null handle");
+    s->impl.set_schedule_reuse(on != 0);
+    return PHX_OK;
+}
+
 int phx_solver_get_groups(phx_solver* s, int32_t* offsets, int32_t cap, int32_t* count, int32_t* lds_count)
 {
     PHX_REQUIRE(s, "null handle");

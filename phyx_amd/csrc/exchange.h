@@ -1,0 +1,161 @@
+// exchange.h — post-solve exchange of an island-sharded solve (BASELINE config 3).
+//
+// Every rank holds a replica of the world, builds the same schedule from the same joints and sweeps only the
+// groups g with g % shard_count == shard (DeviceSolver::set_shard).  The reference merges every island's bodies back
+// into the one body array after its parallel island loop (ref: Solver.cpp:86-91 parallelFor over islands, then
+// FinishBodies :114, 482-494 and FinishJoints :527-547); across GPUs the counterpart is ONE all-gather per step:
+// each rank packs what its groups produced — per body the six solved floats {velocity.xy, angularVelocity,
+// displacingVelocity.xy, displacingAngularVelocity}, per joint the two accumulated impulses — into a contiguous
+// SEGMENT, the segments are all-gathered (RCCL over xGMI by the caller, on the solver's stream), and every rank
+// scatters the other ranks' segments into its own replica.  After that the replicas are bit-identical again and
+// IntegratePosition (ref: World.cpp:57-70) may run on all bodies.
+//
+// Segment of rank r (32-bit words; the layout is a pure function of the schedule, so every rank computes all of it):
+//   [0..7]   header {magic, serial, status, shard, fingerprint lo, fingerprint hi, segment words, 0}
+//   then, for each of its groups g (ascending; the trailing HBM group counts as group lds_groups):
+//            6 words per body of the group's body table (static bodies included: never unpacked),
+//            2 words per slot of the group, the block padded to a multiple of 4 words.
+// All segments are padded to the same length (the longest, rounded up to 64 words) so that one equal-count
+// all-gather moves them; `segment_words` is that common length.
+#pragma once
+
+#include "common.h"
+
+namespace phx {
+
+constexpr int XCH_HEADER_WORDS = 8;
+constexpr unsigned XCH_MAGIC = 0x45584850u;        // "PHXE"
+// status bits accumulated by the unpack check (phx_solver_exchange_status)
+constexpr int XCH_ERR_PEER = 1;          // a peer posted a non-zero status word (it failed before the exchange)
+constexpr int XCH_ERR_SERIAL = 2;        // a peer is at a different step
+constexpr int XCH_ERR_TOPOLOGY = 4;      // a peer solved a different joint topology: the replicas have diverged
+constexpr int XCH_ERR_MAGIC = 8;         // the segment was never written (collective did not run / wrong buffer)
+
+inline long long xch_group_words(int bodies, int slots) { return (6ll * bodies + 2ll * slots + 3) & ~3ll; }
+
+// Pure host function (unit-tested on CPU through phx_exchange_layout): word offset of every group inside its owner's
+// segment (header included) and the common padded segment length.
+inline long long exchange_layout(const int* group_bodies, const int* group_slots, int ngroups, int shard_count, long long* group_offset_words,
+                                 long long* rank_words /* shard_count entries, may be null */)
+{
+    std::vector<long long> used((size_t)shard_count, (long long)XCH_HEADER_WORDS);
+    for (int g = 0; g < ngroups; ++g) {
+        const int r = g % shard_count;
+        if (group_offset_words) group_offset_words[g] = used[r];
+        used[r] += xch_group_words(group_bodies[g], group_slots[g]);
+    }
+    long long longest = XCH_HEADER_WORDS;
+    for (int r = 0; r < shard_count; ++r) { if (rank_words) rank_words[r] = used[r]; longest = std::max(longest, used[r]); }
+    return (longest + 63) & ~63ll;
+}
+
+struct ExchangeView {
+    const int4* desc;          // per LDS group {slot_begin, slot_count, body_begin, body_count}
+    const int* group_bodies;   // body tables of the LDS groups
+    const int* order;          // slot -> joint
+    const long long* xoff;     // per group (HBM group = index lds_groups): word offset inside the owner's segment
+    int lds_groups, shard, shard_count;
+    // the HBM group, if any
+    const int* hbm_bodies; int hbm_body_count, hbm_begin, hbm_end;
+    long long segment_words;   // common padded segment length = stride between ranks in the gathered buffer
+};
+
+// One workgroup per OWNED LDS group (group = shard + blockIdx.x * shard_count): solved fields -> send segment.
+__global__ void __launch_bounds__(256) k_exchange_pack(ExchangeView x, const phx_rigid_body* __restrict__ bodies, const phx_contact_joint* __restrict__ joints,
+                                                       unsigned* __restrict__ send, unsigned serial, unsigned status, unsigned long long fingerprint)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        send[0] = XCH_MAGIC; send[1] = serial; send[2] = status; send[3] = (unsigned)x.shard;
+        send[4] = (unsigned)fingerprint; send[5] = (unsigned)(fingerprint >> 32); send[6] = (unsigned)x.segment_words; send[7] = 0u;
+    }
+    const int g = x.shard + (int)blockIdx.x * x.shard_count;
+    if (g >= x.lds_groups) return;
+    const int4 d = x.desc[g];
+    float* out = reinterpret_cast<float*>(send + x.xoff[g]);
+    for (int i = threadIdx.x; i < d.w; i += blockDim.x) {
+        const phx_rigid_body& b = bodies[x.group_bodies[d.z + i]];
+        float* o = out + 6 * i;
+        o[0] = b.velocity.x; o[1] = b.velocity.y; o[2] = b.angular_velocity;
+        o[3] = b.displacing_velocity.x; o[4] = b.displacing_velocity.y; o[5] = b.displacing_angular_velocity;
+    }
+    float* jo = out + 6 * (size_t)d.w;
+    for (int s = threadIdx.x; s < d.y; s += blockDim.x) {
+        const phx_contact_joint& j = joints[x.order[d.x + s]];
+        jo[2 * s] = j.normal_accumulated_impulse; jo[2 * s + 1] = j.friction_accumulated_impulse;
+    }
+}
+
+// the HBM group of the owning rank (grid-stride)
+__global__ void __launch_bounds__(256) k_exchange_pack_hbm(ExchangeView x, const phx_rigid_body* __restrict__ bodies, const phx_contact_joint* __restrict__ joints,
+                                                           unsigned* __restrict__ send)
+{
+    float* out = reinterpret_cast<float*>(send + x.xoff[x.lds_groups]);
+    const int n = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = t; i < x.hbm_body_count; i += n) {
+        const phx_rigid_body& b = bodies[x.hbm_bodies[i]];
+        float* o = out + 6 * (size_t)i;
+        o[0] = b.velocity.x; o[1] = b.velocity.y; o[2] = b.angular_velocity;
+        o[3] = b.displacing_velocity.x; o[4] = b.displacing_velocity.y; o[5] = b.displacing_angular_velocity;
+    }
+    float* jo = out + 6 * (size_t)x.hbm_body_count;
+    for (int s = t; s < x.hbm_end - x.hbm_begin; s += n) {
+        const phx_contact_joint& j = joints[x.order[x.hbm_begin + s]];
+        jo[2 * (size_t)s] = j.normal_accumulated_impulse; jo[2 * (size_t)s + 1] = j.friction_accumulated_impulse;
+    }
+}
+
+// One workgroup per LDS group; groups of this rank return at once.  Static bodies are never written (their owner never
+// wrote them either, ref: Solver.cpp:562-567 — zero inverse mass leaves the velocity alone).
+// Workgroup 0 also checks every peer's header.
+__global__ void __launch_bounds__(256) k_exchange_unpack(ExchangeView x, phx_rigid_body* __restrict__ bodies, phx_contact_joint* __restrict__ joints,
+                                                         const unsigned* __restrict__ recv, unsigned serial, unsigned long long fingerprint, int* __restrict__ error)
+{
+    if (blockIdx.x == 0 && (int)threadIdx.x < x.shard_count) {
+        const unsigned* h = recv + (size_t)threadIdx.x * x.segment_words;
+        int e = 0;
+        if (h[0] != XCH_MAGIC) e |= XCH_ERR_MAGIC;
+        else {
+            if (h[2] != 0u) e |= XCH_ERR_PEER;
+            if (h[1] != serial) e |= XCH_ERR_SERIAL;
+            if (h[4] != (unsigned)fingerprint || h[5] != (unsigned)(fingerprint >> 32)) e |= XCH_ERR_TOPOLOGY;
+        }
+        if (e) atomicOr(error, e);
+    }
+    const int g = (int)blockIdx.x;
+    if (g >= x.lds_groups || g % x.shard_count == x.shard) return;
+    const int4 d = x.desc[g];
+    const float* in = reinterpret_cast<const float*>(recv + (size_t)(g % x.shard_count) * x.segment_words + x.xoff[g]);
+    for (int i = threadIdx.x; i < d.w; i += blockDim.x) {
+        phx_rigid_body& b = bodies[x.group_bodies[d.z + i]];
+        if (b.inv_mass == 0.f && b.inv_inertia == 0.f) continue;
+        const float* o = in + 6 * i;
+        b.velocity.x = o[0]; b.velocity.y = o[1]; b.angular_velocity = o[2];
+        b.displacing_velocity.x = o[3]; b.displacing_velocity.y = o[4]; b.displacing_angular_velocity = o[5];
+    }
+    const float* ji = in + 6 * (size_t)d.w;
+    for (int s = threadIdx.x; s < d.y; s += blockDim.x) {
+        phx_contact_joint& j = joints[x.order[d.x + s]];
+        j.normal_accumulated_impulse = ji[2 * s]; j.friction_accumulated_impulse = ji[2 * s + 1];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_exchange_unpack_hbm(ExchangeView x, phx_rigid_body* __restrict__ bodies, phx_contact_joint* __restrict__ joints,
+                                                             const unsigned* __restrict__ recv)
+{
+    const float* in = reinterpret_cast<const float*>(recv + (size_t)(x.lds_groups % x.shard_count) * x.segment_words + x.xoff[x.lds_groups]);
+    const int n = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = t; i < x.hbm_body_count; i += n) {
+        phx_rigid_body& b = bodies[x.hbm_bodies[i]];
+        if (b.inv_mass == 0.f && b.inv_inertia == 0.f) continue;
+        const float* o = in + 6 * (size_t)i;
+        b.velocity.x = o[0]; b.velocity.y = o[1]; b.angular_velocity = o[2];
+        b.displacing_velocity.x = o[3]; b.displacing_velocity.y = o[4]; b.displacing_angular_velocity = o[5];
+    }
+    const float* ji = in + 6 * (size_t)x.hbm_body_count;
+    for (int s = t; s < x.hbm_end - x.hbm_begin; s += n) {
+        phx_contact_joint& j = joints[x.order[x.hbm_begin + s]];
+        j.normal_accumulated_impulse = ji[2 * (size_t)s]; j.friction_accumulated_impulse = ji[2 * (size_t)s + 1];
+    }
+}
+
+} // namespace phx

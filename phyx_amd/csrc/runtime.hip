@@ -91,4 +91,36 @@ int phx_memcpy_d2h(int device, void* dst, const void* src, size_t bytes)
     return PHX_OK;
 }
 
+// copies ordered on a caller-named stream (the host returns when the copy is done): for callers that stage device
+// buffers through the host between two pieces of work queued on that stream (gloo transport of the sharded exchange)
+int phx_memcpy_d2h_on(int device, void* dst, const void* src, size_t bytes, void* stream)
+{
+    PHX_TRY(phx::use_device(device));
+    if (bytes) PHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    PHX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PHX_OK;
+}
+
+int phx_memcpy_h2d_on(int device, void* dst, const void* src, size_t bytes, void* stream)
+{
+    PHX_TRY(phx::use_device(device));
+    if (bytes) PHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    PHX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PHX_OK;
+}
+
+int phx_memcpy_d2d_on(int device, void* dst, const void* src, size_t bytes, void* stream)
+{
+    PHX_TRY(phx::use_device(device));
+    if (bytes) PHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return PHX_OK;
+}
+
+int phx_memcpy_d2d(int device, void* dst, const void* src, size_t bytes)
+{
+    PHX_TRY(phx::use_device(device));
+    if (bytes) PHX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return PHX_OK;
+}
+
 } // extern "C"

@@ -42,10 +42,20 @@ public:
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
     int set_body_state_bits(int bits);
     int set_shard(int shard, int count);
+    void set_schedule_reuse(bool on) { reuse_schedule_ = on; }
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
               const phx_config& cfg, int warmup, int steps, phx_bench_result* out, phx_step_hook hook = nullptr, void* user = nullptr);
+
+    // island-sharded solves: pack this rank's results / scatter the other ranks' (exchange.h); the all-gather in between
+    // belongs to the caller (RCCL on stream())
+    int set_exchange_buffers(void* d_send, void* d_recv, size_t segment_capacity_bytes);
+    int exchange_pack(const void* d_bodies, const void* d_joints, size_t* segment_bytes, int status_word = 0);
+    int exchange_unpack(void* d_bodies, void* d_joints);
+    int exchange_status(int* out);
+    size_t exchange_segment_bytes() const { return (size_t)xch_seg_words_ * 4; }
+    int shard_count() const { return shard_count_; }
 
     hipStream_t stream() const { return stream_; }
     // run on a caller-owned stream from now on (the World puts broadphase, step kernels and solver on one stream so that
@@ -129,7 +139,7 @@ private:
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
-    bool use_graphs_ = false, speculate_ = true, half_state_ = false;
+    bool use_graphs_ = false, speculate_ = true, half_state_ = false, reuse_schedule_ = true;
     bool owns_stream_ = true, no_islands_ = false, trace_schedule_ = false;      // environment knobs, read once in init()
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
     bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }
@@ -137,6 +147,17 @@ private:
     struct Pending { bool active = false; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
     int ncp_ = 0;
     unsigned long long raw_fingerprint_ = 0;
+    // exchange of an island-sharded solve (exchange.h)
+    int ensure_exchange_layout();
+    std::vector<int> grp_body_count_;              // per LDS group: entries of its body table (both builders fill it)
+    unsigned* xch_send_ = nullptr;                 // caller-owned: one segment
+    unsigned* xch_recv_ = nullptr;                 // caller-owned: shard_count segments, rank-major
+    long long xch_cap_words_ = 0, xch_seg_words_ = 0, xch_layout_version_ = -1;
+    int xch_layout_shards_ = 0;
+    unsigned xch_serial_ = 0;
+    DevBuf<long long> xch_off_;
+    std::vector<long long> xch_off_host_;
+    DevBuf<int> xch_err_;
     std::vector<hipEvent_t> bench_events_;
 };
 

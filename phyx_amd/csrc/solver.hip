@@ -43,6 +43,7 @@ DeviceSolver::~DeviceSolver()
     jp_used_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
+    xch_off_.release(); xch_err_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -235,6 +236,8 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     const int ng = sched_.lds_groups;
     std::vector<int4> desc(std::max(ng, 1));
     std::vector<int> ncol(std::max(ng, 1));
+    grp_body_count_.assign(ng, 0);
+    for (int g = 0; g < ng; ++g) grp_body_count_[g] = sched_.group_body_offsets[g + 1] - sched_.group_body_offsets[g];
     if (ng) {
         for (int g = 0; g < ng; ++g) {
             desc[g] = make_int4(sched_.group_offsets[g], sched_.group_offsets[g + 1] - sched_.group_offsets[g],
@@ -394,13 +397,20 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_HIP(hipGetLastError());
     int rejected = 0;
     std::vector<int> ncol(std::max(nbins, 1), 0);
+    std::vector<int4> desc;
     PHX_TRY(rb_.add(&rejected, sb_small_.p + 2, sizeof rejected, stream_));
     if (nbins) PHX_TRY(rb_.add(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), stream_));
+    if (nbins && shard_count_ > 1) {          // a sharded solve's exchange layout needs every group's body count (exchange.h)
+        desc.resize(nbins);
+        PHX_TRY(rb_.add(desc.data(), grp_desc_.p, (size_t)nbins * sizeof(int4), stream_));
+    }
     PHX_TRY(rb_.wait(stream_));
     lap("bins");
     if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
     sc.lds_colours = 0;
     for (int g = 0; g < nbins; ++g) sc.lds_colours += ncol[g];
+    grp_body_count_.clear();
+    for (const int4& d : desc) grp_body_count_.push_back(d.w);
     }
     const int rest = nj - lds_slots;
 
@@ -671,6 +681,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
                              pending_.nj == nj && pending_.ncp == ncp && std::memcmp(&pending_.cfg, &cfg, sizeof cfg) == 0))
         PHX_TRY(synchronize());
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
+    if (!reuse_schedule_) topology_changed = true;       // live-topology measurements: rebuild like the reference does every call (ref: Solver.cpp:77, 135)
     if (!topology_changed && speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
         // Same sizes as the schedule in hand: run on it without waiting for the fingerprint.  The fingerprint kernel is
         // queued first; every kernel that writes to the caller's arrays compares it on the device and commits nothing on
@@ -809,7 +820,12 @@ int DeviceSolver::set_body_state_bits(int bits)
 int DeviceSolver::set_shard(int shard, int count)
 {
     PHX_REQUIRE(count >= 1 && shard >= 0 && shard < count, "bad shard");
-    if (shard != shard_ || count != shard_count_) { shard_ = shard; shard_count_ = count; drop_graphs(); }
+    if (shard != shard_ || count != shard_count_) {
+        PHX_TRY(synchronize());
+        // a sharded solve's schedule also carries the groups' body counts for the exchange layout: rebuild on a new count
+        if (count != shard_count_) sched_.valid = false;
+        shard_ = shard; shard_count_ = count; drop_graphs();
+    }
     return PHX_OK;
 }
 
@@ -871,7 +887,13 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
         // every step solves the SAME input: restore a working copy from the caller's (untouched) arrays
         if (nb) PHX_HIP(hipMemcpyAsync(snap_bodies_.p, d_bodies, (size_t)nb * sizeof(phx_rigid_body), hipMemcpyDeviceToDevice, stream_));
         if (nj) PHX_HIP(hipMemcpyAsync(snap_joints_.p, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
-        return solve_device(snap_bodies_.p, nb, d_cps, ncp, snap_joints_.p, nj, cfg);
+        PHX_TRY(solve_device(snap_bodies_.p, nb, d_cps, ncp, snap_joints_.p, nj, cfg));
+        if (xch_send_) {       // island-sharded solve: pack, the caller's all-gather (hook phase 2), unpack — all on the stream
+            PHX_TRY(exchange_pack(snap_bodies_.p, snap_joints_.p, nullptr));
+            if (hook && hook(user, step_hook_step_, 2)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
+            PHX_TRY(exchange_unpack(snap_bodies_.p, snap_joints_.p));
+        }
+        return PHX_OK;
     };
     // the hook's phase 1 fires inside solve_device, between the step's fingerprint and its sweeps
     struct HookScope {

@@ -30,6 +30,9 @@ public:
     int update(float dt, const phx_config& cfg);
     int pre_solve(float dt);
     int finish_step(float dt, const phx_config& cfg);
+    int step_begin(float dt, const phx_config& cfg, size_t* segment_bytes);
+    int step_end(float dt);
+    hipStream_t stream() const { return stream_; }
     int download_bodies(phx_rigid_body* out, int cap);
     int download_manifolds(phx_manifold* out, int cap);
     int download_contact_points(phx_contact_point* out, int cap);
@@ -265,9 +268,29 @@ int World::pre_solve(float dt)
     return PHX_OK;
 }
 
+// A sharded world (island sharding across ranks): this rank solves only its own groups, so the step has
+// two halves around the caller's all-gather of the ranks' results (exchange.h).  The unsplit entry points would integrate
+// the other ranks' bodies with unsolved velocities, so they refuse to run sharded.
+int World::step_begin(float dt, const phx_config& cfg, size_t* segment_bytes)
+{
+    PHX_TRY(pre_solve(dt));
+    PHX_TRY(solve(cfg));
+    return solver_.exchange_pack(d_bodies_.p, d_joints_.p, segment_bytes);
+}
+
+int World::step_end(float dt)
+{
+    PHX_TRY(use_device(device_));
+    PHX_TRY(solver_.exchange_unpack(d_bodies_.p, d_joints_.p));
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
 int World::finish_step(float dt, const phx_config& cfg)
 {
     using clk = std::chrono::steady_clock;
+    if (shard_count > 1) { set_error("a sharded world steps through phx_world_step_begin / all-gather / phx_world_step_end"); return PHX_ERR_STATE; }
     PHX_TRY(use_device(device_));
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
@@ -289,6 +312,7 @@ int World::synchronize()
 
 int World::update(float dt, const phx_config& cfg)
 {
+    if (shard_count > 1) { set_error("a sharded world steps through phx_world_step_begin / all-gather / phx_world_step_end"); return PHX_ERR_STATE; }
     PHX_TRY(pre_solve(dt));
     return finish_step(dt, cfg);
 }
@@ -385,6 +409,20 @@ int phx_world_finish_step(phx_world* w, float dt, const phx_config* cfg)
     PHX_REQUIRE(w && cfg, "null handle / config");
     return w->impl.finish_step(dt, *cfg);
 }
+
+int phx_world_step_begin(phx_world* w, float dt, const phx_config* cfg, size_t* segment_bytes)
+{
+    PHX_REQUIRE(w && cfg, "null handle / config");
+    return w->impl.step_begin(dt, *cfg, segment_bytes);
+}
+
+int phx_world_step_end(phx_world* w, float dt)
+{
+    PHX_REQUIRE(w, "null handle");
+    return w->impl.step_end(dt);
+}
+
+void* phx_world_stream(phx_world* w) { return w ? (void*)w->impl.stream() : nullptr; }
 
 int phx_world_counts(phx_world* w, int32_t* nb, int32_t* nm, int32_t* ncp, int32_t* nj)
 {

@@ -1,11 +1,120 @@
-"""One process per GPU: rendezvous, per-step barrier and max-over-ranks reduction for bench.py.
+"""One process per GPU: rendezvous, the per-step exchange and max-over-ranks reduction for bench.py.
 
 torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU
-tests).  The hot path shards by island, so no body or joint data ever crosses ranks; the only collectives
-are the per-step barrier (a 4-byte all-reduce, BASELINE.json north_star) and the final reduction of the
-timing / unit counters.
+tests and for several ranks sharing one GPU).  The hot path shards by island: every rank steps a replica of the
+world and solves its own groups; ONE all-gather per step carries each rank's results (and its status word) to
+every other rank — it is also the per-step barrier (BASELINE.json north_star).  The layout and the pack / unpack
+kernels live in the C library (csrc/exchange.h); this file only moves the segments.
 """
 import os
+
+import numpy as np
+
+
+class ExchangeError(RuntimeError):
+    """A peer reported a failure, is at another step, or solved another topology (PHX_XCH_* bits in .status)."""
+
+    def __init__(self, status):
+        names = [n for b, n in ((1, "peer error"), (2, "step serial mismatch"), (4, "topology mismatch: replicas diverged"),
+                                (8, "segment never written")) if status & b]
+        super().__init__("island-sharded exchange failed: %s (status %d)" % (", ".join(names) or "?", status))
+        self.status = status
+
+
+class Exchange:
+    """Buffers + transport of the island-sharded exchange for one solver handle.
+
+    all_gather(segment_bytes) moves the first `segment_bytes` of every rank's send buffer into every rank's recv
+    buffer (rank r at byte offset r * segment_bytes), ordered on the solver's stream `stream_ptr`:
+      nccl   torch uint8 tensors, dist.all_gather_into_tensor under an ExternalStream of that stream: RCCL runs behind
+             the pack kernels and in front of the unpack kernels, the host never waits;
+      gloo   staged through the host (d2h on the stream, gloo all_gather, h2d on the stream) — functional path for CPU
+             rendezvous and for ranks that share one GPU;
+      single one rank: a device-to-device copy on the stream.
+    """
+
+    def __init__(self, group, solver, capacity_bytes, device=0):
+        from . import api
+        self.group, self.solver, self.device = group, solver, device
+        self.n = group.world_size
+        self.capacity = (int(capacity_bytes) + 255) // 256 * 256
+        self.stream_ptr = solver.stream_ptr()
+        self.backend = getattr(group, "backend", "single")
+        self.L = api._lib.load()
+        if self.backend == "nccl":
+            torch = group.torch
+            self.send = torch.zeros(self.capacity, dtype=torch.uint8, device=group.device)
+            self.recv = torch.zeros(self.capacity * self.n, dtype=torch.uint8, device=group.device)
+            torch.cuda.synchronize(group.device)
+            self.ext = torch.cuda.ExternalStream(self.stream_ptr, device=group.device)
+            send_ptr, recv_ptr = self.send.data_ptr(), self.recv.data_ptr()
+        else:
+            self.send = api.DeviceBuffer(self.capacity, device)
+            self.recv = api.DeviceBuffer(self.capacity * self.n, device)
+            send_ptr, recv_ptr = self.send.ptr.value, self.recv.ptr.value
+        self.send_ptr, self.recv_ptr = send_ptr, recv_ptr
+        solver.set_exchange_buffers(send_ptr, recv_ptr, self.capacity)
+
+    @staticmethod
+    def capacity_for(body_count, joint_count):
+        """Upper bound of a segment: one rank owning every group (6 floats per body, 2 per joint, header, padding)."""
+        # (a body may appear in one dynamic group; static bodies appear in every group that touches them: <= 2 bodies per joint)
+        return 32 + 24 * (int(body_count) + 2 * int(joint_count)) + 8 * int(joint_count) + 16 * (int(joint_count) + 2) + 256
+
+    def all_gather(self, segment_bytes):
+        seg = int(segment_bytes)
+        if seg > self.capacity:
+            raise ValueError("segment of %d bytes exceeds the exchange capacity %d" % (seg, self.capacity))
+        if self.backend == "nccl":
+            torch, dist = self.group.torch, self.group.dist
+            with torch.cuda.stream(self.ext):
+                dist.all_gather_into_tensor(self.recv[: seg * self.n], self.send[:seg])
+            return
+        import ctypes as C
+        stream = C.c_void_p(self.stream_ptr)
+        if self.backend == "single" or self.n == 1:
+            from .api import check
+            check(self.L.phx_memcpy_d2d_on(self.device, self.recv.address(0), self.send.address(0), seg, stream))
+            return
+        # gloo: host staging, ordered on the solver's stream by the blocking stream copies
+        from .api import check
+        mine = np.zeros(seg, dtype=np.uint8)
+        check(self.L.phx_memcpy_d2h_on(self.device, mine.ctypes.data_as(C.c_void_p), self.send.address(0), seg, stream))
+        allb = self.group.all_gather_bytes(mine)
+        check(self.L.phx_memcpy_h2d_on(self.device, self.recv.address(0), allb.ctypes.data_as(C.c_void_p), seg * self.n, stream))
+
+    def hook(self):
+        """Step hook for Solver.bench: phase 2 = results packed on the stream, run the all-gather now."""
+        def hook(step, phase):
+            if phase == 2:
+                self.all_gather(self.solver.exchange_segment_bytes())
+        return hook
+
+    def check(self):
+        """Synchronises; raises ExchangeError on every rank that saw an inconsistent exchange."""
+        st = self.solver.exchange_status()
+        if st:
+            raise ExchangeError(st)
+
+
+def step_sharded(world, dt, configuration, exchange):
+    """One World::Update of an island-sharded world (ref: World.cpp:19-37 on every rank's replica): solve this rank's
+    groups, all-gather everyone's results, scatter them, integrate.  A rank whose first half fails still enters the
+    collective (so its peers are not left hanging in it) with a non-zero status word, then re-raises; the peers see
+    PHX_XCH_PEER_ERROR at their next Exchange.check()."""
+    from .api import PhxError
+    try:
+        seg = world.StepBegin(dt, configuration)
+    except PhxError:
+        seg = exchange.solver.exchange_segment_bytes() or 256
+        try:
+            exchange.solver.L.phx_solver_exchange_pack(exchange.solver.h, None, None, 1, None)
+        except Exception:
+            pass
+        exchange.all_gather(seg)
+        raise
+    exchange.all_gather(seg)
+    world.StepEnd(dt)
 
 
 class Single:
@@ -26,6 +135,9 @@ class Single:
 
     def stream_hook(self, stream_ptr):
         return None
+
+    def exchange(self, solver, capacity_bytes, device=0):
+        return Exchange(self, solver, capacity_bytes, device)
 
     def shutdown(self):
         pass
@@ -87,6 +199,17 @@ class Group:
                         pending.pop(0).wait()          # the solver's stream waits for the exchange; the host does not
         self._hook_keep = (ext, flag, pending)
         return hook
+
+    def all_gather_bytes(self, mine):
+        """Host-side all-gather of equal-length uint8 arrays -> one array, rank-major (the gloo transport of Exchange)."""
+        torch, dist = self.torch, self.dist
+        mine = np.ascontiguousarray(mine, dtype=np.uint8)
+        parts = [torch.zeros(len(mine), dtype=torch.uint8) for _ in range(self.world_size)]
+        dist.all_gather(parts, torch.from_numpy(mine))
+        return np.concatenate([p.numpy() for p in parts])
+
+    def exchange(self, solver, capacity_bytes, device=None):
+        return Exchange(self, solver, capacity_bytes, self.local_rank if device is None and self.backend == "nccl" else (device or 0))
 
     def _reduce(self, x, op):
         t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)

@@ -1,0 +1,38 @@
+"""Worker of test_two_processes_share_the_gpu_and_exchange_over_gloo: one rank of an island-sharded world.
+Run with RANK / WORLD_SIZE / MASTER_* set; every rank uses GPU 0 and the gloo backend (host-staged all-gather)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import phyx_amd                                   # noqa: E402
+from phyx_amd import scenes, Configuration        # noqa: E402
+from phyx_amd import dist as pdist                # noqa: E402
+
+
+def main():
+    g = pdist.init(int(os.environ["WORLD_SIZE"]), backend="gloo")
+    scene = scenes.stack(16, 24)
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 12, 12)
+    full = phyx_amd.World(0, gravity=-200.0)
+    full.add_scene(scene)
+    mine = phyx_amd.World(0, gravity=-200.0)
+    mine.add_scene(scene)
+    mine.set_shard(g.rank, g.world_size)
+    xch = g.exchange(mine.solver, pdist.Exchange.capacity_for(len(scene["px"]), 8 * len(scene["px"])), device=0)
+    for step in range(12):
+        full.Update(1.0 / 60.0, cfg)
+        pdist.step_sharded(mine, 1.0 / 60.0, cfg, xch)
+        assert mine.bodies.tobytes() == full.bodies.tobytes(), "rank %d: bodies differ at step %d" % (g.rank, step)
+        assert mine.contactJoints.tobytes() == full.contactJoints.tobytes(), "rank %d: joints differ at step %d" % (g.rank, step)
+    xch.check()
+    groups, _ = full.solver.groups()
+    assert len(groups) - 1 >= 2
+    g.barrier()
+    print("sharded worker ok: rank %d of %d, %d groups, %d joints" % (g.rank, g.world_size, len(groups) - 1, mine.counts()[3]))
+    g.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,12 @@ WORKER = textwrap.dedent("""
     hook = g.stream_hook(0)                                 # bench.py's per-step hook (gloo: the blocking all-reduce)
     for step in range(3):
         hook(step, 1); hook(step, 0)
+    import numpy as np
+    seg = np.full(512, 10 + g.rank, dtype=np.uint8)         # the host-staged all-gather of the island-sharded exchange
+    seg[:4] = np.frombuffer(np.uint32(0x45584850).tobytes(), dtype=np.uint8)
+    allb = g.all_gather_bytes(seg)
+    assert allb.shape == (1024,) and (allb[4:512] == 10).all() and (allb[516:] == 11).all()
+    assert allb[:4].tobytes() == allb[512:516].tobytes() == b"PHXE"
     t = g.reduce_max(1.0 + g.rank)                          # max over ranks (timing)
     units = g.reduce_sum(float(n))                          # whole-job units
     print(json.dumps({"rank": g.rank, "world": g.world_size, "first": first, "n": n, "t": t, "units": units, "flags": flags}))

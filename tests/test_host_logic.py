@@ -118,3 +118,27 @@ def test_schedule_handles_hub_and_empty(built_lib):
     assert len(order) == 0 and list(offs) == [0]
     with pytest.raises(phyx_amd.PhxError):
         phyx_amd.schedule_colours([0], [5], [0, 0])
+
+
+def test_exchange_layout_partitions_the_groups_over_the_ranks():
+    """Segment layout of the island-sharded exchange (csrc/exchange.h, host-only): group g belongs to rank g % n, blocks
+    never overlap, every rank's segment fits the common padded length, and one rank alone owns everything."""
+    import phyx_amd
+    rng = np.random.default_rng(5)
+    for ngroups, n in ((0, 1), (1, 8), (5, 2), (999, 8), (1000, 3), (37, 37), (12, 64)):
+        gb = rng.integers(1, 769, ngroups).astype(np.int32)
+        gs = rng.integers(1, 513, ngroups).astype(np.int32)
+        off, rank_words, seg = phyx_amd.exchange_layout(gb, gs, n)
+        assert seg % 64 == 0 and seg >= 8 and len(rank_words) == n
+        assert int(rank_words.max()) <= seg < int(rank_words.max()) + 64
+        for r in range(n):
+            mine = [g for g in range(ngroups) if g % n == r]
+            at = 8                                                  # header words
+            for g in mine:
+                assert off[g] == at and off[g] % 4 == 0
+                at += (6 * int(gb[g]) + 2 * int(gs[g]) + 3) // 4 * 4
+            assert at == rank_words[r]
+        # total payload is independent of the rank count
+        assert int(rank_words.sum()) - 8 * n == int(sum((6 * int(b) + 2 * int(s) + 3) // 4 * 4 for b, s in zip(gb, gs)))
+    with pytest.raises(phyx_amd.PhxError):
+        phyx_amd.exchange_layout([1], [1], 0)

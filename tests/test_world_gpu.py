@@ -60,46 +60,155 @@ def test_differential_fuzz_random_worlds(built_lib):
     assert r.returncode == 0 and "0 diverged" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_island_shards_reproduce_the_unsharded_step(oracle, built_lib):
-    """Multi-GPU sharding is by island: every rank builds the same schedule and sweeps the groups
-    g with g % k == rank.  Emulated on one GPU: k worlds each solve one shard; stitching their bodies together must
-    give the unsharded result bit for bit, because groups are body-disjoint."""
-    scene = scenes.stack(24, 30)                  # 24 columns -> several coalesced islands
-    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 15, 15)
+class _LocalRanks:
+    """k sharded Worlds on ONE GPU: the all-gather of the island-sharded exchange emulated with device-to-device copies
+    (every rank's segment into every rank's recv buffer at offset rank * segment_bytes) — what RCCL does on a node."""
+
+    def __init__(self, scene, k, capacity, gravity=-200.0):
+        self.k = k
+        self.worlds, self.send, self.recv = [], [], []
+        for r in range(k):
+            w = phyx_amd.World(0, gravity=gravity)
+            w.add_scene(scene)
+            w.set_shard(r, k)
+            snd, rcv = phyx_amd.DeviceBuffer(capacity, 0), phyx_amd.DeviceBuffer(capacity * k, 0)
+            w.solver.set_exchange_buffers(snd.ptr.value, rcv.ptr.value, capacity)
+            self.worlds.append(w); self.send.append(snd); self.recv.append(rcv)
+
+    def step(self, dt, cfg):
+        segs = [w.StepBegin(dt, cfg) for w in self.worlds]
+        assert len(set(segs)) == 1, "every rank must derive the same segment size: %r" % (segs,)
+        for w in self.worlds:
+            w.sync()
+        for dst in range(self.k):
+            for src in range(self.k):      # ordered on the destination world's stream, in front of its unpack
+                self.recv[dst].copy_from(self.send[src], segs[0], dst_offset=src * segs[0], stream=self.worlds[dst].stream_ptr())
+        for w in self.worlds:
+            w.StepEnd(dt)
+        return segs[0]
+
+
+def _same_world(a, b, what):
+    assert a.counts() == b.counts(), what
+    assert a.bodies.tobytes() == b.bodies.tobytes(), "bodies differ: " + what
+    assert a.contactJoints.tobytes() == b.contactJoints.tobytes(), "joints differ: " + what
+    assert a.manifolds.tobytes() == b.manifolds.tobytes(), "manifolds differ: " + what
+
+
+@pytest.mark.parametrize("name,k,steps,mode", [("stack", 3, 14, phyx_amd.ISLAND_MULTIPLE), ("falling", 3, 40, phyx_amd.ISLAND_MULTIPLE_SLOPPY),
+                                               ("stack", 8, 10, phyx_amd.ISLAND_MULTIPLE), ("pile", 2, 12, phyx_amd.ISLAND_MULTIPLE)])
+def test_sharded_worlds_stay_in_lockstep_with_the_unsharded_world(oracle, built_lib, name, k, steps, mode):
+    """BASELINE config 3: every rank steps a replica of the world, solves the schedule groups
+    g % k == rank, and the ranks' results are all-gathered before IntegratePosition (the counterpart of the reference
+    merging its islands back, ref: Solver.cpp:86-91, 482-494).  k sharded Worlds on one GPU with the all-gather emulated
+    by device copies must match the unsharded World byte for byte after EVERY step — bodies, joints (warm-start impulses)
+    and manifolds — and every replica must equal every other.  'pile' has an island too big for a workgroup: the
+    HBM group is owned by one rank and exchanged like any other."""
+    scene = {"stack": lambda: scenes.stack(64, 30), "falling": lambda: scenes.falling(4000, width=5000.0, ymax=260.0),
+             "pile": lambda: scenes.falling(1500, width=60.0, ymax=700.0)}[name]()
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, mode, 15, 15)
     full = phyx_amd.World(0, gravity=-200.0)
     full.add_scene(scene)
-    for _ in range(3):
+    from phyx_amd.dist import Exchange
+    ranks = _LocalRanks(scene, k, Exchange.capacity_for(len(scene["px"]), 8 * len(scene["px"])))
+    saw_groups = saw_hbm = 0
+    for step in range(steps):
         full.Update(1.0 / 60.0, cfg)
-    assert full.solver.stats().island_count >= 3
-    k = 3
-    shards = []
-    for r in range(k):
-        w = phyx_amd.World(0, gravity=-200.0)
-        w.add_scene(scene)
-        shards.append(w)
-    for _ in range(2):                             # identical history up to the step under test
-        for w in shards:
-            w.Update(1.0 / 60.0, cfg)
-    for r, w in enumerate(shards):
-        w.set_shard(r, k)
-        w.Update(1.0 / 60.0, cfg)
-    ref = full.bodies
-    joints = full.contactJoints
-    order, _ = full.solver.schedule()              # groups are the unit of sharding: rank = group index % k
-    groups, _ = full.solver.groups()
-    assert len(groups) - 1 >= k
-    owner = np.full(len(ref), -1)
-    for g in range(len(groups) - 1):
-        for j in order[groups[g]:groups[g + 1]]:
-            for body in (joints["body1"][j], joints["body2"][j]):
-                if ref["inv_mass"][body] != 0:
-                    owner[body] = g % k
-    stitched = shards[0].bodies.copy()
-    for r in range(1, k):
-        mine = owner == r
-        stitched[mine] = shards[r].bodies[mine]
-    moved = owner >= 0
-    assert stitched[moved].tobytes() == ref[moved].tobytes()
+        ranks.step(1.0 / 60.0, cfg)
+        for r, w in enumerate(ranks.worlds):
+            _same_world(w, full, "rank %d of %d at step %d" % (r, k, step))
+        groups, lds = full.solver.groups()
+        saw_groups = max(saw_groups, len(groups) - 1)
+        saw_hbm |= int(len(groups) - 1 > lds)
+    assert saw_groups >= (8 if name == "stack" else 2), saw_groups
+    assert name != "pile" or saw_hbm, "the pile scene should have produced an island that only the HBM path can take"
+    for w in ranks.worlds:
+        assert w.solver.exchange_status() == 0
+
+
+def test_sharded_world_at_config3_size_matches_the_oracle(oracle, built_lib):
+    """BASELINE config 3 at full size: stack(1000,200) = 200 001 bodies, Multiple island mode, 8 shards (emulated on one
+    GPU).  Two steps in lockstep with the oracle World driven in the device's group / colour order: every rank's replica
+    must equal the oracle byte for byte after each step."""
+    scene = scenes.stack(1000, 200)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 20, 20)
+    from phyx_amd.dist import Exchange
+    k = 8
+    ranks = _LocalRanks(scene, k, Exchange.capacity_for(200001, 450000) // 4)
+    ow = oracle_world(scene)
+    for step in range(2):
+        seg = ranks.step(1.0 / 60.0, cfg)
+        assert seg * k < 4 * Exchange.capacity_for(200001, 450000)
+        ow.pre_solve(1.0 / 60.0)
+        w0 = ranks.worlds[0]
+        order, offs = w0.solver.schedule()
+        groups, _ = w0.solver.groups()
+        b, cp, j = ow.bodies(), ow.contact_points(), ow.joints()
+        assert len(order) == len(j)
+        oracle.solver_solve_grouped(b, cp, j, order, offs, groups, 20, 20, oracle.STAG_COLOUR_SYNC)
+        ow.integrate_position(1.0 / 60.0)
+        for r in (0, 3, 7):
+            w = ranks.worlds[r]
+            assert w.bodies.tobytes() == ow.bodies().tobytes(), "rank %d bodies differ from the oracle at step %d" % (r, step)
+            assert w.contactJoints.tobytes() == ow.joints().tobytes(), "rank %d joints differ from the oracle at step %d" % (r, step)
+    st = ranks.worlds[0].solver.stats()
+    assert st.island_count >= 900 and st.lds_islands >= 900
+    assert all(w.solver.exchange_status() == 0 for w in ranks.worlds)
+
+
+def test_exchange_detects_a_diverged_or_failed_peer(built_lib):
+    """The all-gather carries a real status: every segment's header holds the step serial, a status word and the topology
+    fingerprint of the schedule the rank solved; the unpack flags a peer that reported a failure, is at another step,
+    solved another topology, or whose segment never arrived."""
+    scene = scenes.stack(6, 12)
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 8, 8)
+    from phyx_amd.dist import Exchange
+    cap = Exchange.capacity_for(80, 400)
+    ranks = _LocalRanks(scene, 2, cap)
+    ranks.step(1.0 / 60.0, cfg)
+    assert [w.solver.exchange_status() for w in ranks.worlds] == [0, 0]
+    # rank 1's segment never arrives at rank 0 (its slot keeps the previous step's header): serial mismatch
+    segs = [w.StepBegin(1.0 / 60.0, cfg) for w in ranks.worlds]
+    for w in ranks.worlds:
+        w.sync()
+    ranks.recv[0].copy_from(ranks.send[0], segs[0], dst_offset=0, stream=ranks.worlds[0].stream_ptr())
+    ranks.recv[1].copy_from(ranks.send[0], segs[0], dst_offset=0, stream=ranks.worlds[1].stream_ptr())
+    ranks.recv[1].copy_from(ranks.send[1], segs[0], dst_offset=segs[0], stream=ranks.worlds[1].stream_ptr())
+    for w in ranks.worlds:
+        w.StepEnd(1.0 / 60.0)
+    assert ranks.worlds[0].solver.exchange_status() & phyx_amd.api.XCH_SERIAL_MISMATCH
+    assert ranks.worlds[1].solver.exchange_status() == 0
+    # a peer posts a failure status; a zeroed slot is a segment that was never written
+    ranks.worlds[1].sync()
+    hdr = ranks.send[1].to_host(32).view(np.uint32).copy()
+    hdr[2] = 7
+    ranks.recv[1].from_host(hdr, offset=0)
+    ranks.recv[1].from_host(np.zeros(8, dtype=np.uint32), offset=segs[0])
+    ranks.worlds[1].StepEnd(1.0 / 60.0)
+    st = ranks.worlds[1].solver.exchange_status()
+    assert st & phyx_amd.api.XCH_PEER_ERROR and st & phyx_amd.api.XCH_BAD_SEGMENT
+    # the unsplit entry points refuse to step a sharded world
+    with pytest.raises(phyx_amd.PhxError):
+        ranks.worlds[0].Update(1.0 / 60.0, cfg)
+
+
+def test_two_processes_share_the_gpu_and_exchange_over_gloo(built_lib):
+    """The real multi-process path (phyx_amd.dist.step_sharded + Exchange) with world_size 2: both ranks on GPU 0, the
+    all-gather staged through gloo.  Each rank checks its replica against an unsharded World after every step."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(root, "tests", "sharded_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=420)
+        assert p.returncode == 0 and "sharded worker ok" in out, out[-1500:] + err[-3000:]
 
 
 def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
