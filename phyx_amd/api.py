@@ -253,6 +253,17 @@ class Solver:
         """False: rebuild the schedule on every solve (the reference rebuilds its grouping every call)."""
         check(self.L.phx_solver_set_schedule_reuse(self.h, 1 if on else 0))
 
+    def set_trace(self, on=True):
+        check(self.L.phx_solver_set_trace(self.h, 1 if on else 0))
+
+    def island_trace(self):
+        """(groups, 8) uint64: phase stamps of the island kernel's workgroups in the last solve (set_trace first)."""
+        n = C.c_int32(0)
+        check(self.L.phx_solver_get_island_trace(self.h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 8), dtype=np.uint64)
+        check(self.L.phx_solver_get_island_trace(self.h, _ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
     def set_shard(self, shard, shard_count):
         """Sweep only the schedule groups g with g % shard_count == shard (multi-GPU island sharding)."""
         check(self.L.phx_solver_set_shard(self.h, shard, shard_count))

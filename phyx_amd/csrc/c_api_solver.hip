@@ -71,6 +71,20 @@ int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on)
     return PHX_OK;
 }
 
+int phx_solver_set_trace(phx_solver* s, int32_t on)
+{
+    PHX_REQUIRE(s, "null handle");
+    s->impl.set_trace(on != 0);
+    return PHX_OK;
+}
+
+int phx_solver_get_island_trace(phx_solver* s, uint64_t* out, int32_t cap_groups, int32_t* groups)
+{
+    PHX_REQUIRE(s, "null handle");
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "trace words");
+    return s->impl.get_island_trace(reinterpret_cast<unsigned long long*>(out), cap_groups, groups);
+}
+
 int phx_solver_get_groups(phx_solver* s, int32_t* offsets, int32_t cap, int32_t* count, int32_t* lds_count)
 {
     PHX_REQUIRE(s, "null handle");

@@ -10,6 +10,7 @@ int DeviceSolver::set_exchange_buffers(void* d_send, void* d_recv, size_t segmen
     PHX_REQUIRE((d_send && d_recv) || segment_capacity_bytes == 0, "null exchange buffers");
     PHX_REQUIRE((reinterpret_cast<uintptr_t>(d_send) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_recv) & 15u) == 0 && segment_capacity_bytes % 256 == 0,
                 "exchange buffers must be 16-byte aligned, the segment capacity a multiple of 256 bytes");
+    if (!xch_send_ && d_send) { PHX_TRY(synchronize()); sched_.valid = false; }      // the next schedule build also fetches the groups' body counts
     xch_send_ = static_cast<unsigned*>(d_send); xch_recv_ = static_cast<unsigned*>(d_recv); xch_cap_words_ = (long long)(segment_capacity_bytes / 4);
     if (!xch_err_.p) {
         PHX_TRY(xch_err_.reserve(1));

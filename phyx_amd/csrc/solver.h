@@ -43,6 +43,8 @@ public:
     int set_body_state_bits(int bits);
     int set_shard(int shard, int count);
     void set_schedule_reuse(bool on) { reuse_schedule_ = on; }
+    void set_trace(bool on) { trace_islands_ = on; drop_graphs(); }
+    int get_island_trace(unsigned long long* out, int cap_groups, int* groups);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
@@ -158,6 +160,8 @@ private:
     DevBuf<long long> xch_off_;
     std::vector<long long> xch_off_host_;
     DevBuf<int> xch_err_;
+    DevBuf<unsigned long long> isl_trace_;
+    bool trace_islands_ = false;
     std::vector<hipEvent_t> bench_events_;
 };
 

@@ -43,7 +43,7 @@ DeviceSolver::~DeviceSolver()
     jp_used_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
-    xch_off_.release(); xch_err_.release();
+    xch_off_.release(); xch_err_.release(); isl_trace_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -400,7 +400,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     std::vector<int4> desc;
     PHX_TRY(rb_.add(&rejected, sb_small_.p + 2, sizeof rejected, stream_));
     if (nbins) PHX_TRY(rb_.add(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), stream_));
-    if (nbins && shard_count_ > 1) {          // a sharded solve's exchange layout needs every group's body count (exchange.h)
+    if (nbins && (shard_count_ > 1 || xch_send_)) {          // a sharded solve's exchange layout needs every group's body count (exchange.h)
         desc.resize(nbins);
         PHX_TRY(rb_.add(desc.data(), grp_desc_.p, (size_t)nbins * sizeof(int4), stream_));
     }
@@ -558,8 +558,16 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         iv.first = shard_; iv.stride = shard_count_;
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
+        iv.trace = nullptr;
+        if (trace_islands_) {
+            if (isl_trace_.reserve((size_t)std::max(lg, 1) * 8) != PHX_OK) return PHX_ERR_HIP;
+            PHX_HIP(hipMemsetAsync(isl_trace_.p, 0, (size_t)lg * 8 * sizeof(unsigned long long), stream_));
+            iv.trace = isl_trace_.p;
+        }
         const bool big = sched_.lds_lanes > ISL_T;
-        if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        if (iv.trace && big)          hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        else if (iv.trace)            hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        else if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
@@ -804,6 +812,19 @@ int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offs
     if ((order && order_cap < nj_) || (offsets && offsets_cap < ncol + 1)) { set_error("schedule buffers too small"); return PHX_ERR_CAPACITY; }
     if (order) std::copy(sched_.order.begin(), sched_.order.end(), order);
     if (offsets) std::copy(sched_.colour_offsets.begin(), sched_.colour_offsets.end(), offsets);
+    return PHX_OK;
+}
+
+// phase stamps of the island kernel's workgroups (diagnostics: tools/island_trace.py)
+int DeviceSolver::get_island_trace(unsigned long long* out, int cap_groups, int* groups)
+{
+    PHX_TRY(synchronize());
+    const int lg = sched_.valid ? sched_.lds_groups : 0;
+    if (groups) *groups = lg;
+    if (!out) return PHX_OK;
+    if (!trace_islands_ || !isl_trace_.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
+    if (cap_groups < lg) { set_error("island trace buffer too small"); return PHX_ERR_CAPACITY; }
+    if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p, (size_t)lg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
 

@@ -354,7 +354,12 @@ struct IslandView {
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
     unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
+    unsigned long long* trace;        // null, or 8 words per group: shader-clock stamps of the kernel's phases (phx_solver_set_trace)
 };
+
+// phase stamps of the island kernel (tools/island_trace.py): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
+// 5 written back; word 6 = XCC id, word 7 = colours << 32 | impulse sweeps executed
+#define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 template <int B>
 __device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[B], int body, int iter, int colour)
@@ -383,7 +388,7 @@ __device__ __forceinline__ void body_store(uint2* p, int i, float4 v)
     p[i] = make_uint2(f2h_bits(v.x) | (f2h_bits(v.y) << 16), f2h_bits(v.z) | ((unsigned)(unsigned short)(short)__float_as_int(v.w) << 16));
 }
 
-template <int T, int NB, bool HALF>
+template <int T, int NB, bool HALF, bool TRACE = false>
 __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
                                                             phx_contact_joint* __restrict__ joints,
                                                             const phx_contact_point* __restrict__ cps, int ci, int pi)
@@ -402,6 +407,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     float4* par = reinterpret_cast<float4*>(sw_raw);
 
     const int group = iv.first + (int)blockIdx.x * iv.stride;
+    PHX_ISL_STAMP(0);
     const int4 d = iv.desc[group];
     const int ncol = iv.ncol[group];
     const int tid = threadIdx.x;
@@ -453,6 +459,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         is_st[i] = (rec_par[k].x == 0.f && rec_par[k].y == 0.f) ? 1 : 0;
     }
     __syncthreads();
+    PHX_ISL_STAMP(1);
     if (live) {
         const float4 p1 = par[l1], p2 = par[l2];           // {im, ii, pos.x, pos.y} of the two bodies
         // RefreshJoints (ref: Solver.cpp:642-693) — same expressions as k_pack_refresh
@@ -473,6 +480,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
     const float tx = -ny, ty = nx;
     __syncthreads();
+    PHX_ISL_STAMP(2);
 
     // PreStepJoints (ref: Solver.cpp:736-750), colour by colour
     for (int c = 0; c < ncol; ++c) {
@@ -493,6 +501,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         __syncthreads();
     }
 
+    PHX_ISL_STAMP(3);
     int done_imp = 0, done_disp = 0;
     bool imp_alive = ci > 0, disp_alive = pi > 0;
     const int iters = ci > pi ? ci : pi;
@@ -568,6 +577,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         __syncthreads();
     }
 
+    PHX_ISL_STAMP(4);
     // results go straight back into the caller's records (commit-gated like k_finish_*); the refreshed constants
     // never leave the registers
     if (*v.fingerprint != v.expected_fingerprint) return;
@@ -590,6 +600,14 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         atomicMax(&iv.executed[2 * slot], done_imp);
         atomicMax(&iv.executed[2 * slot + 1], done_disp);
         atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
+    }
+    if (TRACE) {
+        __builtin_amdgcn_s_waitcnt(0);         // the stores above have left the wave
+        PHX_ISL_STAMP(5);
+        if (tid == 0) {
+            iv.trace[(size_t)group * 8 + 6] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
+            iv.trace[(size_t)group * 8 + 7] = ((unsigned long long)ncol << 32) | (unsigned)done_imp;
+        }
     }
 }
 
