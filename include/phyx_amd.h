@@ -135,7 +135,7 @@ int phx_solver_set_shard(phx_solver* s, int32_t shard, int32_t shard_count);
  * every call (ref: src/Solver.cpp:77, 135) — the cost a world whose contact graph changes every step pays. */
 int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on);
 
-/* Diagnostics: with tracing on, every workgroup of the island kernel stamps the shader clock at its phase boundaries.
+/* Diagnostics: with tracing on, every workgroup of the island kernel stamps the 100 MHz wall clock at its phase boundaries.
  * phx_solver_get_island_trace copies 8 words per LDS group of the last solve: [0] start, [1] records loaded, [2] refreshed,
  * [3] pre-stepped, [4] swept, [5] written back, [6] XCC id, [7] colours << 32 | impulse sweeps executed.  *groups receives
  * the group count (out may be NULL to query it). */

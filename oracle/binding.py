@@ -51,6 +51,8 @@ def build(force=False):
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so) for f in ("phx_oracle.c", "phx_oracle.h"))
     if force or src_newer:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if force:
+        subprocess.check_call(["make", "-B", "-C", _HERE, "libcpubaseline_fast.so", "libcpubaseline_strict.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libphyx_ref_leaf.so")
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -323,3 +325,50 @@ def time_impulse_loop(bodies, cps, joints, iters, threads):
     j = joints.copy()
     sec = lib().phxo_time_impulse_loop(_p(b), len(b), _p(cps), _p(j), len(j), iters, threads, C.byref(visits))
     return sec, int(visits.value)
+
+
+# ---- the CPU baseline (cpu_baseline.c): 8-wide AVX2-order restatement, built with the reference's flags ("fast") and with
+#      the oracle's strict flags ("strict", bit-comparable with phxo_solver_solve in AVX2 mode) -------------------------------
+class BaselinePhases(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("prepare_bodies", "prepare_indices", "prepare_joints", "refresh", "prestep", "impulse",
+                                          "displacement", "finish", "total")] + \
+               [("impulse_iterations", C.c_int32), ("displacement_iterations", C.c_int32), ("group_offset", C.c_int32), ("threads", C.c_int32),
+                ("joint_visits", C.c_int64)]
+
+
+class BaselineBroadphasePhases(C.Structure):
+    _fields_ = [("update_broadphase", C.c_double), ("update_pairs", C.c_double), ("candidate_tests", C.c_int64),
+                ("overlapping_pairs", C.c_int64), ("threads", C.c_int32), ("reps", C.c_int32)]
+
+
+_baseline = {}
+
+
+def baseline_lib(kind="fast"):
+    """kind: 'fast' (-O3 -ffast-math -mavx2 -mfma, the reference's Makefile flags) or 'strict' (the oracle's flags)."""
+    if kind not in _baseline:
+        so = os.path.join(_HERE, "libcpubaseline_%s.so" % kind)
+        src = os.path.join(_HERE, "cpu_baseline.c")
+        if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+            subprocess.check_call(["make", "-C", _HERE, os.path.basename(so)], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        L.phxb_solve.restype = C.c_int
+        L.phxb_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BaselinePhases)]
+        L.phxb_broadphase.restype = C.c_int
+        L.phxb_broadphase.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(BaselineBroadphasePhases)]
+        _baseline[kind] = L
+    return _baseline[kind]
+
+
+def baseline_solve(bodies, cps, joints, contact_iters, penetration_iters, threads=1, sloppy=False, kind="fast"):
+    """Solver::SolveJoints<8> (Single, or Single Sloppy with `threads` workers) IN PLACE on bodies / joints; returns the phases."""
+    ph = BaselinePhases()
+    baseline_lib(kind).phxb_solve(_p(bodies), len(bodies), _p(cps), _p(joints), len(joints), contact_iters, penetration_iters,
+                                  threads, 1 if sloppy else 0, C.byref(ph))
+    return ph
+
+
+def baseline_broadphase(bodies, threads=1, reps=3, kind="fast"):
+    ph = BaselineBroadphasePhases()
+    baseline_lib(kind).phxb_broadphase(_p(bodies), len(bodies), threads, reps, C.byref(ph))
+    return ph

@@ -357,9 +357,9 @@ struct IslandView {
     unsigned long long* trace;        // null, or 8 words per group: shader-clock stamps of the kernel's phases (phx_solver_set_trace)
 };
 
-// phase stamps of the island kernel (tools/island_trace.py): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
+// phase stamps of the island kernel (tools/island_trace.py; the constant 100 MHz clock all XCDs share): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
 // 5 written back; word 6 = XCC id, word 7 = colours << 32 | impulse sweeps executed
-#define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = wall_clock64(); } while (0)
 
 template <int B>
 __device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[B], int body, int iter, int colour)

@@ -59,7 +59,8 @@ class Exchange:
     def capacity_for(body_count, joint_count):
         """Upper bound of a segment: one rank owning every group (6 floats per body, 2 per joint, header, padding)."""
         # (a body may appear in one dynamic group; static bodies appear in every group that touches them: <= 2 bodies per joint)
-        return 32 + 24 * (int(body_count) + 2 * int(joint_count)) + 8 * int(joint_count) + 16 * (int(joint_count) + 2) + 256
+        n = 32 + 24 * (int(body_count) + 2 * int(joint_count)) + 8 * int(joint_count) + 16 * (int(joint_count) + 2) + 256
+        return (n + 255) // 256 * 256
 
     def all_gather(self, segment_bytes):
         seg = int(segment_bytes)

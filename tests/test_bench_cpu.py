@@ -20,11 +20,14 @@ def _bench_module():
 
 def test_cpu_baseline_leg(oracle):
     bodies, cps, joints = presolve_state(scenes.stack(8, 60), 3, iters=20)
-    out = _bench_module().cpu_baseline(bodies, cps, joints, 20, 0.6)
+    out = _bench_module().cpu_baseline(bodies, cps, joints, 20, 3.0)
     assert out["unit"] == "joint-visits/s" and out["kind"] == "port"
-    assert out["value"] > 1e6 and out["single_thread_value"] > 1e6
+    assert out["value"] > 1e6 and out["single_thread"]["value"] > 1e6 and out["scalar_port_single_thread_value"] > 1e6
     assert 1 <= out["cores"] <= (os.cpu_count() or 1)
     assert "impulse sweeps" in out["sample"]
+    for phases in (out["phases_ms"], out["single_thread"]["phases_ms"]):           # the reference's scopes, BASELINE.md §3
+        assert set(phases) >= {"refresh", "prestep", "impulse", "displacement", "prepare_indices"} and phases["impulse"] > 0
+    assert out["broadphase_ms"]["threads_1"]["UpdatePairs"] > 0 and out["broadphase_ms"]["candidate_tests"] > 0
 
 
 def test_bench_fails_loudly_without_gpu(built_lib):

@@ -248,3 +248,43 @@ def test_binary16_rounding_model(oracle):
     with np.errstate(over="ignore"):
         want = vals.astype(np.float16).astype(np.float32)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("name", ["stack2x10", "stack10x100", "tilted60", "falling600"])
+def test_cpu_baseline_strict_build_equals_the_oracle_avx2_order(oracle, name):
+    """oracle/cpu_baseline.c (the 8-wide AVX2-order CPU baseline bench.py times with the reference's flags) is the same
+    algorithm as the oracle's AVX2 mode: built with the oracle's strict flags it reproduces phxo_solver_solve(AVX2, Single)
+    bit for bit — greedy 8-grouping, group-granular skip, SIMD flipsign, early exits.  The fast build (-ffast-math -mfma) stays
+    within SURVEY.md §8(c)'s T1 tolerance of it after one solve."""
+    from helpers import SMALL_SCENES, presolve_state
+    make, warm = SMALL_SCENES[name]
+    bodies, cps, joints = presolve_state(make(), warm)
+    for iters in ((20, 20), (15, 15), (7, 0), (50, 50)):
+        bo, jo = bodies.copy(), joints.copy()
+        _, st = oracle.solver_solve(bo, cps, jo, oracle.SOLVE_AVX2, oracle.ISLAND_SINGLE, *iters)
+        bs, js = bodies.copy(), joints.copy()
+        ph = oracle.baseline_solve(bs, cps, js, iters[0], iters[1], 1, False, "strict")
+        assert bs.tobytes() == bo.tobytes() and js.tobytes() == jo.tobytes()
+        assert (ph.impulse_iterations, ph.displacement_iterations, ph.group_offset) == (st.impulse_iterations, st.displacement_iterations, st.group_offset)
+        b2, j2 = bodies.copy(), joints.copy()
+        oracle.baseline_solve(b2, cps, j2, iters[0], iters[1], 1, True, "strict")          # Sloppy batches, one thread: the same sequence
+        assert b2.tobytes() == bs.tobytes() and j2.tobytes() == js.tobytes()
+        bf, jf = bodies.copy(), joints.copy()
+        oracle.baseline_solve(bf, cps, jf, iters[0], iters[1], 1, False, "fast")
+        if iters[0] <= 20:
+            for f in ("x", "y"):
+                assert np.abs(bf["velocity"][f] - bo["velocity"][f]).max() <= 1e-3           # T1: |dvel| <= 1e-3 (SURVEY.md §8c)
+        bt, jt = bodies.copy(), joints.copy()
+        oracle.baseline_solve(bt, cps, jt, iters[0], iters[1], 3, True, "fast")              # racy like the reference: finite, clamped
+        assert np.isfinite(bt["velocity"]["x"]).all() and (jt["normal_acc"] >= 0).all()
+
+
+def test_cpu_baseline_broadphase_counts_match_the_oracle(oracle):
+    from helpers import presolve_state
+    from phyx_amd import scenes
+    bodies, _, _ = presolve_state(scenes.stack(12, 30), 3)
+    _, _, ent = oracle.broadphase_build(bodies)
+    cand, cnt, tests = oracle.sweep_candidates(ent)
+    for threads in (1, 3):
+        ph = oracle.baseline_broadphase(bodies, threads, 2, "fast")
+        assert ph.overlapping_pairs == len(cand) and ph.candidate_tests == tests

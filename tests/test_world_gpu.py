@@ -134,7 +134,7 @@ def test_sharded_world_at_config3_size_matches_the_oracle(oracle, built_lib):
     cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 20, 20)
     from phyx_amd.dist import Exchange
     k = 8
-    ranks = _LocalRanks(scene, k, Exchange.capacity_for(200001, 450000) // 4)
+    ranks = _LocalRanks(scene, k, Exchange.capacity_for(200001, 450000) // 1024 * 256)
     ow = oracle_world(scene)
     for step in range(2):
         seg = ranks.step(1.0 / 60.0, cfg)

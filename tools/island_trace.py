@@ -27,9 +27,9 @@ t = s.island_trace().astype(np.int64)
 t = t[t[:, 0] != 0]                                   # groups of other shards never ran
 t0 = t[:, 0].min()
 span = (t[:, 5].max() - t0)
-tick_us = span / traced_us                            # ticks per microsecond (the launch is the span, to first order)
+tick_us = 100.0                                       # wall_clock64(): constant 100 MHz
 names = ["start (dispatch ramp)", "records loaded", "refreshed", "pre-stepped", "swept", "written back"]
-print("island launch: %.1f us plain, %.1f us traced; %d workgroups; %.1f ticks/us" % (plain_us, traced_us, len(t), tick_us))
+print("island launch: %.1f us plain, %.1f us traced (HIP events); first start -> last end %.1f us; %d workgroups" % (plain_us, traced_us, span / tick_us, len(t)))
 print("%-24s %10s %10s %10s %10s   (us since the first workgroup started; phase = time since the previous stamp)" % ("stamp", "min", "median", "p95", "max"))
 prev = None
 for k in range(6):
