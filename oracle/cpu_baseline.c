@@ -24,7 +24,11 @@
  */
 #define _GNU_SOURCE
 #include <immintrin.h>
+#include <limits.h>
+#include <linux/futex.h>
 #include <math.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <pthread.h>
 #include <stdatomic.h>
 #include <stdint.h>
@@ -424,7 +428,7 @@ typedef struct pool pool;
 typedef void (*phase_fn)(pool*, int batch, int worker);
 struct pool {
     int threads;
-    atomic_int arrived, sense, next;
+    atomic_int arrived, sense, next, sleepers;
     int batches;
     phase_fn fn;
     int quit;
@@ -434,16 +438,25 @@ struct pool {
     pthread_t* th;
 };
 
+/* A waiter spins for a few tens of microseconds (the gap between two sweeps of the impulse loop), then sleeps on the futex:
+ * during the serial phases (PrepareIndices runs on the main thread only, like the reference) idle workers must not burn the
+ * cores — and their SMT siblings — the main thread is working on. */
 static void pool_barrier(pool* p, int* local_sense)
 {
     *local_sense ^= 1;
     if (atomic_fetch_add(&p->arrived, 1) == p->threads - 1) {
         atomic_store(&p->arrived, 0);
         atomic_store(&p->sense, *local_sense);
+        if (atomic_load(&p->sleepers)) syscall(SYS_futex, &p->sense, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
     } else {
-        int spins = 0;
-        while (atomic_load_explicit(&p->sense, memory_order_acquire) != *local_sense)
-            if (++spins > 2000) { sched_yield(); spins = 0; }
+        for (int spins = 0; atomic_load_explicit(&p->sense, memory_order_acquire) != *local_sense; ++spins) {
+            if (spins < 20000) { _mm_pause(); continue; }
+            atomic_fetch_add(&p->sleepers, 1);
+            while (atomic_load_explicit(&p->sense, memory_order_acquire) != *local_sense)
+                syscall(SYS_futex, &p->sense, FUTEX_WAIT_PRIVATE, *local_sense ^ 1, NULL, NULL, 0);
+            atomic_fetch_sub(&p->sleepers, 1);
+            break;
+        }
     }
 }
 

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "phx_solver_synchronize": (C.c_int, [_vp]),
     "phx_solver_set_schedule_reuse": (C.c_int, [_vp, _i32]),
     "phx_solver_set_trace": (C.c_int, [_vp, _i32]),
+    "phx_solver_get_wave_trace": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_get_island_trace": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_set_shard": (C.c_int, [_vp, _i32, _i32]),
     "phx_solver_set_body_state_bits": (C.c_int, [_vp, _i32]),

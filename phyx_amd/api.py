@@ -264,6 +264,15 @@ class Solver:
         check(self.L.phx_solver_get_island_trace(self.h, _ptr(out), n.value, C.byref(n)))
         return out[:n.value]
 
+    def wave_trace(self):
+        """(groups, waves, 4) uint64: per-wave colour-step cycles of the last traced solve."""
+        n, w = C.c_int32(0), C.c_int32(0)
+        check(self.L.phx_solver_get_island_trace(self.h, None, 0, C.byref(n)))
+        check(self.L.phx_solver_get_wave_trace(self.h, None, 0, C.byref(w)))
+        out = np.zeros((max(n.value, 1), w.value, 4), dtype=np.uint64)
+        check(self.L.phx_solver_get_wave_trace(self.h, _ptr(out), out.size, C.byref(w)))
+        return out[:n.value]
+
     def set_shard(self, shard, shard_count):
         """Sweep only the schedule groups g with g % shard_count == shard (multi-GPU island sharding)."""
         check(self.L.phx_solver_set_shard(self.h, shard, shard_count))

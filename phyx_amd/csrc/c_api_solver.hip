@@ -85,6 +85,12 @@ int phx_solver_get_island_trace(phx_solver* s, uint64_t* out, int32_t cap_groups
     return s->impl.get_island_trace(reinterpret_cast<unsigned long long*>(out), cap_groups, groups);
 }
 
+int phx_solver_get_wave_trace(phx_solver* s, uint64_t* out, int32_t cap_words, int32_t* waves_per_group)
+{
+    PHX_REQUIRE(s, "null handle");
+    return s->impl.get_wave_trace(reinterpret_cast<unsigned long long*>(out), cap_words, waves_per_group);
+}
+
 int phx_solver_get_groups(phx_solver* s, int32_t* offsets, int32_t cap, int32_t* count, int32_t* lds_count)
 {
     PHX_REQUIRE(s, "null handle");

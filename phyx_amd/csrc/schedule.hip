@@ -46,18 +46,20 @@ struct ColourScratch {
     void ensure(int nb) { if (used.size() < (size_t)nb * words) used.assign((size_t)nb * words, 0ull); }
 };
 
+// `comp` (per entry of `joints`): connected component of the joint (any labels; joints between two static bodies may carry -1).
 static int colour_joints(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-                         int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id)
+                         int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id, const std::vector<int>& comp)
 {
     colour.assign(joints.size(), 0);
     std::vector<int> perm;
     priority_order(joints, prio_id, perm);
+    // candidate A: smallest free colour (masks widen beyond 64 colours on demand)
+    std::vector<int> col_a(joints.size(), 0);
     for (;;) {
         sc.ensure(nb);
         const int words = sc.words;
         unsigned long long* used = sc.used.data();
         bool overflow = false;
-        int ncolours = 0;
         size_t done = 0;
         for (size_t i = 0; i < joints.size(); ++i) {
             const size_t k = (size_t)perm[i];
@@ -71,19 +73,74 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
                 if (~m) { c = w * 64 + __builtin_ctzll(~m); break; }
             }
             if (c < 0) { overflow = true; break; }
-            colour[k] = c;
+            col_a[k] = c;
             if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
             if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
-            ncolours = std::max(ncolours, c + 1);
             done = i + 1;
         }
         for (size_t i = 0; i < done; ++i)                      // leave the scratch clean for the next caller
             for (int body : {body1[joints[perm[i]]], body2[joints[perm[i]]]})
                 for (int w = 0; w < words; ++w) used[(size_t)body * words + w] = 0ull;
-        if (!overflow) return ncolours;
+        if (!overflow) break;
         sc.words *= 2;                                         // > 64 * words colours needed: widen the masks and redo
         sc.used.clear();
     }
+    // candidate B: two-ended (schedule.h), one 64-bit mask per body; a component it cannot colour within 64 colours keeps A
+    std::vector<int> col_b(joints.size(), 0);
+    std::vector<unsigned char> comp_bad;                       // per dense component
+    std::vector<int> dense(joints.size());
+    {
+        std::vector<std::pair<int, int>> keyed(joints.size());
+        for (size_t k = 0; k < joints.size(); ++k) keyed[k] = {comp[k], (int)k};
+        std::sort(keyed.begin(), keyed.end());
+        int count = 0;
+        for (size_t i = 0; i < keyed.size(); ++i) {
+            if (i == 0 || keyed[i].first != keyed[i - 1].first || keyed[i].first < 0) ++count;     // every static-static joint is its own class
+            dense[keyed[i].second] = count - 1;
+        }
+        comp_bad.assign(count, 0);
+    }
+    {
+        sc.ensure(nb);
+        const int words = sc.words;
+        unsigned long long* used = sc.used.data();             // word 0 of every body's mask row
+        std::vector<int> degree_of;                            // per touched body, via the same rows: count in a side map
+        std::vector<int> deg(nb, 0);
+        for (int j : joints) { deg[body1[j]]++; deg[body2[j]]++; }
+        for (size_t i = 0; i < joints.size(); ++i) {
+            const size_t k = (size_t)perm[i];
+            const int a = body1[joints[k]], b = body2[joints[k]];
+            const bool da = !is_static[a], db = !is_static[b];
+            unsigned long long m = 0;
+            if (da) m |= used[(size_t)a * words];
+            if (db) m |= used[(size_t)b * words];
+            const int klim = std::max(da ? deg[a] : 0, db ? deg[b] : 0);
+            const int c = colour_pick_two_ended(m, klim, (std::min(a, b) & 1) != 0);
+            if (c < 0) { comp_bad[dense[k]] = 1; continue; }
+            col_b[k] = c;
+            if (da) used[(size_t)a * words] |= 1ull << c;
+            if (db) used[(size_t)b * words] |= 1ull << c;
+        }
+        for (int j : joints) { used[(size_t)body1[j] * words] = 0ull; used[(size_t)body2[j] * words] = 0ull; }
+    }
+    // per component: colours in use under either candidate, the choice, the dense renumbering
+    const size_t ncomp = comp_bad.size();
+    std::vector<int> max_a(ncomp, -1);
+    std::vector<unsigned long long> seen_a(ncomp, 0ull), seen_b(ncomp, 0ull);
+    for (size_t k = 0; k < joints.size(); ++k) {
+        max_a[dense[k]] = std::max(max_a[dense[k]], col_a[k]);
+        if (col_a[k] < 64) seen_a[dense[k]] |= 1ull << col_a[k];
+        seen_b[dense[k]] |= 1ull << col_b[k];
+    }
+    int ncolours = 0;
+    for (size_t k = 0; k < joints.size(); ++k) {
+        const int d = dense[k];
+        const int count_a = max_a[d] + 1;                      // candidate A leaves no gaps inside a component
+        const bool use_b = !comp_bad[d] && __builtin_popcountll(seen_b[d]) < count_a;
+        colour[k] = use_b ? __builtin_popcountll(seen_b[d] & ((1ull << col_b[k]) - 1ull)) : col_a[k];
+        ncolours = std::max(ncolours, colour[k] + 1);
+    }
+    return ncolours;
 }
 
 // append one group made of `joints` coloured by `colour` (stable counting sort by colour)
@@ -119,13 +176,18 @@ static void touched_bodies(const std::vector<int>& joints, const int* body1, con
     for (int b = 0; b < nb; ++b) if (seen[b]) out.push_back(b);
 }
 
+static int components(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, std::vector<int>& root, std::vector<int>& number);
+
 void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out, const int* prio_id)
 {
     reset(out);
     std::vector<int> all(nj), colour;
     for (int j = 0; j < nj; ++j) all[j] = j;
     ColourScratch scratch;
-    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch, prio_id);
+    std::vector<int> root, number, comp(nj);
+    components(body1, body2, nj, is_static, nb, root, number);
+    for (int j = 0; j < nj; ++j) comp[j] = (is_static[body1[j]] && is_static[body2[j]]) ? -1 : number[root[is_static[body1[j]] ? body2[j] : body1[j]]];
+    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch, prio_id, comp);
     if (nj) {
         append_group(out, all, colour, ncol);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
@@ -228,7 +290,7 @@ struct LocalMap {
 };
 
 void build_bin(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-               const LdsCaps& caps, LocalMap& map, BinOut& out, const int* prio_id)
+               const LdsCaps& caps, LocalMap& map, BinOut& out, const int* prio_id, const int* comp_of)
 {
     out = BinOut{};
     map.reset((unsigned)joints.size() * 2u + 8u);
@@ -245,32 +307,55 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
     int nstatic = 0;
     for (int b : out.bodies) nstatic += is_static[b] ? 1 : 0;
     if ((int)out.bodies.size() > caps.max_bodies || (int)out.bodies.size() > 65535 || nstatic > caps.max_static) { out.rejected = true; return; }
-    // first-fit colouring in priority order on per-local-body masks
-    const int words = (caps.max_colours + 63) / 64;
-    std::vector<unsigned long long> used(out.bodies.size() * (size_t)words, 0ull);
-    std::vector<int> colour(joints.size());
+    // two first-fit candidates in priority order on per-local-body masks (schedule.h): A = smallest free colour,
+    // B = two-ended; keep the one with fewer colours
+    if (caps.max_colours > 64) { out.rejected = true; return; }          // one 64-bit mask per body (the device builder's limit)
+    std::vector<unsigned long long> used_a(out.bodies.size(), 0ull), used_b(out.bodies.size(), 0ull);
+    std::vector<int> degree(out.bodies.size(), 0);
+    std::vector<int> col_a(joints.size()), col_b(joints.size());
     std::vector<uint32_t> local(joints.size());
     std::vector<int> perm;
     priority_order(joints, prio_id, perm);
-    int ncol = 0;
-    for (size_t i = 0; i < joints.size(); ++i) {
-        const size_t k = (size_t)perm[i];
+    for (size_t k = 0; k < joints.size(); ++k) {
         bool fresh;
         const int a = *map.find_or_insert(body1[joints[k]], fresh), b = *map.find_or_insert(body2[joints[k]], fresh);
-        const bool da = !is_static[body1[joints[k]]], db = !is_static[body2[joints[k]]];
-        int c = -1;
-        for (int w = 0; w < words && c < 0; ++w) {
-            unsigned long long m = 0;
-            if (da) m |= used[(size_t)a * words + w];
-            if (db) m |= used[(size_t)b * words + w];
-            if (~m) c = w * 64 + __builtin_ctzll(~m);
-        }
-        if (c < 0 || c >= caps.max_colours) { out.rejected = true; return; }
-        if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
-        if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
-        colour[k] = c;
         local[k] = (uint32_t)a | ((uint32_t)b << 16);
-        ncol = std::max(ncol, c + 1);
+        degree[a]++; degree[b]++;
+    }
+    // per component of the bin (components are consecutive numbers): colours in use under either candidate
+    int comp_lo = 0x7fffffff, comp_hi = -1;
+    for (int j : joints) { comp_lo = std::min(comp_lo, comp_of[j]); comp_hi = std::max(comp_hi, comp_of[j]); }
+    const size_t span = joints.empty() ? 0 : (size_t)(comp_hi - comp_lo + 1);
+    std::vector<unsigned long long> seen_a(span, 0ull), seen_b(span, 0ull);
+    std::vector<unsigned char> bad_b(span, 0);
+    for (size_t i = 0; i < joints.size(); ++i) {
+        const size_t k = (size_t)perm[i];
+        const int a = (int)(local[k] & 0xFFFFu), b = (int)(local[k] >> 16);
+        const int ga = body1[joints[k]], gb = body2[joints[k]];
+        const bool da = !is_static[ga], db = !is_static[gb];
+        const size_t comp = (size_t)(comp_of[joints[k]] - comp_lo);
+        unsigned long long ma = 0, mb = 0;
+        if (da) { ma |= used_a[a]; mb |= used_b[a]; }
+        if (db) { ma |= used_a[b]; mb |= used_b[b]; }
+        const int ca = colour_pick_two_ended(ma, 0, false);
+        if (ca < 0 || ca >= caps.max_colours) { out.rejected = true; return; }
+        if (da) used_a[a] |= 1ull << ca;
+        if (db) used_a[b] |= 1ull << ca;
+        col_a[k] = ca; seen_a[comp] |= 1ull << ca;
+        const int klim = std::max(da ? degree[a] : 0, db ? degree[b] : 0);
+        const int cb = colour_pick_two_ended(mb, klim, (std::min(ga, gb) & 1) != 0);
+        if (cb < 0 || cb >= caps.max_colours) { bad_b[comp] = 1; col_b[k] = 0; }
+        else { if (da) used_b[a] |= 1ull << cb; if (db) used_b[b] |= 1ull << cb; col_b[k] = cb; seen_b[comp] |= 1ull << cb; }
+    }
+    int ncol = 0;
+    std::vector<int> colour(joints.size());
+    for (size_t k = 0; k < joints.size(); ++k) {                       // the component's choice, dense renumbering (increasing)
+        const size_t comp = (size_t)(comp_of[joints[k]] - comp_lo);
+        const bool use_b = !bad_b[comp] && __builtin_popcountll(seen_b[comp]) < __builtin_popcountll(seen_a[comp]);
+        const unsigned long long seen = use_b ? seen_b[comp] : seen_a[comp];
+        const int c = use_b ? col_b[k] : col_a[k];
+        colour[k] = __builtin_popcountll(seen & ((1ull << c) - 1ull));
+        ncol = std::max(ncol, colour[k] + 1);
     }
     // stable counting sort by colour
     out.colour_sizes.assign(ncol, 0);
@@ -351,7 +436,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         for (int b = b0; b < b1; ++b) {
             joints.assign(comp_joints.begin() + comp_count[bins[b].first], comp_joints.begin() + comp_count[bins[b].second]);
             if (bins[b].second - bins[b].first > 1) std::sort(joints.begin(), joints.end());      // joint-index order inside the bin
-            build_bin(joints, body1, body2, is_static, caps, map, built[b], prio_id);
+            build_bin(joints, body1, body2, is_static, caps, map, built[b], prio_id, comp_of.data());
             if (built[b].rejected) built[b].order = joints;
         }
     });
@@ -377,9 +462,10 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
     for (int j = 0; j < nj; ++j) if (comp_of[j] < 0) rest.push_back(j);
     if (!rest.empty()) {
         std::sort(rest.begin(), rest.end());
-        std::vector<int> colour;
+        std::vector<int> colour, rest_comp(rest.size());
+        for (size_t k = 0; k < rest.size(); ++k) rest_comp[k] = comp_of[rest[k]];
         ColourScratch scratch;
-        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch, prio_id);
+        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp);
         const size_t first = out.colour_offsets.size() - 1;
         append_group(out, rest, colour, ncol);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());

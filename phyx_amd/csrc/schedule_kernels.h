@@ -125,6 +125,8 @@ struct BinBuildView {
     const int* group_offsets;         // slots of bin g = [group_offsets[g], group_offsets[g+1])
     const phx_contact_joint* joints;
     const unsigned char* is_static;
+    const int* joint_comp;            // joint -> connected component number
+    const int* comp_rank;             // component -> its rank among the components of its bin (< joints of the bin)
     int nb, max_static;
     int* order;                       // out: slot -> joint
     unsigned* slot_local;             // out: local body1 | local body2 << 16
@@ -142,7 +144,11 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     __shared__ __align__(8) int ht_key[HT];              // later reused as the per-body priority table of the colouring
     static_assert((size_t)NB * 8 <= (size_t)HT * 4, "priority table must fit the hash table");
     __shared__ int ht_val[HT];                          // first occurrence position, later the local index
-    __shared__ unsigned long long used[NB];
+    __shared__ unsigned long long used[NB];              // candidate A (smallest free colour): colours taken per local body
+    __shared__ unsigned long long used_b[NB];            // candidate B (two-ended, schedule.h)
+    __shared__ int degree[NB];                           // joints of the bin on each local body
+    __shared__ unsigned long long seen_a[T], seen_b[T];  // per component of the bin: colours in use under either candidate
+    __shared__ unsigned char bad_b[T];
     __shared__ unsigned scan_lds[T / 64];
     __shared__ unsigned hist[64];                         // first slot of each colour
     __shared__ unsigned short wave_count[(T / 64) * 64];   // joints of colour c in wave w, then the exclusive sum over waves
@@ -151,7 +157,8 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     const int g = blockIdx.x, tid = threadIdx.x;
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
     for (int i = tid; i < HT; i += T) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
-    for (int i = tid; i < NB; i += T) used[i] = 0ull;
+    for (int i = tid; i < NB; i += T) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
+    seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0;
     if (tid < 64) hist[tid] = 0;
     if (tid == 0) { bad = 0; n_col = 0; }
     __syncthreads();
@@ -204,7 +211,7 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     }
     __syncthreads();
     int loc[2] = {0, 0};
-    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; }
+    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; atomicAdd(&degree[loc[0]], 1); atomicAdd(&degree[loc[1]], 1); }
     __syncthreads();
     // First-fit colouring in priority order by Jones-Plassmann rounds (schedule.h): every round, an uncoloured joint
     // that holds the highest priority on both its dynamic bodies takes the smallest colour free on them.  One winner
@@ -215,7 +222,9 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     const bool dyn0 = loc[0] >= n_static, dyn1 = loc[1] >= n_static;                  // static bodies sit first in the table
     const unsigned long long key = live ? colour_priority((unsigned)v.joints[j].contact_point_index, (unsigned)j) : 0ull;
     bool pending = live && fits;
-    int mycol = 0;
+    int mycol = 0, mycol_b = 0;
+    const bool from_top = ((b[0] < b[1] ? b[0] : b[1]) & 1) != 0;
+    const int comp = live ? v.comp_rank[v.joint_comp[j]] : 0;
     for (;;) {
         if (pending) { if (dyn0) atomicMax(&best[loc[0]], key); if (dyn1) atomicMax(&best[loc[1]], key); }
         __syncthreads();
@@ -230,12 +239,34 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
                 mycol = __builtin_ctzll(~m);
                 if (dyn0) used[loc[0]] |= 1ull << mycol;
                 if (dyn1) used[loc[1]] |= 1ull << mycol;
+                atomicOr(&seen_a[comp], 1ull << mycol);
+            }
+            {                                            // candidate B: the same winner, the two-ended choice
+                unsigned long long mb = 0;
+                if (dyn0) mb |= used_b[loc[0]];
+                if (dyn1) mb |= used_b[loc[1]];
+                const int d0 = dyn0 ? degree[loc[0]] : 0, d1 = dyn1 ? degree[loc[1]] : 0;
+                const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, from_top);
+                if (cb < 0) bad_b[comp] = 1;
+                else {
+                    mycol_b = cb;
+                    if (dyn0) used_b[loc[0]] |= 1ull << cb;
+                    if (dyn1) used_b[loc[1]] |= 1ull << cb;
+                    atomicOr(&seen_b[comp], 1ull << cb);
+                }
             }
             if (dyn0) best[loc[0]] = 0ull;
             if (dyn1) best[loc[1]] = 0ull;
             pending = false;
         }
         if (!__syncthreads_or(pending ? 1 : 0)) break;
+    }
+    // every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order
+    {
+        const bool use_b = !bad_b[comp] && __popcll(seen_b[comp]) < __popcll(seen_a[comp]);
+        const unsigned long long seen = use_b ? seen_b[comp] : seen_a[comp];
+        const int c = use_b ? mycol_b : mycol;
+        mycol = __popcll(seen & ((1ull << c) - 1ull));
     }
     // stable placement: slot = first slot of my colour + joints of my colour in earlier waves + earlier lanes of my wave
     for (int i = tid; i < (T / 64) * 64; i += T) wave_count[i] = 0;
@@ -289,7 +320,15 @@ struct JpView {
     const phx_contact_joint* joints;
     const unsigned char* is_static;
     int nb;
-    unsigned long long* used;         // per body: colours taken
+    unsigned long long* used;         // per body: colours taken (candidate A: smallest free colour)
+    unsigned long long* used_b;       // per body: colours taken under candidate B (two-ended, schedule.h)
+    unsigned* degree;                 // per body: joints of the group on it (filled by round 0)
+    unsigned* colour_b;               // per entry: candidate B's colour
+    const int* joint_comp;            // joint -> connected component (-1: both bodies static)
+    int ncomp;
+    unsigned long long* seen_a;       // per component (entry ncomp = the static-static joints): colours in use under A / B
+    unsigned long long* seen_b;
+    unsigned char* bad_b;             // per component: B ran out of its 64 colours
     unsigned* colour;                 // per entry: JP_NONE until coloured
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
     int* remaining;                   // per round: nonzero if some joint is still uncoloured after it
@@ -308,8 +347,9 @@ static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigne
         if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) { atomicOr(v.flags, 1); v.colour[k] = 0; continue; }
         const bool da = !v.is_static[a], db = !v.is_static[b];
         const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
-        if (round == 0) { v.touched[a] = 1u; v.touched[b] = 1u; }
+        if (round == 0) { v.touched[a] = 1u; v.touched[b] = 1u; atomicAdd(&v.degree[a], 1u); atomicAdd(&v.degree[b], 1u); }
         else if ((!da || cur[a] == key) && (!db || cur[b] == key)) {
+            const int comp = v.joint_comp[j] < 0 ? v.ncomp : v.joint_comp[j];
             unsigned long long m = 0;
             if (da) m |= v.used[a];
             if (db) m |= v.used[b];
@@ -319,6 +359,21 @@ static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigne
                 c = __builtin_ctzll(~m);
                 if (da) v.used[a] |= 1ull << c;
                 if (db) v.used[b] |= 1ull << c;
+                if (!((v.seen_a[comp] >> c) & 1ull)) atomicOr(&v.seen_a[comp], 1ull << c);      // (test first: a big island's joints all share one word)
+            }
+            {                                            // candidate B: the same winner, the two-ended choice
+                unsigned long long mb = 0;
+                if (da) mb |= v.used_b[a];
+                if (db) mb |= v.used_b[b];
+                const int d0 = da ? (int)v.degree[a] : 0, d1 = db ? (int)v.degree[b] : 0;
+                const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
+                if (cb < 0) v.bad_b[comp] = 1;
+                else {
+                    if (da) v.used_b[a] |= 1ull << cb;
+                    if (db) v.used_b[b] |= 1ull << cb;
+                    if (!((v.seen_b[comp] >> cb) & 1ull)) atomicOr(&v.seen_b[comp], 1ull << cb);
+                    v.colour_b[k] = (unsigned)cb;
+                }
             }
             v.colour[k] = (unsigned)c;
             continue;
@@ -328,6 +383,19 @@ static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigne
         left = true;
     }
     if (__any(left) && (threadIdx.x & 63) == 0) v.remaining[round] = 1;      // a flag, not a count: same-address atomics would serialise
+}
+
+// every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order
+static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
+        const int jc = v.joint_comp[v.ids[k]];
+        const int comp = jc < 0 ? v.ncomp : jc;
+        const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
+        const bool use_b = !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
+        const unsigned c = use_b ? v.colour_b[k] : v.colour[k];
+        v.colour[k] = (unsigned)__popcll((use_b ? sb : sa) & ((1ull << c) - 1ull));
+    }
 }
 
 static __global__ void __launch_bounds__(256) k_jp_hist(const unsigned* __restrict__ colour, int count, unsigned* __restrict__ hist)

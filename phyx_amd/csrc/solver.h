@@ -45,6 +45,7 @@ public:
     void set_schedule_reuse(bool on) { reuse_schedule_ = on; }
     void set_trace(bool on) { trace_islands_ = on; drop_graphs(); }
     int get_island_trace(unsigned long long* out, int cap_groups, int* groups);
+    int get_wave_trace(unsigned long long* out, int cap_words, int* waves_per_group);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
@@ -107,11 +108,13 @@ private:
     DevBuf<unsigned char> slot_colour_;
     DevBuf<unsigned long long> isl_visits_;
     // device schedule builder scratch
-    DevBuf<int> cc_parent_, joint_comp_, bin_of_comp_, grp_goff_, sb_small_;
+    DevBuf<int> cc_parent_, joint_comp_, bin_of_comp_, rank_of_comp_, grp_goff_, sb_small_;
     DevBuf<unsigned char> cc_static_;
     DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_, sort_scan_;
     DevBuf<unsigned long long> jp_best_[3], jp_used_;      // colouring of the HBM group on the device (schedule_kernels.h)
-    DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2];
+    DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
+    DevBuf<unsigned long long> jp_used_b_, jp_seen_;
+    DevBuf<unsigned char> jp_bad_b_;
     DevBuf<int> jp_small_;
     bool gpu_builder_ = true;
     phx_step_hook step_hook_ = nullptr;  // bench(): called with phase 1 between a step's local preparation and its sweeps

@@ -38,9 +38,9 @@ DeviceSolver::~DeviceSolver()
     for (hipEvent_t e : bench_events_) (void)hipEventDestroy(e);
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
-    cc_parent_.release(); joint_comp_.release(); bin_of_comp_.release(); grp_goff_.release(); sb_small_.release(); cc_static_.release();
+    cc_parent_.release(); joint_comp_.release(); bin_of_comp_.release(); rank_of_comp_.release(); grp_goff_.release(); sb_small_.release(); cc_static_.release();
     cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); for (int k = 0; k < 3; ++k) jp_best_[k].release();
-    jp_used_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
+    jp_used_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
@@ -293,11 +293,10 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
-    int nbins = 0, lds_slots = 0, where = 0;
-    if (!want_islands) {
-        // Single mode: one coupled system, every joint goes to the HBM group in joint order
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
-    } else {
+    int nbins = 0, lds_slots = 0, where = 0, ncomp_total = 0;
+    {
+    // (Single mode needs the components too: the colouring candidate is chosen per component, schedule.h — it then sends
+    //  every component to the HBM group)
     // 1. connected components: two hook + compress rounds (stacks converge in two, the second one only confirms it), and
     // 2. the components numbered in body order with their joints counted — queued behind them OPTIMISTICALLY: the 'did the
     //    last round still hook anything' flag comes back in the same round trip as the component count and sizes, and only
@@ -330,6 +329,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     }
     lap("components+count");
     const int ncomp = (int)ncomp_u;
+    ncomp_total = ncomp;
     if (ncomp > guess) {
         comp_size.resize(ncomp);
         PHX_TRY(rb_.add(comp_size.data() + guess, comp_size_.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
@@ -351,16 +351,18 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     int cap_joints = ISL_T, cap_bodies = ISL_B;
     for (int c = 0; c < ncomp; ++c) if ((int)comp_size[c] > ISL_T && (int)comp_size[c] <= ISL_T_BIG) { cap_joints = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
     sc.lds_lanes = cap_joints;
-    std::vector<int> bin_of(std::max(ncomp, 1), -1);
+    if (!want_islands) cap_joints = 0;          // Single mode: one coupled system, every component goes to the HBM group
+    std::vector<int> bin_of(std::max(ncomp, 1), -1), rank_of(std::max(ncomp, 1), 0);     // rank of a component inside its bin (schedule.h: the colouring candidate is chosen per component)
     {
-        int size = 0;
+        int size = 0, rank = 0;
         bool open = false;
         for (int c = 0; c < ncomp; ++c) {
             const int n = (int)comp_size[c];
             if (n == 0) continue;
-            if (n > cap_joints) { open = false; size = 0; continue; }            // -> HBM group
-            if (!open || size + n > cap_joints) { sc.group_offsets.push_back(sc.group_offsets.back()); ++nbins; open = true; size = 0; }
+            if (n > cap_joints || !want_islands) { open = false; size = 0; continue; }            // -> HBM group
+            if (!open || size + n > cap_joints) { sc.group_offsets.push_back(sc.group_offsets.back()); ++nbins; open = true; size = 0; rank = 0; }
             bin_of[c] = nbins - 1;
+            rank_of[c] = rank++;
             size += n;
             sc.group_offsets.back() += n;
         }
@@ -368,17 +370,23 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     lds_slots = sc.group_offsets.back();
     for (int c = 0; c < ncomp; ++c) if (bin_of[c] < 0) bin_of[c] = nbins;
     sc.lds_groups = nbins;
-    PHX_TRY(bin_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(grp_goff_.reserve(nbins + 2));
+    PHX_TRY(bin_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(rank_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(grp_goff_.reserve(nbins + 2));
     if (ncomp) PHX_HIP(hipMemcpyAsync(bin_of_comp_.p, bin_of.data(), (size_t)ncomp * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (ncomp) PHX_HIP(hipMemcpyAsync(rank_of_comp_.p, rank_of.data(), (size_t)ncomp * sizeof(int), hipMemcpyHostToDevice, stream_));
     PHX_HIP(hipMemcpyAsync(grp_goff_.p, sc.group_offsets.data(), (size_t)(nbins + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
     lap("bin");
 
     // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
-    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)bin_of_comp_.p, nj, nbins,
-                       sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2);
-    int bits = 1;
-    while ((1 << bits) <= nbins) ++bits;
-    PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_.p, stream_, &where));
+    if (nbins) {
+        hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)bin_of_comp_.p, nj, nbins,
+                           sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2);
+        int bits = 1;
+        while ((1 << bits) <= nbins) ++bits;
+        PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_.p, stream_, &where));
+    } else {                                    // no bins (Single mode, or nothing fits a workgroup): the HBM group is every joint, in joint order
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
+        PHX_HIP(hipMemsetAsync(sb_small_.p + 2, 0, sizeof(int), stream_));
+    }
     lap("sort");
 
     // 5. one workgroup per bin: body table, colouring, slot arrays
@@ -388,6 +396,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     if (nbins) {
         BinBuildView bv{};
         bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff_.p; bv.joints = d_joints; bv.is_static = cc_static_.p;
+        bv.joint_comp = joint_comp_.p; bv.comp_rank = rank_of_comp_.p;
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
         bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2;
@@ -431,6 +440,16 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = cc_static_.p; jv.nb = nb;
         jv.used = jp_used_.p; jv.colour = jp_keys_[0].p; jv.touched = jp_touched_.p;
         jv.remaining = jp_small_.p; jv.flags = jp_small_.p + JP_ROUNDS_MAX;
+        // the second colouring candidate and the per-component bookkeeping of the choice (schedule.h)
+        PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_degree_.reserve(nbs)); PHX_TRY(jp_colour_b_.reserve(rest));
+        PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
+        PHX_HIP(hipMemsetAsync(jp_used_b_.p, 0, (size_t)nbs * sizeof(unsigned long long), stream_));
+        PHX_HIP(hipMemsetAsync(jp_degree_.p, 0, (size_t)nbs * sizeof(unsigned), stream_));
+        PHX_HIP(hipMemsetAsync(jp_colour_b_.p, 0, (size_t)rest * sizeof(unsigned), stream_));
+        PHX_HIP(hipMemsetAsync(jp_seen_.p, 0, 2 * ((size_t)ncomp_total + 1) * sizeof(unsigned long long), stream_));
+        PHX_HIP(hipMemsetAsync(jp_bad_b_.p, 0, (size_t)ncomp_total + 1, stream_));
+        jv.used_b = jp_used_b_.p; jv.degree = jp_degree_.p; jv.colour_b = jp_colour_b_.p; jv.joint_comp = joint_comp_.p; jv.ncomp = ncomp_total;
+        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
         int round = 0;
         for (bool done = false; !done;) {
             if (round + JP_BATCH > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }       // pathological dependency chain: host builder
@@ -448,6 +467,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         }
         if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d Jones-Plassmann rounds\n", rest, round);
         lap("rest/colour");
+        hipLaunchKernelGGL(k_jp_choose, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
         // colour sizes, bodies touched, static slots: three small scans, one readback
         unsigned* hist = reinterpret_cast<unsigned*>(jp_small_.p + JP_ROUNDS_MAX + 4);
         hipLaunchKernelGGL(k_jp_hist, dim3(std::min(grid_for(rest), 256)), dim3(256), 0, stream_, (const unsigned*)jp_keys_[0].p, rest, hist);
@@ -558,11 +578,13 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         iv.first = shard_; iv.stride = shard_count_;
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
-        iv.trace = nullptr;
+        iv.trace = nullptr; iv.wave_trace = nullptr;
         if (trace_islands_) {
-            if (isl_trace_.reserve((size_t)std::max(lg, 1) * 8) != PHX_OK) return PHX_ERR_HIP;
-            PHX_HIP(hipMemsetAsync(isl_trace_.p, 0, (size_t)lg * 8 * sizeof(unsigned long long), stream_));
+            // 8 words per group, then 4 words per wave (16 waves at most) of every group
+            if (isl_trace_.reserve((size_t)std::max(lg, 1) * (8 + 64)) != PHX_OK) return PHX_ERR_HIP;
+            PHX_HIP(hipMemsetAsync(isl_trace_.p, 0, (size_t)lg * (8 + 64) * sizeof(unsigned long long), stream_));
             iv.trace = isl_trace_.p;
+            iv.wave_trace = isl_trace_.p + (size_t)lg * 8;
         }
         const bool big = sched_.lds_lanes > ISL_T;
         if (iv.trace && big)          hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
@@ -825,6 +847,19 @@ int DeviceSolver::get_island_trace(unsigned long long* out, int cap_groups, int*
     if (!trace_islands_ || !isl_trace_.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
     if (cap_groups < lg) { set_error("island trace buffer too small"); return PHX_ERR_CAPACITY; }
     if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p, (size_t)lg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PHX_OK;
+}
+
+int DeviceSolver::get_wave_trace(unsigned long long* out, int cap_words, int* waves_per_group)
+{
+    PHX_TRY(synchronize());
+    const int lg = sched_.valid ? sched_.lds_groups : 0;
+    const int wpg = sched_.lds_lanes > ISL_T ? ISL_T_BIG / 64 : ISL_T / 64;
+    if (waves_per_group) *waves_per_group = wpg;
+    if (!out) return PHX_OK;
+    if (!trace_islands_ || !isl_trace_.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
+    if (cap_words < lg * wpg * 4) { set_error("wave trace buffer too small"); return PHX_ERR_CAPACITY; }
+    if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p + (size_t)lg * 8, (size_t)lg * wpg * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
 

@@ -354,11 +354,12 @@ struct IslandView {
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
     unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
+    unsigned long long* wave_trace;   // null, or 4 words per wave of every group: cycles {working, at the barrier after work, idle steps}, counts
     unsigned long long* trace;        // null, or 8 words per group: shader-clock stamps of the kernel's phases (phx_solver_set_trace)
 };
 
 // phase stamps of the island kernel (tools/island_trace.py; the constant 100 MHz clock all XCDs share): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
-// 5 written back; word 6 = XCC id, word 7 = colours << 32 | impulse sweeps executed
+// 5 written back; word 6 = XCC id | s_memtime ticks of the whole workgroup << 4, word 7 = colours << 32 | impulse sweeps executed
 #define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = wall_clock64(); } while (0)
 
 template <int B>
@@ -408,6 +409,9 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
 
     const int group = iv.first + (int)blockIdx.x * iv.stride;
     PHX_ISL_STAMP(0);
+    const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
+    // TRACE: per wave, shader cycles spent in colour steps {working: in the joint update, then at the barrier; idle: whole step}
+    unsigned long long tw_work = 0, tw_bar = 0, tw_idle = 0; unsigned tw_nwork = 0, tw_nidle = 0;
     const int4 d = iv.desc[group];
     const int ncol = iv.ncol[group];
     const int tid = threadIdx.x;
@@ -510,6 +514,8 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         if (!imp_on && !disp_on) break;
         if (tid == 0) { flag_imp[(it + 1) & 1] = 0; flag_disp[(it + 1) & 1] = 0; }   // read last at the end of sweep it-1
         for (int c = 0; c < ncol; ++c) {
+            const unsigned long long ts0 = TRACE ? __builtin_readcyclecounter() : 0ull;
+            const bool working = TRACE && __any(col == c);
             if (col == c) {
                 if (imp_on) {
                     float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
@@ -570,7 +576,12 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
                     }
                 }
             }
+            const unsigned long long ts1 = TRACE ? __builtin_readcyclecounter() : 0ull;
             __syncthreads();
+            if (TRACE) {
+                const unsigned long long ts2 = __builtin_readcyclecounter();
+                if (working) { tw_work += ts1 - ts0; tw_bar += ts2 - ts1; ++tw_nwork; } else { tw_idle += ts2 - ts0; ++tw_nidle; }
+            }
         }
         if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[it & 1] != 0; }
         if (disp_on) { done_disp = it + 1; disp_alive = flag_disp[it & 1] != 0; }
@@ -601,11 +612,16 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         atomicMax(&iv.executed[2 * slot + 1], done_disp);
         atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
     }
+    if (TRACE && iv.wave_trace && (tid & 63) == 0) {
+        unsigned long long* w = iv.wave_trace + ((size_t)group * (T / 64) + (tid >> 6)) * 4;
+        w[0] = tw_work; w[1] = tw_bar; w[2] = tw_idle; w[3] = ((unsigned long long)tw_nwork << 32) | tw_nidle;
+    }
     if (TRACE) {
         __builtin_amdgcn_s_waitcnt(0);         // the stores above have left the wave
         PHX_ISL_STAMP(5);
         if (tid == 0) {
-            iv.trace[(size_t)group * 8 + 6] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
+            iv.trace[(size_t)group * 8 + 6] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF)    // HW_REG_XCC_ID[3:0]
+                                              | ((__builtin_readcyclecounter() - cycles0) << 4);                                  // + s_memtime ticks start -> end
             iv.trace[(size_t)group * 8 + 7] = ((unsigned long long)ncol << 32) | (unsigned)done_imp;
         }
     }

@@ -103,7 +103,7 @@ def step_sharded(world, dt, configuration, exchange):
     groups, all-gather everyone's results, scatter them, integrate.  A rank whose first half fails still enters the
     collective (so its peers are not left hanging in it) with a non-zero status word, then re-raises; the peers see
     PHX_XCH_PEER_ERROR at their next Exchange.check()."""
-    from .api import PhxError
+    from ._lib import PhxError
     try:
         seg = world.StepBegin(dt, configuration)
     except PhxError:

@@ -167,7 +167,8 @@ def test_exchange_detects_a_diverged_or_failed_peer(built_lib):
     ranks = _LocalRanks(scene, 2, cap)
     ranks.step(1.0 / 60.0, cfg)
     assert [w.solver.exchange_status() for w in ranks.worlds] == [0, 0]
-    # rank 1's segment never arrives at rank 0 (its slot keeps the previous step's header): serial mismatch
+    # rank 1's segment never arrives at rank 0: its slot keeps the previous step's bytes — an old serial, or no header at
+    # all where the segment length changed with the schedule
     segs = [w.StepBegin(1.0 / 60.0, cfg) for w in ranks.worlds]
     for w in ranks.worlds:
         w.sync()
@@ -176,7 +177,7 @@ def test_exchange_detects_a_diverged_or_failed_peer(built_lib):
     ranks.recv[1].copy_from(ranks.send[1], segs[0], dst_offset=segs[0], stream=ranks.worlds[1].stream_ptr())
     for w in ranks.worlds:
         w.StepEnd(1.0 / 60.0)
-    assert ranks.worlds[0].solver.exchange_status() & phyx_amd.api.XCH_SERIAL_MISMATCH
+    assert ranks.worlds[0].solver.exchange_status() & (phyx_amd.api.XCH_SERIAL_MISMATCH | phyx_amd.api.XCH_BAD_SEGMENT)
     assert ranks.worlds[1].solver.exchange_status() == 0
     # a peer posts a failure status; a zeroed slot is a segment that was never written
     ranks.worlds[1].sync()

@@ -45,6 +45,18 @@ sweep_us = (t[:, 4] - t[:, 3]) / tick_us
 steps = ncol * np.maximum(sw, 1)
 print("colours per group: min %d median %d max %d; sweeps executed: min %d max %d" % (ncol.min(), np.median(ncol), ncol.max(), sw.min(), sw.max()))
 print("us per colour step (sweeps / (colours x sweeps)): median %.3f p95 %.3f  = %.0f cycles at 2.4 GHz" % (np.median(sweep_us / steps), np.percentile(sweep_us / steps, 95), np.median(sweep_us / steps) * 2400))
+ticks = t[:, 6] >> 4
+wall = (t[:, 5] - t[:, 0]) / tick_us
+print("s_memtime ticks per microsecond of wall clock (per workgroup): median %.1f min %.1f max %.1f" % (np.median(ticks / wall), (ticks / wall).min(), (ticks / wall).max()))
+t[:, 6] &= 0xF
 for x in range(8):
     m = t[:, 6] == x
     if m.any(): print("  XCC %d: %4d workgroups, start median %.1f us, end median %.1f us" % (x, m.sum(), np.median((t[m, 0] - t0) / tick_us), np.median((t[m, 5] - t0) / tick_us)))
+
+wt = s.wave_trace().astype(np.float64)
+nwork = (s.wave_trace()[:, :, 3] >> np.uint64(32)).astype(np.float64); nidle = (s.wave_trace()[:, :, 3] & np.uint64(0xffffffff)).astype(np.float64)
+m = nwork > 0
+print("per working colour step of a wave (shader cycles, incl. ~2 s_memtime reads): joint update median %.0f p95 %.0f; barrier behind it median %.0f"
+      % (np.median(wt[:, :, 0][m] / nwork[m]), np.percentile(wt[:, :, 0][m] / nwork[m], 95), np.median(wt[:, :, 1][m] / nwork[m])))
+mi = nidle > 0
+print("per idle colour step of a wave: median %.0f cycles; working steps per wave: median %.0f of %.0f steps" % (np.median(wt[:, :, 2][mi] / nidle[mi]), np.median(nwork[m]), np.median((nwork + nidle)[m])))
