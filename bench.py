@@ -173,6 +173,30 @@ def main():
         live_tot = run(cfg, 2, args.steps, 3)
         solver.set_schedule_reuse(True)
 
+    # ---- N > 1 side measurement (round-1 headline, kept for comparison): weak scaling — every rank solves its OWN slab of 1000
+    #      columns of one N*1000-column world, no data crosses ranks, the ranks meet at a 4-byte all-reduce per step
+    weak = None
+    if world > 1 and not args.no_secondary:
+        first_col, ncols = pdist.shard_columns(args.columns * world, rank, world)
+        wslab = phyx_amd.World(device, gravity=-200.0)
+        wslab.add_scene(scenes.stack(ncols, args.rows, x_offset_columns=first_col))
+        for _ in range(args.scene_steps):
+            wslab.Update(1.0 / 60.0, cfg)
+        wslab.PreSolve(1.0 / 60.0)
+        arrs = [phyx_amd.DeviceArray(a, device) for a in (wslab.bodies, wslab.contactPoints, wslab.contactJoints)]
+        wsolver = phyx_amd.Solver(device)
+        whook = group.stream_hook(wsolver.stream_ptr())
+        for _ in range(2):
+            wsolver.bench(arrs[0], arrs[1], arrs[2], cfg, 0, 1, hook=whook)
+        group.barrier(); wsolver.synchronize()
+        t0 = time.perf_counter()
+        r = wsolver.bench(arrs[0], arrs[1], arrs[2], cfg, 0, args.steps, hook=whook)
+        wsolver.synchronize(); group.barrier()
+        wel = group.reduce_max(time.perf_counter() - t0)
+        wvis = group.reduce_sum(r.joint_visits)
+        weak = {"what": "every rank solves its own 1000-column slab (%d joints here), per-step 4-byte all-reduce, no data exchange" % arrs[2].count,
+                "ms_per_step": 1e3 * wel / max(args.steps, 1), "joint_visits_per_sec": wvis / wel, "scaling": "weak"}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed_max / max(args.steps, 1)
         launches = max(main_tot["launches"], 1)
@@ -235,6 +259,8 @@ def main():
                       "joint_visits_per_sec_sweeps_only": main_tot["visits"] / (main_tot["sweep_ms"] * 1e-3) if main_tot["sweep_ms"] > 0 else None},
             "roofline": roof,
         }
+        if weak is not None:
+            out["extra"]["weak_scaled_slabs"] = weak
         if world > 1:
             out["extra"]["exchange"] = {"segment_bytes_per_rank": solver.exchange_segment_bytes(), "status": exchange_status,
                                         "what": "6 floats per body + 2 per joint of the rank's groups behind a 32-byte header {serial, status, "

@@ -51,19 +51,29 @@ def main(tag, dominant):
            "dominant_kernel": dom[0] if dom else None,
            "hbm_bytes_per_launch": kernels[dom[0]]["hbm_bytes_per_launch_corrected"] if dom else None,
            "kernels": kernels}
-    # duration of the dominant kernel over the launches bench.py times: the kernel-trace stats also average the scene's own
-    # first world steps (3 launches on a stack that has hardly any contacts yet), so recompute from the raw trace
+    # duration of the solve kernels over the launches bench.py times: the kernel-trace stats also average the scene's own first
+    # world steps (3 launches on a stack that has hardly any contacts yet) and the 0-iteration phase measurement, so recompute
+    # from the raw trace: the launches of the main timed region are the ones within 25 % of the median
     trace = os.path.join(SRC, "trace_kernel_trace.csv")
-    if dom and os.path.exists(trace):
-        rows = [r for r in csv.DictReader(open(trace)) if r["Kernel_Name"] == dom[0]]
-        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-        timed = us[3:]                                  # bench.py --scene-steps 3
-        out["dominant_kernel_launch_us"] = {"all_launches": us, "scene_steps_dropped": 3, "mean_of_the_rest": sum(timed) / max(len(timed), 1),
-                                            "min": min(timed) if timed else None, "max": max(timed) if timed else None}
+    if os.path.exists(trace):
+        rows_all = list(csv.DictReader(open(trace)))
+        for key, needle in (("dominant_kernel_launch_us", dominant), ("hbm_colour_kernel_launch_us", "k_solve_colour<true, true>"), ("tail_kernel_launch_us", "k_solve_tail")):
+            us = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows_all if needle in r["Kernel_Name"])
+            if not us:
+                continue
+            med = us[len(us) // 2]
+            timed = [u for u in us if 0.75 * med <= u <= 1.25 * med]
+            out[key] = {"launches": len(us), "median": med, "mean_within_25pct_of_median": sum(timed) / len(timed), "min": us[0], "max": us[-1]}
+    for name, k in kernels.items():
+        if "k_solve_colour<true, true>" in name:
+            out["hbm_colour_kernel"] = name
+            out["hbm_colour_bytes_per_launch"] = k["hbm_bytes_per_launch_corrected"]
+    for extra in ("world_kernel_stats.csv", "world_step_timeline.txt"):
+        if os.path.exists(os.path.join(SRC, extra)):
+            shutil.copy(os.path.join(SRC, extra), os.path.join(DST, tag + "_" + extra))
     json.dump(out, open(os.path.join(DST, tag + "_pmc_traffic.json"), "w"), indent=1)
     print("dominant:", out["dominant_kernel"], "->", out["hbm_bytes_per_launch"], "B per launch")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else "k_solve_islands")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02", sys.argv[2] if len(sys.argv) > 2 else "k_solve_islands<512")
