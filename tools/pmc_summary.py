@@ -21,11 +21,17 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def per_kernel(path):
-    agg = collections.defaultdict(lambda: [0, 0.0])
+    """Counter sums per kernel.  One kernel is launched with several grids (bench.py's side measurements shard the island
+    launch, the world steps have fewer groups): per kernel only the dispatches of its MOST FREQUENT grid size are kept — for the
+    island kernel that is the full 999-workgroup launch of the timed region."""
+    rows = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"]
-        agg[k][0] += 1
-        agg[k][1] += float(r["Counter_Value"])
+        rows[r["Kernel_Name"]].append((r["Grid_Size"], float(r["Counter_Value"])))
+    agg = {}
+    for k, v in rows.items():
+        grid = collections.Counter(g for g, _ in v).most_common(1)[0][0]
+        kept = [x for g, x in v if g == grid]
+        agg[k] = [len(kept), sum(kept), grid]
     return agg
 
 
@@ -39,11 +45,11 @@ def main(tag, dominant):
     write = per_kernel(os.path.join(SRC, "pmc_write_counter_collection.csv"))
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
-        nf, vf = fetch.get(k, [0, 0.0])
-        nw, vw = write.get(k, [0, 0.0])
+        nf, vf, grid = fetch.get(k, [0, 0.0, None])
+        nw, vw, _ = write.get(k, [0, 0.0, None])
         f = vf / nf * 1024 if nf else 0.0
         w = vw / nw * 1024 if nw else 0.0
-        kernels[k] = {"launches": max(nf, nw), "fetch_bytes_per_launch_raw": f, "write_bytes_per_launch_raw": w,
+        kernels[k] = {"launches": max(nf, nw), "grid_size": grid, "fetch_bytes_per_launch_raw": f, "write_bytes_per_launch_raw": w,
                       "hbm_bytes_per_launch_raw": f + w, "hbm_bytes_per_launch_corrected": 2 * f + w}
     dom = [k for k in kernels if dominant in k]
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline",
