@@ -141,9 +141,10 @@ int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on);
  * the group count (out may be NULL to query it). */
 int phx_solver_set_trace(phx_solver* s, int32_t on);
 int phx_solver_get_island_trace(phx_solver* s, uint64_t* out, int32_t cap_groups, int32_t* groups);
-/* per wave of every LDS group (groups x *waves_per_group x 4 words): shader cycles spent in colour steps in which the wave
- * worked {[0] in the joint update, [1] at the barrier behind it}, [2] cycles of the steps it only waited in,
- * [3] working steps << 32 | idle steps */
+/* per wave of every LDS group (groups x *waves_per_group x 8 words): shader cycles spent in colour steps in which the wave
+ * worked {[0] in the joint update with at most 32 lanes active, [1] at the barrier behind it}, [2] cycles of the steps it only
+ * waited in, [3] working steps with at most 32 lanes << 32 | idle steps, [4] cycles in the joint update with more than 32
+ * lanes active, [5] such steps */
 int phx_solver_get_wave_trace(phx_solver* s, uint64_t* out, int32_t cap_words, int32_t* waves_per_group);
 
 /* Post-solve exchange of an island-sharded solve (BASELINE config 3; counterpart of the reference merging every island's

@@ -621,6 +621,41 @@ int phxb_solve(phxo_body* bodies, int nb, const phxo_contact_point* cps, phxo_co
     return 0;
 }
 
+/* ---- test hooks (tests/test_oracle_pins.py pins them against the reference's headers) ---------------------------------- */
+/* 32-bit word offset of a field of the pack8 block = ContactJointPacked<8> (ref: Solver.h:26-45); same field numbering as
+ * oracle/ref_harness/leaf_harness.cpp::ref_packed_offset */
+#include <stddef.h>
+int phxb_pack8_offset(int field)
+{
+    switch (field) {
+    case 0: return (int)offsetof(pack8, b1) / 4;
+    case 1: return (int)offsetof(pack8, b2) / 4;
+    case 2: return (int)offsetof(pack8, cp) / 4;
+    case 3: return (int)(offsetof(pack8, n) + offsetof(lim8, p1x)) / 4;
+    case 4: return (int)(offsetof(pack8, n) + offsetof(lim8, cim)) / 4;
+    case 5: return (int)offsetof(pack8, n_acc) / 4;
+    case 6: return (int)offsetof(pack8, n_dst) / 4;
+    case 7: return (int)offsetof(pack8, n_dstd) / 4;
+    case 8: return (int)offsetof(pack8, n_accd) / 4;
+    case 9: return (int)(offsetof(pack8, f) + offsetof(lim8, p1x)) / 4;
+    case 10: return (int)(offsetof(pack8, f) + offsetof(lim8, cim)) / 4;
+    case 11: return (int)offsetof(pack8, f_acc) / 4;
+    case 12: return (int)sizeof(pack8) / 4;
+    }
+    return -1;
+}
+/* the 8-lane gather / scatter of 16-byte SolveBody records (counterparts of ref: base/SIMD_AVX2.h:324-377) */
+void phxb_test_gather8(const void* base, const int32_t* idx, float* out32)
+{
+    __m256 x, y, z, t;
+    gather8((const sbody*)base, idx, &x, &y, &z, &t);
+    _mm256_storeu_ps(out32, x); _mm256_storeu_ps(out32 + 8, y); _mm256_storeu_ps(out32 + 16, z); _mm256_storeu_ps(out32 + 24, t);
+}
+void phxb_test_scatter8(const float* in32, void* base, const int32_t* idx)
+{
+    scatter8((sbody*)base, idx, _mm256_loadu_ps(in32), _mm256_loadu_ps(in32 + 8), _mm256_loadu_ps(in32 + 16), _mm256_loadu_ps(in32 + 24));
+}
+
 /* ---- broadphase -------------------------------------------------------------------------------------------------- */
 typedef struct { uint32_t value, index; } sort_entry;                                     /* ref: Collider.h:52-56 */
 typedef struct { float minx, maxx, centery, extenty; uint32_t index; } bp_entry;          /* ref: Collider.h:45-50 */

@@ -24,6 +24,27 @@
 #include "base/RadixSort.h"
 #include "base/SIMD.h"
 
+template <int N> static int packed_offset(int field)
+{
+    typedef ContactJointPacked<N> P;
+    switch (field) {
+    case 0: return (int)offsetof(P, body1Index) / 4;
+    case 1: return (int)offsetof(P, body2Index) / 4;
+    case 2: return (int)offsetof(P, contactPointIndex) / 4;
+    case 3: return (int)(offsetof(P, normalLimiter) + offsetof(ContactLimiterPacked<N>, normalProjector1X)) / 4;
+    case 4: return (int)(offsetof(P, normalLimiter) + offsetof(ContactLimiterPacked<N>, compInvMass)) / 4;
+    case 5: return (int)offsetof(P, normalLimiter_accumulatedImpulse) / 4;
+    case 6: return (int)offsetof(P, normalLimiter_dstVelocity) / 4;
+    case 7: return (int)offsetof(P, normalLimiter_dstDisplacingVelocity) / 4;
+    case 8: return (int)offsetof(P, normalLimiter_accumulatedDisplacingImpulse) / 4;
+    case 9: return (int)(offsetof(P, frictionLimiter) + offsetof(ContactLimiterPacked<N>, normalProjector1X)) / 4;
+    case 10: return (int)(offsetof(P, frictionLimiter) + offsetof(ContactLimiterPacked<N>, compInvMass)) / 4;
+    case 11: return (int)offsetof(P, frictionLimiter_accumulatedImpulse) / 4;
+    case 12: return (int)sizeof(P) / 4;
+    }
+    return -1;
+}
+
 extern "C" {
 
 // struct sizes/offsets the C-ABI and the oracle rely on
@@ -163,5 +184,43 @@ float ref_simd8_lane0(int op, float x, float y)
     return out[0];
 }
 #endif
+
+// ContactJointPacked<N> field offsets in 32-bit words (ref: Solver.h:7-45): what the 8-wide CPU baseline's pack8 mirrors.
+// field: 0 body1Index 1 body2Index 2 contactPointIndex 3 normalLimiter.normalProjector1X 4 normalLimiter.compInvMass
+//        5 normalLimiter_accumulatedImpulse 6 normalLimiter_dstVelocity 7 normalLimiter_dstDisplacingVelocity
+//        8 normalLimiter_accumulatedDisplacingImpulse 9 frictionLimiter.normalProjector1X 10 frictionLimiter.compInvMass
+//        11 frictionLimiter_accumulatedImpulse 12 sizeof
+int ref_packed_offset(int n, int field) { return n == 8 ? packed_offset<8>(field) : n == 4 ? packed_offset<4>(field) : packed_offset<1>(field); }
+
+#ifdef __AVX2__
+// the gather / scatter of eight 16-byte SolveBody records the AVX2 solve loops use (ref: base/SIMD_AVX2.h:324-377):
+// out32 = {lane0..7 of v0, of v1, of v2, of v3}
+void ref_loadindexed4_v8(const void* base, const int* indices, unsigned stride, float* out32)
+{
+    simd::V8f v0, v1, v2, v3;
+    simd::loadindexed4(v0, v1, v2, v3, base, indices, stride);
+    _mm256_storeu_ps(out32, v0.v); _mm256_storeu_ps(out32 + 8, v1.v); _mm256_storeu_ps(out32 + 16, v2.v); _mm256_storeu_ps(out32 + 24, v3.v);
+}
+void ref_storeindexed4_v8(const float* in32, void* base, const int* indices, unsigned stride)
+{
+    simd::V8f v0, v1, v2, v3;
+    v0.v = _mm256_loadu_ps(in32); v1.v = _mm256_loadu_ps(in32 + 8); v2.v = _mm256_loadu_ps(in32 + 16); v3.v = _mm256_loadu_ps(in32 + 24);
+    simd::storeindexed4(v0, v1, v2, v3, base, indices, stride);
+}
+#endif
+
+// insert / erase / insert run of the pair set in which no inserted key is ever already present (so the first-tombstone
+// insertion defect of base/DenseHash.h:152-162 cannot create a duplicate): ops[i] = 0 insert, 1 erase; afterwards
+// member[i] = contains(pairs[i]) and the return value is size()
+size_t ref_pairset_mixed_run(const unsigned* pairs, const unsigned char* ops, size_t n, unsigned char* member)
+{
+    DenseHashSet<std::pair<unsigned, unsigned>> set;
+    for (size_t i = 0; i < n; ++i) {
+        const std::pair<unsigned, unsigned> key(pairs[2 * i], pairs[2 * i + 1]);
+        if (ops[i] == 0) set.insert(key); else set.erase(key);
+    }
+    for (size_t i = 0; i < n; ++i) member[i] = set.contains(std::make_pair(pairs[2 * i], pairs[2 * i + 1])) ? 1 : 0;
+    return set.size();
+}
 
 } // extern "C"

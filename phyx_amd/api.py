@@ -265,11 +265,11 @@ class Solver:
         return out[:n.value]
 
     def wave_trace(self):
-        """(groups, waves, 4) uint64: per-wave colour-step cycles of the last traced solve."""
+        """(groups, waves, 8) uint64: per-wave colour-step cycles of the last traced solve."""
         n, w = C.c_int32(0), C.c_int32(0)
         check(self.L.phx_solver_get_island_trace(self.h, None, 0, C.byref(n)))
         check(self.L.phx_solver_get_wave_trace(self.h, None, 0, C.byref(w)))
-        out = np.zeros((max(n.value, 1), w.value, 4), dtype=np.uint64)
+        out = np.zeros((max(n.value, 1), w.value, 8), dtype=np.uint64)
         check(self.L.phx_solver_get_wave_trace(self.h, _ptr(out), out.size, C.byref(w)))
         return out[:n.value]
 

@@ -580,9 +580,9 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
         iv.trace = nullptr; iv.wave_trace = nullptr;
         if (trace_islands_) {
-            // 8 words per group, then 4 words per wave (16 waves at most) of every group
-            if (isl_trace_.reserve((size_t)std::max(lg, 1) * (8 + 64)) != PHX_OK) return PHX_ERR_HIP;
-            PHX_HIP(hipMemsetAsync(isl_trace_.p, 0, (size_t)lg * (8 + 64) * sizeof(unsigned long long), stream_));
+            // 8 words per group, then 8 words per wave (16 waves at most) of every group
+            if (isl_trace_.reserve((size_t)std::max(lg, 1) * (8 + 128)) != PHX_OK) return PHX_ERR_HIP;
+            PHX_HIP(hipMemsetAsync(isl_trace_.p, 0, (size_t)lg * (8 + 128) * sizeof(unsigned long long), stream_));
             iv.trace = isl_trace_.p;
             iv.wave_trace = isl_trace_.p + (size_t)lg * 8;
         }
@@ -858,8 +858,8 @@ int DeviceSolver::get_wave_trace(unsigned long long* out, int cap_words, int* wa
     if (waves_per_group) *waves_per_group = wpg;
     if (!out) return PHX_OK;
     if (!trace_islands_ || !isl_trace_.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
-    if (cap_words < lg * wpg * 4) { set_error("wave trace buffer too small"); return PHX_ERR_CAPACITY; }
-    if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p + (size_t)lg * 8, (size_t)lg * wpg * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (cap_words < lg * wpg * 8) { set_error("wave trace buffer too small"); return PHX_ERR_CAPACITY; }
+    if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p + (size_t)lg * 8, (size_t)lg * wpg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
 

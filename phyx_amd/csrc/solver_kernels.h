@@ -354,7 +354,7 @@ struct IslandView {
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
     unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
-    unsigned long long* wave_trace;   // null, or 4 words per wave of every group: cycles {working, at the barrier after work, idle steps}, counts
+    unsigned long long* wave_trace;   // null, or 8 words per wave of every group: cycles {working with <= 32 lanes, at the barrier after work, idle steps}, counts, cycles working with > 32 lanes, count
     unsigned long long* trace;        // null, or 8 words per group: shader-clock stamps of the kernel's phases (phx_solver_set_trace)
 };
 
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     PHX_ISL_STAMP(0);
     const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
     // TRACE: per wave, shader cycles spent in colour steps {working: in the joint update, then at the barrier; idle: whole step}
-    unsigned long long tw_work = 0, tw_bar = 0, tw_idle = 0; unsigned tw_nwork = 0, tw_nidle = 0;
+    unsigned long long tw_work = 0, tw_bar = 0, tw_idle = 0, tw_work_big = 0; unsigned tw_nwork = 0, tw_nidle = 0, tw_nbig = 0;
     const int4 d = iv.desc[group];
     const int ncol = iv.ncol[group];
     const int tid = threadIdx.x;
@@ -580,7 +580,10 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
             __syncthreads();
             if (TRACE) {
                 const unsigned long long ts2 = __builtin_readcyclecounter();
-                if (working) { tw_work += ts1 - ts0; tw_bar += ts2 - ts1; ++tw_nwork; } else { tw_idle += ts2 - ts0; ++tw_nidle; }
+                if (working) {
+                    if (__popcll(__ballot(col == c)) > 32) { tw_work_big += ts1 - ts0; ++tw_nbig; } else { tw_work += ts1 - ts0; ++tw_nwork; }
+                    tw_bar += ts2 - ts1;
+                } else { tw_idle += ts2 - ts0; ++tw_nidle; }
             }
         }
         if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[it & 1] != 0; }
@@ -613,8 +616,8 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
     }
     if (TRACE && iv.wave_trace && (tid & 63) == 0) {
-        unsigned long long* w = iv.wave_trace + ((size_t)group * (T / 64) + (tid >> 6)) * 4;
-        w[0] = tw_work; w[1] = tw_bar; w[2] = tw_idle; w[3] = ((unsigned long long)tw_nwork << 32) | tw_nidle;
+        unsigned long long* w = iv.wave_trace + ((size_t)group * (T / 64) + (tid >> 6)) * 8;
+        w[0] = tw_work; w[1] = tw_bar; w[2] = tw_idle; w[3] = ((unsigned long long)tw_nwork << 32) | tw_nidle; w[4] = tw_work_big; w[5] = tw_nbig;
     }
     if (TRACE) {
         __builtin_amdgcn_s_waitcnt(0);         // the stores above have left the wave

@@ -159,6 +159,44 @@ def main():
         for op, name in enumerate(("flipsign", "max", "abs")):
             out["simd%d_%s" % (width, name)] = np.array([fn(op, float(a), float(b)) for a, b in zip(sx, sy)], dtype=np.float32)
 
+    # ContactJointPacked<N> field offsets in words, N = 1, 4, 8 (ref: Solver.h:7-45)
+    out["packed_offsets"] = np.array([[R.ref_packed_offset(n, f) for f in range(13)] for n in (1, 4, 8)], dtype=np.int32)
+
+    # the AVX2 gather / scatter of eight 16-byte SolveBody records (ref: base/SIMD_AVX2.h:324-377)
+    import ctypes as C
+    recs = rng.standard_normal((64, 4)).astype(np.float32)
+    base = np.zeros(64 * 4 + 16, dtype=np.float32)
+    off = (-base.ctypes.data // 4) % 4                          # 16-byte aligned start inside the buffer
+    arr = base[off:off + 256].reshape(64, 4)
+    arr[:] = recs
+    idx = rng.permutation(64)[:8 * 6].astype(np.int32).reshape(6, 8)
+    g = np.zeros((6, 32), dtype=np.float32)
+    for k in range(6):
+        R.ref_loadindexed4_v8(C.c_void_p(arr.ctypes.data), idx[k].ctypes.data_as(C.c_void_p), 16, g[k].ctypes.data_as(C.c_void_p))
+    out["gather_records"], out["gather_indices"], out["gather_out"] = recs, idx, g
+    lanes = rng.standard_normal((6, 32)).astype(np.float32)
+    sc = np.zeros((6, 64, 4), dtype=np.float32)
+    for k in range(6):
+        arr[:] = 0
+        R.ref_storeindexed4_v8(lanes[k].ctypes.data_as(C.c_void_p), C.c_void_p(arr.ctypes.data), idx[k].ctypes.data_as(C.c_void_p), 16)
+        sc[k] = arr
+    out["scatter_lanes"], out["scatter_out"] = lanes, sc
+
+    # DenseHashSet with erases, on a run where no inserted key is already present (ref: base/DenseHash.h:208-236)
+    keys = rng.permutation(4000)[:3000].astype(np.uint32)
+    pairs = np.stack([keys // 61, keys % 61 + 100], axis=1).astype(np.uint32)           # 3000 distinct pairs
+    seq, ops = [], []
+    for k in range(1500): seq.append(pairs[k]); ops.append(0)
+    for k in range(0, 1500, 3): seq.append(pairs[k]); ops.append(1)                        # erase every third
+    for k in range(1500, 3000): seq.append(pairs[k]); ops.append(0)                        # fresh keys over the tombstones
+    for k in range(1, 1500, 7): seq.append(pairs[k]); ops.append(1)
+    seq = np.array(seq, dtype=np.uint32); ops = np.array(ops, dtype=np.uint8)
+    member = np.zeros(len(seq), dtype=np.uint8)
+    R.ref_pairset_mixed_run.restype = C.c_size_t
+    size = R.ref_pairset_mixed_run(seq.ctypes.data_as(C.c_void_p), ops.ctypes.data_as(C.c_void_p), C.c_size_t(len(seq)), member.ctypes.data_as(C.c_void_p))
+    out["pairset_mixed_pairs"], out["pairset_mixed_ops"], out["pairset_mixed_member"] = seq, ops, member
+    out["pairset_mixed_size"] = np.array([size], dtype=np.int64)
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "leaf_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

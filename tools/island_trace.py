@@ -53,10 +53,13 @@ for x in range(8):
     m = t[:, 6] == x
     if m.any(): print("  XCC %d: %4d workgroups, start median %.1f us, end median %.1f us" % (x, m.sum(), np.median((t[m, 0] - t0) / tick_us), np.median((t[m, 5] - t0) / tick_us)))
 
-wt = s.wave_trace().astype(np.float64)
-nwork = (s.wave_trace()[:, :, 3] >> np.uint64(32)).astype(np.float64); nidle = (s.wave_trace()[:, :, 3] & np.uint64(0xffffffff)).astype(np.float64)
-m = nwork > 0
-print("per working colour step of a wave (shader cycles, incl. ~2 s_memtime reads): joint update median %.0f p95 %.0f; barrier behind it median %.0f"
-      % (np.median(wt[:, :, 0][m] / nwork[m]), np.percentile(wt[:, :, 0][m] / nwork[m], 95), np.median(wt[:, :, 1][m] / nwork[m])))
-mi = nidle > 0
-print("per idle colour step of a wave: median %.0f cycles; working steps per wave: median %.0f of %.0f steps" % (np.median(wt[:, :, 2][mi] / nidle[mi]), np.median(nwork[m]), np.median((nwork + nidle)[m])))
+raw = s.wave_trace()
+wt = raw.astype(np.float64)
+nsmall = (raw[:, :, 3] >> np.uint64(32)).astype(np.float64); nidle = (raw[:, :, 3] & np.uint64(0xffffffff)).astype(np.float64); nbig = wt[:, :, 5]
+ms, mb, mi = nsmall > 0, nbig > 0, nidle > 0
+print("per working colour step of a wave (shader cycles, incl. ~2 s_memtime reads):")
+print("   joint update with <= 32 lanes active: median %.0f p95 %.0f (%d waves)" % (np.median(wt[:, :, 0][ms] / nsmall[ms]), np.percentile(wt[:, :, 0][ms] / nsmall[ms], 95), ms.sum()))
+print("   joint update with  > 32 lanes active: median %.0f p95 %.0f (%d waves)" % (np.median(wt[:, :, 4][mb] / nbig[mb]), np.percentile(wt[:, :, 4][mb] / nbig[mb], 95), mb.sum()))
+w = (nsmall + nbig) > 0
+print("   barrier behind the update: median %.0f" % np.median(wt[:, :, 1][w] / (nsmall + nbig)[w]))
+print("per idle colour step of a wave: median %.0f cycles" % np.median(wt[:, :, 2][mi] / nidle[mi]))
