@@ -251,7 +251,10 @@ __global__ void __launch_bounds__(256) k_emit_cached(SweepView v, const unsigned
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
         const unsigned dst = row_offset[i];
         const unsigned count = (i + 1 < v.n ? row_offset[i + 1] : total) - dst;
-        if (count == 0 || count > (unsigned)ROW_CACHE) continue;     // nothing new, a hub row (its chunks emit), or a rescanned row
+        if (count == 0 || count > (unsigned)ROW_CACHE) continue;     // nothing new, or a rescanned row
+        // a hub row's pairs are emitted by its chunks and its row_cache entries were never written: skip it explicitly (the
+        // same one-probe test as the count pass) instead of relying on k_sweep_chunks<true> overwriting the slots afterwards
+        if (i + 1 + HUB_LEN < v.n && !(v.entries[i + 1 + HUB_LEN].x > v.entries[i].y)) continue;
         const unsigned ia = v.idx[i];
         for (unsigned k = 0; k < count; ++k) out[dst + k] = make_uint2(ia, v.row_cache[(size_t)i * ROW_CACHE + k]);
     }

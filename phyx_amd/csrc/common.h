@@ -99,6 +99,19 @@ struct DevBuf {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// roctx ranges named after the reference's MICROPROFILE scopes (ref: World.cpp:21, Solver.cpp:133-198, Collider.cpp:253-381),
+// so that rocprofv3 --marker-trace groups this library's kernels by the reference's phases.  The marker library is resolved
+// at run time (dlopen in runtime.hip: librocprofiler-sdk-roctx.so, then libroctx64.so) — no link dependency, and a no-op when
+// it is absent.  A range costs two calls on the host; nothing is synchronised.
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // Small device->host readbacks (counts, flags, fingerprints) through one pinned staging buffer: asynchronous DMAs into
 // pinned memory and ONE stream synchronisation per batch, instead of one blocking staged copy per value into pageable
 // memory (measured: ~25 us of idle GPU per pageable readback, ~16 of them per world step).

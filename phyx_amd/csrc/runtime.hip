@@ -1,7 +1,34 @@
 // runtime.hip — error capture, device selection and the raw device-memory helpers of the C ABI.
 #include "common.h"
 
+#include <cstdlib>
+#include <dlfcn.h>
+
 namespace phx {
+
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi()
+    {
+        const char* off = getenv("PHX_NO_ROCTX");
+        if (off && off[0] == '1') return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so"}) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const RoctxApi& roctx() { static const RoctxApi api; return api; }
+} // namespace
+
+void roctx_push(const char* name) { if (roctx().push) roctx().push(name); }
+void roctx_pop() { if (roctx().pop) roctx().pop(); }
 
 static thread_local char g_error[1024] = "";
 

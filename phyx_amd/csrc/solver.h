@@ -149,7 +149,7 @@ private:
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
     bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }
     // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()
-    struct Pending { bool active = false; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
+    struct Pending { bool active = false; int count = 0; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
     int ncp_ = 0;
     unsigned long long raw_fingerprint_ = 0;
     // exchange of an island-sharded solve (exchange.h)

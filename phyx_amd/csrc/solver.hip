@@ -276,6 +276,7 @@ constexpr int JP_ROUNDS_MAX = 512;
 int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
 {
     *fallback = false;
+    RoctxRange range("GatherIslands + PrepareIndices (schedule build)");          // ref: Solver.cpp:77, 135, 217, 285
     // the topology fingerprint (already queued on the stream) rides along with the first readback of the build
     auto with_fingerprint = [&]() -> int { if (fp_wanted_) { PHX_TRY(rb_.add(fp_wanted_, hash_.p + hash_slot_, sizeof *fp_wanted_, stream_)); fp_wanted_ = nullptr; } return PHX_OK; };
     const bool trace = trace_schedule_;
@@ -678,14 +679,23 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     const bool replay = graph_key_.valid && graph_key_ == key;
 
     PHX_HIP(hipEventRecord(ev_begin_, stream_));
-    if (replay) { if (graph_[0]) PHX_HIP(hipGraphLaunch(graph_[0], stream_)); }
-    else PHX_TRY(enqueue_pre(d_bodies, nb, d_cps, d_joints, nj));
+    {
+        RoctxRange r("PrepareBodies + PrepareJoints + RefreshJoints + PreStepJoints (HBM group)");      // ref: Solver.cpp:70, 135, 146, 157
+        if (replay) { if (graph_[0]) PHX_HIP(hipGraphLaunch(graph_[0], stream_)); }
+        else PHX_TRY(enqueue_pre(d_bodies, nb, d_cps, d_joints, nj));
+    }
     PHX_HIP(hipEventRecord(ev_sweep_begin_, stream_));
-    if (replay) { if (graph_[1]) PHX_HIP(hipGraphLaunch(graph_[1], stream_)); sweep_launches_ = graph_sweep_launches_; }
-    else PHX_TRY(enqueue_sweeps(d_bodies, d_cps, d_joints, nj, ci, pi));
+    {
+        RoctxRange r("SolveJointIsland: Impulse + Displacement");                                        // ref: Solver.cpp:133, 171, 193
+        if (replay) { if (graph_[1]) PHX_HIP(hipGraphLaunch(graph_[1], stream_)); sweep_launches_ = graph_sweep_launches_; }
+        else PHX_TRY(enqueue_sweeps(d_bodies, d_cps, d_joints, nj, ci, pi));
+    }
     PHX_HIP(hipEventRecord(ev_sweep_end_, stream_));
-    if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
-    else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
+    {
+        RoctxRange r("FinishJoints + FinishBodies (HBM group)");                                         // ref: Solver.cpp:213, 114
+        if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
+        else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
+    }
     PHX_HIP(hipEventRecord(ev_end_, stream_));
     last_ci_ = ci; last_pi_ = pi;
     stats_pending_ = true;
@@ -717,6 +727,9 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
         // queued first; every kernel that writes to the caller's arrays compares it on the device and commits nothing on
         // a mismatch; synchronize() reads it back and, if it differs, rebuilds the schedule and repeats the solve.
         PHX_TRY(launch_fingerprint(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp));
+        // a repeat on the same arrays while the previous one is still unverified: both ran on the same cached schedule and are
+        // gated by the same topology, so they are verified together — and replayed together if the schedule was stale
+        pending_.count = pending_.active ? pending_.count + 1 : 1;
         pending_.active = true; pending_.bodies = d_bodies; pending_.cps = d_cps; pending_.joints = d_joints;
         pending_.nb = nb; pending_.ncp = ncp; pending_.nj = nj; pending_.cfg = cfg;
         stats_.recoloured = 0;
@@ -809,7 +822,11 @@ int DeviceSolver::synchronize()
             const bool split = p.cfg.island_mode == PHX_ISLAND_MULTIPLE || p.cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
             stats_.island_count = split ? sched_.island_count : 1;
             stats_.island_max_size = split ? sched_.island_max_size : p.nj;
-            PHX_TRY(enqueue(static_cast<phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_point*>(p.cps), static_cast<phx_contact_joint*>(p.joints), p.nj, p.cfg));
+            // none of the queued solves committed anything: repeat as many as were asked for (e.g. solver-only sub-stepping)
+            for (int k = 0; k < std::max(p.count, 1); ++k) {
+                if (k) PHX_TRY(launch_fingerprint(static_cast<const phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp));
+                PHX_TRY(enqueue(static_cast<phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_point*>(p.cps), static_cast<phx_contact_joint*>(p.joints), p.nj, p.cfg));
+            }
             PHX_HIP(hipStreamSynchronize(stream_));
         }
     }

@@ -255,16 +255,20 @@ int World::pre_solve(float dt)
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
     auto lap = [&](int phase) { if (!phase_timing) return; (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
-    if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt, counters_.p);   // ref: World.cpp:39-55
-    PHX_HIP(hipGetLastError());
-    lap(0);
+    RoctxRange update_range("Update (before SolveJoints)");                 // ref: World.cpp:21
+    {
+        RoctxRange r("IntegrateVelocity");                                  // ref: World.cpp:39-55
+        if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt, counters_.p);
+        PHX_HIP(hipGetLastError());
+        lap(0);
+    }
     // the device runs sort and sweep back to back; the host clock cannot split them, so the whole device broadphase
     // is booked under UpdatePairs and UpdateBroadphase reads 0 (phx_broadphase_stats has the device time)
     phase_ms[1] = 0.0;
-    PHX_TRY(update_pairs()); lap(2);
-    PHX_TRY(update_manifolds()); lap(3);
-    PHX_TRY(pack_manifolds()); lap(4);
-    PHX_TRY(refresh_contact_joints()); lap(5);
+    { RoctxRange r("UpdateBroadphase + UpdatePairs"); PHX_TRY(update_pairs()); lap(2); }            // ref: Collider.cpp:253, 288
+    { RoctxRange r("UpdateManifolds"); PHX_TRY(update_manifolds()); lap(3); }                        // ref: Collider.cpp:370
+    { RoctxRange r("PackManifolds"); PHX_TRY(pack_manifolds()); lap(4); }                            // ref: Collider.cpp:381
+    { RoctxRange r("RefreshContactJoints"); PHX_TRY(refresh_contact_joints()); lap(5); }             // ref: World.cpp:74
     return PHX_OK;
 }
 
@@ -274,14 +278,16 @@ int World::pre_solve(float dt)
 int World::step_begin(float dt, const phx_config& cfg, size_t* segment_bytes)
 {
     PHX_TRY(pre_solve(dt));
-    PHX_TRY(solve(cfg));
+    { RoctxRange r("SolveJoints (this rank's groups)"); PHX_TRY(solve(cfg)); }
+    RoctxRange r("Exchange: pack");
     return solver_.exchange_pack(d_bodies_.p, d_joints_.p, segment_bytes);
 }
 
 int World::step_end(float dt)
 {
     PHX_TRY(use_device(device_));
-    PHX_TRY(solver_.exchange_unpack(d_bodies_.p, d_joints_.p));
+    { RoctxRange r("Exchange: unpack"); PHX_TRY(solver_.exchange_unpack(d_bodies_.p, d_joints_.p)); }
+    RoctxRange r("IntegratePosition");
     if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
     PHX_HIP(hipGetLastError());
     return PHX_OK;
@@ -295,7 +301,8 @@ int World::finish_step(float dt, const phx_config& cfg)
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
     auto lap = [&](int phase) { if (!phase_timing) return; (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
-    PHX_TRY(solve(cfg)); lap(6);
+    { RoctxRange r("SolveJoints"); PHX_TRY(solve(cfg)); lap(6); }
+    RoctxRange r("IntegratePosition");
     if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
     PHX_HIP(hipGetLastError());
     lap(7);

@@ -250,6 +250,33 @@ def test_speculative_schedule_is_verified(solver, oracle):
     assert gb2.tobytes() == ob2.tobytes() and gj2.tobytes() == oj2.tobytes()
 
 
+def test_two_queued_solves_on_a_stale_schedule_are_both_replayed(solver, oracle):
+    """Solver-only sub-stepping: two SolveJoints queued back to back on the same device arrays, no synchronisation in between,
+    while the cached schedule is stale.  Neither commits (the fingerprint gates them); synchronize() must rebuild and replay
+    BOTH, so the arrays hold two successive solves of the new joint list, not one."""
+    a = presolve_state(scenes.stack(6, 40), 3)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 10, 10)
+    db, dc, dj = (phyx_amd.DeviceArray(x) for x in a)
+    solver.SolveJointsDevice(db, dc, dj, cfg)
+    solver.synchronize()                                             # schedule cached for `a`
+    perm = np.random.default_rng(11).permutation(len(a[2]))
+    b = (a[0].copy(), a[1], a[2][perm].copy())
+    import ctypes as C
+    from phyx_amd import _lib
+    L = _lib.load()
+    _lib.check(L.phx_memcpy_h2d(0, db.ptr, b[0].ctypes.data_as(C.c_void_p), b[0].nbytes))
+    _lib.check(L.phx_memcpy_h2d(0, dj.ptr, b[2].ctypes.data_as(C.c_void_p), b[2].nbytes))
+    solver.SolveJointsDevice(db, dc, dj, cfg)                        # speculative on the stale schedule
+    solver.SolveJointsDevice(db, dc, dj, cfg)                        # and again, before the first was verified
+    solver.synchronize()
+    assert solver.stats().recoloured == 1
+    sched = Sched(solver)
+    ob_, cp, oj = (x.copy() for x in b)
+    for _ in range(2):
+        oracle.solver_solve_grouped(ob_, cp, oj, sched.order, sched.colours, sched.groups, 10, 10, oracle.STAG_COLOUR_SYNC)
+    assert db.to_host().tobytes() == ob_.tobytes() and dj.to_host().tobytes() == oj.tobytes()
+
+
 def test_tall_columns_use_the_1024_lane_island_shape(solver, oracle):
     """Columns of 500 boxes are ~1020 joints each: too big for the 512-lane workgroup, they take the 1024-lane
     shape instead of falling back to HBM (BASELINE config 5 geometry, 50 iterations)."""
