@@ -267,6 +267,9 @@ void phx_world_destroy(phx_world* w);
 int  phx_world_add_body(phx_world* w, float px, float py, float angle, float half_x, float half_y);
 /* main.cpp:91-93 groundBody->invMass = invInertia = 0 */
 int  phx_world_set_body_static(phx_world* w, int32_t body);
+/* body->invMass = ..., body->invInertia = ... on a public RigidBody (the demo scenes pin shelves with invMass = 0 only, so they
+ * still rotate: main.cpp:176-177, 194-195; a body is static — exempt from islands — only when both are 0, ref: Solver.cpp:304) */
+int  phx_world_set_body_inverse_mass(phx_world* w, int32_t body, float inv_mass, float inv_inertia);
 int  phx_world_set_gravity(phx_world* w, float gravity);            /* ref: World.h:35 */
 /* Multi-GPU island sharding: every rank steps a replica of the same world and solves only the schedule groups g with
  * g % shard_count == shard (phx_solver_set_shard; the default 0/1 solves everything).  A sharded world (shard_count > 1)

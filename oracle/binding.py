@@ -199,9 +199,12 @@ class OracleWorld:
         return i
 
     def add_scene(self, scene):
+        pinned = scene.get("pinned")                 # invMass = 0 only (ref: main.cpp:176-177): set after the loop below
         for k in range(len(scene["px"])):
             self.add_body(float(scene["px"][k]), float(scene["py"][k]), float(scene["angle"][k]),
                           float(scene["sx"][k]), float(scene["sy"][k]), bool(scene["static"][k]))
+        if pinned is not None and np.any(pinned):
+            self.bodies()["inv_mass"][np.asarray(pinned, dtype=bool)] = 0.0      # the constructor's invInertia stays
 
     def _view(self, getter, dtype):
         n = C.c_int(0)

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "phx_world_destroy": (None, [_vp]),
     "phx_world_add_body": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _f32]),
     "phx_world_set_body_static": (C.c_int, [_vp, _i32]),
+    "phx_world_set_body_inverse_mass": (C.c_int, [_vp, _i32, _f32, _f32]),
     "phx_world_set_gravity": (C.c_int, [_vp, _f32]),
     "phx_world_set_shard": (C.c_int, [_vp, _i32, _i32]),
     "phx_world_update": (C.c_int, [_vp, _f32, C.POINTER(Config)]),

@@ -442,10 +442,20 @@ class World:
             check(self.L.phx_world_set_body_static(self.h, i))
         return i
 
+    def set_inverse_mass(self, body, inv_mass, inv_inertia):
+        """body->invMass / invInertia (the demo pins shelves with invMass = 0 only, ref: main.cpp:176-177)."""
+        check(self.L.phx_world_set_body_inverse_mass(self.h, int(body), float(inv_mass), float(inv_inertia)))
+
     def add_scene(self, scene):
+        pinned = scene.get("pinned")                 # invMass = 0 only: infinitely heavy but free to rotate
         for k in range(len(scene["px"])):
-            self.AddBody((float(scene["px"][k]), float(scene["py"][k])), float(scene["angle"][k]),
-                         (float(scene["sx"][k]), float(scene["sy"][k])), bool(scene["static"][k]))
+            i = self.AddBody((float(scene["px"][k]), float(scene["py"][k])), float(scene["angle"][k]),
+                             (float(scene["sx"][k]), float(scene["sy"][k])), bool(scene["static"][k]))
+            if pinned is not None and pinned[k]:
+                sx, sy = float(scene["sx"][k]), float(scene["sy"][k])
+                mass = np.float32(1e-5) * (np.float32(sx) * np.float32(sy))
+                inertia = mass * (np.float32(sx) * np.float32(sx) + np.float32(sy) * np.float32(sy))
+                self.set_inverse_mass(i, 0.0, float(np.float32(1.0) / inertia))
 
     def set_shard(self, shard, shard_count):
         check(self.L.phx_world_set_shard(self.h, shard, shard_count))

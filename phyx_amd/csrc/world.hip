@@ -26,6 +26,7 @@ public:
 
     int add_body(float px, float py, float angle, float sx, float sy);
     int set_static(int body);
+    int set_inverse_mass(int body, float inv_mass, float inv_inertia);
     int synchronize();
     int update(float dt, const phx_config& cfg);
     int pre_solve(float dt);
@@ -127,6 +128,16 @@ int World::set_static(int body)
     host_bodies_[body].inv_mass = 0.f;
     host_bodies_[body].inv_inertia = 0.f;
     bodies_dirty_ = true;
+    return PHX_OK;
+}
+
+int World::set_inverse_mass(int body, float inv_mass, float inv_inertia)
+{
+    if (!bodies_dirty_ && d_bodies_.p) PHX_TRY(download_bodies(host_bodies_.data(), (int)host_bodies_.size()));
+    host_bodies_[body].inv_mass = inv_mass;
+    host_bodies_[body].inv_inertia = inv_inertia;
+    bodies_dirty_ = true;
+    joints_changed_ = true;              // which bodies are static is part of the schedule's topology
     return PHX_OK;
 }
 
@@ -386,6 +397,14 @@ int phx_world_set_body_static(phx_world* w, int32_t body)
     PHX_REQUIRE(w, "null handle");
     PHX_REQUIRE(body >= 0 && body < w->impl.nb(), "body index out of range");
     return w->impl.set_static(body);
+}
+
+int phx_world_set_body_inverse_mass(phx_world* w, int32_t body, float inv_mass, float inv_inertia)
+{
+    PHX_REQUIRE(w, "null handle");
+    PHX_REQUIRE(body >= 0 && body < w->impl.nb(), "body index out of range");
+    PHX_REQUIRE(inv_mass >= 0.f && inv_inertia >= 0.f, "inverse mass / inertia must not be negative");
+    return w->impl.set_inverse_mass(body, inv_mass, inv_inertia);
 }
 
 int phx_world_set_gravity(phx_world* w, float g) { PHX_REQUIRE(w, "null handle"); w->impl.gravity = g; return PHX_OK; }

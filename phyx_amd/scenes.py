@@ -82,3 +82,63 @@ def tilted(n, seed=7):
         ang.append(-1.5 + 3.0 * ((a >> 40) / float(1 << 24)))
     sc["angle"] = np.asarray(ang, dtype=np.float32)
     return sc
+
+
+def reference(scene, boxes=400, seed=3):
+    """Headless, scaled-down versions of the reference's demo scenes (ref: src/main.cpp:82-230; libc rand() replaced by
+    splitmix64): every scene starts with the ground (static, half-size 10000 x 10) and the 30 x 30 box at (-1000, 1500)
+    (main.cpp:90-95).  `boxes` scales the body count.
+      0 'Falling'  2 'Pyramid'  3 'Reverse Pyramid'  4 'Stacks' (tapered boxes)  5 shelves + falling
+      6 'Dual Stacks' (a tilted static plank)  7 'Islands' (static splitters)
+    Scene 1 ('Wall', boxes touching sideways) is left out: it overflows base/DenseHash.h:191 in the reference itself
+    (SURVEY.md §8c).  Scenes 5 and 6 pin their shelves with invMass = 0 ONLY (main.cpp:176-177, 194-195): key 'pinned'."""
+    px, py, ang, sx, sy, static, pinned = [0.0, -1000.0], [0.0, 1500.0], [0.0, 0.0], [10000.0, 30.0], [10.0, 30.0], [True, False], [False, False]
+    state = [seed]
+
+    def rnd(lo, hi):
+        state[0], z = _splitmix64(state[0])
+        return lo + (hi - lo) * ((z >> 40) / float(1 << 24))
+
+    def add(x, y, hx, hy, angle=0.0, fixed=False, pin=False):
+        px.append(x); py.append(y); ang.append(angle); sx.append(hx); sy.append(hy); static.append(fixed); pinned.append(pin)
+
+    k = scene % 8
+    if k == 0:
+        for _ in range(boxes):
+            add(rnd(-500.0, 500.0) * 0.15, rnd(50.0, 1000.0) * 0.3, 4.0, 4.0)
+    elif k == 2:
+        n = max(4, boxes // 8)
+        for step in range(n):
+            add(0.0, 15.0 + (n - 1 - step) * 10.0, 10.0 + step * 5.0, 5.0)        # widest at the bottom, resting (the demo drops it from y = 1005)
+    elif k == 3:
+        n = max(4, boxes // 8)
+        for step in range(n):
+            add(0.0, 15.0 + step * 10.0, 10.0 + step * 5.0, 5.0)
+    elif k == 4:
+        cols = max(2, boxes // 40)
+        for left in range(-(cols // 2), cols - cols // 2):
+            for b in range(40):
+                add(left * 15.0, 15.0 + b * 10.0, 5.0 - b * 0.03, 5.0)
+    elif k == 5:
+        add(0.0, 400.0, 600.0, 10.0, pin=True)
+        add(800.0, 200.0, 400.0, 10.0, pin=True)
+        for _ in range(boxes):
+            add(rnd(0.0, 500.0) * 0.4, 415.0 + rnd(0.0, 2000.0) * 0.1, 4.0, 4.0)
+    elif k == 6:
+        add(0.0, 400.0, 600.0, 10.0, pin=True)
+        add(800.0, 200.0, 400.0, 10.0, pin=True)
+        add(500.0, 500.0, 600.0, 10.0, angle=-0.5, fixed=True)
+        for _ in range(boxes // 2):
+            add(200.0 + rnd(0.0, 300.0) * 0.3, 700.0 + rnd(0.0, 2000.0) * 0.08, 4.0, 4.0)
+            add(-500.0 + rnd(0.0, 300.0) * 0.3, 415.0 + rnd(0.0, 2000.0) * 0.08, 4.0, 4.0)
+    elif k == 7:
+        groups = 3
+        for g in range(-(groups // 2), groups - groups // 2):
+            add(g * 300.0, 500.0, 20.0, 1000.0, fixed=True)
+            for _ in range(boxes // groups):
+                add(g * 300.0 + rnd(50.0, 250.0) * 0.5, rnd(50.0, 1500.0) * 0.12, 4.0, 4.0)
+    else:
+        raise ValueError("scene 1 ('Wall') is not reproduced: it overflows the reference's own DenseHash")
+    sc = _scene(px, py, ang, sx, sy, static)
+    sc["pinned"] = np.asarray(pinned, dtype=bool)
+    return sc

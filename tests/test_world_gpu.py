@@ -49,6 +49,20 @@ def test_world_lockstep_bit_exact(oracle, built_lib, name, steps, island_mode):
     assert len(ow.joints()) > 0
 
 
+@pytest.mark.parametrize("scene", [0, 2, 3, 4, 5, 6, 7])
+def test_reference_demo_scenes_lockstep(oracle, built_lib, scene):
+    """Headless, scaled-down versions of the reference's demo scenes (ref: main.cpp:97-227, minus the 'Wall' that overflows the
+    reference's own hash set) in lockstep with the oracle World: pyramids (wide boxes on narrow ones), tapered stacks, shelves
+    pinned with invMass = 0 only (they rotate under load), a tilted static plank, static splitters between islands."""
+    sc = scenes.reference(scene, boxes=360)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE_SLOPPY if scene % 2 else phyx_amd.ISLAND_SINGLE, 15, 15)
+    pw, ow = _lockstep(oracle, sc, 30, cfg, check_every=3)
+    assert len(ow.joints()) > 0
+    if "pinned" in sc and sc["pinned"].any():
+        b = pw.bodies
+        assert (b["inv_mass"][sc["pinned"]] == 0).all() and (b["inv_inertia"][sc["pinned"]] > 0).all()
+
+
 def test_differential_fuzz_random_worlds(built_lib):
     """tools/fuzz.py: random worlds (random sizes, angles, overlaps, static shelves, random island mode and iteration counts)
     in lockstep with the oracle, every byte compared after every step.  40 seeds here; 46 000 (and 870 of the --big kind) were run for round 1, 25 000 + 500 of them on the final code."""
