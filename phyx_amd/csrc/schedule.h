@@ -38,10 +38,14 @@ __host__ __device__ inline unsigned long long colour_priority(unsigned id, unsig
 //      structures (a stack: consecutive body indices alternate parity along a column) the two halves of a body's joints are
 //      drawn from opposite ends and never collide, which reaches the optimum of max-degree colours where A needs up to 1.5x as
 //      many; on irregular piles B is a little worse than A.  B is defined for at most 64 colours.
+// B is only attempted for components of at most COLOUR_B_MAX_JOINTS joints: the layered structures it helps are small, and
+// on a large irregular island it would double the colouring's memory traffic to lose anyway.
 // Every CONNECTED COMPONENT keeps the candidate that gives IT fewer colours (A on a tie) and renumbers its colours densely in
 // increasing order.  The choice is per component, so an island's colours — hence its results — do not depend on which other
 // islands share its group, on the workgroup shape or on the island mode.  A colour is one barrier-separated step (LDS groups)
 // or one kernel launch (HBM group) of every sweep, so the largest colour count sets the solve time.
+constexpr int COLOUR_B_MAX_JOINTS = 8192;
+
 __host__ __device__ inline int colour_pick_two_ended(unsigned long long used_mask, int k_limit, bool from_top)
 {
     const unsigned long long free_mask = ~used_mask;

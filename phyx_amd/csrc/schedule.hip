@@ -87,7 +87,7 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
     }
     // candidate B: two-ended (schedule.h), one 64-bit mask per body; a component it cannot colour within 64 colours keeps A
     std::vector<int> col_b(joints.size(), 0);
-    std::vector<unsigned char> comp_bad;                       // per dense component
+    std::vector<unsigned char> comp_bad;                       // per dense component (also set for components too big for B)
     std::vector<int> dense(joints.size());
     {
         std::vector<std::pair<int, int>> keyed(joints.size());
@@ -99,6 +99,10 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
             dense[keyed[i].second] = count - 1;
         }
         comp_bad.assign(count, 0);
+        std::vector<int> size(count, 0);
+        for (size_t k = 0; k < joints.size(); ++k) size[dense[k]]++;
+        for (int d = 0; d < count; ++d) if (size[d] > COLOUR_B_MAX_JOINTS) comp_bad[d] = 1;      // B is not attempted there (schedule.h)
+        for (size_t k = 0; k < joints.size(); ++k) if (comp[k] < 0) comp_bad[dense[k]] = 1;      // static-static joints: colour 0 either way
     }
     {
         sc.ensure(nb);
@@ -115,6 +119,7 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
             if (da) m |= used[(size_t)a * words];
             if (db) m |= used[(size_t)b * words];
             const int klim = std::max(da ? deg[a] : 0, db ? deg[b] : 0);
+            if (comp_bad[dense[k]]) continue;
             const int c = colour_pick_two_ended(m, klim, (std::min(a, b) & 1) != 0);
             if (c < 0) { comp_bad[dense[k]] = 1; continue; }
             col_b[k] = c;

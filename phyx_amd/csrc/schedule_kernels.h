@@ -329,58 +329,103 @@ struct JpView {
     unsigned long long* seen_a;       // per component (entry ncomp = the static-static joints): colours in use under A / B
     unsigned long long* seen_b;
     unsigned char* bad_b;             // per component: B ran out of its 64 colours
+    const unsigned* comp_size;        // per component: joints (B is attempted only up to COLOUR_B_MAX_JOINTS)
     unsigned* colour;                 // per entry: JP_NONE until coloured
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
     int* remaining;                   // per round: nonzero if some joint is still uncoloured after it
     int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours
 };
 
+// `list_in` / `count_in` (null in rounds 0 and 1: every entry): the entries still uncoloured after the previous round;
+// `list_out` / `count_out` (null in round 0): where this round appends the entries it leaves uncoloured.  The uncoloured set
+// shrinks geometrically, so compacting it keeps the cost of the whole colouring near that of its first rounds (a merged
+// 7e5-joint island needs ~40 rounds: 1.7 ms when every round scanned every entry).
 static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigned long long* __restrict__ cur, unsigned long long* next,
-                                                         unsigned long long* zero, int round)
+                                                         unsigned long long* zero, int round, const unsigned* __restrict__ list_in,
+                                                         const int* __restrict__ count_in, unsigned* __restrict__ list_out, int* __restrict__ count_out)
 {
     bool left = false;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
-        if (v.colour[k] != JP_NONE) continue;
-        const unsigned j = v.ids[k];
-        const phx_contact_joint jt = v.joints[j];
-        const unsigned a = (unsigned)jt.body1, b = (unsigned)jt.body2;
-        if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) { atomicOr(v.flags, 1); v.colour[k] = 0; continue; }
-        const bool da = !v.is_static[a], db = !v.is_static[b];
-        const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
-        if (round == 0) { v.touched[a] = 1u; v.touched[b] = 1u; atomicAdd(&v.degree[a], 1u); atomicAdd(&v.degree[b], 1u); }
-        else if ((!da || cur[a] == key) && (!db || cur[b] == key)) {
-            const int comp = v.joint_comp[j] < 0 ? v.ncomp : v.joint_comp[j];
-            unsigned long long m = 0;
-            if (da) m |= v.used[a];
-            if (db) m |= v.used[b];
-            int c = 0;
-            if (!~m) atomicOr(v.flags, 2);
-            else {
-                c = __builtin_ctzll(~m);
-                if (da) v.used[a] |= 1ull << c;
-                if (db) v.used[b] |= 1ull << c;
-                if (!((v.seen_a[comp] >> c) & 1ull)) atomicOr(&v.seen_a[comp], 1ull << c);      // (test first: a big island's joints all share one word)
-            }
-            {                                            // candidate B: the same winner, the two-ended choice
-                unsigned long long mb = 0;
-                if (da) mb |= v.used_b[a];
-                if (db) mb |= v.used_b[b];
-                const int d0 = da ? (int)v.degree[a] : 0, d1 = db ? (int)v.degree[b] : 0;
-                const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
-                if (cb < 0) v.bad_b[comp] = 1;
+    const int n = list_in ? *count_in : v.count;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {       // wave-uniform trip count
+        const int i = base + (int)threadIdx.x;
+        bool stay = false;
+        int k = 0, comp = 0;
+        unsigned long long got_a = 0, got_b = 0;             // the colour bits this lane's joint took under candidates A / B
+        if (i < n) {
+            k = list_in ? (int)list_in[i] : i;
+            if (v.colour[k] == JP_NONE) {
+                const unsigned j = v.ids[k];
+                const phx_contact_joint jt = v.joints[j];
+                const unsigned a = (unsigned)jt.body1, b = (unsigned)jt.body2;
+                if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) { atomicOr(v.flags, 1); v.colour[k] = 0; }
                 else {
-                    if (da) v.used_b[a] |= 1ull << cb;
-                    if (db) v.used_b[b] |= 1ull << cb;
-                    if (!((v.seen_b[comp] >> cb) & 1ull)) atomicOr(&v.seen_b[comp], 1ull << cb);
-                    v.colour_b[k] = (unsigned)cb;
+                    const bool da = !v.is_static[a], db = !v.is_static[b];
+                    const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
+                    bool coloured = false;
+                    if (round == 0) { v.touched[a] = 1u; v.touched[b] = 1u; atomicAdd(&v.degree[a], 1u); atomicAdd(&v.degree[b], 1u); }
+                    else if ((!da || cur[a] == key) && (!db || cur[b] == key)) {
+                        comp = v.joint_comp[j] < 0 ? v.ncomp : v.joint_comp[j];
+                        unsigned long long m = 0;
+                        if (da) m |= v.used[a];
+                        if (db) m |= v.used[b];
+                        int c = 0;
+                        if (!~m) atomicOr(v.flags, 2);
+                        else {
+                            c = __builtin_ctzll(~m);
+                            if (da) v.used[a] |= 1ull << c;
+                            if (db) v.used[b] |= 1ull << c;
+                            got_a = 1ull << c;
+                        }
+                        if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same winner, the two-ended choice
+                            unsigned long long mb = 0;
+                            if (da) mb |= v.used_b[a];
+                            if (db) mb |= v.used_b[b];
+                            const int d0 = da ? (int)v.degree[a] : 0, d1 = db ? (int)v.degree[b] : 0;
+                            const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
+                            if (cb < 0) v.bad_b[comp] = 1;
+                            else {
+                                if (da) v.used_b[a] |= 1ull << cb;
+                                if (db) v.used_b[b] |= 1ull << cb;
+                                got_b = 1ull << cb;
+                                v.colour_b[k] = (unsigned)cb;
+                            }
+                        }
+                        v.colour[k] = (unsigned)c;
+                        coloured = true;
+                    }
+                    if (!coloured) {
+                        if (da) { atomicMax(&next[a], key); zero[a] = 0ull; }
+                        if (db) { atomicMax(&next[b], key); zero[b] = 0ull; }
+                        stay = true;
+                    }
                 }
             }
-            v.colour[k] = (unsigned)c;
-            continue;
         }
-        if (da) { atomicMax(&next[a], key); zero[a] = 0ull; }
-        if (db) { atomicMax(&next[b], key); zero[b] = 0ull; }
-        left = true;
+        if (stay) left = true;
+        // 'colours in use' of the components, wave-aggregated: in a merged island every winner of a round belongs to ONE
+        // component, and thousands of same-address atomics serialise (measured: 357 us for one round of a 7e5-joint island)
+        for (unsigned long long todo = __ballot((got_a | got_b) != 0); todo;) {
+            const int leader = __builtin_ctzll(todo);
+            const int lc = __shfl(comp, leader);
+            const bool mine = (got_a | got_b) != 0 && comp == lc;
+            unsigned long long ra = mine ? got_a : 0ull, rb = mine ? got_b : 0ull;
+            for (int off = 32; off > 0; off >>= 1) { ra |= __shfl_xor(ra, off); rb |= __shfl_xor(rb, off); }
+            if (lane == leader) {
+                if (ra & ~v.seen_a[lc]) atomicOr(&v.seen_a[lc], ra);
+                if (rb & ~v.seen_b[lc]) atomicOr(&v.seen_b[lc], rb);
+            }
+            todo &= ~__ballot(mine);
+        }
+        if (list_out) {                                              // append the survivors of this wave with one atomic
+            const unsigned long long mask = __ballot(stay);
+            if (mask) {
+                int at = 0;
+                if (lane == __builtin_ctzll(mask)) at = atomicAdd(count_out, __popcll(mask));
+                at = __shfl(at, __builtin_ctzll(mask));
+                if (stay) list_out[at + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)k;
+            }
+        }
     }
     if (__any(left) && (threadIdx.x & 63) == 0) v.remaining[round] = 1;      // a flag, not a count: same-address atomics would serialise
 }
@@ -392,7 +437,7 @@ static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
         const int jc = v.joint_comp[v.ids[k]];
         const int comp = jc < 0 ? v.ncomp : jc;
         const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
-        const bool use_b = !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
+        const bool use_b = comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS && !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
         const unsigned c = use_b ? v.colour_b[k] : v.colour[k];
         v.colour[k] = (unsigned)__popcll((use_b ? sb : sa) & ((1ull << c) - 1ull));
     }

@@ -115,7 +115,8 @@ private:
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
     DevBuf<unsigned long long> jp_used_b_, jp_seen_;
     DevBuf<unsigned char> jp_bad_b_;
-    DevBuf<int> jp_small_;
+    DevBuf<int> jp_small_, jp_counts_;
+    DevBuf<unsigned> jp_list_[2];
     bool gpu_builder_ = true;
     phx_step_hook step_hook_ = nullptr;  // bench(): called with phase 1 between a step's local preparation and its sweeps
     void* step_hook_user_ = nullptr;

@@ -40,7 +40,7 @@ DeviceSolver::~DeviceSolver()
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
     cc_parent_.release(); joint_comp_.release(); bin_of_comp_.release(); rank_of_comp_.release(); grp_goff_.release(); sb_small_.release(); cc_static_.release();
     cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); for (int k = 0; k < 3; ++k) jp_best_[k].release();
-    jp_used_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
+    jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
@@ -450,13 +450,20 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_HIP(hipMemsetAsync(jp_seen_.p, 0, 2 * ((size_t)ncomp_total + 1) * sizeof(unsigned long long), stream_));
         PHX_HIP(hipMemsetAsync(jp_bad_b_.p, 0, (size_t)ncomp_total + 1, stream_));
         jv.used_b = jp_used_b_.p; jv.degree = jp_degree_.p; jv.colour_b = jp_colour_b_.p; jv.joint_comp = joint_comp_.p; jv.ncomp = ncomp_total;
-        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
+        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p; jv.comp_size = comp_size_.p;
+        // survivor lists: round r >= 1 appends what it leaves uncoloured to list r & 1, round r >= 2 reads list (r - 1) & 1
+        for (int k = 0; k < 2; ++k) PHX_TRY(jp_list_[k].reserve(rest));
+        PHX_TRY(jp_counts_.reserve(JP_ROUNDS_MAX + 1));
+        PHX_HIP(hipMemsetAsync(jp_counts_.p, 0, (size_t)(JP_ROUNDS_MAX + 1) * sizeof(int), stream_));
         int round = 0;
         for (bool done = false; !done;) {
             if (round + JP_BATCH > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }       // pathological dependency chain: host builder
             for (int k = 0; k < JP_BATCH; ++k, ++round)
                 hipLaunchKernelGGL(k_jp_round, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned long long*)jp_best_[round % 3].p,
-                                   jp_best_[(round + 1) % 3].p, jp_best_[(round + 2) % 3].p, round);
+                                   jp_best_[(round + 1) % 3].p, jp_best_[(round + 2) % 3].p, round,
+                                   round >= 2 ? (const unsigned*)jp_list_[(round - 1) & 1].p : (const unsigned*)nullptr,
+                                   round >= 2 ? (const int*)(jp_counts_.p + round - 1) : (const int*)nullptr,
+                                   round >= 1 ? jp_list_[round & 1].p : (unsigned*)nullptr, round >= 1 ? jp_counts_.p + round : (int*)nullptr);
             int tail[2] = {0, 0};
             PHX_TRY(with_fingerprint());
             PHX_TRY(rb_.add(&tail[0], jp_small_.p + round - 1, sizeof(int), stream_));
