@@ -420,8 +420,8 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     stats_ = phx_broadphase_stats{};
     const int nblocks = std::max(1, div_up(n, RS_TILE));
     for (int k = 0; k < 2; ++k) { PHX_TRY(keys_[k].reserve(std::max(n, 1))); PHX_TRY(idx_[k].reserve(std::max(n, 1))); }
-    PHX_TRY(hist_.reserve((size_t)RS_BINS * nblocks));
-    PHX_TRY(scan_tiles_.reserve((size_t)std::max(div_up(std::max(RS_BINS * nblocks, n), SCAN_TILE), 1)));
+    PHX_TRY(hist_.reserve(radix_hist_words(n)));
+    PHX_TRY(scan_tiles_.reserve((size_t)std::max(div_up(std::max(RS_WIDE_BINS * nblocks, n), SCAN_TILE), 1)));
     int chunk_cap = std::max<int>((int)chunks_.cap, div_up(std::max(n, 1), HUB_CHUNK) * 8 + 64);   // grows on demand below
     PHX_TRY(chunks_.reserve(chunk_cap));
     PHX_TRY(chunk_count_.reserve(chunk_cap));

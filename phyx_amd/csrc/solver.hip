@@ -286,8 +286,8 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(cc_parent_.reserve(nbs)); PHX_TRY(cc_static_.reserve(nbs)); PHX_TRY(cc_flags_.reserve(nbs + 1)); PHX_TRY(comp_size_.reserve(nbs + 1));
     PHX_TRY(joint_comp_.reserve(njs)); PHX_TRY(sb_small_.reserve(8));
     for (int k = 0; k < 2; ++k) { PHX_TRY(sort_keys_[k].reserve(njs)); PHX_TRY(sort_vals_[k].reserve(njs)); }
-    PHX_TRY(sort_hist_.reserve((size_t)RS_BINS * std::max(1, div_up(nj, RS_TILE))));
-    PHX_TRY(sort_scan_.reserve((size_t)div_up(std::max(std::max(nb, nj), RS_BINS * div_up(njs, RS_TILE)), SCAN_TILE) + 2));
+    PHX_TRY(sort_hist_.reserve(radix_hist_words(nj)));
+    PHX_TRY(sort_scan_.reserve((size_t)div_up(std::max(std::max(nb, nj), RS_WIDE_BINS * div_up(njs, RS_TILE)), SCAN_TILE) + 2));
     PHX_TRY(order_.reserve(njs));
 
     hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p);
