@@ -64,12 +64,14 @@ def main(tag, dominant):
     if os.path.exists(trace):
         rows_all = list(csv.DictReader(open(trace)))
         for key, needle in (("dominant_kernel_launch_us", dominant), ("hbm_colour_kernel_launch_us", "k_solve_colour<true, true>"), ("tail_kernel_launch_us", "k_solve_tail")):
-            us = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows_all if needle in r["Kernel_Name"])
-            if not us:
+            mine = [r for r in rows_all if needle in r["Kernel_Name"]]
+            if not mine:
                 continue
+            grid = collections.Counter(r["Grid_Size_X"] for r in mine).most_common(1)[0][0]     # the full launch of the timed region
+            us = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in mine if r["Grid_Size_X"] == grid)
             med = us[len(us) // 2]
             timed = [u for u in us if 0.75 * med <= u <= 1.25 * med]
-            out[key] = {"launches": len(us), "median": med, "mean_within_25pct_of_median": sum(timed) / len(timed), "min": us[0], "max": us[-1]}
+            out[key] = {"launches": len(us), "grid_size": grid, "median": med, "mean_within_25pct_of_median": sum(timed) / len(timed), "min": us[0], "max": us[-1]}
     for name, k in kernels.items():
         if "k_solve_colour<true, true>" in name:
             out["hbm_colour_kernel"] = name
