@@ -37,7 +37,11 @@ int phx_solver_solve_device(phx_solver* s, void* d_bodies, int32_t nb, const voi
 int phx_solver_synchronize(phx_solver* s)
 {
     PHX_REQUIRE(s, "null handle");
-    return s->impl.synchronize();
+    PHX_TRY(s->impl.synchronize());
+    // the internal waits poll a device-written mailbox (common.h Readback); the public call also drains the stream, so that
+    // work the caller orders on OTHER streams afterwards is behind everything queued here
+    PHX_HIP(hipStreamSynchronize(s->impl.stream()));
+    return PHX_OK;
 }
 
 int phx_solver_get_stats(phx_solver* s, phx_solve_stats* out)

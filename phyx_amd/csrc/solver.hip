@@ -442,7 +442,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         jv.used = jp_used_.p; jv.colour = jp_keys_[0].p; jv.touched = jp_touched_.p;
         jv.remaining = jp_small_.p; jv.flags = jp_small_.p + JP_ROUNDS_MAX;
         // the second colouring candidate and the per-component bookkeeping of the choice (schedule.h)
-        PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_degree_.reserve(nbs)); PHX_TRY(jp_colour_b_.reserve(rest));
+        PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_degree_.reserve(nbs + 1)); PHX_TRY(jp_colour_b_.reserve(rest));
         PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
         PHX_HIP(hipMemsetAsync(jp_used_b_.p, 0, (size_t)nbs * sizeof(unsigned long long), stream_));
         PHX_HIP(hipMemsetAsync(jp_degree_.p, 0, (size_t)nbs * sizeof(unsigned), stream_));
@@ -490,12 +490,14 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
         PHX_TRY(rb_.add(&h_touched, jp_touched_.p + nb, sizeof h_touched, stream_));
         // static slots (only the HBM path indexes the global static-tag tables)
+        // (a table of its own: the readback batch reads its sources at wait(), so jp_touched_ must stay as it is until then)
         PHX_TRY(static_slot_.reserve(nbs));
-        hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, nb, jp_touched_.p);
-        PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_.p, stream_));
-        hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)jp_touched_.p, nb, static_slot_.p);
+        unsigned* sflags = jp_degree_.p;                       // per body + 1; the colouring is done with it
+        hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, nb, sflags);
+        PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, sort_scan_.p, stream_));
+        hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)sflags, nb, static_slot_.p);
         unsigned h_nstatic = 0;
-        PHX_TRY(rb_.add(&h_nstatic, jp_touched_.p + nb, sizeof h_nstatic, stream_));
+        PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
         PHX_TRY(rb_.wait(stream_));
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
@@ -805,6 +807,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     stats_.displacement_iterations = nj_ ? std::max(h_disp, isl[1]) : std::min(last_pi_, 1);
     stats_.joint_visits = (long long)isl_visits + (long long)h_imp * hbm_joints;
     float ms = 0.f;
+    PHX_HIP(hipEventSynchronize(ev_end_));             // (already reached: the mailbox post ran behind it)
     PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
     stats_.device_ms = ms;
     stats_pending_ = false;
