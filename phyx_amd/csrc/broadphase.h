@@ -35,7 +35,8 @@ private:
     DevBuf<float4> entries_;
     DevBuf<unsigned long long> table_, small_;
     DevBuf<int4> chunks_;
-    DevBuf<unsigned> chunk_count_, chunk_scan_, scan_tiles_;
+    DevBuf<unsigned> chunk_count_, chunk_scan_;
+    ScanScratch scan_tiles_;
     DevBuf<uint2> new_pairs_, scratch_pairs_;
     DevBuf<phx_rigid_body> st_bodies_;
     DevBuf<int> erase_count_;                 // pairs really tombstoned since the last settle_erase_check()

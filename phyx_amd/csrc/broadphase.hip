@@ -378,7 +378,7 @@ int DeviceBroadphase::init()
 
 int DeviceBroadphase::exclusive_scan(unsigned* data, int count, unsigned* total_out)
 {
-    return device_exclusive_scan(data, count, total_out, scan_tiles_.p, stream_);
+    return device_exclusive_scan(data, count, total_out, scan_tiles_, stream_);
 }
 
 int DeviceBroadphase::resize_table(unsigned want_cap)
@@ -418,10 +418,8 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     n_ = n;
     last_new_ = 0;
     stats_ = phx_broadphase_stats{};
-    const int nblocks = std::max(1, div_up(n, RS_TILE));
     for (int k = 0; k < 2; ++k) { PHX_TRY(keys_[k].reserve(std::max(n, 1))); PHX_TRY(idx_[k].reserve(std::max(n, 1))); }
     PHX_TRY(hist_.reserve(radix_hist_words(n)));
-    PHX_TRY(scan_tiles_.reserve((size_t)std::max(div_up(std::max(RS_WIDE_BINS * nblocks, n), SCAN_TILE), 1)));
     int chunk_cap = std::max<int>((int)chunks_.cap, div_up(std::max(n, 1), HUB_CHUNK) * 8 + 64);   // grows on demand below
     PHX_TRY(chunks_.reserve(chunk_cap));
     PHX_TRY(chunk_count_.reserve(chunk_cap));
@@ -442,7 +440,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
 
     hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap);
     int src = 0;
-    PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_.p, stream_, &src));
+    PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
     sorted_ = src;
     hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, idx_[src].p, n, entries_.p);
 

@@ -98,6 +98,23 @@ struct DevBuf {
     }
 };
 
+// scratch of device_exclusive_scan's single-pass form (device_scan.h): ticket word + one status word per tile + the call counter
+struct ScanScratch {
+    DevBuf<unsigned long long> state;
+    unsigned epoch = 0;
+    int prepare(int tiles, hipStream_t stream)
+    {
+        if ((size_t)tiles + 1 > state.cap || epoch >= (1u << 30) - 2) {
+            PHX_TRY(state.reserve((size_t)tiles + 1));
+            PHX_HIP(hipMemsetAsync(state.p, 0, state.cap * sizeof(unsigned long long), stream));
+            epoch = 0;
+        }
+        ++epoch;
+        return PHX_OK;
+    }
+    void release() { state.release(); epoch = 0; }
+};
+
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 // roctx ranges named after the reference's MICROPROFILE scopes (ref: World.cpp:21, Solver.cpp:133-198, Collider.cpp:253-381),

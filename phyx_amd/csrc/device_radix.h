@@ -103,7 +103,7 @@ static __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const unsig
 static inline size_t radix_hist_words(int n) { return (size_t)RS_WIDE_BINS * (size_t)std::max(1, div_up(n, RS_TILE)); }
 
 static inline int device_radix_sort_pairs(unsigned* k0, unsigned* v0, unsigned* k1, unsigned* v1, int n, int bits,
-                                          unsigned* hist, unsigned* scan_scratch, hipStream_t stream, int* result_buffer)
+                                          unsigned* hist, ScanScratch& scan_scratch, hipStream_t stream, int* result_buffer)
 {
     unsigned* kb[2] = {k0, k1};
     unsigned* vb[2] = {v0, v1};

@@ -6,10 +6,10 @@
 namespace phx {
 
 // ---- exclusive prefix sum over `count` words, in place ---------------------------------------------------
-//   <= 64k words   k_scan_single: one workgroup, one launch
-//   <= 4M words    k_scan_tiles (each 1024-lane workgroup scans a 4096-word tile in LDS and records the tile total)
-//                  + k_scan_add_totals (each workgroup sums the totals before its tile and adds them): two launches
-//   beyond         k_scan_tiles, k_scan_totals (one workgroup scans the tile totals), k_scan_add
+//   <= 32k words   k_scan_single: one workgroup, one launch
+//   beyond         k_scan_lookback: ONE launch — every 1024-lane workgroup scans a 4096-word tile in LDS, publishes the tile's
+//                  total, and finds the sum of the tiles before it by looking back over what its predecessors published
+//                  (Merrill & Garland's decoupled look-back; a launch fewer than scan-tiles + add-totals, ~4 us each here)
 constexpr int SCAN_TILE = 4096;
 
 __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsigned* lds, unsigned* total)
@@ -31,64 +31,86 @@ __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsign
     return before + x - v;
 }
 
-static __global__ void __launch_bounds__(1024) k_scan_tiles(unsigned* __restrict__ data, int count, unsigned* __restrict__ tile_total)
-{
-    __shared__ unsigned lds[16];
-    __shared__ unsigned tot;
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-    unsigned v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (base + k < count) ? data[base + k] : 0u;
-    const unsigned mine = v[0] + v[1] + v[2] + v[3];
-    unsigned run = block_exclusive_scan_1024(mine, lds, threadIdx.x == 0 ? &tot : nullptr);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < count) data[base + k] = run; run += v[k]; }
-    __syncthreads();
-    if (threadIdx.x == 0) tile_total[blockIdx.x] = tot;
-}
+// ---- single-pass scan with decoupled look-back ------------------------------------------------------------
+// state[0] = ticket counter (tiles are taken in ticket order, so a tile's predecessors are always running or done: the
+// look-back cannot wait for a workgroup that was never scheduled); state[1 + t] = status of tile t, ONE 64-bit word
+// {epoch:30, flag:2, value:32} written with a single store, so value and flag can never be seen apart.  The epoch is the
+// host's call counter: words of earlier calls read as 'not published yet', which is why nothing has to be cleared between
+// calls (a memset is a dispatch of its own).  Agent-scope accesses: the tiles run on different XCDs (non-coherent L2s).
+constexpr unsigned SCAN_AGGREGATE = 1u, SCAN_PREFIX = 2u;
+constexpr int SCAN_SPIN_LIMIT = 1 << 22;                 // ~seconds; then trap: a HIP error the host reports instead of a hung device
 
-static __global__ void __launch_bounds__(1024) k_scan_totals(unsigned* __restrict__ tile_total, int tiles, unsigned* __restrict__ grand_total)
+static __global__ void __launch_bounds__(1024) k_scan_lookback(unsigned* __restrict__ data, int count, unsigned long long* __restrict__ state, unsigned epoch,
+                                                               unsigned* __restrict__ grand_total)
 {
     __shared__ unsigned lds[16];
-    __shared__ unsigned tot;
-    unsigned carry = 0;
-    for (int b = 0; b < tiles; b += 1024) {                     // tiles <= 1024 in practice (4M words)
-        const int i = b + threadIdx.x;
-        const unsigned v = i < tiles ? tile_total[i] : 0u;
-        const unsigned ex = block_exclusive_scan_1024(v, lds, threadIdx.x == 0 ? &tot : nullptr);
-        if (i < tiles) tile_total[i] = carry + ex;
-        __syncthreads();
-        carry += tot;
-        __syncthreads();
+    __shared__ unsigned s_tile, s_prefix;
+    const int tiles = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = (unsigned)atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const int tile = (int)s_tile;
+    const int base = tile * SCAN_TILE + threadIdx.x * 4;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    const bool vec = (reinterpret_cast<uintptr_t>(data) & 15u) == 0 && base + 3 < count;
+    if (vec) v = *reinterpret_cast<const uint4*>(data + base);
+    else {
+        if (base < count) v.x = data[base];
+        if (base + 1 < count) v.y = data[base + 1];
+        if (base + 2 < count) v.z = data[base + 2];
+        if (base + 3 < count) v.w = data[base + 3];
     }
-    if (grand_total && threadIdx.x == 0) *grand_total = carry;
-}
-
-static __global__ void __launch_bounds__(1024) k_scan_add(unsigned* __restrict__ data, int count, const unsigned* __restrict__ tile_base)
-{
-    const unsigned add = tile_base[blockIdx.x];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
-}
-
-// second launch of the two-launch form (<= 1024 tiles): every workgroup sums the totals of the tiles before its own
-// (at most 1024 words, one per lane) instead of waiting for a separate scan-of-totals launch
-static __global__ void __launch_bounds__(1024) k_scan_add_totals(unsigned* __restrict__ data, int count, const unsigned* __restrict__ tile_total, int tiles,
-                                                                 unsigned* __restrict__ grand_total)
-{
-    __shared__ unsigned part[16];
-    unsigned x = ((int)threadIdx.x < (int)blockIdx.x) ? tile_total[threadIdx.x] : 0u;
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    const unsigned run = block_exclusive_scan_1024(v.x + v.y + v.z + v.w, lds, nullptr);
+    const unsigned total = lds[15];                        // (stable: nothing writes lds[] below)
+    unsigned long long* status = state + 1;
+    if (threadIdx.x == 0) {
+        const unsigned flag = tile == 0 ? SCAN_PREFIX : SCAN_AGGREGATE;
+        __hip_atomic_store(&status[tile], ((unsigned long long)((epoch << 2) | flag) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == tiles - 1) __hip_atomic_store(&state[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every ticket is out: ready for the next call
+        if (tile == 0) s_prefix = 0u;
+    }
+    if (wave == 0 && tile > 0) {
+        unsigned exclusive = 0;
+        int idx = tile - 1 - lane;                         // the predecessor this lane inspects in the current window of 64
+        for (int spins = 0;;) {
+            unsigned long long w = 0;
+            bool ready = true, prefix = true;              // lanes before tile 0: nothing there, which is a prefix of 0
+            if (idx >= 0) {
+                w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)(w >> 32);
+                ready = (tag >> 2) == epoch && (tag & 3u) != 0u;
+                prefix = ready && (tag & 3u) == SCAN_PREFIX;
+            }
+            const unsigned long long pm = __ballot(prefix), nr = __ballot(!ready);
+            const int nearest = pm ? __builtin_ctzll(pm) : 63;            // lanes 0..nearest are needed
+            const unsigned long long need = nearest >= 63 ? ~0ull : ((2ull << nearest) - 1ull);
+            if (nr & need) {
+                if (++spins > SCAN_SPIN_LIMIT) __builtin_trap();
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            unsigned x = (lane <= nearest && idx >= 0) ? (unsigned)w : 0u;
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            exclusive += __shfl(x, 0);
+            if (pm) break;
+            idx -= 64;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[tile], ((unsigned long long)((epoch << 2) | SCAN_PREFIX) << 32) | (exclusive + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = exclusive;
+        }
+    }
     __syncthreads();
-    unsigned add = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) add += part[w];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (base + k < count) data[base + k] += add;
-    if (grand_total && (int)blockIdx.x == tiles - 1 && threadIdx.x == 0) *grand_total = add + tile_total[tiles - 1];
+    const unsigned r = s_prefix + run;
+    const uint4 o = make_uint4(r, r + v.x, r + v.x + v.y, r + v.x + v.y + v.z);
+    if (vec) *reinterpret_cast<uint4*>(data + base) = o;
+    else {
+        if (base < count) data[base] = o.x;
+        if (base + 1 < count) data[base + 1] = o.y;
+        if (base + 2 < count) data[base + 2] = o.z;
+        if (base + 3 < count) data[base + 3] = o.w;
+    }
+    if (grand_total && tile == tiles - 1 && threadIdx.x == 0) *grand_total = s_prefix + total;
 }
 
 // Short inputs (radix histograms, per-bin tables: a few thousand words) are launch-latency bound, not bandwidth bound:
@@ -147,8 +169,8 @@ static __global__ void __launch_bounds__(1024) k_scan_single(unsigned* __restric
     if (grand_total && threadIdx.x == 0) *grand_total = carry;
 }
 
-// scratch must hold div_up(count, SCAN_TILE) words.  total_out (device pointer, may be null) receives the sum.
-static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, unsigned* scratch, hipStream_t stream)
+// total_out (device pointer, may be null) receives the sum.
+static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, ScanScratch& scratch, hipStream_t stream)
 {
     if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream)); return PHX_OK; }
     if (count <= SCAN_SINGLE_MAX && (reinterpret_cast<uintptr_t>(data) & 15u) == 0) {
@@ -157,14 +179,8 @@ static inline int device_exclusive_scan(unsigned* data, int count, unsigned* tot
         return PHX_OK;
     }
     const int tiles = div_up(count, SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, stream, data, count, scratch);
-    if (tiles <= 1024) {
-        hipLaunchKernelGGL(k_scan_add_totals, dim3(tiles), dim3(1024), 0, stream, data, count, (const unsigned*)scratch, tiles, total_out);
-        PHX_HIP(hipGetLastError());
-        return PHX_OK;
-    }
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, stream, scratch, tiles, total_out);
-    if (tiles > 1) hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(1024), 0, stream, data, count, (const unsigned*)scratch);
+    PHX_TRY(scratch.prepare(tiles, stream));
+    hipLaunchKernelGGL(k_scan_lookback, dim3(tiles), dim3(1024), 0, stream, data, count, scratch.state.p, scratch.epoch, total_out);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }

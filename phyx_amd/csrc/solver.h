@@ -110,7 +110,8 @@ private:
     // device schedule builder scratch
     DevBuf<int> cc_parent_, joint_comp_, bin_of_comp_, rank_of_comp_, grp_goff_, sb_small_;
     DevBuf<unsigned char> cc_static_;
-    DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_, sort_scan_;
+    DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_;
+    ScanScratch sort_scan_;
     DevBuf<unsigned long long> jp_best_[3], jp_used_;      // colouring of the HBM group on the device (schedule_kernels.h)
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
     DevBuf<unsigned long long> jp_used_b_, jp_seen_;

@@ -287,7 +287,6 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(joint_comp_.reserve(njs)); PHX_TRY(sb_small_.reserve(8));
     for (int k = 0; k < 2; ++k) { PHX_TRY(sort_keys_[k].reserve(njs)); PHX_TRY(sort_vals_[k].reserve(njs)); }
     PHX_TRY(sort_hist_.reserve(radix_hist_words(nj)));
-    PHX_TRY(sort_scan_.reserve((size_t)div_up(std::max(std::max(nb, nj), RS_WIDE_BINS * div_up(njs, RS_TILE)), SCAN_TILE) + 2));
     PHX_TRY(order_.reserve(njs));
 
     hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p);
@@ -314,7 +313,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
             hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == 0 ? sb_small_.p : (int*)nullptr);
         }
         hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p, comp_size_.p);
-        PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_.p, stream_));
+        PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
                            (const unsigned*)cc_flags_.p, joint_comp_.p, comp_size_.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
@@ -383,7 +382,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
                            sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2);
         int bits = 1;
         while ((1 << bits) <= nbins) ++bits;
-        PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_.p, stream_, &where));
+        PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_, stream_, &where));
     } else {                                    // no bins (Single mode, or nothing fits a workgroup): the HBM group is every joint, in joint order
         hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
         PHX_HIP(hipMemsetAsync(sb_small_.p + 2, 0, sizeof(int), stream_));
@@ -479,12 +478,12 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         // colour sizes, bodies touched, static slots: three small scans, one readback
         unsigned* hist = reinterpret_cast<unsigned*>(jp_small_.p + JP_ROUNDS_MAX + 4);
         hipLaunchKernelGGL(k_jp_hist, dim3(std::min(grid_for(rest), 256)), dim3(256), 0, stream_, (const unsigned*)jp_keys_[0].p, rest, hist);
-        PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_.p, stream_));
+        PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_, stream_));
         PHX_TRY(hbm_body_list_.reserve(nbs));
         hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned*)jp_touched_.p, nb, hbm_body_list_.p);
         int where2 = 0;
         PHX_HIP(hipMemcpyAsync(jp_vals_[0].p, ids, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 6, sort_hist_.p, sort_scan_.p, stream_, &where2));
+        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 6, sort_hist_.p, sort_scan_, stream_, &where2));
         PHX_HIP(hipMemcpyAsync(order_.p + lds_slots, jp_vals_[where2].p, (size_t)rest * sizeof(int), hipMemcpyDeviceToDevice, stream_));
         unsigned h_hist[JP_MAX_COLOURS], h_touched = 0;
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
@@ -494,7 +493,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(static_slot_.reserve(nbs));
         unsigned* sflags = jp_degree_.p;                       // per body + 1; the colouring is done with it
         hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, nb, sflags);
-        PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, sort_scan_.p, stream_));
+        PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, sort_scan_, stream_));
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)sflags, nb, static_slot_.p);
         unsigned h_nstatic = 0;
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));

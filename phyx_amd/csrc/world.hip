@@ -70,7 +70,8 @@ private:
     DevBuf<phx_manifold> d_manifolds_;
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
-    DevBuf<unsigned> flags_, dead_flags_, scan_tiles_, counters_;     // counters_: [0] dead/new total, [1] dropped points
+    DevBuf<unsigned> flags_, dead_flags_, counters_;
+    ScanScratch scan_tiles_;     // counters_: [0] dead/new total, [1] dropped points
     Readback rb_;
     bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
     DevBuf<int> mover_pos_;
@@ -157,7 +158,6 @@ int World::scratch_for(int n)
 {
     PHX_TRY(flags_.reserve((size_t)n + 2));
     PHX_TRY(mover_pos_.reserve((size_t)n + 2));
-    PHX_TRY(scan_tiles_.reserve((size_t)div_up(n + 1, SCAN_TILE) + 1));
     return PHX_OK;
 }
 
@@ -187,7 +187,7 @@ int World::update_manifolds()                                               // r
 int World::pack_manifolds()                                                 // ref: Collider.cpp:379-416
 {
     if (!nm) return PHX_OK;
-    PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
+    PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
     unsigned host[2] = {0, 0};
     PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
     PHX_TRY(rb_.wait(stream_));
@@ -214,11 +214,11 @@ int World::refresh_contact_joints()                                         // r
     if (nm) {
         hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
                            d_joints_.p, flags_.p);
-        PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_.p, stream_));
+        PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
     }
     if (nj) {
         hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, dead_flags_.p);
-        PHX_TRY(device_exclusive_scan(dead_flags_.p, nj, counters_.p + 1, scan_tiles_.p, stream_));
+        PHX_TRY(device_exclusive_scan(dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
     }
     if (nm || nj) {                                                         // counters_[0], [1]: adjacent words, one copy
         PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
