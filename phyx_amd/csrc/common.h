@@ -98,6 +98,26 @@ struct DevBuf {
     }
 };
 
+// Growable pinned host staging for small uploads: a hipMemcpyAsync out of pageable memory is staged synchronously by the
+// runtime, one copy dispatch per call; the caller packs its tables here and uploads them with ONE asynchronous copy.  The
+// contents must stay untouched until that copy has run (callers reuse it only behind a wait on the same stream).
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return PHX_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 2 + 64;
+        PHX_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+        return PHX_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // scratch of device_exclusive_scan's single-pass form (device_scan.h): ticket word + one status word per tile + the call counter
 struct ScanScratch {
     DevBuf<unsigned long long> state;

@@ -307,12 +307,24 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
 }
 
 // ---- the HBM group (islands too big for a workgroup, or everything in Single mode): the same colouring in HBM ----------
-// One launch per Jones-Plassmann round.  Three per-body priority tables rotate: `cur` was filled by the previous round
-// (highest priority among the joints still uncoloured on each dynamic body), `next` is filled for the following round by
-// the joints that stay uncoloured, `zero` is cleared for the round after that.  A body has at most one winner per round,
-// so the colour-mask updates do not race.
+// First fit in priority order (schedule.h) is a dependency graph: an entry may take its colour once every higher-priority
+// entry on its two dynamic bodies has taken one.  Round 2's builder ran Jones-Plassmann rounds over ALL uncoloured entries
+// (each recomputing 'am I the highest priority left on my bodies' through per-body tables): ~9 random accesses per survivor
+// per round, 40 rounds and 1.9 ms for a merged 7e5-joint island.  Here the graph is made explicit once and then WALKED:
+//   prepare   per entry: bodies + priority cached in 16 bytes, dynamic bodies' entry counts
+//   lists     per dynamic body: its entries (counting sort by body); rank counting inside a list (bodies touch a handful of
+//             entries: one lane; a body with more than JP_THREAD_SORT_MAX of them gets a wave) gives every entry its
+//             successor on that body and the number of predecessors it waits for (0, 1 or 2)
+//   rounds    a round colours the current FRONTIER (entries whose predecessors are all coloured) and releases their
+//             successors into the next frontier; every entry is visited once, a round costs its frontier, and two frontier
+//             entries never share a dynamic body (both would have to be the first uncoloured entry of its list), so the
+//             bodies' colour masks need no atomics.
+// The colours are the ones the host builder computes (tests/test_solver_gpu.py compares the schedules).
 constexpr unsigned JP_NONE = 0xFFFFFFFFu;
 constexpr int JP_MAX_COLOURS = 64;
+constexpr int JP_THREAD_SORT_MAX = 32;
+constexpr int JP_LIST_MAX = 4096;            // longer lists (one body in thousands of joints): host builder
+constexpr unsigned JP_STATIC_BIT = 0x80000000u;
 
 struct JpView {
     const unsigned* ids;              // the group's joints, ascending joint index
@@ -320,9 +332,16 @@ struct JpView {
     const phx_contact_joint* joints;
     const unsigned char* is_static;
     int nb;
+    uint4* ent;                       // per entry: {body1 | static bit, body2 | static bit, priority lo, priority hi}
+    unsigned* offset;                 // per body + 1: entries of the group on it (dynamic bodies only), then their exclusive scan
+    unsigned* cursor;                 // per body: fill position while the lists are built
+    uint4* adj;                       // per (body, position): {priority lo, hi, entry, which of its bodies} — unordered
+    unsigned* ent_comp;               // per entry: connected component (ncomp: both bodies static)
+    uint2* succ;                      // per entry: the next entry on body1 / body2 (JP_NONE: last, or the body is static)
+    unsigned* pred;                   // per entry: predecessors not coloured yet | predecessors << 16
+    unsigned* big;                    // [0] = count, then the bodies whose lists a wave sorts
     unsigned long long* used;         // per body: colours taken (candidate A: smallest free colour)
     unsigned long long* used_b;       // per body: colours taken under candidate B (two-ended, schedule.h)
-    unsigned* degree;                 // per body: joints of the group on it (filled by round 0)
     unsigned* colour_b;               // per entry: candidate B's colour
     const int* joint_comp;            // joint -> connected component (-1: both bodies static)
     int ncomp;
@@ -332,79 +351,178 @@ struct JpView {
     const unsigned* comp_size;        // per component: joints (B is attempted only up to COLOUR_B_MAX_JOINTS)
     unsigned* colour;                 // per entry: JP_NONE until coloured
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
-    int* remaining;                   // per round: nonzero if some joint is still uncoloured after it
-    int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours
+    int* counts;                      // per round: size of the frontier it colours
+    int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX
+    unsigned* hist;                   // per colour: entries (filled after the choice)
 };
 
-// `list_in` / `count_in` (null in rounds 0 and 1: every entry): the entries still uncoloured after the previous round;
-// `list_out` / `count_out` (null in round 0): where this round appends the entries it leaves uncoloured.  The uncoloured set
-// shrinks geometrically, so compacting it keeps the cost of the whole colouring near that of its first rounds (a merged
-// 7e5-joint island needs ~40 rounds: 1.7 ms when every round scanned every entry).
-static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigned long long* __restrict__ cur, unsigned long long* next,
-                                                         unsigned long long* zero, int round, const unsigned* __restrict__ list_in,
-                                                         const int* __restrict__ count_in, unsigned* __restrict__ list_out, int* __restrict__ count_out)
+// every per-body table and the small words in ONE launch (a memset is a dispatch of its own, and there were a dozen)
+static __global__ void __launch_bounds__(256) k_jp_clear(JpView v, int rounds_max)
 {
-    bool left = false;
-    const int n = list_in ? *count_in : v.count;
-    const int lane = threadIdx.x & 63;
-    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {       // wave-uniform trip count
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = i0; i <= v.nb; i += stride) {
+        v.touched[i] = 0u; v.offset[i] = 0u;
+        if (i < v.nb) { v.cursor[i] = 0u; v.used[i] = 0ull; v.used_b[i] = 0ull; }
+    }
+    for (int i = i0; i <= v.ncomp; i += stride) { v.seen_a[i] = 0ull; v.seen_b[i] = 0ull; v.bad_b[i] = 0; }
+    for (int i = i0; i <= rounds_max; i += stride) v.counts[i] = 0;
+    if (i0 < JP_MAX_COLOURS) v.hist[i0] = 0u;
+    if (i0 == 0) { *v.flags = 0; v.big[0] = 0u; }
+}
+
+static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
+        const unsigned j = v.ids[k];
+        const phx_contact_joint jt = v.joints[j];
+        unsigned a = (unsigned)jt.body1, b = (unsigned)jt.body2;
+        const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
+        v.pred[k] = 0u; v.colour_b[k] = 0u; v.colour[k] = JP_NONE;
+        { const int jc = v.joint_comp[j]; v.ent_comp[k] = jc < 0 ? (unsigned)v.ncomp : (unsigned)jc; }
+        v.succ[k] = make_uint2(JP_NONE, JP_NONE);
+        if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) {                  // reported; the entry is parked on nothing
+            atomicOr(v.flags, 1);
+            v.ent[k] = make_uint4(JP_STATIC_BIT, JP_STATIC_BIT, (unsigned)key, (unsigned)(key >> 32));
+            continue;
+        }
+        v.touched[a] = 1u; v.touched[b] = 1u;
+        if (v.is_static[a]) a |= JP_STATIC_BIT; else atomicAdd(&v.offset[a], 1u);
+        if (v.is_static[b]) b |= JP_STATIC_BIT; else atomicAdd(&v.offset[b], 1u);
+        v.ent[k] = make_uint4(a, b, (unsigned)key, (unsigned)(key >> 32));
+    }
+}
+
+// the lists, unordered: a slot carries the entry's priority and which of its bodies this is, so that ordering a list reads
+// nothing but the list
+static __global__ void __launch_bounds__(256) k_jp_fill(JpView v)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
+        const uint4 e = v.ent[k];
+        if (!(e.x & JP_STATIC_BIT)) v.adj[v.offset[e.x] + atomicAdd(&v.cursor[e.x], 1u)] = make_uint4(e.z, e.w, (unsigned)k, 0u);
+        if (!(e.y & JP_STATIC_BIT)) v.adj[v.offset[e.y] + atomicAdd(&v.cursor[e.y], 1u)] = make_uint4(e.z, e.w, (unsigned)k, 1u);
+    }
+}
+
+__device__ __forceinline__ unsigned long long jp_key(const uint4& slot) { return ((unsigned long long)slot.y << 32) | slot.x; }
+
+// the entry with `rank` in its body's list (keys are unique, so rank counting is a sort): it learns its successor on that
+// body when the successor places itself, and waits for one more predecessor unless it is the head
+__device__ __forceinline__ void jp_place(const JpView& v, unsigned o, int d, int i)
+{
+    const uint4 me = v.adj[o + i];
+    const unsigned long long key = jp_key(me);
+    int rank = 0;
+    unsigned long long above = ~0ull;                  // the smallest key above mine = my predecessor
+    unsigned pred_entry = JP_NONE, pred_side = 0;
+    for (int j = 0; j < d; ++j) {
+        const uint4 other = v.adj[o + j];
+        const unsigned long long ok = jp_key(other);
+        if (ok > key) { ++rank; if (ok < above) { above = ok; pred_entry = other.z; pred_side = other.w; } }
+    }
+    if (rank == 0) return;
+    atomicAdd(&v.pred[me.z], 0x10001u);              // low half: predecessors still uncoloured; high half: how many there were
+    if (pred_side) v.succ[pred_entry].y = me.z; else v.succ[pred_entry].x = me.z;
+}
+
+static __global__ void __launch_bounds__(256) k_jp_lists(JpView v)
+{
+    for (int body = blockIdx.x * blockDim.x + threadIdx.x; body < v.nb; body += gridDim.x * blockDim.x) {
+        const unsigned o = v.offset[body];
+        const int d = (int)(v.offset[body + 1] - o);
+        if (d == 0) continue;
+        if (d > JP_THREAD_SORT_MAX) {
+            if (d > JP_LIST_MAX) { atomicOr(v.flags, 4); continue; }
+            v.big[1 + atomicAdd(&v.big[0], 1u)] = (unsigned)body;
+            continue;
+        }
+        for (int i = 0; i < d; ++i) jp_place(v, o, d, i);
+    }
+}
+
+// the long lists: one wave per body
+static __global__ void __launch_bounds__(256) k_jp_lists_big(JpView v)
+{
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+    const int n = (int)v.big[0];
+    for (int w = wave; w < n; w += waves) {
+        const unsigned body = v.big[1 + w];
+        const unsigned o = v.offset[body];
+        const int d = (int)(v.offset[body + 1] - o);
+        for (int i = lane; i < d; i += 64) jp_place(v, o, d, i);
+    }
+}
+
+// One round: colour the frontier, release the successors.  Round 0 has no list: its frontier is every entry that waits for
+// nobody.  The next frontier is appended with ONE atomic per workgroup (thousands of same-address atomics per round
+// serialise: measured 126 us for seeding 7e5 entries with one per wave).
+static __global__ void __launch_bounds__(256) k_jp_front(JpView v, int round, const unsigned* __restrict__ list_in, unsigned* __restrict__ list_out)
+{
+    __shared__ int wave_n[4];
+    __shared__ int block_base;
+    const int n = round ? v.counts[round] : v.count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {             // workgroup-uniform trip count
         const int i = base + (int)threadIdx.x;
-        bool stay = false;
-        int k = 0, comp = 0;
-        unsigned long long got_a = 0, got_b = 0;             // the colour bits this lane's joint took under candidates A / B
-        if (i < n) {
-            k = list_in ? (int)list_in[i] : i;
-            if (v.colour[k] == JP_NONE) {
-                const unsigned j = v.ids[k];
-                const phx_contact_joint jt = v.joints[j];
-                const unsigned a = (unsigned)jt.body1, b = (unsigned)jt.body2;
-                if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) { atomicOr(v.flags, 1); v.colour[k] = 0; }
+        unsigned k = 0, s0 = JP_NONE, s1 = JP_NONE;
+        int comp = 0;
+        unsigned long long got_a = 0, got_b = 0;             // the colour bits this lane's entry took under candidates A / B
+        bool mine_now = i < n;
+        if (mine_now) {
+            k = round ? list_in[i] : (unsigned)i;
+            if (round == 0 && (v.pred[k] >> 16) != 0u) mine_now = false;      // (the high half never changes: the low one is being counted down by this very launch)
+        }
+        if (mine_now) {
+            const uint4 e = v.ent[k];
+            const bool da = !(e.x & JP_STATIC_BIT), db = !(e.y & JP_STATIC_BIT);
+            const unsigned a = e.x & ~JP_STATIC_BIT, b = e.y & ~JP_STATIC_BIT;
+            comp = (int)v.ent_comp[k];
+            unsigned long long m = 0;
+            if (da) m |= v.used[a];
+            if (db) m |= v.used[b];
+            int c = 0;
+            if (!~m) atomicOr(v.flags, 2);
+            else {
+                c = __builtin_ctzll(~m);
+                if (da) v.used[a] |= 1ull << c;
+                if (db) v.used[b] |= 1ull << c;
+                got_a = 1ull << c;
+            }
+            if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
+                unsigned long long mb = 0;
+                if (da) mb |= v.used_b[a];
+                if (db) mb |= v.used_b[b];
+                const int d0 = da ? (int)(v.offset[a + 1] - v.offset[a]) : 0, d1 = db ? (int)(v.offset[b + 1] - v.offset[b]) : 0;
+                const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
+                if (cb < 0) v.bad_b[comp] = 1;
                 else {
-                    const bool da = !v.is_static[a], db = !v.is_static[b];
-                    const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
-                    bool coloured = false;
-                    if (round == 0) { v.touched[a] = 1u; v.touched[b] = 1u; atomicAdd(&v.degree[a], 1u); atomicAdd(&v.degree[b], 1u); }
-                    else if ((!da || cur[a] == key) && (!db || cur[b] == key)) {
-                        comp = v.joint_comp[j] < 0 ? v.ncomp : v.joint_comp[j];
-                        unsigned long long m = 0;
-                        if (da) m |= v.used[a];
-                        if (db) m |= v.used[b];
-                        int c = 0;
-                        if (!~m) atomicOr(v.flags, 2);
-                        else {
-                            c = __builtin_ctzll(~m);
-                            if (da) v.used[a] |= 1ull << c;
-                            if (db) v.used[b] |= 1ull << c;
-                            got_a = 1ull << c;
-                        }
-                        if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same winner, the two-ended choice
-                            unsigned long long mb = 0;
-                            if (da) mb |= v.used_b[a];
-                            if (db) mb |= v.used_b[b];
-                            const int d0 = da ? (int)v.degree[a] : 0, d1 = db ? (int)v.degree[b] : 0;
-                            const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
-                            if (cb < 0) v.bad_b[comp] = 1;
-                            else {
-                                if (da) v.used_b[a] |= 1ull << cb;
-                                if (db) v.used_b[b] |= 1ull << cb;
-                                got_b = 1ull << cb;
-                                v.colour_b[k] = (unsigned)cb;
-                            }
-                        }
-                        v.colour[k] = (unsigned)c;
-                        coloured = true;
-                    }
-                    if (!coloured) {
-                        if (da) { atomicMax(&next[a], key); zero[a] = 0ull; }
-                        if (db) { atomicMax(&next[b], key); zero[b] = 0ull; }
-                        stay = true;
-                    }
+                    if (da) v.used_b[a] |= 1ull << cb;
+                    if (db) v.used_b[b] |= 1ull << cb;
+                    got_b = 1ull << cb;
+                    v.colour_b[k] = (unsigned)cb;
                 }
             }
+            v.colour[k] = (unsigned)c;
+            const uint2 s = v.succ[k];
+            if (s.x != JP_NONE && (atomicSub(&v.pred[s.x], 1u) & 0xFFFFu) == 1u) s0 = s.x;
+            if (s.y != JP_NONE && (atomicSub(&v.pred[s.y], 1u) & 0xFFFFu) == 1u) s1 = s.y;
         }
-        if (stay) left = true;
-        // 'colours in use' of the components, wave-aggregated: in a merged island every winner of a round belongs to ONE
-        // component, and thousands of same-address atomics serialise (measured: 357 us for one round of a 7e5-joint island)
+        // the released successors -> next frontier
+        const unsigned long long m0 = __ballot(s0 != JP_NONE), m1 = __ballot(s1 != JP_NONE);
+        if (lane == 0) wave_n[wave] = __popcll(m0) + __popcll(m1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+            block_base = total ? atomicAdd(v.counts + round + 1, total) : 0;
+        }
+        __syncthreads();
+        int at = block_base;
+        for (int w = 0; w < wave; ++w) at += wave_n[w];
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (s0 != JP_NONE) list_out[at + __popcll(m0 & below)] = s0;
+        if (s1 != JP_NONE) list_out[at + __popcll(m0) + __popcll(m1 & below)] = s1;
+        __syncthreads();                                                     // wave_n / block_base are reused by the next trip
+        // 'colours in use' of the components, wave-aggregated: in a merged island every entry of a round belongs to ONE
+        // component, and thousands of same-address atomics serialise
         for (unsigned long long todo = __ballot((got_a | got_b) != 0); todo;) {
             const int leader = __builtin_ctzll(todo);
             const int lc = __shfl(comp, leader);
@@ -417,17 +535,7 @@ static __global__ void __launch_bounds__(256) k_jp_round(JpView v, const unsigne
             }
             todo &= ~__ballot(mine);
         }
-        if (list_out) {                                              // append the survivors of this wave with one atomic
-            const unsigned long long mask = __ballot(stay);
-            if (mask) {
-                int at = 0;
-                if (lane == __builtin_ctzll(mask)) at = atomicAdd(count_out, __popcll(mask));
-                at = __shfl(at, __builtin_ctzll(mask));
-                if (stay) list_out[at + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)k;
-            }
-        }
     }
-    if (__any(left) && (threadIdx.x & 63) == 0) v.remaining[round] = 1;      // a flag, not a count: same-address atomics would serialise
 }
 
 // every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order

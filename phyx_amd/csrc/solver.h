@@ -108,11 +108,16 @@ private:
     DevBuf<unsigned char> slot_colour_;
     DevBuf<unsigned long long> isl_visits_;
     // device schedule builder scratch
-    DevBuf<int> cc_parent_, joint_comp_, bin_of_comp_, rank_of_comp_, grp_goff_, sb_small_;
+    DevBuf<int> cc_parent_, joint_comp_, bin_tables_, sb_small_;       // bin_tables_: component -> bin | component -> rank in its bin | bin -> first slot
+    PinnedBuf<int> bin_tables_host_;
     DevBuf<unsigned char> cc_static_;
     DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_;
     ScanScratch sort_scan_;
-    DevBuf<unsigned long long> jp_best_[3], jp_used_;      // colouring of the HBM group on the device (schedule_kernels.h)
+    DevBuf<unsigned long long> jp_used_;                    // colouring of the HBM group on the device (schedule_kernels.h)
+    DevBuf<uint4> jp_ent_, jp_adj_;
+    DevBuf<uint2> jp_succ_;
+    DevBuf<unsigned> jp_offset_, jp_cursor_, jp_big_, jp_pred_, jp_ent_comp_;
+    int jp_rounds_guess_ = 0;
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
     DevBuf<unsigned long long> jp_used_b_, jp_seen_;
     DevBuf<unsigned char> jp_bad_b_;

@@ -38,8 +38,8 @@ DeviceSolver::~DeviceSolver()
     for (hipEvent_t e : bench_events_) (void)hipEventDestroy(e);
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
-    cc_parent_.release(); joint_comp_.release(); bin_of_comp_.release(); rank_of_comp_.release(); grp_goff_.release(); sb_small_.release(); cc_static_.release();
-    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); for (int k = 0; k < 3; ++k) jp_best_[k].release();
+    cc_parent_.release(); joint_comp_.release(); bin_tables_.release(); bin_tables_host_.release(); sb_small_.release(); cc_static_.release();
+    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_big_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release();
     jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
@@ -370,15 +370,19 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     lds_slots = sc.group_offsets.back();
     for (int c = 0; c < ncomp; ++c) if (bin_of[c] < 0) bin_of[c] = nbins;
     sc.lds_groups = nbins;
-    PHX_TRY(bin_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(rank_of_comp_.reserve(std::max(ncomp, 1))); PHX_TRY(grp_goff_.reserve(nbins + 2));
-    if (ncomp) PHX_HIP(hipMemcpyAsync(bin_of_comp_.p, bin_of.data(), (size_t)ncomp * sizeof(int), hipMemcpyHostToDevice, stream_));
-    if (ncomp) PHX_HIP(hipMemcpyAsync(rank_of_comp_.p, rank_of.data(), (size_t)ncomp * sizeof(int), hipMemcpyHostToDevice, stream_));
-    PHX_HIP(hipMemcpyAsync(grp_goff_.p, sc.group_offsets.data(), (size_t)(nbins + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
+    // one upload: component -> bin, component -> rank inside its bin, bin -> first slot
+    const size_t nc1 = (size_t)std::max(ncomp, 1), table_words = 2 * nc1 + (size_t)nbins + 2;
+    PHX_TRY(bin_tables_.reserve(table_words)); PHX_TRY(bin_tables_host_.reserve(table_words));
+    std::copy(bin_of.begin(), bin_of.end(), bin_tables_host_.p);
+    std::copy(rank_of.begin(), rank_of.end(), bin_tables_host_.p + nc1);
+    std::copy(sc.group_offsets.begin(), sc.group_offsets.begin() + nbins + 1, bin_tables_host_.p + 2 * nc1);
+    PHX_HIP(hipMemcpyAsync(bin_tables_.p, bin_tables_host_.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
+    const int* bin_of_comp = bin_tables_.p; const int* rank_of_comp = bin_tables_.p + nc1; const int* grp_goff = bin_tables_.p + 2 * nc1;
     lap("bin");
 
     // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
     if (nbins) {
-        hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)bin_of_comp_.p, nj, nbins,
+        hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, bin_of_comp, nj, nbins,
                            sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2);
         int bits = 1;
         while ((1 << bits) <= nbins) ++bits;
@@ -395,8 +399,8 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(slot_local_.reserve(std::max(lds_slots, 1))); PHX_TRY(slot_colour_.reserve(std::max(lds_slots, 1)));
     if (nbins) {
         BinBuildView bv{};
-        bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff_.p; bv.joints = d_joints; bv.is_static = cc_static_.p;
-        bv.joint_comp = joint_comp_.p; bv.comp_rank = rank_of_comp_.p;
+        bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.is_static = cc_static_.p;
+        bv.joint_comp = joint_comp_.p; bv.comp_rank = rank_of_comp;
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
         bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2;
@@ -429,54 +433,52 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     sc.hbm_body_count = 0;
     if (rest > 0) {
         const unsigned* ids = sort_vals_[where].p + lds_slots;
-        for (int k = 0; k < 3; ++k) { PHX_TRY(jp_best_[k].reserve(nbs)); PHX_HIP(hipMemsetAsync(jp_best_[k].p, 0, (size_t)nbs * sizeof(unsigned long long), stream_)); }
-        PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_small_.reserve(JP_ROUNDS_MAX + JP_MAX_COLOURS + 8));
-        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); }
-        PHX_HIP(hipMemsetAsync(jp_used_.p, 0, (size_t)nbs * sizeof(unsigned long long), stream_));
-        PHX_HIP(hipMemsetAsync(jp_touched_.p, 0, (size_t)(nbs + 1) * sizeof(unsigned), stream_));
-        PHX_HIP(hipMemsetAsync(jp_small_.p, 0, (size_t)(JP_ROUNDS_MAX + JP_MAX_COLOURS + 8) * sizeof(int), stream_));
-        PHX_HIP(hipMemsetAsync(jp_keys_[0].p, 0xFF, (size_t)rest * sizeof(unsigned), stream_));
+        PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_degree_.reserve(nbs + 1));
+        PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs)); PHX_TRY(jp_big_.reserve(nbs + 1));
+        PHX_TRY(jp_small_.reserve(JP_MAX_COLOURS + 8)); PHX_TRY(jp_counts_.reserve(JP_ROUNDS_MAX + 2));
+        PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
+        PHX_TRY(jp_ent_.reserve(rest)); PHX_TRY(jp_succ_.reserve(rest)); PHX_TRY(jp_pred_.reserve(rest)); PHX_TRY(jp_colour_b_.reserve(rest));
+        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); PHX_TRY(jp_list_[k].reserve(rest)); }
+        PHX_TRY(jp_adj_.reserve(2 * (size_t)rest)); PHX_TRY(jp_ent_comp_.reserve(rest));
         JpView jv{};
         jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = cc_static_.p; jv.nb = nb;
-        jv.used = jp_used_.p; jv.colour = jp_keys_[0].p; jv.touched = jp_touched_.p;
-        jv.remaining = jp_small_.p; jv.flags = jp_small_.p + JP_ROUNDS_MAX;
-        // the second colouring candidate and the per-component bookkeeping of the choice (schedule.h)
-        PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_degree_.reserve(nbs + 1)); PHX_TRY(jp_colour_b_.reserve(rest));
-        PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
-        PHX_HIP(hipMemsetAsync(jp_used_b_.p, 0, (size_t)nbs * sizeof(unsigned long long), stream_));
-        PHX_HIP(hipMemsetAsync(jp_degree_.p, 0, (size_t)nbs * sizeof(unsigned), stream_));
-        PHX_HIP(hipMemsetAsync(jp_colour_b_.p, 0, (size_t)rest * sizeof(unsigned), stream_));
-        PHX_HIP(hipMemsetAsync(jp_seen_.p, 0, 2 * ((size_t)ncomp_total + 1) * sizeof(unsigned long long), stream_));
-        PHX_HIP(hipMemsetAsync(jp_bad_b_.p, 0, (size_t)ncomp_total + 1, stream_));
-        jv.used_b = jp_used_b_.p; jv.degree = jp_degree_.p; jv.colour_b = jp_colour_b_.p; jv.joint_comp = joint_comp_.p; jv.ncomp = ncomp_total;
-        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p; jv.comp_size = comp_size_.p;
-        // survivor lists: round r >= 1 appends what it leaves uncoloured to list r & 1, round r >= 2 reads list (r - 1) & 1
-        for (int k = 0; k < 2; ++k) PHX_TRY(jp_list_[k].reserve(rest));
-        PHX_TRY(jp_counts_.reserve(JP_ROUNDS_MAX + 1));
-        PHX_HIP(hipMemsetAsync(jp_counts_.p, 0, (size_t)(JP_ROUNDS_MAX + 1) * sizeof(int), stream_));
+        jv.ent = jp_ent_.p; jv.offset = jp_offset_.p; jv.cursor = jp_cursor_.p; jv.adj = jp_adj_.p; jv.ent_comp = jp_ent_comp_.p;
+        jv.succ = jp_succ_.p; jv.pred = jp_pred_.p; jv.big = jp_big_.p;
+        jv.used = jp_used_.p; jv.used_b = jp_used_b_.p; jv.colour = jp_keys_[0].p; jv.colour_b = jp_colour_b_.p; jv.touched = jp_touched_.p;
+        jv.joint_comp = joint_comp_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
+        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
+        jv.counts = jp_counts_.p; jv.flags = jp_small_.p; jv.hist = reinterpret_cast<unsigned*>(jp_small_.p + 4);
+        // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
+        // priority, successor links and predecessor counts
+        hipLaunchKernelGGL(k_jp_clear, dim3(grid_for(std::max(nb + 1, ncomp_total + 1))), dim3(256), 0, stream_, jv, JP_ROUNDS_MAX + 1);
+        hipLaunchKernelGGL(k_jp_prepare, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
+        PHX_TRY(device_exclusive_scan(jp_offset_.p, nb + 1, nullptr, sort_scan_, stream_));
+        hipLaunchKernelGGL(k_jp_fill, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
+        hipLaunchKernelGGL(k_jp_lists, dim3(grid_for(nb)), dim3(256), 0, stream_, jv);
+        hipLaunchKernelGGL(k_jp_lists_big, dim3(64), dim3(256), 0, stream_, jv);
+        // the rounds: as many as the previous build needed (+2) before the first look at the frontier, then in small batches
         int round = 0;
         for (bool done = false; !done;) {
-            if (round + JP_BATCH > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }       // pathological dependency chain: host builder
-            for (int k = 0; k < JP_BATCH; ++k, ++round)
-                hipLaunchKernelGGL(k_jp_round, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned long long*)jp_best_[round % 3].p,
-                                   jp_best_[(round + 1) % 3].p, jp_best_[(round + 2) % 3].p, round,
-                                   round >= 2 ? (const unsigned*)jp_list_[(round - 1) & 1].p : (const unsigned*)nullptr,
-                                   round >= 2 ? (const int*)(jp_counts_.p + round - 1) : (const int*)nullptr,
-                                   round >= 1 ? jp_list_[round & 1].p : (unsigned*)nullptr, round >= 1 ? jp_counts_.p + round : (int*)nullptr);
-            int tail[2] = {0, 0};
+            const int batch = round == 0 ? std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX) : JP_BATCH;
+            if (round + batch > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }           // pathological dependency chain: host builder
+            for (int k = 0; k < batch; ++k, ++round)
+                hipLaunchKernelGGL(k_jp_front, dim3(round ? std::min(grid_for(rest), 512) : grid_for(rest)), dim3(256), 0, stream_, jv, round, (const unsigned*)jp_list_[round & 1].p, jp_list_[(round + 1) & 1].p);
+            int flags = 0;
+            std::vector<int> sizes((size_t)batch + 1, 0);                                      // the frontiers of this batch's rounds and of the next one
             PHX_TRY(with_fingerprint());
-            PHX_TRY(rb_.add(&tail[0], jp_small_.p + round - 1, sizeof(int), stream_));
-            PHX_TRY(rb_.add(&tail[1], jp_small_.p + JP_ROUNDS_MAX, sizeof(int), stream_));
+            PHX_TRY(rb_.add(sizes.data(), jp_counts_.p + round - batch, sizes.size() * sizeof(int), stream_));
+            PHX_TRY(rb_.add(&flags, jp_small_.p, sizeof(int), stream_));
             PHX_TRY(rb_.wait(stream_));
-            if (tail[1] & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
-            if (tail[1] & 2) { *fallback = true; return PHX_OK; }                             // > 64 colours: host builder (wider masks)
-            done = tail[0] == 0;
+            if (flags & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
+            if (flags & 6) { *fallback = true; return PHX_OK; }                               // > 64 colours or a body in thousands of joints: host builder
+            for (int k = (round == batch ? 1 : 0); k <= batch && !done; ++k)                      // (round 0 has no list: it scans every entry)
+                if (sizes[k] == 0) { done = true; jp_rounds_guess_ = round - batch + k; }
         }
-        if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d Jones-Plassmann rounds\n", rest, round);
+        if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d rounds (%d launched)\n", rest, jp_rounds_guess_, round);
         lap("rest/colour");
         hipLaunchKernelGGL(k_jp_choose, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
         // colour sizes, bodies touched, static slots: three small scans, one readback
-        unsigned* hist = reinterpret_cast<unsigned*>(jp_small_.p + JP_ROUNDS_MAX + 4);
+        unsigned* hist = jv.hist;
         hipLaunchKernelGGL(k_jp_hist, dim3(std::min(grid_for(rest), 256)), dim3(256), 0, stream_, (const unsigned*)jp_keys_[0].p, rest, hist);
         PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_, stream_));
         PHX_TRY(hbm_body_list_.reserve(nbs));
