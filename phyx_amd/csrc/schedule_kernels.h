@@ -312,9 +312,9 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
 // (each recomputing 'am I the highest priority left on my bodies' through per-body tables): ~9 random accesses per survivor
 // per round, 40 rounds and 1.9 ms for a merged 7e5-joint island.  Here the graph is made explicit once and then WALKED:
 //   prepare   per entry: bodies + priority cached in 16 bytes, dynamic bodies' entry counts
-//   lists     per dynamic body: its entries (counting sort by body); rank counting inside a list (bodies touch a handful of
-//             entries: one lane; a body with more than JP_THREAD_SORT_MAX of them gets a wave) gives every entry its
-//             successor on that body and the number of predecessors it waits for (0, 1 or 2)
+//   lists     per dynamic body: its entries (counting sort by body); one lane per list slot finds the entry just above it
+//             in priority, which gives every entry its successor on that body and the number of predecessors it waits
+//             for (0, 1 or 2)
 //   rounds    a round colours the current FRONTIER (entries whose predecessors are all coloured) and releases their
 //             successors into the next frontier; every entry is visited once, a round costs its frontier, and two frontier
 //             entries never share a dynamic body (both would have to be the first uncoloured entry of its list), so the
@@ -322,9 +322,11 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
 // The colours are the ones the host builder computes (tests/test_solver_gpu.py compares the schedules).
 constexpr unsigned JP_NONE = 0xFFFFFFFFu;
 constexpr int JP_MAX_COLOURS = 64;
-constexpr int JP_THREAD_SORT_MAX = 32;
 constexpr int JP_LIST_MAX = 4096;            // longer lists (one body in thousands of joints): host builder
 constexpr unsigned JP_STATIC_BIT = 0x80000000u;
+constexpr int JP_FRONT_T = 256;       // lanes per workgroup of a round (1024 was measured slower: a 5e4-entry frontier then covers 50 CUs)
+constexpr int JP_SUBLISTS = 8;        // a frontier is kept as 8 lists with a counter each: same-address atomics with a return value cost ~35 ns
+                                      // apiece, serialised — one counter made them half of a round
 
 struct JpView {
     const unsigned* ids;              // the group's joints, ascending joint index
@@ -339,7 +341,6 @@ struct JpView {
     unsigned* ent_comp;               // per entry: connected component (ncomp: both bodies static)
     uint2* succ;                      // per entry: the next entry on body1 / body2 (JP_NONE: last, or the body is static)
     unsigned* pred;                   // per entry: predecessors not coloured yet | predecessors << 16
-    unsigned* big;                    // [0] = count, then the bodies whose lists a wave sorts
     unsigned long long* used;         // per body: colours taken (candidate A: smallest free colour)
     unsigned long long* used_b;       // per body: colours taken under candidate B (two-ended, schedule.h)
     unsigned* colour_b;               // per entry: candidate B's colour
@@ -351,7 +352,7 @@ struct JpView {
     const unsigned* comp_size;        // per component: joints (B is attempted only up to COLOUR_B_MAX_JOINTS)
     unsigned* colour;                 // per entry: JP_NONE until coloured
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
-    int* counts;                      // per round: size of the frontier it colours
+    int* counts;                      // per round and sublist: size of the frontier it colours
     int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX
     unsigned* hist;                   // per colour: entries (filled after the choice)
 };
@@ -365,9 +366,9 @@ static __global__ void __launch_bounds__(256) k_jp_clear(JpView v, int rounds_ma
         if (i < v.nb) { v.cursor[i] = 0u; v.used[i] = 0ull; v.used_b[i] = 0ull; }
     }
     for (int i = i0; i <= v.ncomp; i += stride) { v.seen_a[i] = 0ull; v.seen_b[i] = 0ull; v.bad_b[i] = 0; }
-    for (int i = i0; i <= rounds_max; i += stride) v.counts[i] = 0;
+    for (int i = i0; i < (rounds_max + 1) * JP_SUBLISTS; i += stride) v.counts[i] = 0;
     if (i0 < JP_MAX_COLOURS) v.hist[i0] = 0u;
-    if (i0 == 0) { *v.flags = 0; v.big[0] = 0u; }
+    if (i0 == 0) *v.flags = 0;
 }
 
 static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
@@ -398,143 +399,148 @@ static __global__ void __launch_bounds__(256) k_jp_fill(JpView v)
 {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
         const uint4 e = v.ent[k];
-        if (!(e.x & JP_STATIC_BIT)) v.adj[v.offset[e.x] + atomicAdd(&v.cursor[e.x], 1u)] = make_uint4(e.z, e.w, (unsigned)k, 0u);
-        if (!(e.y & JP_STATIC_BIT)) v.adj[v.offset[e.y] + atomicAdd(&v.cursor[e.y], 1u)] = make_uint4(e.z, e.w, (unsigned)k, 1u);
+        if (!(e.x & JP_STATIC_BIT)) v.adj[v.offset[e.x] + atomicAdd(&v.cursor[e.x], 1u)] = make_uint4(e.z, e.w, (unsigned)k, e.x);
+        if (!(e.y & JP_STATIC_BIT)) v.adj[v.offset[e.y] + atomicAdd(&v.cursor[e.y], 1u)] = make_uint4(e.z, e.w, (unsigned)k, e.y | JP_STATIC_BIT);
     }
 }
 
 __device__ __forceinline__ unsigned long long jp_key(const uint4& slot) { return ((unsigned long long)slot.y << 32) | slot.x; }
 
-// the entry with `rank` in its body's list (keys are unique, so rank counting is a sort): it learns its successor on that
-// body when the successor places itself, and waits for one more predecessor unless it is the head
-__device__ __forceinline__ void jp_place(const JpView& v, unsigned o, int d, int i)
-{
-    const uint4 me = v.adj[o + i];
-    const unsigned long long key = jp_key(me);
-    int rank = 0;
-    unsigned long long above = ~0ull;                  // the smallest key above mine = my predecessor
-    unsigned pred_entry = JP_NONE, pred_side = 0;
-    for (int j = 0; j < d; ++j) {
-        const uint4 other = v.adj[o + j];
-        const unsigned long long ok = jp_key(other);
-        if (ok > key) { ++rank; if (ok < above) { above = ok; pred_entry = other.z; pred_side = other.w; } }
-    }
-    if (rank == 0) return;
-    atomicAdd(&v.pred[me.z], 0x10001u);              // low half: predecessors still uncoloured; high half: how many there were
-    if (pred_side) v.succ[pred_entry].y = me.z; else v.succ[pred_entry].x = me.z;
-}
-
+// One lane per list slot.  Keys are unique, so counting the keys above mine is a sort: the smallest of them belongs to my
+// predecessor on this body, which learns here that I am its successor; unless I am the head I wait for one more entry.
+// (word 3 of a slot: the body, top bit = 'the entry's second body')
 static __global__ void __launch_bounds__(256) k_jp_lists(JpView v)
 {
-    for (int body = blockIdx.x * blockDim.x + threadIdx.x; body < v.nb; body += gridDim.x * blockDim.x) {
+    const int slots = (int)v.offset[v.nb];              // dynamic sides only: at most two per entry
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < slots; t += gridDim.x * blockDim.x) {
+        const uint4 me = v.adj[t];
+        const unsigned body = me.w & ~JP_STATIC_BIT;
         const unsigned o = v.offset[body];
         const int d = (int)(v.offset[body + 1] - o);
-        if (d == 0) continue;
-        if (d > JP_THREAD_SORT_MAX) {
-            if (d > JP_LIST_MAX) { atomicOr(v.flags, 4); continue; }
-            v.big[1 + atomicAdd(&v.big[0], 1u)] = (unsigned)body;
-            continue;
+        if (d > JP_LIST_MAX) { if ((unsigned)t == o) atomicOr(v.flags, 4); continue; }
+        const unsigned long long key = jp_key(me);
+        unsigned long long above = ~0ull;
+        unsigned pred_entry = JP_NONE, pred_word = 0;
+        for (int j = 0; j < d; ++j) {
+            const uint4 other = v.adj[o + j];
+            const unsigned long long ok = jp_key(other);
+            if (ok > key && ok < above) { above = ok; pred_entry = other.z; pred_word = other.w; }
         }
-        for (int i = 0; i < d; ++i) jp_place(v, o, d, i);
+        if (pred_entry == JP_NONE) continue;             // head of the list
+        atomicAdd(&v.pred[me.z], 0x10001u);              // low half: predecessors still uncoloured; high half: how many there were
+        if (pred_word & JP_STATIC_BIT) v.succ[pred_entry].y = me.z; else v.succ[pred_entry].x = me.z;
     }
 }
 
-// the long lists: one wave per body
-static __global__ void __launch_bounds__(256) k_jp_lists_big(JpView v)
+// round 0's frontier: flag the entries that wait for nobody, scan, compact
+static __global__ void __launch_bounds__(256) k_jp_seed_flags(JpView v, unsigned* __restrict__ flags)
 {
-    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
-    const int n = (int)v.big[0];
-    for (int w = wave; w < n; w += waves) {
-        const unsigned body = v.big[1 + w];
-        const unsigned o = v.offset[body];
-        const int d = (int)(v.offset[body + 1] - o);
-        for (int i = lane; i < d; i += 64) jp_place(v, o, d, i);
-    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u) ? 1u : 0u;
 }
 
-// One round: colour the frontier, release the successors.  Round 0 has no list: its frontier is every entry that waits for
-// nobody.  The next frontier is appended with ONE atomic per workgroup (thousands of same-address atomics per round
-// serialise: measured 126 us for seeding 7e5 entries with one per wave).
-static __global__ void __launch_bounds__(256) k_jp_front(JpView v, int round, const unsigned* __restrict__ list_in, unsigned* __restrict__ list_out)
+static __global__ void __launch_bounds__(256) k_jp_seed(JpView v, const unsigned* __restrict__ scan, unsigned* __restrict__ list_out)
 {
-    __shared__ int wave_n[4];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x)
+        if (scan[k + 1] != scan[k]) list_out[(size_t)(scan[k] % JP_SUBLISTS) * v.count + scan[k] / JP_SUBLISTS] = (unsigned)k;
+    if (blockIdx.x == 0 && threadIdx.x < JP_SUBLISTS) v.counts[threadIdx.x] = ((int)scan[v.count] + JP_SUBLISTS - 1 - (int)threadIdx.x) / JP_SUBLISTS;
+}
+
+// One round: colour the frontier, release the successors.  (Round 0's frontier — every entry that waits for nobody — is
+// compacted by k_jp_seed_flags + a scan + k_jp_seed.)  A lane takes JP_ITEMS entries per trip (their dependent loads overlap) and the next frontier is appended with ONE
+// atomic per workgroup and trip (thousands of same-address atomics per round serialise: measured 126 us for seeding 7e5
+// entries with one per wave).
+constexpr int JP_ITEMS = 1;           // (4 entries per lane was measured slower: a round is latency bound and wants the lanes)
+
+
+static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int round, const unsigned* __restrict__ list_in, unsigned* __restrict__ list_out)
+{
+    __shared__ int wave_n[JP_FRONT_T / 64];
     __shared__ int block_base;
-    const int n = round ? v.counts[round] : v.count;
+    const int sub = blockIdx.x % JP_SUBLISTS, sub_block = blockIdx.x / JP_SUBLISTS, sub_blocks = gridDim.x / JP_SUBLISTS;      // (the grid is a multiple of JP_SUBLISTS)
+    const int n = v.counts[round * JP_SUBLISTS + sub];
+    list_in += (size_t)sub * v.count; list_out += (size_t)sub * v.count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {             // workgroup-uniform trip count
-        const int i = base + (int)threadIdx.x;
-        unsigned k = 0, s0 = JP_NONE, s1 = JP_NONE;
-        int comp = 0;
-        unsigned long long got_a = 0, got_b = 0;             // the colour bits this lane's entry took under candidates A / B
-        bool mine_now = i < n;
-        if (mine_now) {
-            k = round ? list_in[i] : (unsigned)i;
-            if (round == 0 && (v.pred[k] >> 16) != 0u) mine_now = false;      // (the high half never changes: the low one is being counted down by this very launch)
-        }
-        if (mine_now) {
-            const uint4 e = v.ent[k];
-            const bool da = !(e.x & JP_STATIC_BIT), db = !(e.y & JP_STATIC_BIT);
-            const unsigned a = e.x & ~JP_STATIC_BIT, b = e.y & ~JP_STATIC_BIT;
-            comp = (int)v.ent_comp[k];
-            unsigned long long m = 0;
-            if (da) m |= v.used[a];
-            if (db) m |= v.used[b];
-            int c = 0;
-            if (!~m) atomicOr(v.flags, 2);
-            else {
-                c = __builtin_ctzll(~m);
-                if (da) v.used[a] |= 1ull << c;
-                if (db) v.used[b] |= 1ull << c;
-                got_a = 1ull << c;
+    for (int base = sub_block * blockDim.x * JP_ITEMS; base < n; base += sub_blocks * blockDim.x * JP_ITEMS) {      // workgroup-uniform trip count
+        unsigned rel[2 * JP_ITEMS];                          // released successors
+        int released = 0;
+#pragma unroll
+        for (int it = 0; it < JP_ITEMS; ++it) {
+            const int i = base + it * (int)blockDim.x + (int)threadIdx.x;
+            unsigned k = 0, s0 = JP_NONE, s1 = JP_NONE;
+            int comp = 0;
+            unsigned long long got_a = 0, got_b = 0;         // the colour bits this entry took under candidates A / B
+            bool mine_now = i < n;
+            if (mine_now) {
+                k = list_in[i];
             }
-            if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
-                unsigned long long mb = 0;
-                if (da) mb |= v.used_b[a];
-                if (db) mb |= v.used_b[b];
-                const int d0 = da ? (int)(v.offset[a + 1] - v.offset[a]) : 0, d1 = db ? (int)(v.offset[b + 1] - v.offset[b]) : 0;
-                const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
-                if (cb < 0) v.bad_b[comp] = 1;
+            if (mine_now) {
+                const uint4 e = v.ent[k];
+                const bool da = !(e.x & JP_STATIC_BIT), db = !(e.y & JP_STATIC_BIT);
+                const unsigned a = e.x & ~JP_STATIC_BIT, b = e.y & ~JP_STATIC_BIT;
+                comp = (int)v.ent_comp[k];
+                unsigned long long m = 0;
+                if (da) m |= v.used[a];
+                if (db) m |= v.used[b];
+                int c = 0;
+                if (!~m) atomicOr(v.flags, 2);
                 else {
-                    if (da) v.used_b[a] |= 1ull << cb;
-                    if (db) v.used_b[b] |= 1ull << cb;
-                    got_b = 1ull << cb;
-                    v.colour_b[k] = (unsigned)cb;
+                    c = __builtin_ctzll(~m);
+                    if (da) v.used[a] |= 1ull << c;
+                    if (db) v.used[b] |= 1ull << c;
+                    got_a = 1ull << c;
                 }
+                if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
+                    unsigned long long mb = 0;
+                    if (da) mb |= v.used_b[a];
+                    if (db) mb |= v.used_b[b];
+                    const int d0 = da ? (int)(v.offset[a + 1] - v.offset[a]) : 0, d1 = db ? (int)(v.offset[b + 1] - v.offset[b]) : 0;
+                    const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
+                    if (cb < 0) v.bad_b[comp] = 1;
+                    else {
+                        if (da) v.used_b[a] |= 1ull << cb;
+                        if (db) v.used_b[b] |= 1ull << cb;
+                        got_b = 1ull << cb;
+                        v.colour_b[k] = (unsigned)cb;
+                    }
+                }
+                v.colour[k] = (unsigned)c;
+                const uint2 s = v.succ[k];
+                if (s.x != JP_NONE && (atomicSub(&v.pred[s.x], 1u) & 0xFFFFu) == 1u) s0 = s.x;
+                if (s.y != JP_NONE && (atomicSub(&v.pred[s.y], 1u) & 0xFFFFu) == 1u) s1 = s.y;
             }
-            v.colour[k] = (unsigned)c;
-            const uint2 s = v.succ[k];
-            if (s.x != JP_NONE && (atomicSub(&v.pred[s.x], 1u) & 0xFFFFu) == 1u) s0 = s.x;
-            if (s.y != JP_NONE && (atomicSub(&v.pred[s.y], 1u) & 0xFFFFu) == 1u) s1 = s.y;
+            rel[2 * it] = s0; rel[2 * it + 1] = s1;
+            released += (s0 != JP_NONE ? 1 : 0) + (s1 != JP_NONE ? 1 : 0);
+            // 'colours in use' of the components, wave-aggregated: in a merged island every entry of a round belongs to ONE
+            // component, and thousands of same-address atomics serialise
+            for (unsigned long long todo = __ballot((got_a | got_b) != 0); todo;) {
+                const int leader = __builtin_ctzll(todo);
+                const int lc = __shfl(comp, leader);
+                const bool mine = (got_a | got_b) != 0 && comp == lc;
+                unsigned long long ra = mine ? got_a : 0ull, rb = mine ? got_b : 0ull;
+                for (int off = 32; off > 0; off >>= 1) { ra |= __shfl_xor(ra, off); rb |= __shfl_xor(rb, off); }
+                if (lane == leader) {
+                    if (ra & ~v.seen_a[lc]) atomicOr(&v.seen_a[lc], ra);
+                    if (rb & ~v.seen_b[lc]) atomicOr(&v.seen_b[lc], rb);
+                }
+                todo &= ~__ballot(mine);
+            }
         }
-        // the released successors -> next frontier
-        const unsigned long long m0 = __ballot(s0 != JP_NONE), m1 = __ballot(s1 != JP_NONE);
-        if (lane == 0) wave_n[wave] = __popcll(m0) + __popcll(m1);
+        // the released successors -> next frontier: exclusive position of this lane's first one inside the workgroup
+        int incl = released;
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+        if (lane == 63) wave_n[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int total = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
-            block_base = total ? atomicAdd(v.counts + round + 1, total) : 0;
+            int total = 0;
+            for (int w = 0; w < JP_FRONT_T / 64; ++w) total += wave_n[w];
+            block_base = total ? atomicAdd(v.counts + (round + 1) * JP_SUBLISTS + sub, total) : 0;
         }
         __syncthreads();
-        int at = block_base;
+        int at = block_base + incl - released;
         for (int w = 0; w < wave; ++w) at += wave_n[w];
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (s0 != JP_NONE) list_out[at + __popcll(m0 & below)] = s0;
-        if (s1 != JP_NONE) list_out[at + __popcll(m0) + __popcll(m1 & below)] = s1;
+#pragma unroll
+        for (int q = 0; q < 2 * JP_ITEMS; ++q) if (rel[q] != JP_NONE) list_out[at++] = rel[q];
         __syncthreads();                                                     // wave_n / block_base are reused by the next trip
-        // 'colours in use' of the components, wave-aggregated: in a merged island every entry of a round belongs to ONE
-        // component, and thousands of same-address atomics serialise
-        for (unsigned long long todo = __ballot((got_a | got_b) != 0); todo;) {
-            const int leader = __builtin_ctzll(todo);
-            const int lc = __shfl(comp, leader);
-            const bool mine = (got_a | got_b) != 0 && comp == lc;
-            unsigned long long ra = mine ? got_a : 0ull, rb = mine ? got_b : 0ull;
-            for (int off = 32; off > 0; off >>= 1) { ra |= __shfl_xor(ra, off); rb |= __shfl_xor(rb, off); }
-            if (lane == leader) {
-                if (ra & ~v.seen_a[lc]) atomicOr(&v.seen_a[lc], ra);
-                if (rb & ~v.seen_b[lc]) atomicOr(&v.seen_b[lc], rb);
-            }
-            todo &= ~__ballot(mine);
-        }
     }
 }
 

@@ -39,7 +39,7 @@ DeviceSolver::~DeviceSolver()
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
     cc_parent_.release(); joint_comp_.release(); bin_tables_.release(); bin_tables_host_.release(); sb_small_.release(); cc_static_.release();
-    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_big_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release();
+    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release();
     jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
@@ -434,16 +434,16 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     if (rest > 0) {
         const unsigned* ids = sort_vals_[where].p + lds_slots;
         PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_degree_.reserve(nbs + 1));
-        PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs)); PHX_TRY(jp_big_.reserve(nbs + 1));
-        PHX_TRY(jp_small_.reserve(JP_MAX_COLOURS + 8)); PHX_TRY(jp_counts_.reserve(JP_ROUNDS_MAX + 2));
+        PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs));
+        PHX_TRY(jp_small_.reserve(JP_MAX_COLOURS + 8)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
         PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
         PHX_TRY(jp_ent_.reserve(rest)); PHX_TRY(jp_succ_.reserve(rest)); PHX_TRY(jp_pred_.reserve(rest)); PHX_TRY(jp_colour_b_.reserve(rest));
-        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); PHX_TRY(jp_list_[k].reserve(rest)); }
+        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); PHX_TRY(jp_list_[k].reserve((size_t)rest * JP_SUBLISTS)); }
         PHX_TRY(jp_adj_.reserve(2 * (size_t)rest)); PHX_TRY(jp_ent_comp_.reserve(rest));
         JpView jv{};
         jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = cc_static_.p; jv.nb = nb;
         jv.ent = jp_ent_.p; jv.offset = jp_offset_.p; jv.cursor = jp_cursor_.p; jv.adj = jp_adj_.p; jv.ent_comp = jp_ent_comp_.p;
-        jv.succ = jp_succ_.p; jv.pred = jp_pred_.p; jv.big = jp_big_.p;
+        jv.succ = jp_succ_.p; jv.pred = jp_pred_.p;
         jv.used = jp_used_.p; jv.used_b = jp_used_b_.p; jv.colour = jp_keys_[0].p; jv.colour_b = jp_colour_b_.p; jv.touched = jp_touched_.p;
         jv.joint_comp = joint_comp_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
         jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
@@ -454,25 +454,33 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         hipLaunchKernelGGL(k_jp_prepare, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
         PHX_TRY(device_exclusive_scan(jp_offset_.p, nb + 1, nullptr, sort_scan_, stream_));
         hipLaunchKernelGGL(k_jp_fill, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
-        hipLaunchKernelGGL(k_jp_lists, dim3(grid_for(nb)), dim3(256), 0, stream_, jv);
-        hipLaunchKernelGGL(k_jp_lists_big, dim3(64), dim3(256), 0, stream_, jv);
+        hipLaunchKernelGGL(k_jp_lists, dim3(std::max(1, std::min(div_up(2 * rest, 256), 8192))), dim3(256), 0, stream_, jv);
+        {   // round 0's frontier: flags, scan, compaction
+            PHX_TRY(jp_seed_.reserve((size_t)rest + 1));
+            hipLaunchKernelGGL(k_jp_seed_flags, dim3(grid_for(rest + 1)), dim3(256), 0, stream_, jv, jp_seed_.p);
+            PHX_TRY(device_exclusive_scan(jp_seed_.p, rest + 1, nullptr, sort_scan_, stream_));
+            hipLaunchKernelGGL(k_jp_seed, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_seed_.p, jp_list_[0].p);
+        }
         // the rounds: as many as the previous build needed (+2) before the first look at the frontier, then in small batches
         int round = 0;
         for (bool done = false; !done;) {
             const int batch = round == 0 ? std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX) : JP_BATCH;
             if (round + batch > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }           // pathological dependency chain: host builder
             for (int k = 0; k < batch; ++k, ++round)
-                hipLaunchKernelGGL(k_jp_front, dim3(round ? std::min(grid_for(rest), 512) : grid_for(rest)), dim3(256), 0, stream_, jv, round, (const unsigned*)jp_list_[round & 1].p, jp_list_[(round + 1) & 1].p);
+                hipLaunchKernelGGL(k_jp_front, dim3(JP_SUBLISTS * std::max(1, std::min(div_up(rest, JP_FRONT_T * JP_ITEMS * JP_SUBLISTS), 64))), dim3(JP_FRONT_T), 0, stream_, jv, round, (const unsigned*)jp_list_[round & 1].p, jp_list_[(round + 1) & 1].p);
             int flags = 0;
-            std::vector<int> sizes((size_t)batch + 1, 0);                                      // the frontiers of this batch's rounds and of the next one
+            std::vector<int> sizes(((size_t)batch + 1) * JP_SUBLISTS, 0);                      // the frontiers of this batch's rounds and of the next one
             PHX_TRY(with_fingerprint());
-            PHX_TRY(rb_.add(sizes.data(), jp_counts_.p + round - batch, sizes.size() * sizeof(int), stream_));
+            PHX_TRY(rb_.add(sizes.data(), jp_counts_.p + (size_t)(round - batch) * JP_SUBLISTS, sizes.size() * sizeof(int), stream_));
             PHX_TRY(rb_.add(&flags, jp_small_.p, sizeof(int), stream_));
             PHX_TRY(rb_.wait(stream_));
             if (flags & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
             if (flags & 6) { *fallback = true; return PHX_OK; }                               // > 64 colours or a body in thousands of joints: host builder
-            for (int k = (round == batch ? 1 : 0); k <= batch && !done; ++k)                      // (round 0 has no list: it scans every entry)
-                if (sizes[k] == 0) { done = true; jp_rounds_guess_ = round - batch + k; }
+            for (int k = 0; k <= batch && !done; ++k) {
+                int n = 0;
+                for (int q = 0; q < JP_SUBLISTS; ++q) n += sizes[(size_t)k * JP_SUBLISTS + q];
+                if (n == 0) { done = true; jp_rounds_guess_ = round - batch + k; }
+            }
         }
         if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d rounds (%d launched)\n", rest, jp_rounds_guess_, round);
         lap("rest/colour");
