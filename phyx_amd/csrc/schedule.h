@@ -69,7 +69,11 @@ struct Schedule {
     std::vector<uint8_t> slot_colour;     // per slot of an LDS group: colour index inside the group
     std::vector<int> hbm_bodies;          // bodies touched by the HBM group, ascending (the only ones it stages / writes back)
     int hbm_body_count = 0;               // = hbm_bodies.size() when the list is on the host; a device-built list lives in HBM only
-    std::vector<int> hbm_colour_offsets;  // slots of the HBM group's colours (absolute), empty if there is no HBM group
+    std::vector<int> hbm_colour_offsets;  // slots of the HBM group's classes (absolute), empty if there is no HBM group
+    std::vector<int> hbm_class_leaders;   // per class of the HBM group: its leaders (the slots behind them are the followers)
+    // units of the LDS groups, in class order: slots of a unit's leader and follower (-1: none); group g's units are
+    // [group_unit_offsets[g], group_unit_offsets[g + 1])
+    std::vector<int> group_unit_offsets, unit_leader, unit_follower;
     // A schedule built on the device keeps the LDS groups' order / colours in HBM only; `lds_on_host` says whether
     // order[], colour_offsets[], group_first_colour[] above already cover the LDS groups (DeviceSolver::materialise).
     bool lds_on_host = true;
@@ -84,7 +88,7 @@ struct Schedule {
     int hbm_end() const { return has_hbm_group() ? hbm_colour_offsets.back() : 0; }
 };
 
-struct LdsCaps { int max_joints = 512, max_bodies = 768, max_colours = 64, max_static = 1 << 30; };
+struct LdsCaps { int max_joints = 512, max_units = 256, max_bodies = 768, max_colours = 64, max_static = 1 << 30; };
 // (an LDS group's local body table lists its static bodies first, so a static body's local index is also its
 //  slot in the group's small static-tag table)
 
@@ -103,6 +107,9 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
 // `big` (optional) is a roomier shape used for ALL groups when some component fits it but not `caps`.
 void build_island_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb,
                            const LdsCaps& caps, Schedule& out, const LdsCaps* big = nullptr, const int* prio_id = nullptr);
+
+// partner[j] = the other joint of j's unit or -1 (the unit rule above)
+void find_partners(const int* body1, const int* body2, int nj, const int* prio_id, std::vector<int>& partner);
 
 // Solver::GatherIslands semantics (ref: Solver.cpp:285-454): per-joint coalesced island id (-1 for
 // static-static joints) and per-island joint counts.

@@ -34,6 +34,29 @@ static void priority_order(const std::vector<int>& joints, const int* prio_id, s
     for (size_t k = 0; k < joints.size(); ++k) perm[k] = keyed[k].second;
 }
 
+// Units (schedule.h): partner[j] = the other joint of j's unit, or -1.  Two joints form a unit when their priority ids differ
+// in the lowest bit only (the two contact points of one manifold: ids 2m and 2m + 1), their bodies are the same, and each is
+// the smallest-index joint carrying its id (ids are unique in a World; the rule keeps foreign input deterministic).
+void find_partners(const int* body1, const int* body2, int nj, const int* prio_id, std::vector<int>& partner)
+{
+    partner.assign((size_t)std::max(nj, 0), -1);
+    auto id_of = [&](int j) { return prio_id ? prio_id[j] : j; };
+    int max_id = -1;
+    for (int j = 0; j < nj; ++j) max_id = std::max(max_id, id_of(j));
+    if (max_id < 0) return;
+    std::vector<int> first((size_t)max_id + 2, -1);       // id -> smallest joint index carrying it
+    for (int j = nj - 1; j >= 0; --j) if (id_of(j) >= 0) first[id_of(j)] = j;
+    for (int j = 0; j < nj; ++j) {
+        const int id = id_of(j);
+        if (id < 0 || first[id] != j) continue;
+        const int other = first[id ^ 1];
+        if (other < 0 || body1[other] != body1[j] || body2[other] != body2[j]) continue;
+        partner[j] = other;
+    }
+}
+
+static inline bool is_follower(const std::vector<int>& partner, const int* prio_id, int j) { return partner[j] >= 0 && ((prio_id ? prio_id[j] : j) & 1) != 0; }
+
 // first-fit colouring of `joints` (indices into body1/body2), taken in priority order; returns colour per entry.
 // Colouring in decreasing-priority order is what Jones-Plassmann rounds compute in parallel (a joint takes its colour
 // once it holds the highest priority among the uncoloured joints on both its dynamic bodies) — that is how the device
@@ -46,9 +69,11 @@ struct ColourScratch {
     void ensure(int nb) { if (used.size() < (size_t)nb * words) used.assign((size_t)nb * words, 0ull); }
 };
 
-// `comp` (per entry of `joints`): connected component of the joint (any labels; joints between two static bodies may carry -1).
+// `joints`: the LEADERS of the units to colour (schedule.h); `comp` (per entry): connected component of the joint (any labels;
+// joints between two static bodies may carry -1).
 static int colour_joints(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-                         int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id, const std::vector<int>& comp)
+                         int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id, const std::vector<int>& comp,
+                         const std::vector<int>& partner)
 {
     colour.assign(joints.size(), 0);
     std::vector<int> perm;
@@ -100,7 +125,7 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
         }
         comp_bad.assign(count, 0);
         std::vector<int> size(count, 0);
-        for (size_t k = 0; k < joints.size(); ++k) size[dense[k]]++;
+        for (size_t k = 0; k < joints.size(); ++k) size[dense[k]] += partner[joints[k]] >= 0 ? 2 : 1;      // joints of the component, not units
         for (int d = 0; d < count; ++d) if (size[d] > COLOUR_B_MAX_JOINTS) comp_bad[d] = 1;      // B is not attempted there (schedule.h)
         for (size_t k = 0; k < joints.size(); ++k) if (comp[k] < 0) comp_bad[dense[k]] = 1;      // static-static joints: colour 0 either way
     }
@@ -148,18 +173,31 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
     return ncolours;
 }
 
-// append one group made of `joints` coloured by `colour` (stable counting sort by colour)
-static void append_group(Schedule& out, const std::vector<int>& joints, const std::vector<int>& colour, int ncolours)
+// append one group made of the units led by `leaders`, coloured by `colour`: class by class, the leaders that have a follower
+// (joint order), the single leaders (joint order), then the followers in their leaders' order (schedule.h)
+static void append_group(Schedule& out, const std::vector<int>& leaders, const std::vector<int>& colour, int ncolours, const std::vector<int>& partner,
+                         std::vector<int>* class_leaders)
 {
     const int base = (int)out.order.size();
-    std::vector<int> count(ncolours + 1, 0);
-    for (int c : colour) count[c + 1]++;
-    for (int c = 0; c < ncolours; ++c) count[c + 1] += count[c];
-    out.order.resize(base + joints.size());
-    std::vector<int> cursor(count.begin(), count.end() - 1);
-    for (size_t k = 0; k < joints.size(); ++k) out.order[base + cursor[colour[k]]++] = joints[k];
-    for (int c = 0; c < ncolours; ++c) out.colour_offsets.push_back(base + count[c + 1]);
-    out.group_offsets.push_back(base + (int)joints.size());
+    std::vector<int> with(ncolours, 0), single(ncolours, 0);
+    for (size_t k = 0; k < leaders.size(); ++k) (partner[leaders[k]] >= 0 ? with : single)[colour[k]]++;
+    std::vector<int> begin(ncolours + 1, base);
+    for (int c = 0; c < ncolours; ++c) begin[c + 1] = begin[c] + 2 * with[c] + single[c];
+    out.order.resize(begin[ncolours]);
+    std::vector<int> cur_with(ncolours, 0), cur_single(ncolours, 0);
+    for (size_t k = 0; k < leaders.size(); ++k) {
+        const int c = colour[k], j = leaders[k];
+        if (partner[j] >= 0) {
+            const int i = cur_with[c]++;
+            out.order[begin[c] + i] = j;
+            out.order[begin[c] + with[c] + single[c] + i] = partner[j];
+        } else out.order[begin[c] + with[c] + cur_single[c]++] = j;
+    }
+    for (int c = 0; c < ncolours; ++c) {
+        out.colour_offsets.push_back(begin[c + 1]);
+        if (class_leaders) class_leaders->push_back(with[c] + single[c]);
+    }
+    out.group_offsets.push_back(begin[ncolours]);
     out.group_first_colour.push_back((int)out.colour_offsets.size() - 1);
 }
 
@@ -186,15 +224,20 @@ static int components(const int* body1, const int* body2, int nj, const unsigned
 void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out, const int* prio_id)
 {
     reset(out);
-    std::vector<int> all(nj), colour;
-    for (int j = 0; j < nj; ++j) all[j] = j;
+    std::vector<int> partner;
+    find_partners(body1, body2, nj, prio_id, partner);
+    std::vector<int> all(nj), leaders, colour;
+    for (int j = 0; j < nj; ++j) { all[j] = j; if (!is_follower(partner, prio_id, j)) leaders.push_back(j); }
     ColourScratch scratch;
-    std::vector<int> root, number, comp(nj);
+    std::vector<int> root, number, comp(leaders.size());
     components(body1, body2, nj, is_static, nb, root, number);
-    for (int j = 0; j < nj; ++j) comp[j] = (is_static[body1[j]] && is_static[body2[j]]) ? -1 : number[root[is_static[body1[j]] ? body2[j] : body1[j]]];
-    const int ncol = colour_joints(all, body1, body2, is_static, nb, colour, scratch, prio_id, comp);
+    for (size_t k = 0; k < leaders.size(); ++k) {
+        const int j = leaders[k];
+        comp[k] = (is_static[body1[j]] && is_static[body2[j]]) ? -1 : number[root[is_static[body1[j]] ? body2[j] : body1[j]]];
+    }
+    const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, comp, partner);
     if (nj) {
-        append_group(out, all, colour, ncol);
+        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
     }
     out.lds_groups = 0;
@@ -265,10 +308,11 @@ void gather_islands(const int* body1, const int* body2, int nj, const unsigned c
 namespace {
 
 struct BinOut {
-    std::vector<int> order;               // joints, colour-major
-    std::vector<int> colour_sizes;        // joints per colour
+    std::vector<int> order;               // joints, class-major: leaders with a follower, single leaders, followers (schedule.h)
+    std::vector<int> colour_sizes;        // joints per class
     std::vector<uint32_t> slot_local;
     std::vector<uint8_t> slot_colour;
+    std::vector<int> unit_leader, unit_follower;   // per unit, in class order: its slots relative to the bin's first slot (follower: -1 if none)
     std::vector<int> bodies;              // local body table, static first
     bool rejected = false;                // does not fit the caps: its joints go to the HBM group
 };
@@ -295,12 +339,11 @@ struct LocalMap {
 };
 
 void build_bin(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
-               const LdsCaps& caps, LocalMap& map, BinOut& out, const int* prio_id, const int* comp_of)
+               const LdsCaps& caps, LocalMap& map, BinOut& out, const int* prio_id, const int* comp_of, const std::vector<int>& partner)
 {
     out = BinOut{};
     map.reset((unsigned)joints.size() * 2u + 8u);
     // local body table: static bodies first (their local index doubles as the slot in the group's static-tag table)
-    std::vector<int> dynamic;
     for (int pass = 0; pass < 2; ++pass)
         for (int j : joints)
             for (int b : {body1[j], body2[j]}) {
@@ -312,18 +355,22 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
     int nstatic = 0;
     for (int b : out.bodies) nstatic += is_static[b] ? 1 : 0;
     if ((int)out.bodies.size() > caps.max_bodies || (int)out.bodies.size() > 65535 || nstatic > caps.max_static) { out.rejected = true; return; }
+    // the units of the bin, represented by their leaders (joint order)
+    std::vector<int> leaders;
+    for (int j : joints) if (!is_follower(partner, prio_id, j)) leaders.push_back(j);
+    if ((int)leaders.size() > caps.max_units) { out.rejected = true; return; }
     // two first-fit candidates in priority order on per-local-body masks (schedule.h): A = smallest free colour,
     // B = two-ended; keep the one with fewer colours
     if (caps.max_colours > 64) { out.rejected = true; return; }          // one 64-bit mask per body (the device builder's limit)
     std::vector<unsigned long long> used_a(out.bodies.size(), 0ull), used_b(out.bodies.size(), 0ull);
     std::vector<int> degree(out.bodies.size(), 0);
-    std::vector<int> col_a(joints.size()), col_b(joints.size());
-    std::vector<uint32_t> local(joints.size());
+    std::vector<int> col_a(leaders.size()), col_b(leaders.size());
+    std::vector<uint32_t> local(leaders.size());
     std::vector<int> perm;
-    priority_order(joints, prio_id, perm);
-    for (size_t k = 0; k < joints.size(); ++k) {
+    priority_order(leaders, prio_id, perm);
+    for (size_t k = 0; k < leaders.size(); ++k) {
         bool fresh;
-        const int a = *map.find_or_insert(body1[joints[k]], fresh), b = *map.find_or_insert(body2[joints[k]], fresh);
+        const int a = *map.find_or_insert(body1[leaders[k]], fresh), b = *map.find_or_insert(body2[leaders[k]], fresh);
         local[k] = (uint32_t)a | ((uint32_t)b << 16);
         degree[a]++; degree[b]++;
     }
@@ -333,12 +380,12 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
     const size_t span = joints.empty() ? 0 : (size_t)(comp_hi - comp_lo + 1);
     std::vector<unsigned long long> seen_a(span, 0ull), seen_b(span, 0ull);
     std::vector<unsigned char> bad_b(span, 0);
-    for (size_t i = 0; i < joints.size(); ++i) {
+    for (size_t i = 0; i < leaders.size(); ++i) {
         const size_t k = (size_t)perm[i];
         const int a = (int)(local[k] & 0xFFFFu), b = (int)(local[k] >> 16);
-        const int ga = body1[joints[k]], gb = body2[joints[k]];
+        const int ga = body1[leaders[k]], gb = body2[leaders[k]];
         const bool da = !is_static[ga], db = !is_static[gb];
-        const size_t comp = (size_t)(comp_of[joints[k]] - comp_lo);
+        const size_t comp = (size_t)(comp_of[leaders[k]] - comp_lo);
         unsigned long long ma = 0, mb = 0;
         if (da) { ma |= used_a[a]; mb |= used_b[a]; }
         if (db) { ma |= used_a[b]; mb |= used_b[b]; }
@@ -353,24 +400,41 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
         else { if (da) used_b[a] |= 1ull << cb; if (db) used_b[b] |= 1ull << cb; col_b[k] = cb; seen_b[comp] |= 1ull << cb; }
     }
     int ncol = 0;
-    std::vector<int> colour(joints.size());
-    for (size_t k = 0; k < joints.size(); ++k) {                       // the component's choice, dense renumbering (increasing)
-        const size_t comp = (size_t)(comp_of[joints[k]] - comp_lo);
+    std::vector<int> colour(leaders.size());
+    for (size_t k = 0; k < leaders.size(); ++k) {                      // the component's choice, dense renumbering (increasing)
+        const size_t comp = (size_t)(comp_of[leaders[k]] - comp_lo);
         const bool use_b = !bad_b[comp] && __builtin_popcountll(seen_b[comp]) < __builtin_popcountll(seen_a[comp]);
         const unsigned long long seen = use_b ? seen_b[comp] : seen_a[comp];
         const int c = use_b ? col_b[k] : col_a[k];
         colour[k] = __builtin_popcountll(seen & ((1ull << c) - 1ull));
         ncol = std::max(ncol, colour[k] + 1);
     }
-    // stable counting sort by colour
-    out.colour_sizes.assign(ncol, 0);
-    for (int c : colour) out.colour_sizes[c]++;
-    std::vector<int> cursor(ncol, 0);
-    for (int c = 1; c < ncol; ++c) cursor[c] = cursor[c - 1] + out.colour_sizes[c - 1];
+    // class by class: leaders with a follower, single leaders, followers in their leaders' order (all in joint order)
+    std::vector<int> with(ncol, 0), single(ncol, 0);
+    for (size_t k = 0; k < leaders.size(); ++k) (partner[leaders[k]] >= 0 ? with : single)[colour[k]]++;
+    std::vector<int> begin(ncol + 1, 0), unit_begin(ncol + 1, 0);
+    for (int c = 0; c < ncol; ++c) { begin[c + 1] = begin[c] + 2 * with[c] + single[c]; unit_begin[c + 1] = unit_begin[c] + with[c] + single[c]; }
+    out.colour_sizes.resize(ncol);
+    for (int c = 0; c < ncol; ++c) out.colour_sizes[c] = begin[c + 1] - begin[c];
     out.order.resize(joints.size()); out.slot_local.resize(joints.size()); out.slot_colour.resize(joints.size());
-    for (size_t k = 0; k < joints.size(); ++k) {
-        const int at = cursor[colour[k]]++;
-        out.order[at] = joints[k]; out.slot_local[at] = local[k]; out.slot_colour[at] = (uint8_t)colour[k];
+    out.unit_leader.resize(leaders.size()); out.unit_follower.resize(leaders.size());
+    std::vector<int> cur_with(ncol, 0), cur_single(ncol, 0);
+    for (size_t k = 0; k < leaders.size(); ++k) {
+        const int c = colour[k], j = leaders[k];
+        int at, unit;
+        if (partner[j] >= 0) {
+            const int i = cur_with[c]++;
+            at = begin[c] + i; unit = unit_begin[c] + i;
+            const int fat = begin[c] + with[c] + single[c] + i;
+            out.order[fat] = partner[j]; out.slot_local[fat] = local[k]; out.slot_colour[fat] = (uint8_t)c;
+            out.unit_follower[unit] = fat;
+        } else {
+            const int i = cur_single[c]++;
+            at = begin[c] + with[c] + i; unit = unit_begin[c] + with[c] + i;
+            out.unit_follower[unit] = -1;
+        }
+        out.order[at] = j; out.slot_local[at] = local[k]; out.slot_colour[at] = (uint8_t)c;
+        out.unit_leader[unit] = at;
     }
 }
 
@@ -381,14 +445,16 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
 {
     reset(out);
     out.islands = true;
+    std::vector<int> partner;
+    find_partners(body1, body2, nj, prio_id, partner);
     std::vector<int> root, number;
     const int ncomp = components(body1, body2, nj, is_static, nb, root, number);
-    // joints per component, in joint order (CSR)
-    std::vector<int> comp_of(nj), comp_count(ncomp + 1, 0);
+    // joints per component, in joint order (CSR); units per component
+    std::vector<int> comp_of(nj), comp_count(ncomp + 1, 0), comp_units(std::max(ncomp, 1), 0);
     for (int j = 0; j < nj; ++j) {
         const int a = body1[j], b = body2[j];
         comp_of[j] = (is_static[a] && is_static[b]) ? -1 : number[root[is_static[a] ? b : a]];
-        if (comp_of[j] >= 0) comp_count[comp_of[j] + 1]++;
+        if (comp_of[j] >= 0) { comp_count[comp_of[j] + 1]++; if (!is_follower(partner, prio_id, j)) comp_units[comp_of[j]]++; }
     }
     for (int c = 0; c < ncomp; ++c) comp_count[c + 1] += comp_count[c];
     std::vector<int> comp_joints(comp_count[ncomp]);
@@ -406,30 +472,31 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         out.island_count = count; out.island_max_size = mx;
     }
     // pick the workgroup shape: the roomier one only if some component needs it and fits it
+    auto fits = [&](int c, const LdsCaps& k) { return comp_count[c + 1] - comp_count[c] <= k.max_joints && comp_units[c] <= k.max_units; };
     LdsCaps caps = small_caps;
     if (big) {
-        int need = 0;
-        for (int c = 0; c < ncomp; ++c) { const int n = comp_count[c + 1] - comp_count[c]; if (n > small_caps.max_joints && n <= big->max_joints) need = std::max(need, n); }
+        bool need = false;
+        for (int c = 0; c < ncomp; ++c) if (comp_count[c + 1] > comp_count[c] && !fits(c, small_caps) && fits(c, *big)) need = true;
         if (need) caps = *big;
     }
-    out.lds_lanes = caps.max_joints;
+    out.lds_lanes = caps.max_units;
     // greedy binning of consecutive components (serial, one pass); oversized components go to the HBM group whole
     std::vector<int> rest;
     std::vector<std::pair<int, int>> bins;       // [first component, last component)
     {
-        int begin = -1, size = 0;
-        auto flush = [&](int end) { if (begin >= 0 && size > 0) bins.emplace_back(begin, end); begin = -1; size = 0; };
+        int begin = -1, size = 0, units = 0;
+        auto flush = [&](int end) { if (begin >= 0 && size > 0) bins.emplace_back(begin, end); begin = -1; size = 0; units = 0; };
         for (int c = 0; c < ncomp; ++c) {
             const int n = comp_count[c + 1] - comp_count[c];
             if (n == 0) continue;
-            if (n > caps.max_joints) {
+            if (!fits(c, caps)) {
                 flush(c);
                 rest.insert(rest.end(), comp_joints.begin() + comp_count[c], comp_joints.begin() + comp_count[c + 1]);
                 continue;
             }
-            if (size + n > caps.max_joints) flush(c);
+            if (size + n > caps.max_joints || units + comp_units[c] > caps.max_units) flush(c);
             if (begin < 0) begin = c;
-            size += n;
+            size += n; units += comp_units[c];
         }
         flush(ncomp);
     }
@@ -441,7 +508,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         for (int b = b0; b < b1; ++b) {
             joints.assign(comp_joints.begin() + comp_count[bins[b].first], comp_joints.begin() + comp_count[bins[b].second]);
             if (bins[b].second - bins[b].first > 1) std::sort(joints.begin(), joints.end());      // joint-index order inside the bin
-            build_bin(joints, body1, body2, is_static, caps, map, built[b], prio_id, comp_of.data());
+            build_bin(joints, body1, body2, is_static, caps, map, built[b], prio_id, comp_of.data(), partner);
             if (built[b].rejected) built[b].order = joints;
         }
     });
@@ -449,12 +516,18 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
     size_t total_slots = 0, total_bodies = 0;
     for (const BinOut& b : built) if (!b.rejected) { total_slots += b.order.size(); total_bodies += b.bodies.size(); }
     out.order.reserve(nj); out.slot_local.reserve(total_slots); out.slot_colour.reserve(total_slots); out.group_bodies.reserve(total_bodies);
+    out.group_unit_offsets.assign(1, 0);
     for (const BinOut& b : built) {
         if (b.rejected) { rest.insert(rest.end(), b.order.begin(), b.order.end()); continue; }
         const int base = (int)out.order.size();
         out.order.insert(out.order.end(), b.order.begin(), b.order.end());
         out.slot_local.insert(out.slot_local.end(), b.slot_local.begin(), b.slot_local.end());
         out.slot_colour.insert(out.slot_colour.end(), b.slot_colour.begin(), b.slot_colour.end());
+        for (size_t u = 0; u < b.unit_leader.size(); ++u) {
+            out.unit_leader.push_back(base + b.unit_leader[u]);
+            out.unit_follower.push_back(b.unit_follower[u] < 0 ? -1 : base + b.unit_follower[u]);
+        }
+        out.group_unit_offsets.push_back((int)out.unit_leader.size());
         int at = base;
         for (int n : b.colour_sizes) { at += n; out.colour_offsets.push_back(at); }
         out.group_offsets.push_back(at);
@@ -467,12 +540,12 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
     for (int j = 0; j < nj; ++j) if (comp_of[j] < 0) rest.push_back(j);
     if (!rest.empty()) {
         std::sort(rest.begin(), rest.end());
-        std::vector<int> colour, rest_comp(rest.size());
-        for (size_t k = 0; k < rest.size(); ++k) rest_comp[k] = comp_of[rest[k]];
+        std::vector<int> leaders, colour, rest_comp;
+        for (int j : rest) if (!is_follower(partner, prio_id, j)) { leaders.push_back(j); rest_comp.push_back(comp_of[j]); }
         ColourScratch scratch;
-        const int ncol = colour_joints(rest, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp);
+        const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp, partner);
         const size_t first = out.colour_offsets.size() - 1;
-        append_group(out, rest, colour, ncol);
+        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
         touched_bodies(rest, body1, body2, nb, out.hbm_bodies);
         out.hbm_body_count = (int)out.hbm_bodies.size();

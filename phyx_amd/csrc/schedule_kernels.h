@@ -59,32 +59,34 @@ static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb,
 }
 
 // (also zeroes the per-component joint counters that k_joint_components fills next: nb + 1 words)
-static __global__ void __launch_bounds__(256) k_cc_root_flags(const int* __restrict__ parent, int nb, unsigned* __restrict__ flags, unsigned* __restrict__ comp_size)
+static __global__ void __launch_bounds__(256) k_cc_root_flags(const int* __restrict__ parent, int nb, unsigned* __restrict__ flags, unsigned* __restrict__ comp_size,
+                                                              unsigned* __restrict__ comp_units)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) {
         if (i < nb) flags[i] = parent[i] == i ? 1u : 0u;
-        comp_size[i] = 0u;
+        comp_size[i] = 0u; comp_units[i] = 0u;
     }
 }
 
-// joint -> component number (-1 if both bodies are static), and joints per component.
+// joint -> component number (-1 if both bodies are static), and joints and units (schedule.h) per component.
 // The counts are accumulated in a per-workgroup LDS hash table (every lane inserts its own joint: LDS atomics on distinct
 // slots run in parallel, on one slot they cost a few cycles each) and flushed once per workgroup.  Counting straight into
 // memory was fine while every column was its own island, but once a settling scene has merged into one island every
 // wave fired at the SAME counter: 1e4 same-address device atomics were 115 us of this 13 us kernel.
 constexpr int JC_T = 1024, JC_TABLE = 2048;
 static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_contact_joint* __restrict__ joints, int nj, int nb, const int* __restrict__ parent,
-                                                                  const unsigned* __restrict__ root_number, int* __restrict__ joint_comp,
-                                                                  unsigned* __restrict__ comp_size)
+                                                                  const unsigned* __restrict__ root_number, const int* __restrict__ partner,
+                                                                  int* __restrict__ joint_comp, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
 {
     __shared__ int table_key[JC_TABLE];
-    __shared__ unsigned table_cnt[JC_TABLE];
+    __shared__ unsigned table_cnt[JC_TABLE], table_units[JC_TABLE];
     for (int j0 = blockIdx.x * blockDim.x; j0 < nj; j0 += gridDim.x * blockDim.x) {       // uniform trip count per workgroup
-        for (int i = threadIdx.x; i < JC_TABLE; i += JC_T) { table_key[i] = -1; table_cnt[i] = 0; }
+        for (int i = threadIdx.x; i < JC_TABLE; i += JC_T) { table_key[i] = -1; table_cnt[i] = 0; table_units[i] = 0; }
         __syncthreads();
         const int j = j0 + (int)threadIdx.x;
         if (j < nj) {
             const unsigned u = (unsigned)joints[j].body1, v = (unsigned)joints[j].body2;
+            const bool leads = !(partner[j] >= 0 && (joints[j].contact_point_index & 1));      // not the follower of a unit
             int comp = -1;
             if (u < (unsigned)nb && v < (unsigned)nb) {
                 const int pu = parent[u], pv = parent[v];
@@ -96,13 +98,13 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
                 unsigned h = ((unsigned)comp * 2654435761u) >> 21;                         // 11 bits
                 for (;; h = (h + 1) & (JC_TABLE - 1)) {                                    // <= JC_T distinct keys in a table of 2 * JC_T
                     const int seen = atomicCAS(&table_key[h], -1, comp);
-                    if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], 1u); break; }
+                    if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], 1u); if (leads) atomicAdd(&table_units[h], 1u); break; }
                 }
             }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < JC_TABLE; i += JC_T)
-            if (table_key[i] >= 0) atomicAdd(&comp_size[table_key[i]], table_cnt[i]);
+            if (table_key[i] >= 0) { atomicAdd(&comp_size[table_key[i]], table_cnt[i]); if (table_units[i]) atomicAdd(&comp_units[table_key[i]], table_units[i]); }
         __syncthreads();
     }
 }
@@ -119,55 +121,113 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
     }
 }
 
+// ---- units (schedule.h): partner[j] = the other joint of j's unit, or -1 ---------------------------------------------
+// first[id] = smallest joint index carrying contact point id (table of ncp words, 0x7f7f7f7f = nobody)
+static __global__ void __launch_bounds__(256) k_partner_first(const phx_contact_joint* __restrict__ joints, int nj, int ncp, int* __restrict__ first)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        const unsigned id = (unsigned)joints[j].contact_point_index;
+        if (id < (unsigned)ncp) atomicMin(&first[id], j);
+    }
+}
+
+static __global__ void __launch_bounds__(256) k_partner_find(const phx_contact_joint* __restrict__ joints, int nj, int ncp, const int* __restrict__ first,
+                                                             int* __restrict__ partner)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        const phx_contact_joint me = joints[j];
+        const unsigned id = (unsigned)me.contact_point_index;
+        int p = -1;
+        if (id < (unsigned)ncp && first[id] == j && (id ^ 1u) < (unsigned)ncp) {
+            const int other = first[id ^ 1u];
+            if (other != 0x7f7f7f7f) {
+                const phx_contact_joint o = joints[other];
+                if (o.body1 == me.body1 && o.body2 == me.body2) p = other;
+            }
+        }
+        partner[j] = p;
+    }
+}
+
 // ---- one workgroup builds one bin ------------------------------------------------------------------------------
 struct BinBuildView {
     const unsigned* sorted_joints;    // joint indices grouped by bin, joint order inside a bin
     const int* group_offsets;         // slots of bin g = [group_offsets[g], group_offsets[g+1])
     const phx_contact_joint* joints;
+    const int* partner;               // joint -> the other joint of its unit, or -1
     const unsigned char* is_static;
     const int* joint_comp;            // joint -> connected component number
     const int* comp_rank;             // component -> its rank among the components of its bin (< joints of the bin)
     int nb, max_static;
     int* order;                       // out: slot -> joint
     unsigned* slot_local;             // out: local body1 | local body2 << 16
-    unsigned char* slot_colour;       // out
+    unsigned char* slot_colour;       // out: class
     int4* desc;                       // out: {slot_begin, slot_count, body_begin, body_count}
-    int* ncol;                        // out
+    int* ncol;                        // out: classes
+    int* units;                       // out: units
+    int2* unit_slots;                 // out: [g * T + unit] = {leader slot, follower slot or -1}, class-major
     int* bodies;                      // out: body table of bin g at [g * NB, g * NB + body_count)
     int* rejected;                    // out: set to 1 if any bin exceeds the caps (caller falls back to the host builder)
 };
 
-template <int T, int NB>
-static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
+// stable rank of the lanes with `want` among the lanes of the whole workgroup that share their key (< 64), in lane order:
+// returns the rank inside the wave and leaves in wave_count[w * 64 + key] the number of such lanes in wave w
+template <int LANES>
+__device__ __forceinline__ int bin_wave_rank(bool want, int key, unsigned short* wave_count)
 {
-    constexpr int HT = 4 * T;                           // open-addressing table, <= 2T distinct bodies
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank = 0;
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(want && key == k);
+        if (want && key == k) rank = __popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) wave_count[wave * 64 + k] = (unsigned short)__popcll(same);
+        todo &= ~same;
+    }
+    return rank;
+}
+
+// T = unit capacity = lanes of the island kernel; the builder runs one lane per JOINT (2 T lanes).  Followers (the second
+// joint of a unit) only help to build the body table; the colouring and the placement are done by the leaders.
+template <int T, int NB>
+static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
+{
+    constexpr int LANES = 2 * T;
+    constexpr int HT = 4 * LANES;                        // open-addressing table, <= 2 LANES distinct bodies
     __shared__ __align__(8) int ht_key[HT];              // later reused as the per-body priority table of the colouring
     static_assert((size_t)NB * 8 <= (size_t)HT * 4, "priority table must fit the hash table");
     __shared__ int ht_val[HT];                          // first occurrence position, later the local index
     __shared__ unsigned long long used[NB];              // candidate A (smallest free colour): colours taken per local body
     __shared__ unsigned long long used_b[NB];            // candidate B (two-ended, schedule.h)
-    __shared__ int degree[NB];                           // joints of the bin on each local body
-    __shared__ unsigned long long seen_a[T], seen_b[T];  // per component of the bin: colours in use under either candidate
-    __shared__ unsigned char bad_b[T];
-    __shared__ unsigned scan_lds[T / 64];
-    __shared__ unsigned hist[64];                         // first slot of each colour
-    __shared__ unsigned short wave_count[(T / 64) * 64];   // joints of colour c in wave w, then the exclusive sum over waves
-    __shared__ int n_static, n_bodies, n_col, bad;
+    __shared__ int degree[NB];                           // units of the bin on each local body
+    __shared__ unsigned long long seen_a[LANES], seen_b[LANES];  // per component of the bin: colours in use under either candidate
+    __shared__ unsigned char bad_b[LANES];
+    __shared__ unsigned scan_lds[LANES / 64];
+    __shared__ unsigned with_n[64], single_n[64];        // per class: leaders that have a follower / single leaders
+    __shared__ unsigned class_begin[64], unit_begin[64]; // per class: first slot (relative), first unit
+    __shared__ unsigned short wave_with[(LANES / 64) * 64], wave_single[(LANES / 64) * 64];
+    __shared__ int n_static, n_bodies, n_col, n_units, bad;
 
     const int g = blockIdx.x, tid = threadIdx.x;
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
-    for (int i = tid; i < HT; i += T) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
-    for (int i = tid; i < NB; i += T) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
+    for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
+    for (int i = tid; i < NB; i += LANES) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
     seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0;
-    if (tid < 64) hist[tid] = 0;
+    for (int i = tid; i < (LANES / 64) * 64; i += LANES) { wave_with[i] = 0; wave_single[i] = 0; }
     if (tid == 0) { bad = 0; n_col = 0; }
     __syncthreads();
 
     const bool live = tid < count;
-    int j = 0, b[2] = {0, 0}, hs[2] = {0, 0};
+    int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1;
+    bool follower = false;
     if (live) {
         j = (int)v.sorted_joints[begin + tid];
-        b[0] = v.joints[j].body1; b[1] = v.joints[j].body2;
+        const phx_contact_joint jt = v.joints[j];
+        b[0] = jt.body1; b[1] = jt.body2;
+        mate = v.partner[j];
+        follower = mate >= 0 && (jt.contact_point_index & 1) != 0;
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s
             unsigned p = ((unsigned)b[s] * 2654435761u) & (HT - 1);
             for (;;) {
@@ -180,26 +240,26 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
         }
     }
     __syncthreads();
-    // leaders = first occurrences; local index = rank among static leaders, or n_static + rank among dynamic leaders
+    // table leaders = first occurrences; local index = rank among static ones, or n_static + rank among dynamic ones
     bool lead[2] = {false, false}, stat[2] = {false, false};
-    unsigned mine = 0;                                   // static leaders << 16 | dynamic leaders
+    unsigned mine = 0;                                   // static first occurrences << 16 | dynamic ones
     if (live)
         for (int s = 0; s < 2; ++s) {
             lead[s] = ht_val[hs[s]] == 2 * tid + s;
             stat[s] = v.is_static[b[s]] != 0;
             if (lead[s]) mine += stat[s] ? 0x10000u : 1u;
         }
-    // block exclusive scan of `mine`
+    // block exclusive scan of `mine`; the units are counted on the side
     unsigned x = mine;
     const int lane = tid & 63, wave = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
     if (lane == 63) scan_lds[wave] = x;
-    __syncthreads();
+    const int units_here = __syncthreads_count(live && !follower);
     unsigned before = x - mine, total = 0;
-    for (int w = 0; w < T / 64; ++w) { const unsigned t = scan_lds[w]; if (w < wave) before += t; total += t; }
-    if (tid == 0) { n_static = (int)(total >> 16); n_bodies = (int)(total >> 16) + (int)(total & 0xFFFFu); }
+    for (int w = 0; w < LANES / 64; ++w) { const unsigned t = scan_lds[w]; if (w < wave) before += t; total += t; }
+    if (tid == 0) { n_static = (int)(total >> 16); n_bodies = (int)(total >> 16) + (int)(total & 0xFFFFu); n_units = units_here; }
     __syncthreads();                                     // every lane has read ht_val as "first position"
-    const bool fits = n_bodies <= NB && n_static <= v.max_static;
+    const bool fits = n_bodies <= NB && n_static <= v.max_static && units_here <= T;
     if (live && fits) {
         unsigned sb = before >> 16, db = before & 0xFFFFu;
         for (int s = 0; s < 2; ++s)
@@ -210,18 +270,20 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
             }
     }
     __syncthreads();
+    const bool unit = live && fits && !follower;         // this lane leads a unit
     int loc[2] = {0, 0};
-    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; atomicAdd(&degree[loc[0]], 1); atomicAdd(&degree[loc[1]], 1); }
+    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; }
+    if (unit) { atomicAdd(&degree[loc[0]], 1); atomicAdd(&degree[loc[1]], 1); }
     __syncthreads();
-    // First-fit colouring in priority order by Jones-Plassmann rounds (schedule.h): every round, an uncoloured joint
-    // that holds the highest priority on both its dynamic bodies takes the smallest colour free on them.  One winner
+    // First-fit colouring of the units in priority order by Jones-Plassmann rounds (schedule.h): every round, an uncoloured
+    // unit that holds the highest priority on both its dynamic bodies takes the smallest colour free on them.  One winner
     // per body per round, so the mask updates do not race.  ~log(count) rounds of three barriers each.
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ht_key);        // the hash table is dead by now (NB * 8 <= HT * 4)
-    for (int i = tid; i < NB; i += T) best[i] = 0ull;
+    for (int i = tid; i < NB; i += LANES) best[i] = 0ull;
     __syncthreads();
     const bool dyn0 = loc[0] >= n_static, dyn1 = loc[1] >= n_static;                  // static bodies sit first in the table
-    const unsigned long long key = live ? colour_priority((unsigned)v.joints[j].contact_point_index, (unsigned)j) : 0ull;
-    bool pending = live && fits;
+    const unsigned long long key = unit ? colour_priority((unsigned)v.joints[j].contact_point_index, (unsigned)j) : 0ull;
+    bool pending = unit;
     int mycol = 0, mycol_b = 0;
     const bool from_top = ((b[0] < b[1] ? b[0] : b[1]) & 1) != 0;
     const int comp = live ? v.comp_rank[v.joint_comp[j]] : 0;
@@ -268,42 +330,45 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
         const int c = use_b ? mycol_b : mycol;
         mycol = __popcll(seen & ((1ull << c) - 1ull));
     }
-    // stable placement: slot = first slot of my colour + joints of my colour in earlier waves + earlier lanes of my wave
-    for (int i = tid; i < (T / 64) * 64; i += T) wave_count[i] = 0;
+    // placement, class by class: leaders that have a follower (joint order), single leaders (joint order), then the followers
+    // in their leaders' order
+    const bool placed = unit && !bad;
+    const bool paired = placed && mate >= 0;
+    const int rank_with = bin_wave_rank<LANES>(paired, mycol, wave_with);
+    const int rank_single = bin_wave_rank<LANES>(placed && !paired, mycol, wave_single);
     __syncthreads();
-    const bool placed = live && fits && !bad;
-    int rank = 0;
-    {
-        unsigned long long todo = __ballot(placed);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const int k = __shfl(mycol, leader);
-            const unsigned long long same = __ballot(placed && mycol == k);
-            if (placed && mycol == k) rank = __popcll(same & ((1ull << lane) - 1ull));
-            if (lane == leader) wave_count[wave * 64 + k] = (unsigned short)__popcll(same);
-            todo &= ~same;
+    if (tid < 64) {                                      // lane c: per wave -> exclusive over waves; class sizes and starts
+        unsigned run_w = 0, run_s = 0;
+        for (int w = 0; w < LANES / 64; ++w) {
+            const unsigned tw = wave_with[w * 64 + tid], ts = wave_single[w * 64 + tid];
+            wave_with[w * 64 + tid] = (unsigned short)run_w; wave_single[w * 64 + tid] = (unsigned short)run_s;
+            run_w += tw; run_s += ts;
         }
-    }
-    __syncthreads();
-    if (tid < 64) {                                      // lane c: joints of colour c per wave -> exclusive over waves; colour starts
-        unsigned run = 0;
-        for (int w = 0; w < T / 64; ++w) { const unsigned t = wave_count[w * 64 + tid]; wave_count[w * 64 + tid] = (unsigned short)run; run += t; }
-        unsigned x2 = run;
-        for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x2, off); if (lane >= off) x2 += y; }
-        hist[tid] = x2 - run;
-        const unsigned long long nonempty = __ballot(run != 0);
+        with_n[tid] = run_w; single_n[tid] = run_s;
+        unsigned xs = 2 * run_w + run_s, xu = run_w + run_s;
+        const unsigned slots_c = xs, units_c = xu;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned ys = __shfl_up(xs, off), yu = __shfl_up(xu, off); if (lane >= off) { xs += ys; xu += yu; } }
+        class_begin[tid] = xs - slots_c; unit_begin[tid] = xu - units_c;
+        const unsigned long long nonempty = __ballot(units_c != 0);
         if (tid == 0) n_col = nonempty ? 64 - __builtin_clzll(nonempty) : 0;
     }
     __syncthreads();
-    const int at = placed ? (int)(hist[mycol] + wave_count[wave * 64 + mycol]) + rank : 0;
     if (!fits || bad) { if (tid == 0) *v.rejected = 1; return; }
-    if (live) {
-        const int slot = begin + at;
-        v.order[slot] = j;
-        v.slot_local[slot] = (unsigned)loc[0] | ((unsigned)loc[1] << 16);
-        v.slot_colour[slot] = (unsigned char)mycol;
+    if (placed) {
+        const int c = mycol;
+        const int r = paired ? (int)wave_with[wave * 64 + c] + rank_with : (int)wave_single[wave * 64 + c] + rank_single;
+        const int in_class = paired ? r : (int)with_n[c] + r;          // position among the class's leaders
+        const int slot = begin + (int)class_begin[c] + in_class;
+        const unsigned local = (unsigned)loc[0] | ((unsigned)loc[1] << 16);
+        v.order[slot] = j; v.slot_local[slot] = local; v.slot_colour[slot] = (unsigned char)c;
+        int fslot = -1;
+        if (paired) {
+            fslot = begin + (int)class_begin[c] + (int)with_n[c] + (int)single_n[c] + r;
+            v.order[fslot] = mate; v.slot_local[fslot] = local; v.slot_colour[fslot] = (unsigned char)c;
+        }
+        v.unit_slots[(size_t)g * T + unit_begin[c] + in_class] = make_int2(slot, fslot);
     }
-    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; }
+    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = n_units; }
 }
 
 // ---- the HBM group (islands too big for a workgroup, or everything in Single mode): the same colouring in HBM ----------
@@ -345,6 +410,8 @@ struct JpView {
     unsigned long long* used_b;       // per body: colours taken under candidate B (two-ended, schedule.h)
     unsigned* colour_b;               // per entry: candidate B's colour
     const int* joint_comp;            // joint -> connected component (-1: both bodies static)
+    const int* partner;               // joint -> the other joint of its unit, or -1
+    unsigned char* kind;              // per entry: 0 leads a unit of two, 1 a unit of one, 2 follower (takes no part in the colouring)
     int ncomp;
     unsigned long long* seen_a;       // per component (entry ncomp = the static-static joints): colours in use under A / B
     unsigned long long* seen_b;
@@ -354,7 +421,7 @@ struct JpView {
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
     int* counts;                      // per round and sublist: size of the frontier it colours
     int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX
-    unsigned* hist;                   // per colour: entries (filled after the choice)
+    unsigned* hist;                   // per sort key 2 * class + kind: leaders (filled by the choice)
 };
 
 // every per-body table and the small words in ONE launch (a memset is a dispatch of its own, and there were a dozen)
@@ -367,7 +434,7 @@ static __global__ void __launch_bounds__(256) k_jp_clear(JpView v, int rounds_ma
     }
     for (int i = i0; i <= v.ncomp; i += stride) { v.seen_a[i] = 0ull; v.seen_b[i] = 0ull; v.bad_b[i] = 0; }
     for (int i = i0; i < (rounds_max + 1) * JP_SUBLISTS; i += stride) v.counts[i] = 0;
-    if (i0 < JP_MAX_COLOURS) v.hist[i0] = 0u;
+    if (i0 < 2 * JP_MAX_COLOURS) v.hist[i0] = 0u;
     if (i0 == 0) *v.flags = 0;
 }
 
@@ -381,12 +448,19 @@ static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
         v.pred[k] = 0u; v.colour_b[k] = 0u; v.colour[k] = JP_NONE;
         { const int jc = v.joint_comp[j]; v.ent_comp[k] = jc < 0 ? (unsigned)v.ncomp : (unsigned)jc; }
         v.succ[k] = make_uint2(JP_NONE, JP_NONE);
+        const int mate = v.partner[j];
+        const unsigned char kind = mate < 0 ? 1 : ((jt.contact_point_index & 1) ? 2 : 0);
+        v.kind[k] = kind;
         if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) {                  // reported; the entry is parked on nothing
             atomicOr(v.flags, 1);
             v.ent[k] = make_uint4(JP_STATIC_BIT, JP_STATIC_BIT, (unsigned)key, (unsigned)(key >> 32));
             continue;
         }
         v.touched[a] = 1u; v.touched[b] = 1u;
+        if (kind == 2) {                                                   // a follower: its leader colours the unit
+            v.ent[k] = make_uint4(JP_STATIC_BIT, JP_STATIC_BIT, (unsigned)key, (unsigned)(key >> 32));
+            continue;
+        }
         if (v.is_static[a]) a |= JP_STATIC_BIT; else atomicAdd(&v.offset[a], 1u);
         if (v.is_static[b]) b |= JP_STATIC_BIT; else atomicAdd(&v.offset[b], 1u);
         v.ent[k] = make_uint4(a, b, (unsigned)key, (unsigned)(key >> 32));
@@ -435,7 +509,7 @@ static __global__ void __launch_bounds__(256) k_jp_lists(JpView v)
 // round 0's frontier: flag the entries that wait for nobody, scan, compact
 static __global__ void __launch_bounds__(256) k_jp_seed_flags(JpView v, unsigned* __restrict__ flags)
 {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u) ? 1u : 0u;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u && v.kind[k] != 2) ? 1u : 0u;
 }
 
 static __global__ void __launch_bounds__(256) k_jp_seed(JpView v, const unsigned* __restrict__ scan, unsigned* __restrict__ list_out)
@@ -547,24 +621,47 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
 // every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order
 static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
 {
+    __shared__ unsigned h[2 * JP_MAX_COLOURS];
+    if (threadIdx.x < 2 * JP_MAX_COLOURS) h[threadIdx.x] = 0;
+    __syncthreads();
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
-        const int jc = v.joint_comp[v.ids[k]];
-        const int comp = jc < 0 ? v.ncomp : jc;
+        const unsigned char kind = v.kind[k];
+        if (kind == 2) { v.colour[k] = 255u; continue; }                         // followers sort behind every leader; their leaders place them
+        const int comp = (int)v.ent_comp[k];
         const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
         const bool use_b = comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS && !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
         const unsigned c = use_b ? v.colour_b[k] : v.colour[k];
-        v.colour[k] = (unsigned)__popcll((use_b ? sb : sa) & ((1ull << c) - 1ull));
+        const unsigned cls = (unsigned)__popcll((use_b ? sb : sa) & ((1ull << c) - 1ull));
+        const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single'
+        v.colour[k] = key;
+        atomicAdd(&h[key & (2 * JP_MAX_COLOURS - 1)], 1u);
     }
+    __syncthreads();
+    if (threadIdx.x < 2 * JP_MAX_COLOURS && h[threadIdx.x]) atomicAdd(&v.hist[threadIdx.x], h[threadIdx.x]);
 }
 
-static __global__ void __launch_bounds__(256) k_jp_hist(const unsigned* __restrict__ colour, int count, unsigned* __restrict__ hist)
+// the leaders, sorted by (class, kind) and stable in joint order, take their slots — and give their followers theirs:
+// class c = [leaders with a follower][single leaders][followers, in their leaders' order]  (hist: leaders per sort key)
+static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigned* __restrict__ sorted_keys, const unsigned* __restrict__ sorted_joints,
+                                                        int* __restrict__ order_out)
 {
-    __shared__ unsigned h[JP_MAX_COLOURS];
-    if (threadIdx.x < JP_MAX_COLOURS) h[threadIdx.x] = 0;
+    __shared__ unsigned slot_begin[JP_MAX_COLOURS], lead_begin[JP_MAX_COLOURS], lead_n[JP_MAX_COLOURS];
+    if (threadIdx.x < 64) {
+        const unsigned w = v.hist[2 * threadIdx.x], s = v.hist[2 * threadIdx.x + 1];
+        unsigned xs = 2 * w + s, xl = w + s;
+        const unsigned slots_c = xs, lead_c = xl;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned ys = __shfl_up(xs, off), yl = __shfl_up(xl, off); if ((int)threadIdx.x >= off) { xs += ys; xl += yl; } }
+        slot_begin[threadIdx.x] = xs - slots_c; lead_begin[threadIdx.x] = xl - lead_c; lead_n[threadIdx.x] = lead_c;
+    }
     __syncthreads();
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) atomicAdd(&h[colour[k] & (JP_MAX_COLOURS - 1)], 1u);
-    __syncthreads();
-    if (threadIdx.x < JP_MAX_COLOURS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    const int leaders = (int)(lead_begin[JP_MAX_COLOURS - 1] + lead_n[JP_MAX_COLOURS - 1]);
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < leaders; p += gridDim.x * blockDim.x) {
+        const unsigned key = sorted_keys[p], c = key >> 1;
+        const int j = (int)sorted_joints[p];
+        const unsigned r = (unsigned)p - lead_begin[c];
+        order_out[slot_begin[c] + r] = j;
+        if (!(key & 1u)) order_out[slot_begin[c] + lead_n[c] + r] = v.partner[j];
+    }
 }
 
 // bodies flagged in `scan` (already exclusive-scanned, nb + 1 entries) -> ascending list

@@ -103,7 +103,8 @@ private:
     DevBuf<float2> acc_, dd_;
     DevBuf<int> order_, static_slot_, flags_;
     DevBuf<int4> grp_desc_;
-    DevBuf<int> grp_ncol_, grp_bodies_, isl_stats_, hbm_body_list_;
+    DevBuf<int> grp_ncol_, grp_units_, grp_bodies_, isl_stats_, hbm_body_list_;
+    DevBuf<int2> unit_slots_;           // per LDS group (stride = lanes of the kernel shape): {leader slot, follower slot or -1} of its units
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;
     DevBuf<unsigned long long> isl_visits_;
@@ -111,7 +112,7 @@ private:
     DevBuf<int> cc_parent_, joint_comp_, bin_tables_, sb_small_;       // bin_tables_: component -> bin | component -> rank in its bin | bin -> first slot
     PinnedBuf<int> bin_tables_host_;
     DevBuf<unsigned char> cc_static_;
-    DevBuf<unsigned> cc_flags_, comp_size_, sort_keys_[2], sort_vals_[2], sort_hist_;
+    DevBuf<unsigned> cc_flags_, comp_size_, comp_units_, sort_keys_[2], sort_vals_[2], sort_hist_;
     ScanScratch sort_scan_;
     DevBuf<unsigned long long> jp_used_;                    // colouring of the HBM group on the device (schedule_kernels.h)
     DevBuf<uint4> jp_ent_, jp_adj_;
@@ -120,7 +121,8 @@ private:
     int jp_rounds_guess_ = 0;
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
     DevBuf<unsigned long long> jp_used_b_, jp_seen_;
-    DevBuf<unsigned char> jp_bad_b_;
+    DevBuf<unsigned char> jp_bad_b_, jp_kind_;
+    DevBuf<int> partner_, partner_first_;      // joint -> the other joint of its unit (schedule.h); contact point -> first joint carrying it
     DevBuf<int> jp_small_, jp_counts_;
     DevBuf<unsigned> jp_list_[2];
     bool gpu_builder_ = true;

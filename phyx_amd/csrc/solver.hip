@@ -39,10 +39,10 @@ DeviceSolver::~DeviceSolver()
     sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
     cc_parent_.release(); joint_comp_.release(); bin_tables_.release(); bin_tables_host_.release(); sb_small_.release(); cc_static_.release();
-    cc_flags_.release(); comp_size_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release();
+    cc_flags_.release(); comp_size_.release(); comp_units_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release(); jp_kind_.release(); partner_.release(); partner_first_.release();
     jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
-    hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
+    hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_slots_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -203,9 +203,9 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     }
     if (want_islands) {
         LdsCaps caps;
-        caps.max_joints = ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
+        caps.max_units = ISL_T; caps.max_joints = 2 * ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
         LdsCaps big;
-        big.max_joints = ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
+        big.max_units = ISL_T_BIG; big.max_joints = 2 * ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
         build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, &big, prio_id.data());
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_, prio_id.data());
@@ -252,6 +252,20 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         PHX_HIP(hipMemcpyAsync(grp_bodies_.p, sched_.group_bodies.data(), sched_.group_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_local_.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_colour_.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
+        // the units, class-major, at a fixed stride of one workgroup's lanes per group
+        const int lanes = sched_.lds_lanes;
+        std::vector<int> units(ng);
+        std::vector<int2> unit_slots((size_t)ng * lanes, make_int2(0, -1));
+        for (int g = 0; g < ng; ++g) {
+            units[g] = sched_.group_unit_offsets[g + 1] - sched_.group_unit_offsets[g];
+            for (int u = 0; u < units[g]; ++u) {
+                const int at = sched_.group_unit_offsets[g] + u;
+                unit_slots[(size_t)g * lanes + u] = make_int2(sched_.unit_leader[at], sched_.unit_follower[at]);
+            }
+        }
+        PHX_TRY(grp_units_.reserve(ng)); PHX_TRY(unit_slots_.reserve(unit_slots.size()));
+        PHX_HIP(hipMemcpyAsync(grp_units_.p, units.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(unit_slots_.p, unit_slots.data(), unit_slots.size() * sizeof(int2), hipMemcpyHostToDevice, stream_));
     }
     PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sched_.hbm_bodies.size(), 1)));
     if (!sched_.hbm_bodies.empty())
@@ -290,6 +304,11 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(order_.reserve(njs));
 
     hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p);
+    // units (schedule.h): the partner of every joint
+    PHX_TRY(partner_.reserve(njs)); PHX_TRY(partner_first_.reserve(std::max(ncp_, 1))); PHX_TRY(comp_units_.reserve(nbs + 1));
+    PHX_HIP(hipMemsetAsync(partner_first_.p, 0x7f, (size_t)std::max(ncp_, 1) * sizeof(int), stream_));
+    hipLaunchKernelGGL(k_partner_first, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, partner_first_.p);
+    hipLaunchKernelGGL(k_partner_find, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, (const int*)partner_first_.p, partner_.p);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -302,7 +321,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     //    last round still hook anything' flag comes back in the same round trip as the component count and sizes, and only
     //    if it is set (deep island graphs) are more rounds run and the numbering redone.
     unsigned ncomp_u = 0;
-    std::vector<unsigned> comp_size;
+    std::vector<unsigned> comp_size, comp_units;
     int guess = 0;
     for (int round = 0;; round += 2) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
@@ -312,17 +331,18 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
             hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
             hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == 0 ? sb_small_.p : (int*)nullptr);
         }
-        hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p, comp_size_.p);
+        hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p, comp_size_.p, comp_units_.p);
         PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
-                           (const unsigned*)cc_flags_.p, joint_comp_.p, comp_size_.p);
+                           (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
-        comp_size.assign(std::max(guess, 1), 0u);
+        comp_size.assign(std::max(guess, 1), 0u); comp_units.assign(std::max(guess, 1), 0u);
         PHX_TRY(with_fingerprint());
         int pair[2] = {0, 0};                              // {changed, component count}: adjacent words, one copy
         PHX_TRY(rb_.add(pair, sb_small_.p, sizeof pair, stream_));
         PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)guess * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_units.data(), comp_units_.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
         changed = pair[0]; ncomp_u = (unsigned)pair[1];
         if (!changed) break;
@@ -331,11 +351,12 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     const int ncomp = (int)ncomp_u;
     ncomp_total = ncomp;
     if (ncomp > guess) {
-        comp_size.resize(ncomp);
+        comp_size.resize(ncomp); comp_units.resize(ncomp);
         PHX_TRY(rb_.add(comp_size.data() + guess, comp_size_.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_units.data() + guess, comp_units_.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
     }
-    comp_size.resize(std::max(ncomp, 1));
+    comp_size.resize(std::max(ncomp, 1)); comp_units.resize(std::max(ncomp, 1));
     ncomp_guess_ = ncomp;
 
     // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
@@ -348,22 +369,24 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         }
         sc.island_count = count; sc.island_max_size = mx;
     }
-    int cap_joints = ISL_T, cap_bodies = ISL_B;
-    for (int c = 0; c < ncomp; ++c) if ((int)comp_size[c] > ISL_T && (int)comp_size[c] <= ISL_T_BIG) { cap_joints = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
-    sc.lds_lanes = cap_joints;
-    if (!want_islands) cap_joints = 0;          // Single mode: one coupled system, every component goes to the HBM group
+    // the workgroup shape: units = lanes of the island kernel, joints = twice that; the roomier shape only if some component
+    // needs it and fits it (identical to schedule.hip::build_island_schedule)
+    int cap_units = ISL_T, cap_bodies = ISL_B;
+    auto fits = [&](int c, int units) { return (int)comp_size[c] <= 2 * units && (int)comp_units[c] <= units; };
+    for (int c = 0; c < ncomp; ++c) if (comp_size[c] && !fits(c, ISL_T) && fits(c, ISL_T_BIG)) { cap_units = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
+    sc.lds_lanes = cap_units;
     std::vector<int> bin_of(std::max(ncomp, 1), -1), rank_of(std::max(ncomp, 1), 0);     // rank of a component inside its bin (schedule.h: the colouring candidate is chosen per component)
     {
-        int size = 0, rank = 0;
+        int size = 0, units = 0, rank = 0;
         bool open = false;
         for (int c = 0; c < ncomp; ++c) {
-            const int n = (int)comp_size[c];
+            const int n = (int)comp_size[c], u = (int)comp_units[c];
             if (n == 0) continue;
-            if (n > cap_joints || !want_islands) { open = false; size = 0; continue; }            // -> HBM group
-            if (!open || size + n > cap_joints) { sc.group_offsets.push_back(sc.group_offsets.back()); ++nbins; open = true; size = 0; rank = 0; }
+            if (!want_islands || !fits(c, cap_units)) { open = false; size = 0; units = 0; continue; }     // -> HBM group (Single mode: every component)
+            if (!open || size + n > 2 * cap_units || units + u > cap_units) { sc.group_offsets.push_back(sc.group_offsets.back()); ++nbins; open = true; size = 0; units = 0; rank = 0; }
             bin_of[c] = nbins - 1;
             rank_of[c] = rank++;
-            size += n;
+            size += n; units += u;
             sc.group_offsets.back() += n;
         }
     }
@@ -399,13 +422,15 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(slot_local_.reserve(std::max(lds_slots, 1))); PHX_TRY(slot_colour_.reserve(std::max(lds_slots, 1)));
     if (nbins) {
         BinBuildView bv{};
-        bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.is_static = cc_static_.p;
+        PHX_TRY(grp_units_.reserve(nbins)); PHX_TRY(unit_slots_.reserve((size_t)nbins * cap_units));
+        bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.partner = partner_.p; bv.is_static = cc_static_.p;
         bv.joint_comp = joint_comp_.p; bv.comp_rank = rank_of_comp;
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
+        bv.units = grp_units_.p; bv.unit_slots = unit_slots_.p;
         bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2;
-        if (cap_joints > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(ISL_T_BIG), 0, stream_, bv);
-        else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(ISL_T), 0, stream_, bv);
+        if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(2 * ISL_T_BIG), 0, stream_, bv);
+        else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(2 * ISL_T), 0, stream_, bv);
     }
     PHX_HIP(hipGetLastError());
     int rejected = 0;
@@ -435,7 +460,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         const unsigned* ids = sort_vals_[where].p + lds_slots;
         PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_degree_.reserve(nbs + 1));
         PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs));
-        PHX_TRY(jp_small_.reserve(JP_MAX_COLOURS + 8)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
+        PHX_TRY(jp_small_.reserve(2 * JP_MAX_COLOURS + 8)); PHX_TRY(jp_kind_.reserve(rest)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
         PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
         PHX_TRY(jp_ent_.reserve(rest)); PHX_TRY(jp_succ_.reserve(rest)); PHX_TRY(jp_pred_.reserve(rest)); PHX_TRY(jp_colour_b_.reserve(rest));
         for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); PHX_TRY(jp_list_[k].reserve((size_t)rest * JP_SUBLISTS)); }
@@ -445,7 +470,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         jv.ent = jp_ent_.p; jv.offset = jp_offset_.p; jv.cursor = jp_cursor_.p; jv.adj = jp_adj_.p; jv.ent_comp = jp_ent_comp_.p;
         jv.succ = jp_succ_.p; jv.pred = jp_pred_.p;
         jv.used = jp_used_.p; jv.used_b = jp_used_b_.p; jv.colour = jp_keys_[0].p; jv.colour_b = jp_colour_b_.p; jv.touched = jp_touched_.p;
-        jv.joint_comp = joint_comp_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
+        jv.joint_comp = joint_comp_.p; jv.partner = partner_.p; jv.kind = jp_kind_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
         jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
         jv.counts = jp_counts_.p; jv.flags = jp_small_.p; jv.hist = reinterpret_cast<unsigned*>(jp_small_.p + 4);
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
@@ -484,18 +509,19 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         }
         if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d rounds (%d launched)\n", rest, jp_rounds_guess_, round);
         lap("rest/colour");
-        hipLaunchKernelGGL(k_jp_choose, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
-        // colour sizes, bodies touched, static slots: three small scans, one readback
+        hipLaunchKernelGGL(k_jp_choose, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);          // sort keys (class, kind) + their histogram
+        // bodies touched, static slots: two small scans; one readback with the histogram
         unsigned* hist = jv.hist;
-        hipLaunchKernelGGL(k_jp_hist, dim3(std::min(grid_for(rest), 256)), dim3(256), 0, stream_, (const unsigned*)jp_keys_[0].p, rest, hist);
         PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_, stream_));
         PHX_TRY(hbm_body_list_.reserve(nbs));
         hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned*)jp_touched_.p, nb, hbm_body_list_.p);
+        // leaders sorted by (class, kind), stable in joint order (followers behind them all); then every leader places itself
+        // and its follower
         int where2 = 0;
         PHX_HIP(hipMemcpyAsync(jp_vals_[0].p, ids, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 6, sort_hist_.p, sort_scan_, stream_, &where2));
-        PHX_HIP(hipMemcpyAsync(order_.p + lds_slots, jp_vals_[where2].p, (size_t)rest * sizeof(int), hipMemcpyDeviceToDevice, stream_));
-        unsigned h_hist[JP_MAX_COLOURS], h_touched = 0;
+        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 8, sort_hist_.p, sort_scan_, stream_, &where2));
+        hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_keys_[where2].p, (const unsigned*)jp_vals_[where2].p, order_.p + lds_slots);
+        unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0;
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
         PHX_TRY(rb_.add(&h_touched, jp_touched_.p + nb, sizeof h_touched, stream_));
         // static slots (only the HBM path indexes the global static-tag tables)
@@ -511,7 +537,13 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
         sc.hbm_colour_offsets.assign(1, lds_slots);
-        for (int c = 0; c < JP_MAX_COLOURS; ++c) if (h_hist[c]) sc.hbm_colour_offsets.push_back(sc.hbm_colour_offsets.back() + (int)h_hist[c]);
+        sc.hbm_class_leaders.clear();
+        for (int c = 0; c < JP_MAX_COLOURS; ++c) {
+            const int with = (int)h_hist[2 * c], single = (int)h_hist[2 * c + 1];
+            if (!(with + single)) continue;
+            sc.hbm_colour_offsets.push_back(sc.hbm_colour_offsets.back() + 2 * with + single);
+            sc.hbm_class_leaders.push_back(with + single);
+        }
         if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
         PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs)); PHX_TRY(sb_par_.reserve(nbs));
@@ -576,8 +608,8 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
         for (size_t c = 0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
-            const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1];
-            hipLaunchKernelGGL(k_prestep, dim3(grid_for(ce - cb)), dim3(256), 0, stream_, v, cb, ce);
+            const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1], lead = sched_.hbm_class_leaders[c];
+            hipLaunchKernelGGL(k_prestep, dim3(grid_for(lead)), dim3(256), 0, stream_, v, cb, lead, ce - cb - lead);
         }
     }
     PHX_HIP(hipGetLastError());
@@ -595,7 +627,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
     if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
         iv.first = shard_; iv.stride = shard_count_;
-        iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
+        iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_slots = unit_slots_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
         iv.trace = nullptr; iv.wave_trace = nullptr;
         if (trace_islands_) {
@@ -619,11 +651,11 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         for (int it = 0; it < iters; ++it) {
             const bool imp = it < ci, disp = it < pi;
             for (int c = 0; c < ncol; ++c) {
-                const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1];
-                const dim3 g(std::max(1, std::min(div_up(ce - cb, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
-                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, ce, c, it);
-                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, ce, c, it);
-                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, ce, c, it);
+                const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1], lead = sched_.hbm_class_leaders[c], foll = ce - cb - lead;
+                const dim3 g(std::max(1, std::min(div_up(lead, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
+                if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, lead, foll, c, it);
+                else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, lead, foll, c, it);
+                else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, lead, foll, c, it);
                 ++sweep_launches_;
             }
         }

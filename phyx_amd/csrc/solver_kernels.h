@@ -186,28 +186,37 @@ __global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int begin, i
     }
 }
 
-// ---- PreStepJoints (ref: Solver.cpp:697-758), one colour ------------------------------------------
-__global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int end)
+// ---- PreStepJoints (ref: Solver.cpp:697-758), one class: a lane applies its unit's leader, then its follower ----------
+// (a class = `leaders` leader slots followed by `followers` follower slots; follower i belongs to leader i, schedule.h)
+__device__ __forceinline__ void prestep_one(const SolverView& v, int s, float4& B1, float4& B2, bool& st1, bool& st2, int& b1, int& b2)
 {
-    for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
-        const float4 a = v.q0[s], b = v.q1[s], c = v.q2[s];
-        const int4 k = v.q3[s];
-        const float2 acc = v.acc[s];
-        const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
-        const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
-        const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
-        if (!st1) {
-            float4 B = v.sb_imp[k.y];
-            B.x += (nx * im1) * acc.x; B.y += (ny * im1) * acc.x; B.z += (a.z * ii1) * acc.x;
-            B.x += (tx * im1) * acc.y; B.y += (ty * im1) * acc.y; B.z += (b.x * ii1) * acc.y;
-            v.sb_imp[k.y] = B;
-        }
-        if (!st2) {
-            float4 B = v.sb_imp[k.z];
-            B.x += ((-nx) * im2) * acc.x; B.y += ((-ny) * im2) * acc.x; B.z += (a.w * ii2) * acc.x;
-            B.x += ((-tx) * im2) * acc.y; B.y += ((-ty) * im2) * acc.y; B.z += (b.y * ii2) * acc.y;
-            v.sb_imp[k.z] = B;
-        }
+    const float4 a = v.q0[s], b = v.q1[s], c = v.q2[s];
+    const int4 k = v.q3[s];
+    const float2 acc = v.acc[s];
+    const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
+    st1 = (im1 == 0.f && ii1 == 0.f); st2 = (im2 == 0.f && ii2 == 0.f);
+    const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
+    if (b1 < 0) { b1 = k.y; b2 = k.z; if (!st1) B1 = v.sb_imp[b1]; if (!st2) B2 = v.sb_imp[b2]; }      // (the follower shares the leader's bodies)
+    if (!st1) {
+        B1.x += (nx * im1) * acc.x; B1.y += (ny * im1) * acc.x; B1.z += (a.z * ii1) * acc.x;
+        B1.x += (tx * im1) * acc.y; B1.y += (ty * im1) * acc.y; B1.z += (b.x * ii1) * acc.y;
+    }
+    if (!st2) {
+        B2.x += ((-nx) * im2) * acc.x; B2.y += ((-ny) * im2) * acc.x; B2.z += (a.w * ii2) * acc.x;
+        B2.x += ((-tx) * im2) * acc.y; B2.y += ((-ty) * im2) * acc.y; B2.z += (b.y * ii2) * acc.y;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int leaders, int followers)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
+        float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1;
+        bool st1 = false, st2 = false;
+        int b1 = -1, b2 = -1;
+        prestep_one(v, begin + i, B1, B2, st1, st2, b1, b2);
+        if (i < followers) prestep_one(v, begin + leaders + i, B1, B2, st1, st2, b1, b2);
+        if (!st1) v.sb_imp[b1] = B1;
+        if (!st2) v.sb_imp[b2] = B2;
     }
 }
 
@@ -234,8 +243,94 @@ __device__ __forceinline__ void wave_tag_update(unsigned* words, bool want, int 
     }
 }
 
+// the constants and accumulators of one slot, loaded up front (nothing here depends on the body gathers)
+struct HbmJoint { float4 a, f, c; int4 k; float2 acc, d; };
+
+__device__ __forceinline__ HbmJoint hbm_load(const SolverView& v, int s, bool imp_on, bool disp_on)
+{
+    HbmJoint q;
+    q.k = v.q3[s]; q.c = v.q2[s]; q.a = v.q0[s];
+    q.f = make_float4(0.f, 0.f, 0.f, 0.f); q.acc = make_float2(0.f, 0.f); q.d = make_float2(0.f, 0.f);
+    if (imp_on) { q.f = v.q1[s]; q.acc = v.acc[s]; }
+    if (disp_on) q.d = v.dd[s];
+    return q;
+}
+
+// one joint of a unit on the body state the lane holds in registers (ref: Solver.cpp:790-896 impulses, :960-1005 displacement)
+__device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& q, int colour, int iter, bool imp_on, bool disp_on,
+                                          float4& B1, float4& B2, float4& D1, float4& D2, bool st1, bool st2, int ss,
+                                          bool& any_imp, bool& any_disp, bool& tag_imp, bool& tag_disp, bool& dirty_imp, bool& dirty_disp)
+{
+    const float4 a = q.a, f = q.f, c = q.c;
+    const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(q.k.x);
+    const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
+    if (imp_on) {
+        // ref: Solver.cpp:790-798
+        const bool p1 = st1 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
+        const bool p2 = st2 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
+        if (p1 || p2) {
+            float2 acc = q.acc;
+            // normal limiter (ref: :833-858)
+            float dv = f.w;
+            dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
+            dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
+            float dn = dv * c.x;
+            dn = max_ref(dn, -acc.x);
+            B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (a.z * ii1) * dn;
+            B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (a.w * ii2) * dn;
+            acc.x += dn;
+            // friction limiter (ref: :860-889)
+            float fv = 0.f;
+            fv -= tx * B1.x; fv -= ty * B1.y; fv -= f.x * B1.z;
+            fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= f.y * B2.z;
+            float df = fv * f.z;
+            const float force = acc.y + df;
+            const float limit = acc.x * 0.3f;
+            const float signed_limit = force < 0.f ? -limit : limit;          // scalar flipsign, ref: SIMD_Scalar.h:265-268
+            const float adjusted = signed_limit - acc.y;
+            if (fabsf(force) > limit) df = adjusted;
+            acc.y += df;
+            B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (f.x * ii1) * df;
+            B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (f.y * ii2) * df;
+            v.acc[s] = acc;
+            const bool productive = max_ref(fabsf(dn), fabsf(df)) > 1e-4f;      // ref: :894-896
+            if (productive) {
+                B1.w = __int_as_float(iter); B2.w = __int_as_float(iter);
+                any_imp = true;
+                if ((st1 || st2) && ss >= 0) tag_imp = true;
+            }
+            dirty_imp = true;
+        }
+    }
+    if (disp_on) {
+        const bool p1 = st1 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D1.w) > iter - 2);
+        const bool p2 = st2 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D2.w) > iter - 2);
+        if (p1 || p2) {
+            float2 d = q.d;
+            float dv = d.x;                                                      // ref: :973-981
+            dv -= nx * D1.x; dv -= ny * D1.y; dv -= a.z * D1.z;
+            dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= a.w * D2.z;
+            float di = dv * c.x;
+            di = max_ref(di, -d.y);
+            D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (a.z * ii1) * di;
+            D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (a.w * ii2) * di;
+            d.y += di;
+            v.dd[s] = d;
+            const bool productive = fabsf(di) > 1e-4f;                           // ref: :999
+            if (productive) {
+                D1.w = __int_as_float(iter); D2.w = __int_as_float(iter);
+                any_disp = true;
+                if ((st1 || st2) && ss >= 0) tag_disp = true;
+            }
+            dirty_disp = true;
+        }
+    }
+}
+
+// one class: `leaders` leader slots from `begin`, then `followers` follower slots; lane i sweeps leader i, then follower i
+// on the same two bodies (schedule.h) — one gather and one scatter of the body state per unit
 template <bool DO_IMP, bool DO_DISP>
-__global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int begin, int end, int colour, int iter)
+__global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int begin, int leaders, int followers, int colour, int iter)
 {
     // A sweep after an unproductive sweep skips every joint (all tags <= iter-2), which is why the reference may
     // stop there (ref: Solver.cpp:189, 210).  The impulse half needs no flag for that — each joint's own skip
@@ -245,85 +340,27 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
     const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
 
     bool any_imp = false, any_disp = false;
-    for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
-        const int4 k = v.q3[s];
-        const float4 c = v.q2[s];
-        const float4 a = v.q0[s];
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 acc = make_float2(0.f, 0.f), d = make_float2(0.f, 0.f);
-        if (imp_on) { f = v.q1[s]; acc = v.acc[s]; }
-        if (disp_on) d = v.dd[s];
-        const int b1 = k.y, b2 = k.z, ss = k.w;
-        bool tag_imp = false, tag_disp = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
+        const bool has2 = i < followers;
+        const int s0 = begin + i, s1 = begin + leaders + i;
+        HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on), q1{};
+        if (has2) q1 = hbm_load(v, s1, imp_on, disp_on);
+        const int b1 = q0.k.y, b2 = q0.k.z, ss = q0.k.w;
         float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
         if (imp_on) { B1 = v.sb_imp[b1]; B2 = v.sb_imp[b2]; }
         if (disp_on) { D1 = v.sb_disp[b1]; D2 = v.sb_disp[b2]; }
-
-        const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
+        const float im1 = q0.c.y, ii1 = q0.c.z, im2 = q0.c.w, ii2 = __int_as_float(q0.k.x);
         const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
-        const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
-
-        if (imp_on) {
-            // ref: Solver.cpp:790-798
-            const bool p1 = st1 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
-            const bool p2 = st2 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
-            if (p1 || p2) {
-                // normal limiter (ref: :833-858)
-                float dv = f.w;
-                dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
-                dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
-                float dn = dv * c.x;
-                dn = max_ref(dn, -acc.x);
-                B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (a.z * ii1) * dn;
-                B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (a.w * ii2) * dn;
-                acc.x += dn;
-                // friction limiter (ref: :860-889)
-                float fv = 0.f;
-                fv -= tx * B1.x; fv -= ty * B1.y; fv -= f.x * B1.z;
-                fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= f.y * B2.z;
-                float df = fv * f.z;
-                const float force = acc.y + df;
-                const float limit = acc.x * 0.3f;
-                const float signed_limit = force < 0.f ? -limit : limit;          // scalar flipsign, ref: SIMD_Scalar.h:265-268
-                const float adjusted = signed_limit - acc.y;
-                if (fabsf(force) > limit) df = adjusted;
-                acc.y += df;
-                B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (f.x * ii1) * df;
-                B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (f.y * ii2) * df;
-                v.acc[s] = acc;
-                const bool productive = max_ref(fabsf(dn), fabsf(df)) > 1e-4f;      // ref: :894-896
-                if (productive) {
-                    B1.w = __int_as_float(iter); B2.w = __int_as_float(iter);
-                    any_imp = true;
-                    tag_imp = (st1 || st2) && ss >= 0;
-                }
-                if (!st1) v.sb_imp[b1] = B1;
-                if (!st2) v.sb_imp[b2] = B2;
-            }
+        const float4 S1 = B1, S2 = B2, T1 = D1, T2 = D2;
+        bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
+        solve_one(v, s0, q0, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        if (has2) {                                    // a static body's record is never stored: the follower must see it untouched
+            if (st1) { B1 = S1; D1 = T1; }
+            if (st2) { B2 = S2; D2 = T2; }
+            solve_one(v, s1, q1, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
         }
-        if (disp_on) {
-            const bool p1 = st1 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D1.w) > iter - 2);
-            const bool p2 = st2 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D2.w) > iter - 2);
-            if (p1 || p2) {
-                float dv = d.x;                                                      // ref: :973-981
-                dv -= nx * D1.x; dv -= ny * D1.y; dv -= a.z * D1.z;
-                dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= a.w * D2.z;
-                float di = dv * c.x;
-                di = max_ref(di, -d.y);
-                D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (a.z * ii1) * di;
-                D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (a.w * ii2) * di;
-                d.y += di;
-                v.dd[s] = d;
-                const bool productive = fabsf(di) > 1e-4f;                           // ref: :999
-                if (productive) {
-                    D1.w = __int_as_float(iter); D2.w = __int_as_float(iter);
-                    any_disp = true;
-                    tag_disp = (st1 || st2) && ss >= 0;
-                }
-                if (!st1) v.sb_disp[b1] = D1;
-                if (!st2) v.sb_disp[b2] = D2;
-            }
-        }
+        if (dirty_imp) { if (!st1) v.sb_imp[b1] = B1; if (!st2) v.sb_imp[b2] = B2; }
+        if (dirty_disp) { if (!st1) v.sb_disp[b1] = D1; if (!st2) v.sb_disp[b2] = D2; }
         // static-tag updates of this wave, one atomic per distinct static body: every joint on the ground raises the
         // same word to the same value, and same-address atomics serialise at the L2 (thousands per colour otherwise)
         if (DO_IMP) wave_tag_update(v.sw_imp + (iter & 1) * v.nstatic, tag_imp, ss, static_word(iter, colour));
@@ -336,21 +373,26 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
 
 // ---- island kernel: one workgroup solves one GROUP of the schedule entirely out of LDS -----------------
 // (Refresh, PreStep and every impulse / displacement sweep of ref: Solver.cpp:130-215 SolveJointIsland.)
-// A lane owns one joint for the whole solve: its 16 refreshed constants and 3 accumulators live in registers,
-// the group's body velocities live in LDS, colours are separated by workgroup barriers instead of kernel
-// launches, and HBM is touched once on the way in and once on the way out.  The early exit of ref: Solver.cpp:189
-// / :210 is per group, exactly like the reference's per-island loop.
-// Two shapes: 512 lanes / 768 bodies (4 workgroups per CU — the 200-box columns of cfg 2 are 410 joints each) and
-// 1024 lanes / 1024 bodies (2 per CU — the 500-box columns of cfg 5 are ~1020 joints each).
-constexpr int ISL_T = 512, ISL_B = 768;        // lanes = joint capacity of a group; body capacity (dynamic + touched static)
-constexpr int ISL_T_BIG = 1024, ISL_B_BIG = 1024;
+// A lane owns one UNIT (schedule.h: the one or two joints of a body pair) for the whole solve: the refreshed constants and
+// the accumulators of both joints live in registers, the group's body velocities live in LDS, classes are separated by
+// workgroup barriers instead of kernel launches, and HBM is touched once on the way in and once on the way out.  A step
+// sweeps the unit's leader and then its follower on one read and one write of the two bodies: half the barriers and LDS
+// round trips per joint of the one-joint-per-lane kernel of round 2.  The early exit of ref: Solver.cpp:189 / :210 is per
+// group, exactly like the reference's per-island loop.
+// Two shapes: 256 lanes / 512 joints / 768 bodies (4 workgroups per CU — the 200-box columns of cfg 2 are ~205 units each)
+// and 512 lanes / 1024 joints / 1024 bodies (2 per CU — the 500-box columns of cfg 5 are ~510 units each); both leave a
+// lane 128 VGPRs.
+constexpr int ISL_T = 256, ISL_B = 768;        // lanes = unit capacity of a group (joints: twice that); body capacity (dynamic + touched static)
+constexpr int ISL_T_BIG = 512, ISL_B_BIG = 1024;
 
 struct IslandView {
     const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
-    const int* ncol;                  // per group: colours
+    const int* ncol;                  // per group: classes
+    const int* units;                 // per group: units
+    const int2* unit_slots;           // per group g, unit u: [g * T + u] = {leader slot, follower slot or -1}, class-major
     const int* bodies;                // global body ids, group-local order
     const unsigned* slot_local;       // per slot: local body1 | local body2 << 16
-    const unsigned char* slot_colour; // per slot: colour inside the group
+    const unsigned char* slot_colour; // per slot: class inside the group
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
     unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
@@ -359,7 +401,7 @@ struct IslandView {
 };
 
 // phase stamps of the island kernel (tools/island_trace.py; the constant 100 MHz clock all XCDs share): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
-// 5 written back; word 6 = XCC id | s_memtime ticks of the whole workgroup << 4, word 7 = colours << 32 | impulse sweeps executed
+// 5 written back; word 6 = XCC id | s_memtime ticks of the whole workgroup << 4, word 7 = classes << 32 | impulse sweeps executed
 #define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = wall_clock64(); } while (0)
 
 template <int B>
@@ -389,8 +431,99 @@ __device__ __forceinline__ void body_store(uint2* p, int i, float4 v)
     p[i] = make_uint2(f2h_bits(v.x) | (f2h_bits(v.y) << 16), f2h_bits(v.z) | ((unsigned)(unsigned short)(short)__float_as_int(v.w) << 16));
 }
 
+// fp16 ablation: what a store + load of the body record would leave in the registers (identity for fp32 state)
+template <bool HALF> __device__ __forceinline__ float4 body_round(float4 v)
+{
+    if (!HALF) return v;
+    return make_float4(h2f_bits(f2h_bits(v.x)), h2f_bits(f2h_bits(v.y)), h2f_bits(f2h_bits(v.z)), __int_as_float((int)(short)__float_as_int(v.w)));
+}
+
+// the refreshed constants and accumulators of one joint, in registers for the whole solve
+struct IslJoint { float nx, ny, aN1, aN2, aF1, aF2, cimN, cimF, dstV, dstD, accN, accF, accD; };
+
+// RefreshJoints (ref: Solver.cpp:642-693) — same expressions as k_pack_refresh
+__device__ __forceinline__ void isl_refresh(IslJoint& q, float d1x, float d1y, float d2x, float d2y, const float4& p1, const float4& p2)
+{
+    const float pt1x = d1x + p1.z, pt1y = d1y + p1.w;
+    const float pt2x = d2x + p2.z, pt2y = d2y + p2.w;
+    const float w2x = pt1x - p2.z, w2y = pt1y - p2.w;
+    const Limiter N = refresh_limiter(q.nx, q.ny, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
+    const Limiter F = refresh_limiter(-q.ny, q.nx, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
+    const float depth = (pt2x - pt1x) * q.nx + (pt2y - pt1y) * q.ny;
+    const float dst = 0.f;
+    q.dstV = depth < 1.f ? dst - 0.1f : dst;
+    q.dstD = 0.1f * max_ref(0.f, depth - 2.0f * 1.f);
+    q.aN1 = N.a1; q.aN2 = N.a2; q.cimN = N.cim; q.aF1 = F.a1; q.aF2 = F.a2; q.cimF = F.cim;
+}
+
+// PreStepJoints (ref: Solver.cpp:736-750) of one joint on the bodies held in registers
+__device__ __forceinline__ void isl_prestep(const IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2)
+{
+    const float tx = -q.ny, ty = q.nx;
+    B1.x += (q.nx * im1) * q.accN; B1.y += (q.ny * im1) * q.accN; B1.z += (q.aN1 * ii1) * q.accN;
+    B1.x += (tx * im1) * q.accF; B1.y += (ty * im1) * q.accF; B1.z += (q.aF1 * ii1) * q.accF;
+    B2.x += ((-q.nx) * im2) * q.accN; B2.y += ((-q.ny) * im2) * q.accN; B2.z += (q.aN2 * ii2) * q.accN;
+    B2.x += ((-tx) * im2) * q.accF; B2.y += ((-ty) * im2) * q.accF; B2.z += (q.aF2 * ii2) * q.accF;
+}
+
+// one impulse visit (ref: Solver.cpp:790-896); returns whether the joint was evaluated (not skipped), `productive` whether it moved
+template <int NB>
+__device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
+                                            const unsigned (*sw)[NB], int l1, int l2, int it, int c, bool& productive)
+{
+    const bool p1 = st1 ? static_productive_lds(sw, l1, it, c) : (__float_as_int(B1.w) > it - 2);
+    const bool p2 = st2 ? static_productive_lds(sw, l2, it, c) : (__float_as_int(B2.w) > it - 2);
+    productive = false;
+    if (!(p1 || p2)) return false;
+    const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
+    float dv = q.dstV;
+    dv -= nx * B1.x; dv -= ny * B1.y; dv -= q.aN1 * B1.z;
+    dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= q.aN2 * B2.z;
+    float dn = dv * q.cimN;
+    dn = max_ref(dn, -q.accN);
+    B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (q.aN1 * ii1) * dn;
+    B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (q.aN2 * ii2) * dn;
+    q.accN += dn;
+    float fv = 0.f;
+    fv -= tx * B1.x; fv -= ty * B1.y; fv -= q.aF1 * B1.z;
+    fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= q.aF2 * B2.z;
+    float df = fv * q.cimF;
+    const float force = q.accF + df;
+    const float limit = q.accN * 0.3f;
+    const float signed_limit = force < 0.f ? -limit : limit;
+    const float adjusted = signed_limit - q.accF;
+    if (fabsf(force) > limit) df = adjusted;
+    q.accF += df;
+    B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (q.aF1 * ii1) * df;
+    B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (q.aF2 * ii2) * df;
+    if (max_ref(fabsf(dn), fabsf(df)) > 1e-4f) { B1.w = __int_as_float(it); B2.w = __int_as_float(it); productive = true; }
+    return true;
+}
+
+// one displacement visit (ref: Solver.cpp:960-1005)
+template <int NB>
+__device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
+                                             const unsigned (*sw)[NB], int l1, int l2, int it, int c, bool& productive)
+{
+    const bool p1 = st1 ? static_productive_lds(sw, l1, it, c) : (__float_as_int(D1.w) > it - 2);
+    const bool p2 = st2 ? static_productive_lds(sw, l2, it, c) : (__float_as_int(D2.w) > it - 2);
+    productive = false;
+    if (!(p1 || p2)) return false;
+    const float nx = q.nx, ny = q.ny;
+    float dv = q.dstD;
+    dv -= nx * D1.x; dv -= ny * D1.y; dv -= q.aN1 * D1.z;
+    dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= q.aN2 * D2.z;
+    float di = dv * q.cimN;
+    di = max_ref(di, -q.accD);
+    D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (q.aN1 * ii1) * di;
+    D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (q.aN2 * ii2) * di;
+    q.accD += di;
+    if (fabsf(di) > 1e-4f) { D1.w = __int_as_float(it); D2.w = __int_as_float(it); productive = true; }
+    return true;
+}
+
 template <int T, int NB, bool HALF, bool TRACE = false>
-__global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
+__global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
                                                             phx_contact_joint* __restrict__ joints,
                                                             const phx_contact_point* __restrict__ cps, int ci, int pi)
 {
@@ -410,24 +543,26 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     const int group = iv.first + (int)blockIdx.x * iv.stride;
     PHX_ISL_STAMP(0);
     const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
-    // TRACE: per wave, shader cycles spent in colour steps {working: in the joint update, then at the barrier; idle: whole step}
+    // TRACE: per wave, shader cycles spent in class steps {working: in the unit update, then at the barrier; idle: whole step}
     unsigned long long tw_work = 0, tw_bar = 0, tw_idle = 0, tw_work_big = 0; unsigned tw_nwork = 0, tw_nidle = 0, tw_nbig = 0;
     const int4 d = iv.desc[group];
     const int ncol = iv.ncol[group];
+    const int nunits = iv.units[group];
     const int tid = threadIdx.x;
 
     // Set-up is a chain of dependent HBM round trips (index -> record -> contact point); the body chain and the joint
     // chain are independent, so their loads are issued level by level, both chains in flight together.
     constexpr int BI = (NB + T - 1) / T;                   // body records per lane
-    const bool live = tid < d.y;
-    const int s = d.x + tid;
+    const bool live = tid < nunits;
     int body_id[BI];
 #pragma unroll
     for (int k = 0; k < BI; ++k) body_id[k] = tid + k * T < d.w ? iv.bodies[d.z + tid + k * T] : -1;      // level 1
-    const int joint_id = live ? v.order[s] : 0;
+    const int2 us = live ? iv.unit_slots[(size_t)group * T + tid] : make_int2(0, -1);
+    const bool has2 = live && us.y >= 0;
+    const int jid0 = live ? v.order[us.x] : 0, jid1 = has2 ? v.order[us.y] : 0;
     unsigned loc = 0;
     int col = -1;
-    if (live) { loc = iv.slot_local[s]; col = iv.slot_colour[s]; }
+    if (live) { loc = iv.slot_local[us.x]; col = iv.slot_colour[us.x]; }
     if (tid < 2) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
 
     float4 rec_imp[BI], rec_disp[BI], rec_par[BI];
@@ -439,19 +574,25 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
         rec_disp[k] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
         rec_par[k] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
     }
-    phx_contact_joint j;
-    float d1x = 0.f, d1y = 0.f, d2x = 0.f, d2y = 0.f;
-    float nx = 0.f, ny = 0.f, aN1 = 0.f, aN2 = 0.f, aF1 = 0.f, aF2 = 0.f, cimN = 0.f, cimF = 0.f, dstV = 0.f, dstD = 0.f;
-    float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f, accN = 0.f, accF = 0.f, accD = 0.f;
+    IslJoint q0{}, q1{};
+    float4 da0 = make_float4(0.f, 0.f, 0.f, 0.f), da1 = da0;     // delta1, delta2 of the two contact points
     int l1 = 0, l2 = 0;
     if (live) {                                            // PrepareJoints (ref: Solver.cpp:509-521)
-        j = joints[joint_id];
+        const phx_contact_joint j = joints[jid0];
         const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);   // level 3, 32-byte records
-        const float4 da = cp4[0];                          // delta1, delta2
+        da0 = cp4[0];
         const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
-        d1x = da.x; d1y = da.y; d2x = da.z; d2y = da.w; nx = nn.x; ny = nn.y;
+        q0.nx = nn.x; q0.ny = nn.y;
         l1 = (int)(loc & 0xFFFFu); l2 = (int)(loc >> 16);
-        accN = j.normal_accumulated_impulse; accF = j.friction_accumulated_impulse;
+        q0.accN = j.normal_accumulated_impulse; q0.accF = j.friction_accumulated_impulse;
+    }
+    if (has2) {
+        const phx_contact_joint j = joints[jid1];
+        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);
+        da1 = cp4[0];
+        const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
+        q1.nx = nn.x; q1.ny = nn.y;
+        q1.accN = j.normal_accumulated_impulse; q1.accF = j.friction_accumulated_impulse;
     }
 #pragma unroll
     for (int k = 0; k < BI; ++k) {
@@ -464,43 +605,30 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     }
     __syncthreads();
     PHX_ISL_STAMP(1);
+    float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f;
     if (live) {
         const float4 p1 = par[l1], p2 = par[l2];           // {im, ii, pos.x, pos.y} of the two bodies
-        // RefreshJoints (ref: Solver.cpp:642-693) — same expressions as k_pack_refresh
-        const float pt1x = d1x + p1.z, pt1y = d1y + p1.w;
-        const float pt2x = d2x + p2.z, pt2y = d2y + p2.w;
-        const float w2x = pt1x - p2.z, w2y = pt1y - p2.w;
-        const Limiter N = refresh_limiter(nx, ny, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
-        const Limiter F = refresh_limiter(-ny, nx, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
-        const float depth = (pt2x - pt1x) * nx + (pt2y - pt1y) * ny;
-        const float dst = 0.f;
-        dstV = depth < 1.f ? dst - 0.1f : dst;
-        dstD = 0.1f * max_ref(0.f, depth - 2.0f * 1.f);
-        aN1 = N.a1; aN2 = N.a2; cimN = N.cim; aF1 = F.a1; aF2 = F.a2; cimF = F.cim;
+        isl_refresh(q0, da0.x, da0.y, da0.z, da0.w, p1, p2);
+        if (has2) isl_refresh(q1, da1.x, da1.y, da1.z, da1.w, p1, p2);
         im1 = p1.x; ii1 = p1.y; im2 = p2.x; ii2 = p2.y;
     }
     __syncthreads();
     for (int i = tid; i < 4 * NB; i += T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
     const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
-    const float tx = -ny, ty = nx;
     __syncthreads();
     PHX_ISL_STAMP(2);
 
-    // PreStepJoints (ref: Solver.cpp:736-750), colour by colour
+    // PreStepJoints (ref: Solver.cpp:736-750), class by class: leader, then follower
     for (int c = 0; c < ncol; ++c) {
         if (col == c) {
-            if (!st1) {
-                float4 B = body_load(imp, l1);
-                B.x += (nx * im1) * accN; B.y += (ny * im1) * accN; B.z += (aN1 * ii1) * accN;
-                B.x += (tx * im1) * accF; B.y += (ty * im1) * accF; B.z += (aF1 * ii1) * accF;
-                body_store(imp, l1, B);
+            float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
+            isl_prestep(q0, B1, B2, im1, ii1, im2, ii2);
+            if (has2) {
+                if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }      // (the ablation rounds on every joint's store)
+                isl_prestep(q1, B1, B2, im1, ii1, im2, ii2);
             }
-            if (!st2) {
-                float4 B = body_load(imp, l2);
-                B.x += ((-nx) * im2) * accN; B.y += ((-ny) * im2) * accN; B.z += (aN2 * ii2) * accN;
-                B.x += ((-tx) * im2) * accF; B.y += ((-ty) * im2) * accF; B.z += (aF2 * ii2) * accF;
-                body_store(imp, l2, B);
-            }
+            if (!st1) body_store(imp, l1, B1);
+            if (!st2) body_store(imp, l2, B2);
         }
         __syncthreads();
     }
@@ -519,58 +647,42 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
             if (col == c) {
                 if (imp_on) {
                     float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-                    const bool p1 = st1 ? static_productive_lds(swi, l1, it, c) : (__float_as_int(B1.w) > it - 2);
-                    const bool p2 = st2 ? static_productive_lds(swi, l2, it, c) : (__float_as_int(B2.w) > it - 2);
-                    if (p1 || p2) {
-                        float dv = dstV;
-                        dv -= nx * B1.x; dv -= ny * B1.y; dv -= aN1 * B1.z;
-                        dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= aN2 * B2.z;
-                        float dn = dv * cimN;
-                        dn = max_ref(dn, -accN);
-                        B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (aN1 * ii1) * dn;
-                        B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (aN2 * ii2) * dn;
-                        accN += dn;
-                        float fv = 0.f;
-                        fv -= tx * B1.x; fv -= ty * B1.y; fv -= aF1 * B1.z;
-                        fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= aF2 * B2.z;
-                        float df = fv * cimF;
-                        const float force = accF + df;
-                        const float limit = accN * 0.3f;
-                        const float signed_limit = force < 0.f ? -limit : limit;
-                        const float adjusted = signed_limit - accF;
-                        if (fabsf(force) > limit) df = adjusted;
-                        accF += df;
-                        B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (aF1 * ii1) * df;
-                        B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (aF2 * ii2) * df;
-                        if (max_ref(fabsf(dn), fabsf(df)) > 1e-4f) {
-                            B1.w = __int_as_float(it); B2.w = __int_as_float(it);
-                            flag_imp[it & 1] = 1;
-                            if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                            if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
-                        }
+                    bool prod0 = false, prod1 = false;
+                    const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
+                    bool touched = isl_impulse<NB>(q0, B1, B2, im1, ii1, im2, ii2, st1, st2, swi, l1, l2, it, c, prod0);
+                    if (has2) {
+                        if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
+                        if (st1) B1 = S1;
+                        if (st2) B2 = S2;
+                        touched |= isl_impulse<NB>(q1, B1, B2, im1, ii1, im2, ii2, st1, st2, swi, l1, l2, it, c, prod1);
+                    }
+                    if (prod0 || prod1) {
+                        flag_imp[it & 1] = 1;
+                        if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
+                        if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+                    }
+                    if (touched) {
                         if (!st1) body_store(imp, l1, B1);
                         if (!st2) body_store(imp, l2, B2);
                     }
                 }
                 if (disp_on) {
                     float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
-                    const bool p1 = st1 ? static_productive_lds(swd, l1, it, c) : (__float_as_int(D1.w) > it - 2);
-                    const bool p2 = st2 ? static_productive_lds(swd, l2, it, c) : (__float_as_int(D2.w) > it - 2);
-                    if (p1 || p2) {
-                        float dv = dstD;
-                        dv -= nx * D1.x; dv -= ny * D1.y; dv -= aN1 * D1.z;
-                        dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= aN2 * D2.z;
-                        float di = dv * cimN;
-                        di = max_ref(di, -accD);
-                        D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (aN1 * ii1) * di;
-                        D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (aN2 * ii2) * di;
-                        accD += di;
-                        if (fabsf(di) > 1e-4f) {
-                            D1.w = __int_as_float(it); D2.w = __int_as_float(it);
-                            flag_disp[it & 1] = 1;
-                            if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
-                            if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
-                        }
+                    bool prod0 = false, prod1 = false;
+                    const float4 S1 = D1, S2 = D2;
+                    bool touched = isl_displace<NB>(q0, D1, D2, im1, ii1, im2, ii2, st1, st2, swd, l1, l2, it, c, prod0);
+                    if (has2) {
+                        if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
+                        if (st1) D1 = S1;
+                        if (st2) D2 = S2;
+                        touched |= isl_displace<NB>(q1, D1, D2, im1, ii1, im2, ii2, st1, st2, swd, l1, l2, it, c, prod1);
+                    }
+                    if (prod0 || prod1) {
+                        flag_disp[it & 1] = 1;
+                        if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
+                        if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
+                    }
+                    if (touched) {
                         if (!st1) body_store(disp, l1, D1);
                         if (!st2) body_store(disp, l2, D2);
                     }
@@ -596,9 +708,14 @@ __global__ void __launch_bounds__(T, 8) k_solve_islands(SolverView v, IslandView
     // never leave the registers
     if (*v.fingerprint != v.expected_fingerprint) return;
     if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
-        phx_contact_joint& out = joints[joint_id];
-        out.normal_accumulated_impulse = accN;
-        out.friction_accumulated_impulse = accF;
+        phx_contact_joint& out = joints[jid0];
+        out.normal_accumulated_impulse = q0.accN;
+        out.friction_accumulated_impulse = q0.accF;
+    }
+    if (has2) {
+        phx_contact_joint& out = joints[jid1];
+        out.normal_accumulated_impulse = q1.accN;
+        out.friction_accumulated_impulse = q1.accF;
     }
 #pragma unroll
     for (int k = 0; k < BI; ++k) {                         // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only

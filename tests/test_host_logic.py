@@ -26,29 +26,50 @@ def test_falling_scene_is_reproducible():
     assert (np.abs(a["px"][1:]) <= 500).all() and (a["py"][1:] >= 50).all() and (a["py"][1:] <= 1000).all()
 
 
+@pytest.mark.parametrize("ids", ["joint_index", "contact_point_index"])
 @pytest.mark.parametrize("name", list(SMALL_SCENES))
-def test_colour_schedule_invariants(built_lib, name):
+def test_colour_schedule_invariants(built_lib, name, ids):
+    """The schedule rule of csrc/schedule.h restated independently in Python: units (the two joints of a body pair whose ids
+    differ in the lowest bit), first fit over the units in priority order with two candidates, the choice per connected
+    component, and the layout of a class: leaders that have a follower, single leaders, followers in their leaders' order."""
     make, warm = SMALL_SCENES[name]
     bodies, _, joints = presolve_state(make(), warm)
     static = is_static(bodies)
-    order, offs = phyx_amd.schedule_colours(joints["body1"], joints["body2"], static)
     nj = len(joints)
+    pid = np.arange(nj, dtype=np.int32) if ids == "joint_index" else joints["contact_point_index"].astype(np.int32)
+    order, offs = phyx_amd.schedule_colours(joints["body1"], joints["body2"], static, None if ids == "joint_index" else pid)
     assert sorted(order.tolist()) == list(range(nj))                  # a permutation
     assert offs[0] == 0 and offs[-1] == nj and (np.diff(offs) > 0).all()
-    for c in range(len(offs) - 1):
-        sl = order[offs[c]:offs[c + 1]]
-        assert (np.diff(sl) > 0).all()                                # stable: joint order kept inside a colour
-        b = np.concatenate([joints["body1"][sl], joints["body2"][sl]])
-        b = b[static[b] == 0]
-        assert len(np.unique(b)) == len(b), "colour %d touches a dynamic body twice" % c
-    # the colouring rule itself (csrc/schedule.h), restated independently: two first-fit candidates in priority order —
-    # A = smallest free colour, B = two-ended — and every connected component keeps the one that gives it fewer colours
-    prio = np.array([phyx_amd.schedule_priority(j, j) for j in range(nj)], dtype=np.uint64)
-    assert len(np.unique(prio)) == nj and (prio > 0).all()
-    colour_of = np.zeros(nj, dtype=np.int64)
-    for c in range(len(offs) - 1):
-        colour_of[order[offs[c]:offs[c + 1]]] = c
     b1, b2 = joints["body1"].tolist(), joints["body2"].tolist()
+    # units
+    first = {}
+    for j in range(nj - 1, -1, -1):
+        first[int(pid[j])] = j
+    partner = [-1] * nj
+    for j in range(nj):
+        if first[int(pid[j])] != j:
+            continue
+        o = first.get(int(pid[j]) ^ 1, -1)
+        if o >= 0 and b1[o] == b1[j] and b2[o] == b2[j]:
+            partner[j] = o
+    follower = [partner[j] >= 0 and (int(pid[j]) & 1) == 1 for j in range(nj)]
+    assert sum(follower) > 0 or name == "falling600"
+    leaders = [j for j in range(nj) if not follower[j]]
+    class_of = np.zeros(nj, dtype=np.int64)
+    for c in range(len(offs) - 1):
+        sl = order[offs[c]:offs[c + 1]].tolist()
+        class_of[sl] = c
+        lead = [j for j in sl if not follower[j]]
+        with_f = [j for j in lead if partner[j] >= 0]
+        single = [j for j in lead if partner[j] < 0]
+        assert sl == sorted(with_f) + sorted(single) + [partner[j] for j in sorted(with_f)]      # the layout of a class
+        b = np.array([b1[j] for j in lead] + [b2[j] for j in lead])
+        b = b[static[b] == 0]
+        assert len(np.unique(b)) == len(b), "class %d: two units touch a dynamic body" % c
+    # the colouring rule: two first-fit candidates over the UNITS in priority order — A = smallest free colour, B = two-ended
+    # — and every connected component keeps the one that gives it fewer colours
+    prio = {j: phyx_amd.schedule_priority(int(pid[j]), j) for j in leaders}
+    assert len(set(prio.values())) == len(leaders) and min(prio.values()) > 0
     parent = list(range(len(bodies)))
 
     def find(x):
@@ -59,10 +80,10 @@ def test_colour_schedule_invariants(built_lib, name):
     for j in range(nj):
         if not static[b1[j]] and not static[b2[j]]:
             parent[find(b1[j])] = find(b2[j])
-    comp = [("s", j) if static[b1[j]] and static[b2[j]] else ("c", find(b2[j] if static[b1[j]] else b1[j])) for j in range(nj)]
-    degree = np.bincount(np.concatenate([joints["body1"], joints["body2"]]), minlength=len(bodies))
-    used_a, used_b, col_a, col_b, bad_b = {}, {}, [0] * nj, [0] * nj, set()
-    for j in sorted(range(nj), key=lambda j: -int(prio[j])):
+    comp = {j: ("s", j) if static[b1[j]] and static[b2[j]] else ("c", find(b2[j] if static[b1[j]] else b1[j])) for j in leaders}
+    degree = np.bincount(np.array([b1[j] for j in leaders] + [b2[j] for j in leaders]), minlength=len(bodies))      # units per body
+    used_a, used_b, col_a, col_b, bad_b = {}, {}, {}, {}, set()
+    for j in sorted(leaders, key=lambda j: -int(prio[j])):
         dyn = [b for b in (b1[j], b2[j]) if not static[b]]
         ma = 0
         mb = 0
@@ -90,19 +111,19 @@ def test_colour_schedule_invariants(built_lib, name):
         col_b[j] = cb
         for b in dyn:
             used_a[b] = used_a.get(b, 0) | 1 << ca
-    seen_a, seen_b = {}, {}
-    for j in range(nj):
+    seen_a, seen_b, size = {}, {}, {}
+    for j in leaders:
         seen_a.setdefault(comp[j], set()).add(col_a[j])
         seen_b.setdefault(comp[j], set()).add(col_b[j])
-    size = {}
-    for j in range(nj):
-        size[comp[j]] = size.get(comp[j], 0) + 1
-    for j in range(nj):
+        size[comp[j]] = size.get(comp[j], 0) + (2 if partner[j] >= 0 else 1)          # joints of the component
+    for j in leaders:
         use_b = comp[j] not in bad_b and size[comp[j]] <= 8192 and comp[j][0] == "c" and len(seen_b[comp[j]]) < len(seen_a[comp[j]])
         chosen, c = (seen_b[comp[j]], col_b[j]) if use_b else (seen_a[comp[j]], col_a[j])
-        assert colour_of[j] == sum(1 for x in chosen if x < c), "joint %d" % j
-    # and it never needs more colours than plain first-fit
-    assert len(offs) - 1 <= max(col_a) + 1
+        assert class_of[j] == sum(1 for x in chosen if x < c), "joint %d" % j
+        if partner[j] >= 0:
+            assert class_of[partner[j]] == class_of[j]
+    # and it never needs more classes than plain first-fit
+    assert len(offs) - 1 <= max(col_a.values()) + 1
 
 
 @pytest.mark.parametrize("name", list(SMALL_SCENES))
