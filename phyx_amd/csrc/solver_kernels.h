@@ -466,13 +466,14 @@ __device__ __forceinline__ void isl_prestep(const IslJoint& q, float4& B1, float
     B2.x += ((-tx) * im2) * q.accF; B2.y += ((-ty) * im2) * q.accF; B2.z += (q.aF2 * ii2) * q.accF;
 }
 
-// one impulse visit (ref: Solver.cpp:790-896); returns whether the joint was evaluated (not skipped), `productive` whether it moved
-template <int NB>
+// one impulse visit (ref: Solver.cpp:790-896); returns whether the joint was evaluated (not skipped), `productive` whether it moved.
+// sp1 / sp2: 'the static body was productive' (static_productive_lds) — the same for both joints of a unit: a class step
+// cannot change what it returns for that class (tags raised in it carry the class itself, which is not 'earlier').
 __device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
-                                            const unsigned (*sw)[NB], int l1, int l2, int it, int c, bool& productive)
+                                            bool sp1, bool sp2, int it, bool& productive)
 {
-    const bool p1 = st1 ? static_productive_lds(sw, l1, it, c) : (__float_as_int(B1.w) > it - 2);
-    const bool p2 = st2 ? static_productive_lds(sw, l2, it, c) : (__float_as_int(B2.w) > it - 2);
+    const bool p1 = st1 ? sp1 : (__float_as_int(B1.w) > it - 2);
+    const bool p2 = st2 ? sp2 : (__float_as_int(B2.w) > it - 2);
     productive = false;
     if (!(p1 || p2)) return false;
     const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
@@ -501,12 +502,11 @@ __device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2,
 }
 
 // one displacement visit (ref: Solver.cpp:960-1005)
-template <int NB>
 __device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
-                                             const unsigned (*sw)[NB], int l1, int l2, int it, int c, bool& productive)
+                                             bool sp1, bool sp2, int it, bool& productive)
 {
-    const bool p1 = st1 ? static_productive_lds(sw, l1, it, c) : (__float_as_int(D1.w) > it - 2);
-    const bool p2 = st2 ? static_productive_lds(sw, l2, it, c) : (__float_as_int(D2.w) > it - 2);
+    const bool p1 = st1 ? sp1 : (__float_as_int(D1.w) > it - 2);
+    const bool p2 = st2 ? sp2 : (__float_as_int(D2.w) > it - 2);
     productive = false;
     if (!(p1 || p2)) return false;
     const float nx = q.nx, ny = q.ny;
@@ -649,12 +649,13 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                     float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
                     bool prod0 = false, prod1 = false;
                     const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-                    bool touched = isl_impulse<NB>(q0, B1, B2, im1, ii1, im2, ii2, st1, st2, swi, l1, l2, it, c, prod0);
+                    const bool sp1 = st1 && static_productive_lds(swi, l1, it, c), sp2 = st2 && static_productive_lds(swi, l2, it, c);
+                    bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod0);
                     if (has2) {
                         if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
                         if (st1) B1 = S1;
                         if (st2) B2 = S2;
-                        touched |= isl_impulse<NB>(q1, B1, B2, im1, ii1, im2, ii2, st1, st2, swi, l1, l2, it, c, prod1);
+                        touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod1);
                     }
                     if (prod0 || prod1) {
                         flag_imp[it & 1] = 1;
@@ -670,12 +671,13 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                     float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
                     bool prod0 = false, prod1 = false;
                     const float4 S1 = D1, S2 = D2;
-                    bool touched = isl_displace<NB>(q0, D1, D2, im1, ii1, im2, ii2, st1, st2, swd, l1, l2, it, c, prod0);
+                    const bool sp1 = st1 && static_productive_lds(swd, l1, it, c), sp2 = st2 && static_productive_lds(swd, l2, it, c);
+                    bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod0);
                     if (has2) {
                         if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
                         if (st1) D1 = S1;
                         if (st2) D2 = S2;
-                        touched |= isl_displace<NB>(q1, D1, D2, im1, ii1, im2, ii2, st1, st2, swd, l1, l2, it, c, prod1);
+                        touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod1);
                     }
                     if (prod0 || prod1) {
                         flag_disp[it & 1] = 1;
