@@ -34,11 +34,12 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 SHADER_CLOCK_HZ = 2.4e9          # same guide: max clock; cycle figures below are seconds x this
 BYTES_IMPULSE_VISIT = 196        # algorithmic bytes per impulse joint-visit
 BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visit
-# Latency floor of one colour step of the island kernel: LDS read of the two bodies (issue -> use ~64 cycles),
-# the dependent fp32 chain of one joint update that strict operation order leaves (6 subtractions, multiply, max, 2-op body
-# update, 6 subtractions, multiply, add, compare + select, 2-op body update = ~26 dependent ops x ~4 cycles), the LDS
-# write-back (~13 cycles issue for 16 bytes) and one workgroup barrier (~40 cycles)
-COLOUR_STEP_FLOOR_CYCLES = 64 + 26 * 4 + 13 + 40
+# Latency floor of one class step of the island kernel: a lane sweeps the two joints of a unit on one LDS
+# read and one LDS write of the two bodies.  LDS read (issue -> use ~64 cycles), per joint the dependent fp32 chain of one
+# impulse update (normal: 6 subtractions, multiply, clamp, 2-op body update; friction the same: ~26 dependent ops x ~4
+# cycles), the LDS write-back (~13 cycles issue for 16 bytes) and one workgroup barrier (~128 cycles measured for an empty
+# step, tools/probe/colour_step.hip)
+COLOUR_STEP_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
 
 
 def pmc_traffic():
@@ -51,7 +52,7 @@ def pmc_traffic():
                 d = json.load(open(path))
                 out = {"file": "profiles/%s_pmc_traffic.json" % tag}
                 for name, k in d.get("kernels", {}).items():
-                    if "k_solve_islands<512" in name:
+                    if "k_solve_islands<" in name and "k_solve_islands" not in out:
                         out["k_solve_islands"] = k["hbm_bytes_per_launch_corrected"]
                     if "k_solve_colour<true, true>" in name:
                         out["k_solve_colour"] = k["hbm_bytes_per_launch_corrected"]
@@ -205,7 +206,7 @@ def main():
         kname = "k_solve_islands" if lds else "k_solve_colour"
         tbytes = traffic.get(kname)
         roof = {"bound": "hbm",
-                "kernel": "k_solve_islands<512,768> (one workgroup per island group, all sweeps in LDS)" if lds else "k_solve_colour<impulse,displacement>",
+                "kernel": "k_solve_islands<256,768> (one workgroup per island group, one lane per unit of two joints, all sweeps in LDS)" if lds else "k_solve_colour<impulse,displacement>",
                 "achieved": (tbytes / (launch_us * 1e-6) / 1e9) if tbytes else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (tbytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tbytes else None,
                 "traffic": tbytes, "traffic_source": traffic.get("file"),
@@ -222,7 +223,7 @@ def main():
             steps_crit = ncol_max * (st.impulse_iterations + 1)
             model = {"colour_steps_on_critical_path": steps_crit, "colours_of_the_slowest_group": ncol_max,
                      "floor_cycles_per_colour_step": COLOUR_STEP_FLOOR_CYCLES,
-                     "floor_what": "LDS read 64 + 26 dependent fp32 ops x 4 + LDS write 13 + barrier 40 cycles"}
+                     "floor_what": "class step = the two joints of a unit: LDS read 64 + 2 x 26 dependent fp32 ops x 4 + LDS write 13 + barrier 128 cycles"}
             if phases:
                 sweep_us = max(launch_us - phases["setup_prestep_writeback_us"], 0.0)
                 cyc = sweep_us * 1e-6 * SHADER_CLOCK_HZ / max(ncol_max * st.impulse_iterations, 1)

@@ -258,16 +258,18 @@ __device__ __forceinline__ HbmJoint hbm_load(const SolverView& v, int s, bool im
 
 // one joint of a unit on the body state the lane holds in registers (ref: Solver.cpp:790-896 impulses, :960-1005 displacement)
 __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& q, int colour, int iter, bool imp_on, bool disp_on,
-                                          float4& B1, float4& B2, float4& D1, float4& D2, bool st1, bool st2, int ss,
+                                          float4& B1, float4& B2, float4& D1, float4& D2, bool st1, bool st2, int ss, bool sp_imp, bool sp_disp,
                                           bool& any_imp, bool& any_disp, bool& tag_imp, bool& tag_disp, bool& dirty_imp, bool& dirty_disp)
 {
+    // sp_imp / sp_disp: 'the unit's static body was productive' (static_productive) — read once per unit: a class cannot
+    // change what the test returns for that class (tags raised in it carry the class itself, which is not 'earlier')
     const float4 a = q.a, f = q.f, c = q.c;
     const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(q.k.x);
     const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
     if (imp_on) {
         // ref: Solver.cpp:790-798
-        const bool p1 = st1 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B1.w) > iter - 2);
-        const bool p2 = st2 ? static_productive(v.sw_imp, v.nstatic, ss, iter, colour) : (__float_as_int(B2.w) > iter - 2);
+        const bool p1 = st1 ? sp_imp : (__float_as_int(B1.w) > iter - 2);
+        const bool p2 = st2 ? sp_imp : (__float_as_int(B2.w) > iter - 2);
         if (p1 || p2) {
             float2 acc = q.acc;
             // normal limiter (ref: :833-858)
@@ -303,8 +305,8 @@ __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& 
         }
     }
     if (disp_on) {
-        const bool p1 = st1 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D1.w) > iter - 2);
-        const bool p2 = st2 ? static_productive(v.sw_disp, v.nstatic, ss, iter, colour) : (__float_as_int(D2.w) > iter - 2);
+        const bool p1 = st1 ? sp_disp : (__float_as_int(D1.w) > iter - 2);
+        const bool p2 = st2 ? sp_disp : (__float_as_int(D2.w) > iter - 2);
         if (p1 || p2) {
             float2 d = q.d;
             float dv = d.x;                                                      // ref: :973-981
@@ -353,11 +355,13 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
         const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
         const float4 S1 = B1, S2 = B2, T1 = D1, T2 = D2;
         bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
-        solve_one(v, s0, q0, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        const bool sp_imp = imp_on && (st1 || st2) && static_productive(v.sw_imp, v.nstatic, ss, iter, colour);
+        const bool sp_disp = disp_on && (st1 || st2) && static_productive(v.sw_disp, v.nstatic, ss, iter, colour);
+        solve_one(v, s0, q0, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
         if (has2) {                                    // a static body's record is never stored: the follower must see it untouched
             if (st1) { B1 = S1; D1 = T1; }
             if (st2) { B2 = S2; D2 = T2; }
-            solve_one(v, s1, q1, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+            solve_one(v, s1, q1, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
         }
         if (dirty_imp) { if (!st1) v.sb_imp[b1] = B1; if (!st2) v.sb_imp[b2] = B2; }
         if (dirty_disp) { if (!st1) v.sb_disp[b1] = D1; if (!st2) v.sb_disp[b2] = D2; }
