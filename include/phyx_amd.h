@@ -46,7 +46,7 @@ enum { PHX_ISLAND_SINGLE = 0, PHX_ISLAND_MULTIPLE = 1, PHX_ISLAND_SINGLE_SLOPPY 
 /* ref: src/Configuration.h:20-23.  On this backend the wavefront is the SIMD unit, so solve_mode
  * does not select a code path: every mode runs per-joint (scalar, N=1) skip semantics in the
  * device's own colour order.  island_mode picks the schedule:
- *   Single                      one coupled system (one group), solved colour by colour out of HBM;
+ *   Single                      one coupled system (one group), solved class by class out of HBM;
  *   Multiple, Single Sloppy,    the island-aware schedule: connected components (GatherIslands semantics) binned
  *   Multiple Sloppy             into workgroup-sized groups solved out of LDS, each with its own early exit and its
  *                               own copy of the static bodies' tags; components too big for a workgroup go to one
@@ -188,9 +188,13 @@ typedef struct {
 } phx_solve_stats;
 int phx_solver_get_stats(phx_solver* s, phx_solve_stats* out);
 
-/* The schedule the device used: order[k] = index of the joint occupying slot k; colour c owns slots
+/* The schedule the device used: order[k] = index of the joint occupying slot k; colour (class) c owns slots
  * [colour_offsets[c], colour_offsets[c+1]).  Sweeping the slots front to back with the reference's
- * scalar loop reproduces the device result bit for bit (tests/ feeds this to the oracle). */
+ * scalar loop reproduces the device result bit for bit (tests/ feeds this to the oracle).
+ * A class is a set of UNITS that share no dynamic body; a unit is the one or two joints of a body pair (the
+ * two contact points of a manifold).  Its slots are laid out as: the leaders that have a follower (joint
+ * order), the single leaders (joint order), then the followers in their leaders' order — a lane of the
+ * device sweeps a leader and then its follower on one read and one write of the two bodies. */
 int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap,
                             int32_t* colour_offsets, int32_t offsets_cap, int32_t* colour_count);
 /* Groups of the schedule: group g owns slots [group_offsets[g], group_offsets[g+1]) and is an independent
@@ -207,11 +211,15 @@ int phx_solver_get_refreshed(phx_solver* s, int32_t joint_index, float out30[30]
 
 /* Host-only schedule builders (no device needed) — exposed so the ordering logic can be checked on
  * its own.  phx_schedule_colours is this backend's counterpart of Solver::PrepareIndices
- * (ref: src/Solver.cpp:217-273): it partitions the joints into colour classes of joints that share
- * no dynamic body (is_static[b] != 0 exempts body b): joints take the first free colour in order of
- * DECREASING phx_schedule_priority(priority_ids[j], j) — a fixed pseudo-random order, chosen because
- * the device reaches the same colours with ~log n Jones-Plassmann rounds, whereas joint-index order
- * needs one round per box of a stacked column; inside a colour the slots keep joint-index order.
+ * (ref: src/Solver.cpp:217-273).  Joints are first paired into units: two joints whose priority ids
+ * differ in the lowest bit only (contact points 2m and 2m + 1 of manifold m) and whose bodies are the
+ * same form a unit, led by the even id; every other joint is a unit of its own.  The units are
+ * partitioned into classes that share no dynamic body (is_static[b] != 0 exempts body b): they take
+ * their class first-fit in order of DECREASING phx_schedule_priority(priority_ids[j], j) of their
+ * leader j — a fixed pseudo-random order, chosen because the device reaches the same classes in a few
+ * dozen parallel rounds, whereas joint-index order needs one round per box of a stacked column — with
+ * two candidates per connected component (smallest free class / two-ended) of which the component keeps
+ * the one that needs fewer classes.  The layout of a class is described at phx_solver_get_schedule.
  * priority_ids may be NULL (the joint index is used); the solver passes each joint's
  * contactPointIndex, which survives compaction of the joint list (island sharding).
  * phx_schedule_islands follows Solver::GatherIslands (ref: src/Solver.cpp:285-454):

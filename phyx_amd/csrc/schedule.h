@@ -30,20 +30,29 @@ __host__ __device__ inline unsigned long long colour_priority(unsigned id, unsig
     return (((unsigned long long)x << 32) | j) + 1ull;
 }
 
-// Two first-fit candidates, same priority order, same Jones-Plassmann rounds (a joint's turn depends on the priorities only,
+// UNITS.  The joints of one body pair (the two contact points of a manifold) conflict with each other and with nobody
+// else more than either does alone, so they are scheduled as one unit: two joints whose priority ids differ in the lowest bit
+// only (contact points 2m and 2m + 1), whose bodies are the same and which are each the smallest-index joint carrying their
+// id form a unit LED by the even id; every other joint is a unit of its own.  Units — not joints — are coloured (a unit's
+// priority is its leader's), so a 'colour' is a CLASS of units that share no dynamic body, and its slots are: the leaders
+// that have a follower (joint order), the single leaders (joint order), the followers in their leaders' order.  Swept
+// front to back that is: every leader, then every follower — which a lane reproduces by sweeping its leader and then its
+// follower on one read and one write of the two bodies.  Half the barriers (LDS groups) / kernel launches (HBM group) per
+// joint; the static bodies' tags are class-synchronous (solver_kernels.h).
+// Two first-fit candidates, same priority order, same dependency rounds (a unit's turn depends on the priorities only,
 // not on the colours):
-//   A  the smallest colour free on the joint's dynamic bodies;
-//   B  'two-ended': a joint whose lower body index is odd takes the LARGEST free colour below K = the larger joint count of its
-//      dynamic bodies (the smallest free colour >= K if there is none), every other joint the smallest free colour.  On layered
-//      structures (a stack: consecutive body indices alternate parity along a column) the two halves of a body's joints are
-//      drawn from opposite ends and never collide, which reaches the optimum of max-degree colours where A needs up to 1.5x as
-//      many; on irregular piles B is a little worse than A.  B is defined for at most 64 colours.
+//   A  the smallest class free on the unit's dynamic bodies;
+//   B  'two-ended': a unit whose lower body index is odd takes the LARGEST free class below K = the larger unit count of its
+//      dynamic bodies (the smallest free class >= K if there is none), every other unit the smallest free class.  On layered
+//      structures (a stack: consecutive body indices alternate parity along a column) the two halves of a body's units are
+//      drawn from opposite ends and never collide, which reaches the optimum of max-degree classes where A needs up to 1.5x as
+//      many; on irregular piles B is a little worse than A.  B is defined for at most 64 classes.
 // B is only attempted for components of at most COLOUR_B_MAX_JOINTS joints: the layered structures it helps are small, and
 // on a large irregular island it would double the colouring's memory traffic to lose anyway.
-// Every CONNECTED COMPONENT keeps the candidate that gives IT fewer colours (A on a tie) and renumbers its colours densely in
-// increasing order.  The choice is per component, so an island's colours — hence its results — do not depend on which other
-// islands share its group, on the workgroup shape or on the island mode.  A colour is one barrier-separated step (LDS groups)
-// or one kernel launch (HBM group) of every sweep, so the largest colour count sets the solve time.
+// Every CONNECTED COMPONENT keeps the candidate that gives IT fewer classes (A on a tie) and renumbers its classes densely in
+// increasing order.  The choice is per component, so an island's classes — hence its results — do not depend on which other
+// islands share its group, on the workgroup shape or on the island mode.  A class is one barrier-separated step (LDS groups)
+// or one kernel launch (HBM group) of every sweep, so the largest class count sets the solve time.
 constexpr int COLOUR_B_MAX_JOINTS = 8192;
 
 __host__ __device__ inline int colour_pick_two_ended(unsigned long long used_mask, int k_limit, bool from_top)
