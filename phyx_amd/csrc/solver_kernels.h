@@ -741,6 +741,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     if (TRACE && iv.wave_trace && (tid & 63) == 0) {
         unsigned long long* w = iv.wave_trace + ((size_t)group * (T / 64) + (tid >> 6)) * 8;
         w[0] = tw_work; w[1] = tw_bar; w[2] = tw_idle; w[3] = ((unsigned long long)tw_nwork << 32) | tw_nidle; w[4] = tw_work_big; w[5] = tw_nbig;
+        w[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID: wave, SIMD, pipe, CU, SH, SE ... (tools/simd_map.py)
+        w[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF;  // XCC id
     }
     if (TRACE) {
         __builtin_amdgcn_s_waitcnt(0);         // the stores above have left the wave
