@@ -52,7 +52,7 @@ def pmc_traffic():
                 d = json.load(open(path))
                 out = {"file": "profiles/%s_pmc_traffic.json" % tag}
                 for name, k in d.get("kernels", {}).items():
-                    if "k_solve_islands<" in name and "k_solve_islands" not in out:
+                    if "k_solve_islands<256" in name:
                         out["k_solve_islands"] = k["hbm_bytes_per_launch_corrected"]
                     if "k_solve_colour<true, true>" in name:
                         out["k_solve_colour"] = k["hbm_bytes_per_launch_corrected"]
