@@ -27,13 +27,17 @@ def test_falling_scene_is_reproducible():
 
 
 @pytest.mark.parametrize("ids", ["joint_index", "contact_point_index"])
-@pytest.mark.parametrize("name", list(SMALL_SCENES))
+@pytest.mark.parametrize("name", list(SMALL_SCENES) + ["synthetic_units_and_near_misses"])
 def test_colour_schedule_invariants(built_lib, name, ids):
     """The schedule rule of csrc/schedule.h restated independently in Python: units (the two joints of a body pair whose ids
     differ in the lowest bit), first fit over the units in priority order with two candidates, the choice per connected
     component, and the layout of a class: leaders that have a follower, single leaders, followers in their leaders' order."""
-    make, warm = SMALL_SCENES[name]
-    bodies, _, joints = presolve_state(make(), warm)
+    if name in SMALL_SCENES:
+        make, warm = SMALL_SCENES[name]
+        bodies, _, joints = presolve_state(make(), warm)
+    else:                                                            # couples on random body pairs + the near misses that must not pair
+        from test_solver_gpu import _random_state
+        bodies, _, joints = _random_state(np.random.default_rng(6), 300, 900, 0.1, units=True)
     static = is_static(bodies)
     nj = len(joints)
     pid = np.arange(nj, dtype=np.int32) if ids == "joint_index" else joints["contact_point_index"].astype(np.int32)

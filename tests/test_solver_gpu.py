@@ -351,7 +351,7 @@ def test_bench_step_hook(solver):
     assert again.joint_visits * 5 == plain.joint_visits * 3
 
 
-def _random_state(rng, nb, nj, static_frac, dup_ids=False, hub=0):
+def _random_state(rng, nb, nj, static_frac, dup_ids=False, hub=0, units=False):
     """A synthetic solver input with an arbitrary contact graph: random pairs over nb bodies (a few static), plausible
     small offsets and unit normals, so that the arithmetic stays finite while the topology is nothing like a stack."""
     bodies = np.zeros(nb, dtype=phyx_amd.rigid_body_dtype)
@@ -380,6 +380,24 @@ def _random_state(rng, nb, nj, static_frac, dup_ids=False, hub=0):
     joints["body1"], joints["body2"] = b1, b2
     joints["contact_point_index"] = rng.permutation(nj) if not dup_ids else rng.integers(0, max(nj // 4, 1), nj)
     joints["normal_acc"] = rng.uniform(0, 0.1, nj)
+    if units:
+        # couples of joints on one body pair with contact points 2m / 2m+1 (units, csrc/schedule.h), scattered over the joint
+        # array — and the near misses that must NOT pair: the follower's bodies swapped, a third joint claiming the odd id, a
+        # lone even id, an odd id whose even partner sits on other bodies
+        half = nj // 2
+        perm = rng.permutation(nj)
+        lead, foll = perm[:half], perm[half:2 * half]
+        joints["body1"][foll], joints["body2"][foll] = joints["body1"][lead], joints["body2"][lead]
+        joints["contact_point_index"][lead] = 2 * np.arange(half)
+        joints["contact_point_index"][foll] = 2 * np.arange(half) + 1
+        k = half // 10
+        swap = foll[:k]
+        joints["body1"][swap], joints["body2"][swap] = joints["body2"][swap].copy(), joints["body1"][swap].copy()
+        dup = foll[k:2 * k]
+        joints["contact_point_index"][dup] = joints["contact_point_index"][foll[2 * k:3 * k]]          # two joints carry one odd id
+        other = foll[3 * k:4 * k]
+        joints["body2"][other] = (joints["body2"][other] + 1) % nb
+        joints["body2"][other] = np.where(joints["body2"][other] == joints["body1"][other], (joints["body2"][other] + 1) % nb, joints["body2"][other])
     return bodies, cps, joints
 
 
@@ -413,16 +431,17 @@ def test_pathological_priority_chain_falls_back_to_the_host_builder(oracle, buil
     assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
 
 
-@pytest.mark.parametrize("case", ["sparse", "dense", "dup_ids", "mostly_static", "hub_over_64_colours"])
+@pytest.mark.parametrize("case", ["sparse", "dense", "dup_ids", "mostly_static", "hub_over_64_colours", "units_and_near_misses"])
 def test_random_contact_graphs_both_builders_and_oracle(oracle, built_lib, case):
     """Arbitrary contact graphs (not stacks): the device builder must reproduce the host builder's schedule — including
     duplicated priority ids (ties broken by joint index) and a hub that needs more than 64 colours (device falls back to
     the host builder) — and the solve must match the oracle's replay of that schedule bit for bit."""
     import os
-    rng = np.random.default_rng({"sparse": 1, "dense": 2, "dup_ids": 3, "mostly_static": 4, "hub_over_64_colours": 5}[case])
+    rng = np.random.default_rng({"sparse": 1, "dense": 2, "dup_ids": 3, "mostly_static": 4, "hub_over_64_colours": 5, "units_and_near_misses": 6}[case])
     nb, nj, sf, dup, hub = {"sparse": (4000, 3000, 0.05, False, 0), "dense": (600, 6000, 0.05, False, 0), "dup_ids": (2000, 5000, 0.1, True, 0),
-                            "mostly_static": (3000, 4000, 0.7, False, 0), "hub_over_64_colours": (1500, 2500, 0.05, False, 90)}[case]
-    state = _random_state(rng, nb, nj, sf, dup, hub)
+                            "mostly_static": (3000, 4000, 0.7, False, 0), "hub_over_64_colours": (1500, 2500, 0.05, False, 90),
+                            "units_and_near_misses": (3000, 6000, 0.1, False, 0)}[case]
+    state = _random_state(rng, nb, nj, sf, dup, hub, units=case == "units_and_near_misses")
     os.environ["PHX_SCHEDULE_BUILDER"] = "host"
     try:
         host_solver = phyx_amd.Solver(0)
