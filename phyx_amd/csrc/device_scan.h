@@ -31,6 +31,44 @@ __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsign
     return before + x - v;
 }
 
+// ---- where the scanned words come from ------------------------------------------------------------------------
+// The scan kernels take a LOADER: `ScanInPlace` reads the words from the array they are scanned into; any other loader
+// computes word i on the fly (`unsigned operator()(int i) const`, called exactly once per i) — the flag / count kernel that
+// would otherwise run in front of the scan as a dispatch of its own (3-5 us each at the dispatch floor).
+struct ScanInPlace { static constexpr bool in_place = true; __device__ unsigned operator()(int) const { return 0u; } };
+
+template <typename Load>
+__device__ __forceinline__ uint4 scan_load4(const Load& load, const unsigned* __restrict__ data, int base, int count)
+{
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (Load::in_place) {
+        if ((reinterpret_cast<uintptr_t>(data) & 15u) == 0 && base + 3 < count) v = *reinterpret_cast<const uint4*>(data + base);
+        else {
+            if (base < count) v.x = data[base];
+            if (base + 1 < count) v.y = data[base + 1];
+            if (base + 2 < count) v.z = data[base + 2];
+            if (base + 3 < count) v.w = data[base + 3];
+        }
+    } else {
+        if (base < count) v.x = load(base);
+        if (base + 1 < count) v.y = load(base + 1);
+        if (base + 2 < count) v.z = load(base + 2);
+        if (base + 3 < count) v.w = load(base + 3);
+    }
+    return v;
+}
+
+__device__ __forceinline__ void scan_store4(unsigned* __restrict__ data, int base, int count, uint4 o)
+{
+    if ((reinterpret_cast<uintptr_t>(data) & 15u) == 0 && base + 3 < count) *reinterpret_cast<uint4*>(data + base) = o;
+    else {
+        if (base < count) data[base] = o.x;
+        if (base + 1 < count) data[base + 1] = o.y;
+        if (base + 2 < count) data[base + 2] = o.z;
+        if (base + 3 < count) data[base + 3] = o.w;
+    }
+}
+
 // ---- single-pass scan with decoupled look-back ------------------------------------------------------------
 // state[0] = ticket counter (tiles are taken in ticket order, so a tile's predecessors are always running or done: the
 // look-back cannot wait for a workgroup that was never scheduled); state[1 + t] = status of tile t, ONE 64-bit word
@@ -40,7 +78,8 @@ __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsign
 constexpr unsigned SCAN_AGGREGATE = 1u, SCAN_PREFIX = 2u;
 constexpr int SCAN_SPIN_LIMIT = 1 << 22;                 // ~seconds; then trap: a HIP error the host reports instead of a hung device
 
-static __global__ void __launch_bounds__(1024) k_scan_lookback(unsigned* __restrict__ data, int count, unsigned long long* __restrict__ state, unsigned epoch,
+template <typename Load>
+static __global__ void __launch_bounds__(1024) k_scan_lookback(Load load, unsigned* __restrict__ data, int count, unsigned long long* __restrict__ state, unsigned epoch,
                                                                unsigned* __restrict__ grand_total)
 {
     __shared__ unsigned lds[16];
@@ -51,15 +90,7 @@ static __global__ void __launch_bounds__(1024) k_scan_lookback(unsigned* __restr
     __syncthreads();
     const int tile = (int)s_tile;
     const int base = tile * SCAN_TILE + threadIdx.x * 4;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    const bool vec = (reinterpret_cast<uintptr_t>(data) & 15u) == 0 && base + 3 < count;
-    if (vec) v = *reinterpret_cast<const uint4*>(data + base);
-    else {
-        if (base < count) v.x = data[base];
-        if (base + 1 < count) v.y = data[base + 1];
-        if (base + 2 < count) v.z = data[base + 2];
-        if (base + 3 < count) v.w = data[base + 3];
-    }
+    const uint4 v = scan_load4(load, data, base, count);
     const unsigned run = block_exclusive_scan_1024(v.x + v.y + v.z + v.w, lds, nullptr);
     const unsigned total = lds[15];                        // (stable: nothing writes lds[] below)
     unsigned long long* status = state + 1;
@@ -103,13 +134,7 @@ static __global__ void __launch_bounds__(1024) k_scan_lookback(unsigned* __restr
     __syncthreads();
     const unsigned r = s_prefix + run;
     const uint4 o = make_uint4(r, r + v.x, r + v.x + v.y, r + v.x + v.y + v.z);
-    if (vec) *reinterpret_cast<uint4*>(data + base) = o;
-    else {
-        if (base < count) data[base] = o.x;
-        if (base + 1 < count) data[base + 1] = o.y;
-        if (base + 2 < count) data[base + 2] = o.z;
-        if (base + 3 < count) data[base + 3] = o.w;
-    }
+    scan_store4(data, base, count, o);
     if (grand_total && tile == tiles - 1 && threadIdx.x == 0) *grand_total = s_prefix + total;
 }
 
@@ -117,7 +142,8 @@ static __global__ void __launch_bounds__(1024) k_scan_lookback(unsigned* __restr
 // one workgroup walks them tile by tile with a running carry — one launch instead of three.
 constexpr int SCAN_SINGLE_MAX = 8 * SCAN_TILE;      // 32 words per lane
 
-static __global__ void __launch_bounds__(1024) k_scan_single(unsigned* __restrict__ data, int count, unsigned* __restrict__ grand_total)
+template <typename Load>
+static __global__ void __launch_bounds__(1024) k_scan_single(Load load, unsigned* __restrict__ data, int count, unsigned* __restrict__ grand_total)
 {
     // word i belongs to tile i / 4096, lane (i % 4096) / 4: every lane reads one 16-byte vector per tile (coalesced), all
     // tiles' loads in flight together; the tiles' block scans run side by side on one pair of barriers
@@ -130,15 +156,7 @@ static __global__ void __launch_bounds__(1024) k_scan_single(unsigned* __restric
 #pragma unroll
     for (int t = 0; t < TILES_MAX; ++t) {
         const int base = t * SCAN_TILE + threadIdx.x * 4;
-        v[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (t < tiles) {
-            if (base + 3 < count) v[t] = *reinterpret_cast<const uint4*>(data + base);
-            else {
-                if (base < count) v[t].x = data[base];
-                if (base + 1 < count) v[t].y = data[base + 1];
-                if (base + 2 < count) v[t].z = data[base + 2];
-            }
-        }
+        v[t] = t < tiles ? scan_load4(load, data, base, count) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int t = 0; t < TILES_MAX; ++t) {
@@ -158,31 +176,33 @@ static __global__ void __launch_bounds__(1024) k_scan_single(unsigned* __restric
         unsigned run = carry + before + incl[t] - (v[t].x + v[t].y + v[t].z + v[t].w);
         const int base = t * SCAN_TILE + threadIdx.x * 4;
         const uint4 o = make_uint4(run, run + v[t].x, run + v[t].x + v[t].y, run + v[t].x + v[t].y + v[t].z);
-        if (base + 3 < count) *reinterpret_cast<uint4*>(data + base) = o;
-        else {
-            if (base < count) data[base] = o.x;
-            if (base + 1 < count) data[base + 1] = o.y;
-            if (base + 2 < count) data[base + 2] = o.z;
-        }
+        scan_store4(data, base, count, o);
         carry += total;
     }
     if (grand_total && threadIdx.x == 0) *grand_total = carry;
 }
 
-// total_out (device pointer, may be null) receives the sum.
-static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, ScanScratch& scratch, hipStream_t stream)
+// total_out (device pointer, may be null) receives the sum.  `load` computes the words (see the loaders above); the exclusive
+// prefix sums land in data[0 .. count).
+template <typename Load>
+static inline int device_exclusive_scan_of(Load load, unsigned* data, int count, unsigned* total_out, ScanScratch& scratch, hipStream_t stream)
 {
     if (count <= 0) { if (total_out) PHX_HIP(hipMemsetAsync(total_out, 0, sizeof(unsigned), stream)); return PHX_OK; }
-    if (count <= SCAN_SINGLE_MAX && (reinterpret_cast<uintptr_t>(data) & 15u) == 0) {
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, data, count, total_out);
+    if (count <= SCAN_SINGLE_MAX) {
+        hipLaunchKernelGGL((k_scan_single<Load>), dim3(1), dim3(1024), 0, stream, load, data, count, total_out);
         PHX_HIP(hipGetLastError());
         return PHX_OK;
     }
     const int tiles = div_up(count, SCAN_TILE);
     PHX_TRY(scratch.prepare(tiles, stream));
-    hipLaunchKernelGGL(k_scan_lookback, dim3(tiles), dim3(1024), 0, stream, data, count, scratch.state.p, scratch.epoch, total_out);
+    hipLaunchKernelGGL((k_scan_lookback<Load>), dim3(tiles), dim3(1024), 0, stream, load, data, count, scratch.state.p, scratch.epoch, total_out);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
+}
+
+static inline int device_exclusive_scan(unsigned* data, int count, unsigned* total_out, ScanScratch& scratch, hipStream_t stream)
+{
+    return device_exclusive_scan_of(ScanInPlace{}, data, count, total_out, scratch, stream);
 }
 
 } // namespace phx

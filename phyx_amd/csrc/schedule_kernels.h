@@ -58,15 +58,17 @@ static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb,
     }
 }
 
-// (also zeroes the per-component joint counters that k_joint_components fills next: nb + 1 words)
-static __global__ void __launch_bounds__(256) k_cc_root_flags(const int* __restrict__ parent, int nb, unsigned* __restrict__ flags, unsigned* __restrict__ comp_size,
-                                                              unsigned* __restrict__ comp_units)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) {
-        if (i < nb) flags[i] = parent[i] == i ? 1u : 0u;
+// loader of the 'roots before body i' scan (device_scan.h): 1 for every component root; also zeroes the per-component joint
+// and unit counters that k_joint_components fills next (nb + 1 words)
+struct RootFlagLoad {
+    static constexpr bool in_place = false;
+    const int* parent; int nb; unsigned* comp_size; unsigned* comp_units;
+    __device__ unsigned operator()(int i) const
+    {
         comp_size[i] = 0u; comp_units[i] = 0u;
+        return (i < nb && parent[i] == i) ? 1u : 0u;
     }
-}
+};
 
 // joint -> component number (-1 if both bodies are static), and joints and units (schedule.h) per component.
 // The counts are accumulated in a per-workgroup LDS hash table (every lane inserts its own joint: LDS atomics on distinct

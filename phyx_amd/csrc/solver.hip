@@ -331,8 +331,8 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
             hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
             hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == 0 ? sb_small_.p : (int*)nullptr);
         }
-        hipLaunchKernelGGL(k_cc_root_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const int*)cc_parent_.p, nb, cc_flags_.p, comp_size_.p, comp_units_.p);
-        PHX_TRY(device_exclusive_scan(cc_flags_.p, nb, reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
+        PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)cc_parent_.p, nb, comp_size_.p, comp_units_.p}, cc_flags_.p, nb + 1,
+                                         reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
                            (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip

@@ -70,7 +70,8 @@ private:
     DevBuf<phx_manifold> d_manifolds_;
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
-    DevBuf<unsigned> flags_, dead_flags_, counters_;
+    DevBuf<unsigned> flags_, dead_flags_, counters_, joint_seen_;      // joint_seen_[j] == joint_epoch_: a contact point re-attached joint j this step
+    unsigned joint_epoch_ = 0;
     ScanScratch scan_tiles_;     // counters_: [0] dead/new total, [1] dropped points
     Readback rb_;
     bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
@@ -83,7 +84,7 @@ World::~World()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
-    flags_.release(); dead_flags_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
+    flags_.release(); dead_flags_.release(); joint_seen_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
     // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
 
@@ -207,19 +208,18 @@ int World::refresh_contact_joints()                                         // r
 {
     PHX_TRY(scratch_for(std::max(nm, nj + 2 * nm)));
     PHX_TRY(dead_flags_.reserve((size_t)nj + 2));
-    if (nj) hipLaunchKernelGGL(k_joints_reset, dim3(wgrid(nj)), dim3(256), 0, stream_, d_joints_.p, nj);
-    // One host round trip for both counts.  A joint is dead iff no contact point re-attached it (k_joints_match), which is
+    const size_t seen_cap = joint_seen_.cap;
+    PHX_TRY(joint_seen_.reserve((size_t)nj + 2));
+    if (joint_seen_.cap != seen_cap || ++joint_epoch_ == 0) {               // new (uninitialised) table, or the epoch wrapped: stale stamps could alias
+        PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
+        joint_epoch_ = 1;
+    }
+    // One host round trip for both counts.  A joint is dead iff no contact point re-attached it (the match), which is
     // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
     unsigned host[2] = {0, 0};                                              // [0] new joints, [1] dead joints
-    if (nm) {
-        hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
-                           d_joints_.p, flags_.p);
-        PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
-    }
-    if (nj) {
-        hipLaunchKernelGGL(k_joints_flag_dead, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, dead_flags_.p);
-        PHX_TRY(device_exclusive_scan(dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
-    }
+    if (nm) PHX_TRY(device_exclusive_scan_of(JointMatchLoad{(const phx_manifold*)d_manifolds_.p, (const phx_contact_point*)d_cps_.p, d_joints_.p, joint_seen_.p, joint_epoch_},
+                                             flags_.p, nm, counters_.p, scan_tiles_, stream_));
+    if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_}, dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
     if (nm || nj) {                                                         // counters_[0], [1]: adjacent words, one copy
         PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
         PHX_TRY(rb_.wait(stream_));

@@ -127,26 +127,33 @@ static __global__ void __launch_bounds__(256) k_pack_manifolds(phx_manifold* __r
 }
 
 // ---- RefreshContactJoints (ref: World.cpp:72-149) -----------------------------------------------------------
-static __global__ void __launch_bounds__(256) k_joints_reset(phx_contact_joint* __restrict__ joints, int nj)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) joints[i].contact_point_index = -1;
-}
-
-// Match, pass 1: matched points re-attach their joint; count the points that need a new joint
-static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold* __restrict__ manifolds, int nm, const phx_contact_point* __restrict__ cps,
-                                                             phx_contact_joint* __restrict__ joints, unsigned* __restrict__ new_count)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+// The reference resets every joint's contact point, lets the live points re-attach theirs and deletes what stayed reset.
+// Here a joint is alive iff its `seen` stamp carries this step's epoch (no reset pass), and the two counting passes are the
+// LOADERS of their scans (device_scan.h) instead of kernels of their own.
+// Match, pass 1 = loader of the 'new joints before manifold i' scan: matched points re-attach their joint and stamp it; the
+// word is the number of points that need a new joint.
+struct JointMatchLoad {
+    static constexpr bool in_place = false;
+    const phx_manifold* manifolds; const phx_contact_point* cps; phx_contact_joint* joints; unsigned* seen; unsigned epoch;
+    __device__ unsigned operator()(int i) const
+    {
         const phx_manifold m = manifolds[i];
         unsigned fresh = 0;
         for (int k = 0; k < m.point_count; ++k) {
             const int si = cps[m.point_index + k].solver_index;
             if (si < 0) ++fresh;
-            else joints[si].contact_point_index = m.point_index + k;
+            else { joints[si].contact_point_index = m.point_index + k; seen[si] = epoch; }
         }
-        new_count[i] = fresh;
+        return fresh;
     }
-}
+};
+
+// loader of the 'dead joints before joint i' scan (queued behind the match)
+struct JointDeadLoad {
+    static constexpr bool in_place = false;
+    const unsigned* seen; unsigned epoch;
+    __device__ unsigned operator()(int i) const { return seen[i] != epoch ? 1u : 0u; }
+};
 
 // Match, pass 2: new joints appended in manifold order, then point order (ref: World.cpp:108-114)
 static __global__ void __launch_bounds__(256) k_joints_create(const phx_manifold* __restrict__ manifolds, int nm, phx_contact_point* __restrict__ cps,
@@ -165,11 +172,6 @@ static __global__ void __launch_bounds__(256) k_joints_create(const phx_manifold
             joints[at++] = j;
         }
     }
-}
-
-static __global__ void __launch_bounds__(256) k_joints_flag_dead(const phx_contact_joint* __restrict__ joints, int nj, unsigned* __restrict__ dead)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) dead[i] = joints[i].contact_point_index < 0 ? 1u : 0u;
 }
 
 // Cleanup (ref: World.cpp:125-143): holes take movers
