@@ -66,7 +66,8 @@ struct DevBuf {
     int reserve(size_t n)
     {
         if (n <= cap) return PHX_OK;
-        size_t want = n + n / 2 + 64;      // hipMalloc + hipFree cost ~0.2 ms each and synchronise the device: grow generously
+        size_t want = 2 * n + 64;          // hipMalloc + hipFree cost ~0.2 ms each and synchronise the device, and a growing world
+                                           // regrows a score of arrays in the same step (a 3 ms hiccup): double — HBM is 288 GB
         T* np = nullptr;
         PHX_HIP(hipMalloc(reinterpret_cast<void**>(&np), want * sizeof(T)));
         if (p) (void)hipFree(p);
@@ -78,7 +79,7 @@ struct DevBuf {
     int reserve_keep(size_t n, size_t keep, hipStream_t stream)
     {
         if (n <= cap) return PHX_OK;
-        size_t want = n + n / 2 + 64;
+        size_t want = 2 * n + 64;
         T* np = nullptr;
         PHX_HIP(hipMalloc(reinterpret_cast<void**>(&np), want * sizeof(T)));
         if (p && keep) {

@@ -86,6 +86,8 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
         for (int i = threadIdx.x; i < JC_TABLE; i += JC_T) { table_key[i] = -1; table_cnt[i] = 0; table_units[i] = 0; }
         __syncthreads();
         const int j = j0 + (int)threadIdx.x;
+        int mine = -1;
+        unsigned lead_one = 0;
         if (j < nj) {
             const unsigned u = (unsigned)joints[j].body1, v = (unsigned)joints[j].body2;
             const bool leads = !(partner[j] >= 0 && (joints[j].contact_point_index & 1));      // not the follower of a unit
@@ -96,13 +98,23 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
                 if (r >= 0) comp = (int)root_number[r];
             }
             joint_comp[j] = comp;
-            if (comp >= 0) {
+            mine = comp; lead_one = leads ? 1u : 0u;
+        }
+        // one table insert per distinct component of the wave (in a merged world every lane carries the SAME component: a
+        // thousand same-address LDS atomics per workgroup made this the slowest kernel of the schedule build)
+        for (unsigned long long todo = __ballot(mine >= 0); todo;) {
+            const int leader = __builtin_ctzll(todo);
+            const int comp = __shfl(mine, leader);
+            const unsigned long long same = __ballot(mine == comp);
+            const unsigned nlead = (unsigned)__popcll(__ballot(mine == comp && lead_one));
+            if ((int)(threadIdx.x & 63) == leader) {
                 unsigned h = ((unsigned)comp * 2654435761u) >> 21;                         // 11 bits
                 for (;; h = (h + 1) & (JC_TABLE - 1)) {                                    // <= JC_T distinct keys in a table of 2 * JC_T
                     const int seen = atomicCAS(&table_key[h], -1, comp);
-                    if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], 1u); if (leads) atomicAdd(&table_units[h], 1u); break; }
+                    if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], (unsigned)__popcll(same)); if (nlead) atomicAdd(&table_units[h], nlead); break; }
                 }
             }
+            todo &= ~same;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < JC_TABLE; i += JC_T)

@@ -118,7 +118,8 @@ private:
     DevBuf<uint4> jp_ent_, jp_adj_;
     DevBuf<uint2> jp_succ_;
     DevBuf<unsigned> jp_offset_, jp_cursor_, jp_pred_, jp_ent_comp_, jp_seed_;
-    int jp_rounds_guess_ = 0;
+    int jp_rounds_guess_ = 0, cc_pairs_guess_ = 2;
+    unsigned cc_builds_ = 0;
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
     DevBuf<unsigned long long> jp_used_b_, jp_seen_;
     DevBuf<unsigned char> jp_bad_b_, jp_kind_;

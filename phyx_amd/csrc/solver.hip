@@ -323,14 +323,22 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     unsigned ncomp_u = 0;
     std::vector<unsigned> comp_size, comp_units;
     int guess = 0;
+    int pairs_run = 0;
+    // every 32nd build tries one pair fewer than the last one needed, so that the guess can come down again
+    const bool probe_fewer = (++cc_builds_ & 31) == 0 && cc_pairs_guess_ > 2;
+    if (probe_fewer) --cc_pairs_guess_;
     for (int round = 0;; round += 2) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
         int changed = 0;
         if (round) PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));        // (the first pair's flag was cleared by k_cc_init)
-        for (int k = 0; k < 2; ++k) {
+        // (the first batch runs as many hook + compress pairs as the previous build needed: a merged world needs four, and
+        //  finding that out two at a time costs a round trip and a second numbering)
+        const int pairs = round == 0 ? std::max(2, std::min(cc_pairs_guess_, 16)) : 2;
+        for (int k = 0; k < pairs; ++k) {
             hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
-            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == 0 ? sb_small_.p : (int*)nullptr);
+            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == pairs - 2 ? sb_small_.p : (int*)nullptr);
         }
+        pairs_run += pairs;
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)cc_parent_.p, nb, comp_size_.p, comp_units_.p}, cc_flags_.p, nb + 1,
                                          reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
@@ -345,7 +353,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(rb_.add(comp_units.data(), comp_units_.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
         changed = pair[0]; ncomp_u = (unsigned)pair[1];
-        if (!changed) break;
+        if (!changed) { cc_pairs_guess_ = pairs_run; break; }
     }
     lap("components+count");
     const int ncomp = (int)ncomp_u;
