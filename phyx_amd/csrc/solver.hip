@@ -646,12 +646,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
             iv.wave_trace = isl_trace_.p + (size_t)lg * 8;
         }
         const bool big = sched_.lds_lanes > ISL_T;
-        if (iv.trace && big)          hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-        else if (iv.trace)            hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-        else if (big && half_state_)       hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, true>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-        else if (big)                 hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false>), dim3(mine), dim3(ISL_T_BIG), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-        else if (half_state_)         hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, true>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
-        else                          hipLaunchKernelGGL((k_solve_islands<ISL_T, ISL_B, false>), dim3(mine), dim3(ISL_T), 0, stream_, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        launch_solve_islands(stream_, mine, big, half_state_, iv.trace != nullptr, v, iv, d_bodies, d_joints, d_cps, ci, pi);
         ++sweep_launches_;
     }
     if (owns_hbm_group()) {

@@ -26,6 +26,7 @@
 #pragma once
 
 #include "solver.h"
+#include "island_view.h"
 
 #include <hip/hip_fp16.h>
 
@@ -55,7 +56,7 @@ __device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i
 
 // ---- PrepareBodies (ref: Solver.cpp:456-480) -----------------------------------------------------
 // `list` = the bodies the HBM group touches (islands solved in LDS read the records directly)
-__global__ void __launch_bounds__(256) k_unpack_bodies(const phx_rigid_body* __restrict__ bodies, const int* __restrict__ list, int count,
+static __global__ void __launch_bounds__(256) k_unpack_bodies(const phx_rigid_body* __restrict__ bodies, const int* __restrict__ list, int count,
                                                        float4* __restrict__ sb_imp, float4* __restrict__ sb_disp, float4* __restrict__ sb_par)
 {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
@@ -91,7 +92,7 @@ struct ControlWords {
 constexpr int HASH_T = 1024;          // few, fat workgroups: the final same-address atomics serialise (~10 ns each)
 constexpr int HASH_BLOCKS = 128;
 
-__global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
+static __global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
                                                        const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out,
                                                        unsigned long long* next_out, ControlWords cw)
 {
@@ -148,7 +149,7 @@ __device__ __forceinline__ Limiter refresh_limiter(float n1x, float n1y, float w
     return L;
 }
 
-__global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int begin, int end, const phx_contact_joint* __restrict__ joints,
+static __global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int begin, int end, const phx_contact_joint* __restrict__ joints,
                                                       const phx_contact_point* __restrict__ cps, const int* __restrict__ static_slot)
 {
     for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
@@ -207,7 +208,7 @@ __device__ __forceinline__ void prestep_one(const SolverView& v, int s, float4& 
     }
 }
 
-__global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int leaders, int followers)
+static __global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int leaders, int followers)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
         float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1;
@@ -332,7 +333,7 @@ __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& 
 // one class: `leaders` leader slots from `begin`, then `followers` follower slots; lane i sweeps leader i, then follower i
 // on the same two bodies (schedule.h) — one gather and one scatter of the body state per unit
 template <bool DO_IMP, bool DO_DISP>
-__global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int begin, int leaders, int followers, int colour, int iter)
+static __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int begin, int leaders, int followers, int colour, int iter)
 {
     // A sweep after an unproductive sweep skips every joint (all tags <= iter-2), which is why the reference may
     // stop there (ref: Solver.cpp:189, 210).  The impulse half needs no flag for that — each joint's own skip
@@ -375,391 +376,11 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView v, int 
     if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
 }
 
-// ---- island kernel: one workgroup solves one GROUP of the schedule entirely out of LDS -----------------
-// (Refresh, PreStep and every impulse / displacement sweep of ref: Solver.cpp:130-215 SolveJointIsland.)
-// A lane owns one UNIT (schedule.h: the one or two joints of a body pair) for the whole solve: the refreshed constants and
-// the accumulators of both joints live in registers, the group's body velocities live in LDS, classes are separated by
-// workgroup barriers instead of kernel launches, and HBM is touched once on the way in and once on the way out.  A step
-// sweeps the unit's leader and then its follower on one read and one write of the two bodies: half the barriers and LDS
-// round trips per joint of the one-joint-per-lane kernel of round 2.  The early exit of ref: Solver.cpp:189 / :210 is per
-// group, exactly like the reference's per-island loop.
-// Two shapes: 256 lanes / 512 joints / 768 bodies (4 workgroups per CU — the 200-box columns of cfg 2 are ~205 units each)
-// and 512 lanes / 1024 joints / 1024 bodies (2 per CU — the 500-box columns of cfg 5 are ~510 units each); both leave a
-// lane 128 VGPRs.
-constexpr int ISL_T = 256, ISL_B = 768;        // lanes = unit capacity of a group (joints: twice that); body capacity (dynamic + touched static)
-constexpr int ISL_T_BIG = 512, ISL_B_BIG = 1024;
-
-struct IslandView {
-    const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
-    const int* ncol;                  // per group: classes
-    const int* units;                 // per group: units
-    const int2* unit_slots;           // per group g, unit u: [g * T + u] = {leader slot, follower slot or -1}, class-major
-    const int* bodies;                // global body ids, group-local order
-    const unsigned* slot_local;       // per slot: local body1 | local body2 << 16
-    const unsigned char* slot_colour; // per slot: class inside the group
-    int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
-    unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
-    int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
-    unsigned long long* wave_trace;   // null, or 8 words per wave of every group: cycles {working with <= 32 lanes, at the barrier after work, idle steps}, counts, cycles working with > 32 lanes, count
-    unsigned long long* trace;        // null, or 8 words per group: shader-clock stamps of the kernel's phases (phx_solver_set_trace)
-};
-
-// phase stamps of the island kernel (tools/island_trace.py; the constant 100 MHz clock all XCDs share): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
-// 5 written back; word 6 = XCC id | s_memtime ticks of the whole workgroup << 4, word 7 = classes << 32 | impulse sweeps executed
-#define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = wall_clock64(); } while (0)
-
-template <int B>
-__device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[B], int body, int iter, int colour)
-{
-    if (iter == 0) return true;
-    if ((sw[(iter - 1) & 1][body] >> 16) == (unsigned)iter) return true;
-    const unsigned cur = sw[iter & 1][body];
-    return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
-}
-
-// ---- body-state storage of the island kernel: fp32 (default) or the fp16 ablation ------------------------------
-template <bool HALF> struct BodyStore { using type = float4; };
-template <> struct BodyStore<true> { using type = uint2; };
-
-__device__ __forceinline__ float4 body_load(const float4* p, int i) { return p[i]; }
-__device__ __forceinline__ void body_store(float4* p, int i, float4 v) { p[i] = v; }
-__device__ __forceinline__ unsigned f2h_bits(float f) { return (unsigned)__half_as_ushort(__float2half_rn(f)); }
-__device__ __forceinline__ float h2f_bits(unsigned h) { return __half2float(__ushort_as_half((unsigned short)h)); }
-__device__ __forceinline__ float4 body_load(const uint2* p, int i)
-{
-    const uint2 r = p[i];
-    return make_float4(h2f_bits(r.x & 0xFFFFu), h2f_bits(r.x >> 16), h2f_bits(r.y & 0xFFFFu), __int_as_float((int)(short)(r.y >> 16)));
-}
-__device__ __forceinline__ void body_store(uint2* p, int i, float4 v)
-{
-    p[i] = make_uint2(f2h_bits(v.x) | (f2h_bits(v.y) << 16), f2h_bits(v.z) | ((unsigned)(unsigned short)(short)__float_as_int(v.w) << 16));
-}
-
-// fp16 ablation: what a store + load of the body record would leave in the registers (identity for fp32 state)
-template <bool HALF> __device__ __forceinline__ float4 body_round(float4 v)
-{
-    if (!HALF) return v;
-    return make_float4(h2f_bits(f2h_bits(v.x)), h2f_bits(f2h_bits(v.y)), h2f_bits(f2h_bits(v.z)), __int_as_float((int)(short)__float_as_int(v.w)));
-}
-
-// the refreshed constants and accumulators of one joint, in registers for the whole solve
-struct IslJoint { float nx, ny, aN1, aN2, aF1, aF2, cimN, cimF, dstV, dstD, accN, accF, accD; };
-
-// RefreshJoints (ref: Solver.cpp:642-693) — same expressions as k_pack_refresh
-__device__ __forceinline__ void isl_refresh(IslJoint& q, float d1x, float d1y, float d2x, float d2y, const float4& p1, const float4& p2)
-{
-    const float pt1x = d1x + p1.z, pt1y = d1y + p1.w;
-    const float pt2x = d2x + p2.z, pt2y = d2y + p2.w;
-    const float w2x = pt1x - p2.z, w2y = pt1y - p2.w;
-    const Limiter N = refresh_limiter(q.nx, q.ny, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
-    const Limiter F = refresh_limiter(-q.ny, q.nx, d1x, d1y, w2x, w2y, p1.x, p1.y, p2.x, p2.y);
-    const float depth = (pt2x - pt1x) * q.nx + (pt2y - pt1y) * q.ny;
-    const float dst = 0.f;
-    q.dstV = depth < 1.f ? dst - 0.1f : dst;
-    q.dstD = 0.1f * max_ref(0.f, depth - 2.0f * 1.f);
-    q.aN1 = N.a1; q.aN2 = N.a2; q.cimN = N.cim; q.aF1 = F.a1; q.aF2 = F.a2; q.cimF = F.cim;
-}
-
-// PreStepJoints (ref: Solver.cpp:736-750) of one joint on the bodies held in registers
-__device__ __forceinline__ void isl_prestep(const IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2)
-{
-    const float tx = -q.ny, ty = q.nx;
-    B1.x += (q.nx * im1) * q.accN; B1.y += (q.ny * im1) * q.accN; B1.z += (q.aN1 * ii1) * q.accN;
-    B1.x += (tx * im1) * q.accF; B1.y += (ty * im1) * q.accF; B1.z += (q.aF1 * ii1) * q.accF;
-    B2.x += ((-q.nx) * im2) * q.accN; B2.y += ((-q.ny) * im2) * q.accN; B2.z += (q.aN2 * ii2) * q.accN;
-    B2.x += ((-tx) * im2) * q.accF; B2.y += ((-ty) * im2) * q.accF; B2.z += (q.aF2 * ii2) * q.accF;
-}
-
-// one impulse visit (ref: Solver.cpp:790-896); returns whether the joint was evaluated (not skipped), `productive` whether it moved.
-// sp1 / sp2: 'the static body was productive' (static_productive_lds) — the same for both joints of a unit: a class step
-// cannot change what it returns for that class (tags raised in it carry the class itself, which is not 'earlier').
-__device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
-                                            bool sp1, bool sp2, int it, bool& productive)
-{
-    const bool p1 = st1 ? sp1 : (__float_as_int(B1.w) > it - 2);
-    const bool p2 = st2 ? sp2 : (__float_as_int(B2.w) > it - 2);
-    productive = false;
-    if (!(p1 || p2)) return false;
-    const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
-    float dv = q.dstV;
-    dv -= nx * B1.x; dv -= ny * B1.y; dv -= q.aN1 * B1.z;
-    dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= q.aN2 * B2.z;
-    float dn = dv * q.cimN;
-    dn = max_ref(dn, -q.accN);
-    B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (q.aN1 * ii1) * dn;
-    B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (q.aN2 * ii2) * dn;
-    q.accN += dn;
-    float fv = 0.f;
-    fv -= tx * B1.x; fv -= ty * B1.y; fv -= q.aF1 * B1.z;
-    fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= q.aF2 * B2.z;
-    float df = fv * q.cimF;
-    const float force = q.accF + df;
-    const float limit = q.accN * 0.3f;
-    const float signed_limit = force < 0.f ? -limit : limit;
-    const float adjusted = signed_limit - q.accF;
-    if (fabsf(force) > limit) df = adjusted;
-    q.accF += df;
-    B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (q.aF1 * ii1) * df;
-    B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (q.aF2 * ii2) * df;
-    if (max_ref(fabsf(dn), fabsf(df)) > 1e-4f) { B1.w = __int_as_float(it); B2.w = __int_as_float(it); productive = true; }
-    return true;
-}
-
-// one displacement visit (ref: Solver.cpp:960-1005)
-__device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
-                                             bool sp1, bool sp2, int it, bool& productive)
-{
-    const bool p1 = st1 ? sp1 : (__float_as_int(D1.w) > it - 2);
-    const bool p2 = st2 ? sp2 : (__float_as_int(D2.w) > it - 2);
-    productive = false;
-    if (!(p1 || p2)) return false;
-    const float nx = q.nx, ny = q.ny;
-    float dv = q.dstD;
-    dv -= nx * D1.x; dv -= ny * D1.y; dv -= q.aN1 * D1.z;
-    dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= q.aN2 * D2.z;
-    float di = dv * q.cimN;
-    di = max_ref(di, -q.accD);
-    D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (q.aN1 * ii1) * di;
-    D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (q.aN2 * ii2) * di;
-    q.accD += di;
-    if (fabsf(di) > 1e-4f) { D1.w = __int_as_float(it); D2.w = __int_as_float(it); productive = true; }
-    return true;
-}
-
-template <int T, int NB, bool HALF, bool TRACE = false>
-__global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
-                                                            phx_contact_joint* __restrict__ joints,
-                                                            const phx_contact_point* __restrict__ cps, int ci, int pi)
-{
-    // body velocities in LDS: float4 {vx, vy, w, tag}, or — fp16 body-state ablation (BASELINE config 5) — four 16-bit
-    // words {half vx, half vy, half w, int16 tag}; arithmetic is fp32 either way, HALF rounds on every store
-    using BodyT = typename BodyStore<HALF>::type;
-    __shared__ BodyT imp[NB];
-    __shared__ BodyT disp[NB];
-    // static-tag words [imp|disp][parity][body]; during set-up the same 12 KB hold {invMass, invInertia, pos} per body
-    __shared__ __attribute__((aligned(16))) unsigned sw_raw[4 * NB];
-    __shared__ unsigned char is_st[NB];
-    __shared__ int flag_imp[2], flag_disp[2];
-    unsigned (*swi)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw);
-    unsigned (*swd)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw + 2 * NB);
-    float4* par = reinterpret_cast<float4*>(sw_raw);
-
-    const int group = iv.first + (int)blockIdx.x * iv.stride;
-    PHX_ISL_STAMP(0);
-    const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
-    // TRACE: per wave, shader cycles spent in class steps {working: in the unit update, then at the barrier; idle: whole step}
-    unsigned long long tw_work = 0, tw_bar = 0, tw_idle = 0, tw_work_big = 0; unsigned tw_nwork = 0, tw_nidle = 0, tw_nbig = 0;
-    const int4 d = iv.desc[group];
-    const int ncol = iv.ncol[group];
-    const int nunits = iv.units[group];
-    const int tid = threadIdx.x;
-
-    // Set-up is a chain of dependent HBM round trips (index -> record -> contact point); the body chain and the joint
-    // chain are independent, so their loads are issued level by level, both chains in flight together.
-    constexpr int BI = (NB + T - 1) / T;                   // body records per lane
-    const bool live = tid < nunits;
-    int body_id[BI];
-#pragma unroll
-    for (int k = 0; k < BI; ++k) body_id[k] = tid + k * T < d.w ? iv.bodies[d.z + tid + k * T] : -1;      // level 1
-    const int2 us = live ? iv.unit_slots[(size_t)group * T + tid] : make_int2(0, -1);
-    const bool has2 = live && us.y >= 0;
-    const int jid0 = live ? v.order[us.x] : 0, jid1 = has2 ? v.order[us.y] : 0;
-    unsigned loc = 0;
-    int col = -1;
-    if (live) { loc = iv.slot_local[us.x]; col = iv.slot_colour[us.x]; }
-    if (tid < 2) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
-
-    float4 rec_imp[BI], rec_disp[BI], rec_par[BI];
-#pragma unroll
-    for (int k = 0; k < BI; ++k) {                         // level 2: PrepareBodies (ref: Solver.cpp:456-480) straight from
-        if (body_id[k] < 0) continue;                      //          the 128-byte records
-        const phx_rigid_body& b = bodies[body_id[k]];
-        rec_imp[k] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
-        rec_disp[k] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
-        rec_par[k] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
-    }
-    IslJoint q0{}, q1{};
-    float4 da0 = make_float4(0.f, 0.f, 0.f, 0.f), da1 = da0;     // delta1, delta2 of the two contact points
-    int l1 = 0, l2 = 0;
-    if (live) {                                            // PrepareJoints (ref: Solver.cpp:509-521)
-        const phx_contact_joint j = joints[jid0];
-        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);   // level 3, 32-byte records
-        da0 = cp4[0];
-        const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
-        q0.nx = nn.x; q0.ny = nn.y;
-        l1 = (int)(loc & 0xFFFFu); l2 = (int)(loc >> 16);
-        q0.accN = j.normal_accumulated_impulse; q0.accF = j.friction_accumulated_impulse;
-    }
-    if (has2) {
-        const phx_contact_joint j = joints[jid1];
-        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);
-        da1 = cp4[0];
-        const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
-        q1.nx = nn.x; q1.ny = nn.y;
-        q1.accN = j.normal_accumulated_impulse; q1.accF = j.friction_accumulated_impulse;
-    }
-#pragma unroll
-    for (int k = 0; k < BI; ++k) {
-        if (body_id[k] < 0) continue;
-        const int i = tid + k * T;
-        body_store(imp, i, rec_imp[k]);
-        body_store(disp, i, rec_disp[k]);
-        par[i] = rec_par[k];
-        is_st[i] = (rec_par[k].x == 0.f && rec_par[k].y == 0.f) ? 1 : 0;
-    }
-    __syncthreads();
-    PHX_ISL_STAMP(1);
-    float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f;
-    if (live) {
-        const float4 p1 = par[l1], p2 = par[l2];           // {im, ii, pos.x, pos.y} of the two bodies
-        isl_refresh(q0, da0.x, da0.y, da0.z, da0.w, p1, p2);
-        if (has2) isl_refresh(q1, da1.x, da1.y, da1.z, da1.w, p1, p2);
-        im1 = p1.x; ii1 = p1.y; im2 = p2.x; ii2 = p2.y;
-    }
-    __syncthreads();
-    for (int i = tid; i < 4 * NB; i += T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
-    const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
-    __syncthreads();
-    PHX_ISL_STAMP(2);
-
-    // PreStepJoints (ref: Solver.cpp:736-750), class by class: leader, then follower
-    for (int c = 0; c < ncol; ++c) {
-        if (col == c) {
-            float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-            isl_prestep(q0, B1, B2, im1, ii1, im2, ii2);
-            if (has2) {
-                if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }      // (the ablation rounds on every joint's store)
-                isl_prestep(q1, B1, B2, im1, ii1, im2, ii2);
-            }
-            if (!st1) body_store(imp, l1, B1);
-            if (!st2) body_store(imp, l2, B2);
-        }
-        __syncthreads();
-    }
-
-    PHX_ISL_STAMP(3);
-    int done_imp = 0, done_disp = 0;
-    bool imp_alive = ci > 0, disp_alive = pi > 0;
-    const int iters = ci > pi ? ci : pi;
-    for (int it = 0; it < iters; ++it) {
-        const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
-        if (!imp_on && !disp_on) break;
-        if (tid == 0) { flag_imp[(it + 1) & 1] = 0; flag_disp[(it + 1) & 1] = 0; }   // read last at the end of sweep it-1
-        for (int c = 0; c < ncol; ++c) {
-            const unsigned long long ts0 = TRACE ? __builtin_readcyclecounter() : 0ull;
-            const bool working = TRACE && __any(col == c);
-            if (col == c) {
-                if (imp_on) {
-                    float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-                    bool prod0 = false, prod1 = false;
-                    const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-                    const bool sp1 = st1 && static_productive_lds(swi, l1, it, c), sp2 = st2 && static_productive_lds(swi, l2, it, c);
-                    bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod0);
-                    if (has2) {
-                        if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
-                        if (st1) B1 = S1;
-                        if (st2) B2 = S2;
-                        touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod1);
-                    }
-                    if (prod0 || prod1) {
-                        flag_imp[it & 1] = 1;
-                        if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                        if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
-                    }
-                    if (touched) {
-                        if (!st1) body_store(imp, l1, B1);
-                        if (!st2) body_store(imp, l2, B2);
-                    }
-                }
-                if (disp_on) {
-                    float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
-                    bool prod0 = false, prod1 = false;
-                    const float4 S1 = D1, S2 = D2;
-                    const bool sp1 = st1 && static_productive_lds(swd, l1, it, c), sp2 = st2 && static_productive_lds(swd, l2, it, c);
-                    bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod0);
-                    if (has2) {
-                        if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
-                        if (st1) D1 = S1;
-                        if (st2) D2 = S2;
-                        touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod1);
-                    }
-                    if (prod0 || prod1) {
-                        flag_disp[it & 1] = 1;
-                        if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
-                        if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
-                    }
-                    if (touched) {
-                        if (!st1) body_store(disp, l1, D1);
-                        if (!st2) body_store(disp, l2, D2);
-                    }
-                }
-            }
-            const unsigned long long ts1 = TRACE ? __builtin_readcyclecounter() : 0ull;
-            __syncthreads();
-            if (TRACE) {
-                const unsigned long long ts2 = __builtin_readcyclecounter();
-                if (working) {
-                    if (__popcll(__ballot(col == c)) > 32) { tw_work_big += ts1 - ts0; ++tw_nbig; } else { tw_work += ts1 - ts0; ++tw_nwork; }
-                    tw_bar += ts2 - ts1;
-                } else { tw_idle += ts2 - ts0; ++tw_nidle; }
-            }
-        }
-        if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[it & 1] != 0; }
-        if (disp_on) { done_disp = it + 1; disp_alive = flag_disp[it & 1] != 0; }
-        __syncthreads();
-    }
-
-    PHX_ISL_STAMP(4);
-    // results go straight back into the caller's records (commit-gated like k_finish_*); the refreshed constants
-    // never leave the registers
-    if (*v.fingerprint != v.expected_fingerprint) return;
-    if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
-        phx_contact_joint& out = joints[jid0];
-        out.normal_accumulated_impulse = q0.accN;
-        out.friction_accumulated_impulse = q0.accF;
-    }
-    if (has2) {
-        phx_contact_joint& out = joints[jid1];
-        out.normal_accumulated_impulse = q1.accN;
-        out.friction_accumulated_impulse = q1.accF;
-    }
-#pragma unroll
-    for (int k = 0; k < BI; ++k) {                         // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
-        const int i = tid + k * T;
-        if (body_id[k] < 0 || is_st[i]) continue;
-        phx_rigid_body& b = bodies[body_id[k]];
-        const float4 a = body_load(imp, i), e = body_load(disp, i);
-        b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
-        b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
-    }
-    if (tid == 0) {
-        const int slot = group % ISL_STAT_SLOTS;
-        atomicMax(&iv.executed[2 * slot], done_imp);
-        atomicMax(&iv.executed[2 * slot + 1], done_disp);
-        atomicAdd(&iv.visits[slot], (unsigned long long)done_imp * (unsigned long long)d.y);
-    }
-    if (TRACE && iv.wave_trace && (tid & 63) == 0) {
-        unsigned long long* w = iv.wave_trace + ((size_t)group * (T / 64) + (tid >> 6)) * 8;
-        w[0] = tw_work; w[1] = tw_bar; w[2] = tw_idle; w[3] = ((unsigned long long)tw_nwork << 32) | tw_nidle; w[4] = tw_work_big; w[5] = tw_nbig;
-        w[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID: wave, SIMD, pipe, CU, SH, SE ... (tools/simd_map.py)
-        w[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF;  // XCC id
-    }
-    if (TRACE) {
-        __builtin_amdgcn_s_waitcnt(0);         // the stores above have left the wave
-        PHX_ISL_STAMP(5);
-        if (tid == 0) {
-            iv.trace[(size_t)group * 8 + 6] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF)    // HW_REG_XCC_ID[3:0]
-                                              | ((__builtin_readcyclecounter() - cycles0) << 4);                                  // + s_memtime ticks start -> end
-            iv.trace[(size_t)group * 8 + 7] = ((unsigned long long)ncol << 32) | (unsigned)done_imp;
-        }
-    }
-}
-
 // ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------
 // The two finish kernels (and the island kernel's epilogue) are the only places that write to the caller's
 // arrays.  They commit only if the topology fingerprint computed for THIS call equals the one the schedule was
 // built for; otherwise the solve ran on a stale schedule, nothing is written, and the host rebuilds and repeats.
-__global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int begin, int end, phx_contact_joint* __restrict__ joints)
+static __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int begin, int end, phx_contact_joint* __restrict__ joints)
 {
     if (*v.fingerprint != v.expected_fingerprint) return;
     for (int s = begin + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x) {
@@ -770,7 +391,7 @@ __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int begin, 
     }
 }
 
-__global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, phx_rigid_body* __restrict__ bodies)
+static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, phx_rigid_body* __restrict__ bodies)
 {
     if (*v.fingerprint != v.expected_fingerprint) return;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
