@@ -160,7 +160,12 @@ class Group:
             self.device = torch.device("cuda", self.local_rank)
         else:
             self.device = torch.device("cpu")
-        dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+        # (device_id binds the communicator to this rank's GPU up front: no 'guessing device ID' and no lazy init in the first collective)
+        kw = {"device_id": self.device} if backend == "nccl" else {}
+        try:
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kw)
+        except TypeError:                                   # a torch without the device_id argument
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def _sync(self):
