@@ -112,12 +112,19 @@ struct PinnedBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
         const size_t want = n + n / 2 + 64;
-        PHX_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault));
+        PHX_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocCoherent | hipHostMallocMapped));
         cap = want;
         return PHX_OK;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
+
+// small host -> device upload by a kernel that reads the (host-coherent, device-visible) pinned staging directly: a DMA of a
+// few KB waits its turn in the copy engine's queue before anything moves; a dispatch reads them over PCIe in a few microseconds
+static __global__ void __launch_bounds__(256) k_upload_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src_host, int words)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src_host[i];
+}
 
 // scratch of device_exclusive_scan's single-pass form (device_scan.h): ticket word + one status word per tile + the call counter
 struct ScanScratch {

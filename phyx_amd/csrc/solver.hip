@@ -407,7 +407,10 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     std::copy(bin_of.begin(), bin_of.end(), bin_tables_host_.p);
     std::copy(rank_of.begin(), rank_of.end(), bin_tables_host_.p + nc1);
     std::copy(sc.group_offsets.begin(), sc.group_offsets.begin() + nbins + 1, bin_tables_host_.p + 2 * nc1);
-    PHX_HIP(hipMemcpyAsync(bin_tables_.p, bin_tables_host_.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (table_words <= 65536)
+        hipLaunchKernelGGL(k_upload_words, dim3(std::max(1, std::min(div_up((int)table_words, 256), 64))), dim3(256), 0, stream_,
+                           reinterpret_cast<unsigned*>(bin_tables_.p), reinterpret_cast<const unsigned*>(bin_tables_host_.p), (int)table_words);
+    else PHX_HIP(hipMemcpyAsync(bin_tables_.p, bin_tables_host_.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
     const int* bin_of_comp = bin_tables_.p; const int* rank_of_comp = bin_tables_.p + nc1; const int* grp_goff = bin_tables_.p + 2 * nc1;
     lap("bin");
 
