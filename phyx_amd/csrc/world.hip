@@ -217,8 +217,11 @@ int World::refresh_contact_joints()                                         // r
     // One host round trip for both counts.  A joint is dead iff no contact point re-attached it (the match), which is
     // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
     unsigned host[2] = {0, 0};                                              // [0] new joints, [1] dead joints
-    if (nm) PHX_TRY(device_exclusive_scan_of(JointMatchLoad{(const phx_manifold*)d_manifolds_.p, (const phx_contact_point*)d_cps_.p, d_joints_.p, joint_seen_.p, joint_epoch_},
-                                             flags_.p, nm, counters_.p, scan_tiles_, stream_));
+    if (nm) {
+        hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
+                           d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p);
+        PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
+    }
     if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_}, dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
     if (nm || nj) {                                                         // counters_[0], [1]: adjacent words, one copy
         PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));

@@ -128,15 +128,16 @@ static __global__ void __launch_bounds__(256) k_pack_manifolds(phx_manifold* __r
 
 // ---- RefreshContactJoints (ref: World.cpp:72-149) -----------------------------------------------------------
 // The reference resets every joint's contact point, lets the live points re-attach theirs and deletes what stayed reset.
-// Here a joint is alive iff its `seen` stamp carries this step's epoch (no reset pass), and the two counting passes are the
-// LOADERS of their scans (device_scan.h) instead of kernels of their own.
-// Match, pass 1 = loader of the 'new joints before manifold i' scan: matched points re-attach their joint and stamp it; the
-// word is the number of points that need a new joint.
-struct JointMatchLoad {
-    static constexpr bool in_place = false;
-    const phx_manifold* manifolds; const phx_contact_point* cps; phx_contact_joint* joints; unsigned* seen; unsigned epoch;
-    __device__ unsigned operator()(int i) const
-    {
+// Here a joint is alive iff its `seen` stamp carries this step's epoch (no reset pass), and the dead-joint flags are the LOADER
+// of their scan (device_scan.h) instead of a kernel of their own.
+// Match, pass 1: matched points re-attach their joint and stamp it; count the points that need a new joint.  (A kernel of its
+// own: as the loader of its scan it was slower — 25 us against 9 + 5 at 2e5 manifolds, 112 us at 1e6: a scan workgroup is 1024
+// lanes of four items each, too few lanes in flight for this chain of dependent gathers.)
+static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold* __restrict__ manifolds, int nm, const phx_contact_point* __restrict__ cps,
+                                                             phx_contact_joint* __restrict__ joints, unsigned* __restrict__ seen, unsigned epoch,
+                                                             unsigned* __restrict__ new_count)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
         const phx_manifold m = manifolds[i];
         unsigned fresh = 0;
         for (int k = 0; k < m.point_count; ++k) {
@@ -144,9 +145,9 @@ struct JointMatchLoad {
             if (si < 0) ++fresh;
             else { joints[si].contact_point_index = m.point_index + k; seen[si] = epoch; }
         }
-        return fresh;
+        new_count[i] = fresh;
     }
-};
+}
 
 // loader of the 'dead joints before joint i' scan (queued behind the match)
 struct JointDeadLoad {
