@@ -182,6 +182,8 @@ struct BinBuildView {
     int2* unit_slots;                 // out: [g * T + unit] = {leader slot, follower slot or -1}, class-major
     int* bodies;                      // out: body table of bin g at [g * NB, g * NB + body_count)
     int* rejected;                    // out: set to 1 if any bin exceeds the caps (caller falls back to the host builder)
+    unsigned long long* poison;       // the solve's topology fingerprint word: a rejected bin spoils it, so that every kernel that would commit
+                                      // results on this schedule refuses to (the host checks `rejected` only after the solve is queued)
 };
 
 // stable rank of the lanes with `want` among the lanes of the whole workgroup that share their key (< 64), in lane order:
@@ -367,7 +369,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         if (tid == 0) n_col = nonempty ? 64 - __builtin_clzll(nonempty) : 0;
     }
     __syncthreads();
-    if (!fits || bad) { if (tid == 0) *v.rejected = 1; return; }
+    if (!fits || bad) { if (tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); } return; }
     if (placed) {
         const int c = mycol;
         const int r = paired ? (int)wave_with[wave * 64 + c] + rank_with : (int)wave_single[wave * 64 + c] + rank_single;

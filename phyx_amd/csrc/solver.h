@@ -65,6 +65,10 @@ public:
     // consecutive phases need no host synchronisation)
     int adopt_stream(hipStream_t s);
     bool has_pending() const { return pending_.active; }
+    // the gate of an unverified solve (world.hip queues the integrator behind it under the same gate)
+    const unsigned long long* fingerprint_word() const { return hash_.p + hash_slot_; }
+    unsigned long long expected_fingerprint() const { return raw_fingerprint_; }
+    unsigned replays() const { return replays_; }
     int device() const { return device_; }
 
 private:
@@ -119,6 +123,10 @@ private:
     DevBuf<uint2> jp_succ_;
     DevBuf<unsigned> jp_offset_, jp_cursor_, jp_pred_, jp_ent_comp_, jp_seed_;
     int jp_rounds_guess_ = 0, cc_pairs_guess_ = 2;
+    // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
+    bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
+    int unverified_bins_ = 0;
+    unsigned replays_ = 0;                          // solves repeated because nothing could be committed (stale or spoiled schedule)
     unsigned cc_builds_ = 0;
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
     DevBuf<unsigned long long> jp_used_b_, jp_seen_;

@@ -81,6 +81,7 @@ int DeviceSolver::init()
     gpu_builder_ = !(sb && sb[0] == 'h');
     const char* sp = getenv("PHX_NO_SPECULATION");
     speculate_ = !(sp && sp[0] == '1');
+    defer_build_check_ = speculate_;                     // (PHX_NO_SPECULATION=1 also waits for the device build's 'every bin fits' flag)
     const char* ni = getenv("PHX_NO_ISLANDS");           // "1": ignore island modes, always the HBM colour path (A/B measurements)
     no_islands_ = ni && ni[0] == '1';
     trace_schedule_ = getenv("PHX_TRACE_SCHEDULE") != nullptr;      // print the schedule builders' laps to stderr
@@ -134,7 +135,9 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     // Single = one coupled system swept colour by colour out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
-    const bool device_builder = gpu_builder_;
+    const bool device_builder = gpu_builder_ && !force_host_builder_;
+    force_host_builder_ = false;
+    build_unverified_ = false;
     if (!(known_changed && device_builder)) {
         PHX_TRY(rb_.add(&fp, hash_.p + hash_slot_, sizeof fp, stream_));
         PHX_TRY(rb_.wait(stream_));
@@ -170,6 +173,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
             return PHX_OK;
         }
         sched_.valid = false;
+        build_unverified_ = false;                     // (the host builder's schedules need no verification)
     }
     const unsigned long long raw = fp;
     fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
@@ -439,27 +443,33 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
         bv.units = grp_units_.p; bv.unit_slots = unit_slots_.p;
-        bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2;
+        bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2; bv.poison = hash_.p + hash_slot_;
         if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(2 * ISL_T_BIG), 0, stream_, bv);
         else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(2 * ISL_T), 0, stream_, bv);
     }
     PHX_HIP(hipGetLastError());
-    int rejected = 0;
-    std::vector<int> ncol(std::max(nbins, 1), 0);
-    std::vector<int4> desc;
-    PHX_TRY(rb_.add(&rejected, sb_small_.p + 2, sizeof rejected, stream_));
-    if (nbins) PHX_TRY(rb_.add(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), stream_));
-    if (nbins && (shard_count_ > 1 || xch_send_)) {          // a sharded solve's exchange layout needs every group's body count (exchange.h)
-        desc.resize(nbins);
-        PHX_TRY(rb_.add(desc.data(), grp_desc_.p, (size_t)nbins * sizeof(int4), stream_));
-    }
-    PHX_TRY(rb_.wait(stream_));
-    lap("bins");
-    if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
-    sc.lds_colours = 0;
-    for (int g = 0; g < nbins; ++g) sc.lds_colours += ncol[g];
+    // Did every bin fit?  Normally NOT waited for here: a rejected bin spoils the solve's fingerprint word on the device, the
+    // solve is queued behind the build, commits nothing if that happened, and synchronize() finds out (with the classes per group,
+    // a statistic) in the round trip it makes anyway — the host's wait then overlaps the island kernel instead of idling the GPU.
+    // A sharded solve needs the groups' body counts for its exchange layout now.
     grp_body_count_.clear();
-    for (const int4& d : desc) grp_body_count_.push_back(d.w);
+    sc.lds_colours = 0;
+    if (nbins && (shard_count_ > 1 || xch_send_ || !defer_build_check_)) {
+        int rejected = 0;
+        std::vector<int> ncol(nbins, 0);
+        std::vector<int4> desc(nbins);
+        PHX_TRY(rb_.add(&rejected, sb_small_.p + 2, sizeof rejected, stream_));
+        PHX_TRY(rb_.add(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), stream_));
+        PHX_TRY(rb_.add(desc.data(), grp_desc_.p, (size_t)nbins * sizeof(int4), stream_));
+        PHX_TRY(rb_.wait(stream_));
+        lap("bins");
+        if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
+        for (int g = 0; g < nbins; ++g) sc.lds_colours += ncol[g];
+        for (const int4& d : desc) grp_body_count_.push_back(d.w);
+    } else if (nbins) {
+        build_unverified_ = true;
+        unverified_bins_ = nbins;
+    }
     }
     const int rest = nj - lds_slots;
 
@@ -776,6 +786,9 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     if (pending_.active && !(pending_.bodies == d_bodies && pending_.cps == d_cps && pending_.joints == d_joints && pending_.nb == nb &&
                              pending_.nj == nj && pending_.ncp == ncp && std::memcmp(&pending_.cfg, &cfg, sizeof cfg) == 0))
         PHX_TRY(synchronize());
+    // a device-built schedule is verified (did every bin fit?) before anything else runs on it: only the solve that was queued
+    // with the build is covered by the spoiled fingerprint
+    if (build_unverified_) PHX_TRY(synchronize());
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     if (!reuse_schedule_) topology_changed = true;       // live-topology measurements: rebuild like the reference does every call (ref: Solver.cpp:77, 135)
     if (!topology_changed && speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
@@ -791,6 +804,11 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
         stats_.recoloured = 0;
     } else {
         PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp, cfg, false, topology_changed));
+        if (build_unverified_) {       // like a speculative solve: verified (and replayed on a host-built schedule if a bin was rejected) by synchronize()
+            pending_.count = 1;
+            pending_.active = true; pending_.bodies = d_bodies; pending_.cps = d_cps; pending_.joints = d_joints;
+            pending_.nb = nb; pending_.ncp = ncp; pending_.nj = nj; pending_.cfg = cfg;
+        }
     }
     const bool split = cfg.island_mode == PHX_ISLAND_MULTIPLE || cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
     stats_.island_count = split ? sched_.island_count : 1;
@@ -826,9 +844,28 @@ int DeviceSolver::solve_host(phx_rigid_body* bodies, int nb, const phx_contact_p
 // `extra`/`extra_src`: one more 8-byte value to fetch in the same round trip (the fingerprint of a speculative solve)
 int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long long* extra_src)
 {
+    // an unverified device build (build_schedule_device): the classes per group ride along; whether a bin was rejected shows in
+    // the fingerprint the caller compares
+    std::vector<int> ncol;
+    auto with_build = [&]() -> int {
+        if (!build_unverified_) return PHX_OK;
+        ncol.assign((size_t)unverified_bins_, 0);
+        return rb_.add(ncol.data(), grp_ncol_.p, ncol.size() * sizeof(int), stream_);
+    };
+    auto settle_build = [&]() {
+        if (!build_unverified_) return;
+        build_unverified_ = false;
+        build_was_unverified_ = true;                  // (read by synchronize() if the fingerprint does not match)
+        sched_.lds_colours = 0;
+        for (int n : ncol) sched_.lds_colours += n;
+        stats_.colour_count = sched_.ncolours();
+    };
     if (!stats_pending_) {
         if (extra) { PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_)); }
-        return rb_.wait(stream_);
+        PHX_TRY(with_build());
+        PHX_TRY(rb_.wait(stream_));
+        settle_build();
+        return PHX_OK;
     }
     std::vector<int> flags(2 * (size_t)max_iters_);
     int isl_slots[2 * ISL_STAT_SLOTS] = {0};
@@ -837,7 +874,9 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     PHX_TRY(rb_.add(flags.data(), flags_.p, flags.size() * sizeof(int), stream_));
     PHX_TRY(rb_.add(isl_slots, isl_stats_.p, sizeof isl_slots, stream_));
     PHX_TRY(rb_.add(visit_slots, isl_visits_.p, sizeof visit_slots, stream_));
+    PHX_TRY(with_build());
     PHX_TRY(rb_.wait(stream_));
+    settle_build();
     int isl[2] = {0, 0};
     unsigned long long isl_visits = 0;
     for (int k = 0; k < ISL_STAT_SLOTS; ++k) { isl[0] = std::max(isl[0], isl_slots[2 * k]); isl[1] = std::max(isl[1], isl_slots[2 * k + 1]); isl_visits += visit_slots[k]; }
@@ -870,10 +909,19 @@ int DeviceSolver::synchronize()
         PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_));
         const Pending p = pending_;
         pending_.active = false;
+        const bool spoiled_build = build_was_unverified_ && fp != raw_fingerprint_;      // a bin did not fit: the device build spoiled the fingerprint
+        build_was_unverified_ = false;
+        if (spoiled_build) force_host_builder_ = true;
         if (fp != raw_fingerprint_) {
             stats_pending_ = true;                     // those counters belong to a solve that committed nothing
-            // the joint topology changed under the cached schedule: nothing was committed; rebuild and solve again
-            PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp, p.cfg, true));
+            ++replays_;
+            // the joint topology changed under the cached schedule (or the build it ran on had a bin that did not fit): nothing was
+            // committed; rebuild — verified on the spot this time — and solve again
+            const bool keep_defer = defer_build_check_;
+            defer_build_check_ = false;
+            const int rebuilt = ensure_schedule(static_cast<const phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp, p.cfg, true);
+            defer_build_check_ = keep_defer;
+            PHX_TRY(rebuilt);
             stats_.colour_count = sched_.ncolours();
             stats_.lds_islands = sched_.lds_groups;
             const bool split = p.cfg.island_mode == PHX_ISLAND_MULTIPLE || p.cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
@@ -902,6 +950,7 @@ int DeviceSolver::get_stats(phx_solve_stats* out)
 int DeviceSolver::get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours)
 {
     if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(synchronize());                            // (an unverified device build is settled first)
     PHX_TRY(materialise_schedule());
     const int ncol = sched_.ncolours();
     if (ncolours) *ncolours = ncol;
@@ -962,6 +1011,7 @@ int DeviceSolver::set_shard(int shard, int count)
 int DeviceSolver::get_groups(int* offsets, int cap, int* count, int* lds_count)
 {
     if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(synchronize());
     PHX_TRY(materialise_schedule());
     if (count) *count = sched_.ngroups();
     if (lds_count) *lds_count = sched_.lds_groups;
@@ -1052,9 +1102,9 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     ev_sweep_begin_ = keep_b; ev_sweep_end_ = keep_e;
     PHX_TRY(st);
     PHX_HIP(hipEventRecord(bench_events_[2 * steps + 1], stream_));
-    const bool was_pending = pending_.active;
+    const unsigned replays = replays_;
     PHX_TRY(synchronize());
-    if (was_pending && stats_.recoloured) { set_error("bench: topology changed during the timed region"); return PHX_ERR_STATE; }
+    if (replays_ != replays && reuse_schedule_) { set_error("bench: topology changed during the timed region"); return PHX_ERR_STATE; }
     float ms = 0.f;
     PHX_HIP(hipEventElapsedTime(&ms, bench_events_[2 * steps], bench_events_[2 * steps + 1]));
     out->total_ms = ms;

@@ -57,7 +57,8 @@ private:
     int update_manifolds();
     int pack_manifolds();
     int refresh_contact_joints();
-    int solve(const phx_config& cfg);
+    int solve(const phx_config& cfg, bool settle);
+    int solve_and_integrate(float dt, const phx_config& cfg);
     int scratch_for(int n);
 
     int device_;
@@ -251,15 +252,37 @@ int World::refresh_contact_joints()                                         // r
     return PHX_OK;
 }
 
-int World::solve(const phx_config& cfg)                                     // ref: World.cpp:34
+int World::solve(const phx_config& cfg, bool settle)                        // ref: World.cpp:34
 {
     // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
     // keep their velocities here
     PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
     joints_changed_ = false;
-    // a speculative solve (unchanged joint list, cached schedule) must be verified before the integrator consumes its
-    // result; a solve on a freshly built schedule needs no host wait at all (its counters are fetched by the first getter)
-    return solver_.has_pending() ? solver_.synchronize() : PHX_OK;
+    // a solve that is still unverified (it ran speculatively on the cached schedule, or on a device-built schedule whose 'every
+    // bin fits' flag has not been read) must be settled before anything consumes its result unconditionally
+    return settle && solver_.has_pending() ? solver_.synchronize() : PHX_OK;
+}
+
+// IntegratePosition behind the solve.  An unverified solve is NOT waited for first: the integrator is queued behind it gated by
+// the same fingerprint word (it integrates nothing if the solve committed nothing), THEN the host settles the solve — its
+// round trip overlaps the island kernel and the integrator instead of idling the GPU — and repeats the integrator only if the
+// solve had to be repeated.
+int World::solve_and_integrate(float dt, const phx_config& cfg)
+{
+    { RoctxRange r("SolveJoints"); PHX_TRY(solve(cfg, false)); }
+    RoctxRange r("IntegratePosition");                                      // ref: World.cpp:57-70
+    const bool pending = solver_.has_pending();
+    const unsigned replays = solver_.replays();
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt,
+                                 pending ? solver_.fingerprint_word() : (const unsigned long long*)nullptr, solver_.expected_fingerprint());
+    PHX_HIP(hipGetLastError());
+    if (pending) {
+        PHX_TRY(solver_.synchronize());
+        if (solver_.replays() != replays && nb())
+            hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt, (const unsigned long long*)nullptr, 0ull);
+        PHX_HIP(hipGetLastError());
+    }
+    return PHX_OK;
 }
 
 int World::pre_solve(float dt)
@@ -292,7 +315,7 @@ int World::pre_solve(float dt)
 int World::step_begin(float dt, const phx_config& cfg, size_t* segment_bytes)
 {
     PHX_TRY(pre_solve(dt));
-    { RoctxRange r("SolveJoints (this rank's groups)"); PHX_TRY(solve(cfg)); }
+    { RoctxRange r("SolveJoints (this rank's groups)"); PHX_TRY(solve(cfg, true)); }
     RoctxRange r("Exchange: pack");
     return solver_.exchange_pack(d_bodies_.p, d_joints_.p, segment_bytes);
 }
@@ -302,7 +325,7 @@ int World::step_end(float dt)
     PHX_TRY(use_device(device_));
     { RoctxRange r("Exchange: unpack"); PHX_TRY(solver_.exchange_unpack(d_bodies_.p, d_joints_.p)); }
     RoctxRange r("IntegratePosition");
-    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt, (const unsigned long long*)nullptr, 0ull);            // ref: World.cpp:57-70
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -315,10 +338,12 @@ int World::finish_step(float dt, const phx_config& cfg)
     PHX_TRY(sync_bodies_to_device());
     auto t = clk::now();
     auto lap = [&](int phase) { if (!phase_timing) return; (void)hipStreamSynchronize(stream_); auto n = clk::now(); phase_ms[phase] = std::chrono::duration<double, std::milli>(n - t).count(); t = n; };
-    { RoctxRange r("SolveJoints"); PHX_TRY(solve(cfg)); lap(6); }
-    RoctxRange r("IntegratePosition");
-    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt);            // ref: World.cpp:57-70
-    PHX_HIP(hipGetLastError());
+    if (phase_timing) {                                                     // (per-phase host timing: settle the solve before the integrator)
+        { RoctxRange r("SolveJoints"); PHX_TRY(solve(cfg, true)); lap(6); }
+        RoctxRange r("IntegratePosition");
+        if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt, (const unsigned long long*)nullptr, 0ull);
+        PHX_HIP(hipGetLastError());
+    } else PHX_TRY(solve_and_integrate(dt, cfg));
     lap(7);
     return PHX_OK;
 }

@@ -42,8 +42,12 @@ __device__ __forceinline__ void rotate_vec(phx_vec2& v, float c, float s)
     v.x = v.x + delta.x; v.y = v.y + delta.y;
 }
 
-static __global__ void __launch_bounds__(256) k_integrate_position(phx_rigid_body* __restrict__ bodies, int n, float dt)
+// `gate` (may be null): the topology fingerprint word of the solve queued in front; if it differs from `expected` that solve
+// committed nothing (stale or spoiled schedule, solver.hip) and neither does this — the host repeats both.
+static __global__ void __launch_bounds__(256) k_integrate_position(phx_rigid_body* __restrict__ bodies, int n, float dt,
+                                                                   const unsigned long long* __restrict__ gate, unsigned long long expected)
 {
+    if (gate && *gate != expected) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         phx_rigid_body b = bodies[i];
         b.pos.x += b.displacing_velocity.x + b.velocity.x * dt;
