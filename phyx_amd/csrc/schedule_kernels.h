@@ -19,8 +19,9 @@ namespace phx {
 
 // ---- connected components over dynamic bodies --------------------------------------------------------------
 // (`clear`: a word to zero on the way — the 'hooked anything' flag of the first round; saves a memset dispatch)
+// (`first`: the contact point -> first joint table of the unit pairing below, reset to 'nobody' on the same way: ncp words)
 static __global__ void __launch_bounds__(256) k_cc_init(const phx_rigid_body* __restrict__ bodies, int nb, int* __restrict__ parent,
-                                                        unsigned char* __restrict__ is_static, int* __restrict__ clear)
+                                                        unsigned char* __restrict__ is_static, int* __restrict__ clear, int* __restrict__ first, int ncp)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
@@ -28,13 +29,27 @@ static __global__ void __launch_bounds__(256) k_cc_init(const phx_rigid_body* __
         is_static[i] = st ? 1 : 0;
         parent[i] = st ? -1 : i;
     }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncp; i += gridDim.x * blockDim.x) first[i] = 0x7f7f7f7f;
 }
 
 // every joint between two dynamic bodies hooks the larger of the two current labels under the smaller
-static __global__ void __launch_bounds__(256) k_cc_hook(const phx_contact_joint* __restrict__ joints, int nj, int nb, int* parent, int* __restrict__ changed)
+// (`first` / `partner`, if not null — the first round: also pairs the joints into units, schedule.h; the table is complete, k_partner_first ran)
+__device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ joints, int j, const phx_contact_joint& me, int ncp, const int* __restrict__ first)
+{
+    const unsigned id = (unsigned)me.contact_point_index;
+    if (id >= (unsigned)ncp || first[id] != j || (id ^ 1u) >= (unsigned)ncp) return -1;
+    const int other = first[id ^ 1u];
+    if (other == 0x7f7f7f7f) return -1;
+    const phx_contact_joint o = joints[other];
+    return (o.body1 == me.body1 && o.body2 == me.body2) ? other : -1;
+}
+
+static __global__ void __launch_bounds__(256) k_cc_hook(const phx_contact_joint* __restrict__ joints, int nj, int nb, int* parent, int* __restrict__ changed,
+                                                        const int* __restrict__ first, int ncp, int* __restrict__ partner)
 {
     bool any = false;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        if (partner) partner[j] = partner_of(joints, j, joints[j], ncp, first);
         const unsigned u = (unsigned)joints[j].body1, v = (unsigned)joints[j].body2;
         if (u >= (unsigned)nb || v >= (unsigned)nb) continue;          // reported by the fingerprint / validation path
         const int pu = parent[u], pv = parent[v];
@@ -142,24 +157,6 @@ static __global__ void __launch_bounds__(256) k_partner_first(const phx_contact_
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         const unsigned id = (unsigned)joints[j].contact_point_index;
         if (id < (unsigned)ncp) atomicMin(&first[id], j);
-    }
-}
-
-static __global__ void __launch_bounds__(256) k_partner_find(const phx_contact_joint* __restrict__ joints, int nj, int ncp, const int* __restrict__ first,
-                                                             int* __restrict__ partner)
-{
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
-        const phx_contact_joint me = joints[j];
-        const unsigned id = (unsigned)me.contact_point_index;
-        int p = -1;
-        if (id < (unsigned)ncp && first[id] == j && (id ^ 1u) < (unsigned)ncp) {
-            const int other = first[id ^ 1u];
-            if (other != 0x7f7f7f7f) {
-                const phx_contact_joint o = joints[other];
-                if (o.body1 == me.body1 && o.body2 == me.body2) p = other;
-            }
-        }
-        partner[j] = p;
     }
 }
 

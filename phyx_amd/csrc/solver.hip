@@ -307,12 +307,10 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(sort_hist_.reserve(radix_hist_words(nj)));
     PHX_TRY(order_.reserve(njs));
 
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p);
-    // units (schedule.h): the partner of every joint
+    // units (schedule.h): contact point -> first joint carrying it (reset by k_cc_init); the partners are found by the first hook
     PHX_TRY(partner_.reserve(njs)); PHX_TRY(partner_first_.reserve(std::max(ncp_, 1))); PHX_TRY(comp_units_.reserve(nbs + 1));
-    PHX_HIP(hipMemsetAsync(partner_first_.p, 0x7f, (size_t)std::max(ncp_, 1) * sizeof(int), stream_));
+    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, ncp_))), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p, partner_first_.p, ncp_);
     hipLaunchKernelGGL(k_partner_first, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, partner_first_.p);
-    hipLaunchKernelGGL(k_partner_find, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, (const int*)partner_first_.p, partner_.p);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -339,7 +337,9 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         //  finding that out two at a time costs a round trip and a second numbering)
         const int pairs = round == 0 ? std::max(2, std::min(cc_pairs_guess_, 16)) : 2;
         for (int k = 0; k < pairs; ++k) {
-            hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p);
+            const bool pairing = round == 0 && k == 0;      // the first hook also pairs the joints into units
+            hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p,
+                               (const int*)partner_first_.p, ncp_, pairing ? partner_.p : (int*)nullptr);
             hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == pairs - 2 ? sb_small_.p : (int*)nullptr);
         }
         pairs_run += pairs;

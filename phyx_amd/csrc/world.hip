@@ -231,18 +231,19 @@ int World::refresh_contact_joints()                                         // r
         if (!nj) host[1] = 0;
     }
     const int fresh = (int)host[0], dead = (int)host[1], old = nj;
+    const int total = nj + fresh;
+    if (dead) PHX_TRY(mover_pos_.reserve((size_t)total + 2));
     if (fresh) {
         joints_changed_ = true;
         PHX_TRY(d_joints_.reserve_keep((size_t)nj + fresh, nj, stream_));
-        hipLaunchKernelGGL(k_joints_create, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, d_cps_.p, d_joints_.p, nj,
-                           (const unsigned*)flags_.p);
+        const int mover_blocks = dead ? wgrid(dead) : 0;                    // the clean-up's movers ride along (independent of the new joints)
+        hipLaunchKernelGGL(k_joints_create, dim3(wgrid(nm) + mover_blocks), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, d_cps_.p, d_joints_.p, nj,
+                           (const unsigned*)flags_.p, mover_blocks, (const unsigned*)dead_flags_.p, (const unsigned*)(counters_.p + 1), total, mover_pos_.p);
     }
-    const int total = nj + fresh;
     if (dead) {                                                             // cleanup (ref: World.cpp:125-143): holes take movers from the tail
         joints_changed_ = true;
-        PHX_TRY(mover_pos_.reserve((size_t)total + 2));
-        hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)dead_flags_.p, (const unsigned*)(counters_.p + 1), total, old,
-                           mover_pos_.p);
+        if (!fresh) hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)dead_flags_.p, (const unsigned*)(counters_.p + 1), total, old,
+                                       mover_pos_.p);
         hipLaunchKernelGGL(k_joints_fill, dim3(wgrid(total)), dim3(256), 0, stream_, d_joints_.p, total, old, (const unsigned*)dead_flags_.p,
                            (const unsigned*)(counters_.p + 1), (const int*)mover_pos_.p);
     }

@@ -96,17 +96,23 @@ static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* _
 // mover_pos[r] = position of the r-th live element counted from the end (only those at positions >= n').
 // (`n_flagged`: dead_before[] covers positions [0, n_flagged); positions beyond it were appended after the flags were
 //  taken — new joints — and are alive, with every dead element before them)
-static __global__ void __launch_bounds__(256) k_compact_movers(const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
-                                                               int n, int n_flagged, int* __restrict__ mover_pos)
+__device__ __forceinline__ void compact_movers(int block, int blocks, const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
+                                               int n, int n_flagged, int* __restrict__ mover_pos)
 {
     const int D = (int)*dead_total, live = n - D;
-    for (int p = live + blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    for (int p = live + block * (int)blockDim.x + (int)threadIdx.x; p < n; p += blocks * (int)blockDim.x) {
         const int here = p < n_flagged ? (int)dead_before[p] : D;
         const int next = (p + 1 < n_flagged) ? (int)dead_before[p + 1] : D;
         if (next != here) continue;                                      // p itself is dead
         const int dead_after = D - here;
         mover_pos[(n - 1 - p) - dead_after] = p;
     }
+}
+
+static __global__ void __launch_bounds__(256) k_compact_movers(const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
+                                                               int n, int n_flagged, int* __restrict__ mover_pos)
+{
+    compact_movers((int)blockIdx.x, (int)gridDim.x, dead_before, dead_total, n, n_flagged, mover_pos);
 }
 
 // ref: Collider.cpp:385-410.  Every dead manifold's pair is listed for removal from the pair set; holes take movers.
@@ -161,10 +167,19 @@ struct JointDeadLoad {
 };
 
 // Match, pass 2: new joints appended in manifold order, then point order (ref: World.cpp:108-114)
+// (the movers of the clean-up behind it do not depend on the new joints: when there are dead joints too, the last `mover_blocks`
+//  workgroups of the same launch compute them — one dispatch instead of two)
 static __global__ void __launch_bounds__(256) k_joints_create(const phx_manifold* __restrict__ manifolds, int nm, phx_contact_point* __restrict__ cps,
-                                                              phx_contact_joint* __restrict__ joints, int nj_old, const unsigned* __restrict__ new_before)
+                                                              phx_contact_joint* __restrict__ joints, int nj_old, const unsigned* __restrict__ new_before,
+                                                              int mover_blocks, const unsigned* __restrict__ dead_before, const unsigned* __restrict__ dead_total,
+                                                              int total, int* __restrict__ mover_pos)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+    const int create_blocks = (int)gridDim.x - mover_blocks;
+    if ((int)blockIdx.x >= create_blocks) {
+        compact_movers((int)blockIdx.x - create_blocks, mover_blocks, dead_before, dead_total, total, nj_old, mover_pos);
+        return;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += create_blocks * blockDim.x) {
         const phx_manifold m = manifolds[i];
         int at = nj_old + (int)new_before[i];
         for (int k = 0; k < m.point_count; ++k) {
