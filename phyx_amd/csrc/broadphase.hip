@@ -152,6 +152,9 @@ struct SweepView {
     unsigned long long* counters;   // statistics, spread over STAT_SLOTS slots to keep the atomics apart: [2 * slot] candidate tests, [2 * slot + 1] overlapping pairs
 };
 
+constexpr int SWEEP_CAND = 8;        // y-overlapping candidates a row collects before it looks them up in the pair set
+constexpr int SWEEP_GROUP = 8;       // candidates a row fetches per step of its scan
+
 // first position j > i with minx[j] > maxx (entries sorted by minx)
 __device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int n, int i, float maxx)
 {
@@ -172,6 +175,7 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
     // EMIT = false: the count pass (also remembers each row's first ROW_CACHE new partners).
     // EMIT = true : rescans ONLY the rows that found more than ROW_CACHE new pairs; all other rows are emitted from the
     //               cache by k_emit_cached without touching the entries or the pair set again.
+    __shared__ unsigned cand[SWEEP_CAND][256];          // per lane: positions of the candidates that overlap in y, not looked up yet
     unsigned long long tests = 0, overlaps = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
         const float4 a = v.entries[i];
@@ -200,36 +204,58 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
         }
         const unsigned ia = v.idx[i];
         unsigned found = 0;
-        auto test = [&](int j, const float4& b) {
-            if (fabsf(b.z - a.z) <= a.w + b.w) {
-                const unsigned ib = v.idx[j];
-                if (!EMIT) ++overlaps;
-                if (!ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | ib)) {
-                    if (EMIT) out[dst + found] = make_uint2(ia, ib);
-                    else if (found < (unsigned)ROW_CACHE) v.row_cache[(size_t)i * ROW_CACHE + found] = ib;
+        // The candidates that overlap in y are only COLLECTED by the scan (their positions, in j order, in LDS); the pair-set
+        // lookups — two dependent memory round trips each — are made afterwards, all in flight together.  Done inside the scan
+        // they were its whole cost: some lane of the wave hits an overlap in almost every step, and the wave waits for it.
+        int ncand = 0;
+        auto flush = [&]() {
+            unsigned ib[SWEEP_CAND];
+            unsigned long long first[SWEEP_CAND];
+#pragma unroll
+            for (int k = 0; k < SWEEP_CAND; ++k) ib[k] = k < ncand ? v.idx[cand[k][threadIdx.x]] : 0u;
+#pragma unroll
+            for (int k = 0; k < SWEEP_CAND; ++k) first[k] = k < ncand ? v.table[ps_hash(((unsigned long long)ia << 32) | ib[k]) & v.mask] : 0ull;
+#pragma unroll
+            for (int k = 0; k < SWEEP_CAND; ++k) {
+                if (k >= ncand) break;
+                const unsigned long long key = ((unsigned long long)ia << 32) | ib[k];
+                bool present = first[k] == key;
+                if (!present && first[k] != PS_EMPTY) present = ps_contains(v.table, v.mask, key);       // a collision at the home slot: walk on
+                if (!present) {
+                    if (EMIT) out[dst + found] = make_uint2(ia, ib[k]);
+                    else if (found < (unsigned)ROW_CACHE) v.row_cache[(size_t)i * ROW_CACHE + found] = ib[k];
                     ++found;
                 }
             }
+            ncand = 0;
         };
-        // candidates four at a time (four loads in flight), in j order, until the first one that starts beyond maxx
+        auto test = [&](int j, const float4& b) {
+            if (fabsf(b.z - a.z) <= a.w + b.w) {
+                if (!EMIT) ++overlaps;
+                if (ncand == SWEEP_CAND) flush();
+                cand[ncand++][threadIdx.x] = (unsigned)j;
+            }
+        };
+        // candidates SWEEP_GROUP at a time (that many loads in flight), in j order, until the first one that starts beyond maxx
         int j = i + 1;
-        for (;;) {
-            if (j + 4 <= v.n) {
-                const float4 b0 = v.entries[j], b1 = v.entries[j + 1], b2 = v.entries[j + 2], b3 = v.entries[j + 3];
-                if (b0.x > a.y) break;
-                test(j, b0);
-                if (b1.x > a.y) { j += 1; break; }
-                test(j + 1, b1);
-                if (b2.x > a.y) { j += 2; break; }
-                test(j + 2, b2);
-                if (b3.x > a.y) { j += 3; break; }
-                test(j + 3, b3);
-                j += 4;
+        for (bool more = true; more;) {
+            if (j + SWEEP_GROUP <= v.n) {
+                float4 b[SWEEP_GROUP];
+#pragma unroll
+                for (int k = 0; k < SWEEP_GROUP; ++k) b[k] = v.entries[j + k];
+                int k = 0;
+#pragma unroll
+                for (; k < SWEEP_GROUP; ++k) {
+                    if (b[k].x > a.y) { more = false; break; }
+                    test(j + k, b[k]);
+                }
+                j += k;
             } else {
                 for (; j < v.n; ++j) { const float4 b = v.entries[j]; if (b.x > a.y) break; test(j, b); }
-                break;
+                more = false;
             }
         }
+        flush();
         const int len = j - i - 1;
         if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; if (found > (unsigned)ROW_CACHE) *v.cache_overflow = 1; }
     }
