@@ -20,6 +20,7 @@ struct SolverView {
     int4* q3;
     float2* acc;
     float2* dd;
+    float* qn;             // per slot: q2.x again (what a unit's follower reads instead of q2 and q3)
     const int* order;      // slot -> joint index
     unsigned* sw_imp;      // static-body productive words, [2][nstatic] (see static_word())
     unsigned* sw_disp;
@@ -103,6 +104,7 @@ private:
 
     // device state
     DevBuf<float4> sb_imp_, sb_disp_, sb_par_, q0_, q1_, q2_;
+    DevBuf<float> qn_;
     DevBuf<int4> q3_;
     DevBuf<float2> acc_, dd_;
     DevBuf<int> order_, static_slot_, flags_;

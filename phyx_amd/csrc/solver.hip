@@ -36,7 +36,7 @@ DeviceSolver::~DeviceSolver()
     if (stream_) (void)hipStreamSynchronize(stream_);
     drop_graphs();
     for (hipEvent_t e : bench_events_) (void)hipEventDestroy(e);
-    sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release();
+    sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release(); qn_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
     cc_parent_.release(); joint_comp_.release(); bin_tables_.release(); bin_tables_host_.release(); sb_small_.release(); cc_static_.release();
     cc_flags_.release(); comp_size_.release(); comp_units_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release(); jp_kind_.release(); partner_.release(); partner_first_.release();
@@ -94,7 +94,7 @@ SolverView DeviceSolver::view() const
     v.nb = nb_; v.nj = nj_; v.ncp = ncp_; v.nstatic = std::max(nstatic_, 1); v.ncolours = sched_.ncolours();
     v.fingerprint = hash_.p + hash_slot_; v.expected_fingerprint = raw_fingerprint_;
     v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = sb_par_.p;
-    v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p;
+    v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p; v.qn = qn_.p;
     v.order = order_.p;
     v.sw_imp = sw_.p; v.sw_disp = sw_.p + 2 * (size_t)v.nstatic;
     v.imp_active = flags_.p; v.disp_active = flags_.p + max_iters_;
@@ -233,7 +233,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
     PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));      // new table for this solve
     PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb)); PHX_TRY(sb_par_.reserve(nb));
-    PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj));
+    PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj)); PHX_TRY(qn_.reserve(nj));
     PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
     if (nj) PHX_HIP(hipMemcpyAsync(order_.p, sched_.order.data(), (size_t)nj * sizeof(int), hipMemcpyHostToDevice, stream_));
     if (nb) PHX_HIP(hipMemcpyAsync(static_slot_.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
@@ -568,7 +568,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
         PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs)); PHX_TRY(sb_par_.reserve(nbs));
-        PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs));
+        PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs)); PHX_TRY(qn_.reserve(njs));
         PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
     }
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));

@@ -181,6 +181,7 @@ static __global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int b
         v.q0[s] = make_float4(nx, ny, N.a1, N.a2);
         v.q1[s] = make_float4(F.a1, F.a2, F.cim, n_dst);
         v.q2[s] = make_float4(N.cim, p1.x, p1.y, p2.x);
+        v.qn[s] = N.cim;                        // (again, 4 bytes apart: all a unit's FOLLOWER needs of q2 / q3 — the rest is its leader's)
         v.q3[s] = make_int4(__float_as_int(p2.y), j.body1, j.body2, s1 >= 0 ? s1 : s2);
         v.acc[s] = make_float2(j.normal_accumulated_impulse, j.friction_accumulated_impulse);
         v.dd[s] = make_float2(n_dst_disp, 0.f);
@@ -189,15 +190,11 @@ static __global__ void __launch_bounds__(256) k_pack_refresh(SolverView v, int b
 
 // ---- PreStepJoints (ref: Solver.cpp:697-758), one class: a lane applies its unit's leader, then its follower ----------
 // (a class = `leaders` leader slots followed by `followers` follower slots; follower i belongs to leader i, schedule.h)
-__device__ __forceinline__ void prestep_one(const SolverView& v, int s, float4& B1, float4& B2, bool& st1, bool& st2, int& b1, int& b2)
+__device__ __forceinline__ void prestep_one(const SolverView& v, int s, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2, bool st1, bool st2)
 {
-    const float4 a = v.q0[s], b = v.q1[s], c = v.q2[s];
-    const int4 k = v.q3[s];
+    const float4 a = v.q0[s], b = v.q1[s];
     const float2 acc = v.acc[s];
-    const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
-    st1 = (im1 == 0.f && ii1 == 0.f); st2 = (im2 == 0.f && ii2 == 0.f);
     const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
-    if (b1 < 0) { b1 = k.y; b2 = k.z; if (!st1) B1 = v.sb_imp[b1]; if (!st2) B2 = v.sb_imp[b2]; }      // (the follower shares the leader's bodies)
     if (!st1) {
         B1.x += (nx * im1) * acc.x; B1.y += (ny * im1) * acc.x; B1.z += (a.z * ii1) * acc.x;
         B1.x += (tx * im1) * acc.y; B1.y += (ty * im1) * acc.y; B1.z += (b.x * ii1) * acc.y;
@@ -211,13 +208,17 @@ __device__ __forceinline__ void prestep_one(const SolverView& v, int s, float4& 
 static __global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin, int leaders, int followers)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
+        const float4 c = v.q2[begin + i];                  // the unit's bodies and their masses: the leader's record serves both joints
+        const int4 k = v.q3[begin + i];
+        const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(k.x);
+        const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
         float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1;
-        bool st1 = false, st2 = false;
-        int b1 = -1, b2 = -1;
-        prestep_one(v, begin + i, B1, B2, st1, st2, b1, b2);
-        if (i < followers) prestep_one(v, begin + leaders + i, B1, B2, st1, st2, b1, b2);
-        if (!st1) v.sb_imp[b1] = B1;
-        if (!st2) v.sb_imp[b2] = B2;
+        if (!st1) B1 = v.sb_imp[k.y];
+        if (!st2) B2 = v.sb_imp[k.z];
+        prestep_one(v, begin + i, B1, B2, im1, ii1, im2, ii2, st1, st2);
+        if (i < followers) prestep_one(v, begin + leaders + i, B1, B2, im1, ii1, im2, ii2, st1, st2);
+        if (!st1) v.sb_imp[k.y] = B1;
+        if (!st2) v.sb_imp[k.z] = B2;
     }
 }
 
@@ -247,10 +248,14 @@ __device__ __forceinline__ void wave_tag_update(unsigned* words, bool want, int 
 // the constants and accumulators of one slot, loaded up front (nothing here depends on the body gathers)
 struct HbmJoint { float4 a, f, c; int4 k; float2 acc, d; };
 
-__device__ __forceinline__ HbmJoint hbm_load(const SolverView& v, int s, bool imp_on, bool disp_on)
+__device__ __forceinline__ HbmJoint hbm_load(const SolverView& v, int s, bool imp_on, bool disp_on, bool follower)
 {
     HbmJoint q;
-    q.k = v.q3[s]; q.c = v.q2[s]; q.a = v.q0[s];
+    if (follower) {                                        // of q2 / q3 a follower needs its own 1 / (normal mass) only: 4 bytes instead of 32
+        q.k = make_int4(0, 0, 0, 0);
+        q.c = make_float4(v.qn[s], 0.f, 0.f, 0.f);
+    } else { q.k = v.q3[s]; q.c = v.q2[s]; }
+    q.a = v.q0[s];
     q.f = make_float4(0.f, 0.f, 0.f, 0.f); q.acc = make_float2(0.f, 0.f); q.d = make_float2(0.f, 0.f);
     if (imp_on) { q.f = v.q1[s]; q.acc = v.acc[s]; }
     if (disp_on) q.d = v.dd[s];
@@ -259,13 +264,13 @@ __device__ __forceinline__ HbmJoint hbm_load(const SolverView& v, int s, bool im
 
 // one joint of a unit on the body state the lane holds in registers (ref: Solver.cpp:790-896 impulses, :960-1005 displacement)
 __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& q, int colour, int iter, bool imp_on, bool disp_on,
-                                          float4& B1, float4& B2, float4& D1, float4& D2, bool st1, bool st2, int ss, bool sp_imp, bool sp_disp,
+                                          float4& B1, float4& B2, float4& D1, float4& D2, float im1, float ii1, float im2, float ii2, bool st1, bool st2, int ss,
+                                          bool sp_imp, bool sp_disp,
                                           bool& any_imp, bool& any_disp, bool& tag_imp, bool& tag_disp, bool& dirty_imp, bool& dirty_disp)
 {
     // sp_imp / sp_disp: 'the unit's static body was productive' (static_productive) — read once per unit: a class cannot
     // change what the test returns for that class (tags raised in it carry the class itself, which is not 'earlier')
     const float4 a = q.a, f = q.f, c = q.c;
-    const float im1 = c.y, ii1 = c.z, im2 = c.w, ii2 = __int_as_float(q.k.x);
     const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
     if (imp_on) {
         // ref: Solver.cpp:790-798
@@ -346,8 +351,8 @@ static __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
         const bool has2 = i < followers;
         const int s0 = begin + i, s1 = begin + leaders + i;
-        HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on), q1{};
-        if (has2) q1 = hbm_load(v, s1, imp_on, disp_on);
+        HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on, false), q1{};
+        if (has2) q1 = hbm_load(v, s1, imp_on, disp_on, true);
         const int b1 = q0.k.y, b2 = q0.k.z, ss = q0.k.w;
         float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
         if (imp_on) { B1 = v.sb_imp[b1]; B2 = v.sb_imp[b2]; }
@@ -358,11 +363,11 @@ static __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView 
         bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
         const bool sp_imp = imp_on && (st1 || st2) && static_productive(v.sw_imp, v.nstatic, ss, iter, colour);
         const bool sp_disp = disp_on && (st1 || st2) && static_productive(v.sw_disp, v.nstatic, ss, iter, colour);
-        solve_one(v, s0, q0, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        solve_one(v, s0, q0, colour, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
         if (has2) {                                    // a static body's record is never stored: the follower must see it untouched
             if (st1) { B1 = S1; D1 = T1; }
             if (st2) { B2 = S2; D2 = T2; }
-            solve_one(v, s1, q1, colour, iter, imp_on, disp_on, B1, B2, D1, D2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+            solve_one(v, s1, q1, colour, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
         }
         if (dirty_imp) { if (!st1) v.sb_imp[b1] = B1; if (!st2) v.sb_imp[b2] = B2; }
         if (dirty_disp) { if (!st1) v.sb_disp[b1] = D1; if (!st2) v.sb_disp[b2] = D2; }
