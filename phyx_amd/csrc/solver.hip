@@ -481,11 +481,13 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         const unsigned* ids = sort_vals_[where].p + lds_slots;
         PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_degree_.reserve(nbs + 1));
         PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs));
-        PHX_TRY(jp_small_.reserve(2 * JP_MAX_COLOURS + 8)); PHX_TRY(jp_kind_.reserve(rest)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
+        PHX_TRY(jp_small_.reserve(2 * JP_MAX_COLOURS + 8)); PHX_TRY(jp_kind_.reserve(njs)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
         PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
-        PHX_TRY(jp_ent_.reserve(rest)); PHX_TRY(jp_succ_.reserve(rest)); PHX_TRY(jp_pred_.reserve(rest)); PHX_TRY(jp_colour_b_.reserve(rest));
-        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(rest)); PHX_TRY(jp_vals_[k].reserve(rest)); PHX_TRY(jp_list_[k].reserve((size_t)rest * JP_SUBLISTS)); }
-        PHX_TRY(jp_adj_.reserve(2 * (size_t)rest)); PHX_TRY(jp_ent_comp_.reserve(rest));
+        // (sized by the joint count, not by the group's: while a world settles the HBM group grows every step, and regrowing a score
+        //  of arrays — hipMalloc + hipFree each — cost 3 ms whenever it crossed a capacity)
+        PHX_TRY(jp_ent_.reserve(njs)); PHX_TRY(jp_succ_.reserve(njs)); PHX_TRY(jp_pred_.reserve(njs)); PHX_TRY(jp_colour_b_.reserve(njs));
+        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(njs)); PHX_TRY(jp_vals_[k].reserve(njs)); PHX_TRY(jp_list_[k].reserve((size_t)njs * JP_SUBLISTS)); }
+        PHX_TRY(jp_adj_.reserve(2 * (size_t)njs)); PHX_TRY(jp_ent_comp_.reserve(njs));
         JpView jv{};
         jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = cc_static_.p; jv.nb = nb;
         jv.ent = jp_ent_.p; jv.offset = jp_offset_.p; jv.cursor = jp_cursor_.p; jv.adj = jp_adj_.p; jv.ent_comp = jp_ent_comp_.p;
@@ -502,7 +504,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         hipLaunchKernelGGL(k_jp_fill, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
         hipLaunchKernelGGL(k_jp_lists, dim3(std::max(1, std::min(div_up(2 * rest, 256), 8192))), dim3(256), 0, stream_, jv);
         {   // round 0's frontier: flags, scan, compaction
-            PHX_TRY(jp_seed_.reserve((size_t)rest + 1));
+            PHX_TRY(jp_seed_.reserve((size_t)njs + 1));
             hipLaunchKernelGGL(k_jp_seed_flags, dim3(grid_for(rest + 1)), dim3(256), 0, stream_, jv, jp_seed_.p);
             PHX_TRY(device_exclusive_scan(jp_seed_.p, rest + 1, nullptr, sort_scan_, stream_));
             hipLaunchKernelGGL(k_jp_seed, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_seed_.p, jp_list_[0].p);
