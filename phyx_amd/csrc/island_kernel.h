@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     __syncthreads();
     for (int i = tid; i < 4 * NB; i += T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
     const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
+    const bool wave_static = __any(live && (st1 || st2));      // (wave-uniform, fixed for the solve)
     __syncthreads();
     PHX_ISL_STAMP(2);
 
@@ -262,49 +263,59 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
             const unsigned long long ts0 = TRACE ? __builtin_readcyclecounter() : 0ull;
             const bool working = TRACE && __any(col == c);
             if (col == c) {
-                if (imp_on) {
+                // one unit, one sweep half: `s1` / `s2` = the unit's bodies are static.  Called twice below: with the lane's real
+                // flags, and — for a wave none of whose units touches a static body, i.e. almost every wave — with constants,
+                // which folds the tag lookups, the restore copies, their selects and a dozen exec-mask branches away.
+                auto imp_step = [&](const bool s1, const bool s2, const bool two) {
                     float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
                     bool prod0 = false, prod1 = false;
                     const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-                    const bool sp1 = st1 && static_productive_lds(swi, l1, it, c), sp2 = st2 && static_productive_lds(swi, l2, it, c);
-                    bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod0);
-                    if (has2) {
+                    const bool sp1 = s1 && static_productive_lds(swi, l1, it, c), sp2 = s2 && static_productive_lds(swi, l2, it, c);
+                    bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
+                    if (two) {
                         if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
-                        if (st1) B1 = S1;
-                        if (st2) B2 = S2;
-                        touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod1);
+                        if (s1) B1 = S1;
+                        if (s2) B2 = S2;
+                        touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
                     }
                     if (prod0 || prod1) {
                         flag_imp[it & 1] = 1;
-                        if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                        if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+                        if (s1) atomicMax(&swi[it & 1][l1], static_word(it, c));
+                        if (s2) atomicMax(&swi[it & 1][l2], static_word(it, c));
                     }
                     if (touched) {
-                        if (!st1) body_store(imp, l1, B1);
-                        if (!st2) body_store(imp, l2, B2);
+                        if (!s1) body_store(imp, l1, B1);
+                        if (!s2) body_store(imp, l2, B2);
                     }
-                }
-                if (disp_on) {
+                };
+                auto disp_step = [&](const bool s1, const bool s2, const bool two) {
                     float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
                     bool prod0 = false, prod1 = false;
                     const float4 S1 = D1, S2 = D2;
-                    const bool sp1 = st1 && static_productive_lds(swd, l1, it, c), sp2 = st2 && static_productive_lds(swd, l2, it, c);
-                    bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod0);
-                    if (has2) {
+                    const bool sp1 = s1 && static_productive_lds(swd, l1, it, c), sp2 = s2 && static_productive_lds(swd, l2, it, c);
+                    bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
+                    if (two) {
                         if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
-                        if (st1) D1 = S1;
-                        if (st2) D2 = S2;
-                        touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, st1, st2, sp1, sp2, it, prod1);
+                        if (s1) D1 = S1;
+                        if (s2) D2 = S2;
+                        touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
                     }
                     if (prod0 || prod1) {
                         flag_disp[it & 1] = 1;
-                        if (st1) atomicMax(&swd[it & 1][l1], static_word(it, c));
-                        if (st2) atomicMax(&swd[it & 1][l2], static_word(it, c));
+                        if (s1) atomicMax(&swd[it & 1][l1], static_word(it, c));
+                        if (s2) atomicMax(&swd[it & 1][l2], static_word(it, c));
                     }
                     if (touched) {
-                        if (!st1) body_store(disp, l1, D1);
-                        if (!st2) body_store(disp, l2, D2);
+                        if (!s1) body_store(disp, l1, D1);
+                        if (!s2) body_store(disp, l2, D2);
                     }
+                };
+                if (wave_static) {
+                    if (imp_on) imp_step(st1, st2, has2);
+                    if (disp_on) disp_step(st1, st2, has2);
+                } else {
+                    if (imp_on) imp_step(false, false, has2);
+                    if (disp_on) disp_step(false, false, has2);
                 }
             }
             const unsigned long long ts1 = TRACE ? __builtin_readcyclecounter() : 0ull;
