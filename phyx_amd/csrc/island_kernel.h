@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     // static-tag words [imp|disp][parity][body]; during set-up the same 12 KB hold {invMass, invInertia, pos} per body
     __shared__ __attribute__((aligned(16))) unsigned sw_raw[4 * NB];
     __shared__ unsigned char is_st[NB];
-    __shared__ int flag_imp[2], flag_disp[2];
+    __shared__ int flag_imp[3], flag_disp[3];     // 'some joint was productive in sweep it': slot it % 3
     unsigned (*swi)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw);
     unsigned (*swd)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw + 2 * NB);
     float4* par = reinterpret_cast<float4*>(sw_raw);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     unsigned loc = 0;
     int col = -1;
     if (live) { loc = iv.slot_local[us.x]; col = iv.slot_colour[us.x]; }
-    if (tid < 2) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
+    if (tid < 3) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
 
     float4 rec_imp[BI], rec_disp[BI], rec_par[BI];
 #pragma unroll
@@ -258,7 +258,10 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     for (int it = 0; it < iters; ++it) {
         const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
         if (!imp_on && !disp_on) break;
-        if (tid == 0) { flag_imp[(it + 1) & 1] = 0; flag_disp[(it + 1) & 1] = 0; }   // read last at the end of sweep it-1
+        // three slots in rotation: the one cleared here for the next sweep was read last at the end of sweep it - 2, and every
+        // class step of sweep it - 1 has put a barrier in between — so the sweep needs no barrier of its own at its end
+        const int slot = it % 3;
+        if (tid == 0) { const int next = slot == 2 ? 0 : slot + 1; flag_imp[next] = 0; flag_disp[next] = 0; }
         for (int c = 0; c < ncol; ++c) {
             const unsigned long long ts0 = TRACE ? __builtin_readcyclecounter() : 0ull;
             const bool working = TRACE && __any(col == c);
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                         touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
                     }
                     if (prod0 || prod1) {
-                        flag_imp[it & 1] = 1;
+                        flag_imp[slot] = 1;
                         if (s1) atomicMax(&swi[it & 1][l1], static_word(it, c));
                         if (s2) atomicMax(&swi[it & 1][l2], static_word(it, c));
                     }
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                         touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
                     }
                     if (prod0 || prod1) {
-                        flag_disp[it & 1] = 1;
+                        flag_disp[slot] = 1;
                         if (s1) atomicMax(&swd[it & 1][l1], static_word(it, c));
                         if (s2) atomicMax(&swd[it & 1][l2], static_word(it, c));
                     }
@@ -328,9 +331,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                 } else { tw_idle += ts2 - ts0; ++tw_nidle; }
             }
         }
-        if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[it & 1] != 0; }
-        if (disp_on) { done_disp = it + 1; disp_alive = flag_disp[it & 1] != 0; }
-        __syncthreads();
+        if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[slot] != 0; }        // (behind the last class step's barrier)
+        if (disp_on) { done_disp = it + 1; disp_alive = flag_disp[slot] != 0; }
     }
 
     PHX_ISL_STAMP(4);
