@@ -201,7 +201,7 @@ int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap,
  * Gauss-Seidel problem (body-disjoint from every other group, static bodies aside) with its own early exit and
  * its own copy of the static bodies' lastIteration tags — the counterpart of the reference's islands
  * (ref: Solver.cpp:86-91).  The first *lds_group_count groups ran one-workgroup-per-group out of LDS, the rest
- * (at most one) colour by colour out of HBM.  Single island mode always reports one group. */
+ * (at most one) class by class out of HBM.  Single island mode always reports one group. */
 int phx_solver_get_groups(phx_solver* s, int32_t* group_offsets, int32_t offsets_cap, int32_t* group_count, int32_t* lds_group_count);
 
 /* RefreshJoints output for joint `joint_index` of the last solve (ref: Solver.cpp:592-695), expanded

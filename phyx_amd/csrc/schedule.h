@@ -8,7 +8,7 @@
 //   * a GROUP is a run of consecutive colours whose joints share no dynamic body with any other group
 //     (GatherIslands' islands, coalesced into workgroup-sized bins) — groups run in parallel workgroups,
 //     each keeping its bodies in LDS for the whole solve.  The last group may be an "HBM group": whatever does
-//     not fit a workgroup (one huge island) is solved colour by colour out of HBM.
+//     not fit a workgroup (one huge island) is solved class by class out of HBM.
 // Static bodies (invMass == invInertia == 0, ref: Solver.cpp:304) never conflict; each group keeps a private
 // copy of their lastIteration tag.
 #pragma once
@@ -101,11 +101,11 @@ struct LdsCaps { int max_joints = 512, max_units = 256, max_bodies = 768, max_co
 // (an LDS group's local body table lists its static bodies first, so a static body's local index is also its
 //  slot in the group's small static-tag table)
 
-// Colouring rule (every group, host and device builders alike): joints take their colour FIRST-FIT IN ORDER OF DECREASING
-// colour_priority(id, joint index) — a fixed pseudo-random order.  Sequentially that is one pass over the sorted
-// joints; in parallel it is what Jones-Plassmann rounds compute (a joint colours itself once it has the highest
-// priority among the uncoloured joints on both of its dynamic bodies), which needs ~log n rounds where joint-index order
-// would need one round per body of a stacked column.  Inside a colour the slots keep joint-index order.
+// Colouring rule (every group, host and device builders alike; stated in full above): UNITS take their class FIRST-FIT IN ORDER
+// OF DECREASING colour_priority(id, joint index) of their leader — a fixed pseudo-random order.  Sequentially that is one pass
+// over the sorted units; in parallel it is a dependency graph a few dozen rounds deep (a unit takes its class once every
+// higher-priority unit on its dynamic bodies has one), where joint-index order would need one round per body of a stacked
+// column.  The layout of a class: the leaders that have a follower, the single leaders, the followers in their leaders' order.
 
 // One HBM group holding every joint.  `prio_id` (optional, per joint): priority ids; the joint index itself if null.
 void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out,

@@ -132,7 +132,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
     stats_.recoloured = 0;
     ncp_ = ncp;
-    // Single = one coupled system swept colour by colour out of HBM; every other island mode lets the schedule
+    // Single = one coupled system swept class by class out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     const bool device_builder = gpu_builder_ && !force_host_builder_;
@@ -288,7 +288,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
 // ---------------------------------------------------------------------------------------------------
 // device schedule builder (kernels: schedule_kernels.h)
 
-constexpr int JP_BATCH = 8;          // Jones-Plassmann rounds queued between two looks at the 'joints left' counter
+constexpr int JP_BATCH = 8;          // colouring rounds queued between two looks at the frontier sizes
 constexpr int JP_ROUNDS_MAX = 512;
 
 int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
@@ -474,7 +474,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     const int rest = nj - lds_slots;
 
     // 6. the HBM group (components too big for a workgroup, static-static joints; every joint in Single mode): the same
-    //    first-fit-by-priority colouring, one launch per Jones-Plassmann round, then a stable sort by colour
+    //    first-fit-by-priority colouring — a walk of the dependency graph, one launch per frontier — then a stable sort by class
     nstatic_ = 0;
     sc.hbm_body_count = 0;
     if (rest > 0) {
@@ -614,7 +614,7 @@ int DeviceSolver::materialise_schedule()
 }
 
 // The launch sequence of one SolveJoints, in three capturable segments (no sync, no allocation inside):
-//   pre    PrepareBodies, PrepareJoints+RefreshJoints, PreStepJoints colour by colour
+//   pre    PrepareBodies, PrepareJoints+RefreshJoints, PreStepJoints class by class
 //   sweeps `iters` x colours fused impulse+displacement launches
 //   post   FinishJoints, FinishBodies
 int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj)
@@ -623,7 +623,7 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     // (the control words — productive flags, static tags, island counters — were cleared by launch_fingerprint's
     //  fingerprint kernel, which every solve runs first)
     // the HBM group (if any): PrepareBodies for the bodies it touches, PrepareJoints + RefreshJoints over its slots,
-    // PreStep colour by colour.  Groups solved in LDS read and write the caller's records directly.
+    // PreStep class by class.  Groups solved in LDS read and write the caller's records directly.
     const int hbm_bodies = sched_.hbm_body_count;
     if (nj && owns_hbm_group()) {
         hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies, (const int*)hbm_body_list_.p,

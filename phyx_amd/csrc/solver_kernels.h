@@ -223,7 +223,7 @@ static __global__ void __launch_bounds__(256) k_prestep(SolverView v, int begin,
 }
 
 // ---- SolveJointsImpulses + SolveJointsDisplacement (ref: Solver.cpp:760-1018), one colour, one sweep
-// Launch shape: one wavefront per workgroup (64 lanes, one joint per lane).  A colour of the 200k-box scene has
+// Launch shape: one wavefront per workgroup (64 lanes, one unit per lane).  A class of the 200k-box scene has
 // only 2e4-1e5 joints, i.e. a few waves per CU: the kernel is bound by the dependent-load chain
 // (slot -> body index -> body state), not by bandwidth, so (1) single-wave workgroups spread the joints over all
 // 256 CUs and (2) every load that does not depend on the body index is issued up front, before the skip test —
