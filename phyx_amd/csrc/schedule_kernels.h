@@ -215,8 +215,8 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __shared__ unsigned long long used[NB];              // candidate A (smallest free colour): colours taken per local body
     __shared__ unsigned long long used_b[NB];            // candidate B (two-ended, schedule.h)
     __shared__ int degree[NB];                           // units of the bin on each local body
-    __shared__ unsigned long long seen_a[LANES], seen_b[LANES];  // per component of the bin: colours in use under either candidate
-    __shared__ unsigned char bad_b[LANES];
+    __shared__ unsigned long long seen_a[T], seen_b[T];  // per component of the bin (at most one per unit): classes in use under either candidate
+    __shared__ unsigned char bad_b[T];                    // (sized by T, not by the lanes: with them the small shape's LDS is < 40 KB = 4 workgroups per CU)
     __shared__ unsigned scan_lds[LANES / 64];
     __shared__ unsigned with_n[64], single_n[64];        // per class: leaders that have a follower / single leaders
     __shared__ unsigned class_begin[64], unit_begin[64]; // per class: first slot (relative), first unit
@@ -227,7 +227,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
     for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
     for (int i = tid; i < NB; i += LANES) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
-    seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0;
+    if (tid < T) { seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0; }
     for (int i = tid; i < (LANES / 64) * 64; i += LANES) { wave_with[i] = 0; wave_single[i] = 0; }
     if (tid == 0) { bad = 0; n_col = 0; }
     __syncthreads();
