@@ -65,7 +65,7 @@ def test_reference_demo_scenes_lockstep(oracle, built_lib, scene):
 
 def test_differential_fuzz_random_worlds(built_lib):
     """tools/fuzz.py: random worlds (random sizes, angles, overlaps, static shelves, random island mode and iteration counts)
-    in lockstep with the oracle, every byte compared after every step.  40 seeds here; 46 000 (and 870 of the --big kind) were run for round 1, 25 000 + 500 of them on the final code."""
+    in lockstep with the oracle, every byte compared after every step.  40 seeds here; 46 000 (and 870 of the --big kind) were run for round 1, 30 000 + 750 on round 2's code."""
     import os
     import subprocess
     import sys
@@ -258,3 +258,27 @@ def test_world_api_errors(built_lib):
         w.set_shard(3, 2)
     w.Update(1.0 / 60.0, Configuration())          # empty world steps fine
     assert w.counts() == (0, 0, 0, 0)
+
+
+def test_debugging_knobs_do_not_change_results(built_lib):
+    """The readback mailbox, the speculative solve / deferred build check and the device schedule builder are performance
+    mechanisms: with each of them switched off (PHX_NO_MAILBOX, PHX_NO_SPECULATION, PHX_SCHEDULE_BUILDER=host) a world that
+    rebuilds its schedule every step, merges islands and falls back to the host builder (a 90-box clique) must produce the very
+    same bytes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def digest(extra_env, mode):
+        env = dict(os.environ)
+        env.update(extra_env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "knob_check.py"), str(mode)], cwd=root, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return r.stdout.strip().splitlines()[-1]
+    for mode in (phyx_amd.ISLAND_SINGLE, phyx_amd.ISLAND_MULTIPLE_SLOPPY):
+        want = digest({}, mode)
+        assert len(want) == 64
+        for knob in ({"PHX_NO_MAILBOX": "1"}, {"PHX_NO_SPECULATION": "1"}, {"PHX_SCHEDULE_BUILDER": "host"}):
+            assert digest(knob, mode) == want, (knob, mode)
