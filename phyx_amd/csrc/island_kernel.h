@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     float4* par = reinterpret_cast<float4*>(sw_raw);
 
     const int group = iv.first + (int)blockIdx.x * iv.stride;
+    if (iv.stamp_begin) solve_stamp_begin(v.stamps);      // (no HBM group in front of this launch: it is the solve's first kernel)
     PHX_ISL_STAMP(0);
     const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
     // TRACE: per wave, shader cycles spent in class steps {working: in the unit update, then at the barrier; idle: whole step}
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     PHX_ISL_STAMP(4);
     // results go straight back into the caller's records (commit-gated like k_finish_*); the refreshed constants
     // never leave the registers
-    if (*v.fingerprint != v.expected_fingerprint) return;
+    if (*v.fingerprint != v.expected_fingerprint) { if (iv.stamp_end) solve_stamp_end(v.stamps); return; }
     if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
         phx_contact_joint& out = joints[jid0];
         out.normal_accumulated_impulse = q0.accN;
@@ -358,6 +359,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
         b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
     }
+    if (iv.stamp_end) solve_stamp_end(v.stamps);           // (no HBM group behind this launch: it is the solve's last kernel)
     if (tid == 0) {
         const int slot = group % ISL_STAT_SLOTS;
         atomicMax(&iv.executed[2 * slot], done_imp);

@@ -24,6 +24,7 @@ struct SolverView {
     const int* order;      // slot -> joint index
     unsigned* sw_imp;      // static-body productive words, [2][nstatic] (see static_word())
     unsigned* sw_disp;
+    unsigned long long* stamps;   // [0] min clock of the solve's first kernel, [1] max clock of its last (100 MHz wall clock)
     int* imp_active;       // [iter] 1 if any joint was productive in sweep `iter`
     int* disp_active;
 };

@@ -74,7 +74,7 @@ int DeviceSolver::init()
     PHX_TRY(hash_.reserve(2));
     PHX_HIP(hipMemsetAsync(hash_.p, 0, 2 * sizeof(unsigned long long), stream_));
     PHX_TRY(isl_stats_.reserve(2 * ISL_STAT_SLOTS));
-    PHX_TRY(isl_visits_.reserve(ISL_STAT_SLOTS));
+    PHX_TRY(isl_visits_.reserve(ISL_STAT_SLOTS + 2));          // + the solve's two time stamps
     const char* g = getenv("PHX_GRAPHS");               // "1": replay the launch sequence from hipGraphs (measured: no gain on the
     use_graphs_ = g && g[0] == '1';                      // HBM path, 7 us slower per solve on the island path) — off by default
     const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
@@ -98,6 +98,7 @@ SolverView DeviceSolver::view() const
     v.order = order_.p;
     v.sw_imp = sw_.p; v.sw_disp = sw_.p + 2 * (size_t)v.nstatic;
     v.imp_active = flags_.p; v.disp_active = flags_.p + max_iters_;
+    v.stamps = isl_visits_.p + ISL_STAT_SLOTS;
     return v;
 }
 
@@ -627,7 +628,7 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     const int hbm_bodies = sched_.hbm_body_count;
     if (nj && owns_hbm_group()) {
         hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies, (const int*)hbm_body_list_.p,
-                           hbm_bodies, sb_imp_.p, sb_disp_.p, sb_par_.p);
+                           hbm_bodies, sb_imp_.p, sb_disp_.p, sb_par_.p, isl_visits_.p + ISL_STAT_SLOTS);
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
         for (size_t c = 0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
@@ -650,6 +651,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
     if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
         iv.first = shard_; iv.stride = shard_count_;
+        iv.stamp_begin = iv.stamp_end = owns_hbm_group() ? 0 : 1;      // (with an HBM group, its first and last kernels leave the stamps)
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_slots = unit_slots_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
         iv.trace = nullptr; iv.wave_trace = nullptr;
@@ -746,10 +748,9 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     last_key_ = key;
     const bool replay = graph_key_.valid && graph_key_ == key;
 
-    // Two events per solve, not four: an event record is a barrier packet of its own and idles the queue for ~5 us.  Normally the
-    // pair brackets the whole solve (phx_solve_stats.device_ms); inside bench() it brackets the sweeps (the dominant kernel's launch
-    // time the roofline is computed from) and device_ms reports those.
-    if (!time_sweeps_) PHX_HIP(hipEventRecord(ev_begin_, stream_));
+    // No HIP events around a solve: an event record is a barrier packet of its own and idles the queue for ~5 us.  The device time
+    // (phx_solve_stats.device_ms) comes from clock stamps the solve's first and last kernels leave (solve_stamp_begin / _end); only
+    // bench() brackets the sweeps with events — the live launch time its roofline is computed from — and device_ms reports those.
     {
         RoctxRange r("PrepareBodies + PrepareJoints + RefreshJoints + PreStepJoints (HBM group)");      // ref: Solver.cpp:70, 135, 146, 157
         if (replay) { if (graph_[0]) PHX_HIP(hipGraphLaunch(graph_[0], stream_)); }
@@ -767,7 +768,6 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
         if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
         else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
     }
-    if (!time_sweeps_) PHX_HIP(hipEventRecord(ev_end_, stream_));
     timed_sweeps_ = time_sweeps_;
     last_ci_ = ci; last_pi_ = pi;
     stats_pending_ = true;
@@ -879,7 +879,9 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     if (extra) PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_));
     PHX_TRY(rb_.add(flags.data(), flags_.p, flags.size() * sizeof(int), stream_));
     PHX_TRY(rb_.add(isl_slots, isl_stats_.p, sizeof isl_slots, stream_));
+    unsigned long long stamps[2] = {0, 0};
     PHX_TRY(rb_.add(visit_slots, isl_visits_.p, sizeof visit_slots, stream_));
+    PHX_TRY(rb_.add(stamps, isl_visits_.p + ISL_STAT_SLOTS, sizeof stamps, stream_));
     PHX_TRY(with_build());
     PHX_TRY(rb_.wait(stream_));
     settle_build();
@@ -899,9 +901,10 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     stats_.displacement_iterations = nj_ ? std::max(h_disp, isl[1]) : std::min(last_pi_, 1);
     stats_.joint_visits = (long long)isl_visits + (long long)h_imp * hbm_joints;
     float ms = 0.f;
-    hipEvent_t e0 = timed_sweeps_ ? ev_sweep_begin_ : ev_begin_, e1 = timed_sweeps_ ? ev_sweep_end_ : ev_end_;
-    PHX_HIP(hipEventSynchronize(e1));                  // (already reached: the mailbox post ran behind it)
-    PHX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (timed_sweeps_) {
+        PHX_HIP(hipEventSynchronize(ev_sweep_end_));       // (already reached: the mailbox post ran behind it)
+        PHX_HIP(hipEventElapsedTime(&ms, ev_sweep_begin_, ev_sweep_end_));
+    } else if (stamps[1] > stamps[0]) ms = (float)((double)(stamps[1] - stamps[0]) * 1e-5);      // 100 MHz ticks -> ms
     stats_.device_ms = ms;
     stats_pending_ = false;
     return PHX_OK;

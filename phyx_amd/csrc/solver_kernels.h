@@ -54,11 +54,19 @@ __device__ __forceinline__ float max_ref(float l, float r) { return l > r ? l : 
 
 __device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i >= n ? (n > 0 ? n - 1 : 0) : i); }
 
+// Device time of a solve (phx_solve_stats.device_ms) without HIP events — an event record is a barrier packet of its own that
+// idles the queue for ~5 us: the first kernel of the solve leaves the constant 100 MHz clock in stamps[0] (min), every workgroup
+// of its last kernel in stamps[1] (max).
+__device__ __forceinline__ void solve_stamp_begin(unsigned long long* stamps) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(&stamps[0], (unsigned long long)wall_clock64()); }
+__device__ __forceinline__ void solve_stamp_end(unsigned long long* stamps) { if (threadIdx.x == 0) atomicMax(&stamps[1], (unsigned long long)wall_clock64()); }
+
 // ---- PrepareBodies (ref: Solver.cpp:456-480) -----------------------------------------------------
 // `list` = the bodies the HBM group touches (islands solved in LDS read the records directly)
 static __global__ void __launch_bounds__(256) k_unpack_bodies(const phx_rigid_body* __restrict__ bodies, const int* __restrict__ list, int count,
-                                                       float4* __restrict__ sb_imp, float4* __restrict__ sb_disp, float4* __restrict__ sb_par)
+                                                       float4* __restrict__ sb_imp, float4* __restrict__ sb_disp, float4* __restrict__ sb_par,
+                                                       unsigned long long* __restrict__ stamps)
 {
+    solve_stamp_begin(stamps);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int i = list[k];
         const phx_rigid_body& b = bodies[i];
@@ -102,6 +110,7 @@ static __global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_conta
         const int i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
         if (i == 0) *next_out = 0ull;
         if (i < ISL_STAT_SLOTS) { cw.isl_visits[i] = 0ull; cw.isl_stats[2 * i] = 0; cw.isl_stats[2 * i + 1] = 0; }
+        if (i == 0) { cw.isl_visits[ISL_STAT_SLOTS] = ~0ull; cw.isl_visits[ISL_STAT_SLOTS + 1] = 0ull; }      // the solve's time stamps (solve_stamp)
         for (int k = i; k < cw.nflags; k += n) cw.flags[k] = 0;
         for (int k = i; k < cw.nsw; k += n) cw.sw[k] = 0u;
     }
@@ -398,7 +407,7 @@ static __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int 
 
 static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, phx_rigid_body* __restrict__ bodies)
 {
-    if (*v.fingerprint != v.expected_fingerprint) return;
+    if (*v.fingerprint != v.expected_fingerprint) { solve_stamp_end(v.stamps); return; }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int i = list[k];
         const float4 a = v.sb_imp[i], d = v.sb_disp[i];
@@ -406,6 +415,7 @@ static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, cons
         b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
         b.displacing_velocity.x = d.x; b.displacing_velocity.y = d.y; b.displacing_angular_velocity = d.z;
     }
+    solve_stamp_end(v.stamps);
 }
 
 } // namespace phx
