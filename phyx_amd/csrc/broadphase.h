@@ -30,7 +30,7 @@ private:
 
     int device_;
     hipStream_t stream_ = nullptr;
-    hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
+    DevBuf<unsigned long long> stamps_;      // [0] clock at the update's first kernel, [1] at its last (device_ms without HIP events)
     DevBuf<unsigned> keys_[2], idx_[2], hist_, row_count_, row_cache_;
     DevBuf<float4> entries_;
     DevBuf<unsigned long long> table_, small_;

@@ -36,8 +36,12 @@ __device__ __forceinline__ unsigned radix_float(float v)
 // (first kernel of an update: it also clears the update's counters and the hub-chunk counts — two dispatches fewer)
 __global__ void __launch_bounds__(256) k_build_keys(const phx_rigid_body* __restrict__ bodies, int n,
                                                     unsigned* __restrict__ keys, unsigned* __restrict__ idx,
-                                                    unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks)
+                                                    unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
+                                                    unsigned long long* __restrict__ stamps)
 {
+    // the update's device time without HIP events (an event record is a barrier packet of its own: ~5 us of idle queue): this, its
+    // first kernel, leaves the 100 MHz clock in stamps[0]; the count pass's mailbox post and the insert kernel raise stamps[1]
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = (unsigned long long)wall_clock64(); stamps[1] = 0ull; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nsmall; i += gridDim.x * blockDim.x) small[i] = 0ull;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) chunk_count[i] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -80,7 +84,7 @@ __device__ __forceinline__ bool ps_contains(const unsigned long long* __restrict
 }
 
 // keys are distinct and known to be absent
-__global__ void __launch_bounds__(256) k_ps_insert(unsigned long long* table, unsigned mask, const uint2* __restrict__ pairs, int n)
+__global__ void __launch_bounds__(256) k_ps_insert(unsigned long long* table, unsigned mask, const uint2* __restrict__ pairs, int n, unsigned long long* __restrict__ end_stamp)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long k = ((unsigned long long)pairs[i].x << 32) | pairs[i].y;
@@ -94,6 +98,7 @@ __global__ void __launch_bounds__(256) k_ps_insert(unsigned long long* table, un
             p = (p + 1) & mask;
         }
     }
+    if (end_stamp && threadIdx.x == 0) atomicMax(end_stamp, (unsigned long long)wall_clock64());      // (the update's last kernel)
 }
 
 __global__ void __launch_bounds__(256) k_ps_erase(unsigned long long* table, unsigned mask, const uint2* __restrict__ pairs, int n, int* erased)
@@ -383,10 +388,8 @@ DeviceBroadphase::~DeviceBroadphase()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
-    hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); scan_tiles_.release(); small_.release();
+    hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); scan_tiles_.release(); small_.release(); stamps_.release();
     new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release(); erase_count_.release();
-    if (ev_begin_) (void)hipEventDestroy(ev_begin_);
-    if (ev_end_) (void)hipEventDestroy(ev_end_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -394,8 +397,6 @@ int DeviceBroadphase::init()
 {
     PHX_TRY(use_device(device_));
     PHX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    PHX_HIP(hipEventCreate(&ev_begin_));
-    PHX_HIP(hipEventCreate(&ev_end_));
     PHX_TRY(small_.reserve(16 + 2 * STAT_SLOTS));
     PHX_TRY(erase_count_.reserve(1));
     PHX_HIP(hipMemsetAsync(erase_count_.p, 0, sizeof(int), stream_));
@@ -455,16 +456,16 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     // keep the table at most half full counting tombstones, before anything reads it
     if ((unsigned long long)(set_size_ + tombstones_) * 2 > table_cap_) PHX_TRY(resize_table((unsigned)std::max<long long>(4 * set_size_, 1024)));
 
-    PHX_HIP(hipEventRecord(ev_begin_, stream_));
+    PHX_TRY(stamps_.reserve(2));
     if (n == 0) {
-        PHX_HIP(hipEventRecord(ev_end_, stream_));
+        PHX_HIP(hipMemsetAsync(stamps_.p, 0, 2 * sizeof(unsigned long long), stream_));
         PHX_HIP(hipStreamSynchronize(stream_));
         stats_.candidate_tests = 0; stats_.overlapping_pairs = 0; stats_.new_pairs = 0; last_new_ = 0;
         stats_.set_size = (int)set_size_; have_update_ = true; ms_pending_ = true;
         return PHX_OK;
     }
 
-    hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap);
+    hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap, stamps_.p);
     int src = 0;
     PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
     sorted_ = src;
@@ -491,7 +492,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         int erased = 0;
         PHX_TRY(queue_erase_check(&erased));
         PHX_TRY(rb_.add(host_small, small_.p, sizeof host_small, stream_));
-        PHX_TRY(rb_.wait(stream_));
+        PHX_TRY(rb_.wait(stream_, stamps_.p + 1));
         PHX_TRY(settle_erase_check(erased));
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
         if (needed <= chunk_cap) break;
@@ -519,11 +520,10 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
             hipLaunchKernelGGL((k_sweep_rows<true>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p, total);
         if (host_small[2] & 0xFFFFFFFFull) hipLaunchKernelGGL((k_sweep_chunks<true>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
         // ref: Collider.cpp:313 / :341 — the emitted pairs join the persistent set
-        hipLaunchKernelGGL(k_ps_insert, dim3(grid_for((int)total)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)new_pairs_.p, (int)total);
+        hipLaunchKernelGGL(k_ps_insert, dim3(grid_for((int)total)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)new_pairs_.p, (int)total, stamps_.p + 1);
         PHX_HIP(hipGetLastError());
         set_size_ += total;
     }
-    PHX_HIP(hipEventRecord(ev_end_, stream_));
     // (not synchronised here: what follows on this stream — insertions' consumers, the next phase of a World — is ordered
     //  behind it; get_stats / get_new_pairs / get_sorted synchronise before they read)
     stats_.set_size = (int)set_size_;
@@ -628,10 +628,10 @@ int DeviceBroadphase::get_stats(phx_broadphase_stats* out)
     if (!have_update_) { set_error("no broadphase update has run yet"); return PHX_ERR_STATE; }
     PHX_TRY(use_device(device_));
     if (ms_pending_) {
-        PHX_HIP(hipStreamSynchronize(stream_));
-        float ms = 0.f;
-        PHX_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
-        stats_.device_ms = ms;
+        unsigned long long stamps[2] = {0, 0};
+        PHX_TRY(rb_.add(stamps, stamps_.p, sizeof stamps, stream_));
+        PHX_TRY(rb_.wait(stream_));
+        stats_.device_ms = stamps[1] > stamps[0] ? (double)(stamps[1] - stamps[0]) * 1e-5 : 0.0;      // 100 MHz ticks -> ms
         ms_pending_ = false;
     }
     if (erase_unchecked_) {

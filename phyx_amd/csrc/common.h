@@ -166,12 +166,13 @@ struct RoctxRange {
 // work of the stream has finished.  NOTE: sources are read when wait() runs, not when add() is called — nothing queued
 // between the two may overwrite them.  Batches with a large item (> MAIL_WORDS in total) fall back to DMAs + a stream wait.
 struct MailItem { const unsigned* src; unsigned off, words; };
-struct MailArgs { MailItem it[16]; int count; unsigned seq; };
+struct MailArgs { MailItem it[16]; int count; unsigned seq; unsigned long long* stamp; };      // stamp (may be null): receives max(itself, the 100 MHz clock)
 
 static __global__ void __launch_bounds__(1024) k_post_mail(MailArgs a, unsigned* __restrict__ host_words, unsigned* __restrict__ host_seq)
 {
     for (int i = 0; i < a.count; ++i)
         for (unsigned w = threadIdx.x; w < a.it[i].words; w += blockDim.x) host_words[a.it[i].off + w] = a.it[i].src[w];
+    if (a.stamp && threadIdx.x == 0) atomicMax(a.stamp, (unsigned long long)wall_clock64());      // 'the stream got this far at ...' (device timing without events)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -204,12 +205,13 @@ public:
         if ((bytes & 3u) || (reinterpret_cast<uintptr_t>(src) & 3u)) odd_ = true;
         return PHX_OK;
     }
-    int wait(hipStream_t stream)
+    // `stamp` (device pointer, may be null): the post kernel also leaves the clock there (atomicMax) — see k_post_mail
+    int wait(hipStream_t stream, unsigned long long* stamp = nullptr)
     {
         const bool mail = count_ > 0 && !odd_ && !dma_ && used_ <= MAIL_WORDS * 4 && !no_mail();
         if (mail) {
             MailArgs a;
-            a.count = count_; a.seq = ++seq_;
+            a.count = count_; a.seq = ++seq_; a.stamp = stamp;
             for (int i = 0; i < count_; ++i) a.it[i] = MailItem{static_cast<const unsigned*>(items_[i].src), (unsigned)(items_[i].off / 4), (unsigned)(items_[i].bytes / 4)};
             hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(used_ > 1024 ? 1024 : 64), 0, stream, a, reinterpret_cast<unsigned*>(pin_), seq_word());
             PHX_HIP(hipGetLastError());
