@@ -130,6 +130,8 @@ private:
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;
     bool time_sweeps_ = false, timed_sweeps_ = false;   // bench(): the event pair brackets the sweeps instead of the whole solve
+    const unsigned* sw_cleared_ = nullptr;          // the static-tag table launch_fingerprint's kernel cleared for the solve in flight
+    size_t sw_cleared_words_ = 0;
     unsigned replays_ = 0;                          // solves repeated because nothing could be committed (stale or spoiled schedule)
     unsigned cc_builds_ = 0;
     DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;

@@ -108,7 +108,8 @@ int DeviceSolver::launch_fingerprint(const phx_rigid_body* d_bodies, int nb, con
     // of the next solve's fingerprint (the two accumulators alternate)
     ControlWords cw{};
     cw.flags = flags_.p; cw.nflags = flags_.p ? 2 * max_iters_ : 0;
-    cw.sw = sw_.p; cw.nsw = sw_.p ? 4 * std::max(nstatic_, 1) : 0;
+    cw.sw = sw_.p; cw.nsw = sw_.p ? (int)std::min<size_t>(sw_.cap, 1u << 30) : 0;      // (the whole table: a rebuilt schedule may use more of it)
+    sw_cleared_ = sw_.p; sw_cleared_words_ = (size_t)cw.nsw;
     cw.isl_stats = isl_stats_.p; cw.isl_visits = isl_visits_.p;
     int slot = hash_slot_ ^ 1;
     if (use_graphs_) {        // captured graphs have the accumulator's address baked in: one fixed slot, cleared by a memset
@@ -232,7 +233,9 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_TRY(order_.reserve(std::max(nj, 1)));
     PHX_TRY(static_slot_.reserve(std::max(nb, 1)));
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
-    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));      // new table for this solve
+    // new table for this solve — already cleared by this solve's fingerprint kernel unless it has just been (re)allocated
+    if (sw_.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
+        PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
     PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb)); PHX_TRY(sb_par_.reserve(nb));
     PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj)); PHX_TRY(qn_.reserve(nj));
     PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
@@ -575,7 +578,9 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
     }
     PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
-    PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));      // new table for this solve
+    // new table for this solve — already cleared by this solve's fingerprint kernel unless it has just been (re)allocated
+    if (sw_.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
+        PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
     lap("rest");
     sched_ = std::move(sc);
     return PHX_OK;
