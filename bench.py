@@ -205,11 +205,19 @@ def main():
         alg = algorithmic_bytes(main_tot, args.steps) / launches
         kname = "k_solve_islands" if lds else "k_solve_colour"
         tbytes = traffic.get(kname)
+        tsource = traffic.get("file")
+        # the PMC passes profiled the default workload at N = 1: a launch of rank 0 at N > 1 covers only its own groups (its share
+        # of the joint visits), and any other scene size was not profiled at all
+        if (args.columns, args.rows) != (1000, 200):
+            tbytes, tsource = None, "not profiled for this scene size"
+        elif tbytes and world > 1:
+            tbytes *= main_tot["visits"] / max(visits_all, 1)
+            tsource = "%s, scaled by rank 0's share of the joint visits (%d of %d ranks' groups)" % (tsource, 1, world)
         roof = {"bound": "hbm",
                 "kernel": "k_solve_islands<256,768> (one workgroup per island group, one lane per unit of two joints, all sweeps in LDS)" if lds else "k_solve_colour<impulse,displacement>",
                 "achieved": (tbytes / (launch_us * 1e-6) / 1e9) if tbytes else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (tbytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tbytes else None,
-                "traffic": tbytes, "traffic_source": traffic.get("file"),
+                "traffic": tbytes, "traffic_source": tsource,
                 "launches": main_tot["launches"], "avg_launch_us": launch_us,
                 "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / (launch_us * 1e-6) / 1e9,
                 "note": ("achieved / frac = HBM bytes the kernel really moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, `traffic`) over its "
