@@ -181,7 +181,8 @@ typedef struct {
     int32_t impulse_iterations;        /* sweeps executed before the no-productive-joint exit (ref: Solver.cpp:189) */
     int32_t displacement_iterations;   /* ref: Solver.cpp:210 */
     int32_t lds_islands;               /* islands solved by the one-workgroup-per-island kernel */
-    int32_t recoloured;                /* 1 if the joint topology changed and the schedule was rebuilt */
+    int32_t recoloured;                /* 1 if the joint topology changed and the schedule was rebuilt; 2 if that rebuild ran without a host
+                                          round trip (bins made on the device with last build's bin count as the launch grid) */
     int32_t graph_replay;              /* 1 if the launch sequence was replayed from cached hipGraphs */
     double  device_ms;                 /* HIP-event time of the device work of the last solve */
     int64_t joint_visits;              /* joints swept by the impulse loop, skipped ones included; per-island early exits honoured */
@@ -363,6 +364,8 @@ int phx_memcpy_d2d(int device, void* dst, const void* src, size_t bytes);
 int phx_memcpy_d2h_on(int device, void* dst, const void* src, size_t bytes, void* stream);
 int phx_memcpy_h2d_on(int device, void* dst, const void* src, size_t bytes, void* stream);
 int phx_memcpy_d2d_on(int device, void* dst, const void* src, size_t bytes, void* stream);
+/* diagnostics: with PHX_WAIT_CLOCK=1 in the environment, the time this process has spent waiting for device->host readbacks */
+int phx_debug_wait_clock(long long* ns, long long* calls);
 
 #ifdef __cplusplus
 }

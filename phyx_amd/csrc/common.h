@@ -1,5 +1,6 @@
 // common.h — shared plumbing of libphyx_amd: status codes, HIP error capture, POD checks.
 #pragma once
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 
@@ -178,6 +179,9 @@ static __global__ void __launch_bounds__(1024) k_post_mail(MailArgs a, unsigned*
     if (threadIdx.x == 0) __hip_atomic_store(host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+inline long long& wait_clock_ns() { static long long v = 0; return v; }
+inline long long& wait_clock_calls() { static long long v = 0; return v; }
+
 class Readback {
 public:
     Readback() = default;
@@ -234,6 +238,10 @@ private:
     int poll(hipStream_t stream)
     {
         volatile unsigned* word = seq_word();
+        // PHX_WAIT_CLOCK=1 (diagnostics): how long the host spent waiting for mailbox posts, per process (printed by tools/world_quick.py)
+        static const bool clocked = getenv("PHX_WAIT_CLOCK") != nullptr;
+        const auto t0 = clocked ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        struct Stop { bool on; std::chrono::steady_clock::time_point t0; ~Stop() { if (on) { wait_clock_ns() += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++wait_clock_calls(); } } } stop{clocked, t0};
         for (unsigned long long spins = 1;; ++spins) {
             if (__atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq_) return PHX_OK;
             __builtin_ia32_pause();

@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
 
     const int group = iv.first + (int)blockIdx.x * iv.stride;
     if (iv.stamp_begin) solve_stamp_begin(v.stamps);      // (no HBM group in front of this launch: it is the solve's first kernel)
+    if (iv.ngroups_dev && group >= *iv.ngroups_dev) return;  // (workgroup-uniform, in front of every barrier)
     PHX_ISL_STAMP(0);
     const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
     // TRACE: per wave, shader cycles spent in class steps {working: in the unit update, then at the barrier; idle: whole step}

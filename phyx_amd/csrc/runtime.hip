@@ -143,6 +143,14 @@ int phx_memcpy_d2d_on(int device, void* dst, const void* src, size_t bytes, void
     return PHX_OK;
 }
 
+// diagnostics (PHX_WAIT_CLOCK=1): nanoseconds this process has spent waiting for mailbox posts, and the number of waits
+int phx_debug_wait_clock(long long* ns, long long* calls)
+{
+    if (ns) *ns = phx::wait_clock_ns();
+    if (calls) *calls = phx::wait_clock_calls();
+    return PHX_OK;
+}
+
 int phx_memcpy_d2d(int device, void* dst, const void* src, size_t bytes)
 {
     PHX_TRY(phx::use_device(device));

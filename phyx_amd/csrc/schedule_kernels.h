@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "schedule.h"
+#include "device_scan.h"
 
 namespace phx {
 
@@ -93,8 +94,11 @@ struct RootFlagLoad {
 constexpr int JC_T = 1024, JC_TABLE = 2048;
 static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_contact_joint* __restrict__ joints, int nj, int nb, const int* __restrict__ parent,
                                                                   const unsigned* __restrict__ root_number, const int* __restrict__ partner,
-                                                                  int* __restrict__ joint_comp, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
+                                                                  int* __restrict__ joint_comp, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units,
+                                                                  int* __restrict__ unconverged)
 {
+    // (`unconverged`, may be null: raised if some joint's two dynamic bodies still carry different labels — a caller that skipped
+    //  the hook round which only confirms convergence, solver.hip's speculative build, finds out here instead)
     __shared__ int table_key[JC_TABLE];
     __shared__ unsigned table_cnt[JC_TABLE], table_units[JC_TABLE];
     for (int j0 = blockIdx.x * blockDim.x; j0 < nj; j0 += gridDim.x * blockDim.x) {       // uniform trip count per workgroup
@@ -111,6 +115,7 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
                 const int pu = parent[u], pv = parent[v];
                 const int r = pu >= 0 ? pu : pv;
                 if (r >= 0) comp = (int)root_number[r];
+                if (unconverged && pu >= 0 && pv >= 0 && pu != pv) *unconverged = 1;
             }
             joint_comp[j] = comp;
             mine = comp; lead_one = leads ? 1u : 0u;
@@ -139,14 +144,176 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
 }
 
 // (also clears the 'a bin was rejected' flag that k_build_bin may raise)
+// (`ncomp_cap`: entries of bin_of_comp — a speculative build, solver.hip, may meet more components than its table holds; it is
+//  spoiled then, but must not read past the table)
 static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __restrict__ joint_comp, const int* __restrict__ bin_of_comp, int nj, int rest_key,
-                                                               unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ rejected)
+                                                               unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ rejected, int ncomp_cap)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         const int c = joint_comp[j];
-        keys[j] = (unsigned)(c < 0 ? rest_key : bin_of_comp[c]);
+        keys[j] = (unsigned)((c < 0 || c >= ncomp_cap) ? rest_key : bin_of_comp[c]);
         vals[j] = (unsigned)j;
+    }
+}
+
+// ---- binning on the device -------------------------------------------------------------------------------------------
+// The greedy binning of consecutive components (schedule.hip::build_island_schedule; the host runs it over the component
+// sizes it has just read back) restated for ONE workgroup, so that a rebuild needs no host round trip between the
+// connected components and the bins: the host launches everything behind it with last build's bin count as the grid, and
+// reads what came out when it settles the solve (solver.hip, "speculative binning").  Greedy packing is a chain — a bin ends
+// where the next component would overflow it — and a chain is followed in parallel by pointer doubling:
+//   next[a]   the component a bin opened at a would stop in front of: two binary searches over the prefix sums (joints, units)
+//   heads     the components reachable from component 0 along next[]: log2(n) doubling rounds in LDS
+//   tables    bin of a component = heads at or before it - 1; rank inside the bin = non-empty components since the head
+// GatherIslands' published numbers (ref: Solver.cpp:400, 414, 449) are statistics: the host computes them from the component
+// sizes when it settles the solve.  Whatever the host would have decided differently poisons the solve's fingerprint word
+// (`fail` bits below), which makes every kernel of the solve commit nothing; the host then rebuilds the slow way.
+constexpr int BINC_MAX = 8192, BINC_T = 1024;
+constexpr int BINC_FAIL_CC = 1, BINC_FAIL_COUNT = 2, BINC_FAIL_FIT = 4, BINC_FAIL_SHAPE = 8, BINC_FAIL_REST = 16, BINC_FAIL_GRID = 32;
+constexpr unsigned long long BINC_POISON = 0x9E3779B97F4A7C15ull;
+
+struct BinCompView {
+    const unsigned* comp_size;        // joints per component (body order)
+    const unsigned* comp_units;       // units per component
+    const int* cc_small;              // [0] 'the last hook round still hooked something', [1] component count
+    int nj;
+    int cap_units;                    // lanes of the workgroup shape the launches behind this kernel use
+    int small_units;                  // lanes of the small shape (the host picks the roomier one only if some component needs it)
+    int max_bins;                     // grid of the launches behind this kernel
+    int* bin_of; int* rank_of;        // out: per component (BINC_MAX each)
+    int* goff;                        // out: first slot of every bin, max_bins + 1 words
+    int* result;                      // out: [0] bins (0 if spoiled), [1] slots in bins, [4] fail bits, [5] components, [6] bins found
+    unsigned long long* fingerprint;  // the solve's topology fingerprint word: saved to `hash_out`, then replaced by `gate`
+    unsigned long long* hash_out;     //   (the host does not know the hash yet: the solve's kernels compare the word with a constant
+    unsigned long long gate;          //    it does know) — or by a spoiled `gate` if the build cannot be used
+};
+
+// marks the components reachable from component 0 along `jump` (LDS, doubled between the two buffers)
+__device__ __forceinline__ void binc_mark_chain(unsigned short* jump_a, unsigned short* jump_b, unsigned char* reach, int n, bool any)
+{
+    for (int c = threadIdx.x; c < n; c += BINC_T) reach[c] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && any) reach[0] = 1;
+    __syncthreads();
+    unsigned short* cur = jump_a; unsigned short* nxt = jump_b;
+    for (int span = 1; span < n; span <<= 1) {
+        for (int c = threadIdx.x; c < n; c += BINC_T) {
+            const int j = cur[c];
+            if (reach[c] && j < n) reach[j] = 1;           // (a lane that sees this mark a round early marks a component of the chain all the same)
+            nxt[c] = (unsigned short)(j < n ? cur[j] : n);
+        }
+        __syncthreads();
+        unsigned short* t = cur; cur = nxt; nxt = t;
+    }
+}
+
+// inclusive prefix sums of value(c), c < n, handed to out(c, sum), 1024 components per pass; returns the total.  64-bit words:
+// the caller packs several counters into one (their sums must not carry into each other)
+template <typename Value, typename Out>
+__device__ __forceinline__ unsigned long long binc_scan(int n, unsigned long long* scratch, Value value, Out out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (int base = 0; base < n; base += BINC_T) {             // (workgroup-uniform trip count)
+        const int c = base + (int)threadIdx.x;
+        const unsigned long long x = c < n ? value(c) : 0ull;
+        unsigned long long incl = x;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+        if (lane == 63) scratch[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long t = lane < 16 ? scratch[lane] : 0ull;
+            for (int off = 1; off < 16; off <<= 1) { const unsigned long long y = __shfl_up(t, off); if (lane >= off) t += y; }
+            if (lane < 16) scratch[lane] = t;
+        }
+        __syncthreads();
+        if (c < n) out(c, carry + (wave ? scratch[wave - 1] : 0ull) + incl);
+        const unsigned long long total = scratch[15];
+        __syncthreads();                                       // (scratch is reused by the next pass)
+        carry += total;
+    }
+    return carry;
+}
+
+// one word per component: joints (bits 0-24), units (25-49), 'is not empty' (50-63) — speculative binning is for solves of < 2^25 joints
+constexpr int BINC_JOINT_BITS = 25;
+__device__ __forceinline__ unsigned long long binc_pack(unsigned joints, unsigned units)
+{
+    return (unsigned long long)joints | ((unsigned long long)units << BINC_JOINT_BITS) | ((unsigned long long)(joints ? 1u : 0u) << (2 * BINC_JOINT_BITS));
+}
+
+static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
+{
+    __shared__ unsigned ps[BINC_MAX], pu[BINC_MAX];            // inclusive prefix sums: joints, units
+    __shared__ unsigned short pn[BINC_MAX];                    // inclusive count of non-empty components
+    __shared__ unsigned short jump_a[BINC_MAX], jump_b[BINC_MAX];
+    __shared__ unsigned short head_pos[BINC_MAX];              // bin -> its first component
+    __shared__ unsigned short bin_at[BINC_MAX];                // component -> heads at or before it
+    __shared__ unsigned char reach[BINC_MAX];
+    __shared__ unsigned long long scratch[16];
+    __shared__ int s_fail, s_needs_big;
+    const int tid = threadIdx.x;
+    const int n_all = v.cc_small[1];
+    const int n = n_all < BINC_MAX ? n_all : BINC_MAX;
+    if (tid == 0) { s_fail = (v.cc_small[0] ? BINC_FAIL_CC : 0) | (n_all > BINC_MAX ? BINC_FAIL_COUNT : 0); s_needs_big = 0; }
+    __syncthreads();
+    bool misfit = false, wants_big = false;
+    for (int c = tid; c < n; c += BINC_T) {
+        const unsigned sz = v.comp_size[c], un = v.comp_units[c];
+        ps[c] = sz; pu[c] = un;
+        if (sz) {
+            if (sz > 2u * (unsigned)v.cap_units || un > (unsigned)v.cap_units) misfit = true;
+            if (sz > 2u * (unsigned)v.small_units || un > (unsigned)v.small_units) wants_big = true;
+        }
+    }
+    if (misfit) atomicOr(&s_fail, BINC_FAIL_FIT);
+    if (wants_big) s_needs_big = 1;
+    // (each lane scans the components it has just written: no barrier needed in between)
+    constexpr unsigned long long M = (1ull << BINC_JOINT_BITS) - 1ull;
+    const unsigned long long sums = binc_scan(n, scratch, [&](int c) { return binc_pack(ps[c], pu[c]); },
+                                              [&](int c, unsigned long long x) { ps[c] = (unsigned)(x & M); pu[c] = (unsigned)((x >> BINC_JOINT_BITS) & M); pn[c] = (unsigned short)(x >> (2 * BINC_JOINT_BITS)); });
+    const int total = (int)(sums & M);
+    if (tid == 0) {
+        // the host takes the roomier shape iff some component needs it; joints outside every component (both bodies static) and
+        // components that fit no shape go to the HBM group, which this path does not build
+        if ((s_needs_big != 0) != (v.cap_units > v.small_units)) s_fail |= BINC_FAIL_SHAPE;
+        if (total != v.nj) s_fail |= BINC_FAIL_REST;
+    }
+    const unsigned cap_s = 2u * (unsigned)v.cap_units, cap_u = (unsigned)v.cap_units;
+    auto upper = [&](const unsigned* pre, int a, unsigned limit) {          // first e >= a with pre[e] - before(a) > limit, or n
+        const unsigned before = a ? pre[a - 1] : 0u;
+        int lo = a, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid] - before > limit) hi = mid; else lo = mid + 1; }
+        return lo;
+    };
+    auto nonempty = [&](int c) { return (c ? pn[c - 1] : 0) != pn[c]; };
+    for (int a = tid; a < n; a += BINC_T) {
+        const int e1 = upper(ps, a, cap_s), e2 = upper(pu, a, cap_u);
+        int e = e1 < e2 ? e1 : e2;
+        if (e <= a) e = a + 1;                                 // (a misfit: the build is spoiled anyway; keep the chain moving)
+        jump_a[a] = (unsigned short)e;
+    }
+    __syncthreads();
+    binc_mark_chain(jump_a, jump_b, reach, n, total > 0);
+    const int nbins = (int)binc_scan(n, scratch, [&](int c) { return reach[c] ? 1ull : 0ull; }, [&](int c, unsigned long long x) { bin_at[c] = (unsigned short)x; });
+    for (int c = tid; c < n; c += BINC_T) if (reach[c]) head_pos[bin_at[c] - 1] = (unsigned short)c;
+    __syncthreads();
+    for (int c = tid; c < n; c += BINC_T) {
+        const int b = (int)bin_at[c] - 1;                      // (total == 0: no head, every component is empty)
+        if (b < 0) { v.bin_of[c] = 0; v.rank_of[c] = 0; continue; }
+        const int h = head_pos[b];
+        const int before_h = h ? pn[h - 1] : 0, before_c = (int)pn[c] - (nonempty(c) ? 1 : 0);
+        v.bin_of[c] = b; v.rank_of[c] = before_c - before_h;
+        if (reach[c] && b <= v.max_bins) v.goff[b] = (int)(c ? ps[c - 1] : 0u);
+    }
+    if (tid == 0) {
+        if (nbins <= v.max_bins) v.goff[nbins] = total;
+        if (nbins > v.max_bins) s_fail |= BINC_FAIL_GRID;
+        v.result[0] = s_fail ? 0 : nbins;                      // (a spoiled build's tables may be incomplete: nobody runs on them)
+        v.result[1] = total; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
+        *v.hash_out = *v.fingerprint;
+        *v.fingerprint = s_fail ? v.gate + BINC_POISON : v.gate;
     }
 }
 
@@ -178,6 +345,7 @@ struct BinBuildView {
     int* units;                       // out: units
     int2* unit_slots;                 // out: [g * T + unit] = {leader slot, follower slot or -1}, class-major
     int* bodies;                      // out: body table of bin g at [g * NB, g * NB + body_count)
+    const int* nbins_dev;             // (may be null) the bin count, if the launch grid is only an upper bound of it (speculative binning, solver.hip)
     int* rejected;                    // out: set to 1 if any bin exceeds the caps (caller falls back to the host builder)
     unsigned long long* poison;       // the solve's topology fingerprint word: a rejected bin spoils it, so that every kernel that would commit
                                       // results on this schedule refuses to (the host checks `rejected` only after the solve is queued)
@@ -224,6 +392,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __shared__ int n_static, n_bodies, n_col, n_units, bad;
 
     const int g = blockIdx.x, tid = threadIdx.x;
+    if (v.nbins_dev && g >= *v.nbins_dev) return;
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
     for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
     for (int i = tid; i < NB; i += LANES) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }

@@ -69,7 +69,7 @@ public:
     bool has_pending() const { return pending_.active; }
     // the gate of an unverified solve (world.hip queues the integrator behind it under the same gate)
     const unsigned long long* fingerprint_word() const { return hash_.p + hash_slot_; }
-    unsigned long long expected_fingerprint() const { return raw_fingerprint_; }
+    unsigned long long expected_fingerprint() const { return gate_expected_; }
     unsigned replays() const { return replays_; }
     int device() const { return device_; }
 
@@ -77,6 +77,7 @@ private:
     int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
                         bool known_changed = false);
     int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
+    int build_bins_speculative(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc);
     int materialise_schedule();
     int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     struct GraphKey {
@@ -129,6 +130,12 @@ private:
     // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;
+    // speculative binning (build_bins_speculative): the bins are made on the device and the build has no host round trip at all;
+    // what the host would have read — bin count, offsets, GatherIslands' numbers, the topology hash — comes back when the solve is settled
+    bool spec_bins_ok_ = false, spec_bins_pending_ = false, spec_bins_failed_ = false, no_spec_bins_ = false;
+    int spec_bins_guess_ = 0, spec_lanes_ = 0;
+    unsigned long long gate_expected_ = 0, gate_serial_ = 0;      // what the gates of the solve in flight compare the fingerprint word with
+    DevBuf<int> bin_result_;                                      // k_bin_components' results: 8 ints, then the topology hash (8 bytes)
     bool time_sweeps_ = false, timed_sweeps_ = false;   // bench(): the event pair brackets the sweeps instead of the whole solve
     const unsigned* sw_cleared_ = nullptr;          // the static-tag table launch_fingerprint's kernel cleared for the solve in flight
     size_t sw_cleared_words_ = 0;
@@ -164,7 +171,7 @@ private:
     int max_iters_ = 0;
     phx_solve_stats stats_{};
     bool stats_pending_ = false, have_solve_ = false;
-    int last_ci_ = 0, last_pi_ = 0;
+    int last_ci_ = 0, last_pi_ = 0, last_island_mode_ = 0;
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;

@@ -84,6 +84,8 @@ int DeviceSolver::init()
     defer_build_check_ = speculate_;                     // (PHX_NO_SPECULATION=1 also waits for the device build's 'every bin fits' flag)
     const char* ni = getenv("PHX_NO_ISLANDS");           // "1": ignore island modes, always the HBM colour path (A/B measurements)
     no_islands_ = ni && ni[0] == '1';
+    const char* nsb = getenv("PHX_NO_SPEC_BINS");      // "1": every rebuild reads the component sizes back and bins them on the host
+    no_spec_bins_ = (nsb && nsb[0] == '1') || use_graphs_;
     trace_schedule_ = getenv("PHX_TRACE_SCHEDULE") != nullptr;      // print the schedule builders' laps to stderr
     return PHX_OK;
 }
@@ -92,7 +94,7 @@ SolverView DeviceSolver::view() const
 {
     SolverView v{};
     v.nb = nb_; v.nj = nj_; v.ncp = ncp_; v.nstatic = std::max(nstatic_, 1); v.ncolours = sched_.ncolours();
-    v.fingerprint = hash_.p + hash_slot_; v.expected_fingerprint = raw_fingerprint_;
+    v.fingerprint = hash_.p + hash_slot_; v.expected_fingerprint = gate_expected_;
     v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = sb_par_.p;
     v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p; v.qn = qn_.p;
     v.order = order_.p;
@@ -146,7 +148,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         have_fp = true;
         const unsigned long long mixed = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
         if (!force_rebuild && !known_changed && sched_.valid && sched_.fingerprint == mixed && nb == nb_ && nj == nj_ && sched_.islands == want_islands) {
-            raw_fingerprint_ = fp;
+            raw_fingerprint_ = fp; gate_expected_ = fp;
             return PHX_OK;
         }
     }
@@ -159,6 +161,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         fp_wanted_ = have_fp ? nullptr : &fp;
         const int st = build_schedule_device(d_bodies, nb, d_joints, nj, want_islands, &fallback);
         if (st != PHX_OK) { fp_wanted_ = nullptr; return st; }
+        if (spec_bins_pending_) fp_wanted_ = nullptr;   // (the hash comes back with everything else when the solve is settled: collect_stats)
         if (fp_wanted_) {                              // the builder had nothing to read back (no joints) or bailed out early
             fp_wanted_ = nullptr;
             PHX_TRY(rb_.add(&fp, hash_.p + hash_slot_, sizeof fp, stream_));
@@ -168,10 +171,11 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         if (!fallback) {
             sched_.fingerprint = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
             raw_fingerprint_ = fp;
+            if (!spec_bins_pending_) gate_expected_ = fp;
             sched_.valid = true;
             ++schedule_version_;
             drop_graphs();
-            stats_.recoloured = 1;
+            stats_.recoloured = spec_bins_pending_ ? 2 : 1;
             return PHX_OK;
         }
         sched_.valid = false;
@@ -281,7 +285,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_HIP(hipStreamSynchronize(stream_));
     lap("upload");
     sched_.fingerprint = fp;
-    raw_fingerprint_ = raw;
+    raw_fingerprint_ = raw; gate_expected_ = raw;
     sched_.valid = true;
     ++schedule_version_;
     drop_graphs();
@@ -319,6 +323,12 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
     int nbins = 0, lds_slots = 0, where = 0, ncomp_total = 0;
+    spec_bins_pending_ = false;
+    if (spec_bins_ok_ && !no_spec_bins_ && want_islands && defer_build_check_ && shard_count_ == 1 && !xch_send_ && nj > 0 && nj < (1 << BINC_JOINT_BITS) && !trace) {
+        PHX_TRY(build_bins_speculative(d_bodies, nb, d_joints, nj, sc));
+        sched_ = std::move(sc);
+        return PHX_OK;
+    }
     {
     // (Single mode needs the components too: the colouring candidate is chosen per component, schedule.h — it then sends
     //  every component to the HBM group)
@@ -350,7 +360,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)cc_parent_.p, nb, comp_size_.p, comp_units_.p}, cc_flags_.p, nb + 1,
                                          reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
-                           (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p);
+                           (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p, (int*)nullptr);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
         comp_size.assign(std::max(guess, 1), 0u); comp_units.assign(std::max(guess, 1), 0u);
@@ -425,7 +435,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
     if (nbins) {
         hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, bin_of_comp, nj, nbins,
-                           sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2);
+                           sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2, std::max(ncomp, 1));
         int bits = 1;
         while ((1 << bits) <= nbins) ++bits;
         PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_, stream_, &where));
@@ -582,7 +592,82 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     if (sw_.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
         PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
     lap("rest");
+    // the next rebuild may skip the host altogether (build_bins_speculative) if this one was nothing but bins of one shape
+    spec_bins_ok_ = want_islands && rest == 0 && nbins > 0 && ncomp_total <= BINC_MAX;
+    spec_bins_guess_ = nbins; spec_lanes_ = sc.lds_lanes;
     sched_ = std::move(sc);
+    return PHX_OK;
+}
+
+// Speculative binning: the rebuild of a world that was nothing but LDS-sized islands last time (every stack scene) runs without a
+// single host round trip.  The connected components are followed by k_bin_components (schedule_kernels.h), which makes the
+// bins the host loop above would make; the sort, k_build_bin and the island kernel are launched with last build's bin count
+// (+ slack) as their grid and take the real count from the device.  Whatever does not hold any more — a component that fits
+// no workgroup, joints between static bodies, more bins than the grid, the other workgroup shape, unconverged components —
+// spoils the solve's fingerprint word like a rejected bin does: the solve commits nothing, synchronize() rebuilds the
+// long way and repeats it.  The topology hash the host has not seen is replaced on the device by a constant it knows
+// (`gate_expected_`), which is what the solve's kernels compare the word with; the hash itself comes back with the results.
+int DeviceSolver::build_bins_speculative(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
+{
+    // the hook + compress pairs the last build needed, less the one that only confirmed that nothing hooks any more: whether
+    // every joint's bodies ended up under one label is checked by k_joint_components, which reads those labels anyway
+    const int pairs = std::max(1, std::min(cc_pairs_guess_, 16) - 1);
+    for (int k = 0; k < pairs; ++k) {
+        hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p,
+                           (const int*)partner_first_.p, ncp_, k == 0 ? partner_.p : (int*)nullptr);
+        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == pairs - 1 ? sb_small_.p : (int*)nullptr);
+    }
+    PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)cc_parent_.p, nb, comp_size_.p, comp_units_.p}, cc_flags_.p, nb + 1,
+                                     reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
+    hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
+                       (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p, sb_small_.p);
+    // (workgroups beyond the real bin count leave at once, and a settling world doubles its bins within a few steps — columns
+    //  break in two: a roomy grid costs nothing, a grid too small costs a repeated solve)
+    const int grid = 2 * spec_bins_guess_ + 64;
+    const int cap_units = spec_lanes_, cap_bodies = cap_units > ISL_T ? ISL_B_BIG : ISL_B;
+    PHX_TRY(bin_tables_.reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
+    PHX_TRY(bin_result_.reserve(16));
+    BinCompView cv{};
+    cv.comp_size = comp_size_.p; cv.comp_units = comp_units_.p; cv.cc_small = sb_small_.p; cv.nj = nj;
+    cv.cap_units = cap_units; cv.small_units = ISL_T; cv.max_bins = grid;
+    cv.bin_of = bin_tables_.p; cv.rank_of = bin_tables_.p + BINC_MAX; cv.goff = bin_tables_.p + 2 * BINC_MAX;
+    cv.result = bin_result_.p;
+    cv.fingerprint = hash_.p + hash_slot_; cv.hash_out = reinterpret_cast<unsigned long long*>(bin_result_.p + 8);
+    gate_expected_ = 0x5EED000000000000ull | (++gate_serial_ & 0xFFFFFFFFFFFFull);
+    cv.gate = gate_expected_;
+    hipLaunchKernelGGL(k_bin_components, dim3(1), dim3(BINC_T), 0, stream_, cv);
+    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)cv.bin_of, nj, grid,
+                       sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2, BINC_MAX);
+    int bits = 1, where = 0;
+    while ((1 << bits) <= grid) ++bits;
+    PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_, stream_, &where));
+    PHX_TRY(grp_desc_.reserve(grid)); PHX_TRY(grp_ncol_.reserve(grid));
+    PHX_TRY(grp_bodies_.reserve((size_t)grid * cap_bodies));
+    PHX_TRY(slot_local_.reserve(nj)); PHX_TRY(slot_colour_.reserve(nj));
+    PHX_TRY(grp_units_.reserve(grid)); PHX_TRY(unit_slots_.reserve((size_t)grid * cap_units));
+    BinBuildView bv{};
+    bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = cv.goff; bv.joints = d_joints; bv.partner = partner_.p; bv.is_static = cc_static_.p;
+    bv.joint_comp = joint_comp_.p; bv.comp_rank = cv.rank_of;
+    bv.nb = nb; bv.max_static = 1 << 30;
+    bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
+    bv.units = grp_units_.p; bv.unit_slots = unit_slots_.p;
+    bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2; bv.poison = hash_.p + hash_slot_;
+    bv.nbins_dev = bin_result_.p;
+    if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(grid), dim3(2 * ISL_T_BIG), 0, stream_, bv);
+    else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(grid), dim3(2 * ISL_T), 0, stream_, bv);
+    PHX_HIP(hipGetLastError());
+    // provisional: the launch grid stands in for the group count until the solve is settled (collect_stats)
+    sc.lds_groups = grid; sc.lds_lanes = cap_units;
+    sc.group_offsets.assign((size_t)grid + 1, nj); sc.group_offsets[0] = 0;
+    sc.island_count = sched_.island_count; sc.island_max_size = sched_.island_max_size;
+    sc.lds_colours = sched_.lds_colours; sc.hbm_body_count = 0;
+    grp_body_count_.clear();
+    nstatic_ = 0;
+    PHX_TRY(sw_.reserve(4));
+    if (sw_.p != sw_cleared_ || 4 > sw_cleared_words_) PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * sizeof(unsigned), stream_));
+    build_unverified_ = true;
+    unverified_bins_ = grid;
+    spec_bins_pending_ = true;
     return PHX_OK;
 }
 
@@ -656,6 +741,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
     if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
         iv.first = shard_; iv.stride = shard_count_;
+        iv.ngroups_dev = spec_bins_pending_ ? bin_result_.p : nullptr;
         iv.stamp_begin = iv.stamp_end = owns_hbm_group() ? 0 : 1;      // (with an HBM group, its first and last kernels leave the stamps)
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_slots = unit_slots_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
@@ -774,7 +860,7 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
         else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
     }
     timed_sweeps_ = time_sweeps_;
-    last_ci_ = ci; last_pi_ = pi;
+    last_ci_ = ci; last_pi_ = pi; last_island_mode_ = cfg.island_mode;
     stats_pending_ = true;
     have_solve_ = true;
     stats_.graph_replay = replay ? 1 : 0;
@@ -807,6 +893,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
         // queued first; every kernel that writes to the caller's arrays compares it on the device and commits nothing on
         // a mismatch; synchronize() reads it back and, if it differs, rebuilds the schedule and repeats the solve.
         PHX_TRY(launch_fingerprint(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp));
+        gate_expected_ = raw_fingerprint_;
         // a repeat on the same arrays while the previous one is still unverified: both ran on the same cached schedule and are
         // gated by the same topology, so they are verified together — and replayed together if the schedule was stale
         pending_.count = pending_.active ? pending_.count + 1 : 1;
@@ -857,16 +944,60 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
 {
     // an unverified device build (build_schedule_device): the classes per group ride along; whether a bin was rejected shows in
     // the fingerprint the caller compares
-    std::vector<int> ncol;
+    std::vector<int> ncol, goff;
+    std::vector<unsigned> comp_size;
+    int spec[16] = {0};
     auto with_build = [&]() -> int {
         if (!build_unverified_) return PHX_OK;
         ncol.assign((size_t)unverified_bins_, 0);
+        if (spec_bins_pending_) {                      // speculative binning: what the build's round trip would have brought
+            goff.assign((size_t)unverified_bins_ + 1, 0);
+            comp_size.assign((size_t)std::min(std::min(BINC_MAX, nb_), std::max(1024, ncomp_guess_ + ncomp_guess_ / 4)), 0u);
+            PHX_TRY(rb_.add(spec, bin_result_.p, sizeof spec, stream_));
+            PHX_TRY(rb_.add(goff.data(), bin_tables_.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
+            if (!comp_size.empty()) PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, comp_size.size() * sizeof(unsigned), stream_));
+        }
         return rb_.add(ncol.data(), grp_ncol_.p, ncol.size() * sizeof(int), stream_);
+    };
+    auto rest_of_sizes = [&]() -> int {                // more components than last time (+ 25 %): fetch the rest
+        if (!build_unverified_ || !spec_bins_pending_ || spec[4] != 0 || (size_t)spec[5] <= comp_size.size()) return PHX_OK;
+        const size_t have = comp_size.size();
+        comp_size.resize((size_t)spec[5], 0u);
+        PHX_TRY(rb_.add(comp_size.data() + have, comp_size_.p + have, (comp_size.size() - have) * sizeof(unsigned), stream_));
+        return rb_.wait(stream_);
     };
     auto settle_build = [&]() {
         if (!build_unverified_) return;
         build_unverified_ = false;
         build_was_unverified_ = true;                  // (read by synchronize() if the fingerprint does not match)
+        if (spec_bins_pending_) {
+            spec_bins_pending_ = false;
+            spec_bins_failed_ = spec[4] != 0;
+            if ((trace_schedule_ || getenv("PHX_TRACE_SPEC")) && spec_bins_failed_) fprintf(stderr, "[schedule/gpu] speculative binning spoiled: bits %d (%d components, %d bins, grid %d)\n", spec[4], spec[5], spec[6], unverified_bins_);
+            if (spec_bins_failed_) { spec_bins_ok_ = false; return; }      // (the fingerprint word is spoiled: synchronize() rebuilds)
+            const int nbins = std::min(spec[0], unverified_bins_);
+            unsigned long long hash = 0;
+            std::memcpy(&hash, spec + 8, sizeof hash);
+            raw_fingerprint_ = hash;
+            sched_.fingerprint = hash ^ ((unsigned long long)(unsigned)nj_ << 32) ^ (unsigned)nb_;
+            sched_.lds_groups = nbins;
+            sched_.group_offsets.assign(goff.begin(), goff.begin() + nbins + 1);
+            {   // GatherIslands' published numbers from the component sizes, as the builder's long way computes them
+                const int ncomp = spec[5];
+                int run = 0, count = 0, mx = 0;
+                for (int c = 0; c < ncomp; ++c) {
+                    run += (int)comp_size[c];
+                    if (run >= 256 || (run > 0 && c == ncomp - 1)) { ++count; mx = std::max(mx, run); run = 0; }
+                }
+                sched_.island_count = count; sched_.island_max_size = mx;
+            }
+            ncol.resize((size_t)nbins);
+            spec_bins_guess_ = nbins; ncomp_guess_ = spec[5];
+            stats_.lds_islands = nbins;
+            const bool split = last_island_mode_ == PHX_ISLAND_MULTIPLE || last_island_mode_ == PHX_ISLAND_MULTIPLE_SLOPPY;
+            stats_.island_count = split ? sched_.island_count : 1;
+            stats_.island_max_size = split ? sched_.island_max_size : nj_;
+        }
         sched_.lds_colours = 0;
         for (int n : ncol) sched_.lds_colours += n;
         stats_.colour_count = sched_.ncolours();
@@ -875,6 +1006,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
         if (extra) { PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_)); }
         PHX_TRY(with_build());
         PHX_TRY(rb_.wait(stream_));
+        PHX_TRY(rest_of_sizes());
         settle_build();
         return PHX_OK;
     }
@@ -889,6 +1021,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     PHX_TRY(rb_.add(stamps, isl_visits_.p + ISL_STAT_SLOTS, sizeof stamps, stream_));
     PHX_TRY(with_build());
     PHX_TRY(rb_.wait(stream_));
+    PHX_TRY(rest_of_sizes());
     settle_build();
     int isl[2] = {0, 0};
     unsigned long long isl_visits = 0;
@@ -924,10 +1057,11 @@ int DeviceSolver::synchronize()
         PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_));
         const Pending p = pending_;
         pending_.active = false;
-        const bool spoiled_build = build_was_unverified_ && fp != raw_fingerprint_;      // a bin did not fit: the device build spoiled the fingerprint
+        const bool spoiled_build = build_was_unverified_ && fp != gate_expected_;      // a bin did not fit: the device build spoiled the fingerprint
         build_was_unverified_ = false;
-        if (spoiled_build) force_host_builder_ = true;
-        if (fp != raw_fingerprint_) {
+        if (spoiled_build && !spec_bins_failed_) force_host_builder_ = true;      // (a spoiled speculative binning only needs the builder's long way)
+        spec_bins_failed_ = false;
+        if (fp != gate_expected_) {
             stats_pending_ = true;                     // those counters belong to a solve that committed nothing
             ++replays_;
             // the joint topology changed under the cached schedule (or the build it ran on had a bin that did not fit): nothing was

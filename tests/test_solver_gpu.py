@@ -328,6 +328,43 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
         assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
 
 
+def test_speculative_binning_equals_the_builders_long_way(oracle, built_lib):
+    """A rebuild of a world that was nothing but workgroup-sized islands last time makes its bins on the device, with last build's
+    bin count as the launch grid and no host round trip (stats.recoloured == 2).  Whatever does not hold any more — more bins than
+    the grid, the other workgroup shape, an island too big for a workgroup — spoils the solve, which is then rebuilt the long
+    way and repeated.  Schedule, statistics and results must equal those of a solver that never speculates."""
+    import os
+    os.environ["PHX_NO_SPEC_BINS"] = "1"
+    try:
+        plain = phyx_amd.Solver(0)
+    finally:
+        del os.environ["PHX_NO_SPEC_BINS"]
+    spec = phyx_amd.Solver(0)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 12, 12)
+    seq = [("stack40x60", presolve_state(scenes.stack(40, 60), 4), 1),            # first build: the long way
+           ("again", presolve_state(scenes.stack(40, 60), 5), 2),                  # same world one step on: speculative
+           ("fewer bins", presolve_state(scenes.stack(25, 60), 4), 2),
+           ("more bins than the grid", presolve_state(scenes.stack(300, 60), 4), 1),
+           ("again", presolve_state(scenes.stack(300, 60), 5), 2),
+           ("the roomier shape", presolve_state(scenes.stack(5, 500), 3, iters=30), 1),
+           ("again", presolve_state(scenes.stack(5, 500), 4, iters=30), 2),
+           ("back to the small shape", presolve_state(scenes.stack(40, 60), 4), 1),
+           ("again", presolve_state(scenes.stack(40, 60), 5), 2),
+           ("an island for the HBM group", presolve_state(scenes.falling(2500, width=100.0, ymax=400.0), 50), 1),
+           ("after it", presolve_state(scenes.stack(40, 60), 4), 1),               # (the last build had an HBM group: no speculation)
+           ("again", presolve_state(scenes.stack(40, 60), 5), 2),
+           ("tiny", presolve_state(scenes.stack(2, 10), 2), 2)]
+    for what, state, want in seq:
+        pb, pj, ps, _, pst = _device_solve(plain, state, cfg)
+        sb, sj, ss, _, sst = _device_solve(spec, state, cfg)
+        assert pst.recoloured == 1 and sst.recoloured == want, (what, sst.recoloured)
+        assert np.array_equal(ps.order, ss.order) and np.array_equal(ps.colours, ss.colours), what
+        assert np.array_equal(ps.groups, ss.groups) and ps.lds_groups == ss.lds_groups, what
+        assert (pst.island_count, pst.island_max_size, pst.colour_count, pst.lds_islands) == (sst.island_count, sst.island_max_size, sst.colour_count, sst.lds_islands), what
+        assert (pst.impulse_iterations, pst.displacement_iterations, pst.joint_visits) == (sst.impulse_iterations, sst.displacement_iterations, sst.joint_visits), what
+        assert pb.tobytes() == sb.tobytes() and pj.tobytes() == sj.tobytes(), what
+
+
 def test_bench_step_hook(solver):
     """phx_solver_bench_hooked calls back once per queued step (bench.py enqueues the per-step all-reduce there); an
     exception raised in the hook aborts the run and reaches the caller, and the handle stays usable."""
