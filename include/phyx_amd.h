@@ -329,8 +329,12 @@ typedef struct {
     int64_t joint_visits;         /* joints swept by them (skipped joints count as visited)     */
     int64_t impulse_iterations;   /* sweeps executed                                            */
 } phx_bench_result;
-/* runs `steps` solves of identical device-resident input (state restored before each step from a
- * device-side snapshot, outside the event brackets) and reports event timings */
+/* runs `steps` solves of identical device-resident input and reports event timings.  Every step needs the input afresh
+ * (a solve overwrites velocities and impulses): phx_solver_bench_stage, called BEFORE the caller starts its clock, makes
+ * `steps` private copies of (bodies, joints) in HBM and the next bench call on the same arrays solves copy k in step k; without
+ * staged copies (or for warm-up steps) a working copy is restored from the caller's arrays in front of every step, inside the
+ * timed region (two copy dispatches per step). */
+int phx_solver_bench_stage(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_joints, int32_t joint_count, int32_t steps);
 int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_contact_points,
                      int32_t contact_point_count, const void* d_joints, int32_t joint_count,
                      const phx_config* config, int32_t warmup, int32_t steps, phx_bench_result* out);

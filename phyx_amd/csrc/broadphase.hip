@@ -34,11 +34,13 @@ __device__ __forceinline__ unsigned radix_float(float v)
 
 // ref: Collider.cpp:259-265
 // (first kernel of an update: it also clears the update's counters and the hub-chunk counts — two dispatches fewer)
-__global__ void __launch_bounds__(256) k_build_keys(const phx_rigid_body* __restrict__ bodies, int n,
+template <bool INTEGRATE>
+__global__ void __launch_bounds__(256) k_build_keys(phx_rigid_body* __restrict__ bodies, int n,
                                                     unsigned* __restrict__ keys, unsigned* __restrict__ idx,
                                                     unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
-                                                    unsigned long long* __restrict__ stamps)
+                                                    unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters)
 {
+    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;      // (the World's step counters)
     // the update's device time without HIP events (an event record is a barrier packet of its own: ~5 us of idle queue): this, its
     // first kernel, leaves the 100 MHz clock in stamps[0]; the count pass's mailbox post and the insert kernel raise stamps[1]
     if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = (unsigned long long)wall_clock64(); stamps[1] = 0ull; }
@@ -47,6 +49,15 @@ __global__ void __launch_bounds__(256) k_build_keys(const phx_rigid_body* __rest
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         keys[i] = radix_float(bodies[i].aabb_min.x);
         idx[i] = (unsigned)i;
+        if (INTEGRATE) {                                       // IntegrateVelocity (ref: World.cpp:39-55), same statements as k_integrate_velocity
+            phx_rigid_body& b = bodies[i];
+            float ax = b.acceleration.x, ay = b.acceleration.y;
+            if (b.inv_mass > 0.0f) ay += gravity;
+            b.velocity.x += ax * dt; b.velocity.y += ay * dt;
+            b.acceleration.x = 0.f; b.acceleration.y = 0.f;
+            b.angular_velocity += b.angular_acceleration * dt;
+            b.angular_acceleration = 0.f;
+        }
     }
 }
 
@@ -438,7 +449,7 @@ int DeviceBroadphase::clear()
     return resize_table(1024);
 }
 
-int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
+int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n, const StepPrologue* prologue)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(n >= 0 && (n == 0 || d_bodies), "bad body array");
@@ -458,6 +469,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
 
     PHX_TRY(stamps_.reserve(2));
     if (n == 0) {
+        if (prologue) PHX_HIP(hipMemsetAsync(prologue->counters, 0, 4 * sizeof(unsigned), stream_));
         PHX_HIP(hipMemsetAsync(stamps_.p, 0, 2 * sizeof(unsigned long long), stream_));
         PHX_HIP(hipStreamSynchronize(stream_));
         stats_.candidate_tests = 0; stats_.overlapping_pairs = 0; stats_.new_pairs = 0; last_new_ = 0;
@@ -465,7 +477,10 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
         return PHX_OK;
     }
 
-    hipLaunchKernelGGL(k_build_keys, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap, stamps_.p);
+    if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, const_cast<phx_rigid_body*>(d_bodies), n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
+                                     chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
+    else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, const_cast<phx_rigid_body*>(d_bodies), n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
+                            chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
     int src = 0;
     PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
     sorted_ = src;

@@ -107,6 +107,12 @@ int phx_solver_get_refreshed(phx_solver* s, int32_t joint, float out30[30])
     return s->impl.get_refreshed(joint, out30);
 }
 
+int phx_solver_bench_stage(phx_solver* s, const void* d_bodies, int32_t nb, const void* d_joints, int32_t nj, int32_t steps)
+{
+    PHX_REQUIRE(s, "null handle");
+    return s->impl.bench_stage(d_bodies, nb, d_joints, nj, steps);
+}
+
 int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t nb, const void* d_cps, int32_t ncp, const void* d_joints, int32_t nj,
                      const phx_config* cfg, int32_t warmup, int32_t steps, phx_bench_result* out)
 {

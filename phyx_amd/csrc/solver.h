@@ -50,6 +50,7 @@ public:
     int get_wave_trace(unsigned long long* out, int cap_words, int* waves_per_group);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
     int get_refreshed(int joint, float out30[30]);
+    int bench_stage(const void* d_bodies, int nb, const void* d_joints, int nj, int steps);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
               const phx_config& cfg, int warmup, int steps, phx_bench_result* out, phx_step_hook hook = nullptr, void* user = nullptr);
 
@@ -164,6 +165,13 @@ private:
     // bench snapshots
     DevBuf<phx_rigid_body> snap_bodies_;
     DevBuf<phx_contact_joint> snap_joints_;
+    // bench_stage(): private copies of the input, one per timed step, made BEFORE the timed region (the input of every step is
+    // then resident in HBM when the clock starts, and no restore copy runs between the solves)
+    DevBuf<phx_rigid_body> stage_bodies_;
+    DevBuf<phx_contact_joint> stage_joints_;
+    const void* staged_src_bodies_ = nullptr; const void* staged_src_joints_ = nullptr;
+    int staged_nb_ = 0, staged_nj_ = 0, staged_steps_ = 0;
+    bool bench_trusted_ = false;                      // bench(): the timed solves run on copies of the input the schedule was built (and verified) for
 
     Schedule sched_;
     std::vector<int> h_static_slot_;

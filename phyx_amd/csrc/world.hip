@@ -54,6 +54,8 @@ public:
 private:
     int sync_bodies_to_device();
     int update_pairs();
+    bool fuse_velocity_ = false; float step_dt_ = 0.f;      // IntegrateVelocity rides on the broadphase's key build (update_pairs)
+    int fresh_manifolds_ = 0;           // pairs UpdatePairs found this step: their manifolds are created by UpdateManifolds' kernel
     int update_manifolds();
     int pack_manifolds();
     int refresh_contact_joints();
@@ -165,14 +167,15 @@ int World::scratch_for(int n)
 
 int World::update_pairs()                                                   // ref: Collider.cpp:251-345
 {
-    PHX_TRY(broadphase_.update_device(d_bodies_.p, nb()));                  // same stream; returns once the new-pair count is known
+    const DeviceBroadphase::StepPrologue prologue{gravity, step_dt_, counters_.p};
+    PHX_TRY(broadphase_.update_device(d_bodies_.p, nb(), fuse_velocity_ ? &prologue : nullptr));      // same stream; returns once the new-pair count is known
+    fuse_velocity_ = false;
     const int fresh = broadphase_.new_pair_count();
     if (!fresh) return PHX_OK;
     PHX_TRY(d_manifolds_.reserve_keep((size_t)nm + fresh, nm, stream_));
     PHX_TRY(d_cps_.reserve_keep(2 * ((size_t)nm + fresh), 2 * (size_t)nm, stream_));
-    hipLaunchKernelGGL(k_append_manifolds, dim3(wgrid(fresh)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, broadphase_.new_pairs_device(), fresh);
-    PHX_HIP(hipGetLastError());
-    nm += fresh;
+    nm += fresh;                                                            // (created by UpdateManifolds' kernel, in the lane that updates them)
+    fresh_manifolds_ = fresh;
     return PHX_OK;
 }
 
@@ -181,7 +184,8 @@ int World::update_manifolds()                                               // r
     if (!nm) return PHX_OK;
     PHX_TRY(scratch_for(nm));
     hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, (const phx_rigid_body*)d_bodies_.p, d_cps_.p,
-                       flags_.p, reinterpret_cast<int*>(counters_.p + 1));
+                       flags_.p, reinterpret_cast<int*>(counters_.p + 1), nm - fresh_manifolds_, broadphase_.new_pairs_device());
+    fresh_manifolds_ = 0;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -296,7 +300,10 @@ int World::pre_solve(float dt)
     RoctxRange update_range("Update (before SolveJoints)");                 // ref: World.cpp:21
     {
         RoctxRange r("IntegrateVelocity");                                  // ref: World.cpp:39-55
-        if (nb()) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt, counters_.p);
+        // (normally fused into the broadphase's first kernel, update_pairs(); a kernel of its own only when the phases are timed one by one)
+        fuse_velocity_ = !phase_timing;
+        step_dt_ = dt;
+        if (nb() && !fuse_velocity_) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt, counters_.p);
         PHX_HIP(hipGetLastError());
         lap(0);
     }

@@ -63,28 +63,24 @@ static __global__ void __launch_bounds__(256) k_integrate_position(phx_rigid_bod
     }
 }
 
-// ref: Collider.cpp:313-316 — Manifold(index_i, index_j, manifolds.size * kMaxContactPoints), contact slots blank
-static __global__ void __launch_bounds__(256) k_append_manifolds(phx_manifold* __restrict__ manifolds, phx_contact_point* __restrict__ cps,
-                                                                 int nm_old, const uint2* __restrict__ pairs, int count)
-{
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const int m = nm_old + k;
-        phx_manifold mm;
-        mm.body1 = (int)pairs[k].x; mm.body2 = (int)pairs[k].y; mm.point_count = 0; mm.point_index = 2 * m;
-        manifolds[m] = mm;
-        phx_contact_point blank;
-        blank.delta1.x = blank.delta1.y = blank.delta2.x = blank.delta2.y = blank.normal.x = blank.normal.y = 0.f;
-        blank.is_merged = 0; blank.is_newly_created = 0; blank.pad_[0] = 0; blank.pad_[1] = 0; blank.solver_index = -1;
-        cps[2 * m] = blank; cps[2 * m + 1] = blank;
-    }
-}
-
-// ref: Collider.cpp:368-377; also flags the manifolds PackManifolds will drop (ref: Collider.cpp:387)
+// ref: Collider.cpp:368-377; also flags the manifolds PackManifolds will drop (ref: Collider.cpp:387).
+// Manifolds [nm_old, nm) are the pairs UpdatePairs has just found (ref: Collider.cpp:313-316 — Manifold(index_i, index_j,
+// manifolds.size * kMaxContactPoints), contact slots blank): they are created here, in the lane that updates them, instead of
+// by an append kernel of their own in front of this one.
 static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, const phx_rigid_body* __restrict__ bodies,
-                                                                 phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped)
+                                                                 phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped,
+                                                                 int nm_old, const uint2* __restrict__ new_pairs)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
-        phx_manifold m = manifolds[i];
+        phx_manifold m;
+        if (i >= nm_old) {
+            const uint2 pr = new_pairs[i - nm_old];
+            m.body1 = (int)pr.x; m.body2 = (int)pr.y; m.point_count = 0; m.point_index = 2 * i;
+            phx_contact_point blank;
+            blank.delta1.x = blank.delta1.y = blank.delta2.x = blank.delta2.y = blank.normal.x = blank.normal.y = 0.f;
+            blank.is_merged = 0; blank.is_newly_created = 0; blank.pad_[0] = 0; blank.pad_[1] = 0; blank.solver_index = -1;
+            cps[2 * i] = blank; cps[2 * i + 1] = blank;
+        } else m = manifolds[i];
         if (update_manifold(m, bodies, cps + m.point_index)) atomicAdd(dropped, 1);
         manifolds[i] = m;
         dead[i] = (m.point_count == 0 && !aabb_intersects(bodies[m.body1], bodies[m.body2])) ? 1u : 0u;

@@ -365,6 +365,29 @@ def test_speculative_binning_equals_the_builders_long_way(oracle, built_lib):
         assert pb.tobytes() == sb.tobytes() and pj.tobytes() == sj.tobytes(), what
 
 
+def test_bench_on_staged_copies(solver):
+    """bench() on copies of the input staged before the clock starts (phx_solver_bench_stage) does the same work as bench() with
+    the restore copies inside the timed region: same sweeps, same visits; the copies are consumed by one call."""
+    state = presolve_state(scenes.stack(8, 30), 3)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, 10, 10)
+    d = [phyx_amd.DeviceArray(a) for a in state]
+    plain = solver.bench(*d, cfg, 1, 6)
+    solver.bench_stage(d[0], d[2], 6)
+    staged = solver.bench(*d, cfg, 0, 6)
+    again = solver.bench(*d, cfg, 0, 6)                # nothing staged any more: restores in front of every step
+    for r in (staged, again):
+        assert (r.joint_visits, r.impulse_iterations, r.impulse_launches) == (plain.joint_visits, plain.impulse_iterations, plain.impulse_launches)
+    assert d[0].to_host().tobytes() == state[0].tobytes() and d[2].to_host().tobytes() == state[2].tobytes()      # the caller's arrays stay untouched
+    # the live-topology mode (a rebuild inside every step) works on staged copies too
+    solver.set_schedule_reuse(False)
+    try:
+        solver.bench_stage(d[0], d[2], 4)
+        live = solver.bench(*d, cfg, 0, 4)
+    finally:
+        solver.set_schedule_reuse(True)
+    assert live.impulse_iterations * 6 == plain.impulse_iterations * 4
+
+
 def test_bench_step_hook(solver):
     """phx_solver_bench_hooked calls back once per queued step (bench.py enqueues the per-step all-reduce there); an
     exception raised in the hook aborts the run and reaches the caller, and the handle stays usable."""

@@ -38,7 +38,9 @@ def per_kernel(path):
 def main(tag, dominant):
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "trace_kernel_stats.csv"), os.path.join(DST, tag + "_kernel_stats.csv"))
-    for name in ("bench_plain.json", "bench_trace.json"):
+    if os.path.exists(os.path.join(SRC, "main_kernel_stats.csv")):       # the main measurement alone: every island launch is a full one
+        shutil.copy(os.path.join(SRC, "main_kernel_stats.csv"), os.path.join(DST, tag + "_kernel_stats_main_only.csv"))
+    for name in ("bench_plain.json", "bench_trace.json", "bench_main.json"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(DST, tag + "_" + name))
     fetch = per_kernel(os.path.join(SRC, "pmc_fetch_counter_collection.csv"))
@@ -79,6 +81,8 @@ def main(tag, dominant):
     for extra in ("world_kernel_stats.csv", "world_step_timeline.txt"):
         if os.path.exists(os.path.join(SRC, extra)):
             shutil.copy(os.path.join(SRC, extra), os.path.join(DST, tag + "_" + extra))
+    if os.path.exists(os.path.join(SRC, "world_marker_api_stats.csv")):
+        shutil.copy(os.path.join(SRC, "world_marker_api_stats.csv"), os.path.join(DST, tag + "_world_marker_stats.csv"))
     json.dump(out, open(os.path.join(DST, tag + "_pmc_traffic.json"), "w"), indent=1)
     print("dominant:", out["dominant_kernel"], "->", out["hbm_bytes_per_launch"], "B per launch")
 
