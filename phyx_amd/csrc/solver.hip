@@ -1296,6 +1296,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     } else PHX_TRY(synchronize());
     if (replays_ != replays && reuse_schedule_) { set_error("bench: topology changed during the timed region"); return PHX_ERR_STATE; }
     float ms = 0.f;
+    PHX_HIP(hipEventSynchronize(bench_events_[2 * steps + 1]));      // (reached long ago — the mailbox post ran behind it — but the runtime may not have looked yet)
     PHX_HIP(hipEventElapsedTime(&ms, bench_events_[2 * steps], bench_events_[2 * steps + 1]));
     out->total_ms = ms;
     for (int i = 0; i < steps; ++i) {
