@@ -1,5 +1,7 @@
 """Worker of test_two_processes_share_the_gpu_and_exchange_over_gloo: one rank of an island-sharded world.
-Run with RANK / WORLD_SIZE / MASTER_* set; every rank uses GPU 0 and the gloo backend (host-staged all-gather)."""
+Run with RANK / WORLD_SIZE / MASTER_* set; every rank uses GPU 0 and the gloo backend (host-staged all-gather).
+PHX_TEST_BACKEND=nccl (one rank only on a one-GPU box): the same through RCCL on the solver's own stream — the transport a GPU
+node uses (test_exchange_through_rccl_one_rank)."""
 import os
 import sys
 
@@ -12,7 +14,8 @@ from phyx_amd import dist as pdist                # noqa: E402
 
 
 def main():
-    g = pdist.init(int(os.environ["WORLD_SIZE"]), backend="gloo")
+    backend = os.environ.get("PHX_TEST_BACKEND", "gloo")
+    g = pdist.init(int(os.environ["WORLD_SIZE"]), backend=backend, force=True)
     scene = scenes.stack(16, 24)
     cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 12, 12)
     full = phyx_amd.World(0, gravity=-200.0)
@@ -27,6 +30,12 @@ def main():
         assert mine.bodies.tobytes() == full.bodies.tobytes(), "rank %d: bodies differ at step %d" % (g.rank, step)
         assert mine.contactJoints.tobytes() == full.contactJoints.tobytes(), "rank %d: joints differ at step %d" % (g.rank, step)
     xch.check()
+    # bench.py's path: K solves queued back to back, the all-gather of every step enqueued from the step hook
+    state = [phyx_amd.DeviceArray(a, 0) for a in (full.bodies, full.contactPoints, full.contactJoints)]
+    mine.solver.bench_stage(state[0], state[2], 5)
+    r = mine.solver.bench(state[0], state[1], state[2], cfg, 1, 5, hook=xch.hook())
+    xch.check()
+    assert r.impulse_iterations > 0
     groups, _ = full.solver.groups()
     assert len(groups) - 1 >= 2
     g.barrier()

@@ -226,6 +226,21 @@ def test_two_processes_share_the_gpu_and_exchange_over_gloo(built_lib):
         assert p.returncode == 0 and "sharded worker ok" in out, out[-1500:] + err[-3000:]
 
 
+def test_exchange_through_rccl_one_rank(built_lib):
+    """The transport a GPU node uses — torch uint8 tensors as exchange buffers, dist.all_gather_into_tensor (backend "nccl" =
+    RCCL) enqueued on the solver's own stream through an ExternalStream — with the one rank a one-GPU box can host: the sharded
+    step (StepBegin / all-gather / StepEnd) against an unsharded World, and bench()'s per-step hook."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PHX_TEST_BACKEND="nccl")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "sharded_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0 and "sharded worker ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
     """phx_world_update returns once the step is queued on the world's stream; every getter waits for it.  Two worlds, one
     read after every step, one only at the end (with an explicit synchronize), must agree bit for bit; the per-phase timers
