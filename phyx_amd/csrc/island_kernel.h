@@ -164,24 +164,25 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
     // TRACE: per wave, shader cycles spent in class steps {working: in the unit update, then at the barrier; idle: whole step}
     unsigned long long tw_work = 0, tw_bar = 0, tw_idle = 0, tw_work_big = 0; unsigned tw_nwork = 0, tw_nidle = 0, tw_nbig = 0;
+    const int tid = threadIdx.x;
+
+    // Set-up is two dependent HBM round trips: level 1 = the group's descriptor, the lane's unit record and its body ids (all at
+    // addresses that depend on the group number only), level 2 = the body records, the joints and the contact points.
+    constexpr int BI = (NB + T - 1) / T;                   // body records per lane
+    int body_id[BI];
+#pragma unroll
+    for (int k = 0; k < BI; ++k) body_id[k] = tid + k * T < NB ? iv.bodies[(size_t)group * NB + tid + k * T] : -1;      // (entries past the group's count: unused words of its table)
+    const int4 ua = iv.unit_recs[2 * ((size_t)group * T + tid)], ub = iv.unit_recs[2 * ((size_t)group * T + tid) + 1];
     const int4 d = iv.desc[group];
     const int ncol = iv.ncol[group];
     const int nunits = iv.units[group];
-    const int tid = threadIdx.x;
-
-    // Set-up is a chain of dependent HBM round trips (index -> record -> contact point); the body chain and the joint
-    // chain are independent, so their loads are issued level by level, both chains in flight together.
-    constexpr int BI = (NB + T - 1) / T;                   // body records per lane
     const bool live = tid < nunits;
-    int body_id[BI];
 #pragma unroll
-    for (int k = 0; k < BI; ++k) body_id[k] = tid + k * T < d.w ? iv.bodies[d.z + tid + k * T] : -1;      // level 1
-    const int2 us = live ? iv.unit_slots[(size_t)group * T + tid] : make_int2(0, -1);
-    const bool has2 = live && us.y >= 0;
-    const int jid0 = live ? v.order[us.x] : 0, jid1 = has2 ? v.order[us.y] : 0;
-    unsigned loc = 0;
-    int col = -1;
-    if (live) { loc = iv.slot_local[us.x]; col = iv.slot_colour[us.x]; }
+    for (int k = 0; k < BI; ++k) if (tid + k * T >= d.w) body_id[k] = -1;
+    const bool has2 = live && ua.y >= 0;
+    const int jid0 = live ? ua.x : 0, jid1 = has2 ? ua.y : 0;
+    const unsigned loc = live ? (unsigned)ub.x : 0u;
+    const int col = live ? ub.y : -1;
     if (tid < 3) { flag_imp[tid] = 0; flag_disp[tid] = 0; }
 
     float4 rec_imp[BI], rec_disp[BI], rec_par[BI];
@@ -198,7 +199,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     int l1 = 0, l2 = 0;
     if (live) {                                            // PrepareJoints (ref: Solver.cpp:509-521)
         const phx_contact_joint j = joints[jid0];
-        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);   // level 3, 32-byte records
+        // (the contact point index is part of the topology the schedule was built — and is gated — for: ua.z == j.contact_point_index)
+        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(ua.z, v.ncp)]);   // 32-byte records
         da0 = cp4[0];
         const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
         q0.nx = nn.x; q0.ny = nn.y;
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     }
     if (has2) {
         const phx_contact_joint j = joints[jid1];
-        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(j.contact_point_index, v.ncp)]);
+        const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(ua.w, v.ncp)]);
         da1 = cp4[0];
         const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
         q1.nx = nn.x; q1.ny = nn.y;

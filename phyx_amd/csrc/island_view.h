@@ -18,10 +18,11 @@ struct IslandView {
     const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
     const int* ncol;                  // per group: classes
     const int* units;                 // per group: units
-    const int2* unit_slots;           // per group g, unit u: [g * T + u] = {leader slot, follower slot or -1}, class-major
-    const int* bodies;                // global body ids, group-local order
-    const unsigned* slot_local;       // per slot: local body1 | local body2 << 16
-    const unsigned char* slot_colour; // per slot: class inside the group
+    // per group g, unit u (class-major): two 16-byte words at [2 * (g * T + u)] = {leader joint, follower joint or -1, leader's contact
+    // point, follower's contact point}, {local body1 | local body2 << 16, class, -, -}: everything a lane needs to start its joint
+    // and contact-point loads after ONE round trip (round 2's chain was descriptor -> unit -> order -> joint -> contact point)
+    const int4* unit_recs;
+    const int* bodies;                // global body ids, group-local order, group g's table at [g * NB]
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
     unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     const int* ngroups_dev;           // null, or the group count where the launch grid is only an upper bound of it (speculative binning, solver.hip)

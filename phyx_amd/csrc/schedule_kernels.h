@@ -343,7 +343,8 @@ struct BinBuildView {
     int4* desc;                       // out: {slot_begin, slot_count, body_begin, body_count}
     int* ncol;                        // out: classes
     int* units;                       // out: units
-    int2* unit_slots;                 // out: [g * T + unit] = {leader slot, follower slot or -1}, class-major
+    int4* unit_recs;                  // out: two words per unit at [2 * (g * T + unit)], class-major (island_view.h): {leader joint, follower joint or -1,
+                                      //      leader's contact point, follower's}, {local body1 | local body2 << 16, class, leader slot, follower slot or -1}
     int* bodies;                      // out: body table of bin g at [g * NB, g * NB + body_count)
     const int* nbins_dev;             // (may be null) the bin count, if the launch grid is only an upper bound of it (speculative binning, solver.hip)
     int* rejected;                    // out: set to 1 if any bin exceeds the caps (caller falls back to the host builder)
@@ -402,12 +403,12 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __syncthreads();
 
     const bool live = tid < count;
-    int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1;
+    int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1, cpi = 0;
     bool follower = false;
     if (live) {
         j = (int)v.sorted_joints[begin + tid];
         const phx_contact_joint jt = v.joints[j];
-        b[0] = jt.body1; b[1] = jt.body2;
+        b[0] = jt.body1; b[1] = jt.body2; cpi = jt.contact_point_index;
         mate = v.partner[j];
         follower = mate >= 0 && (jt.contact_point_index & 1) != 0;
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s
@@ -548,7 +549,10 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
             fslot = begin + (int)class_begin[c] + (int)with_n[c] + (int)single_n[c] + r;
             v.order[fslot] = mate; v.slot_local[fslot] = local; v.slot_colour[fslot] = (unsigned char)c;
         }
-        v.unit_slots[(size_t)g * T + unit_begin[c] + in_class] = make_int2(slot, fslot);
+        // (a follower's contact point is its leader's + 1: the two ids of a unit differ in the lowest bit and the leader carries the even one)
+        const size_t at = 2 * ((size_t)g * T + unit_begin[c] + in_class);
+        v.unit_recs[at] = make_int4(j, paired ? mate : -1, cpi, cpi ^ 1);
+        v.unit_recs[at + 1] = make_int4((int)local, c, slot, fslot);
     }
     if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = n_units; }
 }

@@ -113,7 +113,7 @@ private:
     DevBuf<int> order_, static_slot_, flags_;
     DevBuf<int4> grp_desc_;
     DevBuf<int> grp_ncol_, grp_units_, grp_bodies_, isl_stats_, hbm_body_list_;
-    DevBuf<int2> unit_slots_;           // per LDS group (stride = lanes of the kernel shape): {leader slot, follower slot or -1} of its units
+    DevBuf<int4> unit_recs_;            // per LDS group (stride = lanes of the kernel shape), two words per unit: joints, contact points, local bodies, class, slots (island_view.h)
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;
     DevBuf<unsigned long long> isl_visits_;

@@ -42,7 +42,7 @@ DeviceSolver::~DeviceSolver()
     cc_flags_.release(); comp_size_.release(); comp_units_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release(); jp_kind_.release(); partner_.release(); partner_first_.release();
     jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
-    hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_slots_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
+    hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_recs_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release(); stage_bodies_.release(); stage_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -251,33 +251,39 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     grp_body_count_.assign(ng, 0);
     for (int g = 0; g < ng; ++g) grp_body_count_[g] = sched_.group_body_offsets[g + 1] - sched_.group_body_offsets[g];
     if (ng) {
+        // the layout the device builder leaves (k_build_bin): group g's body table at g * (body capacity of the shape), its units at
+        // g * lanes — the island kernel addresses both by the group number alone
+        const int lanes = sched_.lds_lanes, cap_bodies = lanes > ISL_T ? ISL_B_BIG : ISL_B;
+        std::vector<int> bodies_strided((size_t)ng * cap_bodies, 0);
         for (int g = 0; g < ng; ++g) {
-            desc[g] = make_int4(sched_.group_offsets[g], sched_.group_offsets[g + 1] - sched_.group_offsets[g],
-                                sched_.group_body_offsets[g], sched_.group_body_offsets[g + 1] - sched_.group_body_offsets[g]);
+            desc[g] = make_int4(sched_.group_offsets[g], sched_.group_offsets[g + 1] - sched_.group_offsets[g], g * cap_bodies, grp_body_count_[g]);
             ncol[g] = sched_.group_first_colour[g + 1] - sched_.group_first_colour[g];
+            std::copy(sched_.group_bodies.begin() + sched_.group_body_offsets[g], sched_.group_bodies.begin() + sched_.group_body_offsets[g + 1], bodies_strided.begin() + (size_t)g * cap_bodies);
         }
         const size_t lds_slots = (size_t)sched_.group_offsets[ng];
         PHX_TRY(grp_desc_.reserve(ng)); PHX_TRY(grp_ncol_.reserve(ng));
-        PHX_TRY(grp_bodies_.reserve(sched_.group_bodies.size())); PHX_TRY(slot_local_.reserve(lds_slots)); PHX_TRY(slot_colour_.reserve(lds_slots));
+        PHX_TRY(grp_bodies_.reserve(bodies_strided.size())); PHX_TRY(slot_local_.reserve(lds_slots)); PHX_TRY(slot_colour_.reserve(lds_slots));
         PHX_HIP(hipMemcpyAsync(grp_desc_.p, desc.data(), (size_t)ng * sizeof(int4), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(grp_ncol_.p, ncol.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(grp_bodies_.p, sched_.group_bodies.data(), sched_.group_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(grp_bodies_.p, bodies_strided.data(), bodies_strided.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_local_.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipMemcpyAsync(slot_colour_.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
         // the units, class-major, at a fixed stride of one workgroup's lanes per group
-        const int lanes = sched_.lds_lanes;
         std::vector<int> units(ng);
-        std::vector<int2> unit_slots((size_t)ng * lanes, make_int2(0, -1));
+        std::vector<int4> unit_recs(2 * (size_t)ng * lanes, make_int4(0, -1, 0, 0));
         for (int g = 0; g < ng; ++g) {
             units[g] = sched_.group_unit_offsets[g + 1] - sched_.group_unit_offsets[g];
             for (int u = 0; u < units[g]; ++u) {
                 const int at = sched_.group_unit_offsets[g] + u;
-                unit_slots[(size_t)g * lanes + u] = make_int2(sched_.unit_leader[at], sched_.unit_follower[at]);
+                const int ls = sched_.unit_leader[at], fs = sched_.unit_follower[at];
+                const int lj = sched_.order[ls], fj = fs >= 0 ? sched_.order[fs] : -1;
+                unit_recs[2 * ((size_t)g * lanes + u)] = make_int4(lj, fj, prio_id[lj], fj >= 0 ? prio_id[fj] : 0);
+                unit_recs[2 * ((size_t)g * lanes + u) + 1] = make_int4((int)sched_.slot_local[ls], (int)sched_.slot_colour[ls], ls, fs);
             }
         }
-        PHX_TRY(grp_units_.reserve(ng)); PHX_TRY(unit_slots_.reserve(unit_slots.size()));
+        PHX_TRY(grp_units_.reserve(ng)); PHX_TRY(unit_recs_.reserve(unit_recs.size()));
         PHX_HIP(hipMemcpyAsync(grp_units_.p, units.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(unit_slots_.p, unit_slots.data(), unit_slots.size() * sizeof(int2), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(unit_recs_.p, unit_recs.data(), unit_recs.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
     }
     PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sched_.hbm_bodies.size(), 1)));
     if (!sched_.hbm_bodies.empty())
@@ -451,12 +457,12 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     PHX_TRY(slot_local_.reserve(std::max(lds_slots, 1))); PHX_TRY(slot_colour_.reserve(std::max(lds_slots, 1)));
     if (nbins) {
         BinBuildView bv{};
-        PHX_TRY(grp_units_.reserve(nbins)); PHX_TRY(unit_slots_.reserve((size_t)nbins * cap_units));
+        PHX_TRY(grp_units_.reserve(nbins)); PHX_TRY(unit_recs_.reserve(2 * (size_t)nbins * cap_units));
         bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.partner = partner_.p; bv.is_static = cc_static_.p;
         bv.joint_comp = joint_comp_.p; bv.comp_rank = rank_of_comp;
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
-        bv.units = grp_units_.p; bv.unit_slots = unit_slots_.p;
+        bv.units = grp_units_.p; bv.unit_recs = unit_recs_.p;
         bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2; bv.poison = hash_.p + hash_slot_;
         if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(2 * ISL_T_BIG), 0, stream_, bv);
         else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(2 * ISL_T), 0, stream_, bv);
@@ -644,13 +650,13 @@ int DeviceSolver::build_bins_speculative(const phx_rigid_body* d_bodies, int nb,
     PHX_TRY(grp_desc_.reserve(grid)); PHX_TRY(grp_ncol_.reserve(grid));
     PHX_TRY(grp_bodies_.reserve((size_t)grid * cap_bodies));
     PHX_TRY(slot_local_.reserve(nj)); PHX_TRY(slot_colour_.reserve(nj));
-    PHX_TRY(grp_units_.reserve(grid)); PHX_TRY(unit_slots_.reserve((size_t)grid * cap_units));
+    PHX_TRY(grp_units_.reserve(grid)); PHX_TRY(unit_recs_.reserve(2 * (size_t)grid * cap_units));
     BinBuildView bv{};
     bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = cv.goff; bv.joints = d_joints; bv.partner = partner_.p; bv.is_static = cc_static_.p;
     bv.joint_comp = joint_comp_.p; bv.comp_rank = cv.rank_of;
     bv.nb = nb; bv.max_static = 1 << 30;
     bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
-    bv.units = grp_units_.p; bv.unit_slots = unit_slots_.p;
+    bv.units = grp_units_.p; bv.unit_recs = unit_recs_.p;
     bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2; bv.poison = hash_.p + hash_slot_;
     bv.nbins_dev = bin_result_.p;
     if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(grid), dim3(2 * ISL_T_BIG), 0, stream_, bv);
@@ -743,7 +749,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         iv.first = shard_; iv.stride = shard_count_;
         iv.ngroups_dev = spec_bins_pending_ ? bin_result_.p : nullptr;
         iv.stamp_begin = iv.stamp_end = owns_hbm_group() ? 0 : 1;      // (with an HBM group, its first and last kernels leave the stamps)
-        iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_slots = unit_slots_.p; iv.bodies = grp_bodies_.p; iv.slot_local = slot_local_.p; iv.slot_colour = slot_colour_.p;
+        iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_recs = unit_recs_.p; iv.bodies = grp_bodies_.p;
         iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
         iv.trace = nullptr; iv.wave_trace = nullptr;
         if (trace_islands_) {
