@@ -345,13 +345,13 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     if (*v.fingerprint != v.expected_fingerprint) { if (iv.stamp_end) solve_stamp_end(v.stamps); return; }
     if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
         phx_contact_joint& out = joints[jid0];
-        out.normal_accumulated_impulse = q0.accN;
-        out.friction_accumulated_impulse = q0.accF;
+        __builtin_nontemporal_store(q0.accN, &out.normal_accumulated_impulse);
+        __builtin_nontemporal_store(q0.accF, &out.friction_accumulated_impulse);
     }
     if (has2) {
         phx_contact_joint& out = joints[jid1];
-        out.normal_accumulated_impulse = q1.accN;
-        out.friction_accumulated_impulse = q1.accF;
+        __builtin_nontemporal_store(q1.accN, &out.normal_accumulated_impulse);
+        __builtin_nontemporal_store(q1.accF, &out.friction_accumulated_impulse);
     }
 #pragma unroll
     for (int k = 0; k < BI; ++k) {                         // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         if (body_id[k] < 0 || is_st[i]) continue;
         phx_rigid_body& b = bodies[body_id[k]];
         const float4 a = body_load(imp, i), e = body_load(disp, i);
-        b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
-        b.displacing_velocity.x = e.x; b.displacing_velocity.y = e.y; b.displacing_angular_velocity = e.z;
+        __builtin_nontemporal_store(a.x, &b.velocity.x); __builtin_nontemporal_store(a.y, &b.velocity.y); __builtin_nontemporal_store(a.z, &b.angular_velocity);
+        __builtin_nontemporal_store(e.x, &b.displacing_velocity.x); __builtin_nontemporal_store(e.y, &b.displacing_velocity.y); __builtin_nontemporal_store(e.z, &b.displacing_angular_velocity);
     }
     if (iv.stamp_end) solve_stamp_end(v.stamps);           // (no HBM group behind this launch: it is the solve's last kernel)
     if (tid == 0) {
