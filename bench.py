@@ -128,7 +128,7 @@ def main():
             slv.synchronize()
             group.barrier()
             el = time.perf_counter() - t0
-            blocks.append(dict(elapsed=el, total_ms=r.total_ms, sweep_ms=r.impulse_kernel_ms, launches=r.impulse_launches,
+            blocks.append(dict(elapsed=el, total_ms=r.total_ms, sweep_ms=r.impulse_kernel_ms, launches=r.impulse_launches, bracketed=r.bracketed_launches,
                                visits=r.joint_visits, iterations=r.impulse_iterations))
         # the block every rank reports must be the same one: rank by the max-over-ranks time
         times = [group.reduce_max(b["elapsed"]) for b in blocks]
@@ -162,7 +162,7 @@ def main():
     phases = None
     if world == 1 and lds and not args.no_secondary:
         zero = run(Configuration(phyx_amd.SOLVE_AVX2, island_mode, 0, 0), 2, 10, 3)
-        phases = {"setup_prestep_writeback_us": 1e3 * zero["sweep_ms"] / max(zero["launches"], 1)}
+        phases = {"setup_prestep_writeback_us": 1e3 * zero["sweep_ms"] / max(zero["bracketed"], 1)}
 
     # ---- secondary (N=1 only, untimed by the driver): strict Single island mode = the general-case (big island) path
     single_tot = live_tot = None
@@ -202,7 +202,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed_max / max(args.steps, 1)
         launches = max(main_tot["launches"], 1)
-        launch_us = 1e3 * main_tot["sweep_ms"] / launches
+        launch_us = 1e3 * main_tot["sweep_ms"] / max(main_tot["bracketed"], 1)      # HIP events around the launches of every 4th timed step
         alg = algorithmic_bytes(main_tot, args.steps) / launches
         kname = "k_solve_islands" if lds else "k_solve_colour"
         tbytes = traffic.get(kname)
@@ -219,7 +219,7 @@ def main():
                 "achieved": (tbytes / (launch_us * 1e-6) / 1e9) if tbytes else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (tbytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tbytes else None,
                 "traffic": tbytes, "traffic_source": tsource,
-                "launches": main_tot["launches"], "avg_launch_us": launch_us,
+                "launches": main_tot["launches"], "launches_bracketed_by_hip_events": main_tot["bracketed"], "avg_launch_us": launch_us,
                 "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / (launch_us * 1e-6) / 1e9,
                 "note": ("achieved / frac = HBM bytes the kernel really moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, `traffic`) over its "
                          "live HIP-event launch time.  algorithmic_GBps = SURVEY.md §8(d) bytes (196 B per impulse joint-visit, 136 B per "
@@ -264,9 +264,9 @@ def main():
             "extra": {"solver_iterations_per_sec": iters_max / elapsed_max,
                       "contacts_resolved_per_sec": nj * args.steps / elapsed_max,
                       "device_ms_per_step": main_tot["total_ms"] / max(args.steps, 1),
-                      "sweep_ms_per_step": main_tot["sweep_ms"] / max(args.steps, 1),
+                      "sweep_ms_per_step": main_tot["sweep_ms"] * main_tot["launches"] / max(main_tot["bracketed"], 1) / max(args.steps, 1),
                       "all_blocks_ms_per_step": [round(x, 5) for x in main_tot["all_blocks_ms_per_step"]],
-                      "joint_visits_per_sec_sweeps_only": main_tot["visits"] / (main_tot["sweep_ms"] * 1e-3) if main_tot["sweep_ms"] > 0 else None},
+                      "joint_visits_per_sec_sweeps_only": main_tot["visits"] / (main_tot["sweep_ms"] * main_tot["launches"] / max(main_tot["bracketed"], 1) * 1e-3) if main_tot["sweep_ms"] > 0 else None},
             "roofline": roof,
         }
         if weak is not None:
@@ -286,7 +286,7 @@ def main():
             k = max(5, args.steps // 2)
             sst = single_tot["stats"]
             sl = max(single_tot["launches"], 1)
-            s_us = 1e3 * single_tot["sweep_ms"] / sl
+            s_us = 1e3 * single_tot["sweep_ms"] / max(single_tot["bracketed"], 1)
             s_alg = algorithmic_bytes(single_tot, k) / sl
             skey = "k_solve_dataflow" if sl <= 2 * k else "k_solve_colour"
             s_tr = traffic.get(skey)
@@ -332,7 +332,7 @@ def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joi
     for n in (1, 2, 4, 8):
         slv.set_shard(0, n)
         tot = run(cfg3, 2, 10, 3, slv=slv, hk=xch.hook())
-        res["n=%d" % n] = {"ms_per_step": 1e3 * tot["elapsed_max"] / 10, "island_launch_us": 1e3 * tot["sweep_ms"] / max(tot["launches"], 1),
+        res["n=%d" % n] = {"ms_per_step": 1e3 * tot["elapsed_max"] / 10, "island_launch_us": 1e3 * tot["sweep_ms"] / max(tot["bracketed"], 1),
                            "segment_bytes": slv.exchange_segment_bytes(), "groups": (tot["stats"].lds_islands + n - 1) // n}
     return res
 
@@ -383,7 +383,7 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     t0 = time.perf_counter(); r = s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 0, 10); el = time.perf_counter() - t0
     st = s5.stats()
     res["cfg5_500k_tall_50it_fp32"] = {"ms_per_step": 1e3 * el / 10, "joint_visits_per_sec": r.joint_visits / el, "joints": arrs[2].count,
-                                       "impulse_sweeps": st.impulse_iterations, "lds_islands": st.lds_islands, "sweep_ms_per_step": r.impulse_kernel_ms / 10}
+                                       "impulse_sweeps": st.impulse_iterations, "lds_islands": st.lds_islands, "sweep_ms_per_step": r.impulse_kernel_ms * r.impulse_launches / max(r.bracketed_launches, 1) / 10}
     # the ablation of config 5: solver-side body state in fp16 (fp32 arithmetic, every store rounds to nearest even)
     def solved(solver):
         b, j = phyx_amd.DeviceArray(w5.bodies, device), phyx_amd.DeviceArray(w5.contactJoints, device)
@@ -397,7 +397,7 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     b16, j16 = solved(s5)
     res["cfg5_500k_tall_50it_fp16_body_state"] = {
         "ms_per_step": 1e3 * el16 / 10, "joint_visits_per_sec": r16.joint_visits / el16, "impulse_sweeps": st16.impulse_iterations,
-        "sweep_ms_per_step": r16.impulse_kernel_ms / 10,
+        "sweep_ms_per_step": r16.impulse_kernel_ms * r16.impulse_launches / max(r16.bracketed_launches, 1) / 10,
         "max_abs_velocity_diff_vs_fp32": float(max(np.abs(b16["velocity"]["x"] - b32["velocity"]["x"]).max(), np.abs(b16["velocity"]["y"] - b32["velocity"]["y"]).max())),
         "mean_abs_velocity_diff_vs_fp32": float(np.abs(b16["velocity"]["y"] - b32["velocity"]["y"]).mean()),
         "max_abs_impulse_diff_vs_fp32": float(np.abs(j16["normal_acc"] - j32["normal_acc"]).max())}

@@ -324,10 +324,11 @@ int  phx_world_set_phase_timing(phx_world* w, int32_t on);
 /* measurement helpers used by bench.py: HIP events on the handle's own stream                     */
 typedef struct {
     double  total_ms;             /* events around the whole timed region                      */
-    double  impulse_kernel_ms;    /* sum of HIP-event brackets around the impulse sweeps        */
-    int64_t impulse_launches;     /* colour kernels launched in those brackets                  */
+    double  impulse_kernel_ms;    /* sum of the HIP-event brackets around the sweep launches of every 4th step (every step if steps < 8) */
+    int64_t impulse_launches;     /* sweep kernels launched by all the steps                    */
     int64_t joint_visits;         /* joints swept by them (skipped joints count as visited)     */
     int64_t impulse_iterations;   /* sweeps executed                                            */
+    int64_t bracketed_launches;   /* sweep kernels inside the brackets: impulse_kernel_ms / this = average launch */
 } phx_bench_result;
 /* runs `steps` solves of identical device-resident input and reports event timings.  Every step needs the input afresh
  * (a solve overwrites velocities and impulses): phx_solver_bench_stage, called BEFORE the caller starts its clock, makes

@@ -38,7 +38,7 @@ class BroadphaseStats(C.Structure):
 
 class BenchResult(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("impulse_kernel_ms", C.c_double), ("impulse_launches", C.c_int64),
-                ("joint_visits", C.c_int64), ("impulse_iterations", C.c_int64)]
+                ("joint_visits", C.c_int64), ("impulse_iterations", C.c_int64), ("bracketed_launches", C.c_int64)]
 
 
 _lib = None
