@@ -321,7 +321,7 @@ int  phx_world_get_phase_ms(phx_world* w, double out8[8]);
 int  phx_world_set_phase_timing(phx_world* w, int32_t on);
 
 /* ---------------------------------------------------------------------------------------------- */
-/* measurement helpers used by bench.py: HIP events on the handle's own stream                     */
+/* measurement helpers used by bench.py: K solves queued back to back, HIP events on the handle's own stream */
 typedef struct {
     double  total_ms;             /* events around the whole timed region                      */
     double  impulse_kernel_ms;    /* sum of the HIP-event brackets around the sweep launches of every 4th step (every step if steps < 8) */
