@@ -301,6 +301,8 @@ def main():
         if world == 1 and not args.no_secondary:
             out["extra"]["cfg3_one_rank_of_n"] = one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run)
             out["extra"]["other_configs"] = other_configs(phyx_amd, scenes, Configuration, device, world_obj, cfg)
+            if (args.columns, args.rows) == (1000, 200):
+                out["extra"]["four_times_the_world_one_rank_of_n"] = four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, device, args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bodies, cps, joints, args.iters, args.cpu_seconds)
         print(json.dumps(out))
@@ -334,6 +336,41 @@ def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joi
         tot = run(cfg3, 2, 10, 3, slv=slv, hk=xch.hook())
         res["n=%d" % n] = {"ms_per_step": 1e3 * tot["elapsed_max"] / 10, "island_launch_us": 1e3 * tot["sweep_ms"] / max(tot["bracketed"], 1),
                            "segment_bytes": slv.exchange_segment_bytes(), "groups": (tot["stats"].lds_islands + n - 1) // n}
+    return res
+
+
+def four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, device, args):
+    """Where island sharding does scale: a world of 4000 columns (800k boxes) is four residency rounds of the island kernel on one
+    GPU (1024 workgroups are resident at once); with 1/N of the groups a rank needs 4/N rounds.  Measured like
+    cfg3_one_rank_of_n: shard 0 of N on this GPU, pack + local copy + unpack, no RCCL time."""
+    import time
+    from phyx_amd import dist as pdist
+    cfg3 = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, args.iters, args.iters)
+    w = phyx_amd.World(device, gravity=-200.0)
+    w.add_scene(scenes.stack(4 * args.columns, args.rows))
+    for _ in range(args.scene_steps):
+        w.Update(1.0 / 60.0, cfg3)
+    w.PreSolve(1.0 / 60.0)
+    arrs = [phyx_amd.DeviceArray(a, device) for a in (w.bodies, w.contactPoints, w.contactJoints)]
+    nb, nj = arrs[0].count, arrs[2].count
+    del w
+    slv = phyx_amd.Solver(device)
+    xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj) // 512 * 256, device)
+    res = {"bodies": nb, "joints": nj}
+    for n in (1, 2, 4, 8):
+        slv.set_shard(0, n)
+        slv.bench(arrs[0], arrs[1], arrs[2], cfg3, 0, 1, hook=xch.hook())
+        best = None
+        for _ in range(3):
+            slv.bench_stage(arrs[0], arrs[2], 5)
+            slv.synchronize()
+            t0 = time.perf_counter()
+            r = slv.bench(arrs[0], arrs[1], arrs[2], cfg3, 0, 5, hook=xch.hook())
+            slv.synchronize()
+            el = (time.perf_counter() - t0) / 5
+            best = el if best is None else min(best, el)
+        res["n=%d" % n] = {"ms_per_step": 1e3 * best, "island_launch_us": 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1),
+                           "groups": (slv.stats().lds_islands + n - 1) // n}
     return res
 
 
