@@ -57,6 +57,7 @@ private:
     bool fuse_velocity_ = false; float step_dt_ = 0.f;      // IntegrateVelocity rides on the broadphase's key build (update_pairs)
     int fresh_manifolds_ = 0;           // pairs UpdatePairs found this step: their manifolds are created by UpdateManifolds' kernel
     int update_manifolds();
+    int finish_pack(int dead, int dropped);
     int pack_manifolds();
     int refresh_contact_joints();
     int solve(const phx_config& cfg, bool settle);
@@ -74,8 +75,13 @@ private:
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
     DevBuf<unsigned> flags_, dead_flags_, counters_, joint_seen_;      // joint_seen_[j] == joint_epoch_: a contact point re-attached joint j this step
+    DevBuf<unsigned> pack_flags_;       // dead-manifold flags, then their scan (a table of its own: the joint match reuses flags_ while the pack may still be pending)
+    // PackManifolds' count is not waited for when the previous step found no dead manifold (the steady state of a stack): the
+    // joint match is queued behind the scan on the assumption that nothing dies, both counts come back in ONE round trip, and
+    // only if a manifold did die is the pack run then and the match repeated (a new epoch makes the first one void)
+    bool pack_pending_ = false, expect_no_dead_manifolds_ = false;
     unsigned joint_epoch_ = 0;
-    ScanScratch scan_tiles_;     // counters_: [0] dead/new total, [1] dropped points
+    ScanScratch scan_tiles_;     // counters_: [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
     Readback rb_;
     bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
     DevBuf<int> mover_pos_;
@@ -87,7 +93,7 @@ World::~World()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
-    flags_.release(); dead_flags_.release(); joint_seen_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
+    flags_.release(); pack_flags_.release(); dead_flags_.release(); joint_seen_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
     // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
 
@@ -183,8 +189,9 @@ int World::update_manifolds()                                               // r
 {
     if (!nm) return PHX_OK;
     PHX_TRY(scratch_for(nm));
+    PHX_TRY(pack_flags_.reserve((size_t)nm + 2));                           // (only here: a pending pack keeps its scan in it until refresh_contact_joints settles it)
     hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, (const phx_rigid_body*)d_bodies_.p, d_cps_.p,
-                       flags_.p, reinterpret_cast<int*>(counters_.p + 1), nm - fresh_manifolds_, broadphase_.new_pairs_device());
+                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device());
     fresh_manifolds_ = 0;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
@@ -192,18 +199,25 @@ int World::update_manifolds()                                               // r
 
 int World::pack_manifolds()                                                 // ref: Collider.cpp:379-416
 {
+    pack_pending_ = false;
     if (!nm) return PHX_OK;
-    PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
-    unsigned host[2] = {0, 0};
-    PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
+    PHX_TRY(device_exclusive_scan(pack_flags_.p, nm, counters_.p + 2, scan_tiles_, stream_));
+    if (expect_no_dead_manifolds_ && !phase_timing) { pack_pending_ = true; return PHX_OK; }      // settled by refresh_contact_joints' round trip
+    unsigned host[2] = {0, 0};                                              // [0] dead manifolds, [1] dropped points
+    PHX_TRY(rb_.add(host, counters_.p + 2, sizeof host, stream_));
     PHX_TRY(rb_.wait(stream_));
-    dropped_points += (int)host[1];
-    const int dead = (int)host[0];
+    return finish_pack((int)host[0], (int)host[1]);
+}
+
+int World::finish_pack(int dead, int dropped)
+{
+    dropped_points += dropped;
+    expect_no_dead_manifolds_ = dead == 0;
     if (!dead) return PHX_OK;
     PHX_TRY(erased_.reserve(dead));
-    hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)flags_.p, (const unsigned*)counters_.p, nm, nm, mover_pos_.p);
-    hipLaunchKernelGGL(k_pack_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, (const unsigned*)flags_.p,
-                       (const unsigned*)counters_.p, (const int*)mover_pos_.p, erased_.p);
+    hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)pack_flags_.p, (const unsigned*)(counters_.p + 2), nm, nm, mover_pos_.p);
+    hipLaunchKernelGGL(k_pack_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, (const unsigned*)pack_flags_.p,
+                       (const unsigned*)(counters_.p + 2), (const int*)mover_pos_.p, erased_.p);
     PHX_HIP(hipGetLastError());
     nm -= dead;
     return broadphase_.erase_pairs_device(erased_.p, dead);                 // ref: Collider.cpp:391 manifoldMap.erase
@@ -215,24 +229,37 @@ int World::refresh_contact_joints()                                         // r
     PHX_TRY(dead_flags_.reserve((size_t)nj + 2));
     const size_t seen_cap = joint_seen_.cap;
     PHX_TRY(joint_seen_.reserve((size_t)nj + 2));
-    if (joint_seen_.cap != seen_cap || ++joint_epoch_ == 0) {               // new (uninitialised) table, or the epoch wrapped: stale stamps could alias
+    if (joint_seen_.cap != seen_cap) {                                      // new (uninitialised) table: stale stamps could alias
         PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
-        joint_epoch_ = 1;
+        joint_epoch_ = 0;
     }
-    // One host round trip for both counts.  A joint is dead iff no contact point re-attached it (the match), which is
+    // One host round trip for the counts.  A joint is dead iff no contact point re-attached it (the match), which is
     // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
-    unsigned host[2] = {0, 0};                                              // [0] new joints, [1] dead joints
-    if (nm) {
-        hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
-                           d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p);
-        PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
-    }
-    if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_}, dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
-    if (nm || nj) {                                                         // counters_[0], [1]: adjacent words, one copy
-        PHX_TRY(rb_.add(host, counters_.p, sizeof host, stream_));
-        PHX_TRY(rb_.wait(stream_));
-        if (!nm) host[0] = 0;                                               // (not written this step)
-        if (!nj) host[1] = 0;
+    unsigned host[4] = {0, 0, 0, 0};                                        // [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
+    for (int attempt = 0;; ++attempt) {
+        if (++joint_epoch_ == 0) {                                          // the epoch wrapped: stale stamps could alias
+            PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
+            joint_epoch_ = 1;
+        }
+        if (nm) {
+            hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
+                               d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p);
+            PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
+        }
+        if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_}, dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
+        if (nm || nj || pack_pending_) {                                    // counters_[0 .. 3]: adjacent words, one copy
+            PHX_TRY(rb_.add(host, counters_.p, pack_pending_ ? sizeof host : 2 * sizeof(unsigned), stream_));
+            PHX_TRY(rb_.wait(stream_));
+            if (!nm) host[0] = 0;                                           // (not written this step)
+            if (!nj) host[1] = 0;
+        }
+        if (!pack_pending_) break;
+        // PackManifolds' count came back with the joints': normally 0 (that was the bet) — if not, pack now and match again
+        pack_pending_ = false;
+        const int nm_before = nm;
+        PHX_TRY(finish_pack((int)host[2], (int)host[3]));
+        if (nm == nm_before) break;
+        if (attempt) { set_error("RefreshContactJoints: the manifold pack did not settle"); return PHX_ERR_STATE; }
     }
     const int fresh = (int)host[0], dead = (int)host[1], old = nj;
     const int total = nj + fresh;
