@@ -122,7 +122,7 @@ struct PinnedBuf {
 
 // small host -> device upload by a kernel that reads the (host-coherent, device-visible) pinned staging directly: a DMA of a
 // few KB waits its turn in the copy engine's queue before anything moves; a dispatch reads them over PCIe in a few microseconds
-static __global__ void __launch_bounds__(256) k_upload_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src_host, int words)
+__attribute__((unused)) static __global__ void __launch_bounds__(256) k_upload_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src_host, int words)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src_host[i];
 }
