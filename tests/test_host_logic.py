@@ -214,3 +214,75 @@ def test_exchange_layout_partitions_the_groups_over_the_ranks():
         assert int(rank_words.sum()) - 8 * n == int(sum((6 * int(b) + 2 * int(s) + 3) // 4 * 4 for b, s in zip(gb, gs)))
     with pytest.raises(phyx_amd.PhxError):
         phyx_amd.exchange_layout([1], [1], 0)
+
+
+def _greedy_bins(sizes, units, cap_units):
+    """The host loop of the schedule builder (csrc/solver.hip, step 3): consecutive components packed greedily."""
+    bin_of, rank_of, goff = [-1] * len(sizes), [0] * len(sizes), [0]
+    size = unit = rank = 0
+    opened = False
+    for c, (n, u) in enumerate(zip(sizes, units)):
+        if n == 0:
+            continue
+        if not opened or size + n > 2 * cap_units or unit + u > cap_units:
+            goff.append(goff[-1]); opened = True; size = unit = rank = 0
+        bin_of[c] = len(goff) - 2; rank_of[c] = rank; rank += 1
+        size += n; unit += u; goff[-1] += n
+    return bin_of, rank_of, goff
+
+
+def _chain_bins(sizes, units, cap_units):
+    """k_bin_components' formulation (csrc/schedule_kernels.h): greedy packing is a chain — every component finds where a bin
+    opened at it would end (binary searches over the prefix sums), the components reachable from component 0 along those links
+    are marked by pointer doubling, and a scan of the marks numbers the bins."""
+    n = len(sizes)
+    ps, pu, pn = np.cumsum(sizes), np.cumsum(units), np.cumsum(np.asarray(sizes) > 0)
+    before = lambda pre, a: int(pre[a - 1]) if a else 0
+    nxt = np.empty(n, dtype=np.int64)
+    for a in range(n):
+        e1 = int(np.searchsorted(ps, before(ps, a) + 2 * cap_units, side="right"))      # first e with ps[e] - before > limit
+        e2 = int(np.searchsorted(pu, before(pu, a) + cap_units, side="right"))
+        nxt[a] = max(min(e1, e2), a + 1)
+    reach = np.zeros(n, dtype=bool)
+    if n and ps[-1] > 0:
+        reach[0] = True
+    jump, span = nxt.copy(), 1
+    while span < n:
+        src = np.nonzero(reach & (jump < n))[0]
+        reach[jump[src]] = True
+        jump = np.where(jump < n, jump[np.minimum(jump, n - 1)], n)
+        span *= 2
+    bin_at = np.cumsum(reach) - 1
+    heads = np.nonzero(reach)[0]
+    bin_of, rank_of = [-1] * n, [0] * n
+    for c in range(n):
+        if sizes[c] == 0:
+            continue
+        h = int(heads[bin_at[c]])
+        bin_of[c] = int(bin_at[c]); rank_of[c] = int(pn[c] - 1 - (pn[h - 1] if h else 0))
+    goff = [before(ps, int(h)) for h in heads] + [int(ps[-1]) if n else 0]
+    return bin_of, rank_of, goff
+
+
+def test_binning_as_a_chain_equals_the_greedy_loop():
+    """The device's binning (pointer doubling over 'where would a bin opened here end') against the sequential greedy loop it
+    replaces, on random component sizes incl. empty components, components that fill a bin alone and long runs of tiny ones."""
+    rng = np.random.default_rng(7)
+    for case in range(300):
+        n = int(rng.integers(1, 400))
+        cap = int(rng.choice([256, 512]))
+        kind = case % 4
+        if kind == 0:
+            sizes = rng.integers(0, 2 * cap + 1, size=n)
+        elif kind == 1:
+            sizes = rng.integers(0, 40, size=n)
+        elif kind == 2:
+            sizes = np.where(rng.random(n) < 0.5, 0, rng.integers(1, 2 * cap + 1, size=n))
+        else:
+            sizes = np.full(n, 440 if cap == 256 else 1000)
+        units = np.minimum(cap, (sizes + 1) // 2 + rng.integers(0, 3, size=n) * (sizes > 0))
+        units = np.where(sizes > 0, np.maximum(units, (sizes + 1) // 2), 0)
+        units = np.minimum(units, np.minimum(sizes, cap))
+        g = _greedy_bins(list(map(int, sizes)), list(map(int, units)), cap)
+        c = _chain_bins(list(map(int, sizes)), list(map(int, units)), cap)
+        assert g == c, (case, n, cap)
