@@ -1287,9 +1287,12 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     PHX_HIP(hipEventRecord(bench_events_[2 * steps], stream_));
     // HIP events bracket the sweep launches of every 4th step only: an event record is a barrier packet of its own (~3 us of idle
     // queue), and bracketing every step's sweeps cost 6.4 us per step — 7 % of the value being measured (tools/exp_events.py)
-    const int bracket_stride = steps >= 8 ? 4 : 1;
+    // (PHX_BENCH_BRACKET_STRIDE=n, measurement of the measurement: 1 = every step, 0 = no events at all — tools/exp_events.py)
+    const char* bs_env = getenv("PHX_BENCH_BRACKET_STRIDE");
+    const int bracket_stride = bs_env ? (atoi(bs_env) > 0 ? atoi(bs_env) : steps + 1) : (steps >= 8 ? 4 : 1);
+    const bool bracket_any = !(bs_env && atoi(bs_env) <= 0);
     for (int i = 0; i < steps && st == PHX_OK; ++i) {
-        time_sweeps_ = i % bracket_stride == 0;
+        time_sweeps_ = bracket_any && i % bracket_stride == 0;
         if (time_sweeps_) { ev_sweep_begin_ = bench_events_[2 * i]; ev_sweep_end_ = bench_events_[2 * i + 1]; }      // (else: still the last bracketed step's pair — a
                                                                                                                   //  solve settled later reads the pair it recorded)
         step_hook_step_ = i;
@@ -1310,13 +1313,13 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     PHX_HIP(hipEventSynchronize(bench_events_[2 * steps + 1]));      // (reached long ago — the mailbox post ran behind it — but the runtime may not have looked yet)
     PHX_HIP(hipEventElapsedTime(&ms, bench_events_[2 * steps], bench_events_[2 * steps + 1]));
     out->total_ms = ms;
-    for (int i = 0; i < steps; i += bracket_stride) {
+    for (int i = 0; bracket_any && i < steps; i += bracket_stride) {
         PHX_HIP(hipEventElapsedTime(&ms, bench_events_[2 * i], bench_events_[2 * i + 1]));
         out->impulse_kernel_ms += ms;
     }
     // identical input every step => identical counters every step
     out->impulse_launches = (long long)sweep_launches_ * steps;
-    out->bracketed_launches = (long long)sweep_launches_ * ((steps + bracket_stride - 1) / bracket_stride);
+    out->bracketed_launches = bracket_any ? (long long)sweep_launches_ * ((steps + bracket_stride - 1) / bracket_stride) : 0;
     out->impulse_iterations = (long long)stats_.impulse_iterations * steps;
     out->joint_visits = stats_.joint_visits * steps;
     return PHX_OK;

@@ -1,4 +1,5 @@
-"""experiment: cost of the per-launch HIP events inside bench() (PHX_EXP_NO_EVENTS=1 drops them)"""
+"""experiment: cost of the HIP events that bracket the sweep launches inside bench(): run with PHX_BENCH_BRACKET_STRIDE=1 (every
+step), unset (every 4th step, the default) and =0 (none)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
