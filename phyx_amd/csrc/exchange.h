@@ -20,6 +20,7 @@
 #pragma once
 
 #include "common.h"
+#include "body_view.h"
 
 namespace phx {
 
@@ -61,7 +62,7 @@ struct ExchangeView {
 };
 
 // One workgroup per OWNED LDS group (group = shard + blockIdx.x * shard_count): solved fields -> send segment.
-__global__ void __launch_bounds__(256) k_exchange_pack(ExchangeView x, const phx_rigid_body* __restrict__ bodies, const phx_contact_joint* __restrict__ joints,
+__global__ void __launch_bounds__(256) k_exchange_pack(ExchangeView x, BodyView bodies, const phx_contact_joint* __restrict__ joints,
                                                        unsigned* __restrict__ send, unsigned serial, unsigned status, unsigned long long fingerprint)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -73,10 +74,11 @@ __global__ void __launch_bounds__(256) k_exchange_pack(ExchangeView x, const phx
     const int4 d = x.desc[g];
     float* out = reinterpret_cast<float*>(send + x.xoff[g]);
     for (int i = threadIdx.x; i < d.w; i += blockDim.x) {
-        const phx_rigid_body& b = bodies[x.group_bodies[d.z + i]];
+        const int id = x.group_bodies[d.z + i];
+        const float4 a = bodies.vel[id], e = bodies.dvel[id];
         float* o = out + 6 * i;
-        o[0] = b.velocity.x; o[1] = b.velocity.y; o[2] = b.angular_velocity;
-        o[3] = b.displacing_velocity.x; o[4] = b.displacing_velocity.y; o[5] = b.displacing_angular_velocity;
+        o[0] = a.x; o[1] = a.y; o[2] = a.z;
+        o[3] = e.x; o[4] = e.y; o[5] = e.z;
     }
     float* jo = out + 6 * (size_t)d.w;
     for (int s = threadIdx.x; s < d.y; s += blockDim.x) {
@@ -86,16 +88,17 @@ __global__ void __launch_bounds__(256) k_exchange_pack(ExchangeView x, const phx
 }
 
 // the HBM group of the owning rank (grid-stride)
-__global__ void __launch_bounds__(256) k_exchange_pack_hbm(ExchangeView x, const phx_rigid_body* __restrict__ bodies, const phx_contact_joint* __restrict__ joints,
+__global__ void __launch_bounds__(256) k_exchange_pack_hbm(ExchangeView x, BodyView bodies, const phx_contact_joint* __restrict__ joints,
                                                            unsigned* __restrict__ send)
 {
     float* out = reinterpret_cast<float*>(send + x.xoff[x.lds_groups]);
     const int n = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = t; i < x.hbm_body_count; i += n) {
-        const phx_rigid_body& b = bodies[x.hbm_bodies[i]];
+        const int id = x.hbm_bodies[i];
+        const float4 a = bodies.vel[id], e = bodies.dvel[id];
         float* o = out + 6 * (size_t)i;
-        o[0] = b.velocity.x; o[1] = b.velocity.y; o[2] = b.angular_velocity;
-        o[3] = b.displacing_velocity.x; o[4] = b.displacing_velocity.y; o[5] = b.displacing_angular_velocity;
+        o[0] = a.x; o[1] = a.y; o[2] = a.z;
+        o[3] = e.x; o[4] = e.y; o[5] = e.z;
     }
     float* jo = out + 6 * (size_t)x.hbm_body_count;
     for (int s = t; s < x.hbm_end - x.hbm_begin; s += n) {
@@ -104,33 +107,42 @@ __global__ void __launch_bounds__(256) k_exchange_pack_hbm(ExchangeView x, const
     }
 }
 
+// what the header of rank r's segment says about it (0 = consistent with this rank's step)
+__device__ __forceinline__ int xch_check_header(const unsigned* __restrict__ h, unsigned serial, unsigned long long fingerprint)
+{
+    if (h[0] != XCH_MAGIC) return XCH_ERR_MAGIC;
+    int e = 0;
+    if (h[2] != 0u) e |= XCH_ERR_PEER;
+    if (h[1] != serial) e |= XCH_ERR_SERIAL;
+    if (h[4] != (unsigned)fingerprint || h[5] != (unsigned)(fingerprint >> 32)) e |= XCH_ERR_TOPOLOGY;
+    return e;
+}
+
 // One workgroup per LDS group; groups of this rank return at once.  Static bodies are never written (their owner never
 // wrote them either, ref: Solver.cpp:562-567 — zero inverse mass leaves the velocity alone).
-// Workgroup 0 also checks every peer's header.
-__global__ void __launch_bounds__(256) k_exchange_unpack(ExchangeView x, phx_rigid_body* __restrict__ bodies, phx_contact_joint* __restrict__ joints,
+// Every workgroup checks ITS owner's header before it scatters anything: a segment whose header is inconsistent (never written,
+// another step, another topology, a peer that failed) is not unpacked at all — the replica keeps its own unsolved values for those
+// groups instead of garbage — and the error word says so.  Workgroup 0 also checks every peer's header (any shard count).
+__global__ void __launch_bounds__(256) k_exchange_unpack(ExchangeView x, BodyView bodies, phx_contact_joint* __restrict__ joints,
                                                          const unsigned* __restrict__ recv, unsigned serial, unsigned long long fingerprint, int* __restrict__ error)
 {
-    if (blockIdx.x == 0 && (int)threadIdx.x < x.shard_count) {
-        const unsigned* h = recv + (size_t)threadIdx.x * x.segment_words;
+    if (blockIdx.x == 0) {
         int e = 0;
-        if (h[0] != XCH_MAGIC) e |= XCH_ERR_MAGIC;
-        else {
-            if (h[2] != 0u) e |= XCH_ERR_PEER;
-            if (h[1] != serial) e |= XCH_ERR_SERIAL;
-            if (h[4] != (unsigned)fingerprint || h[5] != (unsigned)(fingerprint >> 32)) e |= XCH_ERR_TOPOLOGY;
-        }
+        for (int r = (int)threadIdx.x; r < x.shard_count; r += (int)blockDim.x) e |= xch_check_header(recv + (size_t)r * x.segment_words, serial, fingerprint);
         if (e) atomicOr(error, e);
     }
     const int g = (int)blockIdx.x;
     if (g >= x.lds_groups || g % x.shard_count == x.shard) return;
+    if (xch_check_header(recv + (size_t)(g % x.shard_count) * x.segment_words, serial, fingerprint)) return;      // (workgroup-uniform)
     const int4 d = x.desc[g];
     const float* in = reinterpret_cast<const float*>(recv + (size_t)(g % x.shard_count) * x.segment_words + x.xoff[g]);
     for (int i = threadIdx.x; i < d.w; i += blockDim.x) {
-        phx_rigid_body& b = bodies[x.group_bodies[d.z + i]];
-        if (b.inv_mass == 0.f && b.inv_inertia == 0.f) continue;
+        const int id = x.group_bodies[d.z + i];
+        const float4 p = bodies.mpos[id];
+        if (p.x == 0.f && p.y == 0.f) continue;
         const float* o = in + 6 * i;
-        b.velocity.x = o[0]; b.velocity.y = o[1]; b.angular_velocity = o[2];
-        b.displacing_velocity.x = o[3]; b.displacing_velocity.y = o[4]; b.displacing_angular_velocity = o[5];
+        bodies.vel[id] = make_float4(o[0], o[1], o[2], 0.f);
+        bodies.dvel[id] = make_float4(o[3], o[4], o[5], 0.f);
     }
     const float* ji = in + 6 * (size_t)d.w;
     for (int s = threadIdx.x; s < d.y; s += blockDim.x) {
@@ -139,17 +151,19 @@ __global__ void __launch_bounds__(256) k_exchange_unpack(ExchangeView x, phx_rig
     }
 }
 
-__global__ void __launch_bounds__(256) k_exchange_unpack_hbm(ExchangeView x, phx_rigid_body* __restrict__ bodies, phx_contact_joint* __restrict__ joints,
-                                                             const unsigned* __restrict__ recv)
+__global__ void __launch_bounds__(256) k_exchange_unpack_hbm(ExchangeView x, BodyView bodies, phx_contact_joint* __restrict__ joints,
+                                                             const unsigned* __restrict__ recv, unsigned serial, unsigned long long fingerprint)
 {
+    if (xch_check_header(recv + (size_t)(x.lds_groups % x.shard_count) * x.segment_words, serial, fingerprint)) return;      // (see k_exchange_unpack)
     const float* in = reinterpret_cast<const float*>(recv + (size_t)(x.lds_groups % x.shard_count) * x.segment_words + x.xoff[x.lds_groups]);
     const int n = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = t; i < x.hbm_body_count; i += n) {
-        phx_rigid_body& b = bodies[x.hbm_bodies[i]];
-        if (b.inv_mass == 0.f && b.inv_inertia == 0.f) continue;
+        const int id = x.hbm_bodies[i];
+        const float4 p = bodies.mpos[id];
+        if (p.x == 0.f && p.y == 0.f) continue;
         const float* o = in + 6 * (size_t)i;
-        b.velocity.x = o[0]; b.velocity.y = o[1]; b.angular_velocity = o[2];
-        b.displacing_velocity.x = o[3]; b.displacing_velocity.y = o[4]; b.displacing_angular_velocity = o[5];
+        bodies.vel[id] = make_float4(o[0], o[1], o[2], 0.f);
+        bodies.dvel[id] = make_float4(o[3], o[4], o[5], 0.f);
     }
     const float* ji = in + 6 * (size_t)x.hbm_body_count;
     for (int s = t; s < x.hbm_end - x.hbm_begin; s += n) {

@@ -53,7 +53,31 @@ static ExchangeView exchange_view(const Schedule& sc, bool valid, const int4* de
     return x;
 }
 
+// the C-ABI edge: records in, records out (converted around the resident kernels, body_view.h)
 int DeviceSolver::exchange_pack(const void* d_bodies, const void* d_joints, size_t* segment_bytes, int status_word)
+{
+    PHX_TRY(use_device(device_));
+    if (!d_bodies || !d_joints) return exchange_pack_resident(nullptr, nullptr, segment_bytes, status_word);
+    PHX_TRY(synchronize());                            // (the edge arrays may still belong to an unverified solve)
+    Arrays a;
+    PHX_TRY(edge_view(d_bodies, nb_, &a));
+    return exchange_pack_resident(&a.view, d_joints, segment_bytes, status_word);
+}
+
+int DeviceSolver::exchange_unpack(void* d_bodies, void* d_joints)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(d_bodies && d_joints, "null arrays");
+    PHX_TRY(synchronize());
+    Arrays a;
+    PHX_TRY(edge_view(d_bodies, nb_, &a));
+    PHX_TRY(exchange_unpack_resident(a.view, d_joints));
+    if (nb_) hipLaunchKernelGGL(k_view_to_bodies, dim3(std::max(1, std::min(div_up(nb_, 256), 2048))), dim3(256), 0, stream_, a.view, nb_, a.aos, (const unsigned long long*)nullptr, 0ull);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
+int DeviceSolver::exchange_pack_resident(const BodyView* d_bodies, const void* d_joints, size_t* segment_bytes, int status_word)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(xch_send_ && xch_recv_, "exchange buffers not set (phx_solver_set_exchange_buffers)");
@@ -68,11 +92,12 @@ int DeviceSolver::exchange_pack(const void* d_bodies, const void* d_joints, size
     ++xch_serial_;
     const int lg = x.lds_groups;
     const int mine = lg > shard_ ? (lg - shard_ + shard_count_ - 1) / shard_count_ : 0;
-    hipLaunchKernelGGL(k_exchange_pack, dim3(std::max(mine, 1)), dim3(256), 0, stream_, x, static_cast<const phx_rigid_body*>(d_bodies),
+    const BodyView bodies = d_bodies ? *d_bodies : BodyView{nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_exchange_pack, dim3(std::max(mine, 1)), dim3(256), 0, stream_, x, bodies,
                        static_cast<const phx_contact_joint*>(d_joints), xch_send_, xch_serial_, (unsigned)status_word, raw_fingerprint_);
     if (x.hbm_end > x.hbm_begin && owns_hbm_group()) {
         const int n = std::max(x.hbm_body_count, x.hbm_end - x.hbm_begin);
-        hipLaunchKernelGGL(k_exchange_pack_hbm, dim3(std::max(1, std::min(div_up(n, 256), 2048))), dim3(256), 0, stream_, x, static_cast<const phx_rigid_body*>(d_bodies),
+        hipLaunchKernelGGL(k_exchange_pack_hbm, dim3(std::max(1, std::min(div_up(n, 256), 2048))), dim3(256), 0, stream_, x, bodies,
                            static_cast<const phx_contact_joint*>(d_joints), xch_send_);
     }
     PHX_HIP(hipGetLastError());
@@ -80,18 +105,18 @@ int DeviceSolver::exchange_pack(const void* d_bodies, const void* d_joints, size
     return PHX_OK;
 }
 
-int DeviceSolver::exchange_unpack(void* d_bodies, void* d_joints)
+int DeviceSolver::exchange_unpack_resident(const BodyView& d_bodies, void* d_joints)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(xch_send_ && xch_recv_, "exchange buffers not set (phx_solver_set_exchange_buffers)");
     if (xch_layout_version_ != schedule_version_ || xch_layout_shards_ != shard_count_) { set_error("exchange_unpack without a matching exchange_pack"); return PHX_ERR_STATE; }
     const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0, grp_desc_.p, grp_bodies_.p, order_.p, xch_off_.p, hbm_body_list_.p, shard_, shard_count_, xch_seg_words_);
-    hipLaunchKernelGGL(k_exchange_unpack, dim3(std::max(x.lds_groups, 1)), dim3(256), 0, stream_, x, static_cast<phx_rigid_body*>(d_bodies),
+    hipLaunchKernelGGL(k_exchange_unpack, dim3(std::max(x.lds_groups, 1)), dim3(256), 0, stream_, x, d_bodies,
                        static_cast<phx_contact_joint*>(d_joints), (const unsigned*)xch_recv_, xch_serial_, raw_fingerprint_, xch_err_.p);
     if (x.hbm_end > x.hbm_begin && !owns_hbm_group()) {
         const int n = std::max(x.hbm_body_count, x.hbm_end - x.hbm_begin);
-        hipLaunchKernelGGL(k_exchange_unpack_hbm, dim3(std::max(1, std::min(div_up(n, 256), 2048))), dim3(256), 0, stream_, x, static_cast<phx_rigid_body*>(d_bodies),
-                           static_cast<phx_contact_joint*>(d_joints), (const unsigned*)xch_recv_);
+        hipLaunchKernelGGL(k_exchange_unpack_hbm, dim3(std::max(1, std::min(div_up(n, 256), 2048))), dim3(256), 0, stream_, x, d_bodies,
+                           static_cast<phx_contact_joint*>(d_joints), (const unsigned*)xch_recv_, xch_serial_, raw_fingerprint_);
     }
     PHX_HIP(hipGetLastError());
     return PHX_OK;

@@ -140,7 +140,7 @@ __device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2
 }
 
 template <int T, int NB, bool HALF, bool TRACE = false>
-__global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView iv, phx_rigid_body* __restrict__ bodies,
+__global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView iv, BodyView bv,
                                                             phx_contact_joint* __restrict__ joints,
                                                             const phx_contact_point* __restrict__ cps, int ci, int pi)
 {
@@ -153,13 +153,20 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     __shared__ __attribute__((aligned(16))) unsigned sw_raw[4 * NB];
     __shared__ unsigned char is_st[NB];
     __shared__ int flag_imp[3], flag_disp[3];     // 'some joint was productive in sweep it': slot it % 3
+    __shared__ int s_commit;                      // ISL_VERIFY: every workgroup of the launch arrived and none found a difference
     unsigned (*swi)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw);
     unsigned (*swd)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw + 2 * NB);
     float4* par = reinterpret_cast<float4*>(sw_raw);
 
     const int group = iv.first + (int)blockIdx.x * iv.stride;
+    if (iv.next_ctl && blockIdx.x == 0) {                 // first kernel of its solve: the NEXT solve's control set (two sets alternate)
+        if (threadIdx.x < ISL_STAT_SLOTS) { iv.next_visits[threadIdx.x] = 0ull; iv.next_executed[2 * threadIdx.x] = 0; iv.next_executed[2 * threadIdx.x + 1] = 0; }
+        if (threadIdx.x == 0) { *iv.next_ctl = 0ull; iv.next_visits[ISL_STAT_SLOTS] = ~0ull; iv.next_visits[ISL_STAT_SLOTS + 1] = 0ull; }
+        if (threadIdx.x < ISL_SHARDS) iv.next_shards[threadIdx.x * ISL_SHARD_STRIDE] = 0ull;
+    }
     if (iv.stamp_begin) solve_stamp_begin(v.stamps);      // (no HBM group in front of this launch: it is the solve's first kernel)
     if (iv.ngroups_dev && group >= *iv.ngroups_dev) return;  // (workgroup-uniform, in front of every barrier)
+    if (iv.mode == ISL_COMPLETE && iv.done[group] == iv.epoch) return;      // (workgroup-uniform) committed by the launch this one completes
     PHX_ISL_STAMP(0);
     const unsigned long long cycles0 = TRACE ? __builtin_readcyclecounter() : 0ull;
     // TRACE: per wave, shader cycles spent in class steps {working: in the unit update, then at the barrier; idle: whole step}
@@ -175,7 +182,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     const int4 ua = iv.unit_recs[2 * ((size_t)group * T + tid)], ub = iv.unit_recs[2 * ((size_t)group * T + tid) + 1];
     const int4 d = iv.desc[group];
     const int ncol = iv.ncol[group];
-    const int nunits = iv.units[group];
+    const int units_word = iv.units[group];
+    const int nunits = units_word & 0xFFFF, nstatic = units_word >> 16;
     const bool live = tid < nunits;
 #pragma unroll
     for (int k = 0; k < BI; ++k) if (tid + k * T >= d.w) body_id[k] = -1;
@@ -187,16 +195,19 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
 
     float4 rec_imp[BI], rec_disp[BI], rec_par[BI];
 #pragma unroll
-    for (int k = 0; k < BI; ++k) {                         // level 2: PrepareBodies (ref: Solver.cpp:456-480) straight from
-        if (body_id[k] < 0) continue;                      //          the 128-byte records
-        const phx_rigid_body& b = bodies[body_id[k]];
-        rec_imp[k] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
-        rec_disp[k] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
-        rec_par[k] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
+    for (int k = 0; k < BI; ++k) {                         // level 2: the resident arrays ARE PrepareBodies' staged form
+        if (body_id[k] < 0) continue;                      //          (ref: Solver.cpp:456-480; body_view.h): three coalesced 16-byte loads
+        rec_imp[k] = bv.vel[body_id[k]]; rec_imp[k].w = __int_as_float(-1);
+        rec_disp[k] = bv.dvel[body_id[k]]; rec_disp[k].w = __int_as_float(-1);
+        rec_par[k] = bv.mpos[body_id[k]];
     }
     IslJoint q0{}, q1{};
     float4 da0 = make_float4(0.f, 0.f, 0.f, 0.f), da1 = da0;     // delta1, delta2 of the two contact points
     int l1 = 0, l2 = 0;
+    const bool verify = iv.mode == ISL_VERIFY;             // (launch-uniform)
+    bool differs = false;                                  // ISL_VERIFY: the schedule was built for other joints / other static bodies
+    phx_contact_joint jf{};
+    if (has2) jf = joints[jid1];
     if (live) {                                            // PrepareJoints (ref: Solver.cpp:509-521)
         const phx_contact_joint j = joints[jid0];
         // (the contact point index is part of the topology the schedule was built — and is gated — for: ua.z == j.contact_point_index)
@@ -206,14 +217,18 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         q0.nx = nn.x; q0.ny = nn.y;
         l1 = (int)(loc & 0xFFFFu); l2 = (int)(loc >> 16);
         q0.accN = j.normal_accumulated_impulse; q0.accF = j.friction_accumulated_impulse;
+        if (verify) {      // the unit record against the joint it points at (the body ids: two more words of the group's table, L2-warm)
+            const int g1 = iv.bodies[(size_t)group * NB + l1], g2 = iv.bodies[(size_t)group * NB + l2];
+            differs = j.contact_point_index != ua.z || j.body1 != g1 || j.body2 != g2;
+            if (has2) differs |= jf.contact_point_index != ua.w || jf.body1 != g1 || jf.body2 != g2;
+        }
     }
     if (has2) {
-        const phx_contact_joint j = joints[jid1];
         const float4* cp4 = reinterpret_cast<const float4*>(&cps[clamp_index(ua.w, v.ncp)]);
         da1 = cp4[0];
         const float2 nn = *reinterpret_cast<const float2*>(cp4 + 1);
         q1.nx = nn.x; q1.ny = nn.y;
-        q1.accN = j.normal_accumulated_impulse; q1.accF = j.friction_accumulated_impulse;
+        q1.accN = jf.normal_accumulated_impulse; q1.accF = jf.friction_accumulated_impulse;
     }
 #pragma unroll
     for (int k = 0; k < BI; ++k) {
@@ -222,9 +237,20 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         body_store(imp, i, rec_imp[k]);
         body_store(disp, i, rec_disp[k]);
         par[i] = rec_par[k];
-        is_st[i] = (rec_par[k].x == 0.f && rec_par[k].y == 0.f) ? 1 : 0;
+        const bool st = rec_par[k].x == 0.f && rec_par[k].y == 0.f;
+        is_st[i] = st ? 1 : 0;
+        differs |= st != (i < nstatic);                    // (the builders list a group's static bodies first)
     }
-    __syncthreads();
+    unsigned long long arrived_before = 0ull;              // (lane 0) what the shard counter read when this workgroup arrived
+    unsigned my_arrival = 1u;
+    if (verify) {
+        // ARRIVE: this workgroup has compared everything it owns.  One device-scope atomic carries the arrival and the verdict, so
+        // whoever sees all arrivals also sees every verdict (island_view.h).  The returned value is looked at behind PreStep:
+        // nothing waits for this round trip.
+        const int any = __syncthreads_or(differs ? 1 : 0);
+        my_arrival = any ? 1u + ISL_BAD : 1u;
+        if (tid == 0) arrived_before = atomicAdd(&iv.shards[((int)blockIdx.x % ISL_SHARDS) * ISL_SHARD_STRIDE], (unsigned long long)my_arrival);
+    } else __syncthreads();
     PHX_ISL_STAMP(1);
     float im1 = 0.f, ii1 = 0.f, im2 = 0.f, ii2 = 0.f;
     if (live) {
@@ -255,6 +281,12 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         __syncthreads();
     }
 
+    if (verify && tid == 0) {
+        // the last arriver of a shard forwards the shard's verdict to the solve's control word
+        const unsigned now = (unsigned)arrived_before + my_arrival;
+        const unsigned shard = blockIdx.x % ISL_SHARDS, want = (iv.nexpect - shard + ISL_SHARDS - 1) / ISL_SHARDS;
+        if ((now & ISL_ARRIVE_MASK) == want) atomicAdd(iv.ctl, now >= ISL_BAD ? (unsigned long long)(1u + ISL_BAD) : 1ull);
+    }
     PHX_ISL_STAMP(3);
     int done_imp = 0, done_disp = 0;
     bool imp_alive = ci > 0, disp_alive = pi > 0;
@@ -342,7 +374,25 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     PHX_ISL_STAMP(4);
     // results go straight back into the caller's records (commit-gated like k_finish_*); the refreshed constants
     // never leave the registers
-    if (*v.fingerprint != v.expected_fingerprint) { if (iv.stamp_end) solve_stamp_end(v.stamps); return; }
+    if (verify) {
+        // every workgroup of the launch is resident at once (the host launches ISL_VERIFY only then), so by now — tens of
+        // microseconds after its own arrival — all of them have arrived and this wait is one load; it is BOUNDED all the same: if
+        // it runs out (a GPU shared with somebody else's kernels) the group stays uncommitted and the host completes it (ISL_COMPLETE)
+        if (tid == 0) {
+            const unsigned shards = iv.nexpect < (unsigned)ISL_SHARDS ? iv.nexpect : (unsigned)ISL_SHARDS;
+            unsigned lo = 0;
+            int polls = 0;
+            for (; polls < iv.wait_polls; ++polls) {
+                lo = (unsigned)__hip_atomic_load(iv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((lo & ISL_ARRIVE_MASK) >= shards || lo >= ISL_BAD) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            s_commit = lo == shards ? 1 : 0;
+            if (polls == iv.wait_polls) atomicOr(iv.ctl, ISL_TIMEOUT);      // (nobody may take this solve for complete)
+        }
+        __syncthreads();
+        if (!s_commit) { if (iv.stamp_end) solve_stamp_end(v.stamps); return; }
+    } else if (iv.mode == ISL_GATED && *v.fingerprint != v.expected_fingerprint) { if (iv.stamp_end) solve_stamp_end(v.stamps); return; }
     if (live) {                                            // FinishJoints (ref: Solver.cpp:543-544)
         phx_contact_joint& out = joints[jid0];
         __builtin_nontemporal_store(q0.accN, &out.normal_accumulated_impulse);
@@ -357,13 +407,13 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     for (int k = 0; k < BI; ++k) {                         // FinishBodies (ref: Solver.cpp:488-492), dynamic bodies only
         const int i = tid + k * T;
         if (body_id[k] < 0 || is_st[i]) continue;
-        phx_rigid_body& b = bodies[body_id[k]];
         const float4 a = body_load(imp, i), e = body_load(disp, i);
-        __builtin_nontemporal_store(a.x, &b.velocity.x); __builtin_nontemporal_store(a.y, &b.velocity.y); __builtin_nontemporal_store(a.z, &b.angular_velocity);
-        __builtin_nontemporal_store(e.x, &b.displacing_velocity.x); __builtin_nontemporal_store(e.y, &b.displacing_velocity.y); __builtin_nontemporal_store(e.z, &b.displacing_angular_velocity);
+        store_nt(&bv.vel[body_id[k]], a.x, a.y, a.z, 0.f);
+        store_nt(&bv.dvel[body_id[k]], e.x, e.y, e.z, 0.f);
     }
     if (iv.stamp_end) solve_stamp_end(v.stamps);           // (no HBM group behind this launch: it is the solve's last kernel)
     if (tid == 0) {
+        if (iv.mode != ISL_GATED) iv.done[group] = iv.epoch;      // committed
         const int slot = group % ISL_STAT_SLOTS;
         atomicMax(&iv.executed[2 * slot], done_imp);
         atomicMax(&iv.executed[2 * slot + 1], done_disp);

@@ -4,7 +4,7 @@
 namespace phx {
 
 void launch_solve_islands(hipStream_t stream, int groups, bool big_shape, bool half_state, bool trace, const SolverView& v, const IslandView& iv,
-                          phx_rigid_body* bodies, phx_contact_joint* joints, const phx_contact_point* cps, int ci, int pi)
+                          const BodyView& bodies, phx_contact_joint* joints, const phx_contact_point* cps, int ci, int pi)
 {
     const dim3 grid(groups);
     if (trace && big_shape)      hipLaunchKernelGGL((k_solve_islands<ISL_T_BIG, ISL_B_BIG, false, true>), grid, dim3(ISL_T_BIG), 0, stream, v, iv, bodies, joints, cps, ci, pi);

@@ -21,12 +21,13 @@ namespace phx {
 // ---- connected components over dynamic bodies --------------------------------------------------------------
 // (`clear`: a word to zero on the way — the 'hooked anything' flag of the first round; saves a memset dispatch)
 // (`first`: the contact point -> first joint table of the unit pairing below, reset to 'nobody' on the same way: ncp words)
-static __global__ void __launch_bounds__(256) k_cc_init(const phx_rigid_body* __restrict__ bodies, int nb, int* __restrict__ parent,
+static __global__ void __launch_bounds__(256) k_cc_init(const float4* __restrict__ mpos, int nb, int* __restrict__ parent,
                                                         unsigned char* __restrict__ is_static, int* __restrict__ clear, int* __restrict__ first, int ncp)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
-        const bool st = bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f;      // ref: Solver.cpp:304
+        const float4 p = mpos[i];                                       // resident {invMass, invInertia, pos} (body_view.h)
+        const bool st = p.x == 0.f && p.y == 0.f;                       // ref: Solver.cpp:304
         is_static[i] = st ? 1 : 0;
         parent[i] = st ? -1 : i;
     }
@@ -342,7 +343,7 @@ struct BinBuildView {
     unsigned char* slot_colour;       // out: class
     int4* desc;                       // out: {slot_begin, slot_count, body_begin, body_count}
     int* ncol;                        // out: classes
-    int* units;                       // out: units
+    int* units;                       // out: units | static bodies of the bin's table << 16
     int4* unit_recs;                  // out: two words per unit at [2 * (g * T + unit)], class-major (island_view.h): {leader joint, follower joint or -1,
                                       //      leader's contact point, follower's}, {local body1 | local body2 << 16, class, leader slot, follower slot or -1}
     int* bodies;                      // out: body table of bin g at [g * NB, g * NB + body_count)
@@ -554,7 +555,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         v.unit_recs[at] = make_int4(j, paired ? mate : -1, cpi, cpi ^ 1);
         v.unit_recs[at + 1] = make_int4((int)local, c, slot, fslot);
     }
-    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = n_units; }
+    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = n_units | (n_static << 16); }      // (static bodies sit first in the table: the island kernel checks exactly that)
 }
 
 // ---- the HBM group (islands too big for a workgroup, or everything in Single mode): the same colouring in HBM ----------

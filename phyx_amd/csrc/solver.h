@@ -2,6 +2,7 @@
 #pragma once
 
 #include "common.h"
+#include "body_view.h"
 #include "schedule.h"
 
 namespace phx {
@@ -13,7 +14,7 @@ struct SolverView {
     unsigned long long expected_fingerprint;     // the one the schedule in use was built for
     float4* sb_imp;
     float4* sb_disp;
-    float4* sb_par;
+    const float4* sb_par;  // = the resident mpos array of the solve's bodies (body_view.h)
     float4* q0;
     float4* q1;
     float4* q2;
@@ -37,8 +38,11 @@ public:
     int init();
 
     int solve_host(phx_rigid_body* bodies, int nb, const phx_contact_point* cps, int ncp, phx_contact_joint* joints, int nj, const phx_config& cfg);
+    // the C-ABI edge: device-resident 128-byte records (converted to the resident arrays and back around the solve, body_view.h)
     // topology_changed: the caller knows the joint list differs from the previous solve's (skips one host round trip)
     int solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
+    // the resident form (what the World and bench() use): reads vel / dvel / mpos, writes vel / dvel in place
+    int solve_resident(const BodyView& bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
     int synchronize();
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
@@ -57,8 +61,10 @@ public:
     // island-sharded solves: pack this rank's results / scatter the other ranks' (exchange.h); the all-gather in between
     // belongs to the caller (RCCL on stream())
     int set_exchange_buffers(void* d_send, void* d_recv, size_t segment_capacity_bytes);
-    int exchange_pack(const void* d_bodies, const void* d_joints, size_t* segment_bytes, int status_word = 0);
+    int exchange_pack(const void* d_bodies, const void* d_joints, size_t* segment_bytes, int status_word = 0);      // 128-byte records (C-ABI edge)
     int exchange_unpack(void* d_bodies, void* d_joints);
+    int exchange_pack_resident(const BodyView* bodies, const void* d_joints, size_t* segment_bytes, int status_word = 0);   // null bodies: header only
+    int exchange_unpack_resident(const BodyView& bodies, void* d_joints);
     int exchange_status(int* out);
     size_t exchange_segment_bytes() const { return (size_t)xch_seg_words_ * 4; }
     int shard_count() const { return shard_count_; }
@@ -71,16 +77,30 @@ public:
     // the gate of an unverified solve (world.hip queues the integrator behind it under the same gate)
     const unsigned long long* fingerprint_word() const { return hash_.p + hash_slot_; }
     unsigned long long expected_fingerprint() const { return gate_expected_; }
+    // the C-ABI edge's arrays after a solve_device / exchange call on records (tests, bench plumbing)
+    const BodyView& current_view() const { return cur_.view; }
     unsigned replays() const { return replays_; }
     int device() const { return device_; }
 
 private:
-    int ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
+    // the arrays of one solve: the resident view, and — for a solve that came through the C-ABI edge — the caller's records
+    struct Arrays { BodyView view{nullptr, nullptr, nullptr}; phx_rigid_body* aos = nullptr; };
+    int solve_common(const Arrays& a, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed);
+    int edge_view(const void* d_bodies_aos, int nb, Arrays* out);      // converts the records into this handle's edge arrays
+    int ensure_schedule(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
                         bool known_changed = false);
-    int build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
-    int build_bins_speculative(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc);
+    int build_schedule_device(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
+    int build_bins_speculative(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc);
     int materialise_schedule();
-    int launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
+    int launch_fingerprint(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
+    // How the solve being queued is gated (island_view.h): by the hash pass / the build (ISL_GATED) or by the island kernel's own
+    // check of the cached schedule (ISL_VERIFY).  arm_cached_solve picks one for a solve on the cached schedule; false = neither is
+    // possible (no hash on record and the launch is not eligible for ISL_VERIFY): the caller rebuilds.
+    bool arm_cached_solve(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp, int* status);
+    bool verify_eligible(int groups, bool big_shape) const;
+    bool spec_build_applies(bool want_islands, int nj) const;
+    void begin_set(bool hash_runs);                   // the solve being queued takes the other control set
+    int complete_partial();                           // ISL_COMPLETE for the groups a verified launch left uncommitted
     struct GraphKey {
         const void *bodies = nullptr, *cps = nullptr, *joints = nullptr;
         int nb = 0, nj = 0, ncp = 0, ci = 0, pi = 0;
@@ -92,11 +112,11 @@ private:
                    schedule_version == o.schedule_version;
         }
     };
-    int enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg);
-    int enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj);
-    int enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi);
-    int enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj);
-    int capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
+    int enqueue(const Arrays& a, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg);
+    int enqueue_pre(const BodyView& bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj);
+    int enqueue_sweeps(const BodyView& bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi, int mode_override = -1);
+    int enqueue_post(const BodyView& bodies, int nb, phx_contact_joint* d_joints, int nj);
+    int capture_graphs(const GraphKey& key, const BodyView& bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
     void drop_graphs();
     int collect_stats(unsigned long long* extra = nullptr, const unsigned long long* extra_src = nullptr);
     SolverView view() const;
@@ -106,7 +126,9 @@ private:
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
 
     // device state
-    DevBuf<float4> sb_imp_, sb_disp_, sb_par_, q0_, q1_, q2_;
+    DevBuf<float4> sb_imp_, sb_disp_, q0_, q1_, q2_;
+    DevBuf<float4> edge_vel_, edge_dvel_, edge_mpos_;      // resident form of the records a C-ABI edge call handed over
+    Arrays cur_;                                          // arrays of the solve being queued (view() reads the resident mpos from it)
     DevBuf<float> qn_;
     DevBuf<int4> q3_;
     DevBuf<float2> acc_, dd_;
@@ -152,7 +174,16 @@ private:
     phx_step_hook step_hook_ = nullptr;  // bench(): called with phase 1 between a step's local preparation and its sweeps
     void* step_hook_user_ = nullptr;
     int step_hook_step_ = 0;
-    int hash_slot_ = 1;                  // which of the two fingerprint accumulators the solve in flight uses
+    int hash_slot_ = 1;                  // which of the two control sets (control word = fingerprint accumulator, island counters, stamps) the solve in flight uses
+    bool island_clears_next_ = false;    // no hash pass runs in front of this solve: its island launch clears the next solve's control set
+    bool spec_hash_ran_ = false;         // the hash pass ran in front of the speculative build that is being settled
+    bool have_hash_ = false;             // raw_fingerprint_ is the cached schedule's topology hash (a rebuild without a hash pass leaves none)
+    int isl_mode_ = 0;                   // ISL_GATED / ISL_VERIFY of the solve being queued (island_view.h)
+    unsigned isl_nexpect_ = 0, solve_epoch_ = 0;
+    DevBuf<unsigned> isl_done_;          // per LDS group: epoch of the last verified solve that committed it
+    DevBuf<unsigned long long> isl_shards_;   // two control sets of ISL_SHARDS arrival counters (island_view.h)
+    int cu_count_ = 0, isl_wait_polls_ = 0;
+    bool no_fused_verify_ = false;       // PHX_NO_FUSED_VERIFY=1: always the hash pass (A/B measurements)
     unsigned long long* fp_wanted_ = nullptr;   // set by ensure_schedule: deliver the fingerprint with the builder's first readback
     int ncomp_guess_ = 0;               // component count of the previous device build (sizes its readback)
     DevBuf<unsigned> sw_;
@@ -162,12 +193,12 @@ private:
     DevBuf<phx_rigid_body> st_bodies_;
     DevBuf<phx_contact_point> st_cps_;
     DevBuf<phx_contact_joint> st_joints_;
-    // bench snapshots
-    DevBuf<phx_rigid_body> snap_bodies_;
+    // bench snapshots (resident form)
+    DevBuf<float4> snap_vel_, snap_dvel_, snap_mpos_;
     DevBuf<phx_contact_joint> snap_joints_;
     // bench_stage(): private copies of the input, one per timed step, made BEFORE the timed region (the input of every step is
-    // then resident in HBM when the clock starts, and no restore copy runs between the solves)
-    DevBuf<phx_rigid_body> stage_bodies_;
+    // then resident in HBM — in the resident layout — when the clock starts, and no restore copy runs between the solves)
+    DevBuf<float4> stage_vel_, stage_dvel_, stage_mpos_;      // (mpos is read-only: one copy serves every step)
     DevBuf<phx_contact_joint> stage_joints_;
     const void* staged_src_bodies_ = nullptr; const void* staged_src_joints_ = nullptr;
     int staged_nb_ = 0, staged_nj_ = 0, staged_steps_ = 0;
@@ -188,7 +219,10 @@ private:
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
     bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }
     // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()
-    struct Pending { bool active = false; int count = 0; void* bodies = nullptr; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{}; } pending_;
+    struct Pending { bool active = false; int count = 0; Arrays arrays; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{};
+                     int mode = 0; unsigned nexpect = 0; } pending_;
+    void register_pending(const Arrays& a, int nb, const void* cps, int ncp, void* joints, int nj, const phx_config& cfg, bool repeat);
+    bool same_as_pending(const Arrays& a, int nb, const void* cps, int ncp, const void* joints, int nj, const phx_config& cfg) const;
     int ncp_ = 0;
     unsigned long long raw_fingerprint_ = 0;
     // exchange of an island-sharded solve (exchange.h)

@@ -15,7 +15,7 @@ namespace phx {
 // small kernels private to this file
 
 __global__ void __launch_bounds__(256) k_extract_topology(const phx_contact_joint* __restrict__ joints, int nj,
-                                                          const phx_rigid_body* __restrict__ bodies, int nb,
+                                                          const float4* __restrict__ mpos, int nb,
                                                           int2* __restrict__ pairs, int* __restrict__ prio_id, unsigned char* __restrict__ is_static)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
@@ -23,10 +23,12 @@ __global__ void __launch_bounds__(256) k_extract_topology(const phx_contact_join
         prio_id[i] = joints[i].contact_point_index;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
-        is_static[i] = (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) ? 1 : 0;
+        is_static[i] = (mpos[i].x == 0.f && mpos[i].y == 0.f) ? 1 : 0;
 }
 
 static inline int grid_for(int n) { return std::max(1, std::min(div_up(n, 256), 2048)); }
+
+constexpr int STATS_SET = 2 * ISL_STAT_SLOTS, VISITS_SET = ISL_STAT_SLOTS + 2, SHARDS_SET = ISL_SHARDS * ISL_SHARD_STRIDE;      // words of one control set in isl_stats_ / isl_visits_ / isl_shards_
 
 // ---------------------------------------------------------------------------------------------------
 
@@ -36,7 +38,7 @@ DeviceSolver::~DeviceSolver()
     if (stream_) (void)hipStreamSynchronize(stream_);
     drop_graphs();
     for (hipEvent_t e : bench_events_) (void)hipEventDestroy(e);
-    sb_imp_.release(); sb_disp_.release(); sb_par_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release(); qn_.release();
+    sb_imp_.release(); sb_disp_.release(); edge_vel_.release(); edge_dvel_.release(); edge_mpos_.release(); isl_done_.release(); isl_shards_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release(); qn_.release();
     acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
     cc_parent_.release(); joint_comp_.release(); bin_tables_.release(); bin_tables_host_.release(); sb_small_.release(); cc_static_.release();
     cc_flags_.release(); comp_size_.release(); comp_units_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release(); jp_kind_.release(); partner_.release(); partner_first_.release();
@@ -44,7 +46,7 @@ DeviceSolver::~DeviceSolver()
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_recs_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
-    hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_bodies_.release(); snap_joints_.release(); stage_bodies_.release(); stage_joints_.release();
+    hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_vel_.release(); snap_dvel_.release(); snap_mpos_.release(); snap_joints_.release(); stage_vel_.release(); stage_dvel_.release(); stage_mpos_.release(); stage_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
     if (ev_sweep_begin_) (void)hipEventDestroy(ev_sweep_begin_);
@@ -71,10 +73,25 @@ int DeviceSolver::init()
     PHX_HIP(hipEventCreate(&ev_end_));
     PHX_HIP(hipEventCreate(&ev_sweep_begin_));
     PHX_HIP(hipEventCreate(&ev_sweep_end_));
+    // two control sets alternate between consecutive solves; the first kernel of a solve clears the other one (solver_kernels.h)
     PHX_TRY(hash_.reserve(2));
     PHX_HIP(hipMemsetAsync(hash_.p, 0, 2 * sizeof(unsigned long long), stream_));
-    PHX_TRY(isl_stats_.reserve(2 * ISL_STAT_SLOTS));
-    PHX_TRY(isl_visits_.reserve(ISL_STAT_SLOTS + 2));          // + the solve's two time stamps
+    PHX_TRY(isl_stats_.reserve(2 * STATS_SET));
+    PHX_HIP(hipMemsetAsync(isl_stats_.p, 0, 2 * STATS_SET * sizeof(int), stream_));
+    PHX_TRY(isl_visits_.reserve(2 * VISITS_SET));               // per set: the slots + the solve's two time stamps
+    {
+        unsigned long long init[2 * VISITS_SET] = {0};
+        init[ISL_STAT_SLOTS] = ~0ull; init[VISITS_SET + ISL_STAT_SLOTS] = ~0ull;
+        PHX_HIP(hipMemcpyAsync(isl_visits_.p, init, sizeof init, hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+    }
+    PHX_TRY(isl_shards_.reserve(2 * SHARDS_SET));
+    PHX_HIP(hipMemsetAsync(isl_shards_.p, 0, 2 * SHARDS_SET * sizeof(unsigned long long), stream_));
+    PHX_HIP(hipDeviceGetAttribute(&cu_count_, hipDeviceAttributeMultiprocessorCount, device_));
+    const char* nfv = getenv("PHX_NO_FUSED_VERIFY");      // "1": the topology hash pass in front of every solve on a cached schedule (A/B measurements)
+    no_fused_verify_ = nfv && nfv[0] == '1';
+    const char* wp = getenv("PHX_ISL_WAIT_POLLS");        // tests: 0 makes every workgroup of a verified launch give up, so that ISL_COMPLETE runs
+    isl_wait_polls_ = wp ? std::max(0, atoi(wp)) : ISL_WAIT_POLLS;
     const char* g = getenv("PHX_GRAPHS");               // "1": replay the launch sequence from hipGraphs (measured: no gain on the
     use_graphs_ = g && g[0] == '1';                      // HBM path, 7 us slower per solve on the island path) — off by default
     const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
@@ -95,51 +112,106 @@ SolverView DeviceSolver::view() const
     SolverView v{};
     v.nb = nb_; v.nj = nj_; v.ncp = ncp_; v.nstatic = std::max(nstatic_, 1); v.ncolours = sched_.ncolours();
     v.fingerprint = hash_.p + hash_slot_; v.expected_fingerprint = gate_expected_;
-    v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = sb_par_.p;
+    v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = cur_.view.mpos;
     v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p; v.qn = qn_.p;
     v.order = order_.p;
     v.sw_imp = sw_.p; v.sw_disp = sw_.p + 2 * (size_t)v.nstatic;
     v.imp_active = flags_.p; v.disp_active = flags_.p + max_iters_;
-    v.stamps = isl_visits_.p + ISL_STAT_SLOTS;
+    v.stamps = isl_visits_.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS;
     return v;
 }
 
-int DeviceSolver::launch_fingerprint(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp)
+// The solve being queued takes the other control set (control word, island counters, time stamps).  Its first kernel clears
+// the set after it: the hash pass if one runs, else the island launch (enqueue_sweeps).
+void DeviceSolver::begin_set(bool hash_runs)
 {
-    // the fingerprint kernel is the first kernel of every solve: it also clears the solve's control words and the accumulator
-    // of the next solve's fingerprint (the two accumulators alternate)
+    hash_slot_ ^= 1;
+    island_clears_next_ = !hash_runs;
+}
+
+int DeviceSolver::launch_fingerprint(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp)
+{
+    // the hash pass is the first kernel of the solves that run it: it also clears the solve's HBM-path words and the control set of
+    // the next solve (the two sets alternate)
+    begin_set(true);
     ControlWords cw{};
     cw.flags = flags_.p; cw.nflags = flags_.p ? 2 * max_iters_ : 0;
     cw.sw = sw_.p; cw.nsw = sw_.p ? (int)std::min<size_t>(sw_.cap, 1u << 30) : 0;      // (the whole table: a rebuilt schedule may use more of it)
     sw_cleared_ = sw_.p; sw_cleared_words_ = (size_t)cw.nsw;
-    cw.isl_stats = isl_stats_.p; cw.isl_visits = isl_visits_.p;
-    int slot = hash_slot_ ^ 1;
-    if (use_graphs_) {        // captured graphs have the accumulator's address baked in: one fixed slot, cleared by a memset
-        slot = 0; hash_slot_ = 1;
+    int next = hash_slot_ ^ 1;
+    cw.next_ctl = hash_.p + next;
+    if (use_graphs_) {        // captured graphs have the control set's addresses baked in: always set 0 — its word cleared by a memset, its
+        hash_slot_ = 0;       // counters by this kernel (nothing else touches them while it runs)
         PHX_HIP(hipMemsetAsync(hash_.p, 0, sizeof(unsigned long long), stream_));
+        next = 0; cw.next_ctl = hash_.p + 1;
     }
-    hipLaunchKernelGGL(k_topology_hash, dim3(std::max(1, std::min(div_up(std::max(nj, nb), HASH_T), HASH_BLOCKS))), dim3(HASH_T), 0, stream_, d_joints, nj, d_bodies, nb, ncp,
-                       hash_.p + slot, hash_.p + hash_slot_, cw);
-    hash_slot_ = slot;
+    cw.next_executed = isl_stats_.p + (size_t)next * STATS_SET; cw.next_visits = isl_visits_.p + (size_t)next * VISITS_SET;
+    cw.next_shards = isl_shards_.p + (size_t)next * SHARDS_SET;
+    hipLaunchKernelGGL(k_topology_hash, dim3(std::max(1, std::min(div_up(std::max(nj, nb), HASH_T), HASH_BLOCKS))), dim3(HASH_T), 0, stream_, d_joints, nj, d_mpos, nb, ncp,
+                       hash_.p + hash_slot_, cw);
+    isl_mode_ = ISL_GATED;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
 
-int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
+// May a launch of `groups` island workgroups check the cached schedule itself (ISL_VERIFY, island_view.h)?  Only if all of them
+// are resident at once — they wait for each other before they commit — and nobody else needs the topology hash (a sharded solve
+// puts it into its exchange header; graphs bake the launch arguments in).
+bool DeviceSolver::verify_eligible(int groups, bool big_shape) const
+{
+    if (no_fused_verify_ || !speculate_ || use_graphs_ || shard_count_ != 1 || xch_send_ || groups <= 0) return false;
+    const int per_cu = big_shape ? 2 : 4;                   // LDS (37 / 50 KB) and the 128-register budget admit exactly that many
+    return groups <= per_cu * cu_count_ && groups < (int)ISL_BAD / 2;
+}
+
+// would a rebuild take the path without a host round trip (build_bins_speculative)?
+bool DeviceSolver::spec_build_applies(bool want_islands, int nj) const
+{
+    return spec_bins_ok_ && !no_spec_bins_ && want_islands && defer_build_check_ && shard_count_ == 1 && !xch_send_ && nj > 0 && nj < (1 << BINC_JOINT_BITS) &&
+           !trace_schedule_;
+}
+
+// Arms the gate of a solve on the cached schedule.  ISL_VERIFY where the island launch can check the schedule itself — no kernel in
+// front of it at all; else the hash pass, if the schedule's hash is on record.
+bool DeviceSolver::arm_cached_solve(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp, int* status)
+{
+    *status = PHX_OK;
+    const int lg = sched_.lds_groups;
+    const int mine = lg > shard_ ? (lg - shard_ + shard_count_ - 1) / shard_count_ : 0;
+    if (nj > 0 && !sched_.has_hbm_group() && verify_eligible(mine, sched_.lds_lanes > ISL_T)) {
+        begin_set(false);
+        isl_mode_ = ISL_VERIFY;
+        isl_nexpect_ = (unsigned)mine;
+        gate_expected_ = (unsigned long long)std::min(mine, ISL_SHARDS);      // every shard of workgroups arrived, none saw a difference, nobody gave up
+        if (++solve_epoch_ == 0) solve_epoch_ = 1;
+        return true;
+    }
+    if (!have_hash_) return false;
+    *status = launch_fingerprint(d_mpos, nb, d_joints, nj, ncp);
+    gate_expected_ = raw_fingerprint_;
+    return true;
+}
+
+int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
                                   bool known_changed)
 {
     // 1. fingerprint of the joint topology (8 bytes over PCIe).  A caller that KNOWS the topology changed (the World, when
     //    joints were created or destroyed this step) does not wait for it: the value rides along with the builder's first
-    //    readback.
+    //    readback — and a rebuild that needs no host round trip (build_bins_speculative) whose solves the island kernel can
+    //    check itself (ISL_VERIFY) skips the hash pass altogether: nobody would ever compare it with anything.
     unsigned long long fp = 0;
     bool have_fp = false;
-    PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
-    stats_.recoloured = 0;
-    ncp_ = ncp;
     // Single = one coupled system swept class by class out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     const bool device_builder = gpu_builder_ && !force_host_builder_;
+    const bool no_hash = known_changed && device_builder && spec_build_applies(want_islands, nj) && verify_eligible(spec_bins_guess_, spec_lanes_ > ISL_T);
+    if (no_hash) begin_set(false);
+    else PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
+    isl_mode_ = ISL_GATED;
+    have_hash_ = false;
+    stats_.recoloured = 0;
+    ncp_ = ncp;
     force_host_builder_ = false;
     build_unverified_ = false;
     if (!(known_changed && device_builder)) {
@@ -148,7 +220,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         have_fp = true;
         const unsigned long long mixed = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
         if (!force_rebuild && !known_changed && sched_.valid && sched_.fingerprint == mixed && nb == nb_ && nj == nj_ && sched_.islands == want_islands) {
-            raw_fingerprint_ = fp; gate_expected_ = fp;
+            raw_fingerprint_ = fp; gate_expected_ = fp; have_hash_ = true;
             return PHX_OK;
         }
     }
@@ -171,6 +243,8 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         if (!fallback) {
             sched_.fingerprint = fp ^ ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
             raw_fingerprint_ = fp;
+            have_hash_ = !no_hash && !spec_bins_pending_;      // (a speculative build's hash comes back when the solve is settled)
+            spec_hash_ran_ = !no_hash;
             if (!spec_bins_pending_) gate_expected_ = fp;
             sched_.valid = true;
             ++schedule_version_;
@@ -240,7 +314,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     // new table for this solve — already cleared by this solve's fingerprint kernel unless it has just been (re)allocated
     if (sw_.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
         PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
-    PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb)); PHX_TRY(sb_par_.reserve(nb));
+    PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb));
     PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj)); PHX_TRY(qn_.reserve(nj));
     PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
     if (nj) PHX_HIP(hipMemcpyAsync(order_.p, sched_.order.data(), (size_t)nj * sizeof(int), hipMemcpyHostToDevice, stream_));
@@ -272,8 +346,11 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
         std::vector<int> units(ng);
         std::vector<int4> unit_recs(2 * (size_t)ng * lanes, make_int4(0, -1, 0, 0));
         for (int g = 0; g < ng; ++g) {
-            units[g] = sched_.group_unit_offsets[g + 1] - sched_.group_unit_offsets[g];
-            for (int u = 0; u < units[g]; ++u) {
+            const int nunits = sched_.group_unit_offsets[g + 1] - sched_.group_unit_offsets[g];
+            int nstatic_g = 0;                                   // (the group's static bodies sit first in its table)
+            for (int k = sched_.group_body_offsets[g]; k < sched_.group_body_offsets[g + 1] && is_static[sched_.group_bodies[k]]; ++k) ++nstatic_g;
+            units[g] = nunits | (nstatic_g << 16);
+            for (int u = 0; u < nunits; ++u) {
                 const int at = sched_.group_unit_offsets[g] + u;
                 const int ls = sched_.unit_leader[at], fs = sched_.unit_follower[at];
                 const int lj = sched_.order[ls], fj = fs >= 0 ? sched_.order[fs] : -1;
@@ -291,7 +368,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
     PHX_HIP(hipStreamSynchronize(stream_));
     lap("upload");
     sched_.fingerprint = fp;
-    raw_fingerprint_ = raw; gate_expected_ = raw;
+    raw_fingerprint_ = raw; gate_expected_ = raw; have_hash_ = true;
     sched_.valid = true;
     ++schedule_version_;
     drop_graphs();
@@ -305,7 +382,7 @@ int DeviceSolver::ensure_schedule(const phx_rigid_body* d_bodies, int nb, const 
 constexpr int JP_BATCH = 8;          // colouring rounds queued between two looks at the frontier sizes
 constexpr int JP_ROUNDS_MAX = 512;
 
-int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
+int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
 {
     *fallback = false;
     RoctxRange range("GatherIslands + PrepareIndices (schedule build)");          // ref: Solver.cpp:77, 135, 217, 285
@@ -330,7 +407,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
     sc.islands = want_islands; sc.lds_on_host = false;
     int nbins = 0, lds_slots = 0, where = 0, ncomp_total = 0;
     spec_bins_pending_ = false;
-    if (spec_bins_ok_ && !no_spec_bins_ && want_islands && defer_build_check_ && shard_count_ == 1 && !xch_send_ && nj > 0 && nj < (1 << BINC_JOINT_BITS) && !trace) {
+    if (spec_build_applies(want_islands, nj)) {
         PHX_TRY(build_bins_speculative(d_bodies, nb, d_joints, nj, sc));
         sched_ = std::move(sc);
         return PHX_OK;
@@ -589,7 +666,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
         }
         if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
-        PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs)); PHX_TRY(sb_par_.reserve(nbs));
+        PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs));
         PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs)); PHX_TRY(qn_.reserve(njs));
         PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
     }
@@ -613,7 +690,7 @@ int DeviceSolver::build_schedule_device(const phx_rigid_body* d_bodies, int nb, 
 // spoils the solve's fingerprint word like a rejected bin does: the solve commits nothing, synchronize() rebuilds the
 // long way and repeats it.  The topology hash the host has not seen is replaced on the device by a constant it knows
 // (`gate_expected_`), which is what the solve's kernels compare the word with; the hash itself comes back with the results.
-int DeviceSolver::build_bins_speculative(const phx_rigid_body* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
+int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
 {
     // the hook + compress pairs the last build needed, less the one that only confirmed that nothing hooks any more: whether
     // every joint's bodies ended up under one label is checked by k_joint_components, which reads those labels anyway
@@ -714,7 +791,7 @@ int DeviceSolver::materialise_schedule()
 //   pre    PrepareBodies, PrepareJoints+RefreshJoints, PreStepJoints class by class
 //   sweeps `iters` x colours fused impulse+displacement launches
 //   post   FinishJoints, FinishBodies
-int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj)
+int DeviceSolver::enqueue_pre(const BodyView& d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
     // (the control words — productive flags, static tags, island counters — were cleared by launch_fingerprint's
@@ -723,8 +800,8 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     // PreStep class by class.  Groups solved in LDS read and write the caller's records directly.
     const int hbm_bodies = sched_.hbm_body_count;
     if (nj && owns_hbm_group()) {
-        hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies, (const int*)hbm_body_list_.p,
-                           hbm_bodies, sb_imp_.p, sb_disp_.p, sb_par_.p, isl_visits_.p + ISL_STAT_SLOTS);
+        hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, d_bodies, (const int*)hbm_body_list_.p,
+                           hbm_bodies, sb_imp_.p, sb_disp_.p, v.stamps);
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
         for (size_t c = 0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
@@ -736,7 +813,7 @@ int DeviceSolver::enqueue_pre(phx_rigid_body* d_bodies, int nb, const phx_contac
     return PHX_OK;
 }
 
-int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi)
+int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi, int mode_override)
 {
     const SolverView v = view();
     const int iters = std::max(ci, pi);
@@ -750,8 +827,27 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
         iv.ngroups_dev = spec_bins_pending_ ? bin_result_.p : nullptr;
         iv.stamp_begin = iv.stamp_end = owns_hbm_group() ? 0 : 1;      // (with an HBM group, its first and last kernels leave the stamps)
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_recs = unit_recs_.p; iv.bodies = grp_bodies_.p;
-        iv.executed = isl_stats_.p; iv.visits = isl_visits_.p;
+        iv.executed = isl_stats_.p + (size_t)hash_slot_ * STATS_SET; iv.visits = isl_visits_.p + (size_t)hash_slot_ * VISITS_SET;
         iv.trace = nullptr; iv.wave_trace = nullptr;
+        // how the launch is gated (island_view.h).  A launch whose grid is only an upper bound of the group count (speculative
+        // binning) is gated by the build it follows.
+        iv.mode = mode_override >= 0 ? mode_override : isl_mode_;
+        iv.nexpect = isl_nexpect_; iv.ctl = hash_.p + hash_slot_; iv.epoch = solve_epoch_;
+        iv.shards = isl_shards_.p + (size_t)hash_slot_ * SHARDS_SET;
+        iv.wait_polls = isl_wait_polls_;
+        if (iv.mode != ISL_GATED) {
+            if (isl_done_.cap < (size_t)lg) {      // (a new table: no group carries any epoch)
+                if (isl_done_.reserve((size_t)std::max(lg, 1)) != PHX_OK) return PHX_ERR_HIP;
+                PHX_HIP(hipMemsetAsync(isl_done_.p, 0, isl_done_.cap * sizeof(unsigned), stream_));
+            }
+            iv.done = isl_done_.p;
+        }
+        if (island_clears_next_) {                 // no hash pass in front: this launch is the solve's first kernel
+            const int next = hash_slot_ ^ 1;
+            iv.next_ctl = hash_.p + next; iv.next_executed = isl_stats_.p + (size_t)next * STATS_SET; iv.next_visits = isl_visits_.p + (size_t)next * VISITS_SET;
+            iv.next_shards = isl_shards_.p + (size_t)next * SHARDS_SET;
+            island_clears_next_ = false;
+        }
         if (trace_islands_) {
             // 8 words per group, then 8 words per wave (16 waves at most) of every group
             if (isl_trace_.reserve((size_t)std::max(lg, 1) * (8 + 128)) != PHX_OK) return PHX_ERR_HIP;
@@ -781,7 +877,7 @@ int DeviceSolver::enqueue_sweeps(phx_rigid_body* d_bodies, const phx_contact_poi
     return PHX_OK;
 }
 
-int DeviceSolver::enqueue_post(phx_rigid_body* d_bodies, int nb, phx_contact_joint* d_joints, int nj)
+int DeviceSolver::enqueue_post(const BodyView& d_bodies, int nb, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
     if (nj && owns_hbm_group()) {      // only the HBM group has results parked in the solver arrays
@@ -803,7 +899,7 @@ void DeviceSolver::drop_graphs()
 
 // Capture the three segments into hipGraphs.  A solve of the 200k-box scene is ~230 launches of 1-4 us
 // kernels; launched eagerly the host (~4 us per launch) is the bottleneck, replayed from a graph it is not.
-int DeviceSolver::capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints)
+int DeviceSolver::capture_graphs(const GraphKey& key, const BodyView& d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints)
 {
     drop_graphs();
     for (int seg = 0; seg < 3; ++seg) {
@@ -826,8 +922,10 @@ int DeviceSolver::capture_graphs(const GraphKey& key, phx_rigid_body* d_bodies, 
     return PHX_OK;
 }
 
-int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg)
+int DeviceSolver::enqueue(const Arrays& arrays, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, const phx_config& cfg)
 {
+    cur_ = arrays;
+    const BodyView& d_bodies = arrays.view;
     const int ci = cfg.contact_iterations, pi = cfg.penetration_iterations;
     const int iters = std::max(ci, pi);
     if (iters + 1 > max_iters_ || !flags_.p) {
@@ -837,7 +935,7 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
         drop_graphs();
     }
     GraphKey key;
-    key.bodies = d_bodies; key.cps = d_cps; key.joints = d_joints; key.nb = nb; key.nj = nj; key.ncp = ncp_; key.ci = ci; key.pi = pi;
+    key.bodies = d_bodies.vel; key.cps = d_cps; key.joints = d_joints; key.nb = nb; key.nj = nj; key.ncp = ncp_; key.ci = ci; key.pi = pi;
     key.schedule_version = schedule_version_; key.valid = true;
     // graphs pay off from the second solve of an unchanged (schedule, buffers, iteration counts) tuple on
     const bool have = graph_key_.valid && graph_key_ == key;
@@ -864,6 +962,11 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
         RoctxRange r("FinishJoints + FinishBodies (HBM group)");                                         // ref: Solver.cpp:213, 114
         if (replay) { if (graph_[2]) PHX_HIP(hipGraphLaunch(graph_[2], stream_)); }
         else PHX_TRY(enqueue_post(d_bodies, nb, d_joints, nj));
+        // a solve that came through the C-ABI edge: FinishBodies into the caller's records, behind the same gate
+        if (arrays.aos && nb) {
+            hipLaunchKernelGGL(k_view_to_bodies, dim3(grid_for(nb)), dim3(256), 0, stream_, d_bodies, nb, arrays.aos, (const unsigned long long*)(hash_.p + hash_slot_), gate_expected_);
+            PHX_HIP(hipGetLastError());
+        }
     }
     timed_sweeps_ = time_sweeps_;
     last_ci_ = ci; last_pi_ = pi; last_island_mode_ = cfg.island_mode;
@@ -873,50 +976,100 @@ int DeviceSolver::enqueue(phx_rigid_body* d_bodies, int nb, const phx_contact_po
     return PHX_OK;
 }
 
+// the C-ABI edge: PrepareBodies (ref: Solver.cpp:456-480) of the caller's 128-byte records into this handle's resident arrays
+int DeviceSolver::edge_view(const void* d_bodies_aos, int nb, Arrays* out)
+{
+    PHX_TRY(edge_vel_.reserve(std::max(nb, 1))); PHX_TRY(edge_dvel_.reserve(std::max(nb, 1))); PHX_TRY(edge_mpos_.reserve(std::max(nb, 1)));
+    out->view = BodyView{edge_vel_.p, edge_dvel_.p, edge_mpos_.p};
+    out->aos = static_cast<phx_rigid_body*>(const_cast<void*>(d_bodies_aos));
+    if (nb) hipLaunchKernelGGL(k_bodies_to_view, dim3(grid_for(nb)), dim3(256), 0, stream_, static_cast<const phx_rigid_body*>(d_bodies_aos), nb, out->view);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
 int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed)
 {
     PHX_TRY(use_device(device_));
+    PHX_REQUIRE(nb >= 0, "negative count");
+    PHX_REQUIRE(nb == 0 || d_bodies, "null bodies");
+    PHX_REQUIRE((reinterpret_cast<uintptr_t>(d_bodies) & 15u) == 0, "device arrays must be 16-byte aligned");
+    Arrays a;
+    a.aos = static_cast<phx_rigid_body*>(d_bodies);
+    a.view = BodyView{edge_vel_.p, edge_dvel_.p, edge_mpos_.p};      // (identity of the pending solve: refreshed by edge_view below)
+    // an unverified solve on OTHER arrays is still in flight: settle it before the edge arrays are overwritten
+    if (pending_.active && pending_.arrays.aos != a.aos) PHX_TRY(synchronize());
+    if (build_unverified_) PHX_TRY(synchronize());
+    if ((size_t)nb > edge_vel_.cap && pending_.active) PHX_TRY(synchronize());      // (the edge arrays are about to be reallocated)
+    PHX_TRY(edge_view(d_bodies, nb, &a));
+    return solve_common(a, nb, d_cps, ncp, d_joints, nj, cfg, topology_changed);
+}
+
+int DeviceSolver::solve_resident(const BodyView& bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(nb >= 0, "negative count");
+    PHX_REQUIRE(nb == 0 || (bodies.vel && bodies.dvel && bodies.mpos), "null bodies");
+    Arrays a;
+    a.view = bodies;
+    return solve_common(a, nb, d_cps, ncp, d_joints, nj, cfg, topology_changed);
+}
+
+bool DeviceSolver::same_as_pending(const Arrays& a, int nb, const void* cps, int ncp, const void* joints, int nj, const phx_config& cfg) const
+{
+    return pending_.arrays.aos == a.aos && pending_.arrays.view.vel == a.view.vel && pending_.arrays.view.dvel == a.view.dvel && pending_.arrays.view.mpos == a.view.mpos &&
+           pending_.cps == cps && pending_.joints == joints && pending_.nb == nb && pending_.nj == nj && pending_.ncp == ncp && std::memcmp(&pending_.cfg, &cfg, sizeof cfg) == 0;
+}
+
+void DeviceSolver::register_pending(const Arrays& a, int nb, const void* cps, int ncp, void* joints, int nj, const phx_config& cfg, bool repeat)
+{
+    pending_.count = repeat && pending_.active ? pending_.count + 1 : 1;
+    pending_.active = true; pending_.arrays = a; pending_.cps = cps; pending_.joints = joints;
+    pending_.nb = nb; pending_.ncp = ncp; pending_.nj = nj; pending_.cfg = cfg;
+    pending_.mode = isl_mode_; pending_.nexpect = isl_nexpect_;
+}
+
+int DeviceSolver::solve_common(const Arrays& a, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed)
+{
     PHX_REQUIRE(nb >= 0 && nj >= 0 && ncp >= 0, "negative count");
     PHX_REQUIRE(cfg.contact_iterations >= 0 && cfg.penetration_iterations >= 0 && cfg.contact_iterations < 60000 && cfg.penetration_iterations < 60000, "iteration count out of range");
     PHX_REQUIRE(!half_state_ || (cfg.contact_iterations < 32000 && cfg.penetration_iterations < 32000), "fp16 body state keeps the iteration tag in 16 bits");
     PHX_REQUIRE(cfg.solve_mode >= PHX_SOLVE_SCALAR && cfg.solve_mode <= PHX_SOLVE_AVX2, "unknown solve mode");
     PHX_REQUIRE(cfg.island_mode >= PHX_ISLAND_SINGLE && cfg.island_mode <= PHX_ISLAND_MULTIPLE_SLOPPY, "unknown island mode");
-    PHX_REQUIRE(nb == 0 || d_bodies, "null bodies");
     PHX_REQUIRE(nj == 0 || (d_joints && d_cps), "null joints / contact points");
-    PHX_REQUIRE((reinterpret_cast<uintptr_t>(d_bodies) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_cps) & 15u) == 0, "device arrays must be 16-byte aligned");
+    PHX_REQUIRE((reinterpret_cast<uintptr_t>(a.view.vel) & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.view.dvel) & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.view.mpos) & 15u) == 0 &&
+                (reinterpret_cast<uintptr_t>(d_cps) & 15u) == 0, "device arrays must be 16-byte aligned");
     // an unverified solve on OTHER arrays is still in flight: settle it first (a repeat on the same arrays simply
-    // supersedes it — each solve is gated by the fingerprint computed for itself)
-    if (pending_.active && !(pending_.bodies == d_bodies && pending_.cps == d_cps && pending_.joints == d_joints && pending_.nb == nb &&
-                             pending_.nj == nj && pending_.ncp == ncp && std::memcmp(&pending_.cfg, &cfg, sizeof cfg) == 0))
-        PHX_TRY(synchronize());
+    // supersedes it — each solve is gated for itself)
+    if (pending_.active && !same_as_pending(a, nb, d_cps, ncp, d_joints, nj, cfg)) PHX_TRY(synchronize());
     // a device-built schedule is verified (did every bin fit?) before anything else runs on it: only the solve that was queued
-    // with the build is covered by the spoiled fingerprint
+    // with the build is covered by the spoiled control word
     if (build_unverified_) PHX_TRY(synchronize());
+    cur_ = a;
+    const float4* mpos = a.view.mpos;
+    const phx_contact_joint* joints = static_cast<const phx_contact_joint*>(d_joints);
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
     if (!reuse_schedule_) topology_changed = true;       // live-topology measurements: rebuild like the reference does every call (ref: Solver.cpp:77, 135)
+    bool armed = false;
     if (!topology_changed && speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
-        // Same sizes as the schedule in hand: run on it without waiting for the fingerprint.  The fingerprint kernel is
-        // queued first; every kernel that writes to the caller's arrays compares it on the device and commits nothing on
-        // a mismatch; synchronize() reads it back and, if it differs, rebuilds the schedule and repeats the solve.
-        PHX_TRY(launch_fingerprint(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp));
-        gate_expected_ = raw_fingerprint_;
+        // Same sizes as the schedule in hand: run on it without a host round trip.  Every kernel that writes to the caller's
+        // arrays commits only behind the solve's gate — the island launch's own check of the schedule against the arrays
+        // (ISL_VERIFY, island_view.h), or the topology hash pass queued in front (ISL_GATED) — and synchronize() reads the
+        // control word back and, if the schedule was stale, rebuilds it and repeats the solve.
+        int st = PHX_OK;
+        armed = arm_cached_solve(mpos, nb, joints, nj, ncp, &st);
+        PHX_TRY(st);
+    }
+    if (armed) {
         // a repeat on the same arrays while the previous one is still unverified: both ran on the same cached schedule and are
         // gated by the same topology, so they are verified together — and replayed together if the schedule was stale
         // (bench() on staged copies of the input the schedule was verified for: the device gates all the same, bench() checks the
-        //  last fingerprint itself, and nothing is registered for a replay — every step has arrays of its own)
-        if (!bench_trusted_) {
-            pending_.count = pending_.active ? pending_.count + 1 : 1;
-            pending_.active = true; pending_.bodies = d_bodies; pending_.cps = d_cps; pending_.joints = d_joints;
-            pending_.nb = nb; pending_.ncp = ncp; pending_.nj = nj; pending_.cfg = cfg;
-        }
+        //  last control word itself, and nothing is registered for a replay — every step has arrays of its own)
+        if (!bench_trusted_) register_pending(a, nb, d_cps, ncp, d_joints, nj, cfg, true);
         stats_.recoloured = 0;
     } else {
-        PHX_TRY(ensure_schedule(static_cast<const phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_joint*>(d_joints), nj, ncp, cfg, false, topology_changed));
-        if (build_unverified_) {       // like a speculative solve: verified (and replayed on a host-built schedule if a bin was rejected) by synchronize()
-            pending_.count = 1;
-            pending_.active = true; pending_.bodies = d_bodies; pending_.cps = d_cps; pending_.joints = d_joints;
-            pending_.nb = nb; pending_.ncp = ncp; pending_.nj = nj; pending_.cfg = cfg;
-        }
+        PHX_TRY(ensure_schedule(mpos, nb, joints, nj, ncp, cfg, false, topology_changed));
+        // like a speculative solve: verified (and replayed on a host-built schedule if a bin was rejected) by synchronize()
+        if (build_unverified_) register_pending(a, nb, d_cps, ncp, d_joints, nj, cfg, false);
     }
     const bool split = cfg.island_mode == PHX_ISLAND_MULTIPLE || cfg.island_mode == PHX_ISLAND_MULTIPLE_SLOPPY;
     stats_.island_count = split ? sched_.island_count : 1;
@@ -924,7 +1077,7 @@ int DeviceSolver::solve_device(void* d_bodies, int nb, const void* d_cps, int nc
     stats_.colour_count = sched_.ncolours();
     stats_.lds_islands = sched_.lds_groups;
     if (step_hook_ && step_hook_(step_hook_user_, step_hook_step_, 1)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
-    return enqueue(static_cast<phx_rigid_body*>(d_bodies), nb, static_cast<const phx_contact_point*>(d_cps), static_cast<phx_contact_joint*>(d_joints), nj, cfg);
+    return enqueue(a, nb, static_cast<const phx_contact_point*>(d_cps), static_cast<phx_contact_joint*>(d_joints), nj, cfg);
 }
 
 int DeviceSolver::solve_host(phx_rigid_body* bodies, int nb, const phx_contact_point* cps, int ncp, phx_contact_joint* joints, int nj, const phx_config& cfg)
@@ -988,7 +1141,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
             const int nbins = std::min(spec[0], unverified_bins_);
             unsigned long long hash = 0;
             std::memcpy(&hash, spec + 8, sizeof hash);
-            raw_fingerprint_ = hash;
+            raw_fingerprint_ = hash; have_hash_ = spec_hash_ran_;
             sched_.fingerprint = hash ^ ((unsigned long long)(unsigned)nj_ << 32) ^ (unsigned)nb_;
             sched_.lds_groups = nbins;
             sched_.group_offsets.assign(goff.begin(), goff.begin() + nbins + 1);
@@ -1025,10 +1178,10 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     unsigned long long visit_slots[ISL_STAT_SLOTS] = {0};
     if (extra) PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_));
     PHX_TRY(rb_.add(flags.data(), flags_.p, flags.size() * sizeof(int), stream_));
-    PHX_TRY(rb_.add(isl_slots, isl_stats_.p, sizeof isl_slots, stream_));
+    PHX_TRY(rb_.add(isl_slots, isl_stats_.p + (size_t)hash_slot_ * STATS_SET, sizeof isl_slots, stream_));
     unsigned long long stamps[2] = {0, 0};
-    PHX_TRY(rb_.add(visit_slots, isl_visits_.p, sizeof visit_slots, stream_));
-    PHX_TRY(rb_.add(stamps, isl_visits_.p + ISL_STAT_SLOTS, sizeof stamps, stream_));
+    PHX_TRY(rb_.add(visit_slots, isl_visits_.p + (size_t)hash_slot_ * VISITS_SET, sizeof visit_slots, stream_));
+    PHX_TRY(rb_.add(stamps, isl_visits_.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS, sizeof stamps, stream_));
     PHX_TRY(with_build());
     PHX_TRY(rb_.wait(stream_));
     PHX_TRY(rest_of_sizes());
@@ -1058,27 +1211,54 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     return PHX_OK;
 }
 
+// ISL_COMPLETE: the groups a verified launch left uncommitted (the bounded wait of some workgroup ran out before all had
+// arrived; the schedule itself was found correct by every workgroup) are solved by a second launch that skips the committed ones.
+int DeviceSolver::complete_partial()
+{
+    const Pending p = pending_;
+    const int ci = p.cfg.contact_iterations, pi = p.cfg.penetration_iterations;
+    cur_ = p.arrays;
+    island_clears_next_ = false;
+    PHX_TRY(enqueue_sweeps(p.arrays.view, static_cast<const phx_contact_point*>(p.cps), static_cast<phx_contact_joint*>(p.joints), p.nj, ci, pi, ISL_COMPLETE));
+    if (p.arrays.aos && p.nb) hipLaunchKernelGGL(k_view_to_bodies, dim3(grid_for(p.nb)), dim3(256), 0, stream_, p.arrays.view, p.nb, p.arrays.aos, (const unsigned long long*)nullptr, 0ull);
+    PHX_HIP(hipGetLastError());
+    unsigned long long word = 0;
+    PHX_TRY(rb_.add(&word, hash_.p + hash_slot_, sizeof word, stream_));
+    PHX_TRY(rb_.wait(stream_));
+    (void)word;       // (ISL_COMPLETE commits unconditionally: behind it every group carries this solve's epoch)
+    return PHX_OK;
+}
+
 int DeviceSolver::synchronize()
 {
     PHX_TRY(use_device(device_));
     if (pending_.active) {
-        // one round trip: the speculative solve's fingerprint and its counters together
+        // one round trip: the speculative solve's control word and its counters together
         unsigned long long fp = 0;
         PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_));
         const Pending p = pending_;
         pending_.active = false;
-        const bool spoiled_build = build_was_unverified_ && fp != gate_expected_;      // a bin did not fit: the device build spoiled the fingerprint
+        const bool spoiled_build = build_was_unverified_ && fp != gate_expected_;      // a bin did not fit: the device build spoiled the control word
         build_was_unverified_ = false;
         if (spoiled_build && !spec_bins_failed_) force_host_builder_ = true;      // (a spoiled speculative binning only needs the builder's long way)
         spec_bins_failed_ = false;
-        if (fp != gate_expected_) {
+        if (fp != gate_expected_ && p.mode == ISL_VERIFY && (fp & ~ISL_TIMEOUT) == gate_expected_) {
+            // every workgroup arrived and found the schedule correct, but some gave up waiting for the others: finish their groups
+            stats_pending_ = true;
+            ++replays_;                                // (callers that queued work behind the solve's gate repeat it)
+            pending_ = p;
+            const int st = complete_partial();
+            pending_.active = false;
+            PHX_TRY(st);
+        } else if (fp != gate_expected_) {
             stats_pending_ = true;                     // those counters belong to a solve that committed nothing
             ++replays_;
             // the joint topology changed under the cached schedule (or the build it ran on had a bin that did not fit): nothing was
             // committed; rebuild — verified on the spot this time — and solve again
             const bool keep_defer = defer_build_check_;
             defer_build_check_ = false;
-            const int rebuilt = ensure_schedule(static_cast<const phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp, p.cfg, true);
+            cur_ = p.arrays;
+            const int rebuilt = ensure_schedule(p.arrays.view.mpos, p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp, p.cfg, true);
             defer_build_check_ = keep_defer;
             PHX_TRY(rebuilt);
             stats_.colour_count = sched_.ncolours();
@@ -1088,8 +1268,8 @@ int DeviceSolver::synchronize()
             stats_.island_max_size = split ? sched_.island_max_size : p.nj;
             // none of the queued solves committed anything: repeat as many as were asked for (e.g. solver-only sub-stepping)
             for (int k = 0; k < std::max(p.count, 1); ++k) {
-                if (k) PHX_TRY(launch_fingerprint(static_cast<const phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp));
-                PHX_TRY(enqueue(static_cast<phx_rigid_body*>(p.bodies), p.nb, static_cast<const phx_contact_point*>(p.cps), static_cast<phx_contact_joint*>(p.joints), p.nj, p.cfg));
+                if (k) PHX_TRY(launch_fingerprint(p.arrays.view.mpos, p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp));
+                PHX_TRY(enqueue(p.arrays, p.nb, static_cast<const phx_contact_point*>(p.cps), static_cast<phx_contact_joint*>(p.joints), p.nj, p.cfg));
             }
             PHX_HIP(hipStreamSynchronize(stream_));
         }
@@ -1213,22 +1393,29 @@ int DeviceSolver::get_refreshed(int joint, float out[30])
     return PHX_OK;
 }
 
-// One private copy of (bodies, joints) per timed step, made outside the timed region: bench() then solves copy k in step k
-// instead of restoring one working copy in front of every step (two copy dispatches, ~11 us of a 0.1 ms step at cfg 2 size,
-// that are the bench's own scaffolding, not SolveJoints).  Consumed by the next bench() call on the same arrays.
+// One private copy of the solver's in/out arrays per timed step — the resident velocities (body_view.h) and the joints — made
+// outside the timed region: bench() then solves copy k in step k instead of restoring one working copy in front of every step (copy
+// dispatches that are the bench's own scaffolding, not SolveJoints).  The records the caller hands over are converted to the
+// resident layout here, before the clock starts: the timed solves run on HBM-resident inputs in the layout the World keeps
+// them in.  Consumed by the next bench() call on the same arrays.
 int DeviceSolver::bench_stage(const void* d_bodies, int nb, const void* d_joints, int nj, int steps)
 {
     PHX_REQUIRE(nb >= 0 && nj >= 0 && steps >= 0 && steps <= 4096, "bad bench_stage arguments");
     PHX_TRY(use_device(device_));
+    PHX_TRY(synchronize());
     staged_steps_ = 0;
-    const size_t bytes = (size_t)steps * ((size_t)nb * sizeof(phx_rigid_body) + (size_t)nj * sizeof(phx_contact_joint));
+    const size_t bytes = (size_t)steps * ((size_t)nb * 2 * sizeof(float4) + (size_t)nj * sizeof(phx_contact_joint));
     if (!steps || bytes > (8ull << 30)) return PHX_OK;      // too big to stage: bench() restores in front of every step
-    PHX_TRY(stage_bodies_.reserve(std::max<size_t>((size_t)steps * nb, 1)));
+    PHX_TRY(stage_vel_.reserve(std::max<size_t>((size_t)steps * nb, 1)));
+    PHX_TRY(stage_dvel_.reserve(std::max<size_t>((size_t)steps * nb, 1)));
+    PHX_TRY(stage_mpos_.reserve(std::max<size_t>(nb, 1)));
     PHX_TRY(stage_joints_.reserve(std::max<size_t>((size_t)steps * nj, 1)));
     for (int k = 0; k < steps; ++k) {
-        if (nb) PHX_HIP(hipMemcpyAsync(stage_bodies_.p + (size_t)k * nb, d_bodies, (size_t)nb * sizeof(phx_rigid_body), hipMemcpyDeviceToDevice, stream_));
+        if (nb) hipLaunchKernelGGL(k_bodies_to_view, dim3(grid_for(nb)), dim3(256), 0, stream_, static_cast<const phx_rigid_body*>(d_bodies), nb,
+                                   BodyView{stage_vel_.p + (size_t)k * nb, stage_dvel_.p + (size_t)k * nb, stage_mpos_.p});
         if (nj) PHX_HIP(hipMemcpyAsync(stage_joints_.p + (size_t)k * nj, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
     }
+    PHX_HIP(hipGetLastError());
     PHX_HIP(hipStreamSynchronize(stream_));
     staged_src_bodies_ = d_bodies; staged_src_joints_ = d_joints; staged_nb_ = nb; staged_nj_ = nj; staged_steps_ = steps;
     return PHX_OK;
@@ -1239,7 +1426,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
 {
     PHX_REQUIRE(out && warmup >= 0 && steps >= 0 && steps <= 4096, "bad bench arguments");
     PHX_TRY(use_device(device_));
-    PHX_TRY(snap_bodies_.reserve(std::max(nb, 1)));
+    PHX_TRY(snap_vel_.reserve(std::max(nb, 1))); PHX_TRY(snap_dvel_.reserve(std::max(nb, 1))); PHX_TRY(snap_mpos_.reserve(std::max(nb, 1)));
     PHX_TRY(snap_joints_.reserve(std::max(nj, 1)));
     std::memset(out, 0, sizeof *out);
     while ((int)bench_events_.size() < 2 * steps + 2) { hipEvent_t e; PHX_HIP(hipEventCreate(&e)); bench_events_.push_back(e); }
@@ -1248,17 +1435,17 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     const bool staged = staged_steps_ >= steps && steps > 0 && staged_src_bodies_ == d_bodies && staged_src_joints_ == d_joints && staged_nb_ == nb && staged_nj_ == nj;
     staged_steps_ = 0;                                       // (consumed: the solves overwrite the copies)
     auto one_step = [&](int k) -> int {
-        phx_rigid_body* b = snap_bodies_.p; phx_contact_joint* j = snap_joints_.p;
-        if (staged && k >= 0) { b = stage_bodies_.p + (size_t)k * nb; j = stage_joints_.p + (size_t)k * nj; }
+        BodyView b{snap_vel_.p, snap_dvel_.p, snap_mpos_.p}; phx_contact_joint* j = snap_joints_.p;
+        if (staged && k >= 0) { b = BodyView{stage_vel_.p + (size_t)k * nb, stage_dvel_.p + (size_t)k * nb, stage_mpos_.p}; j = stage_joints_.p + (size_t)k * nj; }
         else {
-            if (nb) PHX_HIP(hipMemcpyAsync(b, d_bodies, (size_t)nb * sizeof(phx_rigid_body), hipMemcpyDeviceToDevice, stream_));
+            if (nb) hipLaunchKernelGGL(k_bodies_to_view, dim3(grid_for(nb)), dim3(256), 0, stream_, static_cast<const phx_rigid_body*>(d_bodies), nb, b);
             if (nj) PHX_HIP(hipMemcpyAsync(j, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
         }
-        PHX_TRY(solve_device(b, nb, d_cps, ncp, j, nj, cfg));
+        PHX_TRY(solve_resident(b, nb, d_cps, ncp, j, nj, cfg));
         if (xch_send_) {       // island-sharded solve: pack, the caller's all-gather (hook phase 2), unpack — all on the stream
-            PHX_TRY(exchange_pack(b, j, nullptr));
+            PHX_TRY(exchange_pack_resident(&b, j, nullptr));
             if (hook && hook(user, step_hook_step_, 2)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
-            PHX_TRY(exchange_unpack(b, j));
+            PHX_TRY(exchange_unpack_resident(b, j));
         }
         return PHX_OK;
     };

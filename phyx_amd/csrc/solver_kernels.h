@@ -5,9 +5,10 @@
 // SolveJointsImpulses (:760-914), SolveJointsDisplacement (:916-1018).
 //
 // Layout in HBM:
-//   bodies   sb_imp[b]  = {vx, vy, w, lastIteration}   float4   (ref SolveBody, Solver.h:95-101)
+//   bodies   resident structure of arrays (body_view.h): vel, dvel, mpos = {invMass, invInertia, pos.x, pos.y}
+//            (ref SolveBodyParams minus the unused frame), read in place (sb_par aliases mpos);
+//            sb_imp[b]  = {vx, vy, w, lastIteration}   float4   (ref SolveBody, Solver.h:95-101), the HBM path's working copy
 //            sb_disp[b] = same for the displacing velocities
-//            sb_par[b]  = {invMass, invInertia, pos.x, pos.y}   (ref SolveBodyParams minus the unused frame)
 //            one body = one 16-B gather/scatter granule per array.
 //   joints   stored in SCHEDULE order (slot s), colour c owns the contiguous slot range crange[c]:
 //            q0[s] = {n.x, n.y, angN1, angN2}          normal projector + its angular projectors
@@ -62,17 +63,19 @@ __device__ __forceinline__ void solve_stamp_end(unsigned long long* stamps) { if
 
 // ---- PrepareBodies (ref: Solver.cpp:456-480) -----------------------------------------------------
 // `list` = the bodies the HBM group touches (islands solved in LDS read the records directly)
-static __global__ void __launch_bounds__(256) k_unpack_bodies(const phx_rigid_body* __restrict__ bodies, const int* __restrict__ list, int count,
-                                                       float4* __restrict__ sb_imp, float4* __restrict__ sb_disp, float4* __restrict__ sb_par,
+// (the solver works on private copies of the velocities — sb_imp / sb_disp, with the lastIteration tag in the fourth lane — because
+//  its results are committed only behind the topology gate; {invMass, invInertia, pos} is read from the resident array in place)
+static __global__ void __launch_bounds__(256) k_unpack_bodies(BodyView bodies, const int* __restrict__ list, int count,
+                                                       float4* __restrict__ sb_imp, float4* __restrict__ sb_disp,
                                                        unsigned long long* __restrict__ stamps)
 {
     solve_stamp_begin(stamps);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int i = list[k];
-        const phx_rigid_body& b = bodies[i];
-        sb_imp[i] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, __int_as_float(-1));
-        sb_disp[i] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, __int_as_float(-1));
-        sb_par[i] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
+        float4 a = bodies.vel[i], d = bodies.dvel[i];
+        a.w = __int_as_float(-1); d.w = __int_as_float(-1);
+        sb_imp[i] = a;
+        sb_disp[i] = d;
     }
 }
 
@@ -89,28 +92,33 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
 // the island kernel's per-group statistics go to ISL_STAT_SLOTS slots: thousands of same-address atomics would serialise at the L2
 constexpr int ISL_STAT_SLOTS = 64;
 
-// the per-solve control words: the HBM path's per-sweep 'productive' flags and static-tag words, the island kernel's counters
+// the per-solve control words: the HBM path's per-sweep 'productive' flags and static-tag words (cleared for THIS solve), and the
+// control set of the NEXT solve — its control word, the island kernel's counters, the solve's time stamps; two sets alternate and the
+// first kernel of every solve (this one, or the island kernel when no hash pass runs: island_view.h) clears the other set
 struct ControlWords {
     int* flags; int nflags;
     unsigned* sw; int nsw;
-    int* isl_stats;
-    unsigned long long* isl_visits;
+    unsigned long long* next_ctl;
+    int* next_executed;
+    unsigned long long* next_visits;
+    unsigned long long* next_shards;      // the island kernel's arrival counters (island_view.h)
 };
 
 constexpr int HASH_T = 1024;          // few, fat workgroups: the final same-address atomics serialise (~10 ns each)
 constexpr int HASH_BLOCKS = 128;
 
 static __global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_contact_joint* __restrict__ joints, int nj,
-                                                       const phx_rigid_body* __restrict__ bodies, int nb, int ncp, unsigned long long* out,
-                                                       unsigned long long* next_out, ControlWords cw)
+                                                       const float4* __restrict__ mpos, int nb, int ncp, unsigned long long* out,
+                                                       ControlWords cw)
 {
-    // First kernel of every solve, so it also clears that solve's control words and the accumulator the NEXT solve's
-    // fingerprint will use (two accumulators alternate): one dispatch where there used to be five memsets.
+    // First kernel of the solves that run it (schedules with an HBM group, sharded solves, rebuilds the long way): it also clears
+    // the solve's HBM-path words and the NEXT solve's control set (two sets alternate): one dispatch where there used to be five memsets.
     {
         const int i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
-        if (i == 0) *next_out = 0ull;
-        if (i < ISL_STAT_SLOTS) { cw.isl_visits[i] = 0ull; cw.isl_stats[2 * i] = 0; cw.isl_stats[2 * i + 1] = 0; }
-        if (i == 0) { cw.isl_visits[ISL_STAT_SLOTS] = ~0ull; cw.isl_visits[ISL_STAT_SLOTS + 1] = 0ull; }      // the solve's time stamps (solve_stamp)
+        if (i == 0) *cw.next_ctl = 0ull;
+        if (i < ISL_STAT_SLOTS) { cw.next_visits[i] = 0ull; cw.next_executed[2 * i] = 0; cw.next_executed[2 * i + 1] = 0; }
+        if (i == 0) { cw.next_visits[ISL_STAT_SLOTS] = ~0ull; cw.next_visits[ISL_STAT_SLOTS + 1] = 0ull; }      // the solve's time stamps (solve_stamp)
+        if (i < ISL_SHARDS) cw.next_shards[i * ISL_SHARD_STRIDE] = 0ull;
         for (int k = i; k < cw.nflags; k += n) cw.flags[k] = 0;
         for (int k = i; k < cw.nsw; k += n) cw.sw[k] = 0u;
     }
@@ -126,7 +134,8 @@ static __global__ void __launch_bounds__(HASH_T) k_topology_hash(const phx_conta
             h += 0xBADBADBADBADBAD1ull + (unsigned long long)i;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
-        if (bodies[i].inv_mass == 0.f && bodies[i].inv_inertia == 0.f) h += mix64(0xD1B54A32D192ED03ull * (unsigned long long)(i + 1));
+        const float4 p = mpos[i];
+        if (p.x == 0.f && p.y == 0.f) h += mix64(0xD1B54A32D192ED03ull * (unsigned long long)(i + 1));
     }
     for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
@@ -405,15 +414,15 @@ static __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int 
     }
 }
 
-static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, phx_rigid_body* __restrict__ bodies)
+static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, BodyView bodies)
 {
     if (*v.fingerprint != v.expected_fingerprint) { solve_stamp_end(v.stamps); return; }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int i = list[k];
-        const float4 a = v.sb_imp[i], d = v.sb_disp[i];
-        phx_rigid_body& b = bodies[i];
-        b.velocity.x = a.x; b.velocity.y = a.y; b.angular_velocity = a.z;
-        b.displacing_velocity.x = d.x; b.displacing_velocity.y = d.y; b.displacing_angular_velocity = d.z;
+        float4 a = v.sb_imp[i], d = v.sb_disp[i];
+        a.w = 0.f; d.w = 0.f;
+        bodies.vel[i] = a;
+        bodies.dvel[i] = d;
     }
     solve_stamp_end(v.stamps);
 }

@@ -250,6 +250,63 @@ def test_speculative_schedule_is_verified(solver, oracle):
     assert gb2.tobytes() == ob2.tobytes() and gj2.tobytes() == oj2.tobytes()
 
 
+def test_island_kernel_verifies_the_cached_schedule_itself(solver, oracle):
+    """On a cached schedule with nothing but workgroup-sized islands no hash pass runs: the island kernel compares the joints and the
+    bodies' static-ness it loads anyway with what the schedule recorded (ISL_VERIFY, csrc/island_view.h) and commits only if every
+    workgroup of the launch agrees.  Each kind of difference must be caught — one joint re-wired, one contact-point index changed,
+    one body turned static, one static body turned dynamic — and answered with a rebuild, never with a wrong result."""
+    a = presolve_state(scenes.stack(8, 30), 3)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 12, 12)
+
+    def check(state, must_rebuild):
+        gb, gj, sched, _, st = _device_solve(solver, state, cfg)
+        assert st.recoloured == (1 if must_rebuild else 0)
+        ob_, oj, _ = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+        assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+
+    check(a, True)                                                   # builds the schedule
+    check(a, False)                                                  # verified by the island kernel: reused
+    assert solver.stats().lds_islands > 0 and solver.stats().colour_count > 0
+    j = a[2].copy()
+    k = len(j) // 2
+    j["body2"][k], j["body1"][k] = j["body1"][k], j["body2"][k]      # one joint's bodies swapped: same sizes, other topology
+    check((a[0], a[1], j), True)
+    check((a[0], a[1], j), False)
+    j2 = j.copy()
+    free = sorted(set(range(len(a[1]))) - set(j2["contact_point_index"].tolist()))
+    if free:                                                         # a joint moved to an unused contact point slot (another colouring priority)
+        j2["contact_point_index"][3] = free[0]
+        check((a[0], a[1], j2), True)
+    b = a[0].copy()
+    dyn = int(j["body1"][7])
+    b["inv_mass"][dyn] = 0.0; b["inv_inertia"][dyn] = 0.0             # a dynamic body turned static
+    check((b, a[1], j), True)
+    check((b, a[1], j), False)
+    b2 = b.copy()
+    b2["inv_mass"][0] = 1e-3; b2["inv_inertia"][0] = 1e-5             # the ground turned dynamic: every column joins one island
+    check((b2, a[1], j), True)
+    check(a, True)                                                   # and back
+
+
+def test_island_groups_left_uncommitted_are_completed(oracle, built_lib, monkeypatch):
+    """A workgroup of a verified launch commits only after every workgroup has arrived; its wait is bounded (a GPU shared with
+    somebody else's kernels may not hold them all at once).  With the bound forced to zero every workgroup gives up: the solve must
+    be completed by the second launch (ISL_COMPLETE) and still be the oracle's, bit for bit."""
+    monkeypatch.setenv("PHX_ISL_WAIT_POLLS", "0")
+    solver = phyx_amd.Solver(0)
+    monkeypatch.delenv("PHX_ISL_WAIT_POLLS")
+    state = presolve_state(scenes.stack(12, 25), 3)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE_SLOPPY, 15, 15)
+    first = _device_solve(solver, state, cfg)                       # builds
+    for _ in range(2):                                               # verified launches that all time out
+        gb, gj, sched, _, st = _device_solve(solver, state, cfg)
+        assert st.recoloured == 0
+        assert gb.tobytes() == first[0].tobytes() and gj.tobytes() == first[1].tobytes()
+        ob_, oj, ost = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+        assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+        assert st.impulse_iterations == ost.impulse_iterations and st.joint_visits == ost.joint_visits
+
+
 def test_two_queued_solves_on_a_stale_schedule_are_both_replayed(solver, oracle):
     """Solver-only sub-stepping: two SolveJoints queued back to back on the same device arrays, no synchronisation in between,
     while the cached schedule is stale.  Neither commits (the fingerprint gates them); synchronize() must rebuild and replay
