@@ -24,6 +24,14 @@ struct BodyView {
     float4* mpos;
 };
 
+// everything the World keeps per body: the solver's view + frame, AABB and half size
+struct WorldBodies {
+    BodyView s;
+    float4* frame;      // {xVector.x, xVector.y, yVector.x, yVector.y}
+    float4* aabb;       // {min.x, min.y, max.x, max.y}
+    float2* size;       // geom.size
+};
+
 // 16-byte non-temporal store (results that nobody re-reads before the kernel ends: they should not wait in L2 for the
 // end-of-kernel write-back)
 typedef float f4v __attribute__((ext_vector_type(4)));

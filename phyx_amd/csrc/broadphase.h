@@ -13,8 +13,11 @@ public:
     int clear();
     // `prologue` (World only): IntegrateVelocity (ref: World.cpp:39-55) rides on the update's first kernel — the key of a body is
     // its AABB's min x, which the velocity step does not touch — and the step's four counters are cleared on the way: a dispatch fewer
-    struct StepPrologue { float gravity, dt; unsigned* counters; };
-    int update_device(const phx_rigid_body* d_bodies, int n, const StepPrologue* prologue = nullptr);
+    struct StepPrologue { float gravity, dt; unsigned* counters; float4* vel; const float4* mpos; };      // (resident arrays, body_view.h)
+    // the resident form: one float4 {min.x, min.y, max.x, max.y} per body (what the World keeps, body_view.h)
+    int update_resident(const float4* d_aabb, int n, const StepPrologue* prologue = nullptr);
+    // the C-ABI edge: 128-byte records (their AABBs are extracted into a scratch array first)
+    int update_device(const phx_rigid_body* d_bodies, int n);
     int update_host(const phx_rigid_body* bodies, int n, uint32_t* new_pairs, int cap, int* count);
     int get_new_pairs(uint32_t* out, int cap, int* count);
     int get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* entries, int cap);
@@ -42,6 +45,7 @@ private:
     ScanScratch scan_tiles_;
     DevBuf<uint2> new_pairs_, scratch_pairs_;
     DevBuf<phx_rigid_body> st_bodies_;
+    DevBuf<float4> st_aabb_;
     DevBuf<int> erase_count_;                 // pairs really tombstoned since the last settle_erase_check()
     unsigned table_cap_ = 0;
     long long set_size_ = 0, tombstones_ = 0, erase_unchecked_ = 0;

@@ -34,8 +34,14 @@ __device__ __forceinline__ unsigned radix_float(float v)
 
 // ref: Collider.cpp:259-265
 // (first kernel of an update: it also clears the update's counters and the hub-chunk counts — two dispatches fewer)
+__global__ void __launch_bounds__(256) k_extract_aabb(const phx_rigid_body* __restrict__ bodies, int n, float4* __restrict__ aabb)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        aabb[i] = make_float4(bodies[i].aabb_min.x, bodies[i].aabb_min.y, bodies[i].aabb_max.x, bodies[i].aabb_max.y);
+}
+
 template <bool INTEGRATE>
-__global__ void __launch_bounds__(256) k_build_keys(phx_rigid_body* __restrict__ bodies, int n,
+__global__ void __launch_bounds__(256) k_build_keys(const float4* __restrict__ aabb, float4* __restrict__ vel, const float4* __restrict__ mpos, int n,
                                                     unsigned* __restrict__ keys, unsigned* __restrict__ idx,
                                                     unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
                                                     unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters)
@@ -47,27 +53,26 @@ __global__ void __launch_bounds__(256) k_build_keys(phx_rigid_body* __restrict__
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nsmall; i += gridDim.x * blockDim.x) small[i] = 0ull;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) chunk_count[i] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        keys[i] = radix_float(bodies[i].aabb_min.x);
+        keys[i] = radix_float(aabb[i].x);
         idx[i] = (unsigned)i;
         if (INTEGRATE) {                                       // IntegrateVelocity (ref: World.cpp:39-55), same statements as k_integrate_velocity
-            phx_rigid_body& b = bodies[i];
-            float ax = b.acceleration.x, ay = b.acceleration.y;
-            if (b.inv_mass > 0.0f) ay += gravity;
-            b.velocity.x += ax * dt; b.velocity.y += ay * dt;
-            b.acceleration.x = 0.f; b.acceleration.y = 0.f;
-            b.angular_velocity += b.angular_acceleration * dt;
-            b.angular_acceleration = 0.f;
+            float4 v = vel[i];
+            float ax = 0.f, ay = 0.f, aa = 0.f;                // (the resident world carries no accelerations: world_kernels.h)
+            if (mpos[i].x > 0.0f) ay += gravity;
+            v.x += ax * dt; v.y += ay * dt;
+            v.z += aa * dt;
+            vel[i] = v;
         }
     }
 }
 
 // ref: Collider.cpp:269-283
-__global__ void __launch_bounds__(256) k_gather_entries(const phx_rigid_body* __restrict__ bodies, const unsigned* __restrict__ idx, int n,
+__global__ void __launch_bounds__(256) k_gather_entries(const float4* __restrict__ aabb, const unsigned* __restrict__ idx, int n,
                                                         float4* __restrict__ entries)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const phx_rigid_body& b = bodies[idx[i]];
-        const float minx = b.aabb_min.x, miny = b.aabb_min.y, maxx = b.aabb_max.x, maxy = b.aabb_max.y;
+        const float4 b = aabb[idx[i]];
+        const float minx = b.x, miny = b.y, maxx = b.z, maxy = b.w;
         entries[i] = make_float4(minx, maxx, (miny + maxy) * 0.5f, (maxy - miny) * 0.5f);
     }
 }
@@ -400,7 +405,7 @@ DeviceBroadphase::~DeviceBroadphase()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
     hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); scan_tiles_.release(); small_.release(); stamps_.release();
-    new_pairs_.release(); st_bodies_.release(); scratch_pairs_.release(); erase_count_.release();
+    new_pairs_.release(); st_bodies_.release(); st_aabb_.release(); scratch_pairs_.release(); erase_count_.release();
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -449,7 +454,17 @@ int DeviceBroadphase::clear()
     return resize_table(1024);
 }
 
-int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n, const StepPrologue* prologue)
+int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(n >= 0 && (n == 0 || d_bodies), "bad body array");
+    PHX_TRY(st_aabb_.reserve(std::max(n, 1)));
+    if (n) hipLaunchKernelGGL(k_extract_aabb, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, n, st_aabb_.p);
+    PHX_HIP(hipGetLastError());
+    return update_resident(st_aabb_.p, n);
+}
+
+int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepPrologue* prologue)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(n >= 0 && (n == 0 || d_bodies), "bad body array");
@@ -477,9 +492,9 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n, const
         return PHX_OK;
     }
 
-    if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, const_cast<phx_rigid_body*>(d_bodies), n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
+    if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, prologue->vel, prologue->mpos, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
                                      chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
-    else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, const_cast<phx_rigid_body*>(d_bodies), n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
+    else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (float4*)nullptr, (const float4*)nullptr, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
                             chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
     int src = 0;
     PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));

@@ -1,7 +1,9 @@
 // narrowphase.h — box/box SAT, contact generation and manifold merging as __host__ __device__ functions.
 //
 // This is the step between the two hot halves of the path; it restates
-// ref: src/Collider.cpp:8-245 and src/Geom.h:10-85 on the 128-byte body records.  The functions are
+// ref: src/Collider.cpp:8-245 and src/Geom.h:10-85 on the fields the resident arrays hold (body_view.h): a body is
+// {pos, xVector, yVector, size} here (the reference's Geom keeps a copy of the frame, refreshed by UpdateGeom,
+// RigidBody.h:38-42: the same values).  The functions are
 // plain IEEE float arithmetic (no libm beyond fabsf) so the host loop and a HIP kernel that call them
 // produce identical bits under -ffp-contract=off.
 #pragma once
@@ -22,21 +24,30 @@ __host__ __device__ inline float sqlen(V2 a) { return a.x * a.x + a.y * a.y; }
 __host__ __device__ inline V2 perp(V2 a) { return v2(-a.y, a.x); }                            // ref: Vector2.h GetPerpendicular
 __host__ __device__ inline phx_vec2 pv(V2 a) { phx_vec2 r; r.x = a.x; r.y = a.y; return r; }
 
-// ref: Geom.h:79-85 (uses the Geom copy of the frame, refreshed by UpdateGeom, RigidBody.h:38-42)
+// what the narrowphase reads of a body
+struct NpBody { V2 pos, xv, yv, size; };
+
+// ref: Geom.h:79-85 RecomputeAABB: {min.x, min.y, max.x, max.y}
+__host__ __device__ inline void geom_aabb(V2 pos, V2 xv, V2 yv, V2 size, float& minx, float& miny, float& maxx, float& maxy)
+{
+    const float dx = fabsf(xv.x) * size.x + fabsf(yv.x) * size.y;
+    const float dy = fabsf(xv.y) * size.x + fabsf(yv.y) * size.y;
+    minx = pos.x - dx; miny = pos.y - dy;
+    maxx = pos.x + dx; maxy = pos.y + dy;
+}
+
+// ref: Geom.h:79-85 on a 128-byte record (uses the Geom copy of the frame, refreshed by UpdateGeom, RigidBody.h:38-42)
 __host__ __device__ inline void update_geom(phx_rigid_body& b)
 {
     b.geom_xvector = b.xvector; b.geom_yvector = b.yvector; b.geom_pos = b.pos;
-    const float dx = fabsf(b.geom_xvector.x) * b.geom_size.x + fabsf(b.geom_yvector.x) * b.geom_size.y;
-    const float dy = fabsf(b.geom_xvector.y) * b.geom_size.x + fabsf(b.geom_yvector.y) * b.geom_size.y;
-    b.aabb_min.x = b.geom_pos.x - dx; b.aabb_min.y = b.geom_pos.y - dy;
-    b.aabb_max.x = b.geom_pos.x + dx; b.aabb_max.y = b.geom_pos.y + dy;
+    geom_aabb(v2(b.geom_pos), v2(b.geom_xvector), v2(b.geom_yvector), v2(b.geom_size), b.aabb_min.x, b.aabb_min.y, b.aabb_max.x, b.aabb_max.y);
 }
 
 // ref: Geom.h:66-77 with GetClippingEdge (:22-64) and GetClippingVertex (:10-20)
-__host__ __device__ inline int support_points(const phx_rigid_body& b, V2 axis, V2 out[2])
+__host__ __device__ inline int support_points(const NpBody& b, V2 axis, V2 out[2])
 {
-    const V2 xv = v2(b.geom_xvector), yv = v2(b.geom_yvector), pos = v2(b.geom_pos);
-    const V2 xdim = xv * b.geom_size.x, ydim = yv * b.geom_size.y;
+    const V2 xv = b.xv, yv = b.yv, pos = b.pos;
+    const V2 xdim = xv * b.size.x, ydim = yv * b.size.y;
     const float xdiff = dot(axis, xv), ydiff = dot(axis, yv);
     if (fabsf(xdiff) < 0.1f || fabsf(ydiff) < 0.1f) {
         V2 p1 = pos, p2 = pos, off = v2(0.f, 0.f);
@@ -58,11 +69,11 @@ __host__ __device__ inline int support_points(const phx_rigid_body& b, V2 axis, 
 }
 
 // ref: Collider.cpp:8-56 — returns false when a separating axis exists
-__host__ __device__ inline bool least_penetration_axis(const phx_rigid_body& b1, const phx_rigid_body& b2, V2& axis)
+__host__ __device__ inline bool least_penetration_axis(const NpBody& b1, const NpBody& b2, V2& axis)
 {
-    const V2 a00 = v2(b1.xvector), a01 = v2(b1.yvector), a10 = v2(b2.xvector), a11 = v2(b2.yvector);
-    const V2 e0 = v2(b1.geom_size), e1 = v2(b2.geom_size);
-    const V2 d = v2(b1.pos) - v2(b2.pos);
+    const V2 a00 = b1.xv, a01 = b1.yv, a10 = b2.xv, a11 = b2.yv;
+    const V2 e0 = b1.size, e1 = b2.size;
+    const V2 d = b1.pos - b2.pos;
     const float ad00 = fabsf(dot(a00, a10)), ad01 = fabsf(dot(a00, a11));
     const float r0 = e0.x + e1.x * ad00 + e1.y * ad01;
     const float d0 = fabsf(dot(a00, d)) - r0;
@@ -87,9 +98,9 @@ __host__ __device__ inline bool least_penetration_axis(const phx_rigid_body& b1,
 
 // ref: Collider.cpp:58-92 with ContactPoint::Equals (Manifold.h:31-38)
 __host__ __device__ inline void merge_point(phx_contact_point* pts, int& count, V2 p1, V2 p2, V2 n,
-                                            const phx_rigid_body& b1, const phx_rigid_body& b2)
+                                            const NpBody& b1, const NpBody& b2)
 {
-    const V2 d1 = p1 - v2(b1.pos), d2 = p2 - v2(b2.pos);              // ref: Manifold.h:20-21
+    const V2 d1 = p1 - b1.pos, d2 = p2 - b2.pos;                      // ref: Manifold.h:20-21
     int closest = -1;
     float bestdepth = 3.402823466e+38f;
     for (int i = 0; i < count; ++i) {
@@ -124,9 +135,9 @@ __host__ __device__ inline bool within_segment(V2 p, V2 a, V2 b)
 }
 
 // ref: Collider.cpp:94-209
-__host__ __device__ inline void generate_contacts(const phx_rigid_body& b1, const phx_rigid_body& b2, phx_contact_point* pts, int& count, V2 axis)
+__host__ __device__ inline void generate_contacts(const NpBody& b1, const NpBody& b2, phx_contact_point* pts, int& count, V2 axis)
 {
-    if (dot(axis, v2(b1.pos) - v2(b2.pos)) < 0.0f) axis = -axis;
+    if (dot(axis, b1.pos - b2.pos) < 0.0f) axis = -axis;
     V2 s1[2], s2[2];
     int n1 = support_points(b1, -axis, s1);
     int n2 = support_points(b2, axis, s2);
@@ -167,13 +178,11 @@ __host__ __device__ inline void generate_contacts(const phx_rigid_body& b1, cons
 
 // ref: Collider.cpp:211-245.  Returns true if a third merged point had to be dropped: the reference
 // would write it past the manifold's two slots (only an assert guards it).
-__host__ __device__ inline bool update_manifold(phx_manifold& m, const phx_rigid_body* bodies, phx_contact_point* pts)
+__host__ __device__ inline bool update_manifold(phx_manifold& m, const NpBody& b1, const NpBody& b2, phx_contact_point* pts)
 {
     phx_contact_point np[4];
     for (int i = 0; i < m.point_count; ++i) { np[i] = pts[i]; np[i].is_merged = 0; np[i].is_newly_created = 0; }
     int count = m.point_count;
-    const phx_rigid_body& b1 = bodies[m.body1];
-    const phx_rigid_body& b2 = bodies[m.body2];
     V2 axis;
     if (least_penetration_axis(b1, b2, axis)) generate_contacts(b1, b2, np, count, axis);
     m.point_count = 0;
@@ -186,11 +195,11 @@ __host__ __device__ inline bool update_manifold(phx_manifold& m, const phx_rigid
     return dropped;
 }
 
-// ref: AABB2.h:19-24
-__host__ __device__ inline bool aabb_intersects(const phx_rigid_body& a, const phx_rigid_body& b)
+// ref: AABB2.h:19-24 on {min.x, min.y, max.x, max.y}
+__host__ __device__ inline bool aabb_intersects(const float4& a, const float4& b)
 {
-    if (a.aabb_min.x > b.aabb_max.x || b.aabb_min.x > a.aabb_max.x) return false;
-    if (a.aabb_min.y > b.aabb_max.y || b.aabb_min.y > a.aabb_max.y) return false;
+    if (a.x > b.z || b.x > a.z) return false;
+    if (a.y > b.w || b.y > a.w) return false;
     return true;
 }
 

@@ -1,7 +1,9 @@
 // world.hip — World: the whole step of ref: src/World.cpp:19-37 on HBM-resident arrays.
 //
-// bodies / manifolds / contact points / joints live on the device in the reference's POD layouts; the host keeps
-// only their counts.  Per step: IntegrateVelocity (kernel) -> UpdateBroadphase + UpdatePairs (DeviceBroadphase) ->
+// Bodies live on the device as the RESIDENT structure of arrays (body_view.h: velocities, displacing velocities,
+// {invMass, invInertia, pos}, frame, AABB, size — every kernel of the step reads the 16-byte granules it needs, coalesced);
+// the reference's 128-byte records exist at the C-ABI edge only (construction, phx_world_get_bodies).  Manifolds / contact
+// points / joints live on the device in the reference's POD layouts; the host keeps only their counts.  Per step: IntegrateVelocity (kernel) -> UpdateBroadphase + UpdatePairs (DeviceBroadphase) ->
 // manifold creation + UpdateManifolds (narrowphase kernel) -> PackManifolds -> RefreshContactJoints (scan-based,
 // order-preserving, world_kernels.h) -> SolveJoints (DeviceSolver) -> IntegratePosition (kernel).  What crosses
 // PCIe per step is a handful of counters (new pairs, dead manifolds, new / dead joints) and, only when the joint
@@ -53,6 +55,8 @@ public:
 
 private:
     int sync_bodies_to_device();
+    int refresh_records();               // resident arrays -> the 128-byte records (getters)
+    WorldBodies resident() const { return WorldBodies{BodyView{vel_.p, dvel_.p, mpos_.p}, frame_.p, aabb_.p, size_.p}; }
     int update_pairs();
     bool fuse_velocity_ = false; float step_dt_ = 0.f;      // IntegrateVelocity rides on the broadphase's key build (update_pairs)
     int fresh_manifolds_ = 0;           // pairs UpdatePairs found this step: their manifolds are created by UpdateManifolds' kernel
@@ -70,7 +74,10 @@ private:
     hipStream_t stream_ = nullptr;
     std::vector<phx_rigid_body> host_bodies_;     // construction-time staging; the device copy is authoritative after upload
     bool bodies_dirty_ = false;
-    DevBuf<phx_rigid_body> d_bodies_;
+    DevBuf<phx_rigid_body> d_bodies_;             // the records: uploaded once, refreshed from the resident arrays only when a getter asks
+    DevBuf<float4> vel_, dvel_, mpos_, frame_, aabb_;      // the resident body state (body_view.h)
+    DevBuf<float2> size_;
+    bool records_stale_ = false;                  // a step has run since the records were last refreshed
     DevBuf<phx_manifold> d_manifolds_;
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
@@ -93,6 +100,7 @@ World::~World()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
     d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
+    vel_.release(); dvel_.release(); mpos_.release(); frame_.release(); aabb_.release(); size_.release();
     flags_.release(); pack_flags_.release(); dead_flags_.release(); joint_seen_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
     // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
@@ -157,10 +165,25 @@ int World::sync_bodies_to_device()
     if (!bodies_dirty_) return PHX_OK;
     PHX_TRY(use_device(device_));
     PHX_TRY(d_bodies_.reserve(std::max<size_t>(host_bodies_.size(), 1)));
-    if (!host_bodies_.empty())
+    const size_t n = std::max<size_t>(host_bodies_.size(), 1);
+    PHX_TRY(vel_.reserve(n)); PHX_TRY(dvel_.reserve(n)); PHX_TRY(mpos_.reserve(n)); PHX_TRY(frame_.reserve(n)); PHX_TRY(aabb_.reserve(n)); PHX_TRY(size_.reserve(n));
+    if (!host_bodies_.empty()) {
         PHX_HIP(hipMemcpyAsync(d_bodies_.p, host_bodies_.data(), host_bodies_.size() * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
+        hipLaunchKernelGGL(k_bodies_to_world, dim3(wgrid(nb())), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies_.p, nb(), resident());
+        PHX_HIP(hipGetLastError());
+    }
     PHX_HIP(hipStreamSynchronize(stream_));
     bodies_dirty_ = false;
+    records_stale_ = false;
+    return PHX_OK;
+}
+
+int World::refresh_records()
+{
+    if (!records_stale_ || !nb()) return PHX_OK;
+    hipLaunchKernelGGL(k_world_to_bodies, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), d_bodies_.p);
+    PHX_HIP(hipGetLastError());
+    records_stale_ = false;
     return PHX_OK;
 }
 
@@ -173,8 +196,8 @@ int World::scratch_for(int n)
 
 int World::update_pairs()                                                   // ref: Collider.cpp:251-345
 {
-    const DeviceBroadphase::StepPrologue prologue{gravity, step_dt_, counters_.p};
-    PHX_TRY(broadphase_.update_device(d_bodies_.p, nb(), fuse_velocity_ ? &prologue : nullptr));      // same stream; returns once the new-pair count is known
+    const DeviceBroadphase::StepPrologue prologue{gravity, step_dt_, counters_.p, vel_.p, mpos_.p};
+    PHX_TRY(broadphase_.update_resident(aabb_.p, nb(), fuse_velocity_ ? &prologue : nullptr));      // same stream; returns once the new-pair count is known
     fuse_velocity_ = false;
     const int fresh = broadphase_.new_pair_count();
     if (!fresh) return PHX_OK;
@@ -190,7 +213,7 @@ int World::update_manifolds()                                               // r
     if (!nm) return PHX_OK;
     PHX_TRY(scratch_for(nm));
     PHX_TRY(pack_flags_.reserve((size_t)nm + 2));                           // (only here: a pending pack keeps its scan in it until refresh_contact_joints settles it)
-    hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, (const phx_rigid_body*)d_bodies_.p, d_cps_.p,
+    hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
                        pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device());
     fresh_manifolds_ = 0;
     PHX_HIP(hipGetLastError());
@@ -288,7 +311,7 @@ int World::solve(const phx_config& cfg, bool settle)                        // r
 {
     // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
     // keep their velocities here
-    PHX_TRY(solver_.solve_device(d_bodies_.p, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
+    PHX_TRY(solver_.solve_resident(resident().s, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
     joints_changed_ = false;
     // a solve that is still unverified (it ran speculatively on the cached schedule, or on a device-built schedule whose 'every
     // bin fits' flag has not been read) must be settled before anything consumes its result unconditionally
@@ -305,13 +328,13 @@ int World::solve_and_integrate(float dt, const phx_config& cfg)
     RoctxRange r("IntegratePosition");                                      // ref: World.cpp:57-70
     const bool pending = solver_.has_pending();
     const unsigned replays = solver_.replays();
-    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt,
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt,
                                  pending ? solver_.fingerprint_word() : (const unsigned long long*)nullptr, solver_.expected_fingerprint());
     PHX_HIP(hipGetLastError());
     if (pending) {
         PHX_TRY(solver_.synchronize());
         if (solver_.replays() != replays && nb())
-            hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt, (const unsigned long long*)nullptr, 0ull);
+            hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);
         PHX_HIP(hipGetLastError());
     }
     return PHX_OK;
@@ -330,7 +353,8 @@ int World::pre_solve(float dt)
         // (normally fused into the broadphase's first kernel, update_pairs(); a kernel of its own only when the phases are timed one by one)
         fuse_velocity_ = !phase_timing;
         step_dt_ = dt;
-        if (nb() && !fuse_velocity_) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), gravity, dt, counters_.p);
+        records_stale_ = true;
+        if (nb() && !fuse_velocity_) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, vel_.p, (const float4*)mpos_.p, nb(), gravity, dt, counters_.p);
         PHX_HIP(hipGetLastError());
         lap(0);
     }
@@ -352,15 +376,17 @@ int World::step_begin(float dt, const phx_config& cfg, size_t* segment_bytes)
     PHX_TRY(pre_solve(dt));
     { RoctxRange r("SolveJoints (this rank's groups)"); PHX_TRY(solve(cfg, true)); }
     RoctxRange r("Exchange: pack");
-    return solver_.exchange_pack(d_bodies_.p, d_joints_.p, segment_bytes);
+    const BodyView bodies = resident().s;
+    return solver_.exchange_pack_resident(&bodies, d_joints_.p, segment_bytes);
 }
 
 int World::step_end(float dt)
 {
     PHX_TRY(use_device(device_));
-    { RoctxRange r("Exchange: unpack"); PHX_TRY(solver_.exchange_unpack(d_bodies_.p, d_joints_.p)); }
+    { RoctxRange r("Exchange: unpack"); PHX_TRY(solver_.exchange_unpack_resident(resident().s, d_joints_.p)); }
     RoctxRange r("IntegratePosition");
-    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt, (const unsigned long long*)nullptr, 0ull);            // ref: World.cpp:57-70
+    records_stale_ = true;
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);            // ref: World.cpp:57-70
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -376,9 +402,10 @@ int World::finish_step(float dt, const phx_config& cfg)
     if (phase_timing) {                                                     // (per-phase host timing: settle the solve before the integrator)
         { RoctxRange r("SolveJoints"); PHX_TRY(solve(cfg, true)); lap(6); }
         RoctxRange r("IntegratePosition");
-        if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb(), dt, (const unsigned long long*)nullptr, 0ull);
+        if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);
         PHX_HIP(hipGetLastError());
     } else PHX_TRY(solve_and_integrate(dt, cfg));
+    records_stale_ = true;
     lap(7);
     return PHX_OK;
 }
@@ -418,6 +445,8 @@ int World::download_bodies(phx_rigid_body* out, int cap)
     if (cap < n) { set_error("download_bodies: buffer too small"); return PHX_ERR_CAPACITY; }
     if (bodies_dirty_ || !d_bodies_.p) { if (n && out != host_bodies_.data()) std::memcpy(out, host_bodies_.data(), (size_t)n * sizeof(phx_rigid_body)); return PHX_OK; }
     PHX_TRY(use_device(device_));
+    PHX_TRY(solver_.synchronize());                                         // (an unverified solve is settled before its results are read)
+    PHX_TRY(refresh_records());
     PHX_HIP(hipStreamSynchronize(stream_));
     if (n) PHX_HIP(hipMemcpy(out, d_bodies_.p, (size_t)n * sizeof(phx_rigid_body), hipMemcpyDeviceToHost));
     return PHX_OK;

@@ -19,55 +19,102 @@
 
 namespace phx {
 
+// ---- 128-byte records <-> the World's resident arrays (body_view.h): upload after construction, download for the getters -------
+static __global__ void __launch_bounds__(256) k_bodies_to_world(const phx_rigid_body* __restrict__ bodies, int n, WorldBodies w)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const phx_rigid_body& b = bodies[i];
+        w.s.vel[i] = make_float4(b.velocity.x, b.velocity.y, b.angular_velocity, 0.f);
+        w.s.dvel[i] = make_float4(b.displacing_velocity.x, b.displacing_velocity.y, b.displacing_angular_velocity, 0.f);
+        w.s.mpos[i] = make_float4(b.inv_mass, b.inv_inertia, b.pos.x, b.pos.y);
+        w.frame[i] = make_float4(b.xvector.x, b.xvector.y, b.yvector.x, b.yvector.y);
+        w.aabb[i] = make_float4(b.aabb_min.x, b.aabb_min.y, b.aabb_max.x, b.aabb_max.y);
+        w.size[i] = make_float2(b.geom_size.x, b.geom_size.y);
+    }
+}
+
+// everything a step changes goes back into the records (inverse masses, size, index, the vestigial fields and the accelerations —
+// zero after every IntegrateVelocity, ref: World.cpp:49-52 — are what the upload left there)
+static __global__ void __launch_bounds__(256) k_world_to_bodies(WorldBodies w, int n, phx_rigid_body* __restrict__ bodies)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = w.s.vel[i], d = w.s.dvel[i], m = w.s.mpos[i], f = w.frame[i], a = w.aabb[i];
+        phx_rigid_body& b = bodies[i];
+        b.velocity.x = v.x; b.velocity.y = v.y; b.angular_velocity = v.z;
+        b.displacing_velocity.x = d.x; b.displacing_velocity.y = d.y; b.displacing_angular_velocity = d.z;
+        b.pos.x = m.z; b.pos.y = m.w;
+        b.xvector.x = f.x; b.xvector.y = f.y; b.yvector.x = f.z; b.yvector.y = f.w;
+        b.geom_xvector = b.xvector; b.geom_yvector = b.yvector; b.geom_pos = b.pos;      // UpdateGeom (ref: RigidBody.h:38-42)
+        b.aabb_min.x = a.x; b.aabb_min.y = a.y; b.aabb_max.x = a.z; b.aabb_max.y = a.w;
+    }
+}
+
+// IntegrateVelocity (ref: World.cpp:39-55).  The resident world carries no acceleration arrays: the reference zeroes both
+// accelerations at the end of every IntegrateVelocity (World.cpp:49-52), nothing on the path or in the C ABI ever sets them, so
+// they are zero whenever this runs; the statements keep the reference's form (x + 0 * dt is not x for x = -0).
 // (first kernel of a step: it also clears the step's four counters)
-static __global__ void __launch_bounds__(256) k_integrate_velocity(phx_rigid_body* __restrict__ bodies, int n, float gravity, float dt, unsigned* __restrict__ counters)
+static __global__ void __launch_bounds__(256) k_integrate_velocity(float4* __restrict__ vel, const float4* __restrict__ mpos, int n, float gravity, float dt,
+                                                                   unsigned* __restrict__ counters)
 {
     if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        phx_rigid_body& b = bodies[i];
-        float ax = b.acceleration.x, ay = b.acceleration.y;
-        if (b.inv_mass > 0.0f) ay += gravity;
-        b.velocity.x += ax * dt; b.velocity.y += ay * dt;
-        b.acceleration.x = 0.f; b.acceleration.y = 0.f;
-        b.angular_velocity += b.angular_acceleration * dt;
-        b.angular_acceleration = 0.f;
+        float4 v = vel[i];
+        float ax = 0.f, ay = 0.f, aa = 0.f;
+        if (mpos[i].x > 0.0f) ay += gravity;
+        v.x += ax * dt; v.y += ay * dt;
+        v.z += aa * dt;
+        vel[i] = v;
     }
 }
 
 // Vector2::Rotate (ref: Vector2.h:48-56); the reference's unqualified cos/sin resolve to the double overloads
-__device__ __forceinline__ void rotate_vec(phx_vec2& v, float c, float s)
+__device__ __forceinline__ void rotate_vec(float& vx, float& vy, float c, float s)
 {
-    const V2 x = v2(v), y = perp(x);
+    const V2 x = v2(vx, vy), y = perp(x);
     const V2 delta = (x * c + y * s) - x;
-    v.x = v.x + delta.x; v.y = v.y + delta.y;
+    vx = vx + delta.x; vy = vy + delta.y;
 }
 
-// `gate` (may be null): the topology fingerprint word of the solve queued in front; if it differs from `expected` that solve
+// IntegratePosition (ref: World.cpp:57-70) on the resident arrays: reads 72 bytes per body, writes 64.
+// `gate` (may be null): the control word of the solve queued in front; if it differs from `expected` that solve
 // committed nothing (stale or spoiled schedule, solver.hip) and neither does this — the host repeats both.
-static __global__ void __launch_bounds__(256) k_integrate_position(phx_rigid_body* __restrict__ bodies, int n, float dt,
+static __global__ void __launch_bounds__(256) k_integrate_position(WorldBodies w, int n, float dt,
                                                                    const unsigned long long* __restrict__ gate, unsigned long long expected)
 {
     if (gate && *gate != expected) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        phx_rigid_body b = bodies[i];
-        b.pos.x += b.displacing_velocity.x + b.velocity.x * dt;
-        b.pos.y += b.displacing_velocity.y + b.velocity.y * dt;
-        const float ang = -(b.displacing_angular_velocity + b.angular_velocity * dt);
+        const float4 v = w.s.vel[i], d = w.s.dvel[i];
+        float4 m = w.s.mpos[i], f = w.frame[i];
+        const float2 sz = w.size[i];
+        m.z += d.x + v.x * dt;
+        m.w += d.y + v.y * dt;
+        const float ang = -(d.z + v.z * dt);
         const float c = (float)cos((double)ang), s = (float)sin((double)ang);
-        rotate_vec(b.xvector, c, s);
-        rotate_vec(b.yvector, c, s);
-        b.displacing_velocity.x = 0.f; b.displacing_velocity.y = 0.f;
-        b.displacing_angular_velocity = 0.f;
-        update_geom(b);
-        bodies[i] = b;
+        rotate_vec(f.x, f.y, c, s);
+        rotate_vec(f.z, f.w, c, s);
+        float4 box;
+        geom_aabb(v2(m.z, m.w), v2(f.x, f.y), v2(f.z, f.w), v2(sz.x, sz.y), box.x, box.y, box.z, box.w);
+        w.s.mpos[i] = m;
+        w.frame[i] = f;
+        w.s.dvel[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w.aabb[i] = box;
     }
+}
+
+__device__ __forceinline__ NpBody np_load(const WorldBodies& w, int i)
+{
+    const float4 m = w.s.mpos[i], f = w.frame[i];
+    const float2 sz = w.size[i];
+    NpBody b;
+    b.pos = v2(m.z, m.w); b.xv = v2(f.x, f.y); b.yv = v2(f.z, f.w); b.size = v2(sz.x, sz.y);
+    return b;
 }
 
 // ref: Collider.cpp:368-377; also flags the manifolds PackManifolds will drop (ref: Collider.cpp:387).
 // Manifolds [nm_old, nm) are the pairs UpdatePairs has just found (ref: Collider.cpp:313-316 — Manifold(index_i, index_j,
 // manifolds.size * kMaxContactPoints), contact slots blank): they are created here, in the lane that updates them, instead of
 // by an append kernel of their own in front of this one.
-static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, const phx_rigid_body* __restrict__ bodies,
+static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, WorldBodies bodies,
                                                                  phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped,
                                                                  int nm_old, const uint2* __restrict__ new_pairs)
 {
@@ -81,9 +128,11 @@ static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* _
             blank.is_merged = 0; blank.is_newly_created = 0; blank.pad_[0] = 0; blank.pad_[1] = 0; blank.solver_index = -1;
             cps[2 * i] = blank; cps[2 * i + 1] = blank;
         } else m = manifolds[i];
-        if (update_manifold(m, bodies, cps + m.point_index)) atomicAdd(dropped, 1);
+        // (two bodies = 2 x 40 bytes of the resident arrays; the 128-byte records cost 2 x 128 for the same fields)
+        const NpBody b1 = np_load(bodies, m.body1), b2 = np_load(bodies, m.body2);
+        if (update_manifold(m, b1, b2, cps + m.point_index)) atomicAdd(dropped, 1);
         manifolds[i] = m;
-        dead[i] = (m.point_count == 0 && !aabb_intersects(bodies[m.body1], bodies[m.body2])) ? 1u : 0u;
+        dead[i] = (m.point_count == 0 && !aabb_intersects(bodies.aabb[m.body1], bodies.aabb[m.body2])) ? 1u : 0u;
     }
 }
 

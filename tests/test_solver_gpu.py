@@ -260,7 +260,7 @@ def test_island_kernel_verifies_the_cached_schedule_itself(solver, oracle):
 
     def check(state, must_rebuild):
         gb, gj, sched, _, st = _device_solve(solver, state, cfg)
-        assert st.recoloured == (1 if must_rebuild else 0)
+        assert (st.recoloured != 0) == must_rebuild                   # (1: rebuilt, 2: rebuilt without a host round trip)
         ob_, oj, _ = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
         assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
 
