@@ -78,13 +78,17 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed side measurements (Single mode, live topology, other configs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one rank")
-    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--backend", default="rccl", help="rccl: the library's own RCCL transport (csrc/comm.hip), torch only for the rendezvous; "
+                    "nccl: torch.distributed's ProcessGroupNCCL from a step hook; gloo: host-staged (ranks sharing one GPU)")
     args = ap.parse_args()
 
     from phyx_amd import dist as pdist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: one process per GPU, spawned here (python -m torch.distributed.run works too)
+        sys.exit(pdist.self_launch(args.gpus))
     group = pdist.init(args.gpus, backend=args.backend, force=args.force_dist)
     rank, world = group.rank, group.world_size
-    device = group.local_rank if getattr(group, "backend", "nccl") == "nccl" else 0
+    device = group.local_rank if getattr(group, "backend", "rccl") in ("nccl", "rccl") else 0
 
     import phyx_amd
     from phyx_amd import scenes, Configuration

@@ -110,13 +110,31 @@ int phx_solver_solve(phx_solver* s, phx_rigid_body* bodies, int32_t body_count,
                      const phx_contact_point* contact_points, int32_t contact_point_count,
                      phx_contact_joint* joints, int32_t joint_count, const phx_config* config);
 
-/* Same computation on DEVICE-resident arrays (same layouts, HBM pointers), asynchronous on the
- * solver's stream; nothing crosses PCIe except the topology check word.  This is the entry point
- * a device-resident World uses and the one bench.py times. */
+/* Same computation on DEVICE-resident records (same layouts, HBM pointers), asynchronous on the
+ * solver's stream; nothing crosses PCIe except the solve's control word.  The records are converted to the
+ * resident arrays below and back around the solve (two extra passes over the bodies): the drop-in for a caller
+ * that keeps the reference's RigidBody array in HBM. */
 int phx_solver_solve_device(phx_solver* s, void* d_bodies, int32_t body_count,
                             const void* d_contact_points, int32_t contact_point_count,
                             void* d_joints, int32_t joint_count, const phx_config* config);
 int phx_solver_synchronize(phx_solver* s);
+
+/* The RESIDENT form of body state (north star: "bodies ... laid out SoA in HBM with coalesced loads").  The reference stages
+ * exactly these fields into solver-side arrays on every call (PrepareBodies / FinishBodies, ref: src/Solver.cpp:456-494:
+ * SolveBody {velocity, angularVelocity, lastIteration}, SolveBodyParams {invMass, invInertia, coords}); here the staged form is
+ * what a resident pipeline KEEPS — this library's World does, and bench.py times this entry point — three device arrays of one
+ * 16-byte granule per body:
+ *   vel[b]  = {velocity.x, velocity.y, angularVelocity, 0}                        read + written in place
+ *   dvel[b] = {displacingVelocity.x, .y, displacingAngularVelocity, 0}            read + written in place
+ *   mpos[b] = {invMass, invInertia, pos.x, pos.y}                                 read only
+ * phx_bodies_to_view / phx_view_to_bodies convert between a device array of records and a view (queued on `stream`, a
+ * hipStream_t, e.g. phx_solver_stream; the second writes the four velocity fields only, like FinishBodies). */
+typedef struct { void* vel; void* dvel; void* mpos; } phx_body_view;
+int phx_solver_solve_resident(phx_solver* s, const phx_body_view* bodies, int32_t body_count,
+                              const void* d_contact_points, int32_t contact_point_count,
+                              void* d_joints, int32_t joint_count, const phx_config* config);
+int phx_bodies_to_view(int device, const void* d_bodies, int32_t body_count, const phx_body_view* out, void* stream);
+int phx_view_to_bodies(int device, const phx_body_view* in, int32_t body_count, void* d_bodies, void* stream);
 
 /* Precision ablation (BASELINE config 5): 32 (default) keeps the solver-side body state {velocity, angular velocity}
  * in fp32 like the reference's SolveBody (ref: src/Solver.h:95-101); 16 stores it as IEEE half between joint updates
@@ -172,6 +190,28 @@ size_t phx_solver_exchange_segment_bytes(phx_solver* s);      /* of the last pac
  * rank r actually fills (both optional), *segment_words = the common padded segment length. */
 int    phx_exchange_layout(const int32_t* group_bodies, const int32_t* group_slots, int32_t group_count, int32_t shard_count,
                            int64_t* group_offset_words, int64_t* rank_words, int64_t* segment_words);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Native transport of the island-sharded solve: an RCCL communicator, one process per GPU (xGMI between them).  The        */
+/* reference's islands are solved by threads of one process and merged in its one address space (ref: src/Solver.cpp:86-91, */
+/* 482-494, 527-547); across GPUs that merge is one all-gather per step on the solver's stream, which is also the per-step   */
+/* barrier.  RCCL is resolved at run time (librccl.so.1; PHX_RCCL_LIB overrides): no link dependency, PHX_ERR_NO_DEVICE when */
+/* it cannot be loaded.  Rendezvous is the caller's: rank 0 calls phx_comm_unique_id and hands the PHX_COMM_ID_BYTES bytes   */
+/* to every rank by any out-of-band channel (a file, a socket, MPI, torch.distributed's store), then every rank creates.    */
+#define PHX_COMM_ID_BYTES 128
+typedef struct phx_comm phx_comm;
+int  phx_comm_unique_id(void* out_id);                                  /* ncclGetUniqueId */
+int  phx_comm_create(phx_comm** out, const void* unique_id, int32_t rank, int32_t nranks, int device);   /* ncclCommInitRank (collective) */
+void phx_comm_destroy(phx_comm* c);
+int  phx_comm_rank(phx_comm* c);
+int  phx_comm_size(phx_comm* c);
+/* bytes_per_rank from every rank's d_send into d_recv (rank r at r * bytes_per_rank), queued on `stream` (a hipStream_t) */
+int  phx_comm_all_gather(phx_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);
+int  phx_comm_barrier(phx_comm* c, void* stream);                       /* 4-byte all-reduce + stream wait: the pure barrier */
+int  phx_comm_barrier_async(phx_comm* c, void* stream);                 /* the same all-reduce, only queued: work queued on `stream` behind it waits for every rank */
+int  phx_comm_async_error(phx_comm* c, int32_t* error);                 /* ncclCommGetAsyncError: 0 = healthy */
+/* attach to a solver: phx_solver_bench then runs pack -> all-gather -> unpack natively in every step (exchange buffers must be set) */
+int  phx_solver_set_comm(phx_solver* s, phx_comm* c);
 
 /* results of the last solve (valid after a synchronizing call) — counterparts of
  * Solver::islandCount / islandMaxSize (ref: src/Solver.h:105-106) plus executed sweep counts */
@@ -293,6 +333,14 @@ int  phx_world_set_shard(phx_world* w, int32_t shard, int32_t shard_count);
 int  phx_world_step_begin(phx_world* w, float dt, const phx_config* config, size_t* segment_bytes);
 int  phx_world_step_end(phx_world* w, float dt);
 void* phx_world_stream(phx_world* w);       /* the hipStream_t all of the world's work is queued on */
+/* The same step with the native transport: phx_world_set_comm makes this world rank phx_comm_rank(c) of phx_comm_size(c)
+ * (the world owns and grows its exchange buffers), and phx_world_step_sharded is World::Update of the sharded world in ONE
+ * call — step_begin, ncclAllGather of the segments on the world's stream, step_end — with no host wait around the collective.
+ * Every 16th step (and on phx_world_check_exchange) the peers' headers and ncclCommGetAsyncError are checked: PHX_ERR_STATE
+ * means a peer failed, is at another step or solved another topology (phx_solver_exchange_status has the bits). */
+int  phx_world_set_comm(phx_world* w, phx_comm* c);
+int  phx_world_step_sharded(phx_world* w, float dt, const phx_config* config);
+int  phx_world_check_exchange(phx_world* w);
 int  phx_world_update(phx_world* w, float dt, const phx_config* config);   /* ref: World.cpp:19-37 */
 /* phx_world_update returns once the step is QUEUED on the world's stream (the host waits only where it needs a count
  * to size a launch); every getter synchronises before it reads.  This waits for the device explicitly. */

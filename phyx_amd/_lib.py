@@ -24,6 +24,11 @@ class Config(C.Structure):
                 ("contact_iterations", C.c_int32), ("penetration_iterations", C.c_int32)]
 
 
+class BodyView(C.Structure):
+    """phx_body_view: the resident structure-of-arrays form of body state (three device float4 arrays)."""
+    _fields_ = [("vel", C.c_void_p), ("dvel", C.c_void_p), ("mpos", C.c_void_p)]
+
+
 class SolveStats(C.Structure):
     _fields_ = [("island_count", C.c_int32), ("island_max_size", C.c_int32), ("colour_count", C.c_int32),
                 ("impulse_iterations", C.c_int32), ("displacement_iterations", C.c_int32),
@@ -65,6 +70,22 @@ _SIGNATURES = {
     "phx_solver_exchange_unpack": (C.c_int, [_vp, _vp, _vp]),
     "phx_solver_exchange_status": (C.c_int, [_vp, C.POINTER(_i32)]),
     "phx_solver_exchange_segment_bytes": (C.c_size_t, [_vp]),
+    "phx_comm_unique_id": (C.c_int, [_vp]),
+    "phx_comm_create": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, C.c_int]),
+    "phx_comm_destroy": (None, [_vp]),
+    "phx_comm_rank": (C.c_int, [_vp]),
+    "phx_comm_size": (C.c_int, [_vp]),
+    "phx_comm_all_gather": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "phx_comm_barrier": (C.c_int, [_vp, _vp]),
+    "phx_comm_barrier_async": (C.c_int, [_vp, _vp]),
+    "phx_comm_async_error": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "phx_solver_set_comm": (C.c_int, [_vp, _vp]),
+    "phx_world_set_comm": (C.c_int, [_vp, _vp]),
+    "phx_world_step_sharded": (C.c_int, [_vp, _f32, C.POINTER(Config)]),
+    "phx_world_check_exchange": (C.c_int, [_vp]),
+    "phx_solver_solve_resident": (C.c_int, [_vp, C.POINTER(BodyView), _i32, _vp, _i32, _vp, _i32, C.POINTER(Config)]),
+    "phx_bodies_to_view": (C.c_int, [C.c_int, _vp, _i32, C.POINTER(BodyView), _vp]),
+    "phx_view_to_bodies": (C.c_int, [C.c_int, C.POINTER(BodyView), _i32, _vp, _vp]),
     "phx_world_step_begin": (C.c_int, [_vp, _f32, C.POINTER(Config), C.POINTER(C.c_size_t)]),
     "phx_world_step_end": (C.c_int, [_vp, _f32]),
     "phx_world_stream": (C.c_void_p, [_vp]),

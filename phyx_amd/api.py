@@ -278,6 +278,11 @@ class Solver:
         check(self.L.phx_solver_set_shard(self.h, shard, shard_count))
 
     # ---- island-sharded solves: the post-solve exchange (include/phyx_amd.h: phx_solver_exchange_pack) ----
+    def set_comm(self, comm):
+        """bench(): the all-gather between pack and unpack runs natively on the solver's stream (no step hook needed)."""
+        self._comm = comm
+        check(self.L.phx_solver_set_comm(self.h, comm.h if comm is not None else None))
+
     def set_exchange_buffers(self, send_ptr, recv_ptr, segment_capacity_bytes):
         """Caller-owned device buffers (raw addresses): one segment to send, shard_count segments to receive."""
         check(self.L.phx_solver_set_exchange_buffers(self.h, C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr)), int(segment_capacity_bytes)))
@@ -361,6 +366,48 @@ class Solver:
     def stream_ptr(self):
         """The hipStream_t (as an int) all of this handle's work is queued on."""
         return int(self.L.phx_solver_stream(self.h) or 0)
+
+
+class Comm:
+    """Native RCCL communicator (csrc/comm.hip): one per process / GPU.  `unique_id()` on rank 0, hand the 128 bytes to every
+    rank out of band, then every rank constructs Comm(id, rank, nranks, device) — a collective call."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        L = _lib.load()
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(L.phx_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id, rank, nranks, device=0):
+        self.L = _lib.load()
+        assert len(unique_id) == Comm.ID_BYTES
+        h = C.c_void_p()
+        check(self.L.phx_comm_create(C.byref(h), C.c_char_p(bytes(unique_id)), rank, nranks, device))
+        self.h = h
+        self.rank, self.size, self.device = rank, nranks, device
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            self.L.phx_comm_destroy(h)
+            self.h = C.c_void_p()
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, stream_ptr):
+        check(self.L.phx_comm_all_gather(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), bytes_per_rank, C.c_void_p(stream_ptr)))
+
+    def barrier(self, stream_ptr=0):
+        check(self.L.phx_comm_barrier(self.h, C.c_void_p(stream_ptr)))
+
+    def barrier_async(self, stream_ptr):
+        check(self.L.phx_comm_barrier_async(self.h, C.c_void_p(stream_ptr)))
+
+    def async_error(self):
+        e = C.c_int32(0)
+        check(self.L.phx_comm_async_error(self.h, C.byref(e)))
+        return e.value
 
 
 class Collider:
@@ -480,6 +527,19 @@ class World:
     def StepEnd(self, dt):
         """Second half: scatter the other ranks' results, IntegratePosition."""
         check(self.L.phx_world_step_end(self.h, dt))
+
+    def set_comm(self, comm):
+        """Attach a native communicator (Comm): this world becomes rank comm.rank of comm.size and owns its exchange buffers."""
+        self._comm = comm
+        check(self.L.phx_world_set_comm(self.h, comm.h if comm is not None else None))
+
+    def StepSharded(self, dt, configuration):
+        """World::Update of a sharded world in one library call: step_begin, ncclAllGather on the world's stream, step_end."""
+        cfg = configuration._c()
+        check(self.L.phx_world_step_sharded(self.h, dt, C.byref(cfg)))
+
+    def check_exchange(self):
+        check(self.L.phx_world_check_exchange(self.h))
 
     def stream_ptr(self):
         return int(self.L.phx_world_stream(self.h) or 0)

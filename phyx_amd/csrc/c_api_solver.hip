@@ -34,6 +34,36 @@ int phx_solver_solve_device(phx_solver* s, void* d_bodies, int32_t nb, const voi
     return s->impl.solve_device(d_bodies, nb, d_cps, ncp, d_joints, nj, *cfg);
 }
 
+int phx_solver_solve_resident(phx_solver* s, const phx_body_view* bodies, int32_t nb, const void* d_cps, int32_t ncp,
+                              void* d_joints, int32_t nj, const phx_config* cfg)
+{
+    PHX_REQUIRE(s && cfg && bodies, "null handle / config / view");
+    const phx::BodyView v{static_cast<float4*>(bodies->vel), static_cast<float4*>(bodies->dvel), static_cast<float4*>(bodies->mpos)};
+    return s->impl.solve_resident(v, nb, d_cps, ncp, d_joints, nj, *cfg);
+}
+
+int phx_bodies_to_view(int device, const void* d_bodies, int32_t n, const phx_body_view* out, void* stream)
+{
+    PHX_REQUIRE(n >= 0 && out && (n == 0 || (d_bodies && out->vel && out->dvel && out->mpos)), "bad arguments");
+    PHX_TRY(phx::use_device(device));
+    const phx::BodyView v{static_cast<float4*>(out->vel), static_cast<float4*>(out->dvel), static_cast<float4*>(out->mpos)};
+    if (n) hipLaunchKernelGGL(phx::k_bodies_to_view, dim3(std::max(1, std::min(phx::div_up(n, 256), 2048))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                              static_cast<const phx_rigid_body*>(d_bodies), n, v);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
+int phx_view_to_bodies(int device, const phx_body_view* in, int32_t n, void* d_bodies, void* stream)
+{
+    PHX_REQUIRE(n >= 0 && in && (n == 0 || (d_bodies && in->vel && in->dvel && in->mpos)), "bad arguments");
+    PHX_TRY(phx::use_device(device));
+    const phx::BodyView v{static_cast<float4*>(in->vel), static_cast<float4*>(in->dvel), static_cast<float4*>(in->mpos)};
+    if (n) hipLaunchKernelGGL(phx::k_view_to_bodies, dim3(std::max(1, std::min(phx::div_up(n, 256), 2048))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                              v, n, static_cast<phx_rigid_body*>(d_bodies), (const unsigned long long*)nullptr, 0ull);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+}
+
 int phx_solver_synchronize(phx_solver* s)
 {
     PHX_REQUIRE(s, "null handle");

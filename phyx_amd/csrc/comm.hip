@@ -1,0 +1,214 @@
+// comm.hip — the native RCCL transport of the island-sharded solve (BASELINE config 3).
+//
+// The reference merges its islands' results inside one address space (ref: src/Solver.cpp:86-91 parallelFor over islands, then
+// FinishBodies :482-494 / FinishJoints :527-547); across GPUs the counterpart is ONE collective per step on the solver's stream:
+// the all-gather of the ranks' packed results (exchange.h), which is also the per-step barrier of the north star.  This file lets a
+// C / C++ caller of include/phyx_amd.h run that step without any Python: phx_comm_* wraps an RCCL communicator (one process per
+// GPU, xGMI between them), phx_world_set_comm attaches it to a World, and phx_world_step_sharded is then one call per step —
+// step_begin, ncclAllGather on the world's stream, step_end — with ncclCommGetAsyncError folded into the exchange status.
+//
+// RCCL is resolved at run time (dlopen librccl.so.1, like roctx in runtime.hip): the library has no link dependency on it, a box
+// without it simply cannot create a communicator, and a process that already carries an RCCL (PyTorch's) shares that copy.
+#include "handles.h"
+#include "comm.h"
+
+#include <dlfcn.h>
+
+#include <mutex>
+
+namespace phx {
+
+namespace {
+
+// the slice of rccl.h this transport uses (ref: /opt/rocm/include/rccl/rccl.h — enum values are part of the NCCL ABI)
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[PHX_COMM_ID_BYTES]; };
+enum { ncclSuccess = 0, ncclInProgress = 7 };
+enum { ncclUint8 = 1, ncclInt32 = 2 };
+enum { ncclSum = 0, ncclMax = 2 };
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
+    int (*CommGetAsyncError)(ncclComm_t, int*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("PHX_RCCL_LIB");
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        auto sym = [&](const char* name) { return dlsym(r.lib, name); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
+        r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.CommGetAsyncError && r.AllGather && r.AllReduce;
+    });
+    return r;
+}
+
+int rccl_fail(const char* what, int code)
+{
+    Rccl& r = rccl();
+    set_error("%s: RCCL error %d (%s)", what, code, r.GetErrorString ? r.GetErrorString(code) : "?");
+    return PHX_ERR_HIP;
+}
+
+#define PHX_RCCL(call, what) do { const int rc_ = (call); if (rc_ != ncclSuccess) return rccl_fail(what, rc_); } while (0)
+
+} // namespace
+
+struct Comm::Impl { ncclComm_t comm = nullptr; };
+
+Comm::~Comm()
+{
+    if (impl_ && impl_->comm && rccl().ok) { (void)hipSetDevice(device_); (void)rccl().CommDestroy(impl_->comm); }
+    delete impl_;
+    if (flag_) (void)hipFree(flag_);
+}
+
+int Comm::unique_id(void* out)
+{
+    Rccl& r = rccl();
+    if (!r.ok) { set_error("RCCL is not available (librccl.so.1 could not be loaded: %s)", dlerror() ? dlerror() : "missing symbols"); return PHX_ERR_NO_DEVICE; }
+    ncclUniqueId id;
+    PHX_RCCL(r.GetUniqueId(&id), "ncclGetUniqueId");
+    std::memcpy(out, id.internal, PHX_COMM_ID_BYTES);
+    return PHX_OK;
+}
+
+int Comm::init(const void* unique_id, int rank, int nranks)
+{
+    PHX_REQUIRE(unique_id && nranks >= 1 && rank >= 0 && rank < nranks, "bad communicator arguments");
+    Rccl& r = rccl();
+    if (!r.ok) { set_error("RCCL is not available (librccl.so.1 could not be loaded)"); return PHX_ERR_NO_DEVICE; }
+    PHX_TRY(use_device(device_));
+    rank_ = rank; nranks_ = nranks;
+    impl_ = new (std::nothrow) Impl;
+    PHX_REQUIRE(impl_, "out of host memory");
+    ncclUniqueId id;
+    std::memcpy(id.internal, unique_id, PHX_COMM_ID_BYTES);
+    PHX_RCCL(r.CommInitRank(&impl_->comm, nranks, id, rank), "ncclCommInitRank");
+    PHX_HIP(hipMalloc(reinterpret_cast<void**>(&flag_), 2 * sizeof(int)));
+    PHX_HIP(hipMemset(flag_, 0, 2 * sizeof(int)));
+    return PHX_OK;
+}
+
+int Comm::all_gather(const void* d_send, void* d_recv, size_t bytes_per_rank, hipStream_t stream)
+{
+    PHX_REQUIRE(impl_ && impl_->comm, "communicator not initialised");
+    PHX_TRY(use_device(device_));
+    PHX_RCCL(rccl().AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, impl_->comm, stream), "ncclAllGather");
+    return PHX_OK;
+}
+
+// the pure-barrier variant of the north star: a 4-byte all-reduce (max) of a status word on `stream`; *d_word is in place
+int Comm::all_reduce_max_int(int* d_word, hipStream_t stream)
+{
+    PHX_REQUIRE(impl_ && impl_->comm, "communicator not initialised");
+    PHX_TRY(use_device(device_));
+    PHX_RCCL(rccl().AllReduce(d_word, d_word, 1, ncclInt32, ncclMax, impl_->comm, stream), "ncclAllReduce");
+    return PHX_OK;
+}
+
+int Comm::barrier_async(hipStream_t stream)
+{
+    PHX_HIP(hipMemsetAsync(flag_ + 1, 0, sizeof(int), stream));
+    return all_reduce_max_int(flag_ + 1, stream);
+}
+
+int Comm::barrier(hipStream_t stream)
+{
+    PHX_HIP(hipMemsetAsync(flag_, 0, sizeof(int), stream));
+    PHX_TRY(all_reduce_max_int(flag_, stream));
+    PHX_HIP(hipStreamSynchronize(stream));
+    return PHX_OK;
+}
+
+// ncclCommGetAsyncError: 0 = healthy or still in progress, else the RCCL error code
+int Comm::async_error(int* out)
+{
+    PHX_REQUIRE(impl_ && impl_->comm && out, "communicator not initialised");
+    int e = ncclSuccess;
+    PHX_RCCL(rccl().CommGetAsyncError(impl_->comm, &e), "ncclCommGetAsyncError");
+    *out = (e == ncclSuccess || e == ncclInProgress) ? 0 : e;
+    return PHX_OK;
+}
+
+} // namespace phx
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int phx_comm_unique_id(void* out_id)
+{
+    PHX_REQUIRE(out_id, "null out");
+    return phx::Comm::unique_id(out_id);
+}
+
+int phx_comm_create(phx_comm** out, const void* unique_id, int32_t rank, int32_t nranks, int device)
+{
+    PHX_REQUIRE(out, "null out");
+    *out = nullptr;
+    PHX_TRY(phx::use_device(device));
+    phx_comm* c = new (std::nothrow) phx_comm(device);
+    PHX_REQUIRE(c, "out of host memory");
+    const int st = c->impl.init(unique_id, rank, nranks);
+    if (st != PHX_OK) { delete c; return st; }
+    *out = c;
+    return PHX_OK;
+}
+
+void phx_comm_destroy(phx_comm* c) { delete c; }
+
+int phx_comm_rank(phx_comm* c) { return c ? c->impl.rank() : -1; }
+int phx_comm_size(phx_comm* c) { return c ? c->impl.size() : 0; }
+
+int phx_comm_all_gather(phx_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream)
+{
+    PHX_REQUIRE(c, "null handle");
+    return c->impl.all_gather(d_send, d_recv, bytes_per_rank, static_cast<hipStream_t>(stream));
+}
+
+int phx_comm_barrier(phx_comm* c, void* stream)
+{
+    PHX_REQUIRE(c, "null handle");
+    return c->impl.barrier(static_cast<hipStream_t>(stream));
+}
+
+int phx_comm_barrier_async(phx_comm* c, void* stream)
+{
+    PHX_REQUIRE(c, "null handle");
+    return c->impl.barrier_async(static_cast<hipStream_t>(stream));
+}
+
+int phx_comm_async_error(phx_comm* c, int32_t* error)
+{
+    PHX_REQUIRE(c && error, "null handle / out");
+    int e = 0;
+    PHX_TRY(c->impl.async_error(&e));
+    *error = e;
+    return PHX_OK;
+}
+
+} // extern "C"

@@ -122,6 +122,12 @@ int DeviceSolver::exchange_unpack_resident(const BodyView& d_bodies, void* d_joi
     return PHX_OK;
 }
 
+int DeviceSolver::exchange_all_gather()
+{
+    PHX_REQUIRE(comm_ && xch_send_ && xch_recv_, "no communicator / exchange buffers");
+    return comm_->all_gather(xch_send_, xch_recv_, (size_t)xch_seg_words_ * 4, stream_);
+}
+
 int DeviceSolver::exchange_status(int* out)
 {
     PHX_REQUIRE(out, "null out");
@@ -151,6 +157,13 @@ int phx_solver_set_exchange_buffers(phx_solver* s, void* d_send, void* d_recv, s
 {
     PHX_REQUIRE(s, "null handle");
     return s->impl.set_exchange_buffers(d_send, d_recv, segment_capacity_bytes);
+}
+
+int phx_solver_set_comm(phx_solver* s, phx_comm* c)
+{
+    PHX_REQUIRE(s, "null handle");
+    s->impl.set_comm(c ? &c->impl : nullptr);
+    return PHX_OK;
 }
 
 int phx_solver_exchange_pack(phx_solver* s, const void* d_bodies, const void* d_joints, int32_t status_word, size_t* segment_bytes)

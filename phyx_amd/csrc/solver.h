@@ -4,6 +4,7 @@
 #include "common.h"
 #include "body_view.h"
 #include "schedule.h"
+#include "comm.h"
 
 namespace phx {
 
@@ -68,6 +69,8 @@ public:
     int exchange_status(int* out);
     size_t exchange_segment_bytes() const { return (size_t)xch_seg_words_ * 4; }
     int shard_count() const { return shard_count_; }
+    void set_comm(Comm* c) { comm_ = c; }              // bench(): the all-gather between pack and unpack runs natively (comm.hip)
+    int exchange_all_gather();                        // the segment of the last pack, every rank's into the recv buffer, on stream()
 
     hipStream_t stream() const { return stream_; }
     // run on a caller-owned stream from now on (the World puts broadphase, step kernels and solver on one stream so that
@@ -228,6 +231,7 @@ private:
     // exchange of an island-sharded solve (exchange.h)
     int ensure_exchange_layout();
     std::vector<int> grp_body_count_;              // per LDS group: entries of its body table (both builders fill it)
+    Comm* comm_ = nullptr;
     unsigned* xch_send_ = nullptr;                 // caller-owned: one segment
     unsigned* xch_recv_ = nullptr;                 // caller-owned: shard_count segments, rank-major
     long long xch_cap_words_ = 0, xch_seg_words_ = 0, xch_layout_version_ = -1;

@@ -1444,7 +1444,8 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
         PHX_TRY(solve_resident(b, nb, d_cps, ncp, j, nj, cfg));
         if (xch_send_) {       // island-sharded solve: pack, the caller's all-gather (hook phase 2), unpack — all on the stream
             PHX_TRY(exchange_pack_resident(&b, j, nullptr));
-            if (hook && hook(user, step_hook_step_, 2)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
+            if (comm_) PHX_TRY(exchange_all_gather());      // native transport: RCCL on this stream, no callback
+            else if (hook && hook(user, step_hook_step_, 2)) { set_error("bench: step hook failed"); return PHX_ERR_STATE; }
             PHX_TRY(exchange_unpack_resident(b, j));
         }
         return PHX_OK;

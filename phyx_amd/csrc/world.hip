@@ -35,6 +35,9 @@ public:
     int finish_step(float dt, const phx_config& cfg);
     int step_begin(float dt, const phx_config& cfg, size_t* segment_bytes);
     int step_end(float dt);
+    int set_comm(Comm* c);
+    int step_sharded(float dt, const phx_config& cfg);
+    int check_exchange();
     hipStream_t stream() const { return stream_; }
     int download_bodies(phx_rigid_body* out, int cap);
     int download_manifolds(phx_manifold* out, int cap);
@@ -93,6 +96,12 @@ private:
     bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
     DevBuf<int> mover_pos_;
     DevBuf<uint2> erased_;
+    // native transport (comm.hip): the world owns — and grows — the exchange buffers
+    Comm* comm_ = nullptr;
+    DevBuf<unsigned> xch_send_, xch_recv_;
+    size_t xch_capacity_ = 0;
+    unsigned sharded_steps_ = 0;
+    int ensure_exchange_capacity(size_t bytes);
 };
 
 World::~World()
@@ -101,6 +110,7 @@ World::~World()
     if (stream_) (void)hipStreamSynchronize(stream_);
     d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
     vel_.release(); dvel_.release(); mpos_.release(); frame_.release(); aabb_.release(); size_.release();
+    xch_send_.release(); xch_recv_.release();
     flags_.release(); pack_flags_.release(); dead_flags_.release(); joint_seen_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
     // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
@@ -391,6 +401,72 @@ int World::step_end(float dt)
     return PHX_OK;
 }
 
+// ---- the sharded step with the native transport (comm.hip) -------------------------------------------------------------
+int World::ensure_exchange_capacity(size_t bytes)
+{
+    if (bytes <= xch_capacity_ && xch_send_.p) return PHX_OK;
+    PHX_TRY(solver_.synchronize());
+    PHX_HIP(hipStreamSynchronize(stream_));
+    const size_t cap = (std::max<size_t>(2 * bytes, 1u << 20) + 255) / 256 * 256;
+    PHX_TRY(xch_send_.reserve(cap / 4));
+    PHX_TRY(xch_recv_.reserve(cap / 4 * (size_t)std::max(shard_count, 1)));
+    xch_capacity_ = cap;
+    return solver_.set_exchange_buffers(xch_send_.p, xch_recv_.p, cap);
+}
+
+int World::set_comm(Comm* c)
+{
+    PHX_TRY(use_device(device_));
+    comm_ = c;
+    if (!c) return PHX_OK;
+    shard = c->rank(); shard_count = c->size();
+    PHX_TRY(solver_.set_shard(shard, shard_count));
+    xch_capacity_ = 0;                                                      // (the recv buffer is sized by the rank count)
+    return ensure_exchange_capacity(1u << 20);
+}
+
+int World::step_sharded(float dt, const phx_config& cfg)
+{
+    if (!comm_) { set_error("phx_world_step_sharded needs a communicator (phx_world_set_comm)"); return PHX_ERR_STATE; }
+    size_t seg = 0;
+    int st = step_begin(dt, cfg, &seg);
+    if (st == PHX_ERR_CAPACITY) {
+        // the layout is a pure function of the schedule: every rank finds the same segment size too big and grows the same way;
+        // the solve is done, only the pack is repeated
+        PHX_TRY(ensure_exchange_capacity(solver_.exchange_segment_bytes()));
+        const BodyView bodies = resident().s;
+        st = solver_.exchange_pack_resident(&bodies, d_joints_.p, &seg);
+    }
+    if (st != PHX_OK) {
+        // This rank failed before it could pack.  Its peers are about to enter the collective: enter it too, with a header-only
+        // segment that carries a non-zero status word, so that they are not left hanging in it and find out at their next check.
+        // (The size is the last one all ranks agreed on — right whenever the schedule did not change in this step.)
+        const std::string why = last_error();
+        seg = std::min<size_t>(std::max<size_t>(solver_.exchange_segment_bytes(), 256), xch_capacity_);
+        if (solver_.exchange_pack_resident(nullptr, nullptr, nullptr, 1) == PHX_OK) (void)comm_->all_gather(xch_send_.p, xch_recv_.p, seg, stream_);
+        set_error("%s", why.c_str());
+        return st;
+    }
+    { RoctxRange r("Exchange: all-gather (RCCL)"); PHX_TRY(comm_->all_gather(xch_send_.p, xch_recv_.p, seg, stream_)); }
+    PHX_TRY(step_end(dt));
+    if ((++sharded_steps_ & 15u) == 0) PHX_TRY(check_exchange());
+    return PHX_OK;
+}
+
+// the peers' headers of every exchange so far (exchange.h) and the communicator's asynchronous error state
+int World::check_exchange()
+{
+    int bits = 0;
+    PHX_TRY(solver_.exchange_status(&bits));
+    if (bits) { set_error("island-sharded exchange inconsistent: PHX_XCH bits %d (1 peer error, 2 step serial, 4 topology, 8 segment never written)", bits); return PHX_ERR_STATE; }
+    if (comm_) {
+        int e = 0;
+        PHX_TRY(comm_->async_error(&e));
+        if (e) { set_error("RCCL asynchronous error %d", e); return PHX_ERR_STATE; }
+    }
+    return PHX_OK;
+}
+
 int World::finish_step(float dt, const phx_config& cfg)
 {
     using clk = std::chrono::steady_clock;
@@ -541,6 +617,24 @@ int phx_world_step_end(phx_world* w, float dt)
 }
 
 void* phx_world_stream(phx_world* w) { return w ? (void*)w->impl.stream() : nullptr; }
+
+int phx_world_set_comm(phx_world* w, phx_comm* c)
+{
+    PHX_REQUIRE(w, "null handle");
+    return w->impl.set_comm(c ? &c->impl : nullptr);
+}
+
+int phx_world_step_sharded(phx_world* w, float dt, const phx_config* cfg)
+{
+    PHX_REQUIRE(w && cfg, "null handle / config");
+    return w->impl.step_sharded(dt, *cfg);
+}
+
+int phx_world_check_exchange(phx_world* w)
+{
+    PHX_REQUIRE(w, "null handle");
+    return w->impl.check_exchange();
+}
 
 int phx_world_counts(phx_world* w, int32_t* nb, int32_t* nm, int32_t* ncp, int32_t* nj)
 {

@@ -1,10 +1,13 @@
 """One process per GPU: rendezvous, the per-step exchange and max-over-ranks reduction for bench.py.
 
-torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU
-tests and for several ranks sharing one GPU).  The hot path shards by island: every rank steps a replica of the
-world and solves its own groups; ONE all-gather per step carries each rank's results (and its status word) to
-every other rank — it is also the per-step barrier (BASELINE.json north_star).  The layout and the pack / unpack
-kernels live in the C library (csrc/exchange.h); this file only moves the segments.
+The hot path shards by island: every rank steps a replica of the world and solves its own groups; ONE all-gather per
+step carries each rank's results (and its status word) to every other rank — it is also the per-step barrier
+(BASELINE.json north_star).  The layout, the pack / unpack kernels AND the transport live in the C library
+(csrc/exchange.h, csrc/comm.hip): with backend "rccl" (the default on a GPU node) the all-gather is ncclAllGather called
+by the library on the solver's stream — no Python in a step — and torch.distributed (gloo, CPU) only does the rendezvous
+(hands rank 0's communicator id to every rank) and the max-over-ranks reductions of the timing.  Two more transports are
+kept: "nccl" = torch.distributed's ProcessGroupNCCL driven from a per-step Python hook (round 2's path), and "gloo" =
+segments staged through the host (CPU tests, several ranks sharing one GPU).
 """
 import os
 
@@ -41,6 +44,7 @@ class Exchange:
         self.stream_ptr = solver.stream_ptr()
         self.backend = getattr(group, "backend", "single")
         self.L = api._lib.load()
+        self.comm = getattr(group, "comm", None) if self.backend == "rccl" else None
         if self.backend == "nccl":
             torch = group.torch
             self.send = torch.zeros(self.capacity, dtype=torch.uint8, device=group.device)
@@ -54,6 +58,8 @@ class Exchange:
             send_ptr, recv_ptr = self.send.ptr.value, self.recv.ptr.value
         self.send_ptr, self.recv_ptr = send_ptr, recv_ptr
         solver.set_exchange_buffers(send_ptr, recv_ptr, self.capacity)
+        if self.comm is not None:
+            solver.set_comm(self.comm)      # Solver.bench: pack -> ncclAllGather -> unpack inside the library, no step hook
 
     @staticmethod
     def capacity_for(body_count, joint_count):
@@ -66,6 +72,9 @@ class Exchange:
         seg = int(segment_bytes)
         if seg > self.capacity:
             raise ValueError("segment of %d bytes exceeds the exchange capacity %d" % (seg, self.capacity))
+        if self.comm is not None:
+            self.comm.all_gather(self.send_ptr, self.recv_ptr, seg, self.stream_ptr)
+            return
         if self.backend == "nccl":
             torch, dist = self.group.torch, self.group.dist
             with torch.cuda.stream(self.ext):
@@ -85,7 +94,11 @@ class Exchange:
         check(self.L.phx_memcpy_h2d_on(self.device, self.recv.address(0), allb.ctypes.data_as(C.c_void_p), seg * self.n, stream))
 
     def hook(self):
-        """Step hook for Solver.bench: phase 2 = results packed on the stream, run the all-gather now."""
+        """Step hook for Solver.bench: phase 2 = results packed on the stream, run the all-gather now.
+        (None with the native transport: the library runs the collective itself.)"""
+        if self.comm is not None:
+            return None
+
         def hook(step, phase):
             if phase == 2:
                 self.all_gather(self.solver.exchange_segment_bytes())
@@ -103,19 +116,24 @@ def step_sharded(world, dt, configuration, exchange):
     groups, all-gather everyone's results, scatter them, integrate.  A rank whose first half fails still enters the
     collective (so its peers are not left hanging in it) with a non-zero status word, then re-raises; the peers see
     PHX_XCH_PEER_ERROR at their next Exchange.check()."""
-    from ._lib import PhxError
+    from ._lib import PhxError, check
     try:
         seg = world.StepBegin(dt, configuration)
     except PhxError:
-        seg = exchange.solver.exchange_segment_bytes() or 256
+        # the size every rank agreed on last (right whenever the schedule did not change in this step), never beyond the buffers
+        seg = min(exchange.solver.exchange_segment_bytes() or 256, exchange.capacity)
         try:
-            exchange.solver.L.phx_solver_exchange_pack(exchange.solver.h, None, None, 1, None)
-        except Exception:
-            pass
-        exchange.all_gather(seg)
+            check(exchange.solver.L.phx_solver_exchange_pack(exchange.solver.h, None, None, 1, None))
+            exchange.all_gather(seg)
+        except Exception as e:                     # the step's own error is the one to report; say that the peers were not told
+            import sys
+            sys.stderr.write("phyx_amd.dist: could not post the failure to the peers: %s\n" % e)
         raise
     exchange.all_gather(seg)
     world.StepEnd(dt)
+    exchange.steps = getattr(exchange, "steps", 0) + 1
+    if exchange.steps % 16 == 0:                   # a diverged or failed peer must not go unnoticed for long
+        exchange.check()
 
 
 class Single:
@@ -155,6 +173,7 @@ class Group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         self.backend = backend
+        self.comm = None
         if backend == "nccl":
             torch.cuda.set_device(self.local_rank)
             self.device = torch.device("cuda", self.local_rank)
@@ -162,11 +181,18 @@ class Group:
             self.device = torch.device("cpu")
         # (device_id binds the communicator to this rank's GPU up front: no 'guessing device ID' and no lazy init in the first collective)
         kw = {"device_id": self.device} if backend == "nccl" else {}
+        pg_backend = "gloo" if backend == "rccl" else backend       # native transport: torch only does the rendezvous, on the CPU
         try:
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kw)
+            dist.init_process_group(backend=pg_backend, rank=self.rank, world_size=self.world_size, **kw)
         except TypeError:                                   # a torch without the device_id argument
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+            dist.init_process_group(backend=pg_backend, rank=self.rank, world_size=self.world_size)
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if backend == "rccl":
+            # the library's own RCCL communicator (csrc/comm.hip): rank 0's id reaches everybody through the gloo group
+            from . import api
+            box = [api.Comm.unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.comm = api.Comm(box[0], self.rank, self.world_size, self.local_rank)
 
     def _sync(self):
         if self.backend == "nccl":
@@ -189,6 +215,8 @@ class Group:
         queued, its sweeps are not) makes the stream wait for it — so the exchange overlaps the preparation, the sweeps
         of step s+1 start only after step s of every rank, and the host never blocks.
         (gloo has no streams: there phase 0 is the blocking all-reduce.)"""
+        if self.backend == "rccl":                 # queued on the solver's stream by the library: the next step's kernels wait behind it
+            return lambda step, phase: self.comm.barrier_async(stream_ptr) if phase == 0 else None
         if self.backend != "nccl":
             return lambda step, phase: self.step_barrier() if phase == 0 else None
         ext = self.torch.cuda.ExternalStream(stream_ptr, device=self.device)
@@ -215,7 +243,7 @@ class Group:
         return np.concatenate([p.numpy() for p in parts])
 
     def exchange(self, solver, capacity_bytes, device=None):
-        return Exchange(self, solver, capacity_bytes, self.local_rank if device is None and self.backend == "nccl" else (device or 0))
+        return Exchange(self, solver, capacity_bytes, self.local_rank if device is None and self.backend in ("nccl", "rccl") else (device or 0))
 
     def _reduce(self, x, op):
         t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
@@ -230,19 +258,41 @@ class Group:
         return self._reduce(x, self.dist.ReduceOp.SUM)
 
     def shutdown(self):
+        self.comm = None
         try:
             self.dist.destroy_process_group()
         except Exception:
             pass
 
 
-def init(n_gpus, backend="nccl", force=False):
+def self_launch(n, argv=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): spawn the N ranks ourselves — one process per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the same command line — and wait for them.  Rank 0
+    prints the one JSON line (the children inherit stdout / stderr).  Returns the exit status to leave with."""
+    import socket
+    import subprocess
+    import sys
+    argv = list(sys.argv if argv is None else argv)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def init(n_gpus, backend="rccl", force=False):
     """Returns the process group wrapper; a plain single-process object when WORLD_SIZE is 1/unset."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws == 1 and not force:
         if n_gpus != 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (n_gpus, n_gpus, n_gpus))
+            raise SystemExit("--gpus %d needs one process per GPU (bench.py launches them itself when WORLD_SIZE is unset)" % n_gpus)
         return Single()
     if ws != n_gpus and not force:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (ws, n_gpus))

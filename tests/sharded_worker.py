@@ -30,6 +30,20 @@ def main():
         assert mine.bodies.tobytes() == full.bodies.tobytes(), "rank %d: bodies differ at step %d" % (g.rank, step)
         assert mine.contactJoints.tobytes() == full.contactJoints.tobytes(), "rank %d: joints differ at step %d" % (g.rank, step)
     xch.check()
+    if backend == "rccl":
+        # the native step: one library call per step (phx_world_step_sharded: step_begin, ncclAllGather, step_end), world-owned buffers
+        native = phyx_amd.World(0, gravity=-200.0)
+        native.add_scene(scene)
+        native.set_comm(g.comm)
+        twin = phyx_amd.World(0, gravity=-200.0)
+        twin.add_scene(scene)
+        for step in range(20):
+            twin.Update(1.0 / 60.0, cfg)
+            native.StepSharded(1.0 / 60.0, cfg)
+            if step % 5 == 4:
+                assert native.bodies.tobytes() == twin.bodies.tobytes(), "native sharded step: bodies differ at step %d" % step
+        native.check_exchange()
+        assert g.comm.async_error() == 0
     # bench.py's path: K solves queued back to back, the all-gather of every step enqueued from the step hook
     state = [phyx_amd.DeviceArray(a, 0) for a in (full.bodies, full.contactPoints, full.contactJoints)]
     mine.solver.bench_stage(state[0], state[2], 5)

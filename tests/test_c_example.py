@@ -7,11 +7,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path, built_lib):
-    exe = str(tmp_path / "drop_in")
+def _build(tmp_path, built_lib, name="drop_in"):
+    exe = str(tmp_path / name)
     lib_dir = os.path.join(ROOT, "phyx_amd")
-    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "drop_in.c"), "-L" + lib_dir, "-lphyx_amd", "-Wl,-rpath," + lib_dir, "-o", exe])
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", name + ".c"), "-L" + lib_dir, "-lphyx_amd", "-Wl,-rpath," + lib_dir, "-o", exe])
     return exe
 
 
@@ -35,3 +35,45 @@ def test_c_example_runs_and_drop_in_call_matches_the_world_step(tmp_path, built_
     assert r.returncode == 0, r.stdout + r.stderr
     assert "drop-in call vs world step: identical" in r.stdout
     assert "961 bodies" in r.stdout
+
+
+def test_sharded_example_compiles_and_fails_loudly_without_a_gpu(tmp_path, built_lib):
+    import phyx_amd
+    exe = _build(tmp_path, built_lib, "sharded")
+    try:
+        have_gpu = phyx_amd.device_count() > 0
+    except phyx_amd.PhxError:
+        have_gpu = False
+    if have_gpu:
+        pytest.skip("a GPU is present: covered by the gpu test")
+    r = subprocess.run([exe, "2", "5", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode in (1, 3) and r.stderr            # no device (or no RCCL device): an error, never a silent fallback
+
+
+@pytest.mark.gpu
+def test_sharded_example_runs_the_native_rccl_step(tmp_path, built_lib):
+    """examples/sharded.c with one rank: phx_comm_create (ncclCommInitRank), phx_world_step_sharded (ncclAllGather on the
+    world's stream between the two halves of the step) and the bit-for-bit comparison with the unsharded world, all from plain C."""
+    exe = _build(tmp_path, built_lib, "sharded")
+    r = subprocess.run([exe, "16", "30", "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical after every step" in r.stdout and "RCCL async error 0" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_example_two_ranks_on_one_gpu(tmp_path, built_lib):
+    """Two processes, both on GPU 0, meeting in RCCL (functional only: a real run has one GPU per rank)."""
+    exe = _build(tmp_path, built_lib, "sharded")
+    idf = str(tmp_path / "comm_id")
+    env = dict(os.environ, PHX_NRANKS="2", PHX_ID_FILE=idf, PHX_DEVICE="0")
+    procs = [subprocess.Popen([exe, "12", "20", "8"], env=dict(env, PHX_RANK=str(k)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
+    try:
+        outs = [p.communicate(timeout=600) for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.skip("RCCL does not run two ranks on one device here (timed out)")
+    if any(p.returncode != 0 for p in procs) and any("RCCL error" in o[1] or "ncclCommInitRank" in o[1] for o in outs):
+        pytest.skip("RCCL refuses two ranks on one device: " + outs[0][1][-300:] + outs[1][1][-300:])
+    assert all(p.returncode == 0 for p in procs), str(outs)
+    assert "identical after every step" in outs[0][0]

@@ -79,3 +79,26 @@ def test_single_process_group_is_torch_free():
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     subprocess.check_call([sys.executable, "-c", code], env=env)
+
+
+@pytest.mark.timeout(120)
+def test_self_launch_spawns_one_process_per_rank(tmp_path):
+    """`bench.py --gpus N` started without a launcher spawns its own ranks (phyx_amd.dist.self_launch): every child gets RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* and the same command line; the exit status is the worst child's."""
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys\n"
+                      "open(os.path.join(sys.argv[1], 'rank%s' % os.environ['RANK']), 'w').write(' '.join(os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+                      "sys.exit(3 if os.environ['RANK'] == '1' and len(sys.argv) > 2 else 0)\n")
+    from phyx_amd.dist import self_launch
+    env = dict(os.environ)
+    os.environ.pop("WORLD_SIZE", None)
+    try:
+        assert self_launch(3, [str(script), str(tmp_path)]) == 0
+        got = sorted(p.name for p in tmp_path.glob("rank*"))
+        assert got == ["rank0", "rank1", "rank2"]
+        fields = [(tmp_path / n).read_text().split() for n in got]
+        assert [f[0] for f in fields] == ["0", "1", "2"] and all(f[2] == "3" and f[3] == "127.0.0.1" for f in fields)
+        assert len({f[4] for f in fields}) == 1
+        assert self_launch(2, [str(script), str(tmp_path), "fail"]) == 3
+    finally:
+        os.environ.clear(); os.environ.update(env)

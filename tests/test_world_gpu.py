@@ -241,6 +241,39 @@ def test_exchange_through_rccl_one_rank(built_lib):
     assert p.returncode == 0 and "sharded worker ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+def test_exchange_through_the_native_rccl_transport_one_rank(built_lib):
+    """Backend "rccl": the library's own communicator (csrc/comm.hip: ncclCommInitRank / ncclAllGather resolved at run time),
+    torch.distributed only hands rank 0's id around.  The Exchange path, bench() without a step hook, and the one-call native
+    step phx_world_step_sharded with world-owned buffers, each against an unsharded World."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PHX_TEST_BACKEND="rccl")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "sharded_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0 and "sharded worker ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_bench_launches_its_own_ranks(built_lib):
+    """`python bench.py --gpus 2` without torchrun: bench.py spawns the two ranks itself (here both on GPU 0 over gloo) and rank 0
+    prints the one JSON line of the cfg-3 workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--columns", "48", "--rows", "30", "--steps", "3",
+                        "--warmup", "1", "--repeats", "1", "--no-secondary", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["extra"]["exchange"]["status"] == 0
+
+
 def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
     """phx_world_update returns once the step is queued on the world's stream; every getter waits for it.  Two worlds, one
     read after every step, one only at the end (with an explicit synchronize), must agree bit for bit; the per-phase timers
