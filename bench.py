@@ -113,7 +113,7 @@ def main():
     xch = None
     if world > 1:
         solver.set_shard(rank, world)
-        xch = group.exchange(solver, pdist.Exchange.capacity_for(nb, nj) // 512 * 256)
+        xch = group.exchange(solver, pdist.Exchange.capacity_for(nb, nj))
     hook = xch.hook() if xch else None
 
     def run(config, warmup, steps, repeats, slv=solver, hk=hook):
@@ -334,7 +334,7 @@ def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joi
     cfg3 = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, args.iters, args.iters)
     res = {}
     slv = phyx_amd.Solver(solver.device)
-    xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj) // 512 * 256, solver.device)
+    xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj), solver.device)
     for n in (1, 2, 4, 8):
         slv.set_shard(0, n)
         tot = run(cfg3, 2, 10, 3, slv=slv, hk=xch.hook())
@@ -359,7 +359,7 @@ def four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, d
     nb, nj = arrs[0].count, arrs[2].count
     del w
     slv = phyx_amd.Solver(device)
-    xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj) // 512 * 256, device)
+    xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj), device)
     res = {"bodies": nb, "joints": nj}
     for n in (1, 2, 4, 8):
         slv.set_shard(0, n)

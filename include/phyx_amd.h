@@ -364,6 +364,10 @@ phx_broadphase* phx_world_broadphase(phx_world* w);
  * 0 IntegrateVelocity 1 UpdateBroadphase 2 UpdatePairs 3 UpdateManifolds 4 PackManifolds
  * 5 RefreshContactJoints 6 SolveJoints 7 IntegratePosition */
 int  phx_world_get_phase_ms(phx_world* w, double out8[8]);
+/* diagnostics: [0] steps whose PackManifolds count was settled together with the joint counts (the bet that no manifold dies),
+ * [1] those of them that lost the bet (pack run late, joint match repeated), [2] solves repeated because the cached schedule was
+ * stale or a group was left uncommitted, [3] third contact points dropped (ref: Collider.cpp:241-242 would overflow) */
+int  phx_world_debug_counters(phx_world* w, int64_t out4[4]);
 /* per-phase host timers cost one stream synchronisation per phase; off by default (get_phase_ms then returns the last
  * values measured while it was on) */
 int  phx_world_set_phase_timing(phx_world* w, int32_t on);

@@ -583,6 +583,12 @@ class World:
         """Wait for the queued step (Update returns once the step is queued; getters synchronise on their own)."""
         check(self.L.phx_world_synchronize(self.h))
 
+    def debug_counters(self):
+        """{deferred_packs, deferred_pack_retries, solve_replays, dropped_points} (phx_world_debug_counters)."""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.L.phx_world_debug_counters(self.h, _ptr(out)))
+        return dict(zip(("deferred_packs", "deferred_pack_retries", "solve_replays", "dropped_points"), (int(x) for x in out)))
+
     def set_phase_timing(self, on=True):
         """Per-phase host timers (phase_ms) cost one stream synchronisation per phase; off by default."""
         check(self.L.phx_world_set_phase_timing(self.h, 1 if on else 0))

@@ -212,6 +212,9 @@ public:
     // `stamp` (device pointer, may be null): the post kernel also leaves the clock there (atomicMax) — see k_post_mail
     int wait(hipStream_t stream, unsigned long long* stamp = nullptr)
     {
+        // the batch is over however this function leaves: a failed wait must not keep destinations on a dead caller's stack
+        struct Reset { Readback& r; ~Reset() { r.count_ = 0; r.used_ = 0; r.odd_ = false; r.dma_ = false;
+                                               if (r.want_ > r.cap_ && r.pin_) { (void)hipHostFree(r.pin_); r.pin_ = nullptr; } } } reset{*this};      // (reallocated by the next add())
         const bool mail = count_ > 0 && !odd_ && !dma_ && used_ <= MAIL_WORDS * 4 && !no_mail();
         if (mail) {
             MailArgs a;
@@ -225,8 +228,6 @@ public:
             PHX_HIP(hipStreamSynchronize(stream));
         }
         for (int i = 0; i < count_; ++i) std::memcpy(items_[i].dst, pin_ + items_[i].off, items_[i].bytes);
-        count_ = 0; used_ = 0; odd_ = false; dma_ = false;
-        if (want_ > cap_) { (void)hipHostFree(pin_); pin_ = nullptr; }      // reallocated by the next add()
         return PHX_OK;
     }
 private:

@@ -51,6 +51,7 @@ public:
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool phase_timing = false;          // per-phase host timers: one stream synchronisation per phase, off by default
     int dropped_points = 0;
+    long long deferred_packs = 0, deferred_pack_retries = 0;      // PackManifolds counts settled with the joint counts / of those, the ones that found dead manifolds
     phx_broadphase broadphase_h;     // world-owned handles, also reachable through phx_world_broadphase()/phx_world_solver()
     phx_solver solver_h;
     DeviceBroadphase& broadphase() { return broadphase_; }
@@ -269,7 +270,7 @@ int World::refresh_contact_joints()                                         // r
     // One host round trip for the counts.  A joint is dead iff no contact point re-attached it (the match), which is
     // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
     unsigned host[4] = {0, 0, 0, 0};                                        // [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
-    for (int attempt = 0;; ++attempt) {
+    for (;;) {
         if (++joint_epoch_ == 0) {                                          // the epoch wrapped: stale stamps could alias
             PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
             joint_epoch_ = 1;
@@ -290,9 +291,10 @@ int World::refresh_contact_joints()                                         // r
         // PackManifolds' count came back with the joints': normally 0 (that was the bet) — if not, pack now and match again
         pack_pending_ = false;
         const int nm_before = nm;
+        ++deferred_packs;
         PHX_TRY(finish_pack((int)host[2], (int)host[3]));
         if (nm == nm_before) break;
-        if (attempt) { set_error("RefreshContactJoints: the manifold pack did not settle"); return PHX_ERR_STATE; }
+        ++deferred_pack_retries;                                            // the bet was lost: match again under a new epoch (one more pass: nothing is pending now)
     }
     const int fresh = (int)host[0], dead = (int)host[1], old = nj;
     const int total = nj + fresh;
@@ -661,6 +663,14 @@ int phx_world_synchronize(phx_world* w)
 {
     PHX_REQUIRE(w, "null handle");
     return w->impl.synchronize();
+}
+
+int phx_world_debug_counters(phx_world* w, int64_t out4[4])
+{
+    PHX_REQUIRE(w && out4, "null handle / buffer");
+    out4[0] = w->impl.deferred_packs; out4[1] = w->impl.deferred_pack_retries;
+    out4[2] = (int64_t)w->impl.solver().replays(); out4[3] = (int64_t)w->impl.dropped_points;
+    return PHX_OK;
 }
 
 int phx_world_set_phase_timing(phx_world* w, int32_t on)

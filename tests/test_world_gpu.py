@@ -49,6 +49,18 @@ def test_world_lockstep_bit_exact(oracle, built_lib, name, steps, island_mode):
     assert len(ow.joints()) > 0
 
 
+def test_late_manifold_pack_is_repeated_bit_exactly(oracle, built_lib):
+    """PackManifolds' dead-manifold count is not waited for when the previous step found none: the joint match is queued on the bet
+    that nothing dies and both counts come back in one round trip; if a manifold did die the pack runs then and the match is
+    repeated under a new epoch (csrc/world.hip refresh_contact_joints).  A falling pile loses that bet now and then: the steps in
+    which it does must still equal the oracle's, byte for byte."""
+    scene = scenes.falling(400, width=70.0, ymax=260.0)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE_SLOPPY, 10, 10)
+    pw, ow = _lockstep(oracle, scene, 70, cfg)
+    c = pw.debug_counters()
+    assert c["deferred_packs"] > 0 and c["deferred_pack_retries"] > 0, c
+
+
 @pytest.mark.parametrize("scene", [0, 2, 3, 4, 5, 6, 7])
 def test_reference_demo_scenes_lockstep(oracle, built_lib, scene):
     """Headless, scaled-down versions of the reference's demo scenes (ref: main.cpp:97-227, minus the 'Wall' that overflows the
