@@ -143,8 +143,8 @@ int phx_view_to_bodies(int device, const phx_body_view* in, int32_t body_count, 
 int phx_solver_set_body_state_bits(phx_solver* s, int32_t bits);
 
 /* Island sharding across ranks: the schedule's groups (phx_solver_get_groups) are body-disjoint, so rank `shard` of
- * `shard_count` sweeps only groups g with g % shard_count == shard (the trailing HBM group counts as group
- * lds_count) and leaves every other body and joint untouched.  All ranks must be given the same joints; the union of
+ * `shard_count` sweeps only the groups it owns (phx_exchange_layout's deal: longest processing time first by joint count;
+ * the trailing HBM group counts as group lds_count) and leaves every other body and joint untouched.  All ranks must be given the same joints; the union of
  * their results is the unsharded result, bit for bit.  Default 0 / 1 = everything. */
 int phx_solver_set_shard(phx_solver* s, int32_t shard, int32_t shard_count);
 
@@ -185,11 +185,13 @@ int    phx_solver_exchange_pack(phx_solver* s, const void* d_bodies, const void*
 int    phx_solver_exchange_unpack(phx_solver* s, void* d_bodies, void* d_joints);
 int    phx_solver_exchange_status(phx_solver* s, int32_t* status);
 size_t phx_solver_exchange_segment_bytes(phx_solver* s);      /* of the last pack */
-/* Host-only: the segment layout.  group g (body table of group_bodies[g] entries, group_slots[g] joints) belongs to rank
- * g % shard_count; group_offset_words[g] = 32-bit word offset of its block inside its owner's segment, rank_words[r] = words
- * rank r actually fills (both optional), *segment_words = the common padded segment length. */
+/* Host-only: who solves what, and the segment layout.  The groups (body table of group_bodies[g] entries, group_slots[g] joints)
+ * are dealt to the ranks longest-processing-time first: by decreasing joint count (ties: group number), each to the rank with
+ * the fewest joints so far (ties: lowest rank) — round-robin on uniform columns, balanced on anything else; group_owner[g] = that
+ * rank.  group_offset_words[g] = 32-bit word offset of the group's block inside its owner's segment (a rank's groups in ascending
+ * group order), rank_words[r] = words rank r actually fills (all three optional), *segment_words = the common padded length. */
 int    phx_exchange_layout(const int32_t* group_bodies, const int32_t* group_slots, int32_t group_count, int32_t shard_count,
-                           int64_t* group_offset_words, int64_t* rank_words, int64_t* segment_words);
+                           int32_t* group_owner, int64_t* group_offset_words, int64_t* rank_words, int64_t* segment_words);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Native transport of the island-sharded solve: an RCCL communicator, one process per GPU (xGMI between them).  The        */

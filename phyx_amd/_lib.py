@@ -64,7 +64,7 @@ _SIGNATURES = {
     "phx_memcpy_h2d_on": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "phx_memcpy_d2d_on": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "phx_debug_wait_clock": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
-    "phx_exchange_layout": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(C.c_int64)]),
+    "phx_exchange_layout": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "phx_solver_set_exchange_buffers": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "phx_solver_exchange_pack": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(C.c_size_t)]),
     "phx_solver_exchange_unpack": (C.c_int, [_vp, _vp, _vp]),

@@ -68,16 +68,18 @@ XCH_HEADER_BYTES = 32
 
 
 def exchange_layout(group_bodies, group_slots, shard_count):
-    """Host-only: segment layout of the island-sharded exchange (include/phyx_amd.h: phx_exchange_layout) ->
-    (group_offset_words, rank_words, segment_words)."""
+    """Host-only: the deal of the groups to the ranks (longest processing time first by joint count) and the segment layout
+    of the island-sharded exchange (include/phyx_amd.h: phx_exchange_layout) -> (group_offset_words, rank_words, segment_words,
+    group_owner)."""
     L = _lib.load()
     gb = np.ascontiguousarray(group_bodies, dtype=np.int32)
     gs = np.ascontiguousarray(group_slots, dtype=np.int32)
     off = np.zeros(max(len(gb), 1), dtype=np.int64)
-    rw = np.zeros(shard_count, dtype=np.int64)
+    own = np.zeros(max(len(gb), 1), dtype=np.int32)
+    rw = np.zeros(max(shard_count, 1), dtype=np.int64)
     seg = C.c_int64(0)
-    check(L.phx_exchange_layout(_ptr(gb), _ptr(gs), len(gb), shard_count, _ptr(off), _ptr(rw), C.byref(seg)))
-    return off[:len(gb)], rw, seg.value
+    check(L.phx_exchange_layout(_ptr(gb), _ptr(gs), len(gb), shard_count, _ptr(own), _ptr(off), _ptr(rw), C.byref(seg)))
+    return off[:len(gb)], rw, seg.value, own[:len(gb)]
 
 
 def schedule_priority(priority_id, joint_index):

@@ -1,7 +1,8 @@
 // exchange.h — post-solve exchange of an island-sharded solve (BASELINE config 3).
 //
 // Every rank holds a replica of the world, builds the same schedule from the same joints and sweeps only the
-// groups g with g % shard_count == shard (DeviceSolver::set_shard).  The reference merges every island's bodies back
+// groups it OWNS (DeviceSolver::set_shard): the groups are dealt to the ranks longest-processing-time first by their joint
+// count (exchange_partition below) — a pure function of the schedule, so every rank computes the same deal.  The reference merges every island's bodies back
 // into the one body array after its parallel island loop (ref: Solver.cpp:86-91 parallelFor over islands, then
 // FinishBodies :114, 482-494 and FinishJoints :527-547); across GPUs the counterpart is ONE all-gather per step:
 // each rank packs what its groups produced — per body the six solved floats {velocity.xy, angularVelocity,
@@ -34,14 +35,32 @@ constexpr int XCH_ERR_MAGIC = 8;         // the segment was never written (colle
 
 inline long long xch_group_words(int bodies, int slots) { return (6ll * bodies + 2ll * slots + 3) & ~3ll; }
 
+// Which rank solves which group: longest processing time first — the groups taken by decreasing joint (slot) count, ties by
+// group number, each given to the rank with the least joints so far (ties: the lowest rank).  A group is one latency-bound
+// workgroup (or, the trailing HBM group, a sequence of launches) whose time grows with its joints; on uniform columns this
+// deals them round-robin.  Pure host function of (slot counts, shard count): every rank computes the same owners.
+inline void exchange_partition(const int* group_slots, int ngroups, int shard_count, int* owner)
+{
+    std::vector<int> by_size((size_t)ngroups);
+    for (int g = 0; g < ngroups; ++g) by_size[g] = g;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) { return group_slots[a] > group_slots[b]; });
+    std::vector<long long> load((size_t)shard_count, 0ll);
+    for (int g : by_size) {
+        int best = 0;
+        for (int r = 1; r < shard_count; ++r) if (load[r] < load[best]) best = r;
+        owner[g] = best;
+        load[best] += group_slots[g];
+    }
+}
+
 // Pure host function (unit-tested on CPU through phx_exchange_layout): word offset of every group inside its owner's
-// segment (header included) and the common padded segment length.
-inline long long exchange_layout(const int* group_bodies, const int* group_slots, int ngroups, int shard_count, long long* group_offset_words,
+// segment (header included; a rank's groups in ascending group order) and the common padded segment length.
+inline long long exchange_layout(const int* group_bodies, const int* group_slots, int ngroups, int shard_count, const int* owner, long long* group_offset_words,
                                  long long* rank_words /* shard_count entries, may be null */)
 {
     std::vector<long long> used((size_t)shard_count, (long long)XCH_HEADER_WORDS);
     for (int g = 0; g < ngroups; ++g) {
-        const int r = g % shard_count;
+        const int r = owner[g];
         if (group_offset_words) group_offset_words[g] = used[r];
         used[r] += xch_group_words(group_bodies[g], group_slots[g]);
     }
@@ -55,22 +74,24 @@ struct ExchangeView {
     const int* group_bodies;   // body tables of the LDS groups
     const int* order;          // slot -> joint
     const long long* xoff;     // per group (HBM group = index lds_groups): word offset inside the owner's segment
+    const int* owner;          // per group (HBM group = index lds_groups): the rank that solves it (exchange_partition)
+    const int* mine;           // the LDS groups this rank owns, ascending
     int lds_groups, shard, shard_count;
     // the HBM group, if any
     const int* hbm_bodies; int hbm_body_count, hbm_begin, hbm_end;
     long long segment_words;   // common padded segment length = stride between ranks in the gathered buffer
 };
 
-// One workgroup per OWNED LDS group (group = shard + blockIdx.x * shard_count): solved fields -> send segment.
+// One workgroup per OWNED LDS group (group = mine[blockIdx.x]): solved fields -> send segment.
 __global__ void __launch_bounds__(256) k_exchange_pack(ExchangeView x, BodyView bodies, const phx_contact_joint* __restrict__ joints,
-                                                       unsigned* __restrict__ send, unsigned serial, unsigned status, unsigned long long fingerprint)
+                                                       unsigned* __restrict__ send, unsigned serial, unsigned status, unsigned long long fingerprint, int mine_count)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         send[0] = XCH_MAGIC; send[1] = serial; send[2] = status; send[3] = (unsigned)x.shard;
         send[4] = (unsigned)fingerprint; send[5] = (unsigned)(fingerprint >> 32); send[6] = (unsigned)x.segment_words; send[7] = 0u;
     }
-    const int g = x.shard + (int)blockIdx.x * x.shard_count;
-    if (g >= x.lds_groups) return;
+    if ((int)blockIdx.x >= mine_count) return;
+    const int g = x.mine[blockIdx.x];
     const int4 d = x.desc[g];
     float* out = reinterpret_cast<float*>(send + x.xoff[g]);
     for (int i = threadIdx.x; i < d.w; i += blockDim.x) {
@@ -132,10 +153,12 @@ __global__ void __launch_bounds__(256) k_exchange_unpack(ExchangeView x, BodyVie
         if (e) atomicOr(error, e);
     }
     const int g = (int)blockIdx.x;
-    if (g >= x.lds_groups || g % x.shard_count == x.shard) return;
-    if (xch_check_header(recv + (size_t)(g % x.shard_count) * x.segment_words, serial, fingerprint)) return;      // (workgroup-uniform)
+    if (g >= x.lds_groups) return;
+    const int owner = x.owner[g];
+    if (owner == x.shard) return;
+    if (xch_check_header(recv + (size_t)owner * x.segment_words, serial, fingerprint)) return;      // (workgroup-uniform)
     const int4 d = x.desc[g];
-    const float* in = reinterpret_cast<const float*>(recv + (size_t)(g % x.shard_count) * x.segment_words + x.xoff[g]);
+    const float* in = reinterpret_cast<const float*>(recv + (size_t)owner * x.segment_words + x.xoff[g]);
     for (int i = threadIdx.x; i < d.w; i += blockDim.x) {
         const int id = x.group_bodies[d.z + i];
         const float4 p = bodies.mpos[id];
@@ -154,8 +177,9 @@ __global__ void __launch_bounds__(256) k_exchange_unpack(ExchangeView x, BodyVie
 __global__ void __launch_bounds__(256) k_exchange_unpack_hbm(ExchangeView x, BodyView bodies, phx_contact_joint* __restrict__ joints,
                                                              const unsigned* __restrict__ recv, unsigned serial, unsigned long long fingerprint)
 {
-    if (xch_check_header(recv + (size_t)(x.lds_groups % x.shard_count) * x.segment_words, serial, fingerprint)) return;      // (see k_exchange_unpack)
-    const float* in = reinterpret_cast<const float*>(recv + (size_t)(x.lds_groups % x.shard_count) * x.segment_words + x.xoff[x.lds_groups]);
+    const int owner = x.owner[x.lds_groups];
+    if (xch_check_header(recv + (size_t)owner * x.segment_words, serial, fingerprint)) return;      // (see k_exchange_unpack)
+    const float* in = reinterpret_cast<const float*>(recv + (size_t)owner * x.segment_words + x.xoff[x.lds_groups]);
     const int n = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = t; i < x.hbm_body_count; i += n) {
         const int id = x.hbm_bodies[i];

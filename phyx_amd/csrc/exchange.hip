@@ -19,6 +19,42 @@ int DeviceSolver::set_exchange_buffers(void* d_send, void* d_recv, size_t segmen
     return PHX_OK;
 }
 
+// Which groups this rank solves (exchange_partition: longest processing time first by joint count).  A pure function of
+// (schedule, shard count): recomputed when either changed.  An unsharded solver owns everything and needs no tables.
+int DeviceSolver::ensure_partition()
+{
+    if (partition_version_ == schedule_version_ && partition_shards_ == shard_count_ && partition_shard_ == shard_) return PHX_OK;
+    const bool live = sched_.valid && nj_ > 0;
+    const int lg = live ? sched_.lds_groups : 0;
+    const bool hbm = live && sched_.has_hbm_group();
+    const int ng = lg + (hbm ? 1 : 0);
+    owner_host_.assign((size_t)lg + 1, 0);             // entry lds_groups = the HBM group (present or not)
+    mine_count_ = lg;
+    if (shard_count_ > 1) {
+        if ((int)sched_.group_offsets.size() < lg + 1) { set_error("island sharding: the schedule's group sizes are not on the host"); return PHX_ERR_STATE; }
+        std::vector<int> gs(std::max(ng, 1));
+        for (int g = 0; g < lg; ++g) gs[g] = sched_.group_offsets[g + 1] - sched_.group_offsets[g];
+        if (hbm) gs[lg] = sched_.hbm_end() - sched_.hbm_begin();
+        exchange_partition(gs.data(), ng, shard_count_, owner_host_.data());
+        std::vector<int> mine;
+        for (int g = 0; g < lg; ++g) if (owner_host_[g] == shard_) mine.push_back(g);
+        mine_count_ = (int)mine.size();
+        PHX_TRY(grp_owner_.reserve((size_t)lg + 1)); PHX_TRY(grp_mine_.reserve(std::max<size_t>(mine.size(), 1)));
+        PHX_HIP(hipMemcpyAsync(grp_owner_.p, owner_host_.data(), ((size_t)lg + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
+        if (!mine.empty()) PHX_HIP(hipMemcpyAsync(grp_mine_.p, mine.data(), mine.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));          // (the host vectors go out of scope)
+    } else if (xch_send_) {                              // (one rank with an exchange: the kernels still index the tables)
+        PHX_TRY(grp_owner_.reserve((size_t)lg + 1)); PHX_TRY(grp_mine_.reserve(std::max<size_t>((size_t)lg, 1)));
+        std::vector<int> all((size_t)std::max(lg, 1));
+        for (int g = 0; g < lg; ++g) all[g] = g;
+        PHX_HIP(hipMemcpyAsync(grp_owner_.p, owner_host_.data(), ((size_t)lg + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
+        if (lg) PHX_HIP(hipMemcpyAsync(grp_mine_.p, all.data(), (size_t)lg * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipStreamSynchronize(stream_));
+    }
+    partition_version_ = schedule_version_; partition_shards_ = shard_count_; partition_shard_ = shard_;
+    return PHX_OK;
+}
+
 // the layout is a pure function of (schedule, shard count): recomputed on the host when either changed, one small upload
 int DeviceSolver::ensure_exchange_layout()
 {
@@ -28,11 +64,12 @@ int DeviceSolver::ensure_exchange_layout()
     const bool hbm = live && sched_.has_hbm_group();
     const int ng = lg + (hbm ? 1 : 0);
     if ((int)grp_body_count_.size() < lg) { set_error("exchange: the schedule carries no body counts"); return PHX_ERR_STATE; }
+    PHX_TRY(ensure_partition());
     std::vector<int> gb(std::max(ng, 1)), gs(std::max(ng, 1));
     for (int g = 0; g < lg; ++g) { gb[g] = grp_body_count_[g]; gs[g] = sched_.group_offsets[g + 1] - sched_.group_offsets[g]; }
     if (hbm) { gb[lg] = sched_.hbm_body_count; gs[lg] = sched_.hbm_end() - sched_.hbm_begin(); }
     xch_off_host_.assign((size_t)lg + 1, 0ll);       // entry lds_groups = the HBM group (present or not)
-    xch_seg_words_ = exchange_layout(gb.data(), gs.data(), ng, shard_count_, xch_off_host_.data(), nullptr);
+    xch_seg_words_ = exchange_layout(gb.data(), gs.data(), ng, shard_count_, owner_host_.data(), xch_off_host_.data(), nullptr);
     PHX_TRY(xch_off_.reserve((size_t)lg + 1));
     PHX_HIP(hipMemcpyAsync(xch_off_.p, xch_off_host_.data(), ((size_t)lg + 1) * sizeof(long long), hipMemcpyHostToDevice, stream_));
     xch_layout_version_ = schedule_version_;
@@ -41,10 +78,10 @@ int DeviceSolver::ensure_exchange_layout()
 }
 
 static ExchangeView exchange_view(const Schedule& sc, bool valid, const int4* desc, const int* group_bodies, const int* order, const long long* xoff,
-                                  const int* hbm_bodies, int shard, int shard_count, long long seg_words)
+                                  const int* hbm_bodies, int shard, int shard_count, long long seg_words, const int* owner, const int* mine)
 {
     ExchangeView x{};
-    x.desc = desc; x.group_bodies = group_bodies; x.order = order; x.xoff = xoff;
+    x.desc = desc; x.group_bodies = group_bodies; x.order = order; x.xoff = xoff; x.owner = owner; x.mine = mine;
     x.lds_groups = valid ? sc.lds_groups : 0; x.shard = shard; x.shard_count = shard_count;
     x.hbm_bodies = hbm_bodies;
     const bool hbm = valid && sc.has_hbm_group();
@@ -88,13 +125,12 @@ int DeviceSolver::exchange_pack_resident(const BodyView* d_bodies, const void* d
     }
     // null arrays = header only: a rank that failed earlier in the step still posts its status word
     const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0 && d_bodies && d_joints, grp_desc_.p, grp_bodies_.p, order_.p, xch_off_.p, hbm_body_list_.p, shard_,
-                                         shard_count_, xch_seg_words_);
+                                         shard_count_, xch_seg_words_, grp_owner_.p, grp_mine_.p);
     ++xch_serial_;
-    const int lg = x.lds_groups;
-    const int mine = lg > shard_ ? (lg - shard_ + shard_count_ - 1) / shard_count_ : 0;
+    const int mine = x.lds_groups ? mine_count_ : 0;
     const BodyView bodies = d_bodies ? *d_bodies : BodyView{nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_exchange_pack, dim3(std::max(mine, 1)), dim3(256), 0, stream_, x, bodies,
-                       static_cast<const phx_contact_joint*>(d_joints), xch_send_, xch_serial_, (unsigned)status_word, raw_fingerprint_);
+                       static_cast<const phx_contact_joint*>(d_joints), xch_send_, xch_serial_, (unsigned)status_word, raw_fingerprint_, mine);
     if (x.hbm_end > x.hbm_begin && owns_hbm_group()) {
         const int n = std::max(x.hbm_body_count, x.hbm_end - x.hbm_begin);
         hipLaunchKernelGGL(k_exchange_pack_hbm, dim3(std::max(1, std::min(div_up(n, 256), 2048))), dim3(256), 0, stream_, x, bodies,
@@ -110,7 +146,8 @@ int DeviceSolver::exchange_unpack_resident(const BodyView& d_bodies, void* d_joi
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(xch_send_ && xch_recv_, "exchange buffers not set (phx_solver_set_exchange_buffers)");
     if (xch_layout_version_ != schedule_version_ || xch_layout_shards_ != shard_count_) { set_error("exchange_unpack without a matching exchange_pack"); return PHX_ERR_STATE; }
-    const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0, grp_desc_.p, grp_bodies_.p, order_.p, xch_off_.p, hbm_body_list_.p, shard_, shard_count_, xch_seg_words_);
+    const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0, grp_desc_.p, grp_bodies_.p, order_.p, xch_off_.p, hbm_body_list_.p, shard_, shard_count_, xch_seg_words_,
+                                         grp_owner_.p, grp_mine_.p);
     hipLaunchKernelGGL(k_exchange_unpack, dim3(std::max(x.lds_groups, 1)), dim3(256), 0, stream_, x, d_bodies,
                        static_cast<phx_contact_joint*>(d_joints), (const unsigned*)xch_recv_, xch_serial_, raw_fingerprint_, xch_err_.p);
     if (x.hbm_end > x.hbm_begin && !owns_hbm_group()) {
@@ -143,12 +180,15 @@ int DeviceSolver::exchange_status(int* out)
 extern "C" {
 
 int phx_exchange_layout(const int32_t* group_bodies, const int32_t* group_slots, int32_t group_count, int32_t shard_count,
-                        int64_t* group_offset_words, int64_t* rank_words, int64_t* segment_words)
+                        int32_t* group_owner, int64_t* group_offset_words, int64_t* rank_words, int64_t* segment_words)
 {
     PHX_REQUIRE(group_count >= 0 && shard_count >= 1 && (group_count == 0 || (group_bodies && group_slots)) && segment_words, "bad arguments");
     for (int g = 0; g < group_count; ++g) PHX_REQUIRE(group_bodies[g] >= 0 && group_slots[g] >= 0, "negative count");
     static_assert(sizeof(long long) == sizeof(int64_t), "layout words");
-    *segment_words = phx::exchange_layout(group_bodies, group_slots, group_count, shard_count, reinterpret_cast<long long*>(group_offset_words),
+    std::vector<int> owner((size_t)std::max(group_count, 1), 0);
+    phx::exchange_partition(group_slots, group_count, shard_count, owner.data());
+    if (group_owner) std::copy(owner.begin(), owner.begin() + group_count, group_owner);
+    *segment_words = phx::exchange_layout(group_bodies, group_slots, group_count, shard_count, owner.data(), reinterpret_cast<long long*>(group_offset_words),
                                           reinterpret_cast<long long*>(rank_words));
     return PHX_OK;
 }

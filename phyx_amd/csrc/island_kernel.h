@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     unsigned (*swd)[NB] = reinterpret_cast<unsigned (*)[NB]>(sw_raw + 2 * NB);
     float4* par = reinterpret_cast<float4*>(sw_raw);
 
-    const int group = iv.first + (int)blockIdx.x * iv.stride;
+    const int group = iv.group_list ? iv.group_list[blockIdx.x] : (int)blockIdx.x;
     if (iv.next_ctl && blockIdx.x == 0) {                 // first kernel of its solve: the NEXT solve's control set (two sets alternate)
         if (threadIdx.x < ISL_STAT_SLOTS) { iv.next_visits[threadIdx.x] = 0ull; iv.next_executed[2 * threadIdx.x] = 0; iv.next_executed[2 * threadIdx.x + 1] = 0; }
         if (threadIdx.x == 0) { *iv.next_ctl = 0ull; iv.next_visits[ISL_STAT_SLOTS] = ~0ull; iv.next_visits[ISL_STAT_SLOTS + 1] = 0ull; }

@@ -47,7 +47,7 @@ struct IslandView {
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement
     unsigned long long* visits;       // per slot: sum over groups of impulse sweeps * joints
     const int* ngroups_dev;           // null, or the group count where the launch grid is only an upper bound of it (speculative binning, solver.hip)
-    int first, stride;                // workgroup w solves group first + w * stride (island sharding across ranks; 0, 1 = all)
+    const int* group_list;            // null: workgroup w solves group w; else group_list[w] (island sharding across ranks: the groups this rank owns)
     int stamp_begin, stamp_end;       // this launch is the first / last kernel of the solve: it leaves the solve's time stamps (solver_kernels.h)
     unsigned long long* wave_trace;   // null, or 8 words per wave of every group: cycles {working with <= 32 lanes, at the barrier after work, idle steps}, counts, cycles working with > 32 lanes, count
     unsigned long long* trace;        // null, or 8 words per group: shader-clock stamps of the kernel's phases (phx_solver_set_trace)

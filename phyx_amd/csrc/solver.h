@@ -220,7 +220,14 @@ private:
     bool use_graphs_ = false, speculate_ = true, half_state_ = false, reuse_schedule_ = true;
     bool owns_stream_ = true, no_islands_ = false, trace_schedule_ = false;      // environment knobs, read once in init()
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
-    bool owns_hbm_group() const { return sched_.has_hbm_group() && sched_.lds_groups % shard_count_ == shard_; }
+    // (the deal of the groups to the ranks: exchange.h exchange_partition; shard_count_ == 1 owns everything)
+    bool owns_hbm_group() const { return sched_.has_hbm_group() && (shard_count_ == 1 || (partition_ok() && owner_host_[(size_t)sched_.lds_groups] == shard_)); }
+    bool partition_ok() const { return partition_version_ == schedule_version_ && partition_shards_ == shard_count_ && partition_shard_ == shard_ && owner_host_.size() > (size_t)sched_.lds_groups; }
+    int ensure_partition();
+    std::vector<int> owner_host_;                  // per group (entry lds_groups: the HBM group): the rank that solves it
+    DevBuf<int> grp_owner_, grp_mine_;             // the same on the device; the LDS groups this rank owns, ascending
+    int mine_count_ = 0, partition_shards_ = 0, partition_shard_ = -1;
+    long long partition_version_ = -1;
     // a solve enqueued on the cached schedule before its fingerprint was checked; verified in synchronize()
     struct Pending { bool active = false; int count = 0; Arrays arrays; const void* cps = nullptr; void* joints = nullptr; int nb = 0, ncp = 0, nj = 0; phx_config cfg{};
                      int mode = 0; unsigned nexpect = 0; } pending_;

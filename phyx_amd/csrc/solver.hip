@@ -44,7 +44,7 @@ DeviceSolver::~DeviceSolver()
     cc_flags_.release(); comp_size_.release(); comp_units_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release(); jp_kind_.release(); partner_.release(); partner_first_.release();
     jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
-    hbm_body_list_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_recs_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
+    hbm_body_list_.release(); grp_owner_.release(); grp_mine_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_recs_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_vel_.release(); snap_dvel_.release(); snap_mpos_.release(); snap_joints_.release(); stage_vel_.release(); stage_dvel_.release(); stage_mpos_.release(); stage_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -176,8 +176,7 @@ bool DeviceSolver::spec_build_applies(bool want_islands, int nj) const
 bool DeviceSolver::arm_cached_solve(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp, int* status)
 {
     *status = PHX_OK;
-    const int lg = sched_.lds_groups;
-    const int mine = lg > shard_ ? (lg - shard_ + shard_count_ - 1) / shard_count_ : 0;
+    const int mine = sched_.lds_groups;                  // (ISL_VERIFY is for unsharded solves: verify_eligible)
     if (nj > 0 && !sched_.has_hbm_group() && verify_eligible(mine, sched_.lds_lanes > ISL_T)) {
         begin_set(false);
         isl_mode_ = ISL_VERIFY;
@@ -820,10 +819,11 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
     sweep_launches_ = 0;
     if (!nj) return PHX_OK;
     const int lg = sched_.lds_groups;
-    const int mine = lg > shard_ ? (lg - shard_ + shard_count_ - 1) / shard_count_ : 0;      // groups shard_, shard_ + count, ...
+    if (shard_count_ > 1) PHX_TRY(ensure_partition());       // which groups this rank solves (exchange.h: longest processing time first)
+    const int mine = shard_count_ > 1 ? mine_count_ : lg;
     if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
-        iv.first = shard_; iv.stride = shard_count_;
+        iv.group_list = shard_count_ > 1 ? grp_mine_.p : nullptr;
         iv.ngroups_dev = spec_bins_pending_ ? bin_result_.p : nullptr;
         iv.stamp_begin = iv.stamp_end = owns_hbm_group() ? 0 : 1;      // (with an HBM group, its first and last kernels leave the stamps)
         iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_recs = unit_recs_.p; iv.bodies = grp_bodies_.p;
@@ -926,6 +926,7 @@ int DeviceSolver::enqueue(const Arrays& arrays, int nb, const phx_contact_point*
 {
     cur_ = arrays;
     const BodyView& d_bodies = arrays.view;
+    if (shard_count_ > 1) PHX_TRY(ensure_partition());       // which groups this rank solves (before anything asks owns_hbm_group())
     const int ci = cfg.contact_iterations, pi = cfg.penetration_iterations;
     const int iters = std::max(ci, pi);
     if (iters + 1 > max_iters_ || !flags_.p) {

@@ -193,18 +193,29 @@ def test_schedule_handles_hub_and_empty(built_lib):
 
 
 def test_exchange_layout_partitions_the_groups_over_the_ranks():
-    """Segment layout of the island-sharded exchange (csrc/exchange.h, host-only): group g belongs to rank g % n, blocks
-    never overlap, every rank's segment fits the common padded length, and one rank alone owns everything."""
+    """The deal of the groups to the ranks and the segment layout of the island-sharded exchange (csrc/exchange.h, host-only):
+    groups go longest-processing-time first by joint count (restated here), blocks never overlap, every rank's segment fits the
+    common padded length, the joint load is balanced to within one group, and uniform groups are dealt round-robin."""
     import phyx_amd
     rng = np.random.default_rng(5)
     for ngroups, n in ((0, 1), (1, 8), (5, 2), (999, 8), (1000, 3), (37, 37), (12, 64)):
         gb = rng.integers(1, 769, ngroups).astype(np.int32)
         gs = rng.integers(1, 513, ngroups).astype(np.int32)
-        off, rank_words, seg = phyx_amd.exchange_layout(gb, gs, n)
+        off, rank_words, seg, owner = phyx_amd.exchange_layout(gb, gs, n)
         assert seg % 64 == 0 and seg >= 8 and len(rank_words) == n
         assert int(rank_words.max()) <= seg < int(rank_words.max()) + 64
+        # longest processing time first, restated: decreasing joint count (ties: group number), to the least loaded rank (ties: lowest)
+        load = [0] * n
+        want = [0] * ngroups
+        for g in sorted(range(ngroups), key=lambda g: (-int(gs[g]), g)):
+            r = min(range(n), key=lambda r: (load[r], r))
+            want[g] = r
+            load[r] += int(gs[g])
+        assert owner.tolist() == want
+        if ngroups >= n:
+            assert max(load) - min(load) <= int(gs.max())
         for r in range(n):
-            mine = [g for g in range(ngroups) if g % n == r]
+            mine = [g for g in range(ngroups) if owner[g] == r]
             at = 8                                                  # header words
             for g in mine:
                 assert off[g] == at and off[g] % 4 == 0
@@ -212,6 +223,10 @@ def test_exchange_layout_partitions_the_groups_over_the_ranks():
             assert at == rank_words[r]
         # total payload is independent of the rank count
         assert int(rank_words.sum()) - 8 * n == int(sum((6 * int(b) + 2 * int(s) + 3) // 4 * 4 for b, s in zip(gb, gs)))
+    _, _, _, owner = phyx_amd.exchange_layout([7] * 10, [440] * 10, 4)          # uniform columns: round-robin
+    assert owner.tolist() == [g % 4 for g in range(10)]
+    _, _, _, owner = phyx_amd.exchange_layout([9] * 5, [100, 100, 100, 100, 800], 2)       # one big group (an HBM group): alone on its rank
+    assert owner.tolist() == [1, 1, 1, 1, 0]
     with pytest.raises(phyx_amd.PhxError):
         phyx_amd.exchange_layout([1], [1], 0)
 

@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 3 rocprofv3 evidence for profiles/: bench.py (cfg 2: kernel trace, main-only trace, PMC FETCH / WRITE in separate passes),
+# the world step (timeline + marker stats), and the same for the cfg 4 and cfg 5 workloads (tools/prof_cfg.py).
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 20 --warmup 3 --repeats 3 --no-cpu-baseline"
+timeout 900 python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o trace -- python $R/bench.py $ARGS > $O/bench_trace.json 2> $O/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o main -- python $R/bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_main.json 2> $O/main.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o pmc_fetch -- python $R/bench.py $ARGS > $O/bench_pmc_fetch.json 2> $O/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o pmc_write -- python $R/bench.py $ARGS > $O/bench_pmc_write.json 2> $O/pmc_write.err
+timeout 600 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $O -o world -- python $R/tools/steady.py 12 --no-phase-timing > $O/world_steady.txt 2> $O/world.err
+python $R/tools/timeline.py $O/world_kernel_trace.csv k_build_keys -v > $O/world_step_timeline.txt 2>&1
+for c in cfg4 cfg5; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${c}_trace -- python $R/tools/prof_cfg.py $c > $O/${c}_trace.txt 2> $O/${c}_trace.err
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o ${c}_pmc_fetch -- python $R/tools/prof_cfg.py $c > $O/${c}_fetch.txt 2> $O/${c}_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o ${c}_pmc_write -- python $R/tools/prof_cfg.py $c > $O/${c}_write.txt 2> $O/${c}_write.err
+done
+python $R/tools/timeline.py $O/cfg4_trace_kernel_trace.csv k_build_keys -v > $O/cfg4_step_timeline.txt 2>&1
+ls $O | head -80
+head -12 $O/main_kernel_stats.csv
+head -3 $O/world_step_timeline.txt
+head -14 $O/cfg4_trace_kernel_stats.csv
+head -6 $O/cfg5_trace_kernel_stats.csv
