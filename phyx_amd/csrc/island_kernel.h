@@ -291,9 +291,13 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     int done_imp = 0, done_disp = 0;
     bool imp_alive = ci > 0, disp_alive = pi > 0;
     const int iters = ci > pi ? ci : pi;
+    unsigned early_ctl = 0u;                               // (lane 0) the control word as read a few sweeps in: by then every workgroup has long arrived
     for (int it = 0; it < iters; ++it) {
         const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
         if (!imp_on && !disp_on) break;
+        // ISL_VERIFY: look at the control word NOW, off the critical path (the load returns while the sweeps run); the commit
+        // decision at the end then needs no memory round trip of its own unless some workgroup really is that late
+        if (verify && it == 3 && tid == 0 && iv.wait_polls > 0) early_ctl = (unsigned)__hip_atomic_load(iv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // three slots in rotation: the one cleared here for the next sweep was read last at the end of sweep it - 2, and every
         // class step of sweep it - 1 has put a barrier in between — so the sweep needs no barrier of its own at its end
         const int slot = it % 3;
@@ -380,15 +384,16 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         // it runs out (a GPU shared with somebody else's kernels) the group stays uncommitted and the host completes it (ISL_COMPLETE)
         if (tid == 0) {
             const unsigned shards = iv.nexpect < (unsigned)ISL_SHARDS ? iv.nexpect : (unsigned)ISL_SHARDS;
-            unsigned lo = 0;
+            unsigned lo = early_ctl;
             int polls = 0;
-            for (; polls < iv.wait_polls; ++polls) {
+            const bool settled = (lo & ISL_ARRIVE_MASK) >= shards || lo >= ISL_BAD;      // (complete, or spoiled: both final)
+            for (; !settled && polls < iv.wait_polls; ++polls) {
                 lo = (unsigned)__hip_atomic_load(iv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((lo & ISL_ARRIVE_MASK) >= shards || lo >= ISL_BAD) break;
                 __builtin_amdgcn_s_sleep(32);
             }
             s_commit = lo == shards ? 1 : 0;
-            if (polls == iv.wait_polls) atomicOr(iv.ctl, ISL_TIMEOUT);      // (nobody may take this solve for complete)
+            if (!settled && polls == iv.wait_polls) atomicOr(iv.ctl, ISL_TIMEOUT);      // (nobody may take this solve for complete)
         }
         __syncthreads();
         if (!s_commit) { if (iv.stamp_end) solve_stamp_end(v.stamps); return; }

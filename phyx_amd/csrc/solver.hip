@@ -705,7 +705,10 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
                        (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p, sb_small_.p);
     // (workgroups beyond the real bin count leave at once, and a settling world doubles its bins within a few steps — columns
     //  break in two: a roomy grid costs nothing, a grid too small costs a repeated solve)
-    const int grid = 2 * spec_bins_guess_ + 64;
+    // (up to 2047 bins the joints are grouped by ONE 11-bit radix pass — three launches instead of six — so a grid just above
+    //  that is capped there while it still leaves a quarter of slack)
+    int grid = 2 * spec_bins_guess_ + 64;
+    if (grid > 2047 && spec_bins_guess_ + spec_bins_guess_ / 4 + 16 <= 2047) grid = 2047;
     const int cap_units = spec_lanes_, cap_bodies = cap_units > ISL_T ? ISL_B_BIG : ISL_B;
     PHX_TRY(bin_tables_.reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
     PHX_TRY(bin_result_.reserve(16));
