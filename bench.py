@@ -93,6 +93,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed side measurements (Single mode, live topology, other configs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one rank")
+    ap.add_argument("--mode", default="slab", choices=("slab", "replica"),
+                    help="N > 1: slab = ownership sharding, every rank simulates the islands of its own x-slab and the per-step collective is a "
+                         "4-byte all-reduce (the north star's wording); replica = every rank holds the whole world, solves its share of the "
+                         "islands and all-gathers everybody's results every step")
     ap.add_argument("--backend", default="rccl", help="rccl: the library's own RCCL transport (csrc/comm.hip), torch only for the rendezvous; "
                     "nccl: torch.distributed's ProcessGroupNCCL from a step hook; gloo: host-staged (ranks sharing one GPU)")
     args = ap.parse_args()
@@ -113,8 +117,11 @@ def main():
     island_mode = phyx_amd.ISLAND_SINGLE_SLOPPY if world == 1 else phyx_amd.ISLAND_MULTIPLE
     cfg = Configuration(phyx_amd.SOLVE_AVX2, island_mode, args.iters, args.iters)
 
-    # ---- scene: the same world on every rank, brought to a settled contact state by the product World
-    scene = scenes.stack(args.columns, args.rows)
+    # ---- scene, brought to a settled contact state by the product World.  N = 1 and replica mode: the whole 200k-box world on
+    #      every rank.  Slab mode (N > 1): this rank's x-slab of it — its share of the columns (= islands) plus the static ground
+    mode = "single" if world == 1 else args.mode
+    full_scene = scenes.stack(args.columns, args.rows)
+    scene = pdist.slab_partition(full_scene, world)[rank][0] if mode == "slab" else full_scene
     world_obj = phyx_amd.World(device, gravity=-200.0)
     world_obj.add_scene(scene)
     for _ in range(args.scene_steps):
@@ -122,14 +129,18 @@ def main():
     world_obj.PreSolve(1.0 / 60.0)
     bodies, cps, joints = world_obj.bodies, world_obj.contactPoints, world_obj.contactJoints
     nb, nj = len(bodies), len(joints)
+    nb_total = int(group.reduce_sum(nb - 1)) + 1 if mode == "slab" else nb          # (every slab carries the ground)
+    nj_total = int(group.reduce_sum(nj)) if mode == "slab" else nj
 
     solver = phyx_amd.Solver(device)
     d_bodies, d_cps, d_joints = (phyx_amd.DeviceArray(a, device) for a in (bodies, cps, joints))
     xch = None
-    if world > 1:
+    if mode == "replica":
         solver.set_shard(rank, world)
         xch = group.exchange(solver, pdist.Exchange.capacity_for(nb, nj))
-    hook = xch.hook() if xch else None
+    # per-step collective: replica = the all-gather of everybody's results (run by the library between pack and unpack, or from
+    # this hook with the torch transports); slab = a 4-byte all-reduce queued on the solver's stream behind every step
+    hook = xch.hook() if xch else (group.stream_hook(solver.stream_ptr()) if mode == "slab" else None)
 
     def run(config, warmup, steps, repeats, slv=solver, hk=hook):
         """`repeats` timed blocks of `steps` solves of the resident input under `config`; returns the median block."""
@@ -197,6 +208,11 @@ def main():
         live_tot = run(cfg, 2, args.steps, 3)
         solver.set_schedule_reuse(True)
 
+    # ---- N > 1 side measurement: the OTHER sharding mode on the same 200k-box world (slab <-> replica), same strong-scaling accounting
+    other_mode = None
+    if world > 1 and not args.no_secondary:
+        other_mode = measure_other_mode(phyx_amd, scenes, Configuration, pdist, group, device, args, cfg, "replica" if mode == "slab" else "slab", full_scene)
+
     # ---- N > 1 side measurement (round-1 headline, kept for comparison): weak scaling — every rank solves its OWN slab of 1000
     #      columns of one N*1000-column world, no data crosses ranks, the ranks meet at a 4-byte all-reduce per step
     weak = None
@@ -235,7 +251,7 @@ def main():
             tbytes, tsource = None, "not profiled for this scene size"
         elif tbytes and world > 1:
             tbytes *= main_tot["visits"] / max(visits_all, 1)
-            tsource = "%s, scaled by rank 0's share of the joint visits (%d of %d ranks' groups)" % (tsource, 1, world)
+            tsource = "%s, scaled by rank 0's share of the joint visits (1 of %d ranks)" % (tsource, world)
         roof = {"bound": "hbm",
                 "kernel": "k_solve_islands<256,768> (one workgroup per island group, one lane per unit of two joints, all sweeps in LDS)" if lds else "k_solve_colour<impulse,displacement>",
                 "achieved": (tbytes / (launch_us * 1e-6) / 1e9) if tbytes else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -274,19 +290,25 @@ def main():
                                     "per step on HBM-resident inputs (bodies in the resident structure-of-arrays layout), schedule cached "
                                     "(built in the warm-up) and checked against the arrays inside the island kernel in every step"
                                     % (args.columns, args.rows, nb, nj, args.iters, args.iters)) if world == 1 else
-                                   ("cfg3: the same stack(%d,%d) = %d bodies / %d joints world on every rank, Multiple island mode, the schedule's "
-                                    "groups sharded g %% %d over the GPUs, %d+%d iterations, full SolveJoints per step on HBM-resident inputs + "
-                                    "pack / all-gather (RCCL) / unpack of the solved bodies and joint impulses every step"
-                                    % (args.columns, args.rows, nb, nj, world, args.iters, args.iters)),
-                       "bodies_total": int(nb), "joints_total": int(nj), "colours": st.colour_count,
+                                   (("cfg3, replica mode: the same stack(%d,%d) = %d bodies / %d joints world on every rank, Multiple island mode, the "
+                                     "schedule's groups dealt to the %d GPUs by joint count, %d+%d iterations, one SolveJoints per step on HBM-resident "
+                                     "inputs + pack / all-gather (RCCL) / unpack of the solved bodies and joint impulses every step"
+                                     % (args.columns, args.rows, nb_total, nj_total, world, args.iters, args.iters)) if mode == "replica" else
+                                    ("cfg3, slab mode (ownership sharding): stack(%d,%d) = %d bodies / %d joints cut into %d x-slabs of whole columns "
+                                     "(= islands), one world per GPU holding its slab + the static ground, Multiple island mode, %d+%d iterations, one "
+                                     "SolveJoints per step on HBM-resident inputs; the per-step collective is a 4-byte all-reduce (RCCL) queued on the "
+                                     "solver's stream — nothing else crosses xGMI" % (args.columns, args.rows, nb_total, nj_total, world, args.iters, args.iters))),
+                       "mode": mode,
+                       "bodies_total": int(nb_total), "joints_total": int(nj_total), "colours": st.colour_count,
                        "lds_islands": st.lds_islands, "graph_replay": st.graph_replay,
                        "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,
-                       "parallelism": ("islands sharded by schedule group, 1 rank per GPU, one all-gather of %d bytes per rank per step"
-                                       % solver.exchange_segment_bytes()) if world > 1 else "1 GPU",
+                       "parallelism": (("islands sharded by schedule group, 1 rank per GPU, one all-gather of %d bytes per rank per step"
+                                        % solver.exchange_segment_bytes()) if mode == "replica" else
+                                       ("islands sharded by x-slab, 1 rank per GPU, one 4-byte all-reduce per step" if mode == "slab" else "1 GPU")),
                        "timed_blocks": args.repeats, "reported_block": "median",
                        "device": info["name"], "compute_units": info["compute_units"]},
             "extra": {"solver_iterations_per_sec": iters_max / elapsed_max,
-                      "contacts_resolved_per_sec": nj * args.steps / elapsed_max,
+                      "contacts_resolved_per_sec": nj_total * args.steps / elapsed_max,
                       "device_ms_per_step": main_tot["total_ms"] / max(args.steps, 1),
                       "sweep_ms_per_step": main_tot["sweep_ms"] * main_tot["launches"] / max(main_tot["bracketed"], 1) / max(args.steps, 1),
                       "all_blocks_ms_per_step": [round(x, 5) for x in main_tot["all_blocks_ms_per_step"]],
@@ -299,7 +321,9 @@ def main():
                                               "step (the live launch time of `roofline`); the same block without any event is the figure above")
         if weak is not None:
             out["extra"]["weak_scaled_slabs"] = weak
-        if world > 1:
+        if other_mode is not None:
+            out["extra"]["%s_mode" % other_mode["mode"]] = other_mode
+        if mode == "replica":
             out["extra"]["exchange"] = {"segment_bytes_per_rank": solver.exchange_segment_bytes(), "status": exchange_status,
                                         "what": "6 floats per body + 2 per joint of the rank's groups behind a 32-byte header {serial, status, "
                                                 "topology fingerprint}; status 0 = every rank saw consistent peers in every step"}
@@ -331,6 +355,7 @@ def main():
                              "traffic": s_tr, "traffic_frac": (s_tr / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if s_tr else None}}
         if world == 1 and not args.no_secondary:
             out["extra"]["cfg3_one_rank_of_n"] = one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run)
+            out["extra"]["cfg3_slab_one_rank_of_n"] = slab_one_rank_of_n(phyx_amd, scenes, Configuration, pdist, device, args, full_scene)
             out["extra"]["other_configs"] = other_configs(phyx_amd, scenes, Configuration, device, world_obj, cfg)
             if (args.columns, args.rows) == (1000, 200):
                 out["extra"]["four_times_the_world_one_rank_of_n"] = four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, device, args)
@@ -338,6 +363,39 @@ def main():
             out["cpu_baseline"] = cpu_baseline(bodies, cps, joints, args.iters, args.cpu_seconds)
         print(json.dumps(out))
     group.shutdown()
+
+
+def measure_other_mode(phyx_amd, scenes, Configuration, pdist, group, device, args, cfg, mode, full_scene):
+    """The sharding mode the headline did not use, measured the same way (median of 3 blocks): returns its ms per step and
+    whole-job joint-visits/s."""
+    rank, world = group.rank, group.world_size
+    scene = pdist.slab_partition(full_scene, world)[rank][0] if mode == "slab" else full_scene
+    w = phyx_amd.World(device, gravity=-200.0)
+    w.add_scene(scene)
+    for _ in range(args.scene_steps):
+        w.Update(1.0 / 60.0, cfg)
+    w.PreSolve(1.0 / 60.0)
+    arrs = [phyx_amd.DeviceArray(a, device) for a in (w.bodies, w.contactPoints, w.contactJoints)]
+    slv = phyx_amd.Solver(device)
+    xch = None
+    if mode == "replica":
+        slv.set_shard(rank, world)
+        xch = group.exchange(slv, pdist.Exchange.capacity_for(arrs[0].count, arrs[2].count))
+    hook = xch.hook() if xch else group.stream_hook(slv.stream_ptr())
+    for _ in range(2):
+        slv.bench(arrs[0], arrs[1], arrs[2], cfg, 0, 1, hook=hook)
+    times, visits = [], 0
+    for _ in range(3):
+        slv.bench_stage(arrs[0], arrs[2], args.steps)
+        group.barrier(); slv.synchronize()
+        t0 = time.perf_counter()
+        r = slv.bench(arrs[0], arrs[1], arrs[2], cfg, 0, args.steps, hook=hook)
+        slv.synchronize(); group.barrier()
+        times.append(group.reduce_max(time.perf_counter() - t0))
+        visits = group.reduce_sum(r.joint_visits)
+    el = sorted(times)[1]
+    return {"mode": mode, "ms_per_step": 1e3 * el / max(args.steps, 1), "joint_visits_per_sec": visits / el, "scaling": "strong",
+            "exchange_status": int(group.reduce_max(slv.exchange_status())) if xch else 0}
 
 
 def world_groups_max_colours(solver):
@@ -367,6 +425,39 @@ def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joi
         tot = run(cfg3, 2, 10, 3, slv=slv, hk=xch.hook())
         res["n=%d" % n] = {"ms_per_step": 1e3 * tot["elapsed_max"] / 10, "island_launch_us": 1e3 * tot["sweep_ms"] / max(tot["bracketed"], 1),
                            "segment_bytes": slv.exchange_segment_bytes(), "groups": (tot["stats"].lds_islands + n - 1) // n}
+    return res
+
+
+def slab_one_rank_of_n(phyx_amd, scenes, Configuration, pdist, device, args, full_scene):
+    """What ONE rank of an n-GPU config-3 run in SLAB mode (ownership sharding: bench.py --gpus n, the default) spends per step,
+    measured on this GPU: the solver on rank 0's x-slab of the 200k-box world, no collective (a 4-byte all-reduce in the real
+    run).  A rank with 1/n of the islands is NOT n times faster: the island launch lasts as long as one island's ~84 dependent
+    class steps however few islands there are."""
+    cfg3 = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, args.iters, args.iters)
+    res = {}
+    for n in (2, 4, 8):
+        sub = pdist.slab_partition(full_scene, n)[0][0]
+        w = phyx_amd.World(device, gravity=-200.0)
+        w.add_scene(sub)
+        for _ in range(args.scene_steps):
+            w.Update(1.0 / 60.0, cfg3)
+        w.PreSolve(1.0 / 60.0)
+        arrs = [phyx_amd.DeviceArray(a, device) for a in (w.bodies, w.contactPoints, w.contactJoints)]
+        del w
+        slv = phyx_amd.Solver(device)
+        for _ in range(2):
+            slv.bench(arrs[0], arrs[1], arrs[2], cfg3, 0, 1)
+        best = None
+        for _ in range(3):
+            slv.bench_stage(arrs[0], arrs[2], 10)
+            slv.synchronize()
+            t0 = time.perf_counter()
+            r = slv.bench(arrs[0], arrs[1], arrs[2], cfg3, 0, 10)
+            slv.synchronize()
+            el = (time.perf_counter() - t0) / 10
+            best = el if best is None else min(best, el)
+        res["n=%d" % n] = {"ms_per_step": 1e3 * best, "island_launch_us": 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1),
+                           "joints": arrs[2].count, "groups": slv.stats().lds_islands}
     return res
 
 

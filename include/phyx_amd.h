@@ -366,6 +366,10 @@ phx_broadphase* phx_world_broadphase(phx_world* w);
  * 0 IntegrateVelocity 1 UpdateBroadphase 2 UpdatePairs 3 UpdateManifolds 4 PackManifolds
  * 5 RefreshContactJoints 6 SolveJoints 7 IntegratePosition */
 int  phx_world_get_phase_ms(phx_world* w, double out8[8]);
+/* [min x, max x] over the AABBs of the dynamic bodies, reduced on the device.  An ownership-sharded run (one world per GPU, each
+ * holding the islands of one x-slab: phyx_amd/dist.py SlabWorld) checks it against its slab: as long as no body
+ * leaves its slab no island can span two ranks and the ranks need nothing from each other but the per-step barrier. */
+int  phx_world_x_extent(phx_world* w, float out2[2]);
 /* diagnostics: [0] steps whose PackManifolds count was settled together with the joint counts (the bet that no manifold dies),
  * [1] those of them that lost the bet (pack run late, joint match repeated), [2] solves repeated because the cached schedule was
  * stale or a group was left uncommitted, [3] third contact points dropped (ref: Collider.cpp:241-242 would overflow) */

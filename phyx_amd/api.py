@@ -585,6 +585,12 @@ class World:
         """Wait for the queued step (Update returns once the step is queued; getters synchronise on their own)."""
         check(self.L.phx_world_synchronize(self.h))
 
+    def x_extent(self):
+        """(min x, max x) over the dynamic bodies' AABBs, reduced on the device (phx_world_x_extent)."""
+        out = np.zeros(2, dtype=np.float32)
+        check(self.L.phx_world_x_extent(self.h, _ptr(out)))
+        return float(out[0]), float(out[1])
+
     def debug_counters(self):
         """{deferred_packs, deferred_pack_retries, solve_replays, dropped_points} (phx_world_debug_counters)."""
         out = np.zeros(4, dtype=np.int64)

@@ -38,6 +38,7 @@ public:
     int set_comm(Comm* c);
     int step_sharded(float dt, const phx_config& cfg);
     int check_exchange();
+    int x_extent(float out[2]);
     hipStream_t stream() const { return stream_; }
     int download_bodies(phx_rigid_body* out, int cap);
     int download_manifolds(phx_manifold* out, int cap);
@@ -469,6 +470,26 @@ int World::check_exchange()
     return PHX_OK;
 }
 
+// [min x, max x] over the AABBs of the dynamic bodies (an ownership-sharded caller checks it against its slab, dist.py SlabWorld)
+int World::x_extent(float out[2])
+{
+    PHX_TRY(use_device(device_));
+    PHX_TRY(sync_bodies_to_device());
+    PHX_TRY(flags_.reserve(4));
+    const unsigned init[2] = {0xFFFFFFFFu, 0u};
+    PHX_HIP(hipMemcpyAsync(flags_.p, init, sizeof init, hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));                                 // (`init` is on the stack)
+    if (nb()) hipLaunchKernelGGL(k_x_extent, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), flags_.p);
+    PHX_HIP(hipGetLastError());
+    unsigned keys[2] = {0, 0};
+    PHX_TRY(rb_.add(keys, flags_.p, sizeof keys, stream_));
+    PHX_TRY(rb_.wait(stream_));
+    auto unkey = [](unsigned k) { const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
+    if (keys[0] == 0xFFFFFFFFu) { out[0] = 0.f; out[1] = 0.f; }            // no dynamic body
+    else { out[0] = unkey(keys[0]); out[1] = unkey(keys[1]); }
+    return PHX_OK;
+}
+
 int World::finish_step(float dt, const phx_config& cfg)
 {
     using clk = std::chrono::steady_clock;
@@ -671,6 +692,12 @@ int phx_world_debug_counters(phx_world* w, int64_t out4[4])
     out4[0] = w->impl.deferred_packs; out4[1] = w->impl.deferred_pack_retries;
     out4[2] = (int64_t)w->impl.solver().replays(); out4[3] = (int64_t)w->impl.dropped_points;
     return PHX_OK;
+}
+
+int phx_world_x_extent(phx_world* w, float out2[2])
+{
+    PHX_REQUIRE(w && out2, "null handle / buffer");
+    return w->impl.x_extent(out2);
 }
 
 int phx_world_set_phase_timing(phx_world* w, int32_t on)

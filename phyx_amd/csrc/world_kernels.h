@@ -101,6 +101,22 @@ static __global__ void __launch_bounds__(256) k_integrate_position(WorldBodies w
     }
 }
 
+// x-extent of the dynamic bodies' AABBs (ownership-sharded worlds, dist.py: a rank's bodies must stay inside its slab): the floats
+// are kept as order-preserving unsigned keys so that atomicMin / atomicMax work; out[0] = min key, out[1] = max key
+__device__ __forceinline__ unsigned float_key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static __global__ void __launch_bounds__(256) k_x_extent(WorldBodies w, int n, unsigned* __restrict__ out)
+{
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 m = w.s.mpos[i];
+        if (m.x == 0.f && m.y == 0.f) continue;                            // static bodies belong to every slab
+        const float4 a = w.aabb[i];
+        lo = min(lo, float_key(a.x)); hi = max(hi, float_key(a.z));
+    }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (unsigned)__shfl_down(lo, off)); hi = max(hi, (unsigned)__shfl_down(hi, off)); }
+    if ((threadIdx.x & 63) == 0) { if (lo != 0xFFFFFFFFu) atomicMin(&out[0], lo); if (hi) atomicMax(&out[1], hi); }
+}
+
 __device__ __forceinline__ NpBody np_load(const WorldBodies& w, int i)
 {
     const float4 m = w.s.mpos[i], f = w.frame[i];

@@ -146,6 +146,12 @@ class Single:
     def step_barrier(self):
         pass
 
+    def step_barrier_value(self, value):
+        return int(value)
+
+    def all_gather_bytes(self, mine):
+        return np.ascontiguousarray(mine, dtype=np.uint8)
+
     def reduce_max(self, x):
         return float(x)
 
@@ -204,7 +210,11 @@ class Group:
 
     def step_barrier(self):
         """The per-step exchange of the island-sharded solve: one 4-byte all-reduce (done / error flag)."""
-        self._flag.zero_()
+        return self.step_barrier_value(0)
+
+    def step_barrier_value(self, value):
+        """4-byte all-reduce (max) of this rank's status word; every rank gets the worst one."""
+        self._flag.fill_(int(value))
         self.dist.all_reduce(self._flag, op=self.dist.ReduceOp.MAX)
         self._sync()
         return int(self._flag.item())
@@ -306,3 +316,100 @@ def shard_columns(total_columns, rank, world_size):
     base, extra = divmod(total_columns, world_size)
     first = rank * base + min(rank, extra)
     return first, base + (1 if rank < extra else 0)
+
+
+# ---- ownership sharding: one world per rank, each holding the islands of one x-slab ---------------------------------------
+# BASELINE config 3 read literally ("islands shard naturally across GPUs … RCCL only for the per-step barrier"): instead of a
+# replica of the whole world plus an all-gather of everybody's results (Exchange above), a rank SIMULATES only the bodies whose
+# centre lies in its slab of the x axis — the broadphase's sweep axis, so slabs are natural — plus every static body.  As long
+# as no dynamic body reaches across a slab boundary, no contact, hence no island, spans two ranks: the ranks' worlds are
+# independent sub-problems of the reference's island loop (ref: Solver.cpp:86-91), the per-step collective is a 4-byte
+# all-reduce, and nothing else ever crosses xGMI.  The guard (SlabWorld.check) watches that condition on the device
+# (phx_world_x_extent) and every rank learns of a violation at the same step; re-slabbing with a hand-off of the contact cache
+# is not implemented — a violated guard is reported, never ignored.  gather_bodies() assembles the full world on demand.
+#
+# A slab world is bit-exact against the oracle of ITS OWN slab scene (tests/test_world_gpu.py), not against the unsharded world:
+# colouring priorities hash the contact-point index, which is local to a world, so the two sweep the same islands in different
+# (equally legal) Gauss-Seidel orders — like the reference's own solve modes differ among themselves.
+
+def slab_partition(scene, nranks):
+    """Cuts a scene into `nranks` x-slabs with (nearly) equal numbers of dynamic bodies.  Returns a list of
+    (sub_scene, global_index, (lo, hi)): the rank's bodies in their original relative order (static bodies of the whole scene
+    included in every slab), their indices in the full scene, and the slab's open x-interval (−inf / +inf at the ends)."""
+    px = np.asarray(scene["px"], dtype=np.float64)
+    static = np.asarray(scene["static"], dtype=bool)
+    dyn = np.flatnonzero(~static)
+    order = dyn[np.argsort(px[dyn], kind="stable")]
+    cuts = [len(order) * r // nranks for r in range(nranks + 1)]
+    for c in range(1, nranks):                     # never cut between bodies with the same centre x (a column of a stack)
+        cuts[c] = max(cuts[c], cuts[c - 1])
+        while 0 < cuts[c] < len(order) and px[order[cuts[c]]] == px[order[cuts[c] - 1]]:
+            cuts[c] += 1
+    out = []
+    for r in range(nranks):
+        mine = order[cuts[r]:cuts[r + 1]]
+        # a slab boundary sits half-way between the neighbouring bodies' centres; equal centres must not be split
+        lo = -np.inf if cuts[r] == 0 or not len(mine) else 0.5 * (px[order[cuts[r] - 1]] + px[mine[0]])
+        hi = np.inf if cuts[r + 1] >= len(order) or not len(mine) else 0.5 * (px[mine[-1]] + px[order[cuts[r + 1]]])
+        keep = np.sort(np.concatenate([np.flatnonzero(static), mine]))
+        sub = {k: np.asarray(v)[keep] for k, v in scene.items() if hasattr(v, "__len__") and len(v) == len(px)}
+        out.append((sub, keep, (float(lo), float(hi))))
+    return out
+
+
+class SlabWorld:
+    """One rank of an ownership-sharded world (see the comment above)."""
+
+    def __init__(self, group, scene, device=0, gravity=0.0, check_every=1):
+        import phyx_amd
+        self.group = group
+        sub, self.global_index, self.bounds = slab_partition(scene, group.world_size)[group.rank]
+        self.scene_size = len(scene["px"])
+        self.world = phyx_amd.World(device, gravity=gravity)
+        self.world.add_scene(sub)
+        self.check_every, self.steps = check_every, 0
+
+    def step(self, dt, configuration):
+        """World::Update of this rank's slab, then the per-step barrier (a 4-byte all-reduce that carries the guard's verdict)."""
+        self.world.Update(dt, configuration)
+        self.steps += 1
+        bad = 0
+        if self.steps % self.check_every == 0:
+            bad = 0 if self.inside() else 1
+        flag = self.group.step_barrier_value(bad) if hasattr(self.group, "step_barrier_value") else bad
+        if flag:
+            raise RuntimeError("ownership-sharded world: a body reached the boundary of its slab (rank %d, slab %s); the islands of two "
+                               "ranks may now touch — re-slab the world (gather_bodies) before going on" % (self.group.rank, self.bounds))
+
+    def inside(self):
+        """True iff every dynamic body's AABB lies strictly inside this rank's slab: then no AABB of this rank overlaps one of
+        another rank, the broadphase of the whole world would find no pair between them, and no island spans two ranks."""
+        lo, hi = self.world.x_extent()
+        return lo > self.bounds[0] and hi < self.bounds[1]
+
+    def check(self):
+        flag = 0 if self.inside() else 1
+        flag = self.group.step_barrier_value(flag) if hasattr(self.group, "step_barrier_value") else flag
+        return flag == 0
+
+    def gather_bodies(self):
+        """The whole world's body records, in the full scene's index order, on every rank (static bodies from rank 0)."""
+        import phyx_amd
+        mine = self.world.bodies
+        full = np.zeros(self.scene_size, dtype=phyx_amd.rigid_body_dtype)
+        if self.group.world_size == 1:
+            full[self.global_index] = mine
+            return full
+        n_max = int(self.group.reduce_max(len(mine)))
+        buf = np.zeros(n_max * mine.dtype.itemsize + 8 * n_max + 8, dtype=np.uint8)
+        buf[:8] = np.frombuffer(np.int64(len(mine)).tobytes(), dtype=np.uint8)
+        buf[8:8 + 8 * len(mine)] = np.frombuffer(self.global_index.astype(np.int64).tobytes(), dtype=np.uint8)
+        buf[8 + 8 * n_max:8 + 8 * n_max + mine.nbytes] = np.frombuffer(mine.tobytes(), dtype=np.uint8)
+        allb = self.group.all_gather_bytes(buf).reshape(self.group.world_size, -1)
+        for r in range(self.group.world_size - 1, -1, -1):           # (rank 0 last: its copy of the static bodies wins)
+            n = int(np.frombuffer(allb[r, :8].tobytes(), dtype=np.int64)[0])
+            idx = np.frombuffer(allb[r, 8:8 + 8 * n].tobytes(), dtype=np.int64)
+            rec = np.frombuffer(allb[r, 8 + 8 * n_max:8 + 8 * n_max + n * mine.dtype.itemsize].tobytes(), dtype=phyx_amd.rigid_body_dtype)
+            full[idx] = rec
+        full["index"] = np.arange(self.scene_size, dtype=np.uint32)
+        return full

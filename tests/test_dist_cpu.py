@@ -102,3 +102,31 @@ def test_self_launch_spawns_one_process_per_rank(tmp_path):
         assert self_launch(2, [str(script), str(tmp_path), "fail"]) == 3
     finally:
         os.environ.clear(); os.environ.update(env)
+
+
+def test_slab_partition_cuts_between_columns():
+    """Ownership sharding (phyx_amd.dist.slab_partition): equal shares of the dynamic bodies by x, never a cut through bodies with the
+    same centre (a column of a stack), static bodies in every slab, original relative order kept, slab intervals that tile the axis."""
+    import numpy as np
+    from phyx_amd import scenes
+    from phyx_amd.dist import slab_partition
+    for scene, n in ((scenes.stack(10, 5), 4), (scenes.stack(1000, 3), 8), (scenes.falling(300), 3), (scenes.stack(3, 4), 1), (scenes.stack(2, 6), 4)):
+        parts = slab_partition(scene, n)
+        assert len(parts) == n
+        total = len(scene["px"])
+        static = np.flatnonzero(scene["static"])
+        seen = np.zeros(total, dtype=int)
+        prev_hi = -np.inf
+        for sub, idx, (lo, hi) in parts:
+            assert np.all(np.diff(idx) > 0)                                   # original order
+            assert set(static.tolist()) <= set(idx.tolist())                  # every static body in every slab
+            assert np.array_equal(sub["px"], scene["px"][idx]) and np.array_equal(sub["static"], scene["static"][idx])
+            dyn = idx[~scene["static"][idx]]
+            seen[dyn] += 1
+            if len(dyn):
+                assert lo == prev_hi or (lo == -np.inf and prev_hi == -np.inf)
+                assert np.all(scene["px"][dyn] > lo) and np.all(scene["px"][dyn] < hi)
+                prev_hi = hi
+        assert np.all(seen[~scene["static"]] == 1)                            # every dynamic body in exactly one slab
+    sizes = [len(p[1]) - 1 for p in slab_partition(scenes.stack(1000, 3), 8)]
+    assert max(sizes) - min(sizes) <= 3                                       # whole columns: at most one column of imbalance

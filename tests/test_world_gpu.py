@@ -268,22 +268,74 @@ def test_exchange_through_the_native_rccl_transport_one_rank(built_lib):
     assert p.returncode == 0 and "sharded worker ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
-def test_bench_launches_its_own_ranks(built_lib):
+@pytest.mark.parametrize("mode", ["slab", "replica"])
+def test_bench_launches_its_own_ranks(built_lib, mode):
     """`python bench.py --gpus 2` without torchrun: bench.py spawns the two ranks itself (here both on GPU 0 over gloo) and rank 0
-    prints the one JSON line of the cfg-3 workload."""
+    prints the one JSON line of the cfg-3 workload — in slab mode (ownership sharding, the default) and in replica mode."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--columns", "48", "--rows", "30", "--steps", "3",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--mode", mode, "--columns", "48", "--rows", "30", "--steps", "3",
                         "--warmup", "1", "--repeats", "1", "--no-secondary", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["extra"]["exchange"]["status"] == 0
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["mode"] == mode
+    assert out["config"]["bodies_total"] == 48 * 30 + 1
+    if mode == "replica":
+        assert out["extra"]["exchange"]["status"] == 0
+
+
+def test_slab_worlds_are_exact_sub_worlds_and_the_guard_trips(oracle, built_lib):
+    """Ownership sharding (phyx_amd.dist.SlabWorld: BASELINE config 3 read literally — every rank simulates the islands of its own
+    x-slab, the per-step collective is a 4-byte all-reduce).  Three ranks emulated in one process: every slab world is the oracle's
+    world of that slab, byte for byte; while no body leaves its slab the guard holds and the union agrees with the unsharded world
+    (contact counts up to duplicate manifolds; positions within the spread two legal Gauss-Seidel orders have — a slab world numbers its contact points
+    locally, so its colouring priorities differ); a scene whose bodies interleave across the cut trips the guard at once."""
+    import types
+    from phyx_amd import dist as pdist
+    scene = scenes.stack(12, 20)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 12, 12)
+    parts = pdist.slab_partition(scene, 3)
+    for sub, idx, bounds in parts:                                   # each slab is a world of its own: the usual lockstep bar
+        _lockstep(oracle, sub, 8, cfg, check_every=2)
+    full = phyx_amd.World(0, gravity=-200.0)
+    full.add_scene(scene)
+    slabs = []
+    for r in range(3):
+        g = types.SimpleNamespace(rank=r, world_size=3, step_barrier_value=lambda v: v)
+        slabs.append(pdist.SlabWorld(g, scene, device=0, gravity=-200.0))
+    for _ in range(5):
+        full.Update(1.0 / 60.0, cfg)
+        for sw in slabs:
+            sw.step(1.0 / 60.0, cfg)
+    assert all(sw.inside() for sw in slabs)
+    fb = full.bodies
+    # (a column's boxes tie on their min x up to rounding jitter, and which of two such boxes sorts first decides whether the
+    #  reference's oriented pair key creates a duplicate manifold (b, a) beside (a, b): counts agree only up to those duplicates)
+    assert abs(sum(sw.world.counts()[1] for sw in slabs) - full.counts()[1]) <= 0.03 * full.counts()[1]          # manifolds
+    assert abs(sum(sw.world.counts()[3] for sw in slabs) - full.counts()[3]) <= 0.03 * full.counts()[3]          # joints
+    for sw in slabs:
+        mine = sw.world.bodies
+        dyn = mine["inv_mass"] > 0
+        d = np.maximum(np.abs(mine["pos"]["x"][dyn] - fb["pos"]["x"][sw.global_index][dyn]), np.abs(mine["pos"]["y"][dyn] - fb["pos"]["y"][sw.global_index][dyn]))
+        # two legal sweep orders of an unconverged 20-box stack: the reference's own scalar and AVX2 orders are 2.7e-2 apart after ONE
+        # step and 0.5 after ten on such columns (BASELINE.md §2); five steps must stay inside that band
+        assert float(d.max()) < 0.5 and float(d.mean()) < 0.1, (float(d.max()), float(d.mean()))
+    one = pdist.SlabWorld(types.SimpleNamespace(rank=0, world_size=1, step_barrier_value=lambda v: v, reduce_max=float), scene, device=0, gravity=-200.0)
+    one.step(1.0 / 60.0, cfg)
+    assert one.gather_bodies().tobytes() == one.world.bodies.tobytes()
+    # bodies of both ranks share the same stretch of the x axis: not a slab-shardable world, and the guard says so
+    mixed = scenes.falling(120, width=20.0, ymax=400.0)
+    g = types.SimpleNamespace(rank=0, world_size=2, step_barrier_value=lambda v: v)
+    sw = pdist.SlabWorld(g, mixed, device=0, gravity=-200.0)
+    with pytest.raises(RuntimeError):
+        for _ in range(30):
+            sw.step(1.0 / 60.0, cfg)
 
 
 def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
