@@ -20,7 +20,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file extras.  islands.hip: the SLP vectoriser pairs the joint update's multiplies and adds into v_pk_mul_f32 / v_pk_add_f32
 # and pays for every pair with moves into adjacent registers; measured on the island kernel (bit-identical results): 83.0 us
 # with it, 78.3 us without.  The HBM path's kernels (solver.hip) are a few per cent faster with it, so it stays on there.
-FILE_FLAGS = {"islands.hip": ["-fno-slp-vectorize", "-Wno-unused-function"]}      # (it includes solver_kernels.h for the shared device helpers only)
+# round 3: the machine scheduler's iterative-ilp strategy (orders each block for instruction-level parallelism instead of register
+# pressure — the class step is one wave's dependent chain, and the kernel has registers to spare at 4 waves per SIMD): launch
+# 76.6 -> 74.1 us together with the select-based tag update (tools/build_variants.sh A/B: max-ilp 75.5, max-memory-clause 75.0)
+FILE_FLAGS = {"islands.hip": ["-fno-slp-vectorize", "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}      # (it includes solver_kernels.h for the shared device helpers only)
 # roctx ranges (phase names of the reference's MICROPROFILE scopes) are resolved at run time with dlopen: no link dependency
 LINK = ["-shared", "-ldl"]
 

@@ -92,7 +92,7 @@ __device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2,
     const bool p1 = st1 ? sp1 : (__float_as_int(B1.w) > it - 2);
     const bool p2 = st2 ? sp2 : (__float_as_int(B2.w) > it - 2);
     productive = false;
-    if (!(p1 || p2)) return false;
+    if (!(p1 || p2)) return false;        // (a 'likely' hint on the evaluated path was measured 2 % slower)
     const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
     float dv = q.dstV;
     dv -= nx * B1.x; dv -= ny * B1.y; dv -= q.aN1 * B1.z;
@@ -114,7 +114,9 @@ __device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2,
     q.accF += df;
     B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (q.aF1 * ii1) * df;
     B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (q.aF2 * ii2) * df;
-    if (max_ref(fabsf(dn), fabsf(df)) > 1e-4f) { B1.w = __int_as_float(it); B2.w = __int_as_float(it); productive = true; }
+    // (the tags by select, not under a branch: an exec-mask region — save, two moves, restore — per joint was 1.3 % of the launch)
+    productive = max_ref(fabsf(dn), fabsf(df)) > 1e-4f;
+    B1.w = productive ? __int_as_float(it) : B1.w; B2.w = productive ? __int_as_float(it) : B2.w;
     return true;
 }
 
@@ -135,7 +137,8 @@ __device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2
     D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (q.aN1 * ii1) * di;
     D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (q.aN2 * ii2) * di;
     q.accD += di;
-    if (fabsf(di) > 1e-4f) { D1.w = __int_as_float(it); D2.w = __int_as_float(it); productive = true; }
+    productive = fabsf(di) > 1e-4f;
+    D1.w = productive ? __int_as_float(it) : D1.w; D2.w = productive ? __int_as_float(it) : D2.w;
     return true;
 }
 
