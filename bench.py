@@ -298,7 +298,7 @@ def main():
                                      "(= islands), one world per GPU holding its slab + the static ground, Multiple island mode, %d+%d iterations, one "
                                      "SolveJoints per step on HBM-resident inputs; the per-step collective is a 4-byte all-reduce (RCCL) queued on the "
                                      "solver's stream — nothing else crosses xGMI" % (args.columns, args.rows, nb_total, nj_total, world, args.iters, args.iters))),
-                       "mode": mode,
+                       "mode": mode, "transport": getattr(group, "backend", "none") if world > 1 else "none",
                        "bodies_total": int(nb_total), "joints_total": int(nj_total), "colours": st.colour_count,
                        "lds_islands": st.lds_islands, "graph_replay": st.graph_replay,
                        "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,

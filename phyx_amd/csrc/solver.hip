@@ -748,8 +748,7 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     sc.lds_colours = sched_.lds_colours; sc.hbm_body_count = 0;
     grp_body_count_.clear();
     nstatic_ = 0;
-    PHX_TRY(sw_.reserve(4));
-    if (sw_.p != sw_cleared_ || 4 > sw_cleared_words_) PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * sizeof(unsigned), stream_));
+    PHX_TRY(sw_.reserve(4));      // (the HBM path's static-tag table: a schedule of nothing but LDS groups never reads it — no clearing dispatch)
     build_unverified_ = true;
     unverified_bins_ = grid;
     spec_bins_pending_ = true;

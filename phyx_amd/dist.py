@@ -196,9 +196,29 @@ class Group:
         if backend == "rccl":
             # the library's own RCCL communicator (csrc/comm.hip): rank 0's id reaches everybody through the gloo group
             from . import api
-            box = [api.Comm.unique_id() if self.rank == 0 else None]
+            why = ""
+            box = [None]
+            if self.rank == 0:
+                try:
+                    box = [api.Comm.unique_id()]
+                except Exception as e:             # no RCCL on this box
+                    why = str(e)
             dist.broadcast_object_list(box, src=0)
-            self.comm = api.Comm(box[0], self.rank, self.world_size, self.local_rank)
+            if box[0] is not None:
+                try:
+                    self.comm = api.Comm(box[0], self.rank, self.world_size, self.local_rank)
+                except Exception as e:
+                    why = str(e)
+            # every rank must end up on the same transport
+            ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                import sys
+                self.comm = None
+                self.backend = "gloo"
+                if self.rank == 0:
+                    sys.stderr.write("phyx_amd.dist: no native RCCL communicator (%s): the collectives of this run are staged through the host "
+                                     "(gloo) — functional, not what a GPU node should measure\n" % (why or "a peer failed to create it"))
 
     def _sync(self):
         if self.backend == "nccl":

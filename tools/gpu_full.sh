@@ -11,6 +11,6 @@ import json
 d=json.load(open('gpurun_out/f/bench.json'))
 print("ms/step",d["ms_per_step"],"value %.3g"%d["value"],"launch us",d["roofline"]["avg_launch_us"])
 e=d["extra"]
-print("live",e["live_topology"]["ms_per_step"],"single",e["single_mode"]["ms_per_step"],e["single_mode"]["colours"],"world",e["other_configs"]["cfg2_world_step"]["ms_per_step"])
+print("live",d["live_topology"]["ms_per_step"],"single",d["single_mode"]["ms_per_step"],d["single_mode"]["colours"],"world",e["other_configs"]["cfg2_world_step"]["ms_per_step"])
 print("cpu",json.dumps(d.get("cpu_baseline"))[:1500])
 PY

@@ -8,7 +8,7 @@ import json
 d=json.load(open('gpurun_out/r3b/bench.json'))
 print("ms/step",d["ms_per_step"],"value %.3g"%d["value"],"launch us",d["roofline"]["avg_launch_us"])
 e=d["extra"]
-print("live",e["live_topology"]["ms_per_step"],"single",e["single_mode"]["ms_per_step"],e["single_mode"]["colours"])
+print("live",d["live_topology"]["ms_per_step"],"single",d["single_mode"]["ms_per_step"],d["single_mode"]["colours"])
 oc=e["other_configs"]
 print("world",oc["cfg2_world_step"])
 print("cfg4",oc["cfg4_broadphase_1M"])
