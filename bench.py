@@ -69,8 +69,8 @@ def pmc_traffic():
                 for name, k in d.get("kernels", {}).items():
                     if "k_solve_islands<256" in name:
                         out["k_solve_islands"] = k["hbm_bytes_per_launch_corrected"]
-                    if "k_solve_colour<true, true>" in name:
-                        out["k_solve_colour"] = k["hbm_bytes_per_launch_corrected"]
+                if d.get("hbm_colour_bytes_per_launch"):          # mean over the Single-mode measurement's class launches
+                    out["k_solve_colour"] = d["hbm_colour_bytes_per_launch"]
                     if "k_solve_dataflow" in name:
                         out["k_solve_dataflow"] = k["hbm_bytes_per_launch_corrected"]
                 return out
@@ -193,6 +193,14 @@ def main():
     if world == 1 and lds and not args.no_secondary:
         zero = run(Configuration(phyx_amd.SOLVE_AVX2, island_mode, 0, 0), 2, 10, 3)
         phases = {"setup_prestep_writeback_us": 1e3 * zero["sweep_ms"] / max(zero["bracketed"], 1)}
+        # ... and the cost of a class step as a SLOPE: the same solve with half the impulse sweeps.  (The 0-iteration launch is not
+        # "the full launch minus its sweeps": its workgroups all reach the write-back together, and under in-kernel verification
+        # they wait there for the last arrival, which a full launch hides behind its sweeps.)
+        half_it = max(cfg.contactIterationsCount // 2, 1)
+        half = run(Configuration(phyx_amd.SOLVE_AVX2, island_mode, half_it, cfg.penetrationIterationsCount), 2, 10, 3)
+        if half["stats"].impulse_iterations == half_it and st.impulse_iterations > half_it:
+            phases["half_sweeps"] = half_it
+            phases["half_sweeps_launch_us"] = 1e3 * half["sweep_ms"] / max(half["bracketed"], 1)
 
     # ---- secondary (N=1 only, untimed by the driver): strict Single island mode = the general-case (big island) path
     single_tot = live_tot = unbracketed = None
@@ -273,10 +281,24 @@ def main():
                      "floor_what": "class step = the two joints of a unit: LDS read 64 + 2 x 26 dependent fp32 ops x 4 + LDS write 13 + barrier 128 cycles"}
             if phases:
                 sweep_us = max(launch_us - phases["setup_prestep_writeback_us"], 0.0)
-                cyc = sweep_us * 1e-6 * SHADER_CLOCK_HZ / max(ncol_max * st.impulse_iterations, 1)
-                model.update({"sweeps_us": sweep_us, "setup_prestep_writeback_us": phases["setup_prestep_writeback_us"],
+                cyc0 = sweep_us * 1e-6 * SHADER_CLOCK_HZ / max(ncol_max * st.impulse_iterations, 1)
+                cyc = cyc0
+                model.update({"zero_iteration_launch_us": phases["setup_prestep_writeback_us"],
+                              "cycles_per_colour_step_by_zero_iteration_subtraction": cyc0,
+                              "zero_iteration_note": "launch minus a 0-iteration launch, the figure rounds 1-2 reported; it flatters the class step: "
+                                                     "a 0-iteration launch has every workgroup writing back at once and (in-kernel verification) waiting "
+                                                     "for the last arrival, neither of which the full launch pays"})
+                if "half_sweeps_launch_us" in phases:
+                    dsw = st.impulse_iterations - phases["half_sweeps"]
+                    step_us = (launch_us - phases["half_sweeps_launch_us"]) / max(ncol_max * dsw, 1)
+                    cyc = step_us * 1e-6 * SHADER_CLOCK_HZ
+                    sweep_us = step_us * steps_crit
+                    model.update({"half_sweeps": phases["half_sweeps"], "half_sweeps_launch_us": phases["half_sweeps_launch_us"],
+                                  "how": "slope: (launch with %d impulse sweeps - launch with %d) / (%d sweeps x %d classes of the slowest group)"
+                                         % (st.impulse_iterations, phases["half_sweeps"], dsw, ncol_max)})
+                model.update({"sweeps_us": sweep_us, "setup_prestep_writeback_us": max(launch_us - sweep_us, 0.0),
                               "achieved_cycles_per_colour_step": cyc, "frac_of_latency_floor": COLOUR_STEP_FLOOR_CYCLES / cyc if cyc > 0 else None,
-                              "setup_writeback_GBps": (tbytes / (phases["setup_prestep_writeback_us"] * 1e-6) / 1e9) if tbytes else None})
+                              "setup_writeback_GBps": (tbytes / (max(launch_us - sweep_us, 1e-3) * 1e-6) / 1e9) if tbytes else None})
             roof["latency_model"] = model
         out = {
             "metric": "solver joint-visits/s (contacts/sec) on the 200k-box stack scene; solver iterations/s in extra",
