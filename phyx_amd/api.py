@@ -328,6 +328,12 @@ class Solver:
         check(self.L.phx_solver_get_groups(self.h, _ptr(offs), len(offs), C.byref(n), C.byref(lds)))
         return offs, lds.value
 
+    def partition(self):
+        """(interior_classes, parts, sweep_launches) of the last solve: the partitioned-component path (phx_solver_get_partition)."""
+        ki, parts, launches = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self.L.phx_solver_get_partition(self.h, C.byref(ki), C.byref(parts), C.byref(launches)))
+        return ki.value, parts.value, launches.value
+
     def refreshed(self, joint_index):
         out = np.zeros(30, dtype=np.float32)
         check(self.L.phx_solver_get_refreshed(self.h, joint_index, _ptr(out)))

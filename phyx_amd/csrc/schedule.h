@@ -47,13 +47,33 @@ __host__ __device__ inline unsigned long long colour_priority(unsigned id, unsig
 //      structures (a stack: consecutive body indices alternate parity along a column) the two halves of a body's units are
 //      drawn from opposite ends and never collide, which reaches the optimum of max-degree classes where A needs up to 1.5x as
 //      many; on irregular piles B is a little worse than A.  B is defined for at most 64 classes.
-// B is only attempted for components of at most COLOUR_B_MAX_JOINTS joints: the layered structures it helps are small, and
-// on a large irregular island it would double the colouring's memory traffic to lose anyway.
+// B is only attempted for components of at most COLOUR_B_MAX_JOINTS joints — the ones that fit a workgroup: the layered
+// structures it helps are small, and a larger component is partitioned (below).
 // Every CONNECTED COMPONENT keeps the candidate that gives IT fewer classes (A on a tie) and renumbers its classes densely in
 // increasing order.  The choice is per component, so an island's classes — hence its results — do not depend on which other
 // islands share its group, on the workgroup shape or on the island mode.  A class is one barrier-separated step (LDS groups)
 // or one kernel launch (HBM group) of every sweep, so the largest class count sets the solve time.
-constexpr int COLOUR_B_MAX_JOINTS = 8192;
+constexpr int COLOUR_B_MAX_JOINTS = 1024;
+
+// PARTITIONED COMPONENTS.  A component of more than COLOUR_B_MAX_JOINTS joints (a settled pile: one island of 1e5-1e6 joints)
+// is swept class by class out of HBM, one launch per class and sweep — a solve is classes x sweeps dependent launches.  Most of
+// such an island is local: cut the bodies into PARTS of PART_BODIES consecutive indices; a unit of a partitioned component is
+// INTERIOR if both its bodies are dynamic and lie in one part, every other unit is a BOUNDARY unit.  The two kinds are coloured
+// independently of each other (first fit in the same priority order, candidate A only, a unit conflicting with the units OF ITS
+// KIND on its dynamic bodies), and in the group that holds the component the interior classes come first:
+//   classes [0, KI)   the interior units of the group's partitioned components — class c of every one of them; KI = the largest
+//                     interior class count among them (0 if there are none: then nothing here changes anything);
+//   classes [KI, ..)  everything else of the group: the boundary units of the partitioned components and the units of its other
+//                     components, each component's classes renumbered densely from KI.
+// Interior units of different parts share no body, so the classes [0, KI) of one sweep need no synchronisation ACROSS parts:
+// one launch sweeps them all, a workgroup per part with the part's bodies in LDS and a barrier per class (k_solve_parts);
+// only the boundary classes remain launches of their own.  Like every colouring it is one more legal Gauss-Seidel order, a
+// pure function of the component (its joints' bodies and ids), hence the same in every island mode and on every rank.
+constexpr int PART_BODIES = 512;
+__host__ __device__ inline bool unit_is_interior(unsigned a, unsigned b, bool a_static, bool b_static)
+{
+    return !a_static && !b_static && a / (unsigned)PART_BODIES == b / (unsigned)PART_BODIES;
+}
 
 __host__ __device__ inline int colour_pick_two_ended(unsigned long long used_mask, int k_limit, bool from_top)
 {
@@ -80,6 +100,10 @@ struct Schedule {
     int hbm_body_count = 0;               // = hbm_bodies.size() when the list is on the host; a device-built list lives in HBM only
     std::vector<int> hbm_colour_offsets;  // slots of the HBM group's classes (absolute), empty if there is no HBM group
     std::vector<int> hbm_class_leaders;   // per class of the HBM group: its leaders (the slots behind them are the followers)
+    int hbm_interior_classes = 0;         // KI: the HBM group's leading classes that hold interior units of partitioned components only
+    // the interior units by part (host-built schedules; the device builder leaves its tables in HBM): leader slots sorted by
+    // (part, class, slot), and per part the begin of every interior class in that list ((KI + 1) entries per part)
+    std::vector<int> part_units, part_class_begin;
     // units of the LDS groups, in class order: slots of a unit's leader and follower (-1: none); group g's units are
     // [group_unit_offsets[g], group_unit_offsets[g + 1])
     std::vector<int> group_unit_offsets, unit_leader, unit_follower;

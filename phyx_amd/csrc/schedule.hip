@@ -73,47 +73,17 @@ struct ColourScratch {
 // joints between two static bodies may carry -1).
 static int colour_joints(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
                          int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id, const std::vector<int>& comp,
-                         const std::vector<int>& partner)
+                         const std::vector<int>& partner, int* interior_classes = nullptr)
 {
     colour.assign(joints.size(), 0);
+    if (interior_classes) *interior_classes = 0;
     std::vector<int> perm;
     priority_order(joints, prio_id, perm);
-    // candidate A: smallest free colour (masks widen beyond 64 colours on demand)
-    std::vector<int> col_a(joints.size(), 0);
-    for (;;) {
-        sc.ensure(nb);
-        const int words = sc.words;
-        unsigned long long* used = sc.used.data();
-        bool overflow = false;
-        size_t done = 0;
-        for (size_t i = 0; i < joints.size(); ++i) {
-            const size_t k = (size_t)perm[i];
-            const int a = body1[joints[k]], b = body2[joints[k]];
-            const bool da = !is_static[a], db = !is_static[b];
-            int c = -1;
-            for (int w = 0; w < words; ++w) {
-                unsigned long long m = 0;
-                if (da) m |= used[(size_t)a * words + w];
-                if (db) m |= used[(size_t)b * words + w];
-                if (~m) { c = w * 64 + __builtin_ctzll(~m); break; }
-            }
-            if (c < 0) { overflow = true; break; }
-            col_a[k] = c;
-            if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
-            if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
-            done = i + 1;
-        }
-        for (size_t i = 0; i < done; ++i)                      // leave the scratch clean for the next caller
-            for (int body : {body1[joints[perm[i]]], body2[joints[perm[i]]]})
-                for (int w = 0; w < words; ++w) used[(size_t)body * words + w] = 0ull;
-        if (!overflow) break;
-        sc.words *= 2;                                         // > 64 * words colours needed: widen the masks and redo
-        sc.used.clear();
-    }
-    // candidate B: two-ended (schedule.h), one 64-bit mask per body; a component it cannot colour within 64 colours keeps A
-    std::vector<int> col_b(joints.size(), 0);
+    // components, densely numbered; the big ones are PARTITIONED: their interior units form a kind of their own (schedule.h)
     std::vector<unsigned char> comp_bad;                       // per dense component (also set for components too big for B)
     std::vector<int> dense(joints.size());
+    std::vector<unsigned char> interior(joints.size(), 0);
+    bool any_interior = false;
     {
         std::vector<std::pair<int, int>> keyed(joints.size());
         for (size_t k = 0; k < joints.size(); ++k) keyed[k] = {comp[k], (int)k};
@@ -127,8 +97,53 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
         std::vector<int> size(count, 0);
         for (size_t k = 0; k < joints.size(); ++k) size[dense[k]] += partner[joints[k]] >= 0 ? 2 : 1;      // joints of the component, not units
         for (int d = 0; d < count; ++d) if (size[d] > COLOUR_B_MAX_JOINTS) comp_bad[d] = 1;      // B is not attempted there (schedule.h)
+        for (size_t k = 0; k < joints.size(); ++k) {
+            const int a = body1[joints[k]], b = body2[joints[k]];
+            if (comp[k] >= 0 && size[dense[k]] > COLOUR_B_MAX_JOINTS && unit_is_interior((unsigned)a, (unsigned)b, is_static[a] != 0, is_static[b] != 0)) {
+                interior[k] = 1; any_interior = true;
+            }
+        }
         for (size_t k = 0; k < joints.size(); ++k) if (comp[k] < 0) comp_bad[dense[k]] = 1;      // static-static joints: colour 0 either way
     }
+    // candidate A: smallest free colour (masks widen beyond 64 colours on demand).  Interior units keep masks of their own: rows
+    // nb .. 2 nb of the scratch
+    std::vector<int> col_a(joints.size(), 0);
+    const int rows = any_interior ? 2 * nb : nb;
+    for (;;) {
+        sc.ensure(rows);
+        const int words = sc.words;
+        unsigned long long* used = sc.used.data();
+        bool overflow = false;
+        size_t done = 0;
+        for (size_t i = 0; i < joints.size(); ++i) {
+            const size_t k = (size_t)perm[i];
+            const int shift = interior[k] ? nb : 0;
+            const int a = body1[joints[k]] + shift, b = body2[joints[k]] + shift;
+            const bool da = !is_static[a - shift], db = !is_static[b - shift];
+            int c = -1;
+            for (int w = 0; w < words; ++w) {
+                unsigned long long m = 0;
+                if (da) m |= used[(size_t)a * words + w];
+                if (db) m |= used[(size_t)b * words + w];
+                if (~m) { c = w * 64 + __builtin_ctzll(~m); break; }
+            }
+            if (c < 0) { overflow = true; break; }
+            col_a[k] = c;
+            if (da) used[(size_t)a * words + c / 64] |= 1ull << (c % 64);
+            if (db) used[(size_t)b * words + c / 64] |= 1ull << (c % 64);
+            done = i + 1;
+        }
+        for (size_t i = 0; i < done; ++i) {                    // leave the scratch clean for the next caller
+            const int shift = interior[perm[i]] ? nb : 0;
+            for (int body : {body1[joints[perm[i]]] + shift, body2[joints[perm[i]]] + shift})
+                for (int w = 0; w < words; ++w) used[(size_t)body * words + w] = 0ull;
+        }
+        if (!overflow) break;
+        sc.words *= 2;                                         // > 64 * words colours needed: widen the masks and redo
+        sc.used.clear();
+    }
+    // candidate B: two-ended (schedule.h), one 64-bit mask per body; a component it cannot colour within 64 colours keeps A
+    std::vector<int> col_b(joints.size(), 0);
     {
         sc.ensure(nb);
         const int words = sc.words;
@@ -157,20 +172,49 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
     const size_t ncomp = comp_bad.size();
     std::vector<int> max_a(ncomp, -1);
     std::vector<unsigned long long> seen_a(ncomp, 0ull), seen_b(ncomp, 0ull);
+    int ki = 0;                                                // interior classes of the group (first fit leaves no gaps inside a component and kind)
     for (size_t k = 0; k < joints.size(); ++k) {
+        if (interior[k]) { ki = std::max(ki, col_a[k] + 1); continue; }
         max_a[dense[k]] = std::max(max_a[dense[k]], col_a[k]);
         if (col_a[k] < 64) seen_a[dense[k]] |= 1ull << col_a[k];
         seen_b[dense[k]] |= 1ull << col_b[k];
     }
-    int ncolours = 0;
+    int ncolours = ki;
     for (size_t k = 0; k < joints.size(); ++k) {
+        if (interior[k]) { colour[k] = col_a[k]; continue; }
         const int d = dense[k];
         const int count_a = max_a[d] + 1;                      // candidate A leaves no gaps inside a component
         const bool use_b = !comp_bad[d] && __builtin_popcountll(seen_b[d]) < count_a;
-        colour[k] = use_b ? __builtin_popcountll(seen_b[d] & ((1ull << col_b[k]) - 1ull)) : col_a[k];
+        colour[k] = ki + (use_b ? __builtin_popcountll(seen_b[d] & ((1ull << col_b[k]) - 1ull)) : col_a[k]);
         ncolours = std::max(ncolours, colour[k] + 1);
     }
+    if (interior_classes) *interior_classes = ki;
     return ncolours;
+}
+
+// the interior units of the HBM group by part (schedule.h): leader slots sorted by (part, class, slot) + per part the begin of
+// every interior class
+static void build_part_tables(Schedule& out, const int* body1, int nb)
+{
+    out.part_units.clear(); out.part_class_begin.clear();
+    const int ki = out.hbm_interior_classes;
+    if (ki <= 0) return;
+    const int parts = (nb + PART_BODIES - 1) / PART_BODIES;
+    std::vector<int> count((size_t)parts * ki + 1, 0);
+    for (int c = 0; c < ki; ++c) {
+        const int cb = out.hbm_colour_offsets[c], lead = out.hbm_class_leaders[c];
+        for (int s = cb; s < cb + lead; ++s) count[(size_t)(body1[out.order[s]] / PART_BODIES) * ki + c + 1]++;
+    }
+    for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
+    out.part_units.resize(count.back());
+    std::vector<int> cur(count.begin(), count.end() - 1);
+    for (int c = 0; c < ki; ++c) {
+        const int cb = out.hbm_colour_offsets[c], lead = out.hbm_class_leaders[c];
+        for (int s = cb; s < cb + lead; ++s) out.part_units[cur[(size_t)(body1[out.order[s]] / PART_BODIES) * ki + c]++] = s;
+    }
+    out.part_class_begin.resize((size_t)parts * (ki + 1));
+    for (int p = 0; p < parts; ++p)
+        for (int c = 0; c <= ki; ++c) out.part_class_begin[(size_t)p * (ki + 1) + c] = count[(size_t)p * ki + c];
 }
 
 // append one group made of the units led by `leaders`, coloured by `colour`: class by class, the leaders that have a follower
@@ -235,10 +279,11 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
         const int j = leaders[k];
         comp[k] = (is_static[body1[j]] && is_static[body2[j]]) ? -1 : number[root[is_static[body1[j]] ? body2[j] : body1[j]]];
     }
-    const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, comp, partner);
+    const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, comp, partner, &out.hbm_interior_classes);
     if (nj) {
         append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
+        build_part_tables(out, body1, nb);
     }
     out.lds_groups = 0;
     out.islands = false;
@@ -543,10 +588,11 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         std::vector<int> leaders, colour, rest_comp;
         for (int j : rest) if (!is_follower(partner, prio_id, j)) { leaders.push_back(j); rest_comp.push_back(comp_of[j]); }
         ColourScratch scratch;
-        const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp, partner);
+        const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp, partner, &out.hbm_interior_classes);
         const size_t first = out.colour_offsets.size() - 1;
         append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
+        build_part_tables(out, body1, nb);
         touched_bodies(rest, body1, body2, nb, out.hbm_bodies);
         out.hbm_body_count = (int)out.hbm_bodies.size();
     }

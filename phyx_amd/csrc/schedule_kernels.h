@@ -576,6 +576,7 @@ constexpr unsigned JP_NONE = 0xFFFFFFFFu;
 constexpr int JP_MAX_COLOURS = 64;
 constexpr int JP_LIST_MAX = 4096;            // longer lists (one body in thousands of joints): host builder
 constexpr unsigned JP_STATIC_BIT = 0x80000000u;
+constexpr unsigned char JP_INTERIOR = 4;
 constexpr int JP_FRONT_T = 256;       // lanes per workgroup of a round (1024 was measured slower: a 5e4-entry frontier then covers 50 CUs)
 constexpr int JP_SUBLISTS = 8;        // a frontier is kept as 8 lists with a counter each: same-address atomics with a return value cost ~35 ns
                                       // apiece, serialised — one counter made them half of a round
@@ -598,7 +599,9 @@ struct JpView {
     unsigned* colour_b;               // per entry: candidate B's colour
     const int* joint_comp;            // joint -> connected component (-1: both bodies static)
     const int* partner;               // joint -> the other joint of its unit, or -1
-    unsigned char* kind;              // per entry: 0 leads a unit of two, 1 a unit of one, 2 follower (takes no part in the colouring)
+    unsigned char* kind;              // per entry: 0 leads a unit of two, 1 a unit of one, 2 follower (takes no part in the colouring);
+                                      // | JP_INTERIOR: an interior unit of a partitioned component (schedule.h) — it is coloured on the
+                                      // masks used_b / seen_b / colour_b, which candidate B never touches in a component that big
     int ncomp;
     unsigned long long* seen_a;       // per component (entry ncomp = the static-static joints): colours in use under A / B
     unsigned long long* seen_b;
@@ -607,7 +610,8 @@ struct JpView {
     unsigned* colour;                 // per entry: JP_NONE until coloured
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
     int* counts;                      // per round and sublist: size of the frontier it colours
-    int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX
+    int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX;
+                                      // flags[1] = KI, the group's interior classes (k_jp_interior_classes)
     unsigned* hist;                   // per sort key 2 * class + kind: leaders (filled by the choice)
 };
 
@@ -622,7 +626,7 @@ static __global__ void __launch_bounds__(256) k_jp_clear(JpView v, int rounds_ma
     for (int i = i0; i <= v.ncomp; i += stride) { v.seen_a[i] = 0ull; v.seen_b[i] = 0ull; v.bad_b[i] = 0; }
     for (int i = i0; i < (rounds_max + 1) * JP_SUBLISTS; i += stride) v.counts[i] = 0;
     if (i0 < 2 * JP_MAX_COLOURS) v.hist[i0] = 0u;
-    if (i0 == 0) *v.flags = 0;
+    if (i0 == 0) { v.flags[0] = 0; v.flags[1] = 0; }
 }
 
 static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
@@ -636,7 +640,11 @@ static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
         { const int jc = v.joint_comp[j]; v.ent_comp[k] = jc < 0 ? (unsigned)v.ncomp : (unsigned)jc; }
         v.succ[k] = make_uint2(JP_NONE, JP_NONE);
         const int mate = v.partner[j];
-        const unsigned char kind = mate < 0 ? 1 : ((jt.contact_point_index & 1) ? 2 : 0);
+        unsigned char kind = mate < 0 ? 1 : ((jt.contact_point_index & 1) ? 2 : 0);
+        if (kind != 2 && a < (unsigned)v.nb && b < (unsigned)v.nb) {
+            const int jc = v.joint_comp[j];
+            if (jc >= 0 && v.comp_size[jc] > (unsigned)COLOUR_B_MAX_JOINTS && unit_is_interior(a, b, v.is_static[a] != 0, v.is_static[b] != 0)) kind |= JP_INTERIOR;
+        }
         v.kind[k] = kind;
         if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) {                  // reported; the entry is parked on nothing
             atomicOr(v.flags, 1);
@@ -644,7 +652,7 @@ static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
             continue;
         }
         v.touched[a] = 1u; v.touched[b] = 1u;
-        if (kind == 2) {                                                   // a follower: its leader colours the unit
+        if ((kind & 3) == 2) {                                             // a follower: its leader colours the unit
             v.ent[k] = make_uint4(JP_STATIC_BIT, JP_STATIC_BIT, (unsigned)key, (unsigned)(key >> 32));
             continue;
         }
@@ -696,7 +704,7 @@ static __global__ void __launch_bounds__(256) k_jp_lists(JpView v)
 // round 0's frontier: flag the entries that wait for nobody, scan, compact
 static __global__ void __launch_bounds__(256) k_jp_seed_flags(JpView v, unsigned* __restrict__ flags)
 {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u && v.kind[k] != 2) ? 1u : 0u;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u && (v.kind[k] & 3) != 2) ? 1u : 0u;
 }
 
 static __global__ void __launch_bounds__(256) k_jp_seed(JpView v, const unsigned* __restrict__ scan, unsigned* __restrict__ list_out)
@@ -740,15 +748,26 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
                 const unsigned a = e.x & ~JP_STATIC_BIT, b = e.y & ~JP_STATIC_BIT;
                 comp = (int)v.ent_comp[k];
                 unsigned long long m = 0;
+                int c = 0;
+                if (v.kind[k] & JP_INTERIOR) {                // a kind of its own: its own masks, its own classes (both bodies are dynamic)
+                    m = v.used_b[a] | v.used_b[b];
+                    if (!~m) atomicOr(v.flags, 2);
+                    else {
+                        c = __builtin_ctzll(~m);
+                        v.used_b[a] |= 1ull << c; v.used_b[b] |= 1ull << c;
+                        got_b = 1ull << c;
+                        v.colour_b[k] = (unsigned)c;
+                    }
+                } else {
                 if (da) m |= v.used[a];
                 if (db) m |= v.used[b];
-                int c = 0;
                 if (!~m) atomicOr(v.flags, 2);
                 else {
                     c = __builtin_ctzll(~m);
                     if (da) v.used[a] |= 1ull << c;
                     if (db) v.used[b] |= 1ull << c;
                     got_a = 1ull << c;
+                }
                 }
                 if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
                     unsigned long long mb = 0;
@@ -805,20 +824,32 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
     }
 }
 
-// every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order
+// KI = the largest interior class count among the group's partitioned components (schedule.h)
+static __global__ void __launch_bounds__(256) k_jp_interior_classes(JpView v)
+{
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < v.ncomp; c += gridDim.x * blockDim.x)
+        if (v.comp_size[c] > (unsigned)COLOUR_B_MAX_JOINTS && v.seen_b[c]) atomicMax(v.flags + 1, __popcll(v.seen_b[c]));
+}
+
+// every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order; the
+// interior classes of the partitioned components come first, everything else is numbered from KI
 static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
 {
     __shared__ unsigned h[2 * JP_MAX_COLOURS];
     if (threadIdx.x < 2 * JP_MAX_COLOURS) h[threadIdx.x] = 0;
     __syncthreads();
+    const unsigned ki = (unsigned)v.flags[1];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
-        const unsigned char kind = v.kind[k];
+        const unsigned char kind = v.kind[k] & 3;
         if (kind == 2) { v.colour[k] = 255u; continue; }                         // followers sort behind every leader; their leaders place them
         const int comp = (int)v.ent_comp[k];
         const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
-        const bool use_b = comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS && !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
-        const unsigned c = use_b ? v.colour_b[k] : v.colour[k];
-        const unsigned cls = (unsigned)__popcll((use_b ? sb : sa) & ((1ull << c) - 1ull));
+        const bool interior = (v.kind[k] & JP_INTERIOR) != 0;
+        const bool use_b = !interior && comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS && !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
+        const unsigned c = (use_b || interior) ? v.colour_b[k] : v.colour[k];
+        unsigned cls = (unsigned)__popcll(((use_b || interior) ? sb : sa) & ((1ull << c) - 1ull));
+        if (!interior) cls += ki;
+        if (cls >= (unsigned)JP_MAX_COLOURS) { atomicOr(v.flags, 2); cls = JP_MAX_COLOURS - 1; }
         const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single'
         v.colour[k] = key;
         atomicAdd(&h[key & (2 * JP_MAX_COLOURS - 1)], 1u);
@@ -848,6 +879,37 @@ static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigne
         const unsigned r = (unsigned)p - lead_begin[c];
         order_out[slot_begin[c] + r] = j;
         if (!(key & 1u)) order_out[slot_begin[c] + lead_n[c] + r] = v.partner[j];
+    }
+}
+
+// ---- the interior units by part (schedule.h, k_solve_parts) -------------------------------------------------------------
+// class_tab[c] = {first slot, leaders, followers, leaders of the classes before c}: leader number i of the interior classes
+// is slot tab.x + (i - tab.w) of class c; its key = part * 64 + c, sorted (stable) they are in (part, class, slot) order
+static __global__ void __launch_bounds__(256) k_part_keys(const int* __restrict__ order, const phx_contact_joint* __restrict__ joints,
+                                                         const int4* __restrict__ class_tab, int ki, int leaders,
+                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    __shared__ int4 tab[JP_MAX_COLOURS];
+    if ((int)threadIdx.x < ki) tab[threadIdx.x] = class_tab[threadIdx.x];
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
+        int c = 0;
+        while (c + 1 < ki && i >= tab[c + 1].w) ++c;
+        const int s = tab[c].x + (i - tab[c].w);
+        const unsigned part = (unsigned)joints[order[s]].body1 / (unsigned)PART_BODIES;
+        keys[i] = part * (unsigned)JP_MAX_COLOURS + (unsigned)c;
+        vals[i] = (unsigned)s;
+    }
+}
+
+// class_begin[part * (ki + 1) + c] = the first sorted position whose key is >= part * 64 + c
+static __global__ void __launch_bounds__(256) k_part_table(const unsigned* __restrict__ sorted_keys, int n, int parts, int ki, int* __restrict__ class_begin)
+{
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < parts * (ki + 1); t += gridDim.x * blockDim.x) {
+        const unsigned key = (unsigned)(t / (ki + 1)) * (unsigned)JP_MAX_COLOURS + (unsigned)(t % (ki + 1));
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid; }
+        class_begin[t] = lo;
     }
 }
 

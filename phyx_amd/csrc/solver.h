@@ -31,6 +31,13 @@ struct SolverView {
     int* disp_active;
 };
 
+// the interior units of partitioned components by part (schedule.h; solver_kernels.h k_solve_parts)
+struct PartsView {
+    const int* units;           // leader slots of the interior units, sorted by (part, class, slot)
+    const int* class_begin;     // per part: KI + 1 offsets into units[]
+    const int4* class_tab;      // per class of the HBM group: {first slot, leaders, followers, leaders of the classes before}
+    int ki, parts;
+};
 
 class DeviceSolver {
 public:
@@ -54,6 +61,14 @@ public:
     int get_island_trace(unsigned long long* out, int cap_groups, int* groups);
     int get_wave_trace(unsigned long long* out, int cap_words, int* waves_per_group);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
+    int get_partition(int* interior_classes, int* parts, int* sweep_launches)
+    {
+        PHX_TRY(synchronize());
+        if (interior_classes) *interior_classes = sched_.hbm_interior_classes;
+        if (parts) *parts = parts_in_use() ? part_count_ : 0;
+        if (sweep_launches) *sweep_launches = sweep_launches_;
+        return PHX_OK;
+    }
     int get_refreshed(int joint, float out30[30]);
     int bench_stage(const void* d_bodies, int nb, const void* d_joints, int nj, int steps);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
@@ -138,6 +153,15 @@ private:
     DevBuf<int> order_, static_slot_, flags_;
     DevBuf<int4> grp_desc_;
     DevBuf<int> grp_ncol_, grp_units_, grp_bodies_, isl_stats_, hbm_body_list_;
+    // the interior units of partitioned components by part (schedule.h, k_solve_parts)
+    DevBuf<int> part_units_, part_class_begin_;
+    DevBuf<int4> hbm_class_tab_;
+    int part_count_ = 0;                 // workgroups of k_solve_parts (0: the schedule has no interior classes)
+    bool no_parts_ = false;              // PHX_NO_PARTS=1: sweep the interior classes one launch each (A/B measurements, tests)
+    int upload_class_tab(const Schedule& sc, int* interior_leaders);
+    int upload_part_tables();            // host-built schedules: part_units_ / part_class_begin_ from sched_
+    bool parts_in_use() const { return !no_parts_ && part_count_ > 0 && sched_.hbm_interior_classes > 0; }
+    PartsView parts_view() const { return PartsView{part_units_.p, part_class_begin_.p, hbm_class_tab_.p, sched_.hbm_interior_classes, part_count_}; }
     DevBuf<int4> unit_recs_;            // per LDS group (stride = lanes of the kernel shape), two words per unit: joints, contact points, local bodies, class, slots (island_view.h)
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;

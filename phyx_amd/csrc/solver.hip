@@ -88,6 +88,8 @@ int DeviceSolver::init()
     PHX_TRY(isl_shards_.reserve(2 * SHARDS_SET));
     PHX_HIP(hipMemsetAsync(isl_shards_.p, 0, 2 * SHARDS_SET * sizeof(unsigned long long), stream_));
     PHX_HIP(hipDeviceGetAttribute(&cu_count_, hipDeviceAttributeMultiprocessorCount, device_));
+    const char* np = getenv("PHX_NO_PARTS");              // "1": the interior classes of partitioned components one launch each (A/B, tests)
+    no_parts_ = np && np[0] == '1';
     const char* nfv = getenv("PHX_NO_FUSED_VERIFY");      // "1": the topology hash pass in front of every solve on a cached schedule (A/B measurements)
     no_fused_verify_ = nfv && nfv[0] == '1';
     const char* wp = getenv("PHX_ISL_WAIT_POLLS");        // tests: 0 makes every workgroup of a verified launch give up, so that ISL_COMPLETE runs
@@ -364,6 +366,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
     PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sched_.hbm_bodies.size(), 1)));
     if (!sched_.hbm_bodies.empty())
         PHX_HIP(hipMemcpyAsync(hbm_body_list_.p, sched_.hbm_bodies.data(), sched_.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_TRY(upload_part_tables());
     PHX_HIP(hipStreamSynchronize(stream_));
     lap("upload");
     sched_.fingerprint = fp;
@@ -628,6 +631,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         }
         if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d rounds (%d launched)\n", rest, jp_rounds_guess_, round);
         lap("rest/colour");
+        hipLaunchKernelGGL(k_jp_interior_classes, dim3(grid_for(std::max(ncomp_total, 1))), dim3(256), 0, stream_, jv);
         hipLaunchKernelGGL(k_jp_choose, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);          // sort keys (class, kind) + their histogram
         // bodies touched, static slots: two small scans; one readback with the histogram
         unsigned* hist = jv.hist;
@@ -651,8 +655,12 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, sort_scan_, stream_));
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)sflags, nb, static_slot_.p);
         unsigned h_nstatic = 0;
+        int h_flags[2] = {0, 0};                               // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
+        PHX_TRY(rb_.add(h_flags, jp_small_.p, sizeof h_flags, stream_));
         PHX_TRY(rb_.wait(stream_));
+        if (h_flags[0] & 2) { *fallback = true; return PHX_OK; }
+        sc.hbm_interior_classes = h_flags[1];
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
         sc.hbm_colour_offsets.assign(1, lds_slots);
@@ -665,6 +673,25 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         }
         if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
+        // the interior units by part (schedule.h): keys (part, class) of the interior classes' leaders, one stable sort, the table
+        part_count_ = 0;
+        if (sc.hbm_interior_classes > 0) {
+            const int ki = sc.hbm_interior_classes;
+            if (ki >= (int)sc.hbm_class_leaders.size() + 1 || ki > JP_MAX_COLOURS) { set_error("interior classes out of range"); return PHX_ERR_STATE; }
+            int interior_leaders = 0;
+            PHX_TRY(upload_class_tab(sc, &interior_leaders));
+            const int parts = div_up(nb, PART_BODIES);
+            int bits = 6;
+            while ((1 << (bits - 6)) < parts) ++bits;
+            PHX_TRY(part_units_.reserve(njs)); PHX_TRY(part_class_begin_.reserve((size_t)parts * (ki + 1)));
+            hipLaunchKernelGGL(k_part_keys, dim3(grid_for(interior_leaders)), dim3(256), 0, stream_, (const int*)order_.p, (const phx_contact_joint*)d_joints,
+                               (const int4*)hbm_class_tab_.p, ki, interior_leaders, jp_keys_[0].p, jp_vals_[0].p);
+            int where3 = 0;
+            PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, interior_leaders, bits, sort_hist_.p, sort_scan_, stream_, &where3));
+            PHX_HIP(hipMemcpyAsync(part_units_.p, jp_vals_[where3].p, (size_t)interior_leaders * sizeof(int), hipMemcpyDeviceToDevice, stream_));
+            hipLaunchKernelGGL(k_part_table, dim3(grid_for(parts * (ki + 1))), dim3(256), 0, stream_, (const unsigned*)jp_keys_[where3].p, interior_leaders, parts, ki, part_class_begin_.p);
+            part_count_ = parts;
+        }
         PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs));
         PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs)); PHX_TRY(qn_.reserve(njs));
         PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
@@ -792,6 +819,42 @@ int DeviceSolver::materialise_schedule()
 //   pre    PrepareBodies, PrepareJoints+RefreshJoints, PreStepJoints class by class
 //   sweeps `iters` x colours fused impulse+displacement launches
 //   post   FinishJoints, FinishBodies
+// class_tab[c] = {first slot, leaders, followers, leaders of the classes before c} of the HBM group's classes (k_solve_parts)
+int DeviceSolver::upload_class_tab(const Schedule& sc, int* interior_leaders)
+{
+    std::vector<int4> tab(sc.hbm_class_leaders.size());
+    int before = 0;
+    *interior_leaders = 0;
+    for (size_t c = 0; c < tab.size(); ++c) {
+        const int cb = sc.hbm_colour_offsets[c], lead = sc.hbm_class_leaders[c];
+        tab[c] = make_int4(cb, lead, sc.hbm_colour_offsets[c + 1] - cb - lead, before);
+        before += lead;
+        if ((int)c < sc.hbm_interior_classes) *interior_leaders = before;
+    }
+    PHX_TRY(hbm_class_tab_.reserve(std::max<size_t>(tab.size(), 64)));
+    PHX_HIP(hipMemcpyAsync(hbm_class_tab_.p, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));            // (tab is a local)
+    return PHX_OK;
+}
+
+// host-built schedules: the interior units by part as the builder left them (schedule.hip build_part_tables)
+int DeviceSolver::upload_part_tables()
+{
+    part_count_ = 0;
+    const int ki = sched_.hbm_interior_classes;
+    if (ki <= 0 || sched_.part_units.empty()) return PHX_OK;
+    if (ki > 64) return PHX_OK;                        // (the kernel's class loop is unbounded, but keep the device builder's limit: one launch per class then)
+    int interior_leaders = 0;
+    PHX_TRY(upload_class_tab(sched_, &interior_leaders));
+    if (interior_leaders != (int)sched_.part_units.size()) { set_error("part tables do not match the interior classes"); return PHX_ERR_STATE; }
+    PHX_TRY(part_units_.reserve(sched_.part_units.size())); PHX_TRY(part_class_begin_.reserve(sched_.part_class_begin.size()));
+    PHX_HIP(hipMemcpyAsync(part_units_.p, sched_.part_units.data(), sched_.part_units.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipMemcpyAsync(part_class_begin_.p, sched_.part_class_begin.data(), sched_.part_class_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    part_count_ = (int)(sched_.part_class_begin.size() / (size_t)(ki + 1));
+    return PHX_OK;
+}
+
 int DeviceSolver::enqueue_pre(const BodyView& d_bodies, int nb, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj)
 {
     const SolverView v = view();
@@ -805,7 +868,12 @@ int DeviceSolver::enqueue_pre(const BodyView& d_bodies, int nb, const phx_contac
                            hbm_bodies, sb_imp_.p, sb_disp_.p, v.stamps);
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
-        for (size_t c = 0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
+        size_t c0 = 0;
+        if (parts_in_use()) {          // the interior classes of partitioned components: one launch, a workgroup per part
+            hipLaunchKernelGGL(k_prestep_parts, dim3(part_count_), dim3(PARTS_T), 0, stream_, v, parts_view());
+            c0 = (size_t)sched_.hbm_interior_classes;
+        }
+        for (size_t c = c0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
             const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1], lead = sched_.hbm_class_leaders[c];
             hipLaunchKernelGGL(k_prestep, dim3(grid_for(lead)), dim3(256), 0, stream_, v, cb, lead, ce - cb - lead);
         }
@@ -865,7 +933,17 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
         const int ncol = (int)sched_.hbm_colour_offsets.size() - 1;
         for (int it = 0; it < iters; ++it) {
             const bool imp = it < ci, disp = it < pi;
-            for (int c = 0; c < ncol; ++c) {
+            int c0 = 0;
+            if (parts_in_use()) {      // classes [0, KI) of this sweep in one launch (solver_kernels.h k_solve_parts)
+                const dim3 g(part_count_), b(PARTS_T);
+                const PartsView pv = parts_view();
+                if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true>), g, b, 0, stream_, v, pv, it);
+                else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false>), g, b, 0, stream_, v, pv, it);
+                else             hipLaunchKernelGGL((k_solve_parts<false, true>), g, b, 0, stream_, v, pv, it);
+                ++sweep_launches_;
+                c0 = sched_.hbm_interior_classes;
+            }
+            for (int c = c0; c < ncol; ++c) {
                 const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1], lead = sched_.hbm_class_leaders[c], foll = ce - cb - lead;
                 const dim3 g(std::max(1, std::min(div_up(lead, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
                 if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, lead, foll, c, it);

@@ -399,6 +399,98 @@ static __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView 
     if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
 }
 
+// ---- the interior classes of partitioned components: ONE launch per sweep (schedule.h) ------------------------------------
+// A merged island (a settled pile: 1e5-1e6 joints in one connected component) is swept class by class out of HBM, one launch
+// per class and sweep.  Its interior units — both bodies in one PART of PART_BODIES consecutive indices — occupy the leading
+// classes [0, KI) of the HBM group, and parts share no body: here a workgroup takes one part, holds the part's body
+// velocities in LDS, and sweeps the part's units class by class with a barrier where the HBM path has a kernel boundary.
+// Joint constants and accumulators stay where the HBM path keeps them (q0..q3, acc, dd in schedule order); the arithmetic is
+// solve_one()'s, the slot order is the schedule's: results are bit-identical to KI launches of k_solve_colour.
+// Interior units touch no static body, so the static tags play no part.
+constexpr int PARTS_T = 256;
+// (Measured, settled 200k-box world, 392 parts of ~1050 units in 12 classes: this form — constants requested inside the class
+//  step, ~60 VGPRs — takes ~31 us per sweep: with 1.5 workgroups per CU a class step pays its memory round trip in full.
+//  Keeping the constants of a lane's units in registers across the class steps, all loads in flight up front, was built three
+//  ways — 512 lanes x 3 units, 256 x 5, 256 x 4 with a slimmed record: 57 / 42 us and spills: 33 words per unit x 4-5 units
+//  do not fit 256 VGPRs next to the sweep's own, and above 128 the parts no longer fit the machine in one round.)
+
+template <bool DO_IMP, bool DO_DISP>
+static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, PartsView pv, int iter)
+{
+    __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
+    __shared__ float4 s_disp[DO_DISP ? PART_BODIES : 1];
+    const int part = blockIdx.x, tid = threadIdx.x;
+    const int* cls = pv.class_begin + (size_t)part * (pv.ki + 1);
+    if (cls[0] == cls[pv.ki]) return;                       // nothing of a partitioned component in this part
+    const bool imp_on = DO_IMP;
+    const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
+    if (!imp_on && !disp_on) return;
+    const int base = part * PART_BODIES;
+    const int count = min(PART_BODIES, v.nb - base);
+    for (int i = tid; i < count; i += PARTS_T) {
+        if (DO_IMP) s_imp[i] = v.sb_imp[base + i];
+        if (DO_DISP) { if (disp_on) s_disp[i] = v.sb_disp[base + i]; }
+    }
+    __syncthreads();
+    bool any_imp = false, any_disp = false;
+    for (int c = 0; c < pv.ki; ++c) {
+        const int4 tab = pv.class_tab[c];
+        for (int u = cls[c] + tid; u < cls[c + 1]; u += PARTS_T) {
+            const int s0 = pv.units[u], i = s0 - tab.x;
+            const bool has2 = i < tab.z;
+            const int s1 = tab.x + tab.y + i;
+            HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on, false), q1{};
+            if (has2) q1 = hbm_load(v, s1, imp_on, disp_on, true);
+            const int b1 = q0.k.y - base, b2 = q0.k.z - base;
+            float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
+            if (DO_IMP) { B1 = s_imp[b1]; B2 = s_imp[b2]; }
+            if (DO_DISP) { if (disp_on) { D1 = s_disp[b1]; D2 = s_disp[b2]; } }
+            const float im1 = q0.c.y, ii1 = q0.c.z, im2 = q0.c.w, ii2 = __int_as_float(q0.k.x);
+            bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
+            solve_one(v, s0, q0, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+            if (has2)
+                solve_one(v, s1, q1, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+            if (DO_IMP) { if (dirty_imp) { s_imp[b1] = B1; s_imp[b2] = B2; } }
+            if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < count; i += PARTS_T) {
+        if (DO_IMP) v.sb_imp[base + i] = s_imp[i];
+        if (DO_DISP) { if (disp_on) v.sb_disp[base + i] = s_disp[i]; }
+    }
+    if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
+    if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
+}
+
+// PreStepJoints of the interior classes, the same way (k_prestep's arithmetic and order)
+static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, PartsView pv)
+{
+    __shared__ float4 s_imp[PART_BODIES];
+    const int part = blockIdx.x;
+    const int* cls = pv.class_begin + (size_t)part * (pv.ki + 1);
+    if (cls[0] == cls[pv.ki]) return;
+    const int base = part * PART_BODIES;
+    const int count = min(PART_BODIES, v.nb - base);
+    for (int i = threadIdx.x; i < count; i += PARTS_T) s_imp[i] = v.sb_imp[base + i];
+    __syncthreads();
+    for (int c = 0; c < pv.ki; ++c) {
+        const int4 tab = pv.class_tab[c];
+        for (int u = cls[c] + (int)threadIdx.x; u < cls[c + 1]; u += PARTS_T) {
+            const int s0 = pv.units[u], i = s0 - tab.x;
+            const float4 m = v.q2[s0];
+            const int4 k = v.q3[s0];
+            const float im1 = m.y, ii1 = m.z, im2 = m.w, ii2 = __int_as_float(k.x);
+            float4 B1 = s_imp[k.y - base], B2 = s_imp[k.z - base];
+            prestep_one(v, s0, B1, B2, im1, ii1, im2, ii2, false, false);
+            if (i < tab.z) prestep_one(v, tab.x + tab.y + i, B1, B2, im1, ii1, im2, ii2, false, false);
+            s_imp[k.y - base] = B1; s_imp[k.z - base] = B2;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < count; i += PARTS_T) v.sb_imp[base + i] = s_imp[i];
+}
+
 // ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------
 // The two finish kernels (and the island kernel's epilogue) are the only places that write to the caller's
 // arrays.  They commit only if the topology fingerprint computed for THIS call equals the one the schedule was

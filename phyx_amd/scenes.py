@@ -33,6 +33,22 @@ def stack(nx, ny, x_offset_columns=0):
     return _scene(px, py, np.zeros(n + 1), sx, sy, static)
 
 
+def wall(nx, ny, pitch=10.5):
+    """Ground + ny rows of nx boxes of half-size 5x5 laid like bricks (odd rows shifted by half a pitch), bodies numbered row by
+    row: every box rests on two boxes of the row below, so the whole wall is ONE connected component — the shape of island the
+    HBM path takes (a settled pile), at a size the CPU oracle can still replay (48 x 60: ~1.1e4 joints)."""
+    n = nx * ny
+    r = np.repeat(np.arange(ny, dtype=np.int64), nx)
+    i = np.tile(np.arange(nx, dtype=np.int64), ny)
+    px = np.concatenate([[0.0], (i - nx // 2) * pitch + (r & 1) * 0.5 * pitch]).astype(np.float32)
+    py = np.concatenate([[0.0], 15.0 + 10.0 * r]).astype(np.float32)
+    sx = np.concatenate([[max(nx, 1) * pitch], np.full(n, 5.0)]).astype(np.float32)
+    sy = np.concatenate([[10.0], np.full(n, 5.0)]).astype(np.float32)
+    static = np.zeros(n + 1, dtype=bool)
+    static[0] = True
+    return _scene(px, py, np.zeros(n + 1), sx, sy, static)
+
+
 def clique(n, pitch=0.01):
     """Ground + n boxes of half-size 5x5 dropped almost on top of each other: every box overlaps every other one, so each
     body carries ~2n joints.  More than 64 colours are needed — the case where the device schedule builder hands over to

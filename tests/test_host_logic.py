@@ -27,14 +27,17 @@ def test_falling_scene_is_reproducible():
 
 
 @pytest.mark.parametrize("ids", ["joint_index", "contact_point_index"])
-@pytest.mark.parametrize("name", list(SMALL_SCENES) + ["synthetic_units_and_near_misses"])
+@pytest.mark.parametrize("name", list(SMALL_SCENES) + ["synthetic_units_and_near_misses", "wall48x60"])
 def test_colour_schedule_invariants(built_lib, name, ids):
     """The schedule rule of csrc/schedule.h restated independently in Python: units (the two joints of a body pair whose ids
     differ in the lowest bit), first fit over the units in priority order with two candidates, the choice per connected
-    component, and the layout of a class: leaders that have a follower, single leaders, followers in their leaders' order."""
+    component, the interior / boundary kinds of a component of more than 1024 joints (the wall: one component of 1.1e4), and
+    the layout of a class: leaders that have a follower, single leaders, followers in their leaders' order."""
     if name in SMALL_SCENES:
         make, warm = SMALL_SCENES[name]
         bodies, _, joints = presolve_state(make(), warm)
+    elif name == "wall48x60":
+        bodies, _, joints = presolve_state(scenes.wall(48, 60), 10)      # (the rows come to rest on each other from the bottom up: one component by step 10)
     else:                                                            # couples on random body pairs + the near misses that must not pair
         from test_solver_gpu import _random_state
         bodies, _, joints = _random_state(np.random.default_rng(6), 300, 900, 0.1, units=True)
@@ -86,9 +89,27 @@ def test_colour_schedule_invariants(built_lib, name, ids):
             parent[find(b1[j])] = find(b2[j])
     comp = {j: ("s", j) if static[b1[j]] and static[b2[j]] else ("c", find(b2[j] if static[b1[j]] else b1[j])) for j in leaders}
     degree = np.bincount(np.array([b1[j] for j in leaders] + [b2[j] for j in leaders]), minlength=len(bodies))      # units per body
-    used_a, used_b, col_a, col_b, bad_b = {}, {}, {}, {}, set()
+    size = {}
+    for j in leaders:
+        size[comp[j]] = size.get(comp[j], 0) + (2 if partner[j] >= 0 else 1)          # joints of the component
+    # a component of more than 1024 joints is partitioned: units with both bodies dynamic and in one block of 512 body indices
+    # are INTERIOR, a kind of their own — own masks, own classes, and their classes come first in the group
+    interior = {j: comp[j][0] == "c" and size[comp[j]] > 1024 and not static[b1[j]] and not static[b2[j]] and b1[j] // 512 == b2[j] // 512
+                for j in leaders}
+    assert any(interior.values()) or name != "wall48x60"
+    used_a, used_b, used_i, col_a, col_b, bad_b = {}, {}, {}, {}, {}, set()
     for j in sorted(leaders, key=lambda j: -int(prio[j])):
         dyn = [b for b in (b1[j], b2[j]) if not static[b]]
+        if interior[j]:
+            mi = used_i.get(b1[j], 0) | used_i.get(b2[j], 0)
+            ci = 0
+            while mi >> ci & 1:
+                ci += 1
+            col_a[j] = ci
+            col_b[j] = 0
+            for b in dyn:
+                used_i[b] = used_i.get(b, 0) | 1 << ci
+            continue
         ma = 0
         mb = 0
         for b in dyn:
@@ -115,19 +136,28 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         col_b[j] = cb
         for b in dyn:
             used_a[b] = used_a.get(b, 0) | 1 << ca
-    seen_a, seen_b, size = {}, {}, {}
+    seen_a, seen_b = {}, {}
+    ki = max([col_a[j] + 1 for j in leaders if interior[j]] + [0])                    # the group's interior classes
     for j in leaders:
-        seen_a.setdefault(comp[j], set()).add(col_a[j])
-        seen_b.setdefault(comp[j], set()).add(col_b[j])
-        size[comp[j]] = size.get(comp[j], 0) + (2 if partner[j] >= 0 else 1)          # joints of the component
+        if not interior[j]:
+            seen_a.setdefault(comp[j], set()).add(col_a[j])
+            seen_b.setdefault(comp[j], set()).add(col_b[j])
     for j in leaders:
-        use_b = comp[j] not in bad_b and size[comp[j]] <= 8192 and comp[j][0] == "c" and len(seen_b[comp[j]]) < len(seen_a[comp[j]])
-        chosen, c = (seen_b[comp[j]], col_b[j]) if use_b else (seen_a[comp[j]], col_a[j])
-        assert class_of[j] == sum(1 for x in chosen if x < c), "joint %d" % j
+        if interior[j]:
+            assert class_of[j] == col_a[j] < ki, "joint %d" % j
+        else:
+            use_b = comp[j] not in bad_b and size[comp[j]] <= 1024 and comp[j][0] == "c" and len(seen_b[comp[j]]) < len(seen_a[comp[j]])
+            chosen, c = (seen_b[comp[j]], col_b[j]) if use_b else (seen_a[comp[j]], col_a[j])
+            assert class_of[j] == ki + sum(1 for x in chosen if x < c), "joint %d" % j
         if partner[j] >= 0:
             assert class_of[partner[j]] == class_of[j]
-    # and it never needs more classes than plain first-fit
-    assert len(offs) - 1 <= max(col_a.values()) + 1
+    if name == "wall48x60":
+        # what the partition buys: the interior classes hold most of the units and are one launch per sweep
+        n_int = sum(1 for j in leaders if interior[j])
+        assert n_int > 0.7 * len(leaders) and ki + 1 < len(offs) - 1 <= ki + 8
+    elif not ki:
+        # and it never needs more classes than plain first-fit
+        assert len(offs) - 1 <= max(col_a.values()) + 1
 
 
 @pytest.mark.parametrize("name", list(SMALL_SCENES))

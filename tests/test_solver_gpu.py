@@ -385,6 +385,51 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
         assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
 
 
+@pytest.mark.parametrize("island_mode", [phyx_amd.ISLAND_MULTIPLE, phyx_amd.ISLAND_SINGLE])
+def test_partitioned_component_is_swept_by_parts(oracle, built_lib, monkeypatch, island_mode):
+    """A connected component of more than 1024 joints (here a brick wall: one island of 1.1e4 joints — the shape of a settled pile)
+    is partitioned: units inside one block of 512 bodies get the leading classes of the HBM group and ONE launch per sweep
+    sweeps them all (k_solve_parts), the boundary classes stay one launch each.  Device builder == host builder, the fused
+    launch == one launch per class (PHX_NO_PARTS=1), and all of them == the oracle's replay of the exported schedule."""
+    import os
+    state = presolve_state(scenes.wall(48, 60), 10)
+    assert len(state[2]) > 1024
+    ci, pi = 12, 6
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, island_mode, ci, pi)
+    dev = phyx_amd.Solver(0)
+    monkeypatch.setenv("PHX_SCHEDULE_BUILDER", "host")
+    host = phyx_amd.Solver(0)
+    monkeypatch.delenv("PHX_SCHEDULE_BUILDER")
+    monkeypatch.setenv("PHX_NO_PARTS", "1")
+    plain = phyx_amd.Solver(0)
+    monkeypatch.delenv("PHX_NO_PARTS")
+    gb, gj, sched, _, st = _device_solve(dev, state, cfg)
+    ki, parts, launches = dev.partition()
+    classes = len(sched.colours) - 1
+    assert st.lds_islands == 0 and ki >= 4 and classes - ki >= 1 and parts == (len(state[0]) + 511) // 512
+    sweeps = max(st.impulse_iterations, st.displacement_iterations)
+    assert launches == max(ci, pi) * (1 + classes - ki)            # one launch for the interior classes + one per boundary class
+    hb, hj, hsched, _, hst = _device_solve(host, state, cfg)
+    assert np.array_equal(hsched.order, sched.order) and np.array_equal(hsched.colours, sched.colours) and np.array_equal(hsched.groups, sched.groups)
+    assert host.partition()[:2] == (ki, parts)
+    assert hb.tobytes() == gb.tobytes() and hj.tobytes() == gj.tobytes()
+    pb, pj, psched, _, pst = _device_solve(plain, state, cfg)
+    assert np.array_equal(psched.order, sched.order) and np.array_equal(psched.colours, sched.colours)
+    assert plain.partition() == (ki, 0, max(ci, pi) * classes)
+    assert pb.tobytes() == gb.tobytes() and pj.tobytes() == gj.tobytes()
+    assert (pst.impulse_iterations, pst.displacement_iterations, pst.joint_visits) == (st.impulse_iterations, st.displacement_iterations, st.joint_visits)
+    ob_, oj, ost = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
+    assert (st.impulse_iterations, st.displacement_iterations) == (ost.impulse_iterations, ost.displacement_iterations) and sweeps > 0
+    # interior units: both bodies dynamic, one block of 512 indices; nothing else in the first ki classes
+    b1, b2 = state[2]["body1"], state[2]["body2"]
+    lead = sched.order[:sched.colours[ki]]
+    assert ((b1[lead] // 512) == (b2[lead] // 512)).all() and (state[0]["inv_mass"][b1[lead]] > 0).all() and (state[0]["inv_mass"][b2[lead]] > 0).all()
+    # a second solve on the cached schedule (fingerprint-gated) gives the same bytes
+    gb2, gj2, _, _, st2 = _device_solve(dev, state, cfg)
+    assert st2.recoloured == 0 and gb2.tobytes() == gb.tobytes() and gj2.tobytes() == gj.tobytes()
+
+
 def test_speculative_binning_equals_the_builders_long_way(oracle, built_lib):
     """A rebuild of a world that was nothing but workgroup-sized islands last time makes its bins on the device, with last build's
     bin count as the launch grid and no host round trip (stats.recoloured == 2).  Whatever does not hold any more — more bins than
