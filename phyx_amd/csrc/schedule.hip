@@ -219,9 +219,22 @@ static void build_part_tables(Schedule& out, const int* body1, int nb)
 
 // append one group made of the units led by `leaders`, coloured by `colour`: class by class, the leaders that have a follower
 // (joint order), the single leaders (joint order), then the followers in their leaders' order (schedule.h)
-static void append_group(Schedule& out, const std::vector<int>& leaders, const std::vector<int>& colour, int ncolours, const std::vector<int>& partner,
-                         std::vector<int>* class_leaders)
+// (interior classes — `interior_classes` leading ones, schedule.h — are laid out part by part: leaders ordered by (part, joint),
+//  so that the workgroup that sweeps a part reads its units' constants from consecutive slots)
+static void append_group(Schedule& out, const std::vector<int>& leaders_in, const std::vector<int>& colour_in, int ncolours, const std::vector<int>& partner,
+                         std::vector<int>* class_leaders, int interior_classes = 0, const int* body1 = nullptr)
 {
+    std::vector<int> leaders_sorted, colour_sorted;
+    if (interior_classes > 0) {
+        std::vector<int> idx(leaders_in.size());
+        for (size_t k = 0; k < idx.size(); ++k) idx[k] = (int)k;
+        auto part_of = [&](int k) { return colour_in[k] < interior_classes ? body1[leaders_in[k]] / PART_BODIES : 0; };
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return part_of(x) < part_of(y); });
+        leaders_sorted.resize(idx.size()); colour_sorted.resize(idx.size());
+        for (size_t k = 0; k < idx.size(); ++k) { leaders_sorted[k] = leaders_in[idx[k]]; colour_sorted[k] = colour_in[idx[k]]; }
+    }
+    const std::vector<int>& leaders = interior_classes > 0 ? leaders_sorted : leaders_in;
+    const std::vector<int>& colour = interior_classes > 0 ? colour_sorted : colour_in;
     const int base = (int)out.order.size();
     std::vector<int> with(ncolours, 0), single(ncolours, 0);
     for (size_t k = 0; k < leaders.size(); ++k) (partner[leaders[k]] >= 0 ? with : single)[colour[k]]++;
@@ -281,7 +294,7 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
     }
     const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, comp, partner, &out.hbm_interior_classes);
     if (nj) {
-        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders);
+        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, body1);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
         build_part_tables(out, body1, nb);
     }
@@ -590,7 +603,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         ColourScratch scratch;
         const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp, partner, &out.hbm_interior_classes);
         const size_t first = out.colour_offsets.size() - 1;
-        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders);
+        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, body1);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
         build_part_tables(out, body1, nb);
         touched_bodies(rest, body1, body2, nb, out.hbm_bodies);

@@ -613,6 +613,7 @@ struct JpView {
     int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX;
                                       // flags[1] = KI, the group's interior classes (k_jp_interior_classes)
     unsigned* hist;                   // per sort key 2 * class + kind: leaders (filled by the choice)
+    int part_bits;                    // the sort key of a leader is (2 * class + kind) << part_bits | part (interior units; 0 otherwise)
 };
 
 // every per-body table and the small words in ONE launch (a memset is a dispatch of its own, and there were a dozen)
@@ -841,7 +842,7 @@ static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
     const unsigned ki = (unsigned)v.flags[1];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
         const unsigned char kind = v.kind[k] & 3;
-        if (kind == 2) { v.colour[k] = 255u; continue; }                         // followers sort behind every leader; their leaders place them
+        if (kind == 2) { v.colour[k] = 128u << v.part_bits; continue; }          // followers sort behind every leader; their leaders place them
         const int comp = (int)v.ent_comp[k];
         const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
         const bool interior = (v.kind[k] & JP_INTERIOR) != 0;
@@ -850,15 +851,15 @@ static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
         unsigned cls = (unsigned)__popcll(((use_b || interior) ? sb : sa) & ((1ull << c) - 1ull));
         if (!interior) cls += ki;
         if (cls >= (unsigned)JP_MAX_COLOURS) { atomicOr(v.flags, 2); cls = JP_MAX_COLOURS - 1; }
-        const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single'
-        v.colour[k] = key;
+        const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single', then (interior units) the part
+        v.colour[k] = (key << v.part_bits) | (interior ? (v.ent[k].x & ~JP_STATIC_BIT) / (unsigned)PART_BODIES : 0u);
         atomicAdd(&h[key & (2 * JP_MAX_COLOURS - 1)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 2 * JP_MAX_COLOURS && h[threadIdx.x]) atomicAdd(&v.hist[threadIdx.x], h[threadIdx.x]);
 }
 
-// the leaders, sorted by (class, kind) and stable in joint order, take their slots — and give their followers theirs:
+// the leaders, sorted by (class, kind, part of an interior unit) and stable in joint order, take their slots — and give their followers theirs:
 // class c = [leaders with a follower][single leaders][followers, in their leaders' order]  (hist: leaders per sort key)
 static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigned* __restrict__ sorted_keys, const unsigned* __restrict__ sorted_joints,
                                                         int* __restrict__ order_out)
@@ -874,7 +875,7 @@ static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigne
     __syncthreads();
     const int leaders = (int)(lead_begin[JP_MAX_COLOURS - 1] + lead_n[JP_MAX_COLOURS - 1]);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < leaders; p += gridDim.x * blockDim.x) {
-        const unsigned key = sorted_keys[p], c = key >> 1;
+        const unsigned key = sorted_keys[p] >> v.part_bits, c = key >> 1;
         const int j = (int)sorted_joints[p];
         const unsigned r = (unsigned)p - lead_begin[c];
         order_out[slot_begin[c] + r] = j;

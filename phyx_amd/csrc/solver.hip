@@ -595,6 +595,8 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         jv.joint_comp = joint_comp_.p; jv.partner = partner_.p; jv.kind = jp_kind_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
         jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
         jv.counts = jp_counts_.p; jv.flags = jp_small_.p; jv.hist = reinterpret_cast<unsigned*>(jp_small_.p + 4);
+        jv.part_bits = 0;
+        while ((1 << jv.part_bits) < div_up(nb, PART_BODIES)) ++jv.part_bits;
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
         // priority, successor links and predecessor counts
         hipLaunchKernelGGL(k_jp_clear, dim3(grid_for(std::max(nb + 1, ncomp_total + 1))), dim3(256), 0, stream_, jv, JP_ROUNDS_MAX + 1);
@@ -642,7 +644,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         // and its follower
         int where2 = 0;
         PHX_HIP(hipMemcpyAsync(jp_vals_[0].p, ids, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 8, sort_hist_.p, sort_scan_, stream_, &where2));
+        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 8 + jv.part_bits, sort_hist_.p, sort_scan_, stream_, &where2));
         hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_keys_[where2].p, (const unsigned*)jp_vals_[where2].p, order_.p + lds_slots);
         unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0;
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));

@@ -63,13 +63,14 @@ def test_colour_schedule_invariants(built_lib, name, ids):
     assert sum(follower) > 0 or name == "falling600"
     leaders = [j for j in range(nj) if not follower[j]]
     class_of = np.zeros(nj, dtype=np.int64)
+    layouts = []
     for c in range(len(offs) - 1):
         sl = order[offs[c]:offs[c + 1]].tolist()
         class_of[sl] = c
         lead = [j for j in sl if not follower[j]]
         with_f = [j for j in lead if partner[j] >= 0]
         single = [j for j in lead if partner[j] < 0]
-        assert sl == sorted(with_f) + sorted(single) + [partner[j] for j in sorted(with_f)]      # the layout of a class
+        layouts.append((sl, with_f, single))
         b = np.array([b1[j] for j in lead] + [b2[j] for j in lead])
         b = b[static[b] == 0]
         assert len(np.unique(b)) == len(b), "class %d: two units touch a dynamic body" % c
@@ -142,6 +143,9 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         if not interior[j]:
             seen_a.setdefault(comp[j], set()).add(col_a[j])
             seen_b.setdefault(comp[j], set()).add(col_b[j])
+    for c, (sl, with_f, single) in enumerate(layouts):                # the layout of a class; an interior class is laid out part by part
+        key = (lambda j: (b1[j] // 512, j)) if c < ki else (lambda j: j)
+        assert sl == sorted(with_f, key=key) + sorted(single, key=key) + [partner[j] for j in sorted(with_f, key=key)]
     for j in leaders:
         if interior[j]:
             assert class_of[j] == col_a[j] < ki, "joint %d" % j

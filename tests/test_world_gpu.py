@@ -38,15 +38,19 @@ def _lockstep(oracle, scene, steps, cfg, check_every=1):
     return pw, ow
 
 
-@pytest.mark.parametrize("name,steps", [("stack", 12), ("tilted", 60), ("falling", 50), ("clique", 5)])
+@pytest.mark.parametrize("name,steps", [("stack", 12), ("tilted", 60), ("falling", 50), ("clique", 5), ("wall", 16)])
 @pytest.mark.parametrize("island_mode", [0, 3])
 def test_world_lockstep_bit_exact(oracle, built_lib, name, steps, island_mode):
     scene = {"stack": lambda: scenes.stack(6, 40), "tilted": lambda: scenes.tilted(80),
              "falling": lambda: scenes.falling(500, width=80.0, ymax=300.0),
-             "clique": lambda: scenes.clique(90)}[name]()                  # > 64 colours: host-builder fallback inside a World
+             "clique": lambda: scenes.clique(90),                           # > 64 colours: host-builder fallback inside a World
+             "wall": lambda: scenes.wall(40, 36)}[name]()                   # one island that grows past 1024 joints: partitioned, three parts
     cfg = Configuration(phyx_amd.SOLVE_SCALAR, island_mode, 15, 15)
     pw, ow = _lockstep(oracle, scene, steps, cfg)
     assert len(ow.joints()) > 0
+    if name == "wall":
+        ki, parts, _ = pw.solver.partition()
+        assert ki > 0 and parts == 3
 
 
 def test_late_manifold_pack_is_repeated_bit_exactly(oracle, built_lib):

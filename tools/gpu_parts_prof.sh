@@ -9,3 +9,23 @@ f=$(find /tmp/pp -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/parts/kernel_stats.csv
 head -25 "$f" | cut -c1-200
 tail -3 $R/gpurun_out/parts/prof_stdout.txt | cut -c1-30,330-
+t=$(find /tmp/pp -name "*kernel_trace.csv" | head -1)
+python - "$t" > $R/gpurun_out/parts/last_step.txt <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the last world step starts at the last k_build_keys launch
+idx = max(i for i, r in enumerate(rows) if "k_build_keys" in r["Kernel_Name"])
+step = rows[idx:]
+t0 = int(step[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in step)
+agg = collections.OrderedDict()
+for r in step:
+    n = r["Kernel_Name"].split("(")[0].replace("void phx::", "").replace("phx::", "")
+    a = agg.setdefault(n, [0, 0.0, (int(r["Start_Timestamp"]) - t0) / 1e3])
+    a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+busy = sum(a[1] for a in agg.values())
+print("last step: span %.1f us, %d kernels, busy %.1f us" % ((t1 - t0) / 1e3, len(step), busy))
+for n, a in agg.items():
+    print("%8.1f us first  %4d x  %8.1f us total  %s" % (a[2], a[0], a[1], n))
+PY
+cat $R/gpurun_out/parts/last_step.txt | head -80
