@@ -38,14 +38,16 @@ def run(seed):
         order, offs = pw.solver.schedule(); groups, _ = pw.solver.groups()
         ob.solver_solve_grouped(ow.bodies(), ow.contact_points(), ow.joints(), order, offs, groups, cfg.contactIterationsCount, cfg.penetrationIterationsCount, ob.STAG_COLOUR_SYNC)
         ow.integrate_position(1 / 60)
+        PARTS[0] += 1 if pw.solver.partition()[1] > 0 else 0; PARTS[1] += 1
         if not (pw.bodies.tobytes() == ow.bodies().tobytes() and pw.contactJoints.tobytes() == ow.joints().tobytes() and pw.manifolds.tobytes() == ow.manifolds().tobytes()):
             print("seed %d DIVERGED at step %d (bodies %d, mode %d, iters %d)" % (seed, step, len(sc["px"]), mode, iters)); return False
     return True
 
 
+PARTS = [0, 0]          # steps solved with the partitioned-component path / all steps
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 first = int(args[0]) if len(args) > 0 else 0
 count = int(args[1]) if len(args) > 1 else 40
 t0 = time.time(); bad = [s for s in range(first, first + count) if not run(s)]
-print("fuzz: %d seeds, %d diverged %s, %.0f s" % (count, len(bad), bad, time.time() - t0))
+print("fuzz: %d seeds, %d diverged %s, %.0f s; %d of %d steps took the partitioned-component path" % (count, len(bad), bad, time.time() - t0, PARTS[0], PARTS[1]))
 sys.exit(1 if bad else 0)
