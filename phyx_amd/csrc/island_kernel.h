@@ -93,6 +93,10 @@ __device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2,
     const bool p2 = st2 ? sp2 : (__float_as_int(B2.w) > it - 2);
     productive = false;
     if (!(p1 || p2)) return false;        // (a 'likely' hint on the evaluated path was measured 2 % slower)
+    // (Measured and removed: the x / y halves of every body-wide step as v_pk_mul_f32 / v_pk_add_f32 on the register pairs a
+    //  ds_read_b128 leaves — 24 VALU instructions fewer per unit of ~145, no extra moves, bit-exact — is 3 % SLOWER: the step is a
+    //  dependent chain, a packed fp32 operation occupies the pipe twice as long as a plain one, and nothing waits to fill the slots
+    //  it frees.  DESIGN.md §4.2.)
     const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
     float dv = q.dstV;
     dv -= nx * B1.x; dv -= ny * B1.y; dv -= q.aN1 * B1.z;

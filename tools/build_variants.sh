@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 python -m phyx_amd.build >/dev/null || exit 1
 cp phyx_amd/libphyx_amd.so phyx_amd/lib_v0.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -fno-slp-vectorize -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -fno-slp-vectorize -Wno-unused-function -mllvm -amdgpu-sched-strategy=iterative-ilp"
 i=1
 for extra in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS $extra -c -o /tmp/islands_v$i.o phyx_amd/csrc/islands.hip || exit 1
