@@ -25,3 +25,7 @@ head -12 $O/main_kernel_stats.csv
 head -3 $O/world_step_timeline.txt
 head -14 $O/cfg4_trace_kernel_stats.csv
 head -6 $O/cfg5_trace_kernel_stats.csv
+# the settled world (one merged island, the partitioned-component path): kernel statistics + a per-kernel breakdown of step 62
+$R/tools/gpu_parts_prof.sh 62 > /dev/null 2>&1
+cp $R/gpurun_out/parts/last_step.txt $O/settled_last_step.txt; cp $R/gpurun_out/parts/kernel_stats.csv $O/settled_kernel_stats.csv
+head -5 $O/settled_last_step.txt

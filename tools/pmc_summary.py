@@ -102,7 +102,7 @@ def main(tag, dominant):
             timed = [u for u in us if 0.75 * med <= u <= 1.25 * med]
             out[key] = {"launches": len(us), "grid_size": grid, "median": med, "mean": sum(us) / len(us),
                         "mean_within_25pct_of_median": sum(timed) / len(timed), "min": us[0], "max": us[-1]}
-    for extra in ("world_kernel_stats.csv", "world_step_timeline.txt"):
+    for extra in ("world_kernel_stats.csv", "world_step_timeline.txt", "settled_last_step.txt", "settled_kernel_stats.csv"):
         if os.path.exists(os.path.join(SRC, extra)):
             shutil.copy(os.path.join(SRC, extra), os.path.join(DST, tag + "_" + extra))
     if os.path.exists(os.path.join(SRC, "world_marker_api_stats.csv")):
