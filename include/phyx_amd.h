@@ -364,6 +364,14 @@ int  phx_world_get_bodies(phx_world* w, phx_rigid_body* out, int32_t cap);
 int  phx_world_get_manifolds(phx_world* w, phx_manifold* out, int32_t cap);
 int  phx_world_get_contact_points(phx_world* w, phx_contact_point* out, int32_t cap);
 int  phx_world_get_joints(phx_world* w, phx_contact_joint* out, int32_t cap);
+/* Restore a world from what the four getters above returned (checkpoint / resume; the hand-over of bodies between the ranks of an
+ * ownership-sharded world): bodies, the contact cache — manifolds with their two contact-point slots each, ref: Collider.h:57-58 —
+ * and the joints with their warm-start impulses (ref: World.h:33).  The broadphase's pair set is rebuilt from the manifolds'
+ * body pairs.  A world restored from a saved state steps exactly like the one it was saved from.  Checked: contact_point_count ==
+ * 2 * manifold_count, manifold i owns slots 2i and 2i + 1, every joint's bodies are its manifold's and its contact point's
+ * solver_index points back at it; PHX_ERR_INVALID otherwise.  Any number of bodies (the world's previous content is dropped). */
+int  phx_world_set_state(phx_world* w, const phx_rigid_body* bodies, int32_t body_count, const phx_manifold* manifolds, int32_t manifold_count,
+                         const phx_contact_point* contact_points, int32_t contact_point_count, const phx_contact_joint* joints, int32_t joint_count);
 int  phx_world_get_solve_stats(phx_world* w, phx_solve_stats* out);
 int  phx_world_get_broadphase_stats(phx_world* w, phx_broadphase_stats* out);
 /* handles owned by the world (for stage-level queries after an update) */

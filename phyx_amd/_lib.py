@@ -136,6 +136,7 @@ _SIGNATURES = {
     "phx_world_get_manifolds": (C.c_int, [_vp, _vp, _i32]),
     "phx_world_get_contact_points": (C.c_int, [_vp, _vp, _i32]),
     "phx_world_get_joints": (C.c_int, [_vp, _vp, _i32]),
+    "phx_world_set_state": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32]),
     "phx_world_get_solve_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),
     "phx_world_get_broadphase_stats": (C.c_int, [_vp, C.POINTER(BroadphaseStats)]),
     "phx_world_solver": (_vp, [_vp]),

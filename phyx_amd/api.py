@@ -587,6 +587,16 @@ class World:
     def contactJoints(self):
         return self._get(self.L.phx_world_get_joints, contact_joint_dtype, self.counts()[3])
 
+    def state(self):
+        """(bodies, manifolds, contact points, joints): everything a world carries from one step to the next."""
+        return self.bodies, self.manifolds, self.contactPoints, self.contactJoints
+
+    def set_state(self, bodies, manifolds, contact_points, joints):
+        """Restore a saved state() (phx_world_set_state): the world then steps exactly like the one the state was taken from."""
+        b = np.ascontiguousarray(bodies, dtype=rigid_body_dtype); m = np.ascontiguousarray(manifolds, dtype=manifold_dtype)
+        c = np.ascontiguousarray(contact_points, dtype=contact_point_dtype); j = np.ascontiguousarray(joints, dtype=contact_joint_dtype)
+        check(self.L.phx_world_set_state(self.h, _ptr(b), len(b), _ptr(m), len(m), _ptr(c), len(c), _ptr(j), len(j)))
+
     def sync(self):
         """Wait for the queued step (Update returns once the step is queued; getters synchronise on their own)."""
         check(self.L.phx_world_synchronize(self.h))

@@ -23,6 +23,7 @@ public:
     int get_sorted(phx_sort_entry* sorted, phx_broadphase_entry* entries, int cap);
     int erase_pairs(const uint32_t* pairs, int count);
     int erase_pairs_device(const uint2* d_pairs, int count);      // pairs already in HBM
+    int reset_pairs(const uint2* pairs, int count);               // the pair set becomes exactly these (host) pairs: a world restored from a saved state
     const uint2* new_pairs_device() const { return new_pairs_.p; }   // pairs emitted by the last update, in HBM
     int get_stats(phx_broadphase_stats* out);
     int new_pair_count() const { return last_new_; }

@@ -622,6 +622,26 @@ int DeviceBroadphase::erase_pairs_device(const uint2* d_pairs, int count)
     return PHX_OK;
 }
 
+// the pair set of a restored world (World::set_state): one pair per live manifold, as the broadphase would hold it (ref: Collider.h:58
+// manifoldMap is keyed by the manifold's ordered body pair)
+int DeviceBroadphase::reset_pairs(const uint2* pairs, int count)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(count >= 0 && (count == 0 || pairs), "bad pair list");
+    PHX_TRY(clear());
+    have_update_ = false;
+    if (!count) return PHX_OK;
+    PHX_TRY(resize_table(4u * (unsigned)count + 1024u));
+    PHX_TRY(scratch_pairs_.reserve((size_t)count));
+    PHX_HIP(hipMemcpyAsync(scratch_pairs_.p, pairs, (size_t)count * sizeof(uint2), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(k_ps_insert, dim3(grid_for(count)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)scratch_pairs_.p, count, (unsigned long long*)nullptr);
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipStreamSynchronize(stream_));          // (`pairs` is the caller's)
+    set_size_ = count;
+    stats_.set_size = count;
+    return PHX_OK;
+}
+
 // queue the read of the device's erase counter with a batch the caller is about to wait for ...
 int DeviceBroadphase::queue_erase_check(int* erased)
 {

@@ -44,6 +44,8 @@ public:
     int download_manifolds(phx_manifold* out, int cap);
     int download_contact_points(phx_contact_point* out, int cap);
     int download_joints(phx_contact_joint* out, int cap);
+    int set_state(const phx_rigid_body* bodies, int body_count, const phx_manifold* manifolds, int manifold_count,
+                  const phx_contact_point* cps, int cp_count, const phx_contact_joint* joints, int joint_count);
 
     int nb() const { return (int)host_bodies_.size(); }
     int nm = 0, nj = 0;
@@ -538,6 +540,53 @@ PHX_DOWNLOAD(download_manifolds, phx_manifold, d_manifolds_, nm)
 PHX_DOWNLOAD(download_contact_points, phx_contact_point, d_cps_, 2 * nm)
 PHX_DOWNLOAD(download_joints, phx_contact_joint, d_joints_, nj)
 
+// Restore (or hand over) a whole world: what the four getters return, put back.  The contact cache is the state the reference
+// carries from step to step (ref: Collider.h:57-58 manifolds + manifoldMap, World.h:33 contactJoints with their warm-start
+// impulses, ContactPoint::solverIndex linking the two); everything else a step needs is rebuilt by the step.  Used by
+// checkpoint / resume and by the hand-over of bodies between the ranks of an ownership-sharded world (dist.SlabWorld.reslab).
+int World::set_state(const phx_rigid_body* bodies, int body_count, const phx_manifold* manifolds, int manifold_count,
+                     const phx_contact_point* cps, int cp_count, const phx_contact_joint* joints, int joint_count)
+{
+    PHX_TRY(use_device(device_));
+    PHX_REQUIRE(body_count >= 0 && manifold_count >= 0 && joint_count >= 0 && cp_count == 2 * manifold_count, "bad counts (two contact-point slots per manifold)");
+    PHX_REQUIRE((body_count == 0 || bodies) && (manifold_count == 0 || (manifolds && cps)) && (joint_count == 0 || joints), "null array");
+    PHX_REQUIRE(shard_count == 1 && !comm_, "a sharded world cannot be restored");
+    // the invariants the step's kernels rely on
+    for (int i = 0; i < manifold_count; ++i) {
+        const phx_manifold& m = manifolds[i];
+        PHX_REQUIRE((unsigned)m.body1 < (unsigned)body_count && (unsigned)m.body2 < (unsigned)body_count, "manifold: body index out of range");
+        PHX_REQUIRE(m.point_index == 2 * i && m.point_count >= 0 && m.point_count <= 2, "manifold: its contact points are slots 2i, 2i + 1");
+    }
+    for (int j = 0; j < joint_count; ++j) {
+        const phx_contact_joint& q = joints[j];
+        PHX_REQUIRE((unsigned)q.contact_point_index < (unsigned)cp_count, "joint: contact point out of range");
+        const phx_manifold& m = manifolds[q.contact_point_index / 2];
+        PHX_REQUIRE(q.body1 == m.body1 && q.body2 == m.body2, "joint: bodies differ from its manifold's");
+        PHX_REQUIRE(cps[q.contact_point_index].solver_index == j, "joint: its contact point does not point back at it");
+    }
+    PHX_TRY(synchronize());
+    host_bodies_.assign(bodies, bodies + body_count);
+    bodies_dirty_ = true;
+    PHX_TRY(sync_bodies_to_device());
+    nm = manifold_count; nj = joint_count;
+    PHX_TRY(d_manifolds_.reserve(std::max<size_t>(nm, 1))); PHX_TRY(d_cps_.reserve(std::max<size_t>(2 * (size_t)nm, 1))); PHX_TRY(d_joints_.reserve(std::max<size_t>(nj, 1)));
+    if (nm) {
+        PHX_HIP(hipMemcpyAsync(d_manifolds_.p, manifolds, (size_t)nm * sizeof(phx_manifold), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(d_cps_.p, cps, 2 * (size_t)nm * sizeof(phx_contact_point), hipMemcpyHostToDevice, stream_));
+    }
+    if (nj) PHX_HIP(hipMemcpyAsync(d_joints_.p, joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipStreamSynchronize(stream_));
+    std::vector<uint2> pairs((size_t)nm);
+    for (int i = 0; i < nm; ++i) pairs[i] = make_uint2((unsigned)manifolds[i].body1, (unsigned)manifolds[i].body2);
+    PHX_TRY(broadphase_.reset_pairs(pairs.data(), nm));
+    // nothing of the old world's bookkeeping survives
+    joints_changed_ = true; pack_pending_ = false; expect_no_dead_manifolds_ = false; fresh_manifolds_ = 0; fuse_velocity_ = false;
+    if (joint_seen_.p) { PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_)); }
+    joint_epoch_ = 0;
+    PHX_HIP(hipStreamSynchronize(stream_));
+    return PHX_OK;
+}
+
 int World::download_bodies(phx_rigid_body* out, int cap)
 {
     const int n = nb();
@@ -673,6 +722,13 @@ int phx_world_get_bodies(phx_world* w, phx_rigid_body* out, int32_t cap) { PHX_R
 int phx_world_get_manifolds(phx_world* w, phx_manifold* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_manifolds(out, cap); }
 int phx_world_get_contact_points(phx_world* w, phx_contact_point* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_contact_points(out, cap); }
 int phx_world_get_joints(phx_world* w, phx_contact_joint* out, int32_t cap) { PHX_REQUIRE(w && out, "null handle / buffer"); return w->impl.download_joints(out, cap); }
+
+int phx_world_set_state(phx_world* w, const phx_rigid_body* bodies, int32_t body_count, const phx_manifold* manifolds, int32_t manifold_count,
+                        const phx_contact_point* contact_points, int32_t contact_point_count, const phx_contact_joint* joints, int32_t joint_count)
+{
+    PHX_REQUIRE(w, "null handle");
+    return w->impl.set_state(bodies, body_count, manifolds, manifold_count, contact_points, contact_point_count, joints, joint_count);
+}
 
 int phx_world_get_solve_stats(phx_world* w, phx_solve_stats* out) { PHX_REQUIRE(w, "null handle"); return w->impl.solver().get_stats(out); }
 int phx_world_get_broadphase_stats(phx_world* w, phx_broadphase_stats* out) { PHX_REQUIRE(w, "null handle"); return w->impl.broadphase().get_stats(out); }

@@ -342,6 +342,44 @@ def test_slab_worlds_are_exact_sub_worlds_and_the_guard_trips(oracle, built_lib)
             sw.step(1.0 / 60.0, cfg)
 
 
+def test_world_state_save_and_restore_is_exact(built_lib):
+    """Checkpoint / resume (phx_world_set_state): a fresh world restored from what the four getters return — bodies, manifolds with
+    their contact points, joints with their warm-start impulses; the broadphase's pair set is rebuilt from the manifolds — steps
+    byte for byte like the world the state was taken from, through contacts dying and new ones appearing."""
+    scene = scenes.falling(900, width=120.0, ymax=320.0)
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 12, 8)
+    a = phyx_amd.World(0, gravity=-200.0)
+    a.add_scene(scene)
+    for _ in range(30):
+        a.Update(1.0 / 60.0, cfg)
+    saved = a.state()
+    assert len(saved[1]) > 100 and len(saved[3]) > 100
+    b = phyx_amd.World(0, gravity=-200.0)                                    # never saw the scene
+    b.set_state(*saved)
+    assert b.counts() == a.counts()
+    for got, want in zip(b.state(), saved):
+        assert got.tobytes() == want.tobytes()
+    births = deaths = 0
+    for step in range(25):
+        before = a.counts()[1]
+        a.Update(1.0 / 60.0, cfg)
+        b.Update(1.0 / 60.0, cfg)
+        _same_world(b, a, "restored world at step %d" % step)
+        assert b.contactPoints.tobytes() == a.contactPoints.tobytes()
+        births += a.collider.stats().new_pairs
+        deaths += max(0, before + a.collider.stats().new_pairs - a.counts()[1])
+    assert births > 0 and deaths > 0                                         # the pair set was exercised both ways
+    # a state that does not hang together is refused
+    bodies, manifolds, cps, joints = (x.copy() for x in saved)
+    bad = joints.copy(); bad["body1"][0] += 1
+    with pytest.raises(phyx_amd.PhxError):
+        b.set_state(bodies, manifolds, cps, bad)
+    with pytest.raises(phyx_amd.PhxError):
+        b.set_state(bodies, manifolds, cps[:-1], joints)
+    b.set_state(*saved)                                                      # and the handle is still usable
+    assert b.counts() == (len(bodies), len(manifolds), len(cps), len(joints))
+
+
 def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
     """phx_world_update returns once the step is queued on the world's stream; every getter waits for it.  Two worlds, one
     read after every step, one only at the end (with an explicit synchronize), must agree bit for bit; the per-phase timers
