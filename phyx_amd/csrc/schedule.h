@@ -70,6 +70,7 @@ constexpr int COLOUR_B_MAX_JOINTS = 1024;
 // only the boundary classes remain launches of their own.  Like every colouring it is one more legal Gauss-Seidel order, a
 // pure function of the component (its joints' bodies and ids), hence the same in every island mode and on every rank.
 constexpr int PART_BODIES = 512;
+static_assert((PART_BODIES & (PART_BODIES - 1)) == 0, "local body indices are masked with PART_BODIES - 1");
 __host__ __device__ inline bool unit_is_interior(unsigned a, unsigned b, bool a_static, bool b_static)
 {
     return !a_static && !b_static && a / (unsigned)PART_BODIES == b / (unsigned)PART_BODIES;

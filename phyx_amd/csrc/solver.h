@@ -156,6 +156,7 @@ private:
     // the interior units of partitioned components by part (schedule.h, k_solve_parts)
     DevBuf<int> part_units_, part_class_begin_;
     DevBuf<int4> hbm_class_tab_;
+    std::vector<int4> class_tab_host_;
     int part_count_ = 0;                 // workgroups of k_solve_parts (0: the schedule has no interior classes)
     bool no_parts_ = false;              // PHX_NO_PARTS=1: sweep the interior classes one launch each (A/B measurements, tests)
     int upload_class_tab(const Schedule& sc, int* interior_leaders);

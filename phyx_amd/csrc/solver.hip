@@ -824,7 +824,8 @@ int DeviceSolver::materialise_schedule()
 // class_tab[c] = {first slot, leaders, followers, leaders of the classes before c} of the HBM group's classes (k_solve_parts)
 int DeviceSolver::upload_class_tab(const Schedule& sc, int* interior_leaders)
 {
-    std::vector<int4> tab(sc.hbm_class_leaders.size());
+    std::vector<int4>& tab = class_tab_host_;          // (a member: the copy below is asynchronous)
+    tab.assign(sc.hbm_class_leaders.size(), make_int4(0, 0, 0, 0));
     int before = 0;
     *interior_leaders = 0;
     for (size_t c = 0; c < tab.size(); ++c) {
@@ -835,7 +836,6 @@ int DeviceSolver::upload_class_tab(const Schedule& sc, int* interior_leaders)
     }
     PHX_TRY(hbm_class_tab_.reserve(std::max<size_t>(tab.size(), 64)));
     PHX_HIP(hipMemcpyAsync(hbm_class_tab_.p, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
-    PHX_HIP(hipStreamSynchronize(stream_));            // (tab is a local)
     return PHX_OK;
 }
 

@@ -408,102 +408,53 @@ static __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView 
 // solve_one()'s, the slot order is the schedule's: results are bit-identical to KI launches of k_solve_colour.
 // Interior units touch no static body, so the static tags play no part.
 constexpr int PARTS_T = 256;
-// (Measured, settled 200k-box world, 392 parts of ~1050 units in 12 classes: this form — constants requested inside the class
-//  step, ~60 VGPRs — takes ~31 us per sweep: with 1.5 workgroups per CU a class step pays its memory round trip in full.
-//  Keeping the constants of a lane's units in registers across the class steps, all loads in flight up front, was built three
-//  ways — 512 lanes x 3 units, 256 x 5, 256 x 4 with a slimmed record: 57 / 42 us and spills: 33 words per unit x 4-5 units
-//  do not fit 256 VGPRs next to the sweep's own, and above 128 the parts no longer fit the machine in one round.)
+// (Measured, settled 200k-box world, 392 parts of ~1050 units in 12 classes: 31 us per sweep with the slots of a class in joint
+//  order — five scattered 16-byte gathers per joint, 4x the bytes — and 20 us with the interior classes laid out part by part
+//  (schedule.h).  Requesting a part's constants ahead of the class steps was built four ways — all of a part's units in registers
+//  (512 lanes x 3, 256 x 5, 256 x 4 with a slimmed record: 42-57 us, spills; beyond 128 VGPRs the parts need two rounds), and
+//  chunks of two units per lane (no spills, 188 VGPRs): none is faster than this form, whose ~60 VGPRs let every part be
+//  resident at once; the step is bound by the part with the longest chain of classes.)
 
-// What a lane keeps of a unit it owns (impulse half; the displacement half's two words are read in the class step: it is dead
-// after the first sweep or two of a resting scene)
-struct OwnUnit {
-    float4 a0, f0, c0;                 // leader: q0, q1, q2
-    float4 a1, f1;                     // follower: q0, q1
-    float2 acc0, acc1;
-    float ii2, cn1;                    // q3.x; the follower's 1 / normal mass
-    int b1, b2, s0, s1, cls;           // local bodies, slots (s1 < 0: no follower), class (-1: nothing owned)
-};
-constexpr int PARTS_OWN = 2;          // units a lane holds at a time
-
-// A part's units are sorted by class.  They are taken in CHUNKS of PARTS_T * PARTS_OWN: all of a chunk's constants are requested
-// at once (lane t owns positions t and t + PARTS_T of the chunk) and then the classes the chunk covers are swept out of registers
-// and LDS — one exposed memory round trip per chunk instead of one per class (a part of a settled stack: ~1050 units in 12
-// classes = 3 chunks).  A class that straddles two chunks is swept in two pieces with a barrier between them, which is as good
-// as any other order inside a class.
 template <bool DO_IMP, bool DO_DISP>
 static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, PartsView pv, int iter)
 {
     __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
     __shared__ float4 s_disp[DO_DISP ? PART_BODIES : 1];
-    __shared__ int s_cls[65];
     const int part = blockIdx.x, tid = threadIdx.x;
     const int* cls = pv.class_begin + (size_t)part * (pv.ki + 1);
-    const int first = cls[0], last = cls[pv.ki];
-    if (first == last) return;                              // nothing of a partitioned component in this part
+    if (cls[0] == cls[pv.ki]) return;
     const bool imp_on = DO_IMP;
     const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
     if (!imp_on && !disp_on) return;
     const int base = part * PART_BODIES;
     const int count = min(PART_BODIES, v.nb - base);
-    for (int i = tid; i <= pv.ki; i += PARTS_T) s_cls[i] = cls[i];
     for (int i = tid; i < count; i += PARTS_T) {
         if (DO_IMP) s_imp[i] = v.sb_imp[base + i];
         if (DO_DISP) { if (disp_on) s_disp[i] = v.sb_disp[base + i]; }
     }
     __syncthreads();
     bool any_imp = false, any_disp = false;
-    int c_lo = 0;
-    for (int chunk = first; chunk < last; chunk += PARTS_OWN * PARTS_T) {
-        const int chunk_end = min(chunk + PARTS_OWN * PARTS_T, last);
-        OwnUnit own[PARTS_OWN];
-#pragma unroll
-        for (int k = 0; k < PARTS_OWN; ++k) {
-            const int u = chunk + k * PARTS_T + tid;
-            own[k] = OwnUnit{};
-            own[k].cls = -1; own[k].s1 = -1;
-            if (u < chunk_end) {
-                int c = c_lo;
-                while (u >= s_cls[c + 1]) ++c;
-                const int4 tab = pv.class_tab[c];
-                const int s0 = pv.units[u], i = s0 - tab.x;
-                own[k].cls = c; own[k].s0 = s0;
-                own[k].a0 = v.q0[s0]; own[k].c0 = v.q2[s0];
-                const int4 kk = v.q3[s0];
-                own[k].ii2 = __int_as_float(kk.x); own[k].b1 = kk.y - base; own[k].b2 = kk.z - base;
-                if (DO_IMP) { own[k].f0 = v.q1[s0]; own[k].acc0 = v.acc[s0]; }
-                if (i < tab.z) {
-                    const int s1 = tab.x + tab.y + i;
-                    own[k].s1 = s1;
-                    own[k].a1 = v.q0[s1]; own[k].cn1 = v.qn[s1];
-                    if (DO_IMP) { own[k].f1 = v.q1[s1]; own[k].acc1 = v.acc[s1]; }
-                }
-            }
+    for (int c = 0; c < pv.ki; ++c) {
+        const int4 tab = pv.class_tab[c];
+        for (int u = cls[c] + tid; u < cls[c + 1]; u += PARTS_T) {
+            const int s0 = pv.units[u], i = s0 - tab.x;
+            const bool has2 = i < tab.z;
+            const int s1 = tab.x + tab.y + i;
+            HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on, false), q1{};
+            if (has2) q1 = hbm_load(v, s1, imp_on, disp_on, true);
+            const int b1 = (q0.k.y - base) & (PART_BODIES - 1), b2 = (q0.k.z - base) & (PART_BODIES - 1);      // (masked: a stale schedule may meet other joints, solver.h)
+            float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
+            if (DO_IMP) { B1 = s_imp[b1]; B2 = s_imp[b2]; }
+            if (DO_DISP) { if (disp_on) { D1 = s_disp[b1]; D2 = s_disp[b2]; } }
+            const float im1 = q0.c.y, ii1 = q0.c.z, im2 = q0.c.w, ii2 = __int_as_float(q0.k.x);
+            bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
+            solve_one(v, s0, q0, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+            if (has2)
+                solve_one(v, s1, q1, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+            if (DO_IMP) { if (dirty_imp) { s_imp[b1] = B1; s_imp[b2] = B2; } }
+            if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
         }
-        while (s_cls[c_lo + 1] <= chunk) ++c_lo;            // the classes this chunk covers (workgroup-uniform)
-        int c_hi = c_lo;
-        while (c_hi + 1 < pv.ki && s_cls[c_hi + 1] < chunk_end) ++c_hi;
-        for (int c = c_lo; c <= c_hi; ++c) {
-#pragma unroll
-            for (int k = 0; k < PARTS_OWN; ++k)
-                if (own[k].cls == c) {
-                    HbmJoint q0{}, q1{};
-                    q0.a = own[k].a0; q0.f = own[k].f0; q0.c = own[k].c0; q0.acc = own[k].acc0;
-                    q1.a = own[k].a1; q1.f = own[k].f1; q1.c = make_float4(own[k].cn1, 0.f, 0.f, 0.f); q1.acc = own[k].acc1;
-                    const int s0 = own[k].s0, s1 = own[k].s1, b1 = own[k].b1, b2 = own[k].b2;
-                    if (DO_DISP) { if (disp_on) { q0.d = v.dd[s0]; if (s1 >= 0) q1.d = v.dd[s1]; } }
-                    float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
-                    if (DO_IMP) { B1 = s_imp[b1]; B2 = s_imp[b2]; }
-                    if (DO_DISP) { if (disp_on) { D1 = s_disp[b1]; D2 = s_disp[b2]; } }
-                    const float im1 = q0.c.y, ii1 = q0.c.z, im2 = q0.c.w, ii2 = own[k].ii2;
-                    bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
-                    solve_one(v, s0, q0, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
-                    if (s1 >= 0)
-                        solve_one(v, s1, q1, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
-                    if (DO_IMP) { if (dirty_imp) { s_imp[b1] = B1; s_imp[b2] = B2; } }
-                    if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
-                }
-            __syncthreads();
-        }
+        __syncthreads();
     }
     for (int i = tid; i < count; i += PARTS_T) {
         if (DO_IMP) v.sb_imp[base + i] = s_imp[i];
@@ -531,10 +482,11 @@ static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, 
             const float4 m = v.q2[s0];
             const int4 k = v.q3[s0];
             const float im1 = m.y, ii1 = m.z, im2 = m.w, ii2 = __int_as_float(k.x);
-            float4 B1 = s_imp[k.y - base], B2 = s_imp[k.z - base];
+            const int l1 = (k.y - base) & (PART_BODIES - 1), l2 = (k.z - base) & (PART_BODIES - 1);
+            float4 B1 = s_imp[l1], B2 = s_imp[l2];
             prestep_one(v, s0, B1, B2, im1, ii1, im2, ii2, false, false);
             if (i < tab.z) prestep_one(v, tab.x + tab.y + i, B1, B2, im1, ii1, im2, ii2, false, false);
-            s_imp[k.y - base] = B1; s_imp[k.z - base] = B2;
+            s_imp[l1] = B1; s_imp[l2] = B2;
         }
         __syncthreads();
     }
