@@ -102,9 +102,10 @@ struct Schedule {
     std::vector<int> hbm_colour_offsets;  // slots of the HBM group's classes (absolute), empty if there is no HBM group
     std::vector<int> hbm_class_leaders;   // per class of the HBM group: its leaders (the slots behind them are the followers)
     int hbm_interior_classes = 0;         // KI: the HBM group's leading classes that hold interior units of partitioned components only
-    // the interior units by part (host-built schedules; the device builder leaves its tables in HBM): leader slots sorted by
-    // (part, class, slot), and per part the begin of every interior class in that list ((KI + 1) entries per part)
-    std::vector<int> part_units, part_class_begin;
+    // the interior units by part (host-built schedules; the device builder leaves its tables in HBM): per part and interior class
+    // (64 classes per part) the slot ranges {first, end} of its leaders with a follower and {first, end} of its single leaders,
+    // and the number of interior units before each part (parts + 1)
+    std::vector<int> part_ranges, part_begin;
     // units of the LDS groups, in class order: slots of a unit's leader and follower (-1: none); group g's units are
     // [group_unit_offsets[g], group_unit_offsets[g + 1])
     std::vector<int> group_unit_offsets, unit_leader, unit_follower;

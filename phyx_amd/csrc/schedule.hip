@@ -192,29 +192,27 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
     return ncolours;
 }
 
-// the interior units of the HBM group by part (schedule.h): leader slots sorted by (part, class, slot) + per part the begin of
-// every interior class
-static void build_part_tables(Schedule& out, const int* body1, int nb)
+// the interior classes of the HBM group by part (schedule.h): an interior class is laid out part by part, so a part's units of a
+// class are two runs of slots — its leaders with a follower, its single leaders
+static void build_part_tables(Schedule& out, const int* body1, int nb, const std::vector<int>& partner)
 {
-    out.part_units.clear(); out.part_class_begin.clear();
+    out.part_ranges.clear(); out.part_begin.clear();
     const int ki = out.hbm_interior_classes;
-    if (ki <= 0) return;
+    if (ki <= 0 || ki > 64) return;
     const int parts = (nb + PART_BODIES - 1) / PART_BODIES;
-    std::vector<int> count((size_t)parts * ki + 1, 0);
+    out.part_ranges.assign((size_t)parts * 64 * 4, 0);
+    out.part_begin.assign((size_t)parts + 1, 0);
     for (int c = 0; c < ki; ++c) {
         const int cb = out.hbm_colour_offsets[c], lead = out.hbm_class_leaders[c];
-        for (int s = cb; s < cb + lead; ++s) count[(size_t)(body1[out.order[s]] / PART_BODIES) * ki + c + 1]++;
+        for (int s = cb; s < cb + lead; ++s) {
+            const int j = out.order[s], part = body1[j] / PART_BODIES, kind = partner[j] >= 0 ? 0 : 1;
+            int* row = &out.part_ranges[((size_t)part * 64 + c) * 4 + 2 * kind];
+            if (row[1] == 0) row[0] = s;
+            row[1] = s + 1;
+            out.part_begin[part + 1]++;
+        }
     }
-    for (size_t i = 1; i < count.size(); ++i) count[i] += count[i - 1];
-    out.part_units.resize(count.back());
-    std::vector<int> cur(count.begin(), count.end() - 1);
-    for (int c = 0; c < ki; ++c) {
-        const int cb = out.hbm_colour_offsets[c], lead = out.hbm_class_leaders[c];
-        for (int s = cb; s < cb + lead; ++s) out.part_units[cur[(size_t)(body1[out.order[s]] / PART_BODIES) * ki + c]++] = s;
-    }
-    out.part_class_begin.resize((size_t)parts * (ki + 1));
-    for (int p = 0; p < parts; ++p)
-        for (int c = 0; c <= ki; ++c) out.part_class_begin[(size_t)p * (ki + 1) + c] = count[(size_t)p * ki + c];
+    for (int p = 0; p < parts; ++p) out.part_begin[p + 1] += out.part_begin[p];
 }
 
 // append one group made of the units led by `leaders`, coloured by `colour`: class by class, the leaders that have a follower
@@ -296,7 +294,7 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
     if (nj) {
         append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, body1);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
-        build_part_tables(out, body1, nb);
+        build_part_tables(out, body1, nb, partner);
     }
     out.lds_groups = 0;
     out.islands = false;
@@ -605,7 +603,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         const size_t first = out.colour_offsets.size() - 1;
         append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, body1);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
-        build_part_tables(out, body1, nb);
+        build_part_tables(out, body1, nb, partner);
         touched_bodies(rest, body1, body2, nb, out.hbm_bodies);
         out.hbm_body_count = (int)out.hbm_bodies.size();
     }

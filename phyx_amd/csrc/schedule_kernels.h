@@ -600,8 +600,9 @@ struct JpView {
     const int* joint_comp;            // joint -> connected component (-1: both bodies static)
     const int* partner;               // joint -> the other joint of its unit, or -1
     unsigned char* kind;              // per entry: 0 leads a unit of two, 1 a unit of one, 2 follower (takes no part in the colouring);
-                                      // | JP_INTERIOR: an interior unit of a partitioned component (schedule.h) — it is coloured on the
-                                      // masks used_b / seen_b / colour_b, which candidate B never touches in a component that big
+                                      // | JP_INTERIOR: an interior unit of a partitioned component (schedule.h) — it is coloured inside
+                                      // its part (k_colour_parts) and reports through seen_b / colour_b, which candidate B never touches
+                                      // in a component that big
     int ncomp;
     unsigned long long* seen_a;       // per component (entry ncomp = the static-static joints): colours in use under A / B
     unsigned long long* seen_b;
@@ -613,7 +614,6 @@ struct JpView {
     int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX;
                                       // flags[1] = KI, the group's interior classes (k_jp_interior_classes)
     unsigned* hist;                   // per sort key 2 * class + kind: leaders (filled by the choice)
-    int part_bits;                    // the sort key of a leader is (2 * class + kind) << part_bits | part (interior units; 0 otherwise)
 };
 
 // every per-body table and the small words in ONE launch (a memset is a dispatch of its own, and there were a dozen)
@@ -657,6 +657,10 @@ static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
             v.ent[k] = make_uint4(JP_STATIC_BIT, JP_STATIC_BIT, (unsigned)key, (unsigned)(key >> 32));
             continue;
         }
+        if (kind & JP_INTERIOR) {                                          // coloured inside its part (k_colour_parts): no list, no frontier
+            v.ent[k] = make_uint4(a, b, (unsigned)key, (unsigned)(key >> 32));
+            continue;
+        }
         if (v.is_static[a]) a |= JP_STATIC_BIT; else atomicAdd(&v.offset[a], 1u);
         if (v.is_static[b]) b |= JP_STATIC_BIT; else atomicAdd(&v.offset[b], 1u);
         v.ent[k] = make_uint4(a, b, (unsigned)key, (unsigned)(key >> 32));
@@ -669,6 +673,7 @@ static __global__ void __launch_bounds__(256) k_jp_fill(JpView v)
 {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
         const uint4 e = v.ent[k];
+        if (v.kind[k] & JP_INTERIOR) continue;
         if (!(e.x & JP_STATIC_BIT)) v.adj[v.offset[e.x] + atomicAdd(&v.cursor[e.x], 1u)] = make_uint4(e.z, e.w, (unsigned)k, e.x);
         if (!(e.y & JP_STATIC_BIT)) v.adj[v.offset[e.y] + atomicAdd(&v.cursor[e.y], 1u)] = make_uint4(e.z, e.w, (unsigned)k, e.y | JP_STATIC_BIT);
     }
@@ -705,7 +710,7 @@ static __global__ void __launch_bounds__(256) k_jp_lists(JpView v)
 // round 0's frontier: flag the entries that wait for nobody, scan, compact
 static __global__ void __launch_bounds__(256) k_jp_seed_flags(JpView v, unsigned* __restrict__ flags)
 {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u && (v.kind[k] & 3) != 2) ? 1u : 0u;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= v.count; k += gridDim.x * blockDim.x) flags[k] = (k < v.count && v.pred[k] == 0u && (v.kind[k] & 3) != 2 && !(v.kind[k] & JP_INTERIOR)) ? 1u : 0u;
 }
 
 static __global__ void __launch_bounds__(256) k_jp_seed(JpView v, const unsigned* __restrict__ scan, unsigned* __restrict__ list_out)
@@ -750,16 +755,6 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
                 comp = (int)v.ent_comp[k];
                 unsigned long long m = 0;
                 int c = 0;
-                if (v.kind[k] & JP_INTERIOR) {                // a kind of its own: its own masks, its own classes (both bodies are dynamic)
-                    m = v.used_b[a] | v.used_b[b];
-                    if (!~m) atomicOr(v.flags, 2);
-                    else {
-                        c = __builtin_ctzll(~m);
-                        v.used_b[a] |= 1ull << c; v.used_b[b] |= 1ull << c;
-                        got_b = 1ull << c;
-                        v.colour_b[k] = (unsigned)c;
-                    }
-                } else {
                 if (da) m |= v.used[a];
                 if (db) m |= v.used[b];
                 if (!~m) atomicOr(v.flags, 2);
@@ -768,7 +763,6 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
                     if (da) v.used[a] |= 1ull << c;
                     if (db) v.used[b] |= 1ull << c;
                     got_a = 1ull << c;
-                }
                 }
                 if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
                     unsigned long long mb = 0;
@@ -825,6 +819,84 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
     }
 }
 
+// ---- the interior units of partitioned components, coloured part by part in LDS ----------------------------------------
+// An interior unit conflicts only with interior units of its own part (schedule.h), so first fit in priority order is a problem
+// of ~1e3 units on 512 bodies: one workgroup per part, Jones-Plassmann rounds on LDS — a unit takes the smallest class free on
+// its two bodies once it holds the highest priority among the uncoloured units on both — with barriers where the global walk
+// (k_jp_front) has kernel launches.  The same classes as one sequential pass in decreasing priority.
+constexpr int CP_T = 256, CP_MAXU = 4096;      // a denser part (> 8 units per body) sends the build to the host builder
+
+// keys for the sort by part: an interior entry's part, every other entry behind them all
+static __global__ void __launch_bounds__(256) k_part_sort_keys(JpView v, unsigned behind, unsigned* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
+        keys[k] = (v.kind[k] & JP_INTERIOR) ? v.ent[k].x / (unsigned)PART_BODIES : behind;
+        vals[k] = (unsigned)k;
+    }
+}
+
+// out[t] = the first position of `sorted_keys` (n of them) whose key is >= t, for t = 0 .. count
+static __global__ void __launch_bounds__(256) k_lower_bounds(const unsigned* __restrict__ sorted_keys, int n, int count, int* __restrict__ out)
+{
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= count; t += gridDim.x * blockDim.x) {
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] < (unsigned)t) lo = mid + 1; else hi = mid; }
+        out[t] = lo;
+    }
+}
+
+static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const unsigned* __restrict__ sorted_entries, const int* __restrict__ part_begin)
+{
+    __shared__ unsigned long long s_prio[CP_MAXU], s_used[PART_BODIES], s_max[PART_BODIES];
+    __shared__ unsigned s_bodies[CP_MAXU];
+    __shared__ unsigned char s_col[CP_MAXU];
+    const int part = blockIdx.x, tid = threadIdx.x;
+    const int pb = part_begin[part], n = part_begin[part + 1] - pb;
+    if (n <= 0) return;
+    if (n > CP_MAXU) { if (tid == 0) atomicOr(v.flags, 4); return; }
+    const unsigned base = (unsigned)part * (unsigned)PART_BODIES;
+    for (int i = tid; i < n; i += CP_T) {
+        const uint4 e = v.ent[sorted_entries[pb + i]];
+        s_prio[i] = ((unsigned long long)e.w << 32) | e.z;
+        s_bodies[i] = ((e.x - base) & (PART_BODIES - 1)) | (((e.y - base) & (PART_BODIES - 1)) << 16);
+        s_col[i] = 0xFF;
+    }
+    for (int b = tid; b < PART_BODIES; b += CP_T) { s_used[b] = 0ull; s_max[b] = 0ull; }
+    __syncthreads();
+    for (;;) {
+        for (int i = tid; i < n; i += CP_T)
+            if (s_col[i] == 0xFF) {
+                const unsigned bb = s_bodies[i];
+                atomicMax(&s_max[bb & 0xFFFFu], s_prio[i]);
+                atomicMax(&s_max[bb >> 16], s_prio[i]);
+            }
+        __syncthreads();
+        int left = 0;
+        for (int i = tid; i < n; i += CP_T)
+            if (s_col[i] == 0xFF) {
+                const unsigned bb = s_bodies[i], b1 = bb & 0xFFFFu, b2 = bb >> 16;
+                const unsigned long long p = s_prio[i];
+                if (s_max[b1] == p && s_max[b2] == p) {            // nobody else on these two bodies takes a class in this round
+                    const unsigned long long m = s_used[b1] | s_used[b2];
+                    int c = 0;
+                    if (!~m) atomicOr(v.flags, 2); else c = __builtin_ctzll(~m);
+                    s_used[b1] |= 1ull << c; s_used[b2] |= 1ull << c;
+                    s_col[i] = (unsigned char)c;
+                } else left = 1;
+            }
+        __syncthreads();
+        for (int b = tid; b < PART_BODIES; b += CP_T) s_max[b] = 0ull;
+        if (!__syncthreads_or(left)) break;
+    }
+    for (int i = tid; i < n; i += CP_T) {
+        const unsigned k = sorted_entries[pb + i], c = s_col[i];
+        v.colour_b[k] = c; v.colour[k] = c;
+        const unsigned comp = v.ent_comp[k];
+        const unsigned long long bit = 1ull << c;
+        if (!(__hip_atomic_load(&v.seen_b[comp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&v.seen_b[comp], bit);
+    }
+}
+
 // KI = the largest interior class count among the group's partitioned components (schedule.h)
 static __global__ void __launch_bounds__(256) k_jp_interior_classes(JpView v)
 {
@@ -842,7 +914,7 @@ static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
     const unsigned ki = (unsigned)v.flags[1];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
         const unsigned char kind = v.kind[k] & 3;
-        if (kind == 2) { v.colour[k] = 128u << v.part_bits; continue; }          // followers sort behind every leader; their leaders place them
+        if (kind == 2) { v.colour[k] = 255u; continue; }                         // followers sort behind every leader; their leaders place them
         const int comp = (int)v.ent_comp[k];
         const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
         const bool interior = (v.kind[k] & JP_INTERIOR) != 0;
@@ -851,18 +923,32 @@ static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
         unsigned cls = (unsigned)__popcll(((use_b || interior) ? sb : sa) & ((1ull << c) - 1ull));
         if (!interior) cls += ki;
         if (cls >= (unsigned)JP_MAX_COLOURS) { atomicOr(v.flags, 2); cls = JP_MAX_COLOURS - 1; }
-        const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single', then (interior units) the part
-        v.colour[k] = (key << v.part_bits) | (interior ? (v.ent[k].x & ~JP_STATIC_BIT) / (unsigned)PART_BODIES : 0u);
+        const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single'
+        v.colour[k] = key;
         atomicAdd(&h[key & (2 * JP_MAX_COLOURS - 1)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 2 * JP_MAX_COLOURS && h[threadIdx.x]) atomicAdd(&v.hist[threadIdx.x], h[threadIdx.x]);
 }
 
-// the leaders, sorted by (class, kind, part of an interior unit) and stable in joint order, take their slots — and give their followers theirs:
-// class c = [leaders with a follower][single leaders][followers, in their leaders' order]  (hist: leaders per sort key)
+// the sort's input in the order `perm` (the entries sorted by part, everything but interior units behind them in entry order):
+// a stable sort by (class, kind) of THAT sequence leaves an interior class laid out part by part (schedule.h) and every other class
+// in joint order, in one 8-bit pass
+static __global__ void __launch_bounds__(256) k_jp_sort_input(JpView v, const unsigned* __restrict__ perm, unsigned* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.count; i += gridDim.x * blockDim.x) {
+        const unsigned k = perm ? perm[i] : (unsigned)i;
+        keys[i] = v.colour[k];
+        vals[i] = v.ids[k];
+    }
+}
+
+// the leaders, sorted by (class, kind) — interior classes part by part, otherwise stable in joint order — take their slots and give
+// their followers theirs: class c = [leaders with a follower][single leaders][followers, in their leaders' order]  (hist: leaders
+// per sort key).  Interior classes also leave their parts' slot ranges for k_solve_parts: ranges[part * 64 + c] = {first, end of
+// the leaders with a follower, first, end of the single leaders} (the table is zero on entry).
 static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigned* __restrict__ sorted_keys, const unsigned* __restrict__ sorted_joints,
-                                                        int* __restrict__ order_out)
+                                                        int* __restrict__ order_out, int slot_base, int* __restrict__ ranges)
 {
     __shared__ unsigned slot_begin[JP_MAX_COLOURS], lead_begin[JP_MAX_COLOURS], lead_n[JP_MAX_COLOURS];
     if (threadIdx.x < 64) {
@@ -874,43 +960,22 @@ static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigne
     }
     __syncthreads();
     const int leaders = (int)(lead_begin[JP_MAX_COLOURS - 1] + lead_n[JP_MAX_COLOURS - 1]);
+    const unsigned ki = (unsigned)v.flags[1];
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < leaders; p += gridDim.x * blockDim.x) {
-        const unsigned key = sorted_keys[p] >> v.part_bits, c = key >> 1;
+        const unsigned key = sorted_keys[p], c = key >> 1;
         const int j = (int)sorted_joints[p];
         const unsigned r = (unsigned)p - lead_begin[c];
-        order_out[slot_begin[c] + r] = j;
+        const int slot = (int)(slot_begin[c] + r);
+        order_out[slot] = j;
         if (!(key & 1u)) order_out[slot_begin[c] + lead_n[c] + r] = v.partner[j];
-    }
-}
-
-// ---- the interior units by part (schedule.h, k_solve_parts) -------------------------------------------------------------
-// class_tab[c] = {first slot, leaders, followers, leaders of the classes before c}: leader number i of the interior classes
-// is slot tab.x + (i - tab.w) of class c; its key = part * 64 + c, sorted (stable) they are in (part, class, slot) order
-static __global__ void __launch_bounds__(256) k_part_keys(const int* __restrict__ order, const phx_contact_joint* __restrict__ joints,
-                                                         const int4* __restrict__ class_tab, int ki, int leaders,
-                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals)
-{
-    __shared__ int4 tab[JP_MAX_COLOURS];
-    if ((int)threadIdx.x < ki) tab[threadIdx.x] = class_tab[threadIdx.x];
-    __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < leaders; i += gridDim.x * blockDim.x) {
-        int c = 0;
-        while (c + 1 < ki && i >= tab[c + 1].w) ++c;
-        const int s = tab[c].x + (i - tab[c].w);
-        const unsigned part = (unsigned)joints[order[s]].body1 / (unsigned)PART_BODIES;
-        keys[i] = part * (unsigned)JP_MAX_COLOURS + (unsigned)c;
-        vals[i] = (unsigned)s;
-    }
-}
-
-// class_begin[part * (ki + 1) + c] = the first sorted position whose key is >= part * 64 + c
-static __global__ void __launch_bounds__(256) k_part_table(const unsigned* __restrict__ sorted_keys, int n, int parts, int ki, int* __restrict__ class_begin)
-{
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < parts * (ki + 1); t += gridDim.x * blockDim.x) {
-        const unsigned key = (unsigned)(t / (ki + 1)) * (unsigned)JP_MAX_COLOURS + (unsigned)(t % (ki + 1));
-        int lo = 0, hi = n;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid; }
-        class_begin[t] = lo;
+        if (ranges && c < ki) {                        // an interior unit: first / last of its (part, class, kind) run?
+            const unsigned part = (unsigned)v.joints[j].body1 / (unsigned)PART_BODIES;
+            int* row = ranges + ((size_t)part * JP_MAX_COLOURS + c) * 4 + 2 * (key & 1u);
+            const bool first = p == 0 || sorted_keys[p - 1] != key || (unsigned)v.joints[sorted_joints[p - 1]].body1 / (unsigned)PART_BODIES != part;
+            const bool last = p + 1 >= leaders || sorted_keys[p + 1] != key || (unsigned)v.joints[sorted_joints[p + 1]].body1 / (unsigned)PART_BODIES != part;
+            if (first) row[0] = slot_base + slot;
+            if (last) row[1] = slot_base + slot + 1;
+        }
     }
 }
 

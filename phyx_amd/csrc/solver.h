@@ -33,11 +33,13 @@ struct SolverView {
 
 // the interior units of partitioned components by part (schedule.h; solver_kernels.h k_solve_parts)
 struct PartsView {
-    const int* units;           // leader slots of the interior units, sorted by (part, class, slot)
-    const int* class_begin;     // per part: KI + 1 offsets into units[]
+    const int4* ranges;         // [part * 64 + class]: the part's slots of that interior class = {first, end} of its leaders with a
+                                // follower, {first, end} of its single leaders (an interior class is laid out part by part, schedule.h)
+    const int* part_begin;      // parts + 1: interior units before each part (an empty part is skipped)
     const int4* class_tab;      // per class of the HBM group: {first slot, leaders, followers, leaders of the classes before}
     int ki, parts;
 };
+constexpr int PARTS_CLASS_STRIDE = 64;      // = JP_MAX_COLOURS, the device schedule builder's class limit
 
 class DeviceSolver {
 public:
@@ -154,7 +156,9 @@ private:
     DevBuf<int4> grp_desc_;
     DevBuf<int> grp_ncol_, grp_units_, grp_bodies_, isl_stats_, hbm_body_list_;
     // the interior units of partitioned components by part (schedule.h, k_solve_parts)
-    DevBuf<int> part_units_, part_class_begin_;
+    DevBuf<int> part_begin_;
+    DevBuf<int4> part_ranges_;
+    DevBuf<unsigned> part_keys_[2], part_vals_[2];      // the HBM group's entries sorted by part (k_colour_parts)
     DevBuf<int4> hbm_class_tab_;
     std::vector<int4> class_tab_host_;
     int part_count_ = 0;                 // workgroups of k_solve_parts (0: the schedule has no interior classes)
@@ -162,7 +166,7 @@ private:
     int upload_class_tab(const Schedule& sc, int* interior_leaders);
     int upload_part_tables();            // host-built schedules: part_units_ / part_class_begin_ from sched_
     bool parts_in_use() const { return !no_parts_ && part_count_ > 0 && sched_.hbm_interior_classes > 0; }
-    PartsView parts_view() const { return PartsView{part_units_.p, part_class_begin_.p, hbm_class_tab_.p, sched_.hbm_interior_classes, part_count_}; }
+    PartsView parts_view() const { return PartsView{part_ranges_.p, part_begin_.p, hbm_class_tab_.p, sched_.hbm_interior_classes, part_count_}; }
     DevBuf<int4> unit_recs_;            // per LDS group (stride = lanes of the kernel shape), two words per unit: joints, contact points, local bodies, class, slots (island_view.h)
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;

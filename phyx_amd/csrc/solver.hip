@@ -408,6 +408,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
     int nbins = 0, lds_slots = 0, where = 0, ncomp_total = 0;
+    bool any_partitioned = false;        // some component has more than COLOUR_B_MAX_JOINTS joints (schedule.h)
     spec_bins_pending_ = false;
     if (spec_build_applies(want_islands, nj)) {
         PHX_TRY(build_bins_speculative(d_bodies, nb, d_joints, nj, sc));
@@ -469,6 +470,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     }
     comp_size.resize(std::max(ncomp, 1)); comp_units.resize(std::max(ncomp, 1));
     ncomp_guess_ = ncomp;
+    for (int c = 0; c < ncomp && !any_partitioned; ++c) any_partitioned = comp_size[c] > (unsigned)COLOUR_B_MAX_JOINTS;      // (schedule.h: such a component is partitioned)
 
     // 3. host: GatherIslands' published numbers, workgroup shape, greedy binning of consecutive components
     //    (identical to schedule.hip::build_island_schedule — ncomp integers of work)
@@ -595,12 +597,29 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         jv.joint_comp = joint_comp_.p; jv.partner = partner_.p; jv.kind = jp_kind_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
         jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
         jv.counts = jp_counts_.p; jv.flags = jp_small_.p; jv.hist = reinterpret_cast<unsigned*>(jp_small_.p + 4);
-        jv.part_bits = 0;
-        while ((1 << jv.part_bits) < div_up(nb, PART_BODIES)) ++jv.part_bits;
+        const unsigned* perm = nullptr;                     // the entries sorted by part (partitioned components only)
+        const int parts = div_up(nb, PART_BODIES);
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
         // priority, successor links and predecessor counts
         hipLaunchKernelGGL(k_jp_clear, dim3(grid_for(std::max(nb + 1, ncomp_total + 1))), dim3(256), 0, stream_, jv, JP_ROUNDS_MAX + 1);
         hipLaunchKernelGGL(k_jp_prepare, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
+        // the interior units of partitioned components take their classes inside their parts (k_colour_parts): entries sorted by
+        // part (everything else behind them), the parts' ranges, one workgroup per part — out of the global walk below altogether
+        if (any_partitioned) {
+            for (int k = 0; k < 2; ++k) { PHX_TRY(part_keys_[k].reserve(njs)); PHX_TRY(part_vals_[k].reserve(njs)); }
+            PHX_TRY(part_begin_.reserve((size_t)parts + 2));
+            hipLaunchKernelGGL(k_part_sort_keys, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (unsigned)parts, part_keys_[0].p, part_vals_[0].p);
+            int bits = 1;
+            while ((1 << bits) <= parts) ++bits;                 // keys 0 .. parts
+            int wherep = 0;
+            PHX_TRY(device_radix_sort_pairs(part_keys_[0].p, part_vals_[0].p, part_keys_[1].p, part_vals_[1].p, rest, bits, sort_hist_.p, sort_scan_, stream_, &wherep));
+            hipLaunchKernelGGL(k_lower_bounds, dim3(grid_for(parts + 1)), dim3(256), 0, stream_, (const unsigned*)part_keys_[wherep].p, rest, parts, part_begin_.p);
+            hipLaunchKernelGGL(k_colour_parts, dim3(parts), dim3(CP_T), 0, stream_, jv, (const unsigned*)part_vals_[wherep].p, (const int*)part_begin_.p);
+            perm = part_vals_[wherep].p;
+            // the parts' slot ranges per interior class, left by k_jp_place below
+            PHX_TRY(part_ranges_.reserve((size_t)parts * JP_MAX_COLOURS));
+            PHX_HIP(hipMemsetAsync(part_ranges_.p, 0, (size_t)parts * JP_MAX_COLOURS * sizeof(int4), stream_));
+        }
         PHX_TRY(device_exclusive_scan(jp_offset_.p, nb + 1, nullptr, sort_scan_, stream_));
         hipLaunchKernelGGL(k_jp_fill, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
         hipLaunchKernelGGL(k_jp_lists, dim3(std::max(1, std::min(div_up(2 * rest, 256), 8192))), dim3(256), 0, stream_, jv);
@@ -642,10 +661,13 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned*)jp_touched_.p, nb, hbm_body_list_.p);
         // leaders sorted by (class, kind), stable in joint order (followers behind them all); then every leader places itself
         // and its follower
+        // (the sort's input is gathered in part order where there are parts: one 8-bit pass then leaves the interior classes laid out
+        //  part by part; jv.colour IS jp_keys_[0], so the gather goes to the other pair)
         int where2 = 0;
-        PHX_HIP(hipMemcpyAsync(jp_vals_[0].p, ids, (size_t)rest * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-        PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, rest, 8 + jv.part_bits, sort_hist_.p, sort_scan_, stream_, &where2));
-        hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_keys_[where2].p, (const unsigned*)jp_vals_[where2].p, order_.p + lds_slots);
+        hipLaunchKernelGGL(k_jp_sort_input, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, perm, jp_keys_[1].p, jp_vals_[1].p);
+        PHX_TRY(device_radix_sort_pairs(jp_keys_[1].p, jp_vals_[1].p, jp_keys_[0].p, jp_vals_[0].p, rest, 8, sort_hist_.p, sort_scan_, stream_, &where2));
+        hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_keys_[where2 ^ 1].p, (const unsigned*)jp_vals_[where2 ^ 1].p,
+                           order_.p + lds_slots, lds_slots, perm ? reinterpret_cast<int*>(part_ranges_.p) : (int*)nullptr);
         unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0;
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
         PHX_TRY(rb_.add(&h_touched, jp_touched_.p + nb, sizeof h_touched, stream_));
@@ -675,23 +697,13 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         }
         if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
-        // the interior units by part (schedule.h): keys (part, class) of the interior classes' leaders, one stable sort, the table
+        // k_solve_parts' tables: the classes' slot layout; the parts' ranges were left by k_jp_place, their unit counts by the sort by part
         part_count_ = 0;
         if (sc.hbm_interior_classes > 0) {
             const int ki = sc.hbm_interior_classes;
-            if (ki >= (int)sc.hbm_class_leaders.size() + 1 || ki > JP_MAX_COLOURS) { set_error("interior classes out of range"); return PHX_ERR_STATE; }
+            if (!perm || ki >= (int)sc.hbm_class_leaders.size() + 1 || ki > JP_MAX_COLOURS) { set_error("interior classes out of range"); return PHX_ERR_STATE; }
             int interior_leaders = 0;
             PHX_TRY(upload_class_tab(sc, &interior_leaders));
-            const int parts = div_up(nb, PART_BODIES);
-            int bits = 6;
-            while ((1 << (bits - 6)) < parts) ++bits;
-            PHX_TRY(part_units_.reserve(njs)); PHX_TRY(part_class_begin_.reserve((size_t)parts * (ki + 1)));
-            hipLaunchKernelGGL(k_part_keys, dim3(grid_for(interior_leaders)), dim3(256), 0, stream_, (const int*)order_.p, (const phx_contact_joint*)d_joints,
-                               (const int4*)hbm_class_tab_.p, ki, interior_leaders, jp_keys_[0].p, jp_vals_[0].p);
-            int where3 = 0;
-            PHX_TRY(device_radix_sort_pairs(jp_keys_[0].p, jp_vals_[0].p, jp_keys_[1].p, jp_vals_[1].p, interior_leaders, bits, sort_hist_.p, sort_scan_, stream_, &where3));
-            PHX_HIP(hipMemcpyAsync(part_units_.p, jp_vals_[where3].p, (size_t)interior_leaders * sizeof(int), hipMemcpyDeviceToDevice, stream_));
-            hipLaunchKernelGGL(k_part_table, dim3(grid_for(parts * (ki + 1))), dim3(256), 0, stream_, (const unsigned*)jp_keys_[where3].p, interior_leaders, parts, ki, part_class_begin_.p);
             part_count_ = parts;
         }
         PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs));
@@ -844,16 +856,16 @@ int DeviceSolver::upload_part_tables()
 {
     part_count_ = 0;
     const int ki = sched_.hbm_interior_classes;
-    if (ki <= 0 || sched_.part_units.empty()) return PHX_OK;
-    if (ki > 64) return PHX_OK;                        // (the kernel's class loop is unbounded, but keep the device builder's limit: one launch per class then)
+    if (ki <= 0 || sched_.part_begin.empty()) return PHX_OK;      // (more than 64 interior classes: no tables, one launch per class)
     int interior_leaders = 0;
     PHX_TRY(upload_class_tab(sched_, &interior_leaders));
-    if (interior_leaders != (int)sched_.part_units.size()) { set_error("part tables do not match the interior classes"); return PHX_ERR_STATE; }
-    PHX_TRY(part_units_.reserve(sched_.part_units.size())); PHX_TRY(part_class_begin_.reserve(sched_.part_class_begin.size()));
-    PHX_HIP(hipMemcpyAsync(part_units_.p, sched_.part_units.data(), sched_.part_units.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-    PHX_HIP(hipMemcpyAsync(part_class_begin_.p, sched_.part_class_begin.data(), sched_.part_class_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (interior_leaders != sched_.part_begin.back()) { set_error("part tables do not match the interior classes"); return PHX_ERR_STATE; }
+    const size_t parts = sched_.part_begin.size() - 1;
+    PHX_TRY(part_ranges_.reserve(parts * PARTS_CLASS_STRIDE)); PHX_TRY(part_begin_.reserve(parts + 2));
+    PHX_HIP(hipMemcpyAsync(part_ranges_.p, sched_.part_ranges.data(), sched_.part_ranges.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipMemcpyAsync(part_begin_.p, sched_.part_begin.data(), sched_.part_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
-    part_count_ = (int)(sched_.part_class_begin.size() / (size_t)(ki + 1));
+    part_count_ = (int)parts;
     return PHX_OK;
 }
 

@@ -421,8 +421,8 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
     __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
     __shared__ float4 s_disp[DO_DISP ? PART_BODIES : 1];
     const int part = blockIdx.x, tid = threadIdx.x;
-    const int* cls = pv.class_begin + (size_t)part * (pv.ki + 1);
-    if (cls[0] == cls[pv.ki]) return;
+    if (pv.part_begin[part] == pv.part_begin[part + 1]) return;      // nothing of a partitioned component in this part
+    const int4* ranges = pv.ranges + (size_t)part * PARTS_CLASS_STRIDE;
     const bool imp_on = DO_IMP;
     const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
     if (!imp_on && !disp_on) return;
@@ -435,10 +435,11 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
     __syncthreads();
     bool any_imp = false, any_disp = false;
     for (int c = 0; c < pv.ki; ++c) {
-        const int4 tab = pv.class_tab[c];
-        for (int u = cls[c] + tid; u < cls[c + 1]; u += PARTS_T) {
-            const int s0 = pv.units[u], i = s0 - tab.x;
-            const bool has2 = i < tab.z;
+        const int4 tab = pv.class_tab[c], rg = ranges[c];
+        const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;      // the part's units of this class: n2 with a follower, then the single ones
+        for (int u = tid; u < n; u += PARTS_T) {
+            const bool has2 = u < n2;
+            const int s0 = has2 ? rg.x + u : rg.z + (u - n2), i = s0 - tab.x;
             const int s1 = tab.x + tab.y + i;
             HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on, false), q1{};
             if (has2) q1 = hbm_load(v, s1, imp_on, disp_on, true);
@@ -469,16 +470,17 @@ static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, 
 {
     __shared__ float4 s_imp[PART_BODIES];
     const int part = blockIdx.x;
-    const int* cls = pv.class_begin + (size_t)part * (pv.ki + 1);
-    if (cls[0] == cls[pv.ki]) return;
+    if (pv.part_begin[part] == pv.part_begin[part + 1]) return;
+    const int4* ranges = pv.ranges + (size_t)part * PARTS_CLASS_STRIDE;
     const int base = part * PART_BODIES;
     const int count = min(PART_BODIES, v.nb - base);
     for (int i = threadIdx.x; i < count; i += PARTS_T) s_imp[i] = v.sb_imp[base + i];
     __syncthreads();
     for (int c = 0; c < pv.ki; ++c) {
-        const int4 tab = pv.class_tab[c];
-        for (int u = cls[c] + (int)threadIdx.x; u < cls[c + 1]; u += PARTS_T) {
-            const int s0 = pv.units[u], i = s0 - tab.x;
+        const int4 tab = pv.class_tab[c], rg = ranges[c];
+        const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;
+        for (int u = (int)threadIdx.x; u < n; u += PARTS_T) {
+            const int s0 = u < n2 ? rg.x + u : rg.z + (u - n2), i = s0 - tab.x;
             const float4 m = v.q2[s0];
             const int4 k = v.q3[s0];
             const float im1 = m.y, ii1 = m.z, im2 = m.w, ii2 = __int_as_float(k.x);
