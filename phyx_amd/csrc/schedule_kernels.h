@@ -824,7 +824,7 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
 // of ~1e3 units on 512 bodies: one workgroup per part, Jones-Plassmann rounds on LDS — a unit takes the smallest class free on
 // its two bodies once it holds the highest priority among the uncoloured units on both — with barriers where the global walk
 // (k_jp_front) has kernel launches.  The same classes as one sequential pass in decreasing priority.
-constexpr int CP_T = 256, CP_MAXU = 4096;      // a denser part (> 8 units per body) sends the build to the host builder
+constexpr int CP_T = 256, CP_MAXU = 3072;      // a denser part (> 6 units per body) sends the build to the host builder; (512 lanes: the same time, 1024: 73 us against 55, 128: 87)
 
 // keys for the sort by part: an interior entry's part, every other entry behind them all
 static __global__ void __launch_bounds__(256) k_part_sort_keys(JpView v, unsigned behind, unsigned* __restrict__ keys, unsigned* __restrict__ vals)
@@ -847,7 +847,7 @@ static __global__ void __launch_bounds__(256) k_lower_bounds(const unsigned* __r
 
 static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const unsigned* __restrict__ sorted_entries, const int* __restrict__ part_begin)
 {
-    __shared__ unsigned long long s_prio[CP_MAXU], s_used[PART_BODIES], s_max[PART_BODIES];
+    __shared__ unsigned long long s_prio[CP_MAXU], s_used[PART_BODIES], s_max[2][PART_BODIES];      // (two tables of maxima in turn: one is cleared while the other decides)
     __shared__ unsigned s_bodies[CP_MAXU];
     __shared__ unsigned char s_col[CP_MAXU];
     const int part = blockIdx.x, tid = threadIdx.x;
@@ -861,14 +861,15 @@ static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const un
         s_bodies[i] = ((e.x - base) & (PART_BODIES - 1)) | (((e.y - base) & (PART_BODIES - 1)) << 16);
         s_col[i] = 0xFF;
     }
-    for (int b = tid; b < PART_BODIES; b += CP_T) { s_used[b] = 0ull; s_max[b] = 0ull; }
+    for (int b = tid; b < PART_BODIES; b += CP_T) { s_used[b] = 0ull; s_max[0][b] = 0ull; s_max[1][b] = 0ull; }
     __syncthreads();
-    for (;;) {
+    for (int round = 0;; ++round) {
+        unsigned long long* mx = s_max[round & 1];
         for (int i = tid; i < n; i += CP_T)
             if (s_col[i] == 0xFF) {
                 const unsigned bb = s_bodies[i];
-                atomicMax(&s_max[bb & 0xFFFFu], s_prio[i]);
-                atomicMax(&s_max[bb >> 16], s_prio[i]);
+                atomicMax(&mx[bb & 0xFFFFu], s_prio[i]);
+                atomicMax(&mx[bb >> 16], s_prio[i]);
             }
         __syncthreads();
         int left = 0;
@@ -876,7 +877,7 @@ static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const un
             if (s_col[i] == 0xFF) {
                 const unsigned bb = s_bodies[i], b1 = bb & 0xFFFFu, b2 = bb >> 16;
                 const unsigned long long p = s_prio[i];
-                if (s_max[b1] == p && s_max[b2] == p) {            // nobody else on these two bodies takes a class in this round
+                if (mx[b1] == p && mx[b2] == p) {                  // nobody else on these two bodies takes a class in this round
                     const unsigned long long m = s_used[b1] | s_used[b2];
                     int c = 0;
                     if (!~m) atomicOr(v.flags, 2); else c = __builtin_ctzll(~m);
@@ -884,8 +885,7 @@ static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const un
                     s_col[i] = (unsigned char)c;
                 } else left = 1;
             }
-        __syncthreads();
-        for (int b = tid; b < PART_BODIES; b += CP_T) s_max[b] = 0ull;
+        for (int b = tid; b < PART_BODIES; b += CP_T) s_max[(round + 1) & 1][b] = 0ull;      // (last read before the previous round's closing barrier)
         if (!__syncthreads_or(left)) break;
     }
     for (int i = tid; i < n; i += CP_T) {
