@@ -143,6 +143,9 @@ private:
 
     int device_;
     hipStream_t stream_ = nullptr;
+    hipStream_t side_stream_ = nullptr;      // the LDS islands of a schedule that also has an HBM group (enqueue_sweeps)
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    bool no_side_stream_ = false;            // PHX_NO_SIDE_STREAM=1
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
 
     // device state

@@ -46,6 +46,10 @@ DeviceSolver::~DeviceSolver()
     for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
     hbm_body_list_.release(); grp_owner_.release(); grp_mine_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_recs_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
     xch_off_.release(); xch_err_.release(); isl_trace_.release();
+    part_begin_.release(); part_ranges_.release(); hbm_class_tab_.release(); for (int k = 0; k < 2; ++k) { part_keys_[k].release(); part_vals_[k].release(); }
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (side_stream_) { (void)hipStreamSynchronize(side_stream_); (void)hipStreamDestroy(side_stream_); }
     hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_vel_.release(); snap_dvel_.release(); snap_mpos_.release(); snap_joints_.release(); stage_vel_.release(); stage_dvel_.release(); stage_mpos_.release(); stage_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -73,6 +77,12 @@ int DeviceSolver::init()
     PHX_HIP(hipEventCreate(&ev_end_));
     PHX_HIP(hipEventCreate(&ev_sweep_begin_));
     PHX_HIP(hipEventCreate(&ev_sweep_end_));
+    // the LDS islands of a schedule that also has an HBM group run beside its sweeps (enqueue_sweeps)
+    PHX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+    PHX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    PHX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    const char* ns = getenv("PHX_NO_SIDE_STREAM");        // "1": everything on the one stream (A/B measurements)
+    no_side_stream_ = ns && ns[0] == '1';
     // two control sets alternate between consecutive solves; the first kernel of a solve clears the other one (solver_kernels.h)
     PHX_TRY(hash_.reserve(2));
     PHX_HIP(hipMemsetAsync(hash_.p, 0, 2 * sizeof(unsigned long long), stream_));
@@ -905,6 +915,7 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
     const int lg = sched_.lds_groups;
     if (shard_count_ > 1) PHX_TRY(ensure_partition());       // which groups this rank solves (exchange.h: longest processing time first)
     const int mine = shard_count_ > 1 ? mine_count_ : lg;
+    bool forked = false;
     if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
         iv.group_list = shard_count_ > 1 ? grp_mine_.p : nullptr;
@@ -940,7 +951,16 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
             iv.wave_trace = isl_trace_.p + (size_t)lg * 8;
         }
         const bool big = sched_.lds_lanes > ISL_T;
-        launch_solve_islands(stream_, mine, big, half_state_, iv.trace != nullptr, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        // A schedule with LDS islands AND an HBM group (a world that is merging, or settled around a few loose stacks): the island
+        // launch is one group's chain of class steps — ~90 us whatever the group count — and touches nothing the HBM group's
+        // classes x sweeps launches touch, so it runs beside them on a second stream: fork here, join behind the sweeps.
+        forked = owns_hbm_group() && !use_graphs_ && !no_side_stream_ && !trace_islands_ && side_stream_;
+        if (forked) {
+            PHX_HIP(hipEventRecord(ev_fork_, stream_));
+            PHX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+        }
+        launch_solve_islands(forked ? side_stream_ : stream_, mine, big, half_state_, iv.trace != nullptr, v, iv, d_bodies, d_joints, d_cps, ci, pi);
+        if (forked) PHX_HIP(hipEventRecord(ev_join_, side_stream_));
         ++sweep_launches_;
     }
     if (owns_hbm_group()) {
@@ -967,6 +987,7 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
             }
         }
     }
+    if (forked) PHX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
