@@ -57,23 +57,40 @@ constexpr int COLOUR_B_MAX_JOINTS = 1024;
 
 // PARTITIONED COMPONENTS.  A component of more than COLOUR_B_MAX_JOINTS joints (a settled pile: one island of 1e5-1e6 joints)
 // is swept class by class out of HBM, one launch per class and sweep — a solve is classes x sweeps dependent launches.  Most of
-// such an island is local: cut the bodies into PARTS of PART_BODIES consecutive indices; a unit of a partitioned component is
-// INTERIOR if both its bodies are dynamic and lie in one part, every other unit is a BOUNDARY unit.  The two kinds are coloured
-// independently of each other (first fit in the same priority order, candidate A only, a unit conflicting with the units OF ITS
-// KIND on its dynamic bodies), and in the group that holds the component the interior classes come first:
-//   classes [0, KI)   the interior units of the group's partitioned components — class c of every one of them; KI = the largest
-//                     interior class count among them (0 if there are none: then nothing here changes anything);
-//   classes [KI, ..)  everything else of the group: the boundary units of the partitioned components and the units of its other
-//                     components, each component's classes renumbered densely from KI.
-// Interior units of different parts share no body, so the classes [0, KI) of one sweep need no synchronisation ACROSS parts:
-// one launch sweeps them all, a workgroup per part with the part's bodies in LDS and a barrier per class (k_solve_parts);
-// only the boundary classes remain launches of their own.  Like every colouring it is one more legal Gauss-Seidel order, a
-// pure function of the component (its joints' bodies and ids), hence the same in every island mode and on every rank.
+// such an island is local: cut the bodies into PARTS of PART_BODIES consecutive indices, twice — level 0 at multiples of
+// PART_BODIES, level 1 shifted by half a part.  A unit of a partitioned component whose bodies are both dynamic is INTERIOR AT
+// LEVEL 0 if they lie in one level-0 part, otherwise INTERIOR AT LEVEL 1 if they lie in one level-1 part (the units that straddle
+// a level-0 boundary); every other unit of the group is a REST unit.  The three kinds are coloured independently of each other
+// (first fit in the same priority order, candidate A only, a unit conflicting with the units OF ITS KIND on its dynamic bodies),
+// and in the group that holds the component they come in that order:
+//   classes [0, KI0)        the level-0 interior units of the group's partitioned components — class c of every one of them;
+//                           KI0 = the largest such class count among them (0 if there are none: then nothing here changes anything);
+//   classes [KI0, KI)       the level-1 interior units, likewise (KI = KI0 + KI1);
+//   classes [KI, ..)        everything else of the group: the rest units of the partitioned components and the units of its other
+//                           components, each component's classes renumbered densely from KI.
+// Inside an interior class the slots are laid out part by part.  Interior units of different parts of one level share no body,
+// so the classes of a level need no synchronisation ACROSS parts: one launch per level and sweep sweeps them, a workgroup per
+// part with the part's bodies in LDS and a barrier per class (k_solve_parts); only the rest classes remain launches of their
+// own.  Like every colouring it is one more legal Gauss-Seidel order, a pure function of the component (its joints' bodies and
+// ids), hence the same in every island mode and on every rank.
 constexpr int PART_BODIES = 512;
 static_assert((PART_BODIES & (PART_BODIES - 1)) == 0, "local body indices are masked with PART_BODIES - 1");
-__host__ __device__ inline bool unit_is_interior(unsigned a, unsigned b, bool a_static, bool b_static)
+// parts are numbered over both levels: level 0 = [0, P), level 1 = [P, 2P + 1), P = ceil(bodies / PART_BODIES)
+__host__ __device__ inline int parts_per_level(int nb) { return (nb + PART_BODIES - 1) / PART_BODIES; }
+__host__ __device__ inline int parts_total(int nb) { return 2 * parts_per_level(nb) + 1; }
+__host__ __device__ inline int part_first_body(int part, int nb)      // (negative for the first part of level 1)
 {
-    return !a_static && !b_static && a / (unsigned)PART_BODIES == b / (unsigned)PART_BODIES;
+    const int P = parts_per_level(nb);
+    return part < P ? part * PART_BODIES : (part - P) * PART_BODIES - PART_BODIES / 2;
+}
+// the part a unit on bodies (a, b) is interior to, or -1 (a rest unit)
+__host__ __device__ inline int unit_part(unsigned a, unsigned b, bool a_static, bool b_static, int nb)
+{
+    if (a_static || b_static) return -1;
+    if (a / (unsigned)PART_BODIES == b / (unsigned)PART_BODIES) return (int)(a / (unsigned)PART_BODIES);
+    const unsigned h = (unsigned)PART_BODIES / 2u;
+    if ((a + h) / (unsigned)PART_BODIES == (b + h) / (unsigned)PART_BODIES) return parts_per_level(nb) + (int)((a + h) / (unsigned)PART_BODIES);
+    return -1;
 }
 
 __host__ __device__ inline int colour_pick_two_ended(unsigned long long used_mask, int k_limit, bool from_top)
@@ -102,9 +119,10 @@ struct Schedule {
     std::vector<int> hbm_colour_offsets;  // slots of the HBM group's classes (absolute), empty if there is no HBM group
     std::vector<int> hbm_class_leaders;   // per class of the HBM group: its leaders (the slots behind them are the followers)
     int hbm_interior_classes = 0;         // KI: the HBM group's leading classes that hold interior units of partitioned components only
-    // the interior units by part (host-built schedules; the device builder leaves its tables in HBM): per part and interior class
-    // (64 classes per part) the slot ranges {first, end} of its leaders with a follower and {first, end} of its single leaders,
-    // and the number of interior units before each part (parts + 1)
+    int hbm_interior_classes0 = 0;        // KI0: the level-0 ones among them (the first KI0)
+    // the interior units by part (host-built schedules; the device builder leaves its tables in HBM): per part (parts_total) and
+    // interior class (64 classes per part) the slot ranges {first, end} of its leaders with a follower and {first, end} of its
+    // single leaders, and the number of interior units before each part (parts_total + 1)
     std::vector<int> part_ranges, part_begin;
     // units of the LDS groups, in class order: slots of a unit's leader and follower (-1: none); group g's units are
     // [group_unit_offsets[g], group_unit_offsets[g + 1])

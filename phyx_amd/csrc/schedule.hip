@@ -73,17 +73,20 @@ struct ColourScratch {
 // joints between two static bodies may carry -1).
 static int colour_joints(const std::vector<int>& joints, const int* body1, const int* body2, const unsigned char* is_static,
                          int nb, std::vector<int>& colour, ColourScratch& sc, const int* prio_id, const std::vector<int>& comp,
-                         const std::vector<int>& partner, int* interior_classes = nullptr)
+                         const std::vector<int>& partner, int* interior_classes = nullptr, std::vector<int>* part_of = nullptr)
 {
+    // interior_classes (optional): {KI, KI0} of the group (schedule.h); part_of (optional): per entry the part it is interior to, or -1
     colour.assign(joints.size(), 0);
-    if (interior_classes) *interior_classes = 0;
+    if (interior_classes) { interior_classes[0] = 0; interior_classes[1] = 0; }
     std::vector<int> perm;
     priority_order(joints, prio_id, perm);
     // components, densely numbered; the big ones are PARTITIONED: their interior units form a kind of their own (schedule.h)
     std::vector<unsigned char> comp_bad;                       // per dense component (also set for components too big for B)
     std::vector<int> dense(joints.size());
-    std::vector<unsigned char> interior(joints.size(), 0);
+    std::vector<unsigned char> interior(joints.size(), 0);      // 0: a rest unit; 1 + level: interior at that level
+    std::vector<int> upart(joints.size(), -1);
     bool any_interior = false;
+    const int P = parts_per_level(nb);
     {
         std::vector<std::pair<int, int>> keyed(joints.size());
         for (size_t k = 0; k < joints.size(); ++k) keyed[k] = {comp[k], (int)k};
@@ -99,16 +102,17 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
         for (int d = 0; d < count; ++d) if (size[d] > COLOUR_B_MAX_JOINTS) comp_bad[d] = 1;      // B is not attempted there (schedule.h)
         for (size_t k = 0; k < joints.size(); ++k) {
             const int a = body1[joints[k]], b = body2[joints[k]];
-            if (comp[k] >= 0 && size[dense[k]] > COLOUR_B_MAX_JOINTS && unit_is_interior((unsigned)a, (unsigned)b, is_static[a] != 0, is_static[b] != 0)) {
-                interior[k] = 1; any_interior = true;
+            if (comp[k] >= 0 && size[dense[k]] > COLOUR_B_MAX_JOINTS) {
+                upart[k] = unit_part((unsigned)a, (unsigned)b, is_static[a] != 0, is_static[b] != 0, nb);
+                if (upart[k] >= 0) { interior[k] = upart[k] < P ? 1 : 2; any_interior = true; }
             }
         }
         for (size_t k = 0; k < joints.size(); ++k) if (comp[k] < 0) comp_bad[dense[k]] = 1;      // static-static joints: colour 0 either way
     }
-    // candidate A: smallest free colour (masks widen beyond 64 colours on demand).  Interior units keep masks of their own: rows
-    // nb .. 2 nb of the scratch
+    // candidate A: smallest free colour (masks widen beyond 64 colours on demand).  Interior units keep masks of their own, per
+    // level: rows nb .. 3 nb of the scratch
     std::vector<int> col_a(joints.size(), 0);
-    const int rows = any_interior ? 2 * nb : nb;
+    const int rows = any_interior ? 3 * nb : nb;
     for (;;) {
         sc.ensure(rows);
         const int words = sc.words;
@@ -117,7 +121,7 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
         size_t done = 0;
         for (size_t i = 0; i < joints.size(); ++i) {
             const size_t k = (size_t)perm[i];
-            const int shift = interior[k] ? nb : 0;
+            const int shift = interior[k] * nb;
             const int a = body1[joints[k]] + shift, b = body2[joints[k]] + shift;
             const bool da = !is_static[a - shift], db = !is_static[b - shift];
             int c = -1;
@@ -134,7 +138,7 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
             done = i + 1;
         }
         for (size_t i = 0; i < done; ++i) {                    // leave the scratch clean for the next caller
-            const int shift = interior[perm[i]] ? nb : 0;
+            const int shift = interior[perm[i]] * nb;
             for (int body : {body1[joints[perm[i]]] + shift, body2[joints[perm[i]]] + shift})
                 for (int w = 0; w < words; ++w) used[(size_t)body * words + w] = 0ull;
         }
@@ -172,40 +176,44 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
     const size_t ncomp = comp_bad.size();
     std::vector<int> max_a(ncomp, -1);
     std::vector<unsigned long long> seen_a(ncomp, 0ull), seen_b(ncomp, 0ull);
-    int ki = 0;                                                // interior classes of the group (first fit leaves no gaps inside a component and kind)
+    int ki0 = 0, ki1 = 0;                                      // interior classes of the group per level (first fit leaves no gaps inside a component and kind)
     for (size_t k = 0; k < joints.size(); ++k) {
-        if (interior[k]) { ki = std::max(ki, col_a[k] + 1); continue; }
+        if (interior[k] == 1) { ki0 = std::max(ki0, col_a[k] + 1); continue; }
+        if (interior[k] == 2) { ki1 = std::max(ki1, col_a[k] + 1); continue; }
         max_a[dense[k]] = std::max(max_a[dense[k]], col_a[k]);
         if (col_a[k] < 64) seen_a[dense[k]] |= 1ull << col_a[k];
         seen_b[dense[k]] |= 1ull << col_b[k];
     }
+    const int ki = ki0 + ki1;
     int ncolours = ki;
     for (size_t k = 0; k < joints.size(); ++k) {
-        if (interior[k]) { colour[k] = col_a[k]; continue; }
+        if (interior[k]) { colour[k] = (interior[k] == 2 ? ki0 : 0) + col_a[k]; continue; }
         const int d = dense[k];
         const int count_a = max_a[d] + 1;                      // candidate A leaves no gaps inside a component
         const bool use_b = !comp_bad[d] && __builtin_popcountll(seen_b[d]) < count_a;
         colour[k] = ki + (use_b ? __builtin_popcountll(seen_b[d] & ((1ull << col_b[k]) - 1ull)) : col_a[k]);
         ncolours = std::max(ncolours, colour[k] + 1);
     }
-    if (interior_classes) *interior_classes = ki;
+    if (interior_classes) { interior_classes[0] = ki; interior_classes[1] = ki0; }
+    if (part_of) *part_of = upart;
     return ncolours;
 }
 
 // the interior classes of the HBM group by part (schedule.h): an interior class is laid out part by part, so a part's units of a
 // class are two runs of slots — its leaders with a follower, its single leaders
-static void build_part_tables(Schedule& out, const int* body1, int nb, const std::vector<int>& partner)
+static void build_part_tables(Schedule& out, const int* body1, const int* body2, const unsigned char* is_static, int nb, const std::vector<int>& partner)
 {
     out.part_ranges.clear(); out.part_begin.clear();
     const int ki = out.hbm_interior_classes;
     if (ki <= 0 || ki > 64) return;
-    const int parts = (nb + PART_BODIES - 1) / PART_BODIES;
+    const int parts = parts_total(nb);
     out.part_ranges.assign((size_t)parts * 64 * 4, 0);
     out.part_begin.assign((size_t)parts + 1, 0);
     for (int c = 0; c < ki; ++c) {
         const int cb = out.hbm_colour_offsets[c], lead = out.hbm_class_leaders[c];
         for (int s = cb; s < cb + lead; ++s) {
-            const int j = out.order[s], part = body1[j] / PART_BODIES, kind = partner[j] >= 0 ? 0 : 1;
+            const int j = out.order[s], kind = partner[j] >= 0 ? 0 : 1;
+            const int part = unit_part((unsigned)body1[j], (unsigned)body2[j], is_static[body1[j]] != 0, is_static[body2[j]] != 0, nb);
             int* row = &out.part_ranges[((size_t)part * 64 + c) * 4 + 2 * kind];
             if (row[1] == 0) row[0] = s;
             row[1] = s + 1;
@@ -220,13 +228,13 @@ static void build_part_tables(Schedule& out, const int* body1, int nb, const std
 // (interior classes — `interior_classes` leading ones, schedule.h — are laid out part by part: leaders ordered by (part, joint),
 //  so that the workgroup that sweeps a part reads its units' constants from consecutive slots)
 static void append_group(Schedule& out, const std::vector<int>& leaders_in, const std::vector<int>& colour_in, int ncolours, const std::vector<int>& partner,
-                         std::vector<int>* class_leaders, int interior_classes = 0, const int* body1 = nullptr)
+                         std::vector<int>* class_leaders, int interior_classes = 0, const std::vector<int>* unit_parts = nullptr)
 {
     std::vector<int> leaders_sorted, colour_sorted;
     if (interior_classes > 0) {
         std::vector<int> idx(leaders_in.size());
         for (size_t k = 0; k < idx.size(); ++k) idx[k] = (int)k;
-        auto part_of = [&](int k) { return colour_in[k] < interior_classes ? body1[leaders_in[k]] / PART_BODIES : 0; };
+        auto part_of = [&](int k) { return colour_in[k] < interior_classes ? (*unit_parts)[k] : 0; };
         std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return part_of(x) < part_of(y); });
         leaders_sorted.resize(idx.size()); colour_sorted.resize(idx.size());
         for (size_t k = 0; k < idx.size(); ++k) { leaders_sorted[k] = leaders_in[idx[k]]; colour_sorted[k] = colour_in[idx[k]]; }
@@ -290,11 +298,14 @@ void build_colour_schedule(const int* body1, const int* body2, int nj, const uns
         const int j = leaders[k];
         comp[k] = (is_static[body1[j]] && is_static[body2[j]]) ? -1 : number[root[is_static[body1[j]] ? body2[j] : body1[j]]];
     }
-    const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, comp, partner, &out.hbm_interior_classes);
+    int ki[2] = {0, 0};
+    std::vector<int> unit_parts;
+    const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, comp, partner, ki, &unit_parts);
+    out.hbm_interior_classes = ki[0]; out.hbm_interior_classes0 = ki[1];
     if (nj) {
-        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, body1);
+        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, &unit_parts);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin(), out.colour_offsets.end());
-        build_part_tables(out, body1, nb, partner);
+        build_part_tables(out, body1, body2, is_static, nb, partner);
     }
     out.lds_groups = 0;
     out.islands = false;
@@ -599,11 +610,14 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         std::vector<int> leaders, colour, rest_comp;
         for (int j : rest) if (!is_follower(partner, prio_id, j)) { leaders.push_back(j); rest_comp.push_back(comp_of[j]); }
         ColourScratch scratch;
-        const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp, partner, &out.hbm_interior_classes);
+        int ki[2] = {0, 0};
+        std::vector<int> unit_parts;
+        const int ncol = colour_joints(leaders, body1, body2, is_static, nb, colour, scratch, prio_id, rest_comp, partner, ki, &unit_parts);
+        out.hbm_interior_classes = ki[0]; out.hbm_interior_classes0 = ki[1];
         const size_t first = out.colour_offsets.size() - 1;
-        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, body1);
+        append_group(out, leaders, colour, ncol, partner, &out.hbm_class_leaders, out.hbm_interior_classes, &unit_parts);
         out.hbm_colour_offsets.assign(out.colour_offsets.begin() + first, out.colour_offsets.end());
-        build_part_tables(out, body1, nb, partner);
+        build_part_tables(out, body1, body2, is_static, nb, partner);
         touched_bodies(rest, body1, body2, nb, out.hbm_bodies);
         out.hbm_body_count = (int)out.hbm_bodies.size();
     }

@@ -576,7 +576,7 @@ constexpr unsigned JP_NONE = 0xFFFFFFFFu;
 constexpr int JP_MAX_COLOURS = 64;
 constexpr int JP_LIST_MAX = 4096;            // longer lists (one body in thousands of joints): host builder
 constexpr unsigned JP_STATIC_BIT = 0x80000000u;
-constexpr unsigned char JP_INTERIOR = 4;
+constexpr unsigned char JP_INTERIOR = 4, JP_LEVEL1 = 8;      // an interior unit of a partitioned component (schedule.h), and its level
 constexpr int JP_FRONT_T = 256;       // lanes per workgroup of a round (1024 was measured slower: a 5e4-entry frontier then covers 50 CUs)
 constexpr int JP_SUBLISTS = 8;        // a frontier is kept as 8 lists with a counter each: same-address atomics with a return value cost ~35 ns
                                       // apiece, serialised — one counter made them half of a round
@@ -606,13 +606,14 @@ struct JpView {
     int ncomp;
     unsigned long long* seen_a;       // per component (entry ncomp = the static-static joints): colours in use under A / B
     unsigned long long* seen_b;
+    unsigned long long* seen_c;       // per component: classes in use among its level-1 interior units (level 0: seen_b)
     unsigned char* bad_b;             // per component: B ran out of its 64 colours
     const unsigned* comp_size;        // per component: joints (B is attempted only up to COLOUR_B_MAX_JOINTS)
     unsigned* colour;                 // per entry: JP_NONE until coloured
     unsigned* touched;                // per body: 1 if the group touches it (nb + 1 words, scanned afterwards)
     int* counts;                      // per round and sublist: size of the frontier it colours
     int* flags;                       // bit 0: body index out of range, bit 1: more than JP_MAX_COLOURS colours, bit 2: a list longer than JP_LIST_MAX;
-                                      // flags[1] = KI, the group's interior classes (k_jp_interior_classes)
+                                      // flags[1] = KI0, flags[2] = KI1: the group's interior classes per level (k_jp_interior_classes)
     unsigned* hist;                   // per sort key 2 * class + kind: leaders (filled by the choice)
 };
 
@@ -624,10 +625,10 @@ static __global__ void __launch_bounds__(256) k_jp_clear(JpView v, int rounds_ma
         v.touched[i] = 0u; v.offset[i] = 0u;
         if (i < v.nb) { v.cursor[i] = 0u; v.used[i] = 0ull; v.used_b[i] = 0ull; }
     }
-    for (int i = i0; i <= v.ncomp; i += stride) { v.seen_a[i] = 0ull; v.seen_b[i] = 0ull; v.bad_b[i] = 0; }
+    for (int i = i0; i <= v.ncomp; i += stride) { v.seen_a[i] = 0ull; v.seen_b[i] = 0ull; v.seen_c[i] = 0ull; v.bad_b[i] = 0; }
     for (int i = i0; i < (rounds_max + 1) * JP_SUBLISTS; i += stride) v.counts[i] = 0;
     if (i0 < 2 * JP_MAX_COLOURS) v.hist[i0] = 0u;
-    if (i0 == 0) { v.flags[0] = 0; v.flags[1] = 0; }
+    if (i0 == 0) { v.flags[0] = 0; v.flags[1] = 0; v.flags[2] = 0; }
 }
 
 static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
@@ -644,7 +645,10 @@ static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
         unsigned char kind = mate < 0 ? 1 : ((jt.contact_point_index & 1) ? 2 : 0);
         if (kind != 2 && a < (unsigned)v.nb && b < (unsigned)v.nb) {
             const int jc = v.joint_comp[j];
-            if (jc >= 0 && v.comp_size[jc] > (unsigned)COLOUR_B_MAX_JOINTS && unit_is_interior(a, b, v.is_static[a] != 0, v.is_static[b] != 0)) kind |= JP_INTERIOR;
+            if (jc >= 0 && v.comp_size[jc] > (unsigned)COLOUR_B_MAX_JOINTS) {
+                const int part = unit_part(a, b, v.is_static[a] != 0, v.is_static[b] != 0, v.nb);
+                if (part >= 0) kind |= part < parts_per_level(v.nb) ? JP_INTERIOR : (unsigned char)(JP_INTERIOR | JP_LEVEL1);
+            }
         }
         v.kind[k] = kind;
         if (a >= (unsigned)v.nb || b >= (unsigned)v.nb) {                  // reported; the entry is parked on nothing
@@ -830,7 +834,7 @@ constexpr int CP_T = 256, CP_MAXU = 3072;      // a denser part (> 6 units per b
 static __global__ void __launch_bounds__(256) k_part_sort_keys(JpView v, unsigned behind, unsigned* __restrict__ keys, unsigned* __restrict__ vals)
 {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
-        keys[k] = (v.kind[k] & JP_INTERIOR) ? v.ent[k].x / (unsigned)PART_BODIES : behind;
+        keys[k] = (v.kind[k] & JP_INTERIOR) ? (unsigned)unit_part(v.ent[k].x, v.ent[k].y, false, false, v.nb) : behind;
         vals[k] = (unsigned)k;
     }
 }
@@ -854,11 +858,12 @@ static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const un
     const int pb = part_begin[part], n = part_begin[part + 1] - pb;
     if (n <= 0) return;
     if (n > CP_MAXU) { if (tid == 0) atomicOr(v.flags, 4); return; }
-    const unsigned base = (unsigned)part * (unsigned)PART_BODIES;
+    const int base = part_first_body(part, v.nb);
+    unsigned long long* seen = part < parts_per_level(v.nb) ? v.seen_b : v.seen_c;
     for (int i = tid; i < n; i += CP_T) {
         const uint4 e = v.ent[sorted_entries[pb + i]];
         s_prio[i] = ((unsigned long long)e.w << 32) | e.z;
-        s_bodies[i] = ((e.x - base) & (PART_BODIES - 1)) | (((e.y - base) & (PART_BODIES - 1)) << 16);
+        s_bodies[i] = (unsigned)(((int)e.x - base) & (PART_BODIES - 1)) | ((unsigned)(((int)e.y - base) & (PART_BODIES - 1)) << 16);
         s_col[i] = 0xFF;
     }
     for (int b = tid; b < PART_BODIES; b += CP_T) { s_used[b] = 0ull; s_max[0][b] = 0ull; s_max[1][b] = 0ull; }
@@ -893,15 +898,18 @@ static __global__ void __launch_bounds__(CP_T) k_colour_parts(JpView v, const un
         v.colour_b[k] = c; v.colour[k] = c;
         const unsigned comp = v.ent_comp[k];
         const unsigned long long bit = 1ull << c;
-        if (!(__hip_atomic_load(&v.seen_b[comp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&v.seen_b[comp], bit);
+        if (!(__hip_atomic_load(&seen[comp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&seen[comp], bit);
     }
 }
 
-// KI = the largest interior class count among the group's partitioned components (schedule.h)
+// KI0, KI1 = the largest interior class counts, per level, among the group's partitioned components (schedule.h)
 static __global__ void __launch_bounds__(256) k_jp_interior_classes(JpView v)
 {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < v.ncomp; c += gridDim.x * blockDim.x)
-        if (v.comp_size[c] > (unsigned)COLOUR_B_MAX_JOINTS && v.seen_b[c]) atomicMax(v.flags + 1, __popcll(v.seen_b[c]));
+        if (v.comp_size[c] > (unsigned)COLOUR_B_MAX_JOINTS) {
+            if (v.seen_b[c]) atomicMax(v.flags + 1, __popcll(v.seen_b[c]));
+            if (v.seen_c[c]) atomicMax(v.flags + 2, __popcll(v.seen_c[c]));
+        }
 }
 
 // every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order; the
@@ -911,17 +919,17 @@ static __global__ void __launch_bounds__(256) k_jp_choose(JpView v)
     __shared__ unsigned h[2 * JP_MAX_COLOURS];
     if (threadIdx.x < 2 * JP_MAX_COLOURS) h[threadIdx.x] = 0;
     __syncthreads();
-    const unsigned ki = (unsigned)v.flags[1];
+    const unsigned ki0 = (unsigned)v.flags[1], ki = ki0 + (unsigned)v.flags[2];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < v.count; k += gridDim.x * blockDim.x) {
         const unsigned char kind = v.kind[k] & 3;
         if (kind == 2) { v.colour[k] = 255u; continue; }                         // followers sort behind every leader; their leaders place them
         const int comp = (int)v.ent_comp[k];
-        const unsigned long long sa = v.seen_a[comp], sb = v.seen_b[comp];
-        const bool interior = (v.kind[k] & JP_INTERIOR) != 0;
+        const bool interior = (v.kind[k] & JP_INTERIOR) != 0, level1 = (v.kind[k] & JP_LEVEL1) != 0;
+        const unsigned long long sa = v.seen_a[comp], sb = level1 ? v.seen_c[comp] : v.seen_b[comp];
         const bool use_b = !interior && comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS && !v.bad_b[comp] && __popcll(sb) < __popcll(sa);
         const unsigned c = (use_b || interior) ? v.colour_b[k] : v.colour[k];
         unsigned cls = (unsigned)__popcll(((use_b || interior) ? sb : sa) & ((1ull << c) - 1ull));
-        if (!interior) cls += ki;
+        cls += interior ? (level1 ? ki0 : 0u) : ki;
         if (cls >= (unsigned)JP_MAX_COLOURS) { atomicOr(v.flags, 2); cls = JP_MAX_COLOURS - 1; }
         const unsigned key = 2 * cls + kind;            // sort key: class, then 'leads a unit of two' before 'single'
         v.colour[k] = key;
@@ -960,7 +968,7 @@ static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigne
     }
     __syncthreads();
     const int leaders = (int)(lead_begin[JP_MAX_COLOURS - 1] + lead_n[JP_MAX_COLOURS - 1]);
-    const unsigned ki = (unsigned)v.flags[1];
+    const unsigned ki = (unsigned)(v.flags[1] + v.flags[2]);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < leaders; p += gridDim.x * blockDim.x) {
         const unsigned key = sorted_keys[p], c = key >> 1;
         const int j = (int)sorted_joints[p];
@@ -969,10 +977,11 @@ static __global__ void __launch_bounds__(256) k_jp_place(JpView v, const unsigne
         order_out[slot] = j;
         if (!(key & 1u)) order_out[slot_begin[c] + lead_n[c] + r] = v.partner[j];
         if (ranges && c < ki) {                        // an interior unit: first / last of its (part, class, kind) run?
-            const unsigned part = (unsigned)v.joints[j].body1 / (unsigned)PART_BODIES;
+            auto part_of = [&](int joint) { const phx_contact_joint q = v.joints[joint]; return unit_part((unsigned)q.body1, (unsigned)q.body2, false, false, v.nb); };
+            const int part = max(part_of(j), 0);           // (an interior class holds interior units only)
             int* row = ranges + ((size_t)part * JP_MAX_COLOURS + c) * 4 + 2 * (key & 1u);
-            const bool first = p == 0 || sorted_keys[p - 1] != key || (unsigned)v.joints[sorted_joints[p - 1]].body1 / (unsigned)PART_BODIES != part;
-            const bool last = p + 1 >= leaders || sorted_keys[p + 1] != key || (unsigned)v.joints[sorted_joints[p + 1]].body1 / (unsigned)PART_BODIES != part;
+            const bool first = p == 0 || sorted_keys[p - 1] != key || part_of((int)sorted_joints[p - 1]) != part;
+            const bool last = p + 1 >= leaders || sorted_keys[p + 1] != key || part_of((int)sorted_joints[p + 1]) != part;
             if (first) row[0] = slot_base + slot;
             if (last) row[1] = slot_base + slot + 1;
         }

@@ -37,7 +37,8 @@ struct PartsView {
                                 // follower, {first, end} of its single leaders (an interior class is laid out part by part, schedule.h)
     const int* part_begin;      // parts + 1: interior units before each part (an empty part is skipped)
     const int4* class_tab;      // per class of the HBM group: {first slot, leaders, followers, leaders of the classes before}
-    int ki, parts;
+    int first_part, parts;      // the parts of ONE level (schedule.h): a launch sweeps them, workgroup w = part first_part + w
+    int c0, c1;                 // ... and that level's classes [c0, c1)
 };
 constexpr int PARTS_CLASS_STRIDE = 64;      // = JP_MAX_COLOURS, the device schedule builder's class limit
 
@@ -169,7 +170,13 @@ private:
     int upload_class_tab(const Schedule& sc, int* interior_leaders);
     int upload_part_tables();            // host-built schedules: part_units_ / part_class_begin_ from sched_
     bool parts_in_use() const { return !no_parts_ && part_count_ > 0 && sched_.hbm_interior_classes > 0; }
-    PartsView parts_view() const { return PartsView{part_ranges_.p, part_begin_.p, hbm_class_tab_.p, sched_.hbm_interior_classes, part_count_}; }
+    int part_levels() const { return sched_.hbm_interior_classes > sched_.hbm_interior_classes0 ? 2 : 1; }
+    PartsView parts_view(int level, int nb) const
+    {
+        const int P = parts_per_level(nb), ki0 = sched_.hbm_interior_classes0, ki = sched_.hbm_interior_classes;
+        return level == 0 ? PartsView{part_ranges_.p, part_begin_.p, hbm_class_tab_.p, 0, P, 0, ki0}
+                          : PartsView{part_ranges_.p, part_begin_.p, hbm_class_tab_.p, P, P + 1, ki0, ki};
+    }
     DevBuf<int4> unit_recs_;            // per LDS group (stride = lanes of the kernel shape), two words per unit: joints, contact points, local bodies, class, slots (island_view.h)
     DevBuf<unsigned> slot_local_;
     DevBuf<unsigned char> slot_colour_;

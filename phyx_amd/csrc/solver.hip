@@ -593,7 +593,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_degree_.reserve(nbs + 1));
         PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs));
         PHX_TRY(jp_small_.reserve(2 * JP_MAX_COLOURS + 8)); PHX_TRY(jp_kind_.reserve(njs)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
-        PHX_TRY(jp_seen_.reserve(2 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
+        PHX_TRY(jp_seen_.reserve(3 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
         // (sized by the joint count, not by the group's: while a world settles the HBM group grows every step, and regrowing a score
         //  of arrays — hipMalloc + hipFree each — cost 3 ms whenever it crossed a capacity)
         PHX_TRY(jp_ent_.reserve(njs)); PHX_TRY(jp_succ_.reserve(njs)); PHX_TRY(jp_pred_.reserve(njs)); PHX_TRY(jp_colour_b_.reserve(njs));
@@ -605,10 +605,10 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         jv.succ = jp_succ_.p; jv.pred = jp_pred_.p;
         jv.used = jp_used_.p; jv.used_b = jp_used_b_.p; jv.colour = jp_keys_[0].p; jv.colour_b = jp_colour_b_.p; jv.touched = jp_touched_.p;
         jv.joint_comp = joint_comp_.p; jv.partner = partner_.p; jv.kind = jp_kind_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
-        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.bad_b = jp_bad_b_.p;
+        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.seen_c = jp_seen_.p + 2 * ((size_t)ncomp_total + 1); jv.bad_b = jp_bad_b_.p;
         jv.counts = jp_counts_.p; jv.flags = jp_small_.p; jv.hist = reinterpret_cast<unsigned*>(jp_small_.p + 4);
         const unsigned* perm = nullptr;                     // the entries sorted by part (partitioned components only)
-        const int parts = div_up(nb, PART_BODIES);
+        const int parts = parts_total(nb);                    // over both levels (schedule.h)
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
         // priority, successor links and predecessor counts
         hipLaunchKernelGGL(k_jp_clear, dim3(grid_for(std::max(nb + 1, ncomp_total + 1))), dim3(256), 0, stream_, jv, JP_ROUNDS_MAX + 1);
@@ -689,12 +689,12 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, sort_scan_, stream_));
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)sflags, nb, static_slot_.p);
         unsigned h_nstatic = 0;
-        int h_flags[2] = {0, 0};                               // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI
+        int h_flags[3] = {0, 0, 0};                            // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI0; [2] KI1
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
         PHX_TRY(rb_.add(h_flags, jp_small_.p, sizeof h_flags, stream_));
         PHX_TRY(rb_.wait(stream_));
         if (h_flags[0] & 2) { *fallback = true; return PHX_OK; }
-        sc.hbm_interior_classes = h_flags[1];
+        sc.hbm_interior_classes = h_flags[1] + h_flags[2]; sc.hbm_interior_classes0 = h_flags[1];
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
         sc.hbm_colour_offsets.assign(1, lds_slots);
@@ -893,8 +893,11 @@ int DeviceSolver::enqueue_pre(const BodyView& d_bodies, int nb, const phx_contac
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
         size_t c0 = 0;
-        if (parts_in_use()) {          // the interior classes of partitioned components: one launch, a workgroup per part
-            hipLaunchKernelGGL(k_prestep_parts, dim3(part_count_), dim3(PARTS_T), 0, stream_, v, parts_view());
+        if (parts_in_use()) {          // the interior classes of partitioned components: one launch per level, a workgroup per part
+            for (int level = 0; level < part_levels(); ++level) {
+                const PartsView pv = parts_view(level, nb);
+                hipLaunchKernelGGL(k_prestep_parts, dim3(pv.parts), dim3(PARTS_T), 0, stream_, v, pv);
+            }
             c0 = (size_t)sched_.hbm_interior_classes;
         }
         for (size_t c = c0; c + 1 < sched_.hbm_colour_offsets.size(); ++c) {
@@ -968,13 +971,15 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
         for (int it = 0; it < iters; ++it) {
             const bool imp = it < ci, disp = it < pi;
             int c0 = 0;
-            if (parts_in_use()) {      // classes [0, KI) of this sweep in one launch (solver_kernels.h k_solve_parts)
-                const dim3 g(part_count_), b(PARTS_T);
-                const PartsView pv = parts_view();
-                if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true>), g, b, 0, stream_, v, pv, it);
-                else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false>), g, b, 0, stream_, v, pv, it);
-                else             hipLaunchKernelGGL((k_solve_parts<false, true>), g, b, 0, stream_, v, pv, it);
-                ++sweep_launches_;
+            if (parts_in_use()) {      // classes [0, KI) of this sweep: one launch per level (solver_kernels.h k_solve_parts)
+                for (int level = 0; level < part_levels(); ++level) {
+                    const PartsView pv = parts_view(level, v.nb);
+                    const dim3 g(pv.parts), b(PARTS_T);
+                    if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true>), g, b, 0, stream_, v, pv, it);
+                    else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false>), g, b, 0, stream_, v, pv, it);
+                    else             hipLaunchKernelGGL((k_solve_parts<false, true>), g, b, 0, stream_, v, pv, it);
+                    ++sweep_launches_;
+                }
                 c0 = sched_.hbm_interior_classes;
             }
             for (int c = c0; c < ncol; ++c) {

@@ -420,21 +420,22 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
 {
     __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
     __shared__ float4 s_disp[DO_DISP ? PART_BODIES : 1];
-    const int part = blockIdx.x, tid = threadIdx.x;
+    const int part = pv.first_part + (int)blockIdx.x, tid = threadIdx.x;
     if (pv.part_begin[part] == pv.part_begin[part + 1]) return;      // nothing of a partitioned component in this part
     const int4* ranges = pv.ranges + (size_t)part * PARTS_CLASS_STRIDE;
     const bool imp_on = DO_IMP;
     const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
     if (!imp_on && !disp_on) return;
-    const int base = part * PART_BODIES;
-    const int count = min(PART_BODIES, v.nb - base);
-    for (int i = tid; i < count; i += PARTS_T) {
-        if (DO_IMP) s_imp[i] = v.sb_imp[base + i];
-        if (DO_DISP) { if (disp_on) s_disp[i] = v.sb_disp[base + i]; }
+    const int base = part_first_body(part, v.nb);           // (level 1: shifted by half a part; its first part starts below body 0)
+    for (int i = tid; i < PART_BODIES; i += PARTS_T) {
+        const int g = base + i;
+        if (g < 0 || g >= v.nb) continue;
+        if (DO_IMP) s_imp[i] = v.sb_imp[g];
+        if (DO_DISP) { if (disp_on) s_disp[i] = v.sb_disp[g]; }
     }
     __syncthreads();
     bool any_imp = false, any_disp = false;
-    for (int c = 0; c < pv.ki; ++c) {
+    for (int c = pv.c0; c < pv.c1; ++c) {
         const int4 tab = pv.class_tab[c], rg = ranges[c];
         const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;      // the part's units of this class: n2 with a follower, then the single ones
         for (int u = tid; u < n; u += PARTS_T) {
@@ -457,9 +458,11 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
         }
         __syncthreads();
     }
-    for (int i = tid; i < count; i += PARTS_T) {
-        if (DO_IMP) v.sb_imp[base + i] = s_imp[i];
-        if (DO_DISP) { if (disp_on) v.sb_disp[base + i] = s_disp[i]; }
+    for (int i = tid; i < PART_BODIES; i += PARTS_T) {
+        const int g = base + i;
+        if (g < 0 || g >= v.nb) continue;
+        if (DO_IMP) v.sb_imp[g] = s_imp[i];
+        if (DO_DISP) { if (disp_on) v.sb_disp[g] = s_disp[i]; }
     }
     if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
     if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
@@ -469,14 +472,13 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
 static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, PartsView pv)
 {
     __shared__ float4 s_imp[PART_BODIES];
-    const int part = blockIdx.x;
+    const int part = pv.first_part + (int)blockIdx.x;
     if (pv.part_begin[part] == pv.part_begin[part + 1]) return;
     const int4* ranges = pv.ranges + (size_t)part * PARTS_CLASS_STRIDE;
-    const int base = part * PART_BODIES;
-    const int count = min(PART_BODIES, v.nb - base);
-    for (int i = threadIdx.x; i < count; i += PARTS_T) s_imp[i] = v.sb_imp[base + i];
+    const int base = part_first_body(part, v.nb);
+    for (int i = threadIdx.x; i < PART_BODIES; i += PARTS_T) { const int g = base + i; if (g >= 0 && g < v.nb) s_imp[i] = v.sb_imp[g]; }
     __syncthreads();
-    for (int c = 0; c < pv.ki; ++c) {
+    for (int c = pv.c0; c < pv.c1; ++c) {
         const int4 tab = pv.class_tab[c], rg = ranges[c];
         const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;
         for (int u = (int)threadIdx.x; u < n; u += PARTS_T) {
@@ -492,7 +494,7 @@ static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, 
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < count; i += PARTS_T) v.sb_imp[base + i] = s_imp[i];
+    for (int i = threadIdx.x; i < PART_BODIES; i += PARTS_T) { const int g = base + i; if (g >= 0 && g < v.nb) v.sb_imp[g] = s_imp[i]; }
 }
 
 // ---- FinishJoints + FinishBodies (ref: Solver.cpp:482-494, 527-547) --------------------------------

@@ -93,23 +93,35 @@ def test_colour_schedule_invariants(built_lib, name, ids):
     size = {}
     for j in leaders:
         size[comp[j]] = size.get(comp[j], 0) + (2 if partner[j] >= 0 else 1)          # joints of the component
-    # a component of more than 1024 joints is partitioned: units with both bodies dynamic and in one block of 512 body indices
-    # are INTERIOR, a kind of their own — own masks, own classes, and their classes come first in the group
-    interior = {j: comp[j][0] == "c" and size[comp[j]] > 1024 and not static[b1[j]] and not static[b2[j]] and b1[j] // 512 == b2[j] // 512
-                for j in leaders}
+    # a component of more than 1024 joints is partitioned: a unit with both bodies dynamic and in one block of 512 body indices
+    # is INTERIOR AT LEVEL 0, otherwise — if they share a block of the same grid shifted by 256 — AT LEVEL 1; each level is a kind
+    # of its own — own masks, own classes — and their classes come first in the group, level 0 before level 1
+    nparts = (len(bodies) + 511) // 512
+
+    def level_part(j):
+        if not (comp[j][0] == "c" and size[comp[j]] > 1024) or static[b1[j]] or static[b2[j]]:
+            return None
+        if b1[j] // 512 == b2[j] // 512:
+            return 0, b1[j] // 512
+        if (b1[j] + 256) // 512 == (b2[j] + 256) // 512:
+            return 1, nparts + (b1[j] + 256) // 512
+        return None
+    where = {j: level_part(j) for j in leaders}
+    interior = {j: where[j] is not None for j in leaders}
     assert any(interior.values()) or name != "wall48x60"
-    used_a, used_b, used_i, col_a, col_b, bad_b = {}, {}, {}, {}, {}, set()
+    used_a, used_b, used_i, col_a, col_b, bad_b = {}, {}, ({}, {}), {}, {}, set()
     for j in sorted(leaders, key=lambda j: -int(prio[j])):
         dyn = [b for b in (b1[j], b2[j]) if not static[b]]
         if interior[j]:
-            mi = used_i.get(b1[j], 0) | used_i.get(b2[j], 0)
+            used = used_i[where[j][0]]
+            mi = used.get(b1[j], 0) | used.get(b2[j], 0)
             ci = 0
             while mi >> ci & 1:
                 ci += 1
             col_a[j] = ci
             col_b[j] = 0
             for b in dyn:
-                used_i[b] = used_i.get(b, 0) | 1 << ci
+                used[b] = used.get(b, 0) | 1 << ci
             continue
         ma = 0
         mb = 0
@@ -138,17 +150,18 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         for b in dyn:
             used_a[b] = used_a.get(b, 0) | 1 << ca
     seen_a, seen_b = {}, {}
-    ki = max([col_a[j] + 1 for j in leaders if interior[j]] + [0])                    # the group's interior classes
+    ki0 = max([col_a[j] + 1 for j in leaders if interior[j] and where[j][0] == 0] + [0])      # the group's interior classes, per level
+    ki = ki0 + max([col_a[j] + 1 for j in leaders if interior[j] and where[j][0] == 1] + [0])
     for j in leaders:
         if not interior[j]:
             seen_a.setdefault(comp[j], set()).add(col_a[j])
             seen_b.setdefault(comp[j], set()).add(col_b[j])
     for c, (sl, with_f, single) in enumerate(layouts):                # the layout of a class; an interior class is laid out part by part
-        key = (lambda j: (b1[j] // 512, j)) if c < ki else (lambda j: j)
+        key = (lambda j: (where[j][1], j)) if c < ki else (lambda j: j)
         assert sl == sorted(with_f, key=key) + sorted(single, key=key) + [partner[j] for j in sorted(with_f, key=key)]
     for j in leaders:
         if interior[j]:
-            assert class_of[j] == col_a[j] < ki, "joint %d" % j
+            assert class_of[j] == (ki0 if where[j][0] else 0) + col_a[j] < ki, "joint %d" % j
         else:
             use_b = comp[j] not in bad_b and size[comp[j]] <= 1024 and comp[j][0] == "c" and len(seen_b[comp[j]]) < len(seen_a[comp[j]])
             chosen, c = (seen_b[comp[j]], col_b[j]) if use_b else (seen_a[comp[j]], col_a[j])
@@ -158,7 +171,7 @@ def test_colour_schedule_invariants(built_lib, name, ids):
     if name == "wall48x60":
         # what the partition buys: the interior classes hold most of the units and are one launch per sweep
         n_int = sum(1 for j in leaders if interior[j])
-        assert n_int > 0.7 * len(leaders) and ki + 1 < len(offs) - 1 <= ki + 8
+        assert n_int > 0.9 * len(leaders) and ki0 < ki < len(offs) - 1 <= ki + 4
     elif not ki:
         # and it never needs more classes than plain first-fit
         assert len(offs) - 1 <= max(col_a.values()) + 1
