@@ -248,9 +248,10 @@ int phx_solver_get_schedule(phx_solver* s, int32_t* order, int32_t order_cap,
 int phx_solver_get_groups(phx_solver* s, int32_t* group_offsets, int32_t offsets_cap, int32_t* group_count, int32_t* lds_group_count);
 
 /* Partitioned components: a connected component of more than 1024 joints — a settled pile — has its units
- * split into INTERIOR ones (both bodies dynamic and in the same block of 512 consecutive body indices) and the rest; the interior
- * units occupy the first `interior_classes` classes of the schedule's last group and are swept by ONE launch per sweep (a
- * workgroup per block, `parts` of them; 0 when the schedule has no such component or PHX_NO_PARTS=1).  `sweep_launches`:
+ * split into INTERIOR ones (both bodies dynamic and in the same block of 512 consecutive body indices: level 0; or, failing that,
+ * in the same block of that grid shifted by 256: level 1) and the rest; the interior units occupy the first `interior_classes`
+ * classes of the schedule's last group (level 0 before level 1) and are swept by ONE launch per level and sweep (a workgroup per
+ * block, `parts` of them over both levels; 0 when the schedule has no such component or PHX_NO_PARTS=1).  `sweep_launches`:
  * kernel launches of the last solve's sweeps. */
 int phx_solver_get_partition(phx_solver* s, int32_t* interior_classes, int32_t* parts, int32_t* sweep_launches);
 
