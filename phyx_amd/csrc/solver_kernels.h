@@ -413,7 +413,10 @@ constexpr int PARTS_T = 256;
 //  (schedule.h).  Requesting a part's constants ahead of the class steps was built four ways — all of a part's units in registers
 //  (512 lanes x 3, 256 x 5, 256 x 4 with a slimmed record: 42-57 us, spills; beyond 128 VGPRs the parts need two rounds), and
 //  chunks of two units per lane (no spills, 188 VGPRs): none is faster than this form, whose ~60 VGPRs let every part be
-//  resident at once; the step is bound by the part with the longest chain of classes.)
+//  resident at once; the step is bound by the part with the longest chain of classes.  Also built: the workgroup's eight waves as
+//  four pairs that take the classes in turn, each requesting the constants of its next class the moment it has swept one, with
+//  bare `s_waitcnt lgkmcnt(0); s_barrier` between classes so that those loads stay in flight — bit-exact, and 23 us per launch
+//  against 15.)
 
 template <bool DO_IMP, bool DO_DISP>
 static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, PartsView pv, int iter)
@@ -467,6 +470,7 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
     if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
     if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
 }
+
 
 // PreStepJoints of the interior classes, the same way (k_prestep's arithmetic and order)
 static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, PartsView pv)
