@@ -545,7 +545,8 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     sst = cfg2_world.solver.stats()
     ki, parts, launches = cfg2_world.solver.partition()
     res["settled_world_step"] = {"what": "World::Update of the same 200k-box world at steps 57-61: the columns have merged into one island (HBM path; its "
-                                         "interior units — both bodies in one block of 512 — swept by one launch per sweep, a workgroup per block)",
+                                         "interior units — both bodies in one block of 512 body indices, of the plain grid or of the grid shifted by 256 — "
+                                         "swept by one launch per level and sweep, a workgroup per block)",
                                  "ms_per_step": 1e3 * float(np.median(t)), "lds_islands": sst.lds_islands, "colours": sst.colour_count,
                                  "interior_classes": ki, "parts": parts, "sweep_launches_per_solve": launches,
                                  "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), cfg2_world.counts()))}
