@@ -27,7 +27,7 @@ def test_falling_scene_is_reproducible():
 
 
 @pytest.mark.parametrize("ids", ["joint_index", "contact_point_index"])
-@pytest.mark.parametrize("name", list(SMALL_SCENES) + ["synthetic_units_and_near_misses", "wall48x60"])
+@pytest.mark.parametrize("name", list(SMALL_SCENES) + ["synthetic_units_and_near_misses", "wall48x60", "synthetic_one_big_component"])
 def test_colour_schedule_invariants(built_lib, name, ids):
     """The schedule rule of csrc/schedule.h restated independently in Python: units (the two joints of a body pair whose ids
     differ in the lowest bit), first fit over the units in priority order with two candidates, the choice per connected
@@ -38,6 +38,9 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         bodies, _, joints = presolve_state(make(), warm)
     elif name == "wall48x60":
         bodies, _, joints = presolve_state(scenes.wall(48, 60), 10)      # (the rows come to rest on each other from the bottom up: one component by step 10)
+    elif name == "synthetic_one_big_component":                      # random pairs over 1500 bodies: one component of thousands of joints,
+        from test_solver_gpu import _random_state                    # its units of all three kinds (interior at level 0 / 1, rest)
+        bodies, _, joints = _random_state(np.random.default_rng(11), 1500, 5000, 0.02, units=True)
     else:                                                            # couples on random body pairs + the near misses that must not pair
         from test_solver_gpu import _random_state
         bodies, _, joints = _random_state(np.random.default_rng(6), 300, 900, 0.1, units=True)
@@ -60,7 +63,7 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         if o >= 0 and b1[o] == b1[j] and b2[o] == b2[j]:
             partner[j] = o
     follower = [partner[j] >= 0 and (int(pid[j]) & 1) == 1 for j in range(nj)]
-    assert sum(follower) > 0 or name == "falling600"
+    assert sum(follower) > 0 or name == "falling600" or (name == "synthetic_one_big_component" and ids == "joint_index")
     leaders = [j for j in range(nj) if not follower[j]]
     class_of = np.zeros(nj, dtype=np.int64)
     layouts = []
@@ -108,7 +111,10 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         return None
     where = {j: level_part(j) for j in leaders}
     interior = {j: where[j] is not None for j in leaders}
-    assert any(interior.values()) or name != "wall48x60"
+    assert any(interior.values()) or name not in ("wall48x60", "synthetic_one_big_component")
+    if name == "synthetic_one_big_component":
+        kinds = [where[j][0] if where[j] else 2 for j in leaders]
+        assert min(kinds.count(0), kinds.count(1), kinds.count(2)) > 50
     used_a, used_b, used_i, col_a, col_b, bad_b = {}, {}, ({}, {}), {}, {}, set()
     for j in sorted(leaders, key=lambda j: -int(prio[j])):
         dyn = [b for b in (b1[j], b2[j]) if not static[b]]
