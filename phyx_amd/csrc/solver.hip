@@ -975,9 +975,15 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
                 for (int level = 0; level < part_levels(); ++level) {
                     const PartsView pv = parts_view(level, v.nb);
                     const dim3 g(pv.parts), b(PARTS_T);
-                    if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true>), g, b, 0, stream_, v, pv, it);
-                    else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false>), g, b, 0, stream_, v, pv, it);
-                    else             hipLaunchKernelGGL((k_solve_parts<false, true>), g, b, 0, stream_, v, pv, it);
+                    if (level == 0) {
+                        if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true, false>), g, b, 0, stream_, v, pv, it);
+                        else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false, false>), g, b, 0, stream_, v, pv, it);
+                        else             hipLaunchKernelGGL((k_solve_parts<false, true, false>), g, b, 0, stream_, v, pv, it);
+                    } else {           // a level-1 part has a few dozen units: a lane owns one, everything requested up front
+                        if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true, true>), g, b, 0, stream_, v, pv, it);
+                        else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false, true>), g, b, 0, stream_, v, pv, it);
+                        else             hipLaunchKernelGGL((k_solve_parts<false, true, true>), g, b, 0, stream_, v, pv, it);
+                    }
                     ++sweep_launches_;
                 }
                 c0 = sched_.hbm_interior_classes;

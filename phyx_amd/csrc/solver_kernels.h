@@ -418,7 +418,10 @@ constexpr int PARTS_T = 256;
 //  bare `s_waitcnt lgkmcnt(0); s_barrier` between classes so that those loads stay in flight — bit-exact, and 23 us per launch
 //  against 15.)
 
-template <bool DO_IMP, bool DO_DISP>
+// OWN_ONE (the level-1 launch: a part there has a few dozen units): lane t owns the part's t-th unit and requests its constants
+// together with the part's bodies — one memory round trip for the whole launch instead of one per class; units beyond the lanes
+// (a part with more than PARTS_T of them) are requested in their class step as in the plain form.
+template <bool DO_IMP, bool DO_DISP, bool OWN_ONE>
 static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, PartsView pv, int iter)
 {
     __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
@@ -430,6 +433,22 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
     const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
     if (!imp_on && !disp_on) return;
     const int base = part_first_body(part, v.nb);           // (level 1: shifted by half a part; its first part starts below body 0)
+    int own_c = -1, own_s0 = 0, own_s1 = -1;
+    HbmJoint own_q0{}, own_q1{};
+    if (OWN_ONE) {
+        int before = 0;
+        for (int c = pv.c0; c < pv.c1 && own_c < 0; ++c) {
+            const int4 tab = pv.class_tab[c], rg = ranges[c];
+            const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z, u = tid - before;
+            if (u < n) {
+                own_c = c;
+                own_s0 = u < n2 ? rg.x + u : rg.z + (u - n2);
+                own_q0 = hbm_load(v, own_s0, imp_on, disp_on, false);
+                if (u < n2) { own_s1 = tab.x + tab.y + (own_s0 - tab.x); own_q1 = hbm_load(v, own_s1, imp_on, disp_on, true); }
+            }
+            before += n;
+        }
+    }
     for (int i = tid; i < PART_BODIES; i += PARTS_T) {
         const int g = base + i;
         if (g < 0 || g >= v.nb) continue;
@@ -438,27 +457,33 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
     }
     __syncthreads();
     bool any_imp = false, any_disp = false;
+    auto sweep = [&](int s0, int s1, HbmJoint& q0, HbmJoint& q1, int c) {
+        const int b1 = (q0.k.y - base) & (PART_BODIES - 1), b2 = (q0.k.z - base) & (PART_BODIES - 1);      // (masked: a stale schedule may meet other joints, solver.h)
+        float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
+        if (DO_IMP) { B1 = s_imp[b1]; B2 = s_imp[b2]; }
+        if (DO_DISP) { if (disp_on) { D1 = s_disp[b1]; D2 = s_disp[b2]; } }
+        const float im1 = q0.c.y, ii1 = q0.c.z, im2 = q0.c.w, ii2 = __int_as_float(q0.k.x);
+        bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
+        solve_one(v, s0, q0, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        if (s1 >= 0)
+            solve_one(v, s1, q1, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        if (DO_IMP) { if (dirty_imp) { s_imp[b1] = B1; s_imp[b2] = B2; } }
+        if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
+    };
+    int before = 0;                                         // units of the level's earlier classes in this part
     for (int c = pv.c0; c < pv.c1; ++c) {
         const int4 tab = pv.class_tab[c], rg = ranges[c];
         const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;      // the part's units of this class: n2 with a follower, then the single ones
-        for (int u = tid; u < n; u += PARTS_T) {
+        if (OWN_ONE) { if (own_c == c) sweep(own_s0, own_s1, own_q0, own_q1, c); }
+        for (int u = OWN_ONE ? max(PARTS_T - before, 0) + tid : tid; u < n; u += PARTS_T) {      // (OWN_ONE: the units no lane owns)
             const bool has2 = u < n2;
             const int s0 = has2 ? rg.x + u : rg.z + (u - n2), i = s0 - tab.x;
-            const int s1 = tab.x + tab.y + i;
+            const int s1 = has2 ? tab.x + tab.y + i : -1;
             HbmJoint q0 = hbm_load(v, s0, imp_on, disp_on, false), q1{};
             if (has2) q1 = hbm_load(v, s1, imp_on, disp_on, true);
-            const int b1 = (q0.k.y - base) & (PART_BODIES - 1), b2 = (q0.k.z - base) & (PART_BODIES - 1);      // (masked: a stale schedule may meet other joints, solver.h)
-            float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
-            if (DO_IMP) { B1 = s_imp[b1]; B2 = s_imp[b2]; }
-            if (DO_DISP) { if (disp_on) { D1 = s_disp[b1]; D2 = s_disp[b2]; } }
-            const float im1 = q0.c.y, ii1 = q0.c.z, im2 = q0.c.w, ii2 = __int_as_float(q0.k.x);
-            bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
-            solve_one(v, s0, q0, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
-            if (has2)
-                solve_one(v, s1, q1, c, iter, imp_on, disp_on, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
-            if (DO_IMP) { if (dirty_imp) { s_imp[b1] = B1; s_imp[b2] = B2; } }
-            if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
+            sweep(s0, s1, q0, q1, c);
         }
+        before += n;
         __syncthreads();
     }
     for (int i = tid; i < PART_BODIES; i += PARTS_T) {
