@@ -63,6 +63,6 @@ for B in (200, 256, 400, 512, 768, 1024, 2048):
         ki, _ = first_fit(d1, d2, len(b), oi)          # parts are body-disjoint: one pass colours them all, max = classes of the worst part
         oe = order[~interior[order]]
         ke, ce = first_fit(d1, d2, len(b), oe)
-        sizes = np.bincount(ce, minlength=ke)
+        sizes = np.bincount(ce[~interior], minlength=ke)
         print("B=%5d off=%d: interior %7d (%.1f %%) in %d classes -> 1 launch; interface %7d in %d classes (sizes %s) -> %d launches per sweep"
               % (B, off, ni, 100.0 * ni / nu, ki, nu - ni, ke, " ".join(str(int(x)) for x in sizes), 1 + ke))
