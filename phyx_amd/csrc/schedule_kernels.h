@@ -170,7 +170,7 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
 // GatherIslands' published numbers (ref: Solver.cpp:400, 414, 449) are statistics: the host computes them from the component
 // sizes when it settles the solve.  Whatever the host would have decided differently poisons the solve's fingerprint word
 // (`fail` bits below), which makes every kernel of the solve commit nothing; the host then rebuilds the slow way.
-constexpr int BINC_MAX = 8192, BINC_T = 1024;
+constexpr int BINC_WINDOW = 8192, BINC_MAX = 65536, BINC_T = 1024;      // components per window of the chain / at most (tables, indices)
 constexpr int BINC_FAIL_CC = 1, BINC_FAIL_COUNT = 2, BINC_FAIL_FIT = 4, BINC_FAIL_SHAPE = 8, BINC_FAIL_REST = 16, BINC_FAIL_GRID = 32;
 constexpr unsigned long long BINC_POISON = 0x9E3779B97F4A7C15ull;
 
@@ -246,73 +246,91 @@ __device__ __forceinline__ unsigned long long binc_pack(unsigned joints, unsigne
 
 static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
 {
-    __shared__ unsigned ps[BINC_MAX], pu[BINC_MAX];            // inclusive prefix sums: joints, units
-    __shared__ unsigned short pn[BINC_MAX];                    // inclusive count of non-empty components
-    __shared__ unsigned short jump_a[BINC_MAX], jump_b[BINC_MAX];
-    __shared__ unsigned short head_pos[BINC_MAX];              // bin -> its first component
-    __shared__ unsigned short bin_at[BINC_MAX];                // component -> heads at or before it
-    __shared__ unsigned char reach[BINC_MAX];
+    // The chain of bins is built in WINDOWS of BINC_WINDOW components (what the tables below hold): a window starts at a bin's head,
+    // every bin that ends inside it is final, and the next window starts at the head of the bin the window's end cuts — two windows
+    // for the 1e4 columns of the 1M-box world, one for anything up to 8192 components.
+    __shared__ unsigned ps[BINC_WINDOW], pu[BINC_WINDOW];      // inclusive prefix sums: joints, units
+    __shared__ unsigned short pn[BINC_WINDOW];                 // inclusive count of non-empty components
+    __shared__ unsigned short jump_a[BINC_WINDOW], jump_b[BINC_WINDOW];
+    __shared__ unsigned short head_pos[BINC_WINDOW];           // bin -> its first component
+    __shared__ unsigned short bin_at[BINC_WINDOW];             // component -> heads at or before it
+    __shared__ unsigned char reach[BINC_WINDOW];
     __shared__ unsigned long long scratch[16];
     __shared__ int s_fail, s_needs_big;
     const int tid = threadIdx.x;
     const int n_all = v.cc_small[1];
-    const int n = n_all < BINC_MAX ? n_all : BINC_MAX;
+    const int n_total = n_all < BINC_MAX ? n_all : BINC_MAX;
     if (tid == 0) { s_fail = (v.cc_small[0] ? BINC_FAIL_CC : 0) | (n_all > BINC_MAX ? BINC_FAIL_COUNT : 0); s_needs_big = 0; }
     __syncthreads();
-    bool misfit = false, wants_big = false;
-    for (int c = tid; c < n; c += BINC_T) {
-        const unsigned sz = v.comp_size[c], un = v.comp_units[c];
-        ps[c] = sz; pu[c] = un;
-        if (sz) {
-            if (sz > 2u * (unsigned)v.cap_units || un > (unsigned)v.cap_units) misfit = true;
-            if (sz > 2u * (unsigned)v.small_units || un > (unsigned)v.small_units) wants_big = true;
-        }
-    }
-    if (misfit) atomicOr(&s_fail, BINC_FAIL_FIT);
-    if (wants_big) s_needs_big = 1;
-    // (each lane scans the components it has just written: no barrier needed in between)
     constexpr unsigned long long M = (1ull << BINC_JOINT_BITS) - 1ull;
-    const unsigned long long sums = binc_scan(n, scratch, [&](int c) { return binc_pack(ps[c], pu[c]); },
-                                              [&](int c, unsigned long long x) { ps[c] = (unsigned)(x & M); pu[c] = (unsigned)((x >> BINC_JOINT_BITS) & M); pn[c] = (unsigned short)(x >> (2 * BINC_JOINT_BITS)); });
-    const int total = (int)(sums & M);
+    const unsigned cap_s = 2u * (unsigned)v.cap_units, cap_u = (unsigned)v.cap_units;
+    int w0 = 0, bins_before = 0, slots_before = 0;             // (workgroup-uniform)
+    do {
+        const int n = min(BINC_WINDOW, n_total - w0);
+        bool misfit = false, wants_big = false;
+        for (int c = tid; c < n; c += BINC_T) {
+            const unsigned sz = v.comp_size[w0 + c], un = v.comp_units[w0 + c];
+            ps[c] = sz; pu[c] = un;
+            if (sz) {
+                if (sz > 2u * (unsigned)v.cap_units || un > (unsigned)v.cap_units) misfit = true;
+                if (sz > 2u * (unsigned)v.small_units || un > (unsigned)v.small_units) wants_big = true;
+            }
+        }
+        if (misfit) atomicOr(&s_fail, BINC_FAIL_FIT);
+        if (wants_big) s_needs_big = 1;
+        // (each lane scans the components it has just written: no barrier needed in between)
+        const unsigned long long sums = binc_scan(n, scratch, [&](int c) { return binc_pack(ps[c], pu[c]); },
+                                                  [&](int c, unsigned long long x) { ps[c] = (unsigned)(x & M); pu[c] = (unsigned)((x >> BINC_JOINT_BITS) & M); pn[c] = (unsigned short)(x >> (2 * BINC_JOINT_BITS)); });
+        const int window_joints = (int)(sums & M);
+        auto upper = [&](const unsigned* pre, int a, unsigned limit) {          // first e >= a with pre[e] - before(a) > limit, or n
+            const unsigned before = a ? pre[a - 1] : 0u;
+            int lo = a, hi = n;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid] - before > limit) hi = mid; else lo = mid + 1; }
+            return lo;
+        };
+        auto nonempty = [&](int c) { return (c ? pn[c - 1] : 0) != pn[c]; };
+        for (int a = tid; a < n; a += BINC_T) {
+            const int e1 = upper(ps, a, cap_s), e2 = upper(pu, a, cap_u);
+            int e = e1 < e2 ? e1 : e2;
+            if (e <= a) e = a + 1;                             // (a misfit: the build is spoiled anyway; keep the chain moving)
+            jump_a[a] = (unsigned short)e;
+        }
+        __syncthreads();
+        binc_mark_chain(jump_a, jump_b, reach, n, window_joints > 0);
+        const int heads = (int)binc_scan(n, scratch, [&](int c) { return reach[c] ? 1ull : 0ull; }, [&](int c, unsigned long long x) { bin_at[c] = (unsigned short)x; });
+        for (int c = tid; c < n; c += BINC_T) if (reach[c]) head_pos[bin_at[c] - 1] = (unsigned short)c;
+        __syncthreads();
+        // what this window settles: everything if it reaches the last component, otherwise the bins in front of its last head
+        const bool last_window = w0 + n >= n_total;
+        const int consumed = last_window ? n : (heads > 0 ? (int)head_pos[heads - 1] : n);
+        const int bins_here = last_window ? heads : (heads > 0 ? heads - 1 : 0);
+        if (!last_window && consumed == 0) {                   // one bin wider than a window (thousands of empty components): not this path
+            if (tid == 0) s_fail |= BINC_FAIL_COUNT;
+            __syncthreads();
+            break;
+        }
+        for (int c = tid; c < consumed; c += BINC_T) {
+            const int b = (int)bin_at[c] - 1;                  // (no joints in the window: no head, every component is empty)
+            if (b < 0) { v.bin_of[w0 + c] = bins_before; v.rank_of[w0 + c] = 0; continue; }
+            const int h = head_pos[b];
+            const int before_h = h ? pn[h - 1] : 0, before_c = (int)pn[c] - (nonempty(c) ? 1 : 0);
+            v.bin_of[w0 + c] = bins_before + b; v.rank_of[w0 + c] = before_c - before_h;
+            if (reach[c] && bins_before + b <= v.max_bins) v.goff[bins_before + b] = slots_before + (int)(c ? ps[c - 1] : 0u);
+        }
+        const int slots_here = consumed ? (int)ps[consumed - 1] : 0;
+        __syncthreads();                                       // (the tables are rewritten by the next window)
+        w0 += consumed; bins_before += bins_here; slots_before += slots_here;
+    } while (w0 < n_total);
     if (tid == 0) {
         // the host takes the roomier shape iff some component needs it; joints outside every component (both bodies static) and
         // components that fit no shape go to the HBM group, which this path does not build
         if ((s_needs_big != 0) != (v.cap_units > v.small_units)) s_fail |= BINC_FAIL_SHAPE;
-        if (total != v.nj) s_fail |= BINC_FAIL_REST;
-    }
-    const unsigned cap_s = 2u * (unsigned)v.cap_units, cap_u = (unsigned)v.cap_units;
-    auto upper = [&](const unsigned* pre, int a, unsigned limit) {          // first e >= a with pre[e] - before(a) > limit, or n
-        const unsigned before = a ? pre[a - 1] : 0u;
-        int lo = a, hi = n;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid] - before > limit) hi = mid; else lo = mid + 1; }
-        return lo;
-    };
-    auto nonempty = [&](int c) { return (c ? pn[c - 1] : 0) != pn[c]; };
-    for (int a = tid; a < n; a += BINC_T) {
-        const int e1 = upper(ps, a, cap_s), e2 = upper(pu, a, cap_u);
-        int e = e1 < e2 ? e1 : e2;
-        if (e <= a) e = a + 1;                                 // (a misfit: the build is spoiled anyway; keep the chain moving)
-        jump_a[a] = (unsigned short)e;
-    }
-    __syncthreads();
-    binc_mark_chain(jump_a, jump_b, reach, n, total > 0);
-    const int nbins = (int)binc_scan(n, scratch, [&](int c) { return reach[c] ? 1ull : 0ull; }, [&](int c, unsigned long long x) { bin_at[c] = (unsigned short)x; });
-    for (int c = tid; c < n; c += BINC_T) if (reach[c]) head_pos[bin_at[c] - 1] = (unsigned short)c;
-    __syncthreads();
-    for (int c = tid; c < n; c += BINC_T) {
-        const int b = (int)bin_at[c] - 1;                      // (total == 0: no head, every component is empty)
-        if (b < 0) { v.bin_of[c] = 0; v.rank_of[c] = 0; continue; }
-        const int h = head_pos[b];
-        const int before_h = h ? pn[h - 1] : 0, before_c = (int)pn[c] - (nonempty(c) ? 1 : 0);
-        v.bin_of[c] = b; v.rank_of[c] = before_c - before_h;
-        if (reach[c] && b <= v.max_bins) v.goff[b] = (int)(c ? ps[c - 1] : 0u);
-    }
-    if (tid == 0) {
-        if (nbins <= v.max_bins) v.goff[nbins] = total;
+        if (slots_before != v.nj) s_fail |= BINC_FAIL_REST;
+        const int nbins = bins_before;
+        if (nbins <= v.max_bins) v.goff[nbins] = slots_before;
         if (nbins > v.max_bins) s_fail |= BINC_FAIL_GRID;
         v.result[0] = s_fail ? 0 : nbins;                      // (a spoiled build's tables may be incomplete: nobody runs on them)
-        v.result[1] = total; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
+        v.result[1] = slots_before; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
         *v.hash_out = *v.fingerprint;
         *v.fingerprint = s_fail ? v.gate + BINC_POISON : v.gate;
     }

@@ -456,7 +456,10 @@ def test_speculative_binning_equals_the_builders_long_way(oracle, built_lib):
            ("an island for the HBM group", presolve_state(scenes.falling(2500, width=100.0, ymax=400.0), 50), 1),
            ("after it", presolve_state(scenes.stack(40, 60), 4), 1),               # (the last build had an HBM group: no speculation)
            ("again", presolve_state(scenes.stack(40, 60), 5), 2),
-           ("tiny", presolve_state(scenes.stack(2, 10), 2), 2)]
+           ("tiny", presolve_state(scenes.stack(2, 10), 2), 2),
+           ("more components than one window of the binning kernel holds", presolve_state(scenes.stack(9000, 3), 3), 1),      # (more bins than the grid)
+           ("again: two windows", presolve_state(scenes.stack(9000, 3), 4), 2),
+           ("and three", presolve_state(scenes.stack(17000, 2), 3), 2)]
     for what, state, want in seq:
         pb, pj, ps, _, pst = _device_solve(plain, state, cfg)
         sb, sj, ss, _, sst = _device_solve(spec, state, cfg)
