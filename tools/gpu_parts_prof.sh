@@ -29,3 +29,13 @@ for n, a in agg.items():
     print("%8.1f us first  %4d x  %8.1f us total  %s" % (a[2], a[0], a[1], n))
 PY
 cat $R/gpurun_out/parts/last_step.txt | head -80
+# PMC traffic of the same run (separate passes, --pmc only): gpurun_out/prof/settled_pmc_{fetch,write}_counter_collection.csv for
+# tools/pmc_summary.py (side_config "settled")
+if [ "${2:-}" = "pmc" ]; then
+  mkdir -p $R/gpurun_out/prof
+  for c in fetch write; do
+    C=$([ $c = fetch ] && echo FETCH_SIZE || echo WRITE_SIZE)
+    timeout 600 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/prof -o settled_pmc_$c -- python $R/tools/steady.py ${1:-60} --no-phase-timing > /dev/null 2>&1
+  done
+  cp "$f" $R/gpurun_out/prof/settled_trace_kernel_stats.csv
+fi

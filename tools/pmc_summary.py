@@ -149,3 +149,5 @@ if __name__ == "__main__":
         side_config(tag, "cfg4", "k_sweep_rows")
     if os.path.exists(os.path.join(SRC, "cfg5_pmc_fetch_counter_collection.csv")):
         side_config(tag, "cfg5", "k_solve_islands<512")
+    if os.path.exists(os.path.join(SRC, "settled_pmc_fetch_counter_collection.csv")):      # tools/gpu_parts_prof.sh N pmc
+        side_config(tag, "settled", "k_solve_parts<true, true, false>")
