@@ -416,7 +416,9 @@ def test_world_api_errors(built_lib):
 
 def test_debugging_knobs_do_not_change_results(built_lib):
     """The readback mailbox, the speculative solve / deferred build check and the device schedule builder are performance
-    mechanisms: with each of them switched off (PHX_NO_MAILBOX, PHX_NO_SPECULATION, PHX_SCHEDULE_BUILDER=host, PHX_NO_SPEC_BINS) a world that
+    mechanisms — like the fused launches of partitioned components, the second stream and the in-kernel schedule check: with each of
+    them switched off (PHX_NO_MAILBOX, PHX_NO_SPECULATION, PHX_SCHEDULE_BUILDER=host, PHX_NO_SPEC_BINS, PHX_NO_PARTS, PHX_NO_SIDE_STREAM,
+    PHX_NO_FUSED_VERIFY) a world that
     rebuilds its schedule every step, merges islands and falls back to the host builder (a 90-box clique) must produce the very
     same bytes."""
     import os
@@ -434,5 +436,6 @@ def test_debugging_knobs_do_not_change_results(built_lib):
     for mode in (phyx_amd.ISLAND_SINGLE, phyx_amd.ISLAND_MULTIPLE_SLOPPY):
         want = digest({}, mode)
         assert len(want) == 64
-        for knob in ({"PHX_NO_MAILBOX": "1"}, {"PHX_NO_SPECULATION": "1"}, {"PHX_SCHEDULE_BUILDER": "host"}, {"PHX_NO_SPEC_BINS": "1"}):
+        for knob in ({"PHX_NO_MAILBOX": "1"}, {"PHX_NO_SPECULATION": "1"}, {"PHX_SCHEDULE_BUILDER": "host"}, {"PHX_NO_SPEC_BINS": "1"},
+                     {"PHX_NO_PARTS": "1"}, {"PHX_NO_SIDE_STREAM": "1"}, {"PHX_NO_FUSED_VERIFY": "1"}):
             assert digest(knob, mode) == want, (knob, mode)
