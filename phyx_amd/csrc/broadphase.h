@@ -47,6 +47,12 @@ private:
     DevBuf<uint2> new_pairs_, scratch_pairs_;
     DevBuf<phx_rigid_body> st_bodies_;
     DevBuf<float4> st_aabb_;
+    // the two-level sort (splitter_sort.h): last update's splitters, bucket sizes + cursors, bucket bases, bucket per body, bucketed composites
+    DevBuf<unsigned long long> splitters_, bucketed_;
+    DevBuf<unsigned> ss_count_, ss_base_, ss_stats_;
+    DevBuf<unsigned short> bucket_of_;
+    int splitters_n_ = -1;                    // body count the splitters on record were taken for
+    bool split_unbalanced_ = false, split_sorted_ = false;
     DevBuf<int> erase_count_;                 // pairs really tombstoned since the last settle_erase_check()
     unsigned table_cap_ = 0;
     long long set_size_ = 0, tombstones_ = 0, erase_unchecked_ = 0;

@@ -17,6 +17,7 @@
 #include "handles.h"
 #include "device_scan.h"
 #include "device_radix.h"
+#include "splitter_sort.h"
 
 #include <algorithm>
 
@@ -67,13 +68,16 @@ __global__ void __launch_bounds__(256) k_build_keys(const float4* __restrict__ a
 }
 
 // ref: Collider.cpp:269-283
-__global__ void __launch_bounds__(256) k_gather_entries(const float4* __restrict__ aabb, const unsigned* __restrict__ idx, int n,
-                                                        float4* __restrict__ entries)
+// (`splitters`: the records at positions SS_STRIDE, 2 SS_STRIDE, ... of the sorted sequence — what the next update deals its bodies
+//  into buckets by, splitter_sort.h)
+__global__ void __launch_bounds__(256) k_gather_entries(const float4* __restrict__ aabb, const unsigned* __restrict__ keys, const unsigned* __restrict__ idx, int n,
+                                                        float4* __restrict__ entries, unsigned long long* __restrict__ splitters)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 b = aabb[idx[i]];
         const float minx = b.x, miny = b.y, maxx = b.z, maxy = b.w;
         entries[i] = make_float4(minx, maxx, (miny + maxy) * 0.5f, (maxy - miny) * 0.5f);
+        if (i && i % SS_STRIDE == 0) splitters[i / SS_STRIDE - 1] = ((unsigned long long)keys[i] << 32) | idx[i];
     }
 }
 
@@ -492,14 +496,42 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         return PHX_OK;
     }
 
-    if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, prologue->vel, prologue->mpos, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
-                                     chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
-    else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (float4*)nullptr, (const float4*)nullptr, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
-                            chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
+    // The sort.  With last update's splitters on record (same body count): the two-level sort of splitter_sort.h — three launches;
+    // otherwise (first update, another body count, buckets that got out of balance) the stable LSD radix sort — eleven — whose
+    // gather leaves the splitters for the next update.  Both produce the reference's sorted sequence (ref: base/RadixSort.h:28-95).
+    const int buckets = ss_buckets(n);
+    PHX_TRY(splitters_.reserve(SS_MAX_BUCKETS)); PHX_TRY(ss_stats_.reserve(2));
+    static const bool no_split = getenv("PHX_NO_SPLIT_SORT") != nullptr;      // A/B measurements, tests
+    const bool split = !no_split && buckets <= SS_MAX_BUCKETS && (buckets == 1 || (splitters_n_ == n && !split_unbalanced_));
     int src = 0;
-    PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
+    if (split) {
+        if (!ss_count_.p) { PHX_TRY(ss_count_.reserve(2 * SS_MAX_BUCKETS)); PHX_HIP(hipMemsetAsync(ss_count_.p, 0, ss_count_.cap * sizeof(unsigned), stream_)); }
+        PHX_TRY(ss_base_.reserve(SS_MAX_BUCKETS + 1)); PHX_TRY(bucket_of_.reserve(n)); PHX_TRY(bucketed_.reserve(n));
+        SplitSortView sv{};
+        sv.aabb = d_bodies; sv.n = n; sv.buckets = buckets; sv.splitters = splitters_.p; sv.keys = keys_[0].p; sv.bucket_of = bucket_of_.p;
+        sv.count = ss_count_.p; sv.cursor = ss_count_.p + SS_MAX_BUCKETS; sv.base = ss_base_.p; sv.bucketed = bucketed_.p;
+        sv.keys_out = keys_[1].p; sv.idx_out = idx_[1].p; sv.entries = entries_.p; sv.next_splitters = splitters_.p; sv.max_bucket = ss_stats_.p;
+        const dim3 tiles(div_up(n, SS_TILE));
+        if (prologue) hipLaunchKernelGGL((k_keys_buckets<true>), tiles, dim3(SS_TILE_T), 0, stream_, sv, prologue->vel, prologue->mpos, small_.p, 16 + 2 * STAT_SLOTS,
+                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
+        else hipLaunchKernelGGL((k_keys_buckets<false>), tiles, dim3(SS_TILE_T), 0, stream_, sv, (float4*)nullptr, (const float4*)nullptr, small_.p, 16 + 2 * STAT_SLOTS,
+                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
+        hipLaunchKernelGGL(k_bucket_scatter, tiles, dim3(SS_TILE_T), 0, stream_, sv);
+        hipLaunchKernelGGL(k_bucket_sort, dim3(buckets), dim3(SS_SORT_T), 0, stream_, sv);
+        src = 1;
+    } else {
+        if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, prologue->vel, prologue->mpos, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
+                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
+        else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (float4*)nullptr, (const float4*)nullptr, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
+                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
+        PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
+        hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (const unsigned*)keys_[src].p, (const unsigned*)idx_[src].p, n, entries_.p, splitters_.p);
+        PHX_HIP(hipMemsetAsync(ss_stats_.p, 0, sizeof(unsigned), stream_));
+        split_unbalanced_ = false;
+    }
     sorted_ = src;
-    hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, idx_[src].p, n, entries_.p);
+    splitters_n_ = n;
+    split_sorted_ = split;
 
     // sweep: count -> scan -> emit
     SweepView v{};
@@ -522,8 +554,11 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         int erased = 0;
         PHX_TRY(queue_erase_check(&erased));
         PHX_TRY(rb_.add(host_small, small_.p, sizeof host_small, stream_));
+        unsigned max_bucket = 0;
+        if (split) PHX_TRY(rb_.add(&max_bucket, ss_stats_.p, sizeof max_bucket, stream_));
         PHX_TRY(rb_.wait(stream_, stamps_.p + 1));
         PHX_TRY(settle_erase_check(erased));
+        if (split && max_bucket > (unsigned)SS_LDS_RECORDS) split_unbalanced_ = true;      // (stale splitters: the next update sorts the long way and takes fresh ones)
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
         if (needed <= chunk_cap) break;
         // pathological overlap (many rows each spanning thousands of candidates): the chunk list was too short.

@@ -103,5 +103,51 @@ def test_full_size_1m_boxes_properties(collider, oracle):
     assert st.overlapping_pairs == cnt == len(new) and st.candidate_tests == tests
     a, c = b[new[:, 0]], b[new[:, 1]]
     assert (a["aabb_min"]["x"] <= c["aabb_max"]["x"]).all() and (c["aabb_min"]["x"] <= a["aabb_max"]["x"]).all()
-    # idempotence: a second update over the same bodies reports nothing new
+    # idempotence: a second update over the same bodies reports nothing new — and it takes the two-level sort (splitters of the
+    # first update on record: csrc/splitter_sort.h), which must leave the very same sequence
     assert len(collider.UpdateBroadphaseAndPairs(b)) == 0
+    gs2, ge2 = collider.sorted(len(b))
+    assert gs2.tobytes() == srt.tobytes() and ge2.tobytes() == ent.tobytes()
+
+
+def _random_boxes(rng, n, minx):
+    b = np.zeros(n, dtype=phyx_amd.rigid_body_dtype)
+    b["aabb_min"]["x"] = minx
+    b["aabb_max"]["x"] = minx + rng.uniform(0, 3, n).astype(np.float32)
+    b["aabb_min"]["y"] = rng.uniform(-50, 50, n).astype(np.float32)
+    b["aabb_max"]["y"] = b["aabb_min"]["y"] + rng.uniform(0, 30, n).astype(np.float32)
+    return b
+
+
+def test_two_level_sort_with_fresh_stale_and_useless_splitters(collider, oracle):
+    """csrc/splitter_sort.h: from its second update on (same body count) a Collider deals the bodies into buckets by the previous
+    update's splitters and sorts the buckets in LDS.  The splitters only balance the work: the sorted sequence must equal the
+    reference's stable radix sort whatever they are — bodies that moved a little (the normal case), a completely different scene of
+    the same size (buckets of thousands of records: the workgroup's in-HBM network), all keys equal (ties resolved by the index)."""
+    rng = np.random.default_rng(17)
+    n = 20000
+    x = np.sort(rng.uniform(-5000, 5000, n)).astype(np.float32)
+    _check_update(collider, oracle, _random_boxes(rng, n, x), set())                 # LSD sort, leaves splitters
+    collider.clear()
+    _check_update(collider, oracle, _random_boxes(rng, n, x + rng.normal(0, 2.0, n).astype(np.float32)), set())    # moved a little
+    collider.clear()
+    _check_update(collider, oracle, _random_boxes(rng, n, x[::-1].copy()), set())     # index order reversed against the splitters
+    collider.clear()
+    _check_update(collider, oracle, _random_boxes(rng, n, np.full(n, 7.25, np.float32) + (rng.integers(0, 2, n) * 1e-3).astype(np.float32)), set())   # two key values: most bodies in two buckets
+    collider.clear()
+    _check_update(collider, oracle, _random_boxes(rng, n, np.full(n, -3.5, np.float32)), set())   # after an unbalanced update: the LSD sort again
+    collider.clear()
+    _check_update(collider, oracle, _random_boxes(rng, n, np.full(n, -3.5, np.float32)), set())   # every key equal, splitters by index
+    collider.clear()
+    _check_update(collider, oracle, _random_boxes(rng, n, rng.uniform(-1e4, 1e4, n).astype(np.float32)), set())
+
+
+@pytest.mark.parametrize("n", [767, 768, 769, 1536, 1537, 4095, 4097, 12289])
+def test_two_level_sort_edge_sizes(collider, oracle, n):
+    """bucket counts 1, 2, 3, ... — records at the bucket boundaries, the last bucket short"""
+    rng = np.random.default_rng(n)
+    vals = np.array([-7507.5, -15.0, -0.0, 0.0, 5.0, 20.0, 1e-30, -1e-30, 3e38], dtype=np.float32)
+    for rep in range(3):
+        collider.clear()
+        minx = np.where(rng.random(n) < 0.3, rng.choice(vals, size=n), rng.uniform(-100, 100, n)).astype(np.float32)
+        _check_update(collider, oracle, _random_boxes(rng, n, minx), set())
