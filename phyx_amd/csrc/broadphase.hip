@@ -71,13 +71,13 @@ __global__ void __launch_bounds__(256) k_build_keys(const float4* __restrict__ a
 // (`splitters`: the records at positions SS_STRIDE, 2 SS_STRIDE, ... of the sorted sequence — what the next update deals its bodies
 //  into buckets by, splitter_sort.h)
 __global__ void __launch_bounds__(256) k_gather_entries(const float4* __restrict__ aabb, const unsigned* __restrict__ keys, const unsigned* __restrict__ idx, int n,
-                                                        float4* __restrict__ entries, unsigned long long* __restrict__ splitters)
+                                                        float4* __restrict__ entries, unsigned long long* __restrict__ splitters, int stride)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 b = aabb[idx[i]];
         const float minx = b.x, miny = b.y, maxx = b.z, maxy = b.w;
         entries[i] = make_float4(minx, maxx, (miny + maxy) * 0.5f, (maxy - miny) * 0.5f);
-        if (i && i % SS_STRIDE == 0) splitters[i / SS_STRIDE - 1] = ((unsigned long long)keys[i] << 32) | idx[i];
+        if (i && i % stride == 0) splitters[i / stride - 1] = ((unsigned long long)keys[i] << 32) | idx[i];
     }
 }
 
@@ -508,7 +508,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         if (!ss_count_.p) { PHX_TRY(ss_count_.reserve(2 * SS_MAX_BUCKETS)); PHX_HIP(hipMemsetAsync(ss_count_.p, 0, ss_count_.cap * sizeof(unsigned), stream_)); }
         PHX_TRY(ss_base_.reserve(SS_MAX_BUCKETS + 1)); PHX_TRY(bucket_of_.reserve(n)); PHX_TRY(bucketed_.reserve(n));
         SplitSortView sv{};
-        sv.aabb = d_bodies; sv.n = n; sv.buckets = buckets; sv.splitters = splitters_.p; sv.keys = keys_[0].p; sv.bucket_of = bucket_of_.p;
+        sv.aabb = d_bodies; sv.n = n; sv.buckets = buckets; sv.stride = ss_stride(n); sv.splitters = splitters_.p; sv.keys = keys_[0].p; sv.bucket_of = bucket_of_.p;
         sv.count = ss_count_.p; sv.cursor = ss_count_.p + SS_MAX_BUCKETS; sv.base = ss_base_.p; sv.bucketed = bucketed_.p;
         sv.keys_out = keys_[1].p; sv.idx_out = idx_[1].p; sv.entries = entries_.p; sv.next_splitters = splitters_.p; sv.max_bucket = ss_stats_.p;
         const dim3 tiles(div_up(n, SS_TILE));
@@ -525,7 +525,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (float4*)nullptr, (const float4*)nullptr, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
                                 chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
         PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
-        hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (const unsigned*)keys_[src].p, (const unsigned*)idx_[src].p, n, entries_.p, splitters_.p);
+        hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (const unsigned*)keys_[src].p, (const unsigned*)idx_[src].p, n, entries_.p, splitters_.p, ss_stride(n));
         PHX_HIP(hipMemsetAsync(ss_stats_.p, 0, sizeof(unsigned), stream_));
         split_unbalanced_ = false;
     }
@@ -558,7 +558,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         if (split) PHX_TRY(rb_.add(&max_bucket, ss_stats_.p, sizeof max_bucket, stream_));
         PHX_TRY(rb_.wait(stream_, stamps_.p + 1));
         PHX_TRY(settle_erase_check(erased));
-        if (split && max_bucket > (unsigned)SS_LDS_RECORDS) split_unbalanced_ = true;      // (stale splitters: the next update sorts the long way and takes fresh ones)
+        if (split && max_bucket > (unsigned)(4 * ss_stride(n))) split_unbalanced_ = true;      // (stale splitters: the next update sorts the long way and takes fresh ones)
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
         if (needed <= chunk_cap) break;
         // pathological overlap (many rows each spanning thousands of candidates): the chunk list was too short.

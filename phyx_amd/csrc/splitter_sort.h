@@ -21,16 +21,18 @@
 
 namespace phx {
 
-constexpr int SS_STRIDE = 768;                 // records per bucket the splitters aim at
+constexpr int SS_STRIDE = 256;                 // records per bucket the splitters aim at (the bucket sort is by rank: quadratic in that)
 constexpr int SS_MAX_BUCKETS = 4096;           // (LDS: the splitters, 8 bytes each, + a counter each)
 constexpr int SS_TILE_T = 256, SS_TILE_ITEMS = 2, SS_TILE = SS_TILE_T * SS_TILE_ITEMS;      // (small tiles: 2e5 bodies must still be a few hundred workgroups)
-constexpr int SS_SORT_T = 512;                 // one pair per lane and step for a bucket of <= 1024 records
-constexpr int SS_LDS_RECORDS = 2048;           // a bucket of at most that many records is sorted in LDS (16 KB)
+constexpr int SS_SORT_T = 256;
+constexpr int SS_LDS_RECORDS = 4096;           // a bucket of at most that many records is sorted in LDS (32 KB)
 
-static inline int ss_buckets(int n) { return std::max(1, div_up(n, SS_STRIDE)); }
+// the stride of a body count: SS_STRIDE while that makes at most SS_MAX_BUCKETS buckets, wider (in steps of 64) beyond
+static inline int ss_stride(int n) { return std::max(SS_STRIDE, div_up(div_up(std::max(n, 1), SS_MAX_BUCKETS), 64) * 64); }
+static inline int ss_buckets(int n) { return std::max(1, div_up(n, ss_stride(n))); }
 
 struct SplitSortView {
-    const float4* aabb; int n, buckets;
+    const float4* aabb; int n, buckets, stride;      // stride = ss_stride(n)
     const unsigned long long* splitters;       // buckets - 1 composites, ascending (last update's records at positions SS_STRIDE, 2 SS_STRIDE, ...)
     unsigned* keys;                            // scratch: key per body
     unsigned short* bucket_of;                 // scratch: bucket per body
@@ -194,30 +196,39 @@ struct SsHbm { unsigned long long* d; __device__ unsigned long long get(int i) c
 
 __global__ void __launch_bounds__(SS_SORT_T) k_bucket_sort(SplitSortView v)
 {
-    __shared__ unsigned long long rec[SS_LDS_RECORDS];
+    __shared__ __align__(16) unsigned long long rec[SS_LDS_RECORDS];
     const int b = blockIdx.x;
     const unsigned first = v.base[b], m = v.base[b + 1] - first;
-    if (threadIdx.x == 0) { v.count[b] = 0u; v.cursor[b] = 0u; if (m > (unsigned)(2 * SS_STRIDE)) atomicMax(v.max_bucket, m); }
+    if (threadIdx.x == 0) { v.count[b] = 0u; v.cursor[b] = 0u; if (m > (unsigned)(4 * v.stride)) atomicMax(v.max_bucket, m); }
     if (m == 0) return;
     int P = 2;
     while ((unsigned)P < m) P <<= 1;
     const bool in_lds = m <= (unsigned)SS_LDS_RECORDS;
     unsigned long long* src = v.bucketed + first;
     if (in_lds) {
-        for (int i = threadIdx.x; i < (int)m; i += SS_SORT_T) rec[i] = src[i];
-        ss_bitonic(SsLds{rec}, (int)m, P);
+        // by RANK: the composites are distinct, so a record's sorted position is the number of records of the bucket below it — m
+        // broadcast reads of LDS, two records each, independent of each other.  (A bitonic network in LDS is ~50 DEPENDENT steps of
+        // ~0.25 us for ~1e3 records: 18 us per launch where this takes 8.)
+        for (int i = threadIdx.x; i < (int)((m + 1u) & ~1u); i += SS_SORT_T) rec[i] = i < (int)m ? src[i] : ~0ull;
+        __syncthreads();
     } else {
         ss_bitonic(SsHbm{src}, (int)m, P);
     }
+    const ulonglong2* two = reinterpret_cast<const ulonglong2*>(rec);
     for (int i = threadIdx.x; i < (int)m; i += SS_SORT_T) {
         const unsigned long long c = in_lds ? rec[i] : __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned p = first + (unsigned)i, body = (unsigned)c;
+        unsigned at = (unsigned)i;
+        if (in_lds) {
+            at = 0u;
+            for (int q = 0; q < (int)((m + 1u) >> 1); ++q) { const ulonglong2 e = two[q]; at += (e.x < c) + (e.y < c); }
+        }
+        const unsigned p = first + at, body = (unsigned)c;
         v.keys_out[p] = (unsigned)(c >> 32);
         v.idx_out[p] = body;
         const float4 bb = v.aabb[body];                    // ref: Collider.cpp:269-283
         const float minx = bb.x, miny = bb.y, maxx = bb.z, maxy = bb.w;
         v.entries[p] = make_float4(minx, maxx, (miny + maxy) * 0.5f, (maxy - miny) * 0.5f);
-        if (p && p % (unsigned)SS_STRIDE == 0u) v.next_splitters[p / (unsigned)SS_STRIDE - 1u] = c;
+        if (p && p % (unsigned)v.stride == 0u) v.next_splitters[p / (unsigned)v.stride - 1u] = c;
     }
 }
 

@@ -142,7 +142,7 @@ def test_two_level_sort_with_fresh_stale_and_useless_splitters(collider, oracle)
     _check_update(collider, oracle, _random_boxes(rng, n, rng.uniform(-1e4, 1e4, n).astype(np.float32)), set())
 
 
-@pytest.mark.parametrize("n", [767, 768, 769, 1536, 1537, 4095, 4097, 12289])
+@pytest.mark.parametrize("n", [255, 256, 257, 512, 513, 767, 769, 4095, 4097, 12289])
 def test_two_level_sort_edge_sizes(collider, oracle, n):
     """bucket counts 1, 2, 3, ... — records at the bucket boundaries, the last bucket short"""
     rng = np.random.default_rng(n)
