@@ -60,7 +60,7 @@ def pmc_file(name):
 def pmc_traffic():
     """HBM bytes per launch of the solve kernels from the committed PMC passes (tools/gpu_prof.sh -> tools/pmc_summary.py):
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same script, read side corrected x2 as MI355X_MICROARCH.md §HBM says."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
         if os.path.exists(path):
             try:
@@ -105,6 +105,40 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: one process per GPU, spawned here (python -m torch.distributed.run works too)
         sys.exit(pdist.self_launch(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return run_bench(args, pdist)
+    # N > 1: nobody has ever watched this path on more than one GPU, so it must not be able to hang its launcher.  Every blocking
+    # wait on a peer is bounded (PHX_COMM_TIMEOUT_S: the rendezvous, ncclCommInitRank, the library's host-side waits), a watchdog
+    # bounds the whole run (PHX_BENCH_TIMEOUT_S, default 900 s), and whatever goes wrong ends as ONE JSON line with an "error"
+    # field from rank 0 and a non-zero exit status.
+    rank = int(os.environ.get("RANK", "0"))
+
+    def error_line(msg):
+        if rank == 0:
+            print(json.dumps({"metric": "solver joint-visits/s (contacts/sec) on the 200k-box stack scene; solver iterations/s in extra",
+                              "value": None, "unit": "joint-visits/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": "cfg3 (not completed)", "mode": args.mode, "transport": args.backend},
+                              "error": msg}), flush=True)
+        sys.stderr.write("bench.py rank %d: %s\n" % (rank, msg))
+    try:
+        limit = float(os.environ.get("PHX_BENCH_TIMEOUT_S", "0")) or 900.0
+    except ValueError:
+        limit = 900.0
+    dog = pdist.watchdog(limit, lambda: error_line("rank %d made no progress for %.0f s (PHX_BENCH_TIMEOUT_S): a peer is missing or a collective hangs" % (rank, limit)))
+    try:
+        run_bench(args, pdist)
+    except BaseException as e:                     # (SystemExit from dist.init included)
+        dog.cancel()
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        error_line("%s: %s" % (type(e).__name__, e))
+        sys.stdout.flush()
+        os._exit(1)                                # (not sys.exit: torch's / RCCL's teardown may wait for the peers that caused this)
+    dog.cancel()
+
+
+def run_bench(args, pdist):
     group = pdist.init(args.gpus, backend=args.backend, force=args.force_dist)
     rank, world = group.rank, group.world_size
     device = group.local_rank if getattr(group, "backend", "rccl") in ("nccl", "rccl") else 0
@@ -253,6 +287,8 @@ def main():
         kname = "k_solve_islands" if lds else "k_solve_colour"
         tbytes = traffic.get(kname)
         tsource = traffic.get("file")
+        if tsource:
+            tsource += " (a committed rocprofv3 --pmc pass of this script; NOT measured in this run)"
         # the PMC passes profiled the default workload at N = 1: a launch of rank 0 at N > 1 covers only its own groups (its share
         # of the joint visits), and any other scene size was not profiled at all
         if (args.columns, args.rows) != (1000, 200):
@@ -306,7 +342,7 @@ def main():
             "unit": "joint-visits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "none (one GPU)" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("cfg2: stack(%d,%d) = %d bodies / %d joints, Single Sloppy island mode, %d+%d iterations, one SolveJoints "
                                     "per step on HBM-resident inputs (bodies in the resident structure-of-arrays layout), schedule cached "
@@ -321,6 +357,7 @@ def main():
                                      "SolveJoints per step on HBM-resident inputs; the per-step collective is a 4-byte all-reduce (RCCL) queued on the "
                                      "solver's stream — nothing else crosses xGMI" % (args.columns, args.rows, nb_total, nj_total, world, args.iters, args.iters))),
                        "mode": mode, "transport": getattr(group, "backend", "none") if world > 1 else "none",
+                       "transport_info": group.info() if hasattr(group, "info") else None,
                        "bodies_total": int(nb_total), "joints_total": int(nj_total), "colours": st.colour_count,
                        "lds_islands": st.lds_islands, "graph_replay": st.graph_replay,
                        "impulse_sweeps_per_step": st.impulse_iterations, "displacement_sweeps_per_step": st.displacement_iterations,
@@ -330,7 +367,8 @@ def main():
                        "timed_blocks": args.repeats, "reported_block": "median",
                        "device": info["name"], "compute_units": info["compute_units"]},
             "extra": {"solver_iterations_per_sec": iters_max / elapsed_max,
-                      "contacts_resolved_per_sec": nj_total * args.steps / elapsed_max,
+                      "contacts_per_sec_of_solve_time": nj_total * args.steps / elapsed_max,
+                      "contacts_resolved_per_sec": None,      # (joints / full World::Update time, SURVEY.md §8(d): filled from cfg2_world_step below)
                       "device_ms_per_step": main_tot["total_ms"] / max(args.steps, 1),
                       "sweep_ms_per_step": main_tot["sweep_ms"] * main_tot["launches"] / max(main_tot["bracketed"], 1) / max(args.steps, 1),
                       "all_blocks_ms_per_step": [round(x, 5) for x in main_tot["all_blocks_ms_per_step"]],
@@ -379,6 +417,9 @@ def main():
             out["extra"]["cfg3_one_rank_of_n"] = one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run)
             out["extra"]["cfg3_slab_one_rank_of_n"] = slab_one_rank_of_n(phyx_amd, scenes, Configuration, pdist, device, args, full_scene)
             out["extra"]["other_configs"] = other_configs(phyx_amd, scenes, Configuration, device, world_obj, cfg)
+            ws = out["extra"]["other_configs"].get("cfg2_world_step") or {}
+            if ws.get("ms_per_step") and (args.columns, args.rows) == (1000, 200):
+                out["extra"]["contacts_resolved_per_sec"] = ws["counts"]["joints"] / (1e-3 * ws["ms_per_step"])
             if (args.columns, args.rows) == (1000, 200):
                 out["extra"]["four_times_the_world_one_rank_of_n"] = four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, device, args)
         if not args.no_cpu_baseline and world == 1:
@@ -562,8 +603,8 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     # algorithmic bytes: 112 B per body for key build + radix sort + gather, 20 B per candidate test.  The sweep
     # is an L1-resident latency loop (PMC: ~6 % of its algorithmic bytes reach HBM), so this is NOT quoted against the HBM peak.
     alg = 112.0 * w4.counts()[0] + 20.0 * bs.candidate_tests
-    pm4 = pmc_file("r03_pmc_traffic_cfg4")
-    bp_kernels = ("k_build_keys", "k_radix_hist", "k_radix_scatter", "k_scan_", "k_gather_entries", "k_sweep_rows", "k_sweep_chunks", "k_emit", "k_ps_insert")
+    pm4 = pmc_file("r04_pmc_traffic_cfg4") or pmc_file("r03_pmc_traffic_cfg4")
+    bp_kernels = ("k_build_keys", "k_keys_buckets", "k_bucket_scatter", "k_bucket_sort", "k_radix_hist", "k_radix_scatter", "k_scan_", "k_gather_entries", "k_sweep_rows", "k_sweep_chunks", "k_emit", "k_ps_insert")
     bp_traffic = sum(v * launches_per_update(k) for k, v in pm4.get("kernels", {}).items() if any(n in k for n in bp_kernels)) or None
     res["cfg4_broadphase_1M"] = {"device_ms": bs.device_ms, "candidate_tests": bs.candidate_tests, "new_pairs": bs.new_pairs,
                                  "candidate_tests_per_sec": bs.candidate_tests / (bs.device_ms * 1e-3),
@@ -591,7 +632,7 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     t0 = time.perf_counter(); r = s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 0, 10); el = time.perf_counter() - t0
     st = s5.stats()
     launch5_us = 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1)
-    pm5 = pmc_file("r03_pmc_traffic_cfg5")
+    pm5 = pmc_file("r04_pmc_traffic_cfg5") or pmc_file("r03_pmc_traffic_cfg5")
     tr5 = next((v for k, v in pm5.get("kernels", {}).items() if "k_solve_islands<512" in k), None)
     alg5 = (BYTES_IMPULSE_VISIT * r.joint_visits + BYTES_DISPLACEMENT_VISIT * st.displacement_iterations * arrs[2].count * 10) / max(r.impulse_launches, 1)
     res["cfg5_500k_tall_50it_fp32"] = {"ms_per_step": 1e3 * el / 10, "joint_visits_per_sec": r.joint_visits / el, "joints": arrs[2].count,
@@ -638,7 +679,10 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
     all cores).  `value` = impulse-loop joint-visits/s at T threads; the scalar (N = 1) oracle loop is kept next to it.
     Reported beside the GPU number, not a target."""
     from oracle import binding as ob
-    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))            # the cores this process may really use (a container's share), not the box's
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
     b = bodies.view(ob.body_dtype); cp = cps.view(ob.contact_point_dtype); j = joints.view(ob.joint_dtype)
     t_begin = time.perf_counter()
     names = ("prepare_bodies", "prepare_indices", "prepare_joints", "refresh", "prestep", "impulse", "displacement", "finish", "total")
@@ -647,6 +691,8 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
         ph = ob.baseline_solve(b.copy(), cp, j.copy(), iters, iters, threads, threads > 1, "fast")
         return {n: getattr(ph, n) for n in names}, ph.joint_visits, ph.impulse_iterations
 
+    # `value` is taken on ALL host threads; a short probe over smaller counts rides along, because the racy
+    # 512-joint sweep stops scaling long before all cores and the best count says so
     probe = {}
     for t in sorted({1, 4, 8, 16, 32, 64, 128, ncpu}):
         if t > ncpu or time.perf_counter() - t_begin > 0.5 * budget_s:
@@ -654,7 +700,7 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
         solve(t)
         ph, visits, _ = solve(t)
         probe[t] = visits / ph["impulse"]
-    best = max(probe, key=probe.get)
+    best = ncpu
 
     def sample(threads, seconds):
         acc = {n: [] for n in names}
@@ -678,10 +724,11 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
     # the scalar (N = 1) restatement, impulse loop only (the round-1 baseline)
     sec, v = ob.time_impulse_loop(b, cp, j, iters, 1)
     ms = lambda d: {k: round(1e3 * x, 3) for k, x in d.items()}
-    return {"value": vm / many["impulse"], "unit": "joint-visits/s", "cores": best, "kind": "port",
+    return {"value": vm / many["impulse"], "unit": "joint-visits/s", "cores": best, "host_threads": ncpu, "kind": "port",
+            "best_of_probe": {"threads": max(probe, key=probe.get), "value": max(probe.values())} if probe else None,
             "sample": "%d x one full SolveJoints<8> of the same %d-joint solver input (%d impulse sweeps run), AVX2-order baseline built "
-                      "-O3 -ffast-math -mavx2 -mfma, %d threads in 512-joint batches (Single Sloppy; best of probe %s M visits/s; host has "
-                      "%d cores); value = joints x sweeps / median impulse-loop time" % (nm, len(j), swm, best, {k: round(x / 1e6) for k, x in probe.items()}, ncpu),
+                      "-O3 -ffast-math -mavx2 -mfma, %d threads = every host thread, in 512-joint batches pulled from one shared counter (Single "
+                      "Sloppy; probe %s M visits/s by thread count; %d host threads); value = joints x sweeps / median impulse-loop time" % (nm, len(j), swm, best, {k: round(x / 1e6) for k, x in probe.items()}, ncpu),
             "solve_ms_per_step": 1e3 * many["total"], "phases_ms": ms(many),
             "single_thread": {"value": v1 / one["impulse"], "solve_ms_per_step": 1e3 * one["total"], "phases_ms": ms(one), "samples": n1,
                               "island_mode": "Single"},

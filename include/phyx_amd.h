@@ -203,8 +203,11 @@ int    phx_exchange_layout(const int32_t* group_bodies, const int32_t* group_slo
 #define PHX_COMM_ID_BYTES 128
 typedef struct phx_comm phx_comm;
 int  phx_comm_unique_id(void* out_id);                                  /* ncclGetUniqueId */
-int  phx_comm_create(phx_comm** out, const void* unique_id, int32_t rank, int32_t nranks, int device);   /* ncclCommInitRank (collective) */
+/* ncclCommInitRank (collective).  A rank whose peers do not arrive within PHX_COMM_TIMEOUT_S seconds (environment, default 120) gives */
+/* up with PHX_ERR_STATE instead of hanging; the same bound holds wherever this library blocks the host on a collective.            */
+int  phx_comm_create(phx_comm** out, const void* unique_id, int32_t rank, int32_t nranks, int device);
 void phx_comm_destroy(phx_comm* c);
+int  phx_comm_rccl_version(void);                                       /* ncclGetVersion of the RCCL in use, 0 if none could be loaded */
 int  phx_comm_rank(phx_comm* c);
 int  phx_comm_size(phx_comm* c);
 /* bytes_per_rank from every rank's d_send into d_recv (rank r at r * bytes_per_rank), queued on `stream` (a hipStream_t) */

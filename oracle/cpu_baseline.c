@@ -422,74 +422,83 @@ static int prepare_indices8(const phxo_contact_joint* joints, int32_t* joint_ind
     return out & ~(N - 1);
 }
 
-/* ---- persistent thread pool: phases separated by a sense-reversing spin barrier, batches pulled from a shared counter
- *      (the reference's WorkQueue + parallelFor with granularity 1, ref: base/Parallel.h:60-110) ---- */
+/* ---- persistent thread pool: like the reference's WorkQueue + parallelFor (ref: base/Parallel.h:27-103) a phase is a
+ *      shared atomic batch counter that every worker — the caller included, :94 — pulls from, and it is over when every BATCH
+ *      is done (:96-102 waits for ready == groupCount), not when every THREAD has arrived: a worker that wakes up late (or not at
+ *      all: more threads than free cores) finds nothing to pull and delays nobody.  (Round 3's pool met at a full barrier of all
+ *      threads twice per phase: one descheduled thread held everybody, and 128 / 256 threads ran 10-100x slower than 64.) ---- */
 typedef struct pool pool;
 typedef void (*phase_fn)(pool*, int batch, int worker);
 struct pool {
     int threads;
-    atomic_int arrived, sense, next, sleepers;
+    _Atomic unsigned long long ticket;      /* phase number << 32 | next batch of that phase */
+    atomic_int phase_word;                  /* the phase number again: what sleeping workers wait on (futex) */
+    atomic_int done, sleepers, quit;
     int batches;
     phase_fn fn;
-    int quit;
     ctx* c;
     int batch_size, iter;
     atomic_int productive;
     pthread_t* th;
 };
 
-/* A waiter spins for a few tens of microseconds (the gap between two sweeps of the impulse loop), then sleeps on the futex:
- * during the serial phases (PrepareIndices runs on the main thread only, like the reference) idle workers must not burn the
- * cores — and their SMT siblings — the main thread is working on. */
-static void pool_barrier(pool* p, int* local_sense)
-{
-    *local_sense ^= 1;
-    if (atomic_fetch_add(&p->arrived, 1) == p->threads - 1) {
-        atomic_store(&p->arrived, 0);
-        atomic_store(&p->sense, *local_sense);
-        if (atomic_load(&p->sleepers)) syscall(SYS_futex, &p->sense, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
-    } else {
-        for (int spins = 0; atomic_load_explicit(&p->sense, memory_order_acquire) != *local_sense; ++spins) {
-            if (spins < 20000) { _mm_pause(); continue; }
-            atomic_fetch_add(&p->sleepers, 1);
-            while (atomic_load_explicit(&p->sense, memory_order_acquire) != *local_sense)
-                syscall(SYS_futex, &p->sense, FUTEX_WAIT_PRIVATE, *local_sense ^ 1, NULL, NULL, 0);
-            atomic_fetch_sub(&p->sleepers, 1);
-            break;
-        }
-    }
-}
-
-static void pool_work(pool* p, int worker)
+/* batches of phase `phase`, until they run out or the pool has moved on */
+static void pool_pull(pool* p, unsigned phase, int worker)
 {
     for (;;) {
-        const int b = atomic_fetch_add(&p->next, 1);
-        if (b >= p->batches) break;
-        p->fn(p, b, worker);
+        unsigned long long t = atomic_load_explicit(&p->ticket, memory_order_acquire);
+        if ((unsigned)(t >> 32) != phase || (int)(unsigned)t >= p->batches) return;
+        if (!atomic_compare_exchange_weak_explicit(&p->ticket, &t, t + 1, memory_order_acq_rel, memory_order_acquire)) continue;
+        p->fn(p, (int)(unsigned)t, worker);
+        atomic_fetch_add_explicit(&p->done, 1, memory_order_release);
     }
 }
 
 typedef struct { pool* p; int worker; } warg;
+/* A worker spins for a few tens of microseconds for the next phase (the gap between two sweeps of the impulse loop), then sleeps on
+ * the futex: during the serial phases (PrepareIndices runs on the main thread only, like the reference) idle workers must not
+ * burn the cores — and their SMT siblings — the main thread is working on. */
 static void* pool_thread(void* a)
 {
     pool* p = ((warg*)a)->p; const int worker = ((warg*)a)->worker;
-    int sense = 0;
+    unsigned seen = 0;
     for (;;) {
-        pool_barrier(p, &sense);                    /* phase published */
-        if (p->quit) break;
-        pool_work(p, worker);
-        pool_barrier(p, &sense);                    /* phase done */
+        unsigned now;
+        for (int spins = 0; (now = (unsigned)atomic_load_explicit(&p->phase_word, memory_order_acquire)) == seen; ++spins) {
+            if (atomic_load_explicit(&p->quit, memory_order_acquire)) return NULL;
+            if (spins < 20000) { _mm_pause(); continue; }
+            atomic_fetch_add(&p->sleepers, 1);
+            syscall(SYS_futex, &p->phase_word, FUTEX_WAIT_PRIVATE, (int)seen, NULL, NULL, 0);
+            atomic_fetch_sub(&p->sleepers, 1);
+            spins = 0;
+        }
+        if (atomic_load_explicit(&p->quit, memory_order_acquire)) return NULL;
+        seen = now;
+        pool_pull(p, seen, worker);
     }
-    return NULL;
 }
 
-/* run one phase on all threads (the caller is worker 0, ref: base/Parallel.h:94) */
-static void pool_run(pool* p, int* sense, phase_fn fn, int batches)
+/* run one phase: the caller is worker 0 (ref: base/Parallel.h:94) and waits for the batches, not for the threads */
+static void pool_run(pool* p, int* phase_counter, phase_fn fn, int batches)
 {
-    p->fn = fn; p->batches = batches; atomic_store(&p->next, 0);
-    if (p->threads > 1) pool_barrier(p, sense);
-    pool_work(p, 0);
-    if (p->threads > 1) pool_barrier(p, sense);
+    const unsigned phase = (unsigned)++*phase_counter;
+    p->fn = fn; p->batches = batches;
+    atomic_store_explicit(&p->done, 0, memory_order_relaxed);
+    atomic_store_explicit(&p->ticket, (unsigned long long)phase << 32, memory_order_release);
+    if (p->threads > 1) {
+        atomic_store_explicit(&p->phase_word, (int)phase, memory_order_release);
+        if (atomic_load(&p->sleepers)) syscall(SYS_futex, &p->phase_word, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
+    }
+    pool_pull(p, phase, 0);
+    while (atomic_load_explicit(&p->done, memory_order_acquire) < batches) _mm_pause();
+}
+
+static void pool_stop(pool* p)
+{
+    atomic_store_explicit(&p->quit, 1, memory_order_release);
+    atomic_fetch_add(&p->phase_word, 1);
+    syscall(SYS_futex, &p->phase_word, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
+    for (int t = 1; t < p->threads; ++t) pthread_join(p->th[t], NULL);
 }
 
 static inline void batch_range(pool* p, int batch, int* vb, int* ve, int* tb, int* te)
@@ -613,7 +622,7 @@ int phxb_solve(phxo_body* bodies, int nb, const phxo_contact_point* cps, phxo_co
     ph.total = t1 - t_begin;
     ph.group_offset = c.group_offset; ph.threads = threads;
 
-    if (threads > 1) { p.quit = 1; pool_barrier(&p, &sense); for (int t = 1; t < threads; ++t) pthread_join(p.th[t], NULL); }
+    if (threads > 1) pool_stop(&p);
     free(args); free(p.th); free(group_bodies); free(work);
     free(c.imp); free(c.disp); free(c.par); free(c.packs); free(c.joint_index);
     FAST_MODE_LEAVE();

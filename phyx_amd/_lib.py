@@ -73,6 +73,7 @@ _SIGNATURES = {
     "phx_comm_unique_id": (C.c_int, [_vp]),
     "phx_comm_create": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, C.c_int]),
     "phx_comm_destroy": (None, [_vp]),
+    "phx_comm_rccl_version": (C.c_int, []),
     "phx_comm_rank": (C.c_int, [_vp]),
     "phx_comm_size": (C.c_int, [_vp]),
     "phx_comm_all_gather": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),

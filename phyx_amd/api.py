@@ -389,6 +389,11 @@ class Comm:
         check(L.phx_comm_unique_id(buf))
         return buf.raw
 
+    @staticmethod
+    def rccl_version():
+        """ncclGetVersion of the RCCL the library resolved (0: none)"""
+        return int(_lib.load().phx_comm_rccl_version())
+
     def __init__(self, unique_id, rank, nranks, device=0):
         self.L = _lib.load()
         assert len(unique_id) == Comm.ID_BYTES

@@ -18,6 +18,9 @@ public:
     int barrier(hipStream_t stream);
     int barrier_async(hipStream_t stream);
     int async_error(int* out);
+    int agree(int status, long long bytes, int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream);
+    int wait_stream(hipStream_t stream, const char* what);      // hipStreamSynchronize with the communicator's time bound
+    static int version();                             // ncclGetVersion (0 if RCCL is not available)
     int rank() const { return rank_; }
     int size() const { return nranks_; }
     int device() const { return device_; }

@@ -14,7 +14,11 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <future>
 #include <mutex>
+#include <string>
+#include <thread>
 
 namespace phx {
 
@@ -37,6 +41,8 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    std::string why;                  // why the library is not usable (dlopen's message, or the symbol that is missing), captured where it happened
     bool ok = false;
 };
 
@@ -51,6 +57,8 @@ Rccl& rccl()
             if (!n || !*n) continue;
             r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char* e = dlerror();                 // (dlerror() clears the state it returns: read it once, here)
+            r.why = e ? e : "dlopen failed";
         }
         if (!r.lib) return;
         auto sym = [&](const char* name) { return dlsym(r.lib, name); };
@@ -62,7 +70,9 @@ Rccl& rccl()
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.CommGetAsyncError && r.AllGather && r.AllReduce;
+        r.why = r.ok ? "" : "librccl was loaded but lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclCommGetAsyncError / ncclAllGather / ncclAllReduce";
     });
     return r;
 }
@@ -75,6 +85,14 @@ int rccl_fail(const char* what, int code)
 }
 
 #define PHX_RCCL(call, what) do { const int rc_ = (call); if (rc_ != ncclSuccess) return rccl_fail(what, rc_); } while (0)
+
+// how long a rank waits for its peers — in ncclCommInitRank, and wherever the host blocks on a collective — before it gives up
+// with an error instead of hanging its launcher: PHX_COMM_TIMEOUT_S seconds (default 120)
+double comm_timeout_s()
+{
+    static const double t = [] { const char* e = getenv("PHX_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    return t;
+}
 
 } // namespace
 
@@ -90,7 +108,7 @@ Comm::~Comm()
 int Comm::unique_id(void* out)
 {
     Rccl& r = rccl();
-    if (!r.ok) { set_error("RCCL is not available (librccl.so.1 could not be loaded: %s)", dlerror() ? dlerror() : "missing symbols"); return PHX_ERR_NO_DEVICE; }
+    if (!r.ok) { set_error("RCCL is not available (%s)", r.why.c_str()); return PHX_ERR_NO_DEVICE; }
     ncclUniqueId id;
     PHX_RCCL(r.GetUniqueId(&id), "ncclGetUniqueId");
     std::memcpy(out, id.internal, PHX_COMM_ID_BYTES);
@@ -101,17 +119,78 @@ int Comm::init(const void* unique_id, int rank, int nranks)
 {
     PHX_REQUIRE(unique_id && nranks >= 1 && rank >= 0 && rank < nranks, "bad communicator arguments");
     Rccl& r = rccl();
-    if (!r.ok) { set_error("RCCL is not available (librccl.so.1 could not be loaded)"); return PHX_ERR_NO_DEVICE; }
+    if (!r.ok) { set_error("RCCL is not available (%s)", r.why.c_str()); return PHX_ERR_NO_DEVICE; }
     PHX_TRY(use_device(device_));
     rank_ = rank; nranks_ = nranks;
     impl_ = new (std::nothrow) Impl;
     PHX_REQUIRE(impl_, "out of host memory");
     ncclUniqueId id;
     std::memcpy(id.internal, unique_id, PHX_COMM_ID_BYTES);
-    PHX_RCCL(r.CommInitRank(&impl_->comm, nranks, id, rank), "ncclCommInitRank");
-    PHX_HIP(hipMalloc(reinterpret_cast<void**>(&flag_), 2 * sizeof(int)));
-    PHX_HIP(hipMemset(flag_, 0, 2 * sizeof(int)));
+    // ncclCommInitRank blocks until all `nranks` ranks have called it: a peer that never arrives (it crashed, it was given
+    // another id) would hang this rank — and its launcher — for good.  It runs on a helper thread that is waited for with a
+    // bound; a rank that gives up leaves the thread behind (it cannot be cancelled) and reports.
+    struct Result { ncclComm_t comm = nullptr; int rc = ncclSuccess; };
+    auto done = std::make_shared<std::promise<Result>>();
+    std::future<Result> fut = done->get_future();
+    const int device = device_;
+    std::thread([done, device, nranks, id, rank] {
+        Result res;
+        (void)hipSetDevice(device);
+        res.rc = rccl().CommInitRank(&res.comm, nranks, id, rank);
+        done->set_value(res);
+    }).detach();
+    if (fut.wait_for(std::chrono::duration<double>(comm_timeout_s())) != std::future_status::ready) {
+        set_error("ncclCommInitRank: rank %d of %d still waits for its peers after %.0f s (PHX_COMM_TIMEOUT_S) — a rank is missing or holds another communicator id", rank, nranks, comm_timeout_s());
+        return PHX_ERR_STATE;
+    }
+    const Result res = fut.get();
+    if (res.rc != ncclSuccess) return rccl_fail("ncclCommInitRank", res.rc);
+    impl_->comm = res.comm;
+    PHX_HIP(hipMalloc(reinterpret_cast<void**>(&flag_), 8 * sizeof(int)));
+    PHX_HIP(hipMemset(flag_, 0, 8 * sizeof(int)));
     return PHX_OK;
+}
+
+// bounded hipStreamSynchronize: a collective some peer never joins must not hang the host for good
+int Comm::wait_stream(hipStream_t stream, const char* what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return PHX_OK;
+        if (q != hipErrorNotReady) { set_error("%s: %s", what, hipGetErrorString(q)); return PHX_ERR_HIP; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) {
+            if (impl_ && impl_->comm && rccl().CommAbort) { (void)rccl().CommAbort(impl_->comm); impl_->comm = nullptr; }      // (later calls fail at once)
+            set_error("%s: rank %d of %d still waits after %.0f s (PHX_COMM_TIMEOUT_S) — a peer never entered the collective; the communicator was aborted", what, rank_, nranks_, comm_timeout_s());
+            return PHX_ERR_STATE;
+        }
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// what every rank must know before a collective whose size depends on the step: did a peer fail, and do all ranks mean the same
+// byte count?  One all-reduce (max) of {status, bytes, -bytes} on `stream`, waited for (bounded).
+int Comm::agree(int status, long long bytes, int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream)
+{
+    PHX_REQUIRE(impl_ && impl_->comm, "communicator not initialised");
+    PHX_REQUIRE(bytes >= 0 && bytes < (1ll << 31), "segment size out of range");
+    PHX_TRY(use_device(device_));
+    int h[4] = {status, (int)bytes, -(int)bytes, 0};
+    PHX_HIP(hipMemcpyAsync(flag_ + 4, h, sizeof h, hipMemcpyHostToDevice, stream));
+    PHX_RCCL(rccl().AllReduce(flag_ + 4, flag_ + 4, 4, ncclInt32, ncclMax, impl_->comm, stream), "ncclAllReduce");
+    PHX_TRY(wait_stream(stream, "agreement before the all-gather"));
+    PHX_HIP(hipMemcpy(h, flag_ + 4, sizeof h, hipMemcpyDeviceToHost));
+    if (worst_status) *worst_status = h[0];
+    if (max_bytes) *max_bytes = h[1];
+    if (min_bytes) *min_bytes = -(long long)h[2];
+    return PHX_OK;
+}
+
+int Comm::version()
+{
+    int v = 0;
+    if (rccl().ok && rccl().GetVersion) (void)rccl().GetVersion(&v);
+    return v;
 }
 
 int Comm::all_gather(const void* d_send, void* d_recv, size_t bytes_per_rank, hipStream_t stream)
@@ -141,8 +220,7 @@ int Comm::barrier(hipStream_t stream)
 {
     PHX_HIP(hipMemsetAsync(flag_, 0, sizeof(int), stream));
     PHX_TRY(all_reduce_max_int(flag_, stream));
-    PHX_HIP(hipStreamSynchronize(stream));
-    return PHX_OK;
+    return wait_stream(stream, "barrier");
 }
 
 // ncclCommGetAsyncError: 0 = healthy or still in progress, else the RCCL error code
@@ -181,6 +259,7 @@ int phx_comm_create(phx_comm** out, const void* unique_id, int32_t rank, int32_t
 
 void phx_comm_destroy(phx_comm* c) { delete c; }
 
+int phx_comm_rccl_version(void) { return phx::Comm::version(); }
 int phx_comm_rank(phx_comm* c) { return c ? c->impl.rank() : -1; }
 int phx_comm_size(phx_comm* c) { return c ? c->impl.size() : 0; }
 

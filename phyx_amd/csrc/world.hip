@@ -442,16 +442,17 @@ int World::step_sharded(float dt, const phx_config& cfg)
         const BodyView bodies = resident().s;
         st = solver_.exchange_pack_resident(&bodies, d_joints_.p, &seg);
     }
-    if (st != PHX_OK) {
-        // This rank failed before it could pack.  Its peers are about to enter the collective: enter it too, with a header-only
-        // segment that carries a non-zero status word, so that they are not left hanging in it and find out at their next check.
-        // (The size is the last one all ranks agreed on — right whenever the schedule did not change in this step.)
-        const std::string why = last_error();
-        seg = std::min<size_t>(std::max<size_t>(solver_.exchange_segment_bytes(), 256), xch_capacity_);
-        if (solver_.exchange_pack_resident(nullptr, nullptr, nullptr, 1) == PHX_OK) (void)comm_->all_gather(xch_send_.p, xch_recv_.p, seg, stream_);
-        set_error("%s", why.c_str());
-        return st;
-    }
+    // Before the collective every rank learns whether a peer failed in this step and whether all ranks mean the same segment size
+    // (a pure function of the schedule, hence equal on replicas that agree): one 16-byte all-reduce, waited for with the
+    // communicator's time bound.  A failed or diverged step ends HERE on every rank, with an error, and nobody enters an all-gather
+    // with a byte count its peers do not share (which would hang or corrupt instead of reporting).
+    const std::string why = st != PHX_OK ? last_error() : std::string();
+    int worst = 0; long long lo = 0, hi = 0;
+    const int agreed = comm_->agree(st != PHX_OK ? 1 : 0, st != PHX_OK ? 0ll : (long long)seg, &worst, &lo, &hi, stream_);
+    if (st != PHX_OK) { set_error("%s", why.c_str()); return st; }
+    PHX_TRY(agreed);
+    if (worst) { set_error("island-sharded step: a peer failed before the exchange (this rank's half of the step is done, nothing was exchanged)"); return PHX_ERR_STATE; }
+    if (lo != hi) { set_error("island-sharded step: the ranks' segment sizes differ (%lld .. %lld bytes): the replicas diverged", lo, hi); return PHX_ERR_STATE; }
     { RoctxRange r("Exchange: all-gather (RCCL)"); PHX_TRY(comm_->all_gather(xch_send_.p, xch_recv_.p, seg, stream_)); }
     PHX_TRY(step_end(dt));
     if ((++sharded_steps_ & 15u) == 0) PHX_TRY(check_exchange());

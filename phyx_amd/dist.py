@@ -113,22 +113,22 @@ class Exchange:
 
 def step_sharded(world, dt, configuration, exchange):
     """One World::Update of an island-sharded world (ref: World.cpp:19-37 on every rank's replica): solve this rank's
-    groups, all-gather everyone's results, scatter them, integrate.  A rank whose first half fails still enters the
-    collective (so its peers are not left hanging in it) with a non-zero status word, then re-raises; the peers see
-    PHX_XCH_PEER_ERROR at their next Exchange.check()."""
-    from ._lib import PhxError, check
+    groups, all-gather everyone's results, scatter them, integrate.  Before the collective the ranks AGREE (one small
+    all-reduce: Group.agree) on whether anyone failed in this step and on the segment size: a failed or diverged step ends
+    there on every rank with an error, and nobody enters an all-gather whose byte count its peers do not share."""
+    from ._lib import PhxError
+    err, seg = None, 0
     try:
         seg = world.StepBegin(dt, configuration)
-    except PhxError:
-        # the size every rank agreed on last (right whenever the schedule did not change in this step), never beyond the buffers
-        seg = min(exchange.solver.exchange_segment_bytes() or 256, exchange.capacity)
-        try:
-            check(exchange.solver.L.phx_solver_exchange_pack(exchange.solver.h, None, None, 1, None))
-            exchange.all_gather(seg)
-        except Exception as e:                     # the step's own error is the one to report; say that the peers were not told
-            import sys
-            sys.stderr.write("phyx_amd.dist: could not post the failure to the peers: %s\n" % e)
-        raise
+    except PhxError as e:
+        err = e
+    worst, lo, hi = exchange.group.agree(1 if err is not None else 0, seg)
+    if err is not None:
+        raise err
+    if worst:
+        raise ExchangeError(1)
+    if lo != hi:
+        raise ExchangeError(4)
     exchange.all_gather(seg)
     world.StepEnd(dt)
     exchange.steps = getattr(exchange, "steps", 0) + 1
@@ -148,6 +148,9 @@ class Single:
 
     def step_barrier_value(self, value):
         return int(value)
+
+    def agree(self, status, nbytes):
+        return int(status), int(nbytes), int(nbytes)
 
     def all_gather_bytes(self, mine):
         return np.ascontiguousarray(mine, dtype=np.uint8)
@@ -188,10 +191,14 @@ class Group:
         # (device_id binds the communicator to this rank's GPU up front: no 'guessing device ID' and no lazy init in the first collective)
         kw = {"device_id": self.device} if backend == "nccl" else {}
         pg_backend = "gloo" if backend == "rccl" else backend       # native transport: torch only does the rendezvous, on the CPU
+        # (a rank that never shows up must not hang the others for torch's default half hour: PHX_COMM_TIMEOUT_S, like csrc/comm.hip)
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=comm_timeout_s())
         try:
             dist.init_process_group(backend=pg_backend, rank=self.rank, world_size=self.world_size, **kw)
         except TypeError:                                   # a torch without the device_id argument
-            dist.init_process_group(backend=pg_backend, rank=self.rank, world_size=self.world_size)
+            kw.pop("device_id", None)
+            dist.init_process_group(backend=pg_backend, rank=self.rank, world_size=self.world_size, **kw)
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         if backend == "rccl":
             # the library's own RCCL communicator (csrc/comm.hip): rank 0's id reaches everybody through the gloo group
@@ -238,6 +245,21 @@ class Group:
         self.dist.all_reduce(self._flag, op=self.dist.ReduceOp.MAX)
         self._sync()
         return int(self._flag.item())
+
+    def agree(self, status, nbytes):
+        """(worst status, smallest, largest byte count) over all ranks: what step_sharded needs to know before the all-gather."""
+        t = self.torch.tensor([int(status), int(nbytes), -int(nbytes)], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self._sync()
+        v = t.tolist()
+        return int(v[0]), -int(v[2]), int(v[1])
+
+    def info(self):
+        """what this run's transport is, for bench.py's config"""
+        from . import api
+        v = api.Comm.rccl_version() if self.backend == "rccl" else 0
+        return {"backend": self.backend, "ranks_seen": self.world_size, "rccl_version": v,
+                "native_communicator": self.comm is not None}
 
     def stream_hook(self, stream_ptr):
         """hook(step, phase) for Solver.bench: the per-step exchange (a 4-byte all-reduce) lives ON THE SOLVER'S OWN STREAM.
@@ -295,14 +317,47 @@ class Group:
             pass
 
 
-def self_launch(n, argv=None):
+def comm_timeout_s():
+    """seconds a rank waits for its peers before it gives up (PHX_COMM_TIMEOUT_S, default 120; csrc/comm.hip reads the same)"""
+    try:
+        v = float(os.environ.get("PHX_COMM_TIMEOUT_S", "0"))
+    except ValueError:
+        v = 0.0
+    return v if v > 0 else 120.0
+
+
+def watchdog(seconds, on_expiry):
+    """Arms a timer thread that calls on_expiry() and then leaves the process with status 3 — for a rank that may block inside a
+    collective some peer never joins (ctypes and torch release the GIL there).  Returns the timer: .cancel() it when done."""
+    import threading
+
+    def fire():
+        try:
+            on_expiry()
+        finally:
+            os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def self_launch(n, argv=None, timeout_s=None):
     """`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): spawn the N ranks ourselves — one process per
     GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the same command line — and wait for them.  Rank 0
-    prints the one JSON line (the children inherit stdout / stderr).  Returns the exit status to leave with."""
+    prints the one JSON line (the children inherit stdout / stderr).  Returns the exit status to leave with.
+    A rank that dies takes the others down with it (they would wait for it in the next collective), and the whole run is bounded
+    by `timeout_s` (PHX_LAUNCH_TIMEOUT_S, default 1800): the launcher never hangs."""
     import socket
     import subprocess
     import sys
+    import time
     argv = list(sys.argv if argv is None else argv)
+    if timeout_s is None:
+        try:
+            timeout_s = float(os.environ.get("PHX_LAUNCH_TIMEOUT_S", "0")) or 1800.0
+        except ValueError:
+            timeout_s = 1800.0
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -311,9 +366,30 @@ def self_launch(n, argv=None):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable] + argv, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    rc, t0 = 0, time.time()
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+        if live and (rc != 0 or time.time() - t0 > timeout_s):
+            if rc == 0:
+                rc = 124
+                sys.stderr.write("phyx_amd.dist.self_launch: %d rank(s) still running after %.0f s: terminating them\n" % (len(live), timeout_s))
+            for p in live:                         # (exactly the processes started above)
+                p.terminate()
+            deadline = time.time() + 10.0
+            for p in live:
+                try:
+                    p.wait(max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            live = []
     return rc
 
 

@@ -272,24 +272,48 @@ def test_exchange_through_the_native_rccl_transport_one_rank(built_lib):
     assert p.returncode == 0 and "sharded worker ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+def test_native_communicator_gives_up_on_a_missing_peer(built_lib):
+    """csrc/comm.hip: ncclCommInitRank blocks until every rank has called it.  A rank whose peer never arrives must come back with an
+    error after PHX_COMM_TIMEOUT_S seconds instead of hanging its launcher (the first multi-GPU run of the native transport is
+    the driver's: it must not be able to hang)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import phyx_amd\nfrom phyx_amd import api\nfrom phyx_amd._lib import PhxError\n"
+            "assert api.Comm.rccl_version() > 0\n"
+            "uid = api.Comm.unique_id()\n"
+            "try:\n    api.Comm(uid, 0, 2, 0)\nexcept PhxError as e:\n    print('GAVE UP:', e); sys.stdout.flush()\n    import os; os._exit(0)\n"
+            "print('created?!')\n" % root)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PHX_COMM_TIMEOUT_S="4"), capture_output=True, text=True, timeout=300)
+    assert "GAVE UP" in p.stdout and "still waits for its peers" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
+    assert time.time() - t0 < 120
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
 @pytest.mark.parametrize("mode", ["slab", "replica"])
-def test_bench_launches_its_own_ranks(built_lib, mode):
-    """`python bench.py --gpus 2` without torchrun: bench.py spawns the two ranks itself (here both on GPU 0 over gloo) and rank 0
-    prints the one JSON line of the cfg-3 workload — in slab mode (ownership sharding, the default) and in replica mode."""
+def test_bench_launches_its_own_ranks(built_lib, mode, ranks):
+    """`python bench.py --gpus N` without torchrun: bench.py spawns the N ranks itself (here all of them on GPU 0 over gloo) and rank 0
+    prints the one JSON line of the cfg-3 workload — in slab mode (ownership sharding, the default) and in replica mode; N = 8 is
+    the shape of the driver's scaling run (eight processes, eight slabs / eight shares of the groups, the per-step collective)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--mode", mode, "--columns", "48", "--rows", "30", "--steps", "3",
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--mode", mode, "--columns", "48", "--rows", "30", "--steps", "3",
                         "--warmup", "1", "--repeats", "1", "--no-secondary", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=600)
+                       text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["mode"] == mode
+    assert out["n_gpus"] == ranks and out["steps"] == 3 and out["value"] > 0 and out["config"]["mode"] == mode and "error" not in out
     assert out["config"]["bodies_total"] == 48 * 30 + 1
+    assert out["config"]["transport_info"]["ranks_seen"] == ranks
     if mode == "replica":
         assert out["extra"]["exchange"]["status"] == 0
 
