@@ -13,7 +13,7 @@ public:
     int clear();
     // `prologue` (World only): IntegrateVelocity (ref: World.cpp:39-55) rides on the update's first kernel — the key of a body is
     // its AABB's min x, which the velocity step does not touch — and the step's four counters are cleared on the way: a dispatch fewer
-    struct StepPrologue { float gravity, dt; unsigned* counters; float4* vel; const float4* mpos; };      // (resident arrays, body_view.h)
+    struct StepPrologue { float gravity, dt; unsigned* counters; float4* vel; const float4* mpos; const float4* accel; };      // (resident arrays, body_view.h)
     // the resident form: one float4 {min.x, min.y, max.x, max.y} per body (what the World keeps, body_view.h)
     int update_resident(const float4* d_aabb, int n, const StepPrologue* prologue = nullptr);
     // the C-ABI edge: 128-byte records (their AABBs are extracted into a scratch array first)

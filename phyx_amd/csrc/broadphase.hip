@@ -45,7 +45,7 @@ template <bool INTEGRATE>
 __global__ void __launch_bounds__(256) k_build_keys(const float4* __restrict__ aabb, float4* __restrict__ vel, const float4* __restrict__ mpos, int n,
                                                     unsigned* __restrict__ keys, unsigned* __restrict__ idx,
                                                     unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
-                                                    unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters)
+                                                    unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters, const float4* __restrict__ accel)
 {
     if (INTEGRATE && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;      // (the World's step counters)
     // the update's device time without HIP events (an event record is a barrier packet of its own: ~5 us of idle queue): this, its
@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) k_build_keys(const float4* __restrict__ a
         if (INTEGRATE) {                                       // IntegrateVelocity (ref: World.cpp:39-55), same statements as k_integrate_velocity
             float4 v = vel[i];
             float ax = 0.f, ay = 0.f, aa = 0.f;                // (the resident world carries no accelerations: world_kernels.h)
+            if (accel) { const float4 a = accel[i]; ax = a.x; ay = a.y; aa = a.z; }      // (... but for the first step after an upload that came with some)
             if (mpos[i].x > 0.0f) ay += gravity;
             v.x += ax * dt; v.y += ay * dt;
             v.z += aa * dt;
@@ -513,17 +514,17 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         sv.keys_out = keys_[1].p; sv.idx_out = idx_[1].p; sv.entries = entries_.p; sv.next_splitters = splitters_.p; sv.max_bucket = ss_stats_.p;
         const dim3 tiles(div_up(n, SS_TILE));
         if (prologue) hipLaunchKernelGGL((k_keys_buckets<true>), tiles, dim3(SS_TILE_T), 0, stream_, sv, prologue->vel, prologue->mpos, small_.p, 16 + 2 * STAT_SLOTS,
-                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
+                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters, prologue->accel);
         else hipLaunchKernelGGL((k_keys_buckets<false>), tiles, dim3(SS_TILE_T), 0, stream_, sv, (float4*)nullptr, (const float4*)nullptr, small_.p, 16 + 2 * STAT_SLOTS,
-                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
+                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr, (const float4*)nullptr);
         hipLaunchKernelGGL(k_bucket_scatter, tiles, dim3(SS_TILE_T), 0, stream_, sv);
         hipLaunchKernelGGL(k_bucket_sort, dim3(buckets), dim3(SS_SORT_T), 0, stream_, sv);
         src = 1;
     } else {
         if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, prologue->vel, prologue->mpos, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
-                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters);
+                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters, prologue->accel);
         else hipLaunchKernelGGL((k_build_keys<false>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (float4*)nullptr, (const float4*)nullptr, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
-                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr);
+                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr, (const float4*)nullptr);
         PHX_TRY(device_radix_sort_pairs(keys_[0].p, idx_[0].p, keys_[1].p, idx_[1].p, n, 32, hist_.p, scan_tiles_, stream_, &src));
         hipLaunchKernelGGL(k_gather_entries, dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, (const unsigned*)keys_[src].p, (const unsigned*)idx_[src].p, n, entries_.p, splitters_.p, ss_stride(n));
         PHX_HIP(hipMemsetAsync(ss_stats_.p, 0, sizeof(unsigned), stream_));

@@ -66,4 +66,7 @@ struct IslandView {
 void launch_solve_islands(hipStream_t stream, int groups, bool big_shape, bool half_state, bool trace, const SolverView& v, const IslandView& iv,
                           const BodyView& bodies, phx_contact_joint* joints, const phx_contact_point* cps, int ci, int pi);
 
+// resident workgroups per CU of that instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor, cached; 0 if the query failed)
+int island_blocks_per_cu(bool big_shape, bool half_state);
+
 } // namespace phx

@@ -244,6 +244,7 @@ private:
     DevBuf<phx_contact_joint> stage_joints_;
     const void* staged_src_bodies_ = nullptr; const void* staged_src_joints_ = nullptr;
     int staged_nb_ = 0, staged_nj_ = 0, staged_steps_ = 0;
+    bool in_bench_loop_ = false;                      // bench()'s timed loop: unverified solves are chained on purpose
     bool bench_trusted_ = false;                      // bench(): the timed solves run on copies of the input the schedule was built (and verified) for
 
     Schedule sched_;

@@ -172,8 +172,10 @@ int DeviceSolver::launch_fingerprint(const float4* d_mpos, int nb, const phx_con
 bool DeviceSolver::verify_eligible(int groups, bool big_shape) const
 {
     if (no_fused_verify_ || !speculate_ || use_graphs_ || shard_count_ != 1 || xch_send_ || groups <= 0) return false;
-    const int per_cu = big_shape ? 2 : 4;                   // LDS (37 / 50 KB) and the 128-register budget admit exactly that many
-    return groups <= per_cu * cu_count_ && groups < (int)ISL_BAD / 2;
+    // (LDS — 37 / 50 KB — and the 128-register budget admit 4 / 2 workgroups per CU; asked of the runtime for the instantiation
+    //  at hand rather than assumed, and never more than that: the occupancy query has been seen one block high)
+    const int per_cu = std::min(island_blocks_per_cu(big_shape, half_state_), big_shape ? 2 : 4);
+    return per_cu > 0 && groups <= per_cu * cu_count_ && groups < (int)ISL_BAD / 2;
 }
 
 // would a rebuild take the path without a host round trip (build_bins_speculative)?
@@ -1168,6 +1170,12 @@ int DeviceSolver::solve_common(const Arrays& a, int nb, const void* d_cps, int n
     // an unverified solve on OTHER arrays is still in flight: settle it first (a repeat on the same arrays simply
     // supersedes it — each solve is gated for itself)
     if (pending_.active && !same_as_pending(a, nb, d_cps, ncp, d_joints, nj, cfg)) PHX_TRY(synchronize());
+    // ... and so is an unverified solve whose launch checks the schedule ITSELF (ISL_VERIFY): a workgroup that gives up its bounded wait
+    // marks the solve's control word, which the NEXT solve's first kernel clears (two control sets alternate) — chained, a timed-out
+    // solve would never be completed (complete_partial) and its late groups would silently get one solve fewer.  Hash-gated repeats
+    // share one verdict and commit all or nothing: they may chain.
+    // (bench()'s timed loop queues its steps back to back by design and settles them at the end: a measurement, not a caller)
+    if (pending_.active && pending_.mode == ISL_VERIFY && !in_bench_loop_) PHX_TRY(synchronize());
     // a device-built schedule is verified (did every bin fit?) before anything else runs on it: only the solve that was queued
     // with the build is covered by the spoiled control word
     if (build_unverified_) PHX_TRY(synchronize());
@@ -1371,6 +1379,9 @@ int DeviceSolver::synchronize()
         spec_bins_failed_ = false;
         if (fp != gate_expected_ && p.mode == ISL_VERIFY && (fp & ~ISL_TIMEOUT) == gate_expected_) {
             // every workgroup arrived and found the schedule correct, but some gave up waiting for the others: finish their groups
+            // (and stop checking the schedule inside the launch on this handle: whatever delayed them — a GPU shared with somebody
+            //  else's kernels — makes every such solve a ~20 ms cliff; the hash-gated form has no wait between workgroups)
+            no_fused_verify_ = true;
             stats_pending_ = true;
             ++replays_;                                // (callers that queued work behind the solve's gate repeat it)
             pending_ = p;
@@ -1598,6 +1609,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
         ~SweepEvents() { s.ev_sweep_begin_ = b; s.ev_sweep_end_ = e; s.time_sweeps_ = false; s.timed_sweeps_ = false; }
     } sweep_events(*this);
     int st = PHX_OK;
+    struct InLoop { DeviceSolver& s; explicit InLoop(DeviceSolver& s_) : s(s_) { s.in_bench_loop_ = true; } ~InLoop() { s.in_bench_loop_ = false; } } in_loop(*this);
     struct Trusted { DeviceSolver& s; Trusted(DeviceSolver& s_, bool on) : s(s_) { s.bench_trusted_ = on; } ~Trusted() { s.bench_trusted_ = false; } } trusted(*this, staged && reuse_schedule_ && speculate_);
     PHX_HIP(hipEventRecord(bench_events_[2 * steps], stream_));
     // HIP events bracket the sweep launches of every 4th step only: an event record is a barrier packet of its own (~3 us of idle

@@ -69,7 +69,7 @@ __device__ __forceinline__ int ss_bucket(const unsigned long long* spl, int nspl
 template <bool INTEGRATE>
 __global__ void __launch_bounds__(SS_TILE_T) k_keys_buckets(SplitSortView v, float4* __restrict__ vel, const float4* __restrict__ mpos,
                                                             unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
-                                                            unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters)
+                                                            unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters, const float4* __restrict__ accel)
 {
     __shared__ unsigned long long spl[SS_MAX_BUCKETS];
     __shared__ unsigned hist[SS_MAX_BUCKETS];
@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(SS_TILE_T) k_keys_buckets(SplitSortView v, flo
         if (INTEGRATE) {
             float4 w = vel[i];
             float ax = 0.f, ay = 0.f, aa = 0.f;
+            if (accel) { const float4 a = accel[i]; ax = a.x; ay = a.y; aa = a.z; }
             if (mpos[i].x > 0.0f) ay += gravity;
             w.x += ax * dt; w.y += ay * dt;
             w.z += aa * dt;

@@ -85,6 +85,7 @@ private:
     DevBuf<float4> vel_, dvel_, mpos_, frame_, aabb_;      // the resident body state (body_view.h)
     DevBuf<float2> size_;
     bool records_stale_ = false;                  // a step has run since the records were last refreshed
+    DevBuf<float4> accel_; bool accel_pending_ = false;      // accelerations the uploaded records came with: consumed by the next IntegrateVelocity
     DevBuf<phx_manifold> d_manifolds_;
     DevBuf<phx_contact_point> d_cps_;
     DevBuf<phx_contact_joint> d_joints_;
@@ -185,6 +186,17 @@ int World::sync_bodies_to_device()
         PHX_HIP(hipMemcpyAsync(d_bodies_.p, host_bodies_.data(), host_bodies_.size() * sizeof(phx_rigid_body), hipMemcpyHostToDevice, stream_));
         hipLaunchKernelGGL(k_bodies_to_world, dim3(wgrid(nb())), dim3(256), 0, stream_, (const phx_rigid_body*)d_bodies_.p, nb(), resident());
         PHX_HIP(hipGetLastError());
+        // records that come with accelerations (a handed-over state; AddBody leaves none): the next IntegrateVelocity applies them,
+        // once, like the reference (ref: World.cpp:44-53)
+        accel_pending_ = false;
+        for (const phx_rigid_body& b : host_bodies_) if (b.acceleration.x != 0.f || b.acceleration.y != 0.f || b.angular_acceleration != 0.f) { accel_pending_ = true; break; }
+        if (accel_pending_) {
+            std::vector<float4> acc(host_bodies_.size());
+            for (size_t i = 0; i < acc.size(); ++i) acc[i] = make_float4(host_bodies_[i].acceleration.x, host_bodies_[i].acceleration.y, host_bodies_[i].angular_acceleration, 0.f);
+            PHX_TRY(accel_.reserve(acc.size()));
+            PHX_HIP(hipMemcpyAsync(accel_.p, acc.data(), acc.size() * sizeof(float4), hipMemcpyHostToDevice, stream_));
+            PHX_HIP(hipStreamSynchronize(stream_));      // (`acc` is a local)
+        }
     }
     PHX_HIP(hipStreamSynchronize(stream_));
     bodies_dirty_ = false;
@@ -210,9 +222,14 @@ int World::scratch_for(int n)
 
 int World::update_pairs()                                                   // ref: Collider.cpp:251-345
 {
-    const DeviceBroadphase::StepPrologue prologue{gravity, step_dt_, counters_.p, vel_.p, mpos_.p};
+    const DeviceBroadphase::StepPrologue prologue{gravity, step_dt_, counters_.p, vel_.p, mpos_.p, accel_pending_ ? (const float4*)accel_.p : nullptr};
     PHX_TRY(broadphase_.update_resident(aabb_.p, nb(), fuse_velocity_ ? &prologue : nullptr));      // same stream; returns once the new-pair count is known
     fuse_velocity_ = false;
+    if (accel_pending_) {                  // IntegrateVelocity of this step has consumed the uploaded accelerations (ref: World.cpp:50, 53)
+        accel_pending_ = false;
+        if (nb()) hipLaunchKernelGGL(k_clear_accelerations, dim3(wgrid(nb())), dim3(256), 0, stream_, d_bodies_.p, nb());
+        PHX_HIP(hipGetLastError());
+    }
     const int fresh = broadphase_.new_pair_count();
     if (!fresh) return PHX_OK;
     PHX_TRY(d_manifolds_.reserve_keep((size_t)nm + fresh, nm, stream_));
@@ -369,7 +386,7 @@ int World::pre_solve(float dt)
         fuse_velocity_ = !phase_timing;
         step_dt_ = dt;
         records_stale_ = true;
-        if (nb() && !fuse_velocity_) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, vel_.p, (const float4*)mpos_.p, nb(), gravity, dt, counters_.p);
+        if (nb() && !fuse_velocity_) hipLaunchKernelGGL(k_integrate_velocity, dim3(wgrid(nb())), dim3(256), 0, stream_, vel_.p, (const float4*)mpos_.p, nb(), gravity, dt, counters_.p, accel_pending_ ? (const float4*)accel_.p : nullptr);
         PHX_HIP(hipGetLastError());
         lap(0);
     }
@@ -544,7 +561,7 @@ PHX_DOWNLOAD(download_joints, phx_contact_joint, d_joints_, nj)
 // Restore (or hand over) a whole world: what the four getters return, put back.  The contact cache is the state the reference
 // carries from step to step (ref: Collider.h:57-58 manifolds + manifoldMap, World.h:33 contactJoints with their warm-start
 // impulses, ContactPoint::solverIndex linking the two); everything else a step needs is rebuilt by the step.  Used by
-// checkpoint / resume and by the hand-over of bodies between the ranks of an ownership-sharded world (dist.SlabWorld.reslab).
+// checkpoint / resume and by the hand-over of bodies between the ranks of an ownership-sharded world.
 int World::set_state(const phx_rigid_body* bodies, int body_count, const phx_manifold* manifolds, int manifold_count,
                      const phx_contact_point* cps, int cp_count, const phx_contact_joint* joints, int joint_count)
 {

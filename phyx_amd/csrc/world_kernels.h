@@ -49,21 +49,32 @@ static __global__ void __launch_bounds__(256) k_world_to_bodies(WorldBodies w, i
     }
 }
 
-// IntegrateVelocity (ref: World.cpp:39-55).  The resident world carries no acceleration arrays: the reference zeroes both
-// accelerations at the end of every IntegrateVelocity (World.cpp:49-52), nothing on the path or in the C ABI ever sets them, so
-// they are zero whenever this runs; the statements keep the reference's form (x + 0 * dt is not x for x = -0).
+// IntegrateVelocity (ref: World.cpp:39-55).  The reference zeroes both accelerations at the end of every IntegrateVelocity
+// (World.cpp:49-52) and nothing on the path sets them, so the resident world carries no acceleration arrays: they are zero
+// whenever this runs — except in the FIRST step after an upload of records that came with accelerations (phx_world_set_state /
+// set_bodies of a foreign or handed-over state): `accel` = {acceleration.x, .y, angularAcceleration} per body for that one step,
+// null otherwise.  The statements keep the reference's form (x + 0 * dt is not x for x = -0).
 // (first kernel of a step: it also clears the step's four counters)
 static __global__ void __launch_bounds__(256) k_integrate_velocity(float4* __restrict__ vel, const float4* __restrict__ mpos, int n, float gravity, float dt,
-                                                                   unsigned* __restrict__ counters)
+                                                                   unsigned* __restrict__ counters, const float4* __restrict__ accel)
 {
     if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = vel[i];
         float ax = 0.f, ay = 0.f, aa = 0.f;
+        if (accel) { const float4 a = accel[i]; ax = a.x; ay = a.y; aa = a.z; }
         if (mpos[i].x > 0.0f) ay += gravity;
         v.x += ax * dt; v.y += ay * dt;
         v.z += aa * dt;
         vel[i] = v;
+    }
+}
+
+// the records' accelerations once IntegrateVelocity has consumed them (ref: World.cpp:50, 53)
+static __global__ void __launch_bounds__(256) k_clear_accelerations(phx_rigid_body* __restrict__ bodies, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        bodies[i].acceleration.x = 0.f; bodies[i].acceleration.y = 0.f; bodies[i].angular_acceleration = 0.f;
     }
 }
 

@@ -98,9 +98,11 @@ def test_full_size_1m_boxes_properties(collider, oracle):
     gs, ge = collider.sorted(len(b))
     assert gs.tobytes() == srt.tobytes() and ge.tobytes() == ent.tobytes()
     assert (np.diff(gs["value"].astype(np.int64)) >= 0).all()
-    _, cnt, tests = oracle.sweep_candidates(ent, cap=0)
+    cand, cnt, tests = oracle.sweep_candidates(ent)                        # the reference's serial sweep (ref: Collider.cpp:296-318): every pair, in its order
     st = collider.stats()
     assert st.overlapping_pairs == cnt == len(new) and st.candidate_tests == tests
+    assert new.tobytes() == np.ascontiguousarray(cand, dtype=np.uint32).tobytes(), "the 1M-body pair list differs from the serial sweep's, element by element"
+
     a, c = b[new[:, 0]], b[new[:, 1]]
     assert (a["aabb_min"]["x"] <= c["aabb_max"]["x"]).all() and (c["aabb_min"]["x"] <= a["aabb_max"]["x"]).all()
     # idempotence: a second update over the same bodies reports nothing new — and it takes the two-level sort (splitters of the

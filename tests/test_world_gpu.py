@@ -186,6 +186,51 @@ def test_sharded_world_at_config3_size_matches_the_oracle(oracle, built_lib):
     assert all(w.solver.exchange_status() == 0 for w in ranks.worlds)
 
 
+def test_slab_worlds_at_config3_size_match_their_oracles(oracle, built_lib):
+    """BASELINE config 3 in SLAB mode — what `bench.py --gpus 8` runs by default — at full size: stack(1000,200) cut into 8 x-slabs of
+    125 columns (+ the ground), one World per slab (here all on GPU 0), five steps.  Every slab world equals the oracle world of
+    its own sub-scene byte for byte after every step, the guard (no body near its slab's boundary) holds, and against the UNSHARDED
+    200k world the union stays inside the stated tolerance (another legal Gauss-Seidel order: a slab numbers its contact points
+    locally): manifold counts within 3 %, max |position difference| < 0.5 after five steps."""
+    import types
+    from phyx_amd import dist as pdist
+    scene = scenes.stack(1000, 200)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 20, 20)
+    k = 8
+    parts = pdist.slab_partition(scene, k)
+    assert sum(len(idx) - 1 for _, idx, _ in parts) == 200000
+    slabs, oracles = [], []
+    for r in range(k):
+        g = types.SimpleNamespace(rank=r, world_size=k, step_barrier_value=lambda v: v)
+        slabs.append(pdist.SlabWorld(g, scene, device=0, gravity=-200.0))
+        oracles.append(oracle_world(parts[r][0]))
+    full = phyx_amd.World(0, gravity=-200.0)
+    full.add_scene(scene)
+    for step in range(5):
+        full.Update(1.0 / 60.0, cfg)
+        for r in range(k):
+            slabs[r].step(1.0 / 60.0, cfg)                                  # (raises if the guard trips)
+            w, ow = slabs[r].world, oracles[r]
+            ow.pre_solve(1.0 / 60.0)
+            order, offs = w.solver.schedule()
+            groups, _ = w.solver.groups()
+            oracle.solver_solve_grouped(ow.bodies(), ow.contact_points(), ow.joints(), order, offs, groups, 20, 20, oracle.STAG_COLOUR_SYNC)
+            ow.integrate_position(1.0 / 60.0)
+            assert w.counts() == (len(ow.bodies()), len(ow.manifolds()), len(ow.contact_points()), len(ow.joints())), "slab %d step %d" % (r, step)
+            assert w.bodies.tobytes() == ow.bodies().tobytes(), "slab %d bodies differ from its oracle at step %d" % (r, step)
+            assert w.contactJoints.tobytes() == ow.joints().tobytes(), "slab %d joints differ from its oracle at step %d" % (r, step)
+    st = slabs[0].world.solver.stats()
+    assert st.lds_islands >= 100 and all(s.check() for s in slabs)
+    union = np.zeros(len(scene["px"]), dtype=phyx_amd.rigid_body_dtype)
+    for r in range(k - 1, -1, -1):
+        union[slabs[r].global_index] = slabs[r].world.bodies
+    fb = full.bodies
+    dpos = np.hypot(union["pos"]["x"] - fb["pos"]["x"], union["pos"]["y"] - fb["pos"]["y"])
+    assert dpos.max() < 0.5, dpos.max()
+    nm_union, nm_full = sum(s.world.counts()[1] for s in slabs), full.counts()[1]
+    assert abs(nm_union - nm_full) <= 0.03 * nm_full, (nm_union, nm_full)
+
+
 def test_exchange_detects_a_diverged_or_failed_peer(built_lib):
     """The all-gather carries a real status: every segment's header holds the step serial, a status word and the topology
     fingerprint of the schedule the rank solved; the unpack flags a peer that reported a failure, is at another step,
@@ -402,6 +447,37 @@ def test_world_state_save_and_restore_is_exact(built_lib):
         b.set_state(bodies, manifolds, cps[:-1], joints)
     b.set_state(*saved)                                                      # and the handle is still usable
     assert b.counts() == (len(bodies), len(manifolds), len(cps), len(joints))
+
+
+def test_uploaded_accelerations_are_applied_once(oracle, built_lib):
+    """Records handed to phx_world_set_state may carry accelerations (the reference's demo sets them on a dragged body, ref:
+    main.cpp:345-346); IntegrateVelocity applies them once and zeroes them (ref: World.cpp:44-53).  A restored world must do the
+    same — the resident arrays carry no accelerations, so the first step after the upload takes them from a one-shot table —
+    byte for byte with the oracle world whose records were given the same accelerations."""
+    scene = scenes.stack(3, 14)
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 10, 10)
+    pw, ow = _lockstep(oracle, scene, 3, cfg)
+    bodies, manifolds, cps, joints = (x.copy() for x in pw.state())
+    rng = np.random.default_rng(3)
+    n = len(bodies)
+    ax, ay, aa = (rng.normal(0, 40, n).astype(np.float32) for _ in range(3))
+    ax[0] = ay[0] = aa[0] = 0                                              # (the static ground)
+    bodies["acceleration"]["x"] = ax; bodies["acceleration"]["y"] = ay; bodies["angular_acceleration"] = aa
+    live = ow.bodies()                                                       # the oracle world's own records
+    live["acceleration"]["x"] = ax; live["acceleration"]["y"] = ay; live["angular_acceleration"] = aa
+    w = phyx_amd.World(0, gravity=-200.0)
+    w.set_state(bodies, manifolds, cps, joints)
+    assert w.bodies.tobytes() == ow.bodies().tobytes()
+    for step in range(3):
+        w.Update(1.0 / 60.0, cfg)
+        ow.pre_solve(1.0 / 60.0)
+        order, offs = w.solver.schedule()
+        groups, _ = w.solver.groups()
+        oracle.solver_solve_grouped(ow.bodies(), ow.contact_points(), ow.joints(), order, offs, groups, 10, 10, oracle.STAG_COLOUR_SYNC)
+        ow.integrate_position(1.0 / 60.0)
+        assert w.bodies.tobytes() == ow.bodies().tobytes(), "bodies differ at step %d after the upload" % step
+        assert not w.bodies["acceleration"]["x"].any() and not w.bodies["angular_acceleration"].any()
+        assert w.contactJoints.tobytes() == ow.joints().tobytes()
 
 
 def test_update_is_queued_and_getters_synchronise(oracle, built_lib):
