@@ -408,9 +408,7 @@ DeviceBroadphase::~DeviceBroadphase()
 {
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
-    for (int k = 0; k < 2; ++k) { keys_[k].release(); idx_[k].release(); }
-    hist_.release(); entries_.release(); table_.release(); row_count_.release(); row_cache_.release(); chunks_.release(); chunk_count_.release(); chunk_scan_.release(); scan_tiles_.release(); small_.release(); stamps_.release();
-    new_pairs_.release(); st_bodies_.release(); st_aabb_.release(); scratch_pairs_.release(); erase_count_.release();
+    // (device buffers are DevBuf members: freed with the object)
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -441,8 +439,7 @@ int DeviceBroadphase::resize_table(unsigned want_cap)
         PHX_HIP(hipGetLastError());
     }
     PHX_HIP(hipStreamSynchronize(stream_));
-    table_.release();
-    table_ = fresh;
+    table_ = std::move(fresh);
     table_cap_ = cap;
     tombstones_ = 0;
     return PHX_OK;

@@ -64,6 +64,13 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    // owns its allocation: freed with the object (the owners' destructors select the device first; no hand-kept release lists)
+    DevBuf() = default;
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
     int reserve(size_t n)
     {
         if (n <= cap) return PHX_OK;
@@ -107,6 +114,10 @@ template <typename T>
 struct PinnedBuf {
     T* p = nullptr;
     size_t cap = 0;
+    PinnedBuf() = default;
+    ~PinnedBuf() { release(); }
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
     int reserve(size_t n)
     {
         if (n <= cap) return PHX_OK;

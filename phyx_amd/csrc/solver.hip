@@ -38,19 +38,10 @@ DeviceSolver::~DeviceSolver()
     if (stream_) (void)hipStreamSynchronize(stream_);
     drop_graphs();
     for (hipEvent_t e : bench_events_) (void)hipEventDestroy(e);
-    sb_imp_.release(); sb_disp_.release(); edge_vel_.release(); edge_dvel_.release(); edge_mpos_.release(); isl_done_.release(); isl_shards_.release(); q0_.release(); q1_.release(); q2_.release(); q3_.release(); qn_.release();
-    acc_.release(); dd_.release(); order_.release(); static_slot_.release(); flags_.release(); sw_.release();
-    cc_parent_.release(); joint_comp_.release(); bin_tables_.release(); bin_tables_host_.release(); sb_small_.release(); cc_static_.release();
-    cc_flags_.release(); comp_size_.release(); comp_units_.release(); sort_hist_.release(); sort_scan_.release(); jp_ent_.release(); jp_succ_.release(); jp_offset_.release(); jp_cursor_.release(); jp_pred_.release(); jp_adj_.release(); jp_ent_comp_.release(); jp_seed_.release(); jp_kind_.release(); partner_.release(); partner_first_.release();
-    jp_used_.release(); jp_list_[0].release(); jp_list_[1].release(); jp_counts_.release(); jp_used_b_.release(); jp_degree_.release(); jp_colour_b_.release(); jp_seen_.release(); jp_bad_b_.release(); jp_touched_.release(); jp_small_.release(); for (int k = 0; k < 2; ++k) { jp_keys_[k].release(); jp_vals_[k].release(); }
-    for (int k = 0; k < 2; ++k) { sort_keys_[k].release(); sort_vals_[k].release(); }
-    hbm_body_list_.release(); grp_owner_.release(); grp_mine_.release(); grp_desc_.release(); grp_ncol_.release(); grp_units_.release(); unit_recs_.release(); grp_bodies_.release(); isl_stats_.release(); slot_local_.release(); slot_colour_.release(); isl_visits_.release();
-    xch_off_.release(); xch_err_.release(); isl_trace_.release();
-    part_begin_.release(); part_ranges_.release(); hbm_class_tab_.release(); for (int k = 0; k < 2; ++k) { part_keys_[k].release(); part_vals_[k].release(); }
+    // (every device buffer is a DevBuf member: freed with the object, after this body — the device is selected above)
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (side_stream_) { (void)hipStreamSynchronize(side_stream_); (void)hipStreamDestroy(side_stream_); }
-    hash_.release(); st_bodies_.release(); st_cps_.release(); st_joints_.release(); snap_vel_.release(); snap_dvel_.release(); snap_mpos_.release(); snap_joints_.release(); stage_vel_.release(); stage_dvel_.release(); stage_mpos_.release(); stage_joints_.release();
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
     if (ev_sweep_begin_) (void)hipEventDestroy(ev_sweep_begin_);

@@ -113,10 +113,7 @@ World::~World()
 {
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) (void)hipStreamSynchronize(stream_);
-    d_bodies_.release(); d_manifolds_.release(); d_cps_.release(); d_joints_.release();
-    vel_.release(); dvel_.release(); mpos_.release(); frame_.release(); aabb_.release(); size_.release();
-    xch_send_.release(); xch_recv_.release();
-    flags_.release(); pack_flags_.release(); dead_flags_.release(); joint_seen_.release(); scan_tiles_.release(); counters_.release(); mover_pos_.release(); erased_.release();
+    // (device buffers are DevBuf members: freed with the object)
     // (stream_ belongs to the broadphase handle, which is destroyed after this body and after the solver handle)
 }
 
