@@ -55,6 +55,13 @@ __host__ __device__ inline unsigned long long colour_priority(unsigned id, unsig
 // or one kernel launch (HBM group) of every sweep, so the largest class count sets the solve time.
 constexpr int COLOUR_B_MAX_JOINTS = 1024;
 
+// BINNING.  Groups run in parallel workgroups and share nothing, so WHICH components share a group changes no result — only how
+// well the workgroups are filled.  Consecutive components (body order) are packed greedily into a bin until the next one would
+// overflow the workgroup shape's joints or units, and a bin never spans a multiple of BIN_CHUNK component numbers: that cuts the
+// chain 'a bin ends where the next component would overflow it' into independent pieces, which is what lets the device make the
+// bins in a few microseconds (schedule_kernels.h k_bin_components) at the price of one partly filled bin per 64 components.
+constexpr int BIN_CHUNK = 64;
+
 // PARTITIONED COMPONENTS.  A component of more than COLOUR_B_MAX_JOINTS joints (a settled pile: one island of 1e5-1e6 joints)
 // is swept class by class out of HBM, one launch per class and sweep — a solve is classes x sweeps dependent launches.  Most of
 // such an island is local: cut the bodies into PARTS of PART_BODIES consecutive indices, twice — level 0 at multiples of

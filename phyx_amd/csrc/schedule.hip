@@ -554,6 +554,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
         int begin = -1, size = 0, units = 0;
         auto flush = [&](int end) { if (begin >= 0 && size > 0) bins.emplace_back(begin, end); begin = -1; size = 0; units = 0; };
         for (int c = 0; c < ncomp; ++c) {
+            if (c % BIN_CHUNK == 0) flush(c);              // (schedule.h BINNING: a bin never spans a chunk boundary)
             const int n = comp_count[c + 1] - comp_count[c];
             if (n == 0) continue;
             if (!fits(c, caps)) {

@@ -159,18 +159,21 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
 }
 
 // ---- binning on the device -------------------------------------------------------------------------------------------
-// The greedy binning of consecutive components (schedule.hip::build_island_schedule; the host runs it over the component
-// sizes it has just read back) restated for ONE workgroup, so that a rebuild needs no host round trip between the
-// connected components and the bins: the host launches everything behind it with last build's bin count as the grid, and
-// reads what came out when it settles the solve (solver.hip, "speculative binning").  Greedy packing is a chain — a bin ends
-// where the next component would overflow it — and a chain is followed in parallel by pointer doubling:
-//   next[a]   the component a bin opened at a would stop in front of: two binary searches over the prefix sums (joints, units)
-//   heads     the components reachable from component 0 along next[]: log2(n) doubling rounds in LDS
-//   tables    bin of a component = heads at or before it - 1; rank inside the bin = non-empty components since the head
+// The binning rule (schedule.h BIN_CHUNK; host: schedule.hip::build_island_schedule and DeviceSolver::build_device) restated for
+// ONE workgroup, so that a rebuild needs no host round trip between the connected components and the bins: the host launches
+// everything behind it with last build's bin count as the grid, and reads what came out when it settles the solve (solver.hip,
+// "speculative binning").  Consecutive components are packed greedily, and a bin never spans a multiple of BIN_CHUNK component
+// numbers: greedy packing is a chain (a bin ends where the next component would overflow it), and the chunk boundaries cut it
+// into independent pieces of 64 components — a wave packs a chunk, a lane per component, a scan over the chunks numbers the bins
+// and places their slots.  (Round 3 followed the unbroken chain by pointer doubling over windows of 8192 components:
+// ~65 barrier-separated rounds per window, 16 us for the 1000 columns of cfg 2 and 67 us for the 10000 of cfg 4; the chunked
+// rule costs one partly filled bin per 64 components and takes a few microseconds.)
 // GatherIslands' published numbers (ref: Solver.cpp:400, 414, 449) are statistics: the host computes them from the component
 // sizes when it settles the solve.  Whatever the host would have decided differently poisons the solve's fingerprint word
 // (`fail` bits below), which makes every kernel of the solve commit nothing; the host then rebuilds the slow way.
-constexpr int BINC_WINDOW = 8192, BINC_MAX = 65536, BINC_T = 1024;      // components per window of the chain / at most (tables, indices)
+constexpr int BINC_MAX = 65536, BINC_T = BINC_MAX / BIN_CHUNK;      // components at most (tables, indices); lanes = chunks
+static_assert(BINC_T == 1024 && BIN_CHUNK == 64, "one lane per chunk of 64 components, one workgroup");
+constexpr int BINC_JOINT_BITS = 30;      // speculative binning is for solves of < 2^30 joints (the lanes' scan packs bins << 32 | slots)
 constexpr int BINC_FAIL_CC = 1, BINC_FAIL_COUNT = 2, BINC_FAIL_FIT = 4, BINC_FAIL_SHAPE = 8, BINC_FAIL_REST = 16, BINC_FAIL_GRID = 32;
 constexpr unsigned long long BINC_POISON = 0x9E3779B97F4A7C15ull;
 
@@ -190,147 +193,112 @@ struct BinCompView {
     unsigned long long gate;          //    it does know) — or by a spoiled `gate` if the build cannot be used
 };
 
-// marks the components reachable from component 0 along `jump` (LDS, doubled between the two buffers)
-__device__ __forceinline__ void binc_mark_chain(unsigned short* jump_a, unsigned short* jump_b, unsigned char* reach, int n, bool any)
-{
-    for (int c = threadIdx.x; c < n; c += BINC_T) reach[c] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0 && any) reach[0] = 1;
-    __syncthreads();
-    unsigned short* cur = jump_a; unsigned short* nxt = jump_b;
-    for (int span = 1; span < n; span <<= 1) {
-        for (int c = threadIdx.x; c < n; c += BINC_T) {
-            const int j = cur[c];
-            if (reach[c] && j < n) reach[j] = 1;           // (a lane that sees this mark a round early marks a component of the chain all the same)
-            nxt[c] = (unsigned short)(j < n ? cur[j] : n);
-        }
-        __syncthreads();
-        unsigned short* t = cur; cur = nxt; nxt = t;
-    }
-}
-
-// inclusive prefix sums of value(c), c < n, handed to out(c, sum), 1024 components per pass; returns the total.  64-bit words:
-// the caller packs several counters into one (their sums must not carry into each other)
-template <typename Value, typename Out>
-__device__ __forceinline__ unsigned long long binc_scan(int n, unsigned long long* scratch, Value value, Out out)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long carry = 0;
-    for (int base = 0; base < n; base += BINC_T) {             // (workgroup-uniform trip count)
-        const int c = base + (int)threadIdx.x;
-        const unsigned long long x = c < n ? value(c) : 0ull;
-        unsigned long long incl = x;
-        for (int off = 1; off < 64; off <<= 1) { const unsigned long long y = __shfl_up(incl, off); if (lane >= off) incl += y; }
-        if (lane == 63) scratch[wave] = incl;
-        __syncthreads();
-        if (wave == 0) {
-            unsigned long long t = lane < 16 ? scratch[lane] : 0ull;
-            for (int off = 1; off < 16; off <<= 1) { const unsigned long long y = __shfl_up(t, off); if (lane >= off) t += y; }
-            if (lane < 16) scratch[lane] = t;
-        }
-        __syncthreads();
-        if (c < n) out(c, carry + (wave ? scratch[wave - 1] : 0ull) + incl);
-        const unsigned long long total = scratch[15];
-        __syncthreads();                                       // (scratch is reused by the next pass)
-        carry += total;
-    }
-    return carry;
-}
-
-// one word per component: joints (bits 0-24), units (25-49), 'is not empty' (50-63) — speculative binning is for solves of < 2^25 joints
-constexpr int BINC_JOINT_BITS = 25;
-__device__ __forceinline__ unsigned long long binc_pack(unsigned joints, unsigned units)
-{
-    return (unsigned long long)joints | ((unsigned long long)units << BINC_JOINT_BITS) | ((unsigned long long)(joints ? 1u : 0u) << (2 * BINC_JOINT_BITS));
-}
+// (a wave's own LDS operations are ordered; the compiler only has to be told that other lanes' stores count)
+#define PHX_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
 {
-    // The chain of bins is built in WINDOWS of BINC_WINDOW components (what the tables below hold): a window starts at a bin's head,
-    // every bin that ends inside it is final, and the next window starts at the head of the bin the window's end cuts — two windows
-    // for the 1e4 columns of the 1M-box world, one for anything up to 8192 components.
-    __shared__ unsigned ps[BINC_WINDOW], pu[BINC_WINDOW];      // inclusive prefix sums: joints, units
-    __shared__ unsigned short pn[BINC_WINDOW];                 // inclusive count of non-empty components
-    __shared__ unsigned short jump_a[BINC_WINDOW], jump_b[BINC_WINDOW];
-    __shared__ unsigned short head_pos[BINC_WINDOW];           // bin -> its first component
-    __shared__ unsigned short bin_at[BINC_WINDOW];             // component -> heads at or before it
-    __shared__ unsigned char reach[BINC_WINDOW];
-    __shared__ unsigned long long scratch[16];
+    // a WAVE packs a chunk, a lane per component: prefix sums of joints and units by shuffles, then the chain of bin heads — the next
+    // head is the first lane whose prefix, counted from the current head, overflows the shape (a ballot), one step per bin — which
+    // leaves the chunk's heads as a 64-bit mask; everything else (a component's bin, its rank in it, the bin's first slot) is
+    // bit counting on that mask.  The masks wait in LDS for the scan over the chunks.
+    __shared__ unsigned long long head_mask[BINC_T];
+    __shared__ unsigned chunk_bins[BINC_T], chunk_slots[BINC_T];      // per chunk, then exclusive over the chunks
+    __shared__ unsigned long long wave_sum[BINC_T / 64];
+    __shared__ unsigned pre_s[BINC_T / 64][64], pre_u[BINC_T / 64][64];      // a wave's chunk: inclusive prefixes of joints / units
+    __shared__ unsigned char jump[BINC_T / 64][64], reach[BINC_T / 64][64];
     __shared__ int s_fail, s_needs_big;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_all = v.cc_small[1];
     const int n_total = n_all < BINC_MAX ? n_all : BINC_MAX;
+    const int nchunks = (n_total + BIN_CHUNK - 1) / BIN_CHUNK;
     if (tid == 0) { s_fail = (v.cc_small[0] ? BINC_FAIL_CC : 0) | (n_all > BINC_MAX ? BINC_FAIL_COUNT : 0); s_needs_big = 0; }
+    chunk_bins[tid] = 0u; chunk_slots[tid] = 0u; head_mask[tid] = 0ull;
     __syncthreads();
-    constexpr unsigned long long M = (1ull << BINC_JOINT_BITS) - 1ull;
     const unsigned cap_s = 2u * (unsigned)v.cap_units, cap_u = (unsigned)v.cap_units;
-    int w0 = 0, bins_before = 0, slots_before = 0;             // (workgroup-uniform)
-    do {
-        const int n = min(BINC_WINDOW, n_total - w0);
-        bool misfit = false, wants_big = false;
-        for (int c = tid; c < n; c += BINC_T) {
-            const unsigned sz = v.comp_size[w0 + c], un = v.comp_units[w0 + c];
-            ps[c] = sz; pu[c] = un;
-            if (sz) {
-                if (sz > 2u * (unsigned)v.cap_units || un > (unsigned)v.cap_units) misfit = true;
-                if (sz > 2u * (unsigned)v.small_units || un > (unsigned)v.small_units) wants_big = true;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    bool misfit = false, wants_big = false;
+    for (int ch = wave; ch < nchunks; ch += BINC_T / 64) {      // (wave-uniform)
+        const int c = ch * BIN_CHUNK + lane;
+        const unsigned n = c < n_total ? v.comp_size[c] : 0u, u = n ? v.comp_units[c] : 0u;
+        if (n && (n > cap_s || u > cap_u)) misfit = true;
+        if (n && (n > 2u * (unsigned)v.small_units || u > (unsigned)v.small_units)) wants_big = true;
+        unsigned ps = n, pu = u;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned a = __shfl_up(ps, off), b = __shfl_up(pu, off); if (lane >= off) { ps += a; pu += b; } }
+        const unsigned long long nonempty = __ballot(n != 0u);
+        // Where a bin opened at lane l ends — the first lane whose prefix, counted from l, overflows the shape — is a binary search per
+        // lane over the chunk's 64 prefixes (the conditions are monotone), and the heads are the lanes reachable from the first
+        // non-empty one along those links: six doubling rounds.  ~2000 cycles a chunk however many bins it holds (walking the chain
+        // head by head, one ballot and two broadcasts a step, was 300 cycles per BIN: 19 us for the 1000 one-column bins of cfg 2).
+        unsigned* wps = &pre_s[wave][0]; unsigned* wpu = &pre_u[wave][0]; unsigned char* wj = &jump[wave][0]; unsigned char* wr = &reach[wave][0];
+        wps[lane] = ps; wpu[lane] = pu;
+        PHX_WAVE_FENCE();
+        const unsigned lim_s = ps - n + cap_s, lim_u = pu - u + cap_u;      // a bin opened here holds lanes whose prefix stays <= these
+        int lo = 0;                                                          // first lane with ps > lim_s or pu > lim_u (64: none)
+        for (int step = 32; step > 0; step >>= 1) { const int probe = lo + step - 1; if (wps[probe] <= lim_s && wpu[probe] <= lim_u) lo += step; }
+        if (lo == 63 && wps[63] <= lim_s && wpu[63] <= lim_u) lo = 64;
+        int nxt = lo > lane ? lo : lane + 1;                                 // (a misfit overflows alone: keep the chain moving)
+        wj[lane] = (unsigned char)nxt; wr[lane] = 0;
+        PHX_WAVE_FENCE();
+        if (nonempty && lane == __builtin_ctzll(nonempty)) wr[lane] = 1;
+        PHX_WAVE_FENCE();
+        for (int round = 0; round < 6; ++round) {
+            const int j = wj[lane];
+            const bool mark = wr[lane] && j < 64;
+            const int jj = j < 64 ? wj[j] : 64;
+            PHX_WAVE_FENCE();
+            if (mark) wr[j] = 1;
+            wj[lane] = (unsigned char)jj;
+            PHX_WAVE_FENCE();
+        }
+        const unsigned long long heads = __ballot(wr[lane] != 0);
+        PHX_WAVE_FENCE();
+        if (lane == 0) { head_mask[ch] = heads; chunk_bins[ch] = (unsigned)__popcll(heads); }
+        if (lane == 63) chunk_slots[ch] = ps;
+    }
+    if (misfit) atomicOr(&s_fail, BINC_FAIL_FIT);
+    if (wants_big) s_needs_big = 1;
+    __syncthreads();
+    // exclusive scan over the chunks (one per lane of the workgroup): bins << 32 | slots
+    const unsigned long long mine = ((unsigned long long)chunk_bins[tid] << 32) | chunk_slots[tid];
+    unsigned long long incl = mine;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned long long y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    unsigned long long before = incl - mine, total = 0;
+    for (int w = 0; w < BINC_T / 64; ++w) { const unsigned long long t = wave_sum[w]; if (w < wave) before += t; total += t; }
+    chunk_bins[tid] = (unsigned)(before >> 32); chunk_slots[tid] = (unsigned)before;
+    __syncthreads();
+    for (int ch = wave; ch < nchunks; ch += BINC_T / 64) {
+        const int c = ch * BIN_CHUNK + lane;
+        const unsigned n = c < n_total ? v.comp_size[c] : 0u;
+        unsigned ps = n;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned a = __shfl_up(ps, off); if (lane >= off) ps += a; }
+        const unsigned long long nonempty = __ballot(n != 0u), heads = head_mask[ch];
+        const unsigned long long upto = below | (1ull << lane);
+        const int local_bin = __popcll(heads & upto) - 1;          // (-1: an empty component in front of the chunk's first head)
+        if (c < n_total) {
+            const int bin = (int)chunk_bins[ch] + (local_bin < 0 ? 0 : local_bin);
+            int rank = 0;
+            if (n && local_bin >= 0) {
+                const int h = 63 - __builtin_clzll(heads & upto);     // my bin's head
+                rank = __popcll(nonempty & upto & ~((1ull << h) - 1ull)) - 1;
             }
+            v.bin_of[c] = bin; v.rank_of[c] = rank;
+            if ((heads >> lane) & 1ull) { if (bin <= v.max_bins) v.goff[bin] = (int)(chunk_slots[ch] + ps - n); }
         }
-        if (misfit) atomicOr(&s_fail, BINC_FAIL_FIT);
-        if (wants_big) s_needs_big = 1;
-        // (each lane scans the components it has just written: no barrier needed in between)
-        const unsigned long long sums = binc_scan(n, scratch, [&](int c) { return binc_pack(ps[c], pu[c]); },
-                                                  [&](int c, unsigned long long x) { ps[c] = (unsigned)(x & M); pu[c] = (unsigned)((x >> BINC_JOINT_BITS) & M); pn[c] = (unsigned short)(x >> (2 * BINC_JOINT_BITS)); });
-        const int window_joints = (int)(sums & M);
-        auto upper = [&](const unsigned* pre, int a, unsigned limit) {          // first e >= a with pre[e] - before(a) > limit, or n
-            const unsigned before = a ? pre[a - 1] : 0u;
-            int lo = a, hi = n;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pre[mid] - before > limit) hi = mid; else lo = mid + 1; }
-            return lo;
-        };
-        auto nonempty = [&](int c) { return (c ? pn[c - 1] : 0) != pn[c]; };
-        for (int a = tid; a < n; a += BINC_T) {
-            const int e1 = upper(ps, a, cap_s), e2 = upper(pu, a, cap_u);
-            int e = e1 < e2 ? e1 : e2;
-            if (e <= a) e = a + 1;                             // (a misfit: the build is spoiled anyway; keep the chain moving)
-            jump_a[a] = (unsigned short)e;
-        }
-        __syncthreads();
-        binc_mark_chain(jump_a, jump_b, reach, n, window_joints > 0);
-        const int heads = (int)binc_scan(n, scratch, [&](int c) { return reach[c] ? 1ull : 0ull; }, [&](int c, unsigned long long x) { bin_at[c] = (unsigned short)x; });
-        for (int c = tid; c < n; c += BINC_T) if (reach[c]) head_pos[bin_at[c] - 1] = (unsigned short)c;
-        __syncthreads();
-        // what this window settles: everything if it reaches the last component, otherwise the bins in front of its last head
-        const bool last_window = w0 + n >= n_total;
-        const int consumed = last_window ? n : (heads > 0 ? (int)head_pos[heads - 1] : n);
-        const int bins_here = last_window ? heads : (heads > 0 ? heads - 1 : 0);
-        if (!last_window && consumed == 0) {                   // one bin wider than a window (thousands of empty components): not this path
-            if (tid == 0) s_fail |= BINC_FAIL_COUNT;
-            __syncthreads();
-            break;
-        }
-        for (int c = tid; c < consumed; c += BINC_T) {
-            const int b = (int)bin_at[c] - 1;                  // (no joints in the window: no head, every component is empty)
-            if (b < 0) { v.bin_of[w0 + c] = bins_before; v.rank_of[w0 + c] = 0; continue; }
-            const int h = head_pos[b];
-            const int before_h = h ? pn[h - 1] : 0, before_c = (int)pn[c] - (nonempty(c) ? 1 : 0);
-            v.bin_of[w0 + c] = bins_before + b; v.rank_of[w0 + c] = before_c - before_h;
-            if (reach[c] && bins_before + b <= v.max_bins) v.goff[bins_before + b] = slots_before + (int)(c ? ps[c - 1] : 0u);
-        }
-        const int slots_here = consumed ? (int)ps[consumed - 1] : 0;
-        __syncthreads();                                       // (the tables are rewritten by the next window)
-        w0 += consumed; bins_before += bins_here; slots_before += slots_here;
-    } while (w0 < n_total);
+    }
+    __syncthreads();
     if (tid == 0) {
         // the host takes the roomier shape iff some component needs it; joints outside every component (both bodies static) and
         // components that fit no shape go to the HBM group, which this path does not build
+        const int nbins = (int)(total >> 32), slots_all = (int)(unsigned)total;
         if ((s_needs_big != 0) != (v.cap_units > v.small_units)) s_fail |= BINC_FAIL_SHAPE;
-        if (slots_before != v.nj) s_fail |= BINC_FAIL_REST;
-        const int nbins = bins_before;
-        if (nbins <= v.max_bins) v.goff[nbins] = slots_before;
+        if (slots_all != v.nj) s_fail |= BINC_FAIL_REST;
+        if (nbins <= v.max_bins) v.goff[nbins] = slots_all;
         if (nbins > v.max_bins) s_fail |= BINC_FAIL_GRID;
         v.result[0] = s_fail ? 0 : nbins;                      // (a spoiled build's tables may be incomplete: nobody runs on them)
-        v.result[1] = slots_before; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
+        v.result[1] = slots_all; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
         *v.hash_out = *v.fingerprint;
         *v.fingerprint = s_fail ? v.gate + BINC_POISON : v.gate;
     }

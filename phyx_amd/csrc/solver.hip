@@ -496,6 +496,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         int size = 0, units = 0, rank = 0;
         bool open = false;
         for (int c = 0; c < ncomp; ++c) {
+            if (c % BIN_CHUNK == 0) { open = false; size = 0; units = 0; }      // (schedule.h BINNING: a bin never spans a chunk boundary)
             const int n = (int)comp_size[c], u = (int)comp_units[c];
             if (n == 0) continue;
             if (!want_islands || !fits(c, cap_units)) { open = false; size = 0; units = 0; continue; }     // -> HBM group (Single mode: every component)

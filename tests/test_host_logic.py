@@ -284,12 +284,18 @@ def test_exchange_layout_partitions_the_groups_over_the_ranks():
         phyx_amd.exchange_layout([1], [1], 0)
 
 
+BIN_CHUNK = 64          # csrc/schedule.h: a bin never spans a multiple of BIN_CHUNK component numbers
+
+
 def _greedy_bins(sizes, units, cap_units):
-    """The host loop of the schedule builder (csrc/solver.hip, step 3): consecutive components packed greedily."""
+    """The host loop of the schedule builder (csrc/solver.hip, step 3; csrc/schedule.hip): consecutive components packed greedily,
+    every chunk of BIN_CHUNK component numbers starting a fresh bin."""
     bin_of, rank_of, goff = [-1] * len(sizes), [0] * len(sizes), [0]
     size = unit = rank = 0
     opened = False
     for c, (n, u) in enumerate(zip(sizes, units)):
+        if c % BIN_CHUNK == 0:
+            opened = False
         if n == 0:
             continue
         if not opened or size + n > 2 * cap_units or unit + u > cap_units:
@@ -299,45 +305,44 @@ def _greedy_bins(sizes, units, cap_units):
     return bin_of, rank_of, goff
 
 
-def _chain_bins(sizes, units, cap_units):
-    """k_bin_components' formulation (csrc/schedule_kernels.h): greedy packing is a chain — every component finds where a bin
-    opened at it would end (binary searches over the prefix sums), the components reachable from component 0 along those links
-    are marked by pointer doubling, and a scan of the marks numbers the bins."""
+def _chunk_bins(sizes, units, cap_units):
+    """k_bin_components' formulation (csrc/schedule_kernels.h): a lane packs its chunk of BIN_CHUNK components on its own (pass 1:
+    how many bins, how many slots), an exclusive scan over the lanes numbers the bins and places their slots, pass 2 writes."""
     n = len(sizes)
-    ps, pu, pn = np.cumsum(sizes), np.cumsum(units), np.cumsum(np.asarray(sizes) > 0)
-    before = lambda pre, a: int(pre[a - 1]) if a else 0
-    nxt = np.empty(n, dtype=np.int64)
-    for a in range(n):
-        e1 = int(np.searchsorted(ps, before(ps, a) + 2 * cap_units, side="right"))      # first e with ps[e] - before > limit
-        e2 = int(np.searchsorted(pu, before(pu, a) + cap_units, side="right"))
-        nxt[a] = max(min(e1, e2), a + 1)
-    reach = np.zeros(n, dtype=bool)
-    if n and ps[-1] > 0:
-        reach[0] = True
-    jump, span = nxt.copy(), 1
-    while span < n:
-        src = np.nonzero(reach & (jump < n))[0]
-        reach[jump[src]] = True
-        jump = np.where(jump < n, jump[np.minimum(jump, n - 1)], n)
-        span *= 2
-    bin_at = np.cumsum(reach) - 1
-    heads = np.nonzero(reach)[0]
-    bin_of, rank_of = [-1] * n, [0] * n
-    for c in range(n):
-        if sizes[c] == 0:
-            continue
-        h = int(heads[bin_at[c]])
-        bin_of[c] = int(bin_at[c]); rank_of[c] = int(pn[c] - 1 - (pn[h - 1] if h else 0))
-    goff = [before(ps, int(h)) for h in heads] + [int(ps[-1]) if n else 0]
-    return bin_of, rank_of, goff
+    chunks = [(c0, min(n, c0 + BIN_CHUNK)) for c0 in range(0, n, BIN_CHUNK)]
+
+    def walk(c0, c1, first_bin, first_slot, out):
+        size = unit = rank = 0
+        opened, b, at, bins = False, first_bin - 1, first_slot, 0
+        for c in range(c0, c1):
+            if sizes[c] == 0:
+                continue
+            if not opened or size + sizes[c] > 2 * cap_units or unit + units[c] > cap_units:
+                b += 1; bins += 1; opened = True; size = unit = rank = 0
+                if out is not None:
+                    out[2][b] = at
+            if out is not None:
+                out[0][c] = b; out[1][c] = rank
+            rank += 1; size += sizes[c]; unit += units[c]; at += sizes[c]
+        return bins, at - first_slot
+    counts = [walk(c0, c1, 0, 0, None) for c0, c1 in chunks]
+    nbins, nslots = sum(b for b, _ in counts), sum(s for _, s in counts)
+    out = ([-1] * n, [0] * n, [0] * (nbins + 1))
+    b = s = 0
+    for (c0, c1), (cb, cs) in zip(chunks, counts):
+        walk(c0, c1, b, s, out)
+        b += cb; s += cs
+    out[2][nbins] = nslots
+    return out
 
 
-def test_binning_as_a_chain_equals_the_greedy_loop():
-    """The device's binning (pointer doubling over 'where would a bin opened here end') against the sequential greedy loop it
-    replaces, on random component sizes incl. empty components, components that fill a bin alone and long runs of tiny ones."""
+def test_binning_by_chunks_equals_the_greedy_loop():
+    """The device's binning (a lane per chunk of 64 components, a scan over the lanes) against the sequential loop of the host
+    builders, on random component sizes incl. empty components, components that fill a bin alone and long runs of tiny ones;
+    and what the chunk rule costs in bins against unbroken greedy packing."""
     rng = np.random.default_rng(7)
     for case in range(300):
-        n = int(rng.integers(1, 400))
+        n = int(rng.integers(1, 700))
         cap = int(rng.choice([256, 512]))
         kind = case % 4
         if kind == 0:
@@ -352,5 +357,8 @@ def test_binning_as_a_chain_equals_the_greedy_loop():
         units = np.where(sizes > 0, np.maximum(units, (sizes + 1) // 2), 0)
         units = np.minimum(units, np.minimum(sizes, cap))
         g = _greedy_bins(list(map(int, sizes)), list(map(int, units)), cap)
-        c = _chain_bins(list(map(int, sizes)), list(map(int, units)), cap)
-        assert g == c, (case, n, cap)
+        c = _chunk_bins(list(map(int, sizes)), list(map(int, units)), cap)
+        assert g[0] == c[0] and g[1] == c[1] and g[2] == c[2], (case, n, cap)
+    # the price of the chunk boundaries: the 1e4 columns of the 1M-box world (206-joint components, two to a bin)
+    sizes, units = [206] * 10000, [103] * 10000
+    assert len(_greedy_bins(sizes, units, 256)[2]) - 1 == 5000
