@@ -178,8 +178,9 @@ struct SweepView {
     unsigned long long* counters;   // statistics, spread over STAT_SLOTS slots to keep the atomics apart: [2 * slot] candidate tests, [2 * slot + 1] overlapping pairs
 };
 
-constexpr int SWEEP_CAND = 8;        // y-overlapping candidates a row collects before it looks them up in the pair set
-constexpr int SWEEP_GROUP = 8;       // candidates a row fetches per step of its scan
+constexpr int SWEEP_CAND = 16;       // y-overlapping candidates a row can hold before it must look them up in the pair set
+constexpr int SWEEP_LOOK = 8;        // lookups a row keeps in flight
+constexpr int SWEEP_GROUP = 8;       // candidates the wave reads from its staged block per step of its walk
 
 // first position j > i with minx[j] > maxx (entries sorted by minx)
 __device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int n, int i, float maxx)
@@ -192,9 +193,14 @@ __device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int 
     return lo;
 }
 
-// One sorted row per lane: lane l of a wave owns row i0+l and reads entries[i0+l+1+t] in step t, so a wave's loads are
-// contiguous and L1/L2-resident.  Candidates are fetched four at a time so that four loads are in flight per lane (the
-// loop is latency-bound, not bandwidth-bound: staging the window through LDS was measured and bought nothing).
+// One sorted row per lane, and the wave walks the CANDIDATES together: lane l owns row i0 + l, the wave steps through positions
+// c = i0 + 1, i0 + 2, ... and every lane whose row has begun (c > its row) and not ended (minx[c] <= its maxx) tests the SAME
+// candidate — whose record is therefore one scalar load for the wave (eight per fetch) instead of a 16-byte gather per lane.
+// (Round 3 let every lane fetch its own window, eight loads in flight per lane: 20 M tests were 320 MB through the L1s and a
+// row's scan a chain of dependent gathers — 44 us at cfg 2, 95 us at cfg 4.)  A lane sees its candidates in the same increasing
+// order as before, so counts, caches and the emission order are unchanged.
+#define PHX_SWEEP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total)
 {
@@ -202,88 +208,117 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
     // EMIT = true : rescans ONLY the rows that found more than ROW_CACHE new pairs; all other rows are emitted from the
     //               cache by k_emit_cached without touching the entries or the pair set again.
     __shared__ unsigned cand[SWEEP_CAND][256];          // per lane: positions of the candidates that overlap in y, not looked up yet
+    __shared__ float4 stage[4][2][64];                  // per wave: the block of 64 candidates under test, and the next one
     unsigned long long tests = 0, overlaps = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
-        const float4 a = v.entries[i];
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < v.n; base += gridDim.x * blockDim.x) {      // (wave-uniform)
+        const int i = base + lane;
+        const bool in_range = i < v.n;
+        const float4 a = in_range ? v.entries[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // a hub row (more than HUB_LEN candidates) is recognised by one probe: entries are sorted by minx, so the row is a
         // hub iff the candidate HUB_LEN places ahead still starts at or before this row's maxx.  Only hub rows pay the
         // binary search for their end; every other row finds it by scanning (ref: Collider.cpp:300-303 breaks the same way).
-        const bool hub = i + 1 + HUB_LEN < v.n && !(v.entries[i + 1 + HUB_LEN].x > a.y);
-        if (hub) {
-            if (!EMIT) {
-                // hand the row to the chunk kernels: its chunks sit contiguously and in j order in the list
-                const int end = scan_end(v.entries, v.n, i, a.y);
-                const int len = end - i - 1;
-                const int nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
-                const int first = atomicAdd(v.n_chunks, nc);
-                for (int k = 0; k < nc && first + k < v.chunk_cap; ++k)
-                    v.chunks[first + k] = make_int4(i, i + 1 + k * HUB_CHUNK, min(end, i + 1 + (k + 1) * HUB_CHUNK), first);
-                v.row_count[i] = 0;
-                tests += (unsigned long long)len;
-            }
-            continue;
+        const bool hub = in_range && i + 1 + HUB_LEN < v.n && !(v.entries[i + 1 + HUB_LEN].x > a.y);
+        if (hub && !EMIT) {
+            // hand the row to the chunk kernels: its chunks sit contiguously and in j order in the list
+            const int end = scan_end(v.entries, v.n, i, a.y);
+            const int len = end - i - 1;
+            const int nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
+            const int first = atomicAdd(v.n_chunks, nc);
+            for (int k = 0; k < nc && first + k < v.chunk_cap; ++k)
+                v.chunks[first + k] = make_int4(i, i + 1 + k * HUB_CHUNK, min(end, i + 1 + (k + 1) * HUB_CHUNK), first);
+            v.row_count[i] = 0;
+            tests += (unsigned long long)len;
         }
-        const unsigned dst = EMIT ? row_offset[i] : 0u;
-        if (EMIT) {
+        bool scanning = in_range && !hub;
+        const unsigned dst = EMIT && scanning ? row_offset[i] : 0u;
+        if (EMIT && scanning) {
             const unsigned next = i + 1 < v.n ? row_offset[i + 1] : total;
-            if (next - dst <= (unsigned)ROW_CACHE) continue;             // emitted from the cache
+            if (next - dst <= (unsigned)ROW_CACHE) scanning = false;      // emitted from the cache
         }
-        const unsigned ia = v.idx[i];
+        const unsigned ia = scanning ? v.idx[i] : 0u;
         unsigned found = 0;
         // The candidates that overlap in y are only COLLECTED by the scan (their positions, in j order, in LDS); the pair-set
         // lookups — two dependent memory round trips each — are made afterwards, all in flight together.  Done inside the scan
         // they were its whole cost: some lane of the wave hits an overlap in almost every step, and the wave waits for it.
         int ncand = 0;
         auto flush = [&]() {
-            unsigned ib[SWEEP_CAND];
-            unsigned long long first[SWEEP_CAND];
+            for (int h = 0; h < ncand; h += SWEEP_LOOK) {          // SWEEP_LOOK lookups in flight at a time
+                unsigned ib[SWEEP_LOOK];
+                unsigned long long first[SWEEP_LOOK];
 #pragma unroll
-            for (int k = 0; k < SWEEP_CAND; ++k) ib[k] = k < ncand ? v.idx[cand[k][threadIdx.x]] : 0u;
+                for (int k = 0; k < SWEEP_LOOK; ++k) ib[k] = h + k < ncand ? v.idx[cand[h + k][threadIdx.x]] : 0u;
 #pragma unroll
-            for (int k = 0; k < SWEEP_CAND; ++k) first[k] = k < ncand ? v.table[ps_hash(((unsigned long long)ia << 32) | ib[k]) & v.mask] : 0ull;
+                for (int k = 0; k < SWEEP_LOOK; ++k) first[k] = h + k < ncand ? v.table[ps_hash(((unsigned long long)ia << 32) | ib[k]) & v.mask] : 0ull;
 #pragma unroll
-            for (int k = 0; k < SWEEP_CAND; ++k) {
-                if (k >= ncand) break;
-                const unsigned long long key = ((unsigned long long)ia << 32) | ib[k];
-                bool present = first[k] == key;
-                if (!present && first[k] != PS_EMPTY) present = ps_contains(v.table, v.mask, key);       // a collision at the home slot: walk on
-                if (!present) {
-                    if (EMIT) out[dst + found] = make_uint2(ia, ib[k]);
-                    else if (found < (unsigned)ROW_CACHE) v.row_cache[(size_t)i * ROW_CACHE + found] = ib[k];
-                    ++found;
+                for (int k = 0; k < SWEEP_LOOK; ++k) {
+                    if (h + k >= ncand) break;
+                    const unsigned long long key = ((unsigned long long)ia << 32) | ib[k];
+                    bool present = first[k] == key;
+                    if (!present && first[k] != PS_EMPTY) present = ps_contains(v.table, v.mask, key);       // a collision at the home slot: walk on
+                    if (!present) {
+                        if (EMIT) out[dst + found] = make_uint2(ia, ib[k]);
+                        else if (found < (unsigned)ROW_CACHE) v.row_cache[(size_t)i * ROW_CACHE + found] = ib[k];
+                        ++found;
+                    }
                 }
             }
             ncand = 0;
         };
-        auto test = [&](int j, const float4& b) {
-            if (fabsf(b.z - a.z) <= a.w + b.w) {
-                if (!EMIT) ++overlaps;
-                if (ncand == SWEEP_CAND) flush();
-                cand[ncand++][threadIdx.x] = (unsigned)j;
-            }
-        };
-        // candidates SWEEP_GROUP at a time (that many loads in flight), in j order, until the first one that starts beyond maxx
-        int j = i + 1;
-        for (bool more = true; more;) {
-            if (j + SWEEP_GROUP <= v.n) {
+        // the wave's walk, 64 candidates per fetch: lane l fetches record c + l (one coalesced load for the wave), the block waits in
+        // LDS, and the wave reads it record by record at a uniform address (a broadcast) — the NEXT block's fetch is already in
+        // flight while this one is tested, so the walk never waits for memory: a fetch per 8 candidates (scalar loads, or eight
+        // gathers per lane before that) was a ~1 us round trip each, 30 of them in a row per wave.
+        int len = 0;
+        bool ended = !scanning;
+        int ended_w = scanning ? 0 : -1;
+        const int c0 = __builtin_amdgcn_readfirstlane(base) + 1;
+        float4* my_stage = &stage[threadIdx.x >> 6][0][0];
+        float4 nxt = v.entries[min(c0 + lane, v.n - 1)];
+        int buf = 0;
+        for (int c = c0; c < v.n && __ballot(!ended); c += 64) {
+            my_stage[buf * 64 + lane] = nxt;
+            if (c + 64 < v.n) nxt = v.entries[min(c + 64 + lane, v.n - 1)];
+            PHX_SWEEP_WAVE_SYNC();
+            const float4* blockp = my_stage + buf * 64;
+            const int rel = i - c;                                   // candidate g of this block lies behind my row iff g > rel
+            for (int g = 0; g < 64 && c + g < v.n && __ballot(!ended); g += SWEEP_GROUP) {
+                // (the list holds SWEEP_CAND = 2 x SWEEP_GROUP positions and is emptied HERE, once per group, when the next eight might
+                //  not fit: emptied where it fills up — inside the unrolled tests — the lookups' code stood eight times in the hot loop)
+                if (ncand > SWEEP_CAND - SWEEP_GROUP) flush();
                 float4 b[SWEEP_GROUP];
 #pragma unroll
-                for (int k = 0; k < SWEEP_GROUP; ++k) b[k] = v.entries[j + k];
-                int k = 0;
+                for (int k = 0; k < SWEEP_GROUP; ++k) b[k] = blockp[g + k];
+                // The tests are PREDICATED, not branched: a CU's waves share one scalar unit, and a branch is three or four scalar
+                // instructions (compare-to-mask, s_and_saveexec, s_cbranch, the exec restore) — twelve waves walking 260 candidates
+                // with three nested branches each were bound by it (~20 us of the kernel's 45).  Lane state lives in VGPRs as
+                // all-ones / zero words; the only branch left is 'some lane of the wave overlaps this candidate in y'.
 #pragma unroll
-                for (; k < SWEEP_GROUP; ++k) {
-                    if (b[k].x > a.y) { more = false; break; }
-                    test(j + k, b[k]);
+                for (int k = 0; k < SWEEP_GROUP; ++k) {
+                    const int j = c + g + k;
+                    const int started = (rel - (g + k)) >> 31;                          // -1 iff this candidate lies behind my row (j > i)
+                    const int in_list = (j - v.n) >> 31;                                // -1 iff j < n
+                    const int beyond = b[k].x > a.y ? -1 : 0;                           // ref: Collider.cpp:300-303: the row ends here
+                    const int live = started & in_list & ~ended_w;
+                    ended_w |= live & beyond;
+                    const int tested = live & ~beyond;
+                    len -= tested;
+                    const int ov = (fabsf(b[k].z - a.z) <= a.w + b[k].w ? -1 : 0) & tested;
+                    if (__any(ov)) {
+                        if (ov) {
+                            if (!EMIT) ++overlaps;
+                            cand[ncand++][threadIdx.x] = (unsigned)j;
+                        }
+                    }
                 }
-                j += k;
-            } else {
-                for (; j < v.n; ++j) { const float4 b = v.entries[j]; if (b.x > a.y) break; test(j, b); }
-                more = false;
+                ended = ended_w != 0;
             }
+            buf ^= 1;
         }
-        flush();
-        const int len = j - i - 1;
-        if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; if (found > (unsigned)ROW_CACHE) *v.cache_overflow = 1; }
+        if (scanning) {
+            flush();
+            if (!EMIT) { v.row_count[i] = found; tests += (unsigned long long)len; if (found > (unsigned)ROW_CACHE) *v.cache_overflow = 1; }
+        }
     }
     if (!EMIT) {
         for (int off = 32; off > 0; off >>= 1) { tests += __shfl_down(tests, off); overlaps += __shfl_down(overlaps, off); }
@@ -296,7 +331,6 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
         }
     }
 }
-
 // emit pass for every row with at most ROW_CACHE new pairs: straight from what the count pass remembered
 __global__ void __launch_bounds__(256) k_emit_cached(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total)
 {
