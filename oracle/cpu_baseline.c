@@ -431,25 +431,25 @@ typedef struct pool pool;
 typedef void (*phase_fn)(pool*, int batch, int worker);
 struct pool {
     int threads;
-    _Atomic unsigned long long ticket;      /* phase number << 32 | next batch of that phase */
+    _Atomic unsigned long long ticket;      /* phase << 48 | batches of the phase << 24 | next batch: ONE fetch-and-add hands out a batch,
+                                               and what it returns says by itself whether that batch exists */
     atomic_int phase_word;                  /* the phase number again: what sleeping workers wait on (futex) */
     atomic_int done, sleepers, quit;
-    int batches;
-    phase_fn fn;
+    phase_fn fn[2];                         /* what phase e runs: fn[e & 1] (a worker holding a batch of phase e keeps the phase open) */
     ctx* c;
     int batch_size, iter;
     atomic_int productive;
     pthread_t* th;
 };
 
-/* batches of phase `phase`, until they run out or the pool has moved on */
-static void pool_pull(pool* p, unsigned phase, int worker)
+/* batches of whatever phase the ticket is in, until they run out (a worker that arrives late simply helps the phase it finds) */
+static void pool_pull(pool* p, int worker)
 {
     for (;;) {
-        unsigned long long t = atomic_load_explicit(&p->ticket, memory_order_acquire);
-        if ((unsigned)(t >> 32) != phase || (int)(unsigned)t >= p->batches) return;
-        if (!atomic_compare_exchange_weak_explicit(&p->ticket, &t, t + 1, memory_order_acq_rel, memory_order_acquire)) continue;
-        p->fn(p, (int)(unsigned)t, worker);
+        const unsigned long long t = atomic_fetch_add_explicit(&p->ticket, 1ull, memory_order_acq_rel);
+        const unsigned e = (unsigned)(t >> 48), n = (unsigned)(t >> 24) & 0xFFFFFFu, b = (unsigned)t & 0xFFFFFFu;
+        if (b >= n) return;
+        p->fn[e & 1](p, (int)b, worker);
         atomic_fetch_add_explicit(&p->done, 1, memory_order_release);
     }
 }
@@ -474,7 +474,7 @@ static void* pool_thread(void* a)
         }
         if (atomic_load_explicit(&p->quit, memory_order_acquire)) return NULL;
         seen = now;
-        pool_pull(p, seen, worker);
+        pool_pull(p, worker);
     }
 }
 
@@ -482,14 +482,14 @@ static void* pool_thread(void* a)
 static void pool_run(pool* p, int* phase_counter, phase_fn fn, int batches)
 {
     const unsigned phase = (unsigned)++*phase_counter;
-    p->fn = fn; p->batches = batches;
+    p->fn[phase & 1] = fn;
     atomic_store_explicit(&p->done, 0, memory_order_relaxed);
-    atomic_store_explicit(&p->ticket, (unsigned long long)phase << 32, memory_order_release);
+    atomic_store_explicit(&p->ticket, ((unsigned long long)(phase & 0xFFFFu) << 48) | ((unsigned long long)(unsigned)batches << 24), memory_order_release);
     if (p->threads > 1) {
         atomic_store_explicit(&p->phase_word, (int)phase, memory_order_release);
         if (atomic_load(&p->sleepers)) syscall(SYS_futex, &p->phase_word, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
     }
-    pool_pull(p, phase, 0);
+    pool_pull(p, 0);
     while (atomic_load_explicit(&p->done, memory_order_acquire) < batches) _mm_pause();
 }
 

@@ -15,7 +15,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last world step starts at the last k_build_keys launch
-idx = max(i for i, r in enumerate(rows) if "k_build_keys" in r["Kernel_Name"])
+idx = max(i for i, r in enumerate(rows) if "k_build_keys" in r["Kernel_Name"] or "k_keys_buckets" in r["Kernel_Name"])
 step = rows[idx:]
 t0 = int(step[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in step)
 agg = collections.OrderedDict()
