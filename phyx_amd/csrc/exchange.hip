@@ -124,7 +124,7 @@ int DeviceSolver::exchange_pack_resident(const BodyView* d_bodies, const void* d
         return PHX_ERR_CAPACITY;
     }
     // null arrays = header only: a rank that failed earlier in the step still posts its status word
-    const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0 && d_bodies && d_joints, grp_desc_.p, grp_bodies_.p, order_.p, xch_off_.p, hbm_body_list_.p, shard_,
+    const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0 && d_bodies && d_joints, isl_.desc.p, isl_.bodies.p, hbm_.order.p, xch_off_.p, hbm_.hbm_body_list.p, shard_,
                                          shard_count_, xch_seg_words_, grp_owner_.p, grp_mine_.p);
     ++xch_serial_;
     const int mine = x.lds_groups ? mine_count_ : 0;
@@ -146,7 +146,7 @@ int DeviceSolver::exchange_unpack_resident(const BodyView& d_bodies, void* d_joi
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(xch_send_ && xch_recv_, "exchange buffers not set (phx_solver_set_exchange_buffers)");
     if (xch_layout_version_ != schedule_version_ || xch_layout_shards_ != shard_count_) { set_error("exchange_unpack without a matching exchange_pack"); return PHX_ERR_STATE; }
-    const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0, grp_desc_.p, grp_bodies_.p, order_.p, xch_off_.p, hbm_body_list_.p, shard_, shard_count_, xch_seg_words_,
+    const ExchangeView x = exchange_view(sched_, sched_.valid && nj_ > 0, isl_.desc.p, isl_.bodies.p, hbm_.order.p, xch_off_.p, hbm_.hbm_body_list.p, shard_, shard_count_, xch_seg_words_,
                                          grp_owner_.p, grp_mine_.p);
     hipLaunchKernelGGL(k_exchange_unpack, dim3(std::max(x.lds_groups, 1)), dim3(256), 0, stream_, x, d_bodies,
                        static_cast<phx_contact_joint*>(d_joints), (const unsigned*)xch_recv_, xch_serial_, raw_fingerprint_, xch_err_.p);

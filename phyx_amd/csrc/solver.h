@@ -68,7 +68,7 @@ public:
     {
         PHX_TRY(synchronize());
         if (interior_classes) *interior_classes = sched_.hbm_interior_classes;
-        if (parts) *parts = parts_in_use() ? part_count_ : 0;
+        if (parts) *parts = parts_in_use() ? parts_.count : 0;
         if (sweep_launches) *sweep_launches = sweep_launches_;
         return PHX_OK;
     }
@@ -146,73 +146,100 @@ private:
     hipStream_t stream_ = nullptr;
     hipStream_t side_stream_ = nullptr;      // the LDS islands of a schedule that also has an HBM group (enqueue_sweeps)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-    bool no_side_stream_ = false;            // PHX_NO_SIDE_STREAM=1
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
 
+
+    // ---- what the handle owns, by path.  Every buffer is a DevBuf (freed with the handle); init() reads the environment once ----
+    // the PHX_* knobs (measurement and debugging; README.md lists them)
+    struct Options {
+        bool no_side_stream = false;      // PHX_NO_SIDE_STREAM=1: everything on the one stream
+        bool no_parts = false;            // PHX_NO_PARTS=1: sweep the interior classes one launch each
+        bool no_fused_verify = false;     // PHX_NO_FUSED_VERIFY=1: always the hash pass (also set for good once a verified launch timed out)
+        bool use_graphs = false;          // PHX_GRAPHS=1
+        bool gpu_builder = true;          // PHX_SCHEDULE_BUILDER=host clears it
+        bool speculate = true;            // PHX_NO_SPECULATION=1 clears it
+        bool no_islands = false;          // PHX_NO_ISLANDS=1
+        bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
+        bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
+        int isl_wait_polls = 0;           // PHX_ISL_WAIT_POLLS
+        static Options from_env();
+    } opt_;
+    // the HBM path (any island size; everything in Single mode): solver-side body state, joint constants in schedule order,
+    // per-sweep 'productive' flags, static tags, the bodies the HBM group touches
+    struct HbmPath {
+        DevBuf<float4> sb_imp, sb_disp, q0, q1, q2;
+        DevBuf<float> qn;
+        DevBuf<int4> q3;
+        DevBuf<float2> acc, dd;
+        DevBuf<int> order, static_slot, flags, hbm_body_list;
+        DevBuf<unsigned> sw;
+    } hbm_;
+    // the island path: per-group tables the island kernel addresses by the group number alone (island_view.h), its counters and
+    // control sets
+    struct IslandPath {
+        DevBuf<int4> desc;
+        DevBuf<int> ncol, units, bodies, stats;
+        DevBuf<int4> unit_recs;           // per LDS group (stride = lanes of the kernel shape), two words per unit: joints, contact points, local bodies, class, slots
+        DevBuf<unsigned> slot_local;
+        DevBuf<unsigned char> slot_colour;
+        DevBuf<unsigned long long> visits;
+        DevBuf<unsigned> done;            // per LDS group: epoch of the last verified solve that committed it
+        DevBuf<unsigned long long> shards;    // two control sets of ISL_SHARDS arrival counters
+        DevBuf<unsigned long long> trace;
+    } isl_;
+    // the interior units of partitioned components by part (schedule.h, k_solve_parts)
+    struct PartsPath {
+        DevBuf<int> begin;
+        DevBuf<int4> ranges;
+        DevBuf<unsigned> keys[2], vals[2];    // the HBM group's entries sorted by part (k_colour_parts)
+        DevBuf<int4> class_tab;
+        std::vector<int4> class_tab_host;
+        int count = 0;                        // workgroups of k_solve_parts (0: the schedule has no interior classes)
+    } parts_;
+    // scratch of the device schedule builder (schedule_kernels.h): components, units, binning, the sort by bin, the colouring of the HBM group
+    struct ScheduleBuilder {
+        DevBuf<int> cc_parent, joint_comp, bin_tables, sb_small;      // bin_tables: component -> bin | component -> rank in its bin | bin -> first slot
+        PinnedBuf<int> bin_tables_host;
+        DevBuf<unsigned char> cc_static;
+        DevBuf<unsigned> cc_flags, comp_size, comp_units, sort_keys[2], sort_vals[2], sort_hist;
+        ScanScratch sort_scan;
+        DevBuf<int> partner, partner_first;   // joint -> the other joint of its unit (schedule.h); contact point -> first joint carrying it
+        DevBuf<int> bin_result;               // k_bin_components' results: 8 ints, then the topology hash (8 bytes)
+        DevBuf<unsigned long long> jp_used, jp_used_b, jp_seen;
+        DevBuf<uint4> jp_ent, jp_adj;
+        DevBuf<uint2> jp_succ;
+        DevBuf<unsigned> jp_offset, jp_cursor, jp_pred, jp_ent_comp, jp_seed, jp_touched, jp_keys[2], jp_vals[2], jp_degree, jp_colour_b, jp_list[2];
+        DevBuf<unsigned char> jp_bad_b, jp_kind;
+        DevBuf<int> jp_small, jp_counts;
+    } bld_;
+
     // device state
-    DevBuf<float4> sb_imp_, sb_disp_, q0_, q1_, q2_;
     DevBuf<float4> edge_vel_, edge_dvel_, edge_mpos_;      // resident form of the records a C-ABI edge call handed over
     Arrays cur_;                                          // arrays of the solve being queued (view() reads the resident mpos from it)
-    DevBuf<float> qn_;
-    DevBuf<int4> q3_;
-    DevBuf<float2> acc_, dd_;
-    DevBuf<int> order_, static_slot_, flags_;
-    DevBuf<int4> grp_desc_;
-    DevBuf<int> grp_ncol_, grp_units_, grp_bodies_, isl_stats_, hbm_body_list_;
-    // the interior units of partitioned components by part (schedule.h, k_solve_parts)
-    DevBuf<int> part_begin_;
-    DevBuf<int4> part_ranges_;
-    DevBuf<unsigned> part_keys_[2], part_vals_[2];      // the HBM group's entries sorted by part (k_colour_parts)
-    DevBuf<int4> hbm_class_tab_;
-    std::vector<int4> class_tab_host_;
-    int part_count_ = 0;                 // workgroups of k_solve_parts (0: the schedule has no interior classes)
-    bool no_parts_ = false;              // PHX_NO_PARTS=1: sweep the interior classes one launch each (A/B measurements, tests)
     int upload_class_tab(const Schedule& sc, int* interior_leaders);
     int upload_part_tables();            // host-built schedules: part_units_ / part_class_begin_ from sched_
-    bool parts_in_use() const { return !no_parts_ && part_count_ > 0 && sched_.hbm_interior_classes > 0; }
+    bool parts_in_use() const { return !opt_.no_parts && parts_.count > 0 && sched_.hbm_interior_classes > 0; }
     int part_levels() const { return sched_.hbm_interior_classes > sched_.hbm_interior_classes0 ? 2 : 1; }
     PartsView parts_view(int level, int nb) const
     {
         const int P = parts_per_level(nb), ki0 = sched_.hbm_interior_classes0, ki = sched_.hbm_interior_classes;
-        return level == 0 ? PartsView{part_ranges_.p, part_begin_.p, hbm_class_tab_.p, 0, P, 0, ki0}
-                          : PartsView{part_ranges_.p, part_begin_.p, hbm_class_tab_.p, P, P + 1, ki0, ki};
+        return level == 0 ? PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, 0, P, 0, ki0}
+                          : PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, P, P + 1, ki0, ki};
     }
-    DevBuf<int4> unit_recs_;            // per LDS group (stride = lanes of the kernel shape), two words per unit: joints, contact points, local bodies, class, slots (island_view.h)
-    DevBuf<unsigned> slot_local_;
-    DevBuf<unsigned char> slot_colour_;
-    DevBuf<unsigned long long> isl_visits_;
-    // device schedule builder scratch
-    DevBuf<int> cc_parent_, joint_comp_, bin_tables_, sb_small_;       // bin_tables_: component -> bin | component -> rank in its bin | bin -> first slot
-    PinnedBuf<int> bin_tables_host_;
-    DevBuf<unsigned char> cc_static_;
-    DevBuf<unsigned> cc_flags_, comp_size_, comp_units_, sort_keys_[2], sort_vals_[2], sort_hist_;
-    ScanScratch sort_scan_;
-    DevBuf<unsigned long long> jp_used_;                    // colouring of the HBM group on the device (schedule_kernels.h)
-    DevBuf<uint4> jp_ent_, jp_adj_;
-    DevBuf<uint2> jp_succ_;
-    DevBuf<unsigned> jp_offset_, jp_cursor_, jp_pred_, jp_ent_comp_, jp_seed_;
     int jp_rounds_guess_ = 0, cc_pairs_guess_ = 2;
     // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;
     // speculative binning (build_bins_speculative): the bins are made on the device and the build has no host round trip at all;
     // what the host would have read — bin count, offsets, GatherIslands' numbers, the topology hash — comes back when the solve is settled
-    bool spec_bins_ok_ = false, spec_bins_pending_ = false, spec_bins_failed_ = false, no_spec_bins_ = false;
+    bool spec_bins_ok_ = false, spec_bins_pending_ = false, spec_bins_failed_ = false;
     int spec_bins_guess_ = 0, spec_lanes_ = 0;
     unsigned long long gate_expected_ = 0, gate_serial_ = 0;      // what the gates of the solve in flight compare the fingerprint word with
-    DevBuf<int> bin_result_;                                      // k_bin_components' results: 8 ints, then the topology hash (8 bytes)
     bool time_sweeps_ = false, timed_sweeps_ = false;   // bench(): the event pair brackets the sweeps instead of the whole solve
     const unsigned* sw_cleared_ = nullptr;          // the static-tag table launch_fingerprint's kernel cleared for the solve in flight
     size_t sw_cleared_words_ = 0;
     unsigned replays_ = 0;                          // solves repeated because nothing could be committed (stale or spoiled schedule)
     unsigned cc_builds_ = 0;
-    DevBuf<unsigned> jp_touched_, jp_keys_[2], jp_vals_[2], jp_degree_, jp_colour_b_;
-    DevBuf<unsigned long long> jp_used_b_, jp_seen_;
-    DevBuf<unsigned char> jp_bad_b_, jp_kind_;
-    DevBuf<int> partner_, partner_first_;      // joint -> the other joint of its unit (schedule.h); contact point -> first joint carrying it
-    DevBuf<int> jp_small_, jp_counts_;
-    DevBuf<unsigned> jp_list_[2];
-    bool gpu_builder_ = true;
     phx_step_hook step_hook_ = nullptr;  // bench(): called with phase 1 between a step's local preparation and its sweeps
     void* step_hook_user_ = nullptr;
     int step_hook_step_ = 0;
@@ -222,13 +249,9 @@ private:
     bool have_hash_ = false;             // raw_fingerprint_ is the cached schedule's topology hash (a rebuild without a hash pass leaves none)
     int isl_mode_ = 0;                   // ISL_GATED / ISL_VERIFY of the solve being queued (island_view.h)
     unsigned isl_nexpect_ = 0, solve_epoch_ = 0;
-    DevBuf<unsigned> isl_done_;          // per LDS group: epoch of the last verified solve that committed it
-    DevBuf<unsigned long long> isl_shards_;   // two control sets of ISL_SHARDS arrival counters (island_view.h)
-    int cu_count_ = 0, isl_wait_polls_ = 0;
-    bool no_fused_verify_ = false;       // PHX_NO_FUSED_VERIFY=1: always the hash pass (A/B measurements)
+    int cu_count_ = 0;
     unsigned long long* fp_wanted_ = nullptr;   // set by ensure_schedule: deliver the fingerprint with the builder's first readback
     int ncomp_guess_ = 0;               // component count of the previous device build (sizes its readback)
-    DevBuf<unsigned> sw_;
     DevBuf<unsigned long long> hash_;
     Readback rb_;                        // pinned staging for every small device->host readback of this handle
     // staging for the host-pointer entry point
@@ -257,8 +280,8 @@ private:
     long long sweep_launches_ = 0, graph_sweep_launches_ = 0, schedule_version_ = 0;
     hipGraphExec_t graph_[3] = {nullptr, nullptr, nullptr};
     GraphKey graph_key_, last_key_;
-    bool use_graphs_ = false, speculate_ = true, half_state_ = false, reuse_schedule_ = true;
-    bool owns_stream_ = true, no_islands_ = false, trace_schedule_ = false;      // environment knobs, read once in init()
+    bool half_state_ = false, reuse_schedule_ = true;
+    bool owns_stream_ = true;
     int shard_ = 0, shard_count_ = 1;    // this handle sweeps groups g with g % shard_count_ == shard_ (the HBM group counts as group lds_groups)
     // (the deal of the groups to the ranks: exchange.h exchange_partition; shard_count_ == 1 owns everything)
     bool owns_hbm_group() const { return sched_.has_hbm_group() && (shard_count_ == 1 || (partition_ok() && owner_host_[(size_t)sched_.lds_groups] == shard_)); }
@@ -287,7 +310,6 @@ private:
     DevBuf<long long> xch_off_;
     std::vector<long long> xch_off_host_;
     DevBuf<int> xch_err_;
-    DevBuf<unsigned long long> isl_trace_;
     bool trace_islands_ = false;
     std::vector<hipEvent_t> bench_events_;
 };

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) k_extract_topology(const phx_contact_join
 
 static inline int grid_for(int n) { return std::max(1, std::min(div_up(n, 256), 2048)); }
 
-constexpr int STATS_SET = 2 * ISL_STAT_SLOTS, VISITS_SET = ISL_STAT_SLOTS + 2, SHARDS_SET = ISL_SHARDS * ISL_SHARD_STRIDE;      // words of one control set in isl_stats_ / isl_visits_ / isl_shards_
+constexpr int STATS_SET = 2 * ISL_STAT_SLOTS, VISITS_SET = ISL_STAT_SLOTS + 2, SHARDS_SET = ISL_SHARDS * ISL_SHARD_STRIDE;      // words of one control set in isl_.stats / isl_.visits / isl_.shards
 
 // ---------------------------------------------------------------------------------------------------
 
@@ -60,6 +60,26 @@ int DeviceSolver::adopt_stream(hipStream_t s)
     return PHX_OK;
 }
 
+// the PHX_* knobs, read once per handle (measurement and debugging only: README.md)
+DeviceSolver::Options DeviceSolver::Options::from_env()
+{
+    auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+    Options o;
+    o.no_side_stream = on("PHX_NO_SIDE_STREAM");          // everything on the one stream (A/B measurements)
+    o.no_parts = on("PHX_NO_PARTS");                      // the interior classes of partitioned components one launch each (A/B, tests)
+    o.no_fused_verify = on("PHX_NO_FUSED_VERIFY");        // the topology hash pass in front of every solve on a cached schedule
+    const char* wp = getenv("PHX_ISL_WAIT_POLLS");        // tests: 0 makes every workgroup of a verified launch give up, so that ISL_COMPLETE runs
+    o.isl_wait_polls = wp ? std::max(0, atoi(wp)) : ISL_WAIT_POLLS;
+    o.use_graphs = on("PHX_GRAPHS");                      // replay the launch sequence from hipGraphs (measured slower: off by default)
+    const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
+    o.gpu_builder = !(sb && sb[0] == 'h');
+    o.speculate = !on("PHX_NO_SPECULATION");
+    o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
+    o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
+    o.trace_schedule = getenv("PHX_TRACE_SCHEDULE") != nullptr;  // print the schedule builders' laps to stderr
+    return o;
+}
+
 int DeviceSolver::init()
 {
     PHX_TRY(use_device(device_));
@@ -72,41 +92,23 @@ int DeviceSolver::init()
     PHX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
     PHX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     PHX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    const char* ns = getenv("PHX_NO_SIDE_STREAM");        // "1": everything on the one stream (A/B measurements)
-    no_side_stream_ = ns && ns[0] == '1';
     // two control sets alternate between consecutive solves; the first kernel of a solve clears the other one (solver_kernels.h)
     PHX_TRY(hash_.reserve(2));
     PHX_HIP(hipMemsetAsync(hash_.p, 0, 2 * sizeof(unsigned long long), stream_));
-    PHX_TRY(isl_stats_.reserve(2 * STATS_SET));
-    PHX_HIP(hipMemsetAsync(isl_stats_.p, 0, 2 * STATS_SET * sizeof(int), stream_));
-    PHX_TRY(isl_visits_.reserve(2 * VISITS_SET));               // per set: the slots + the solve's two time stamps
+    PHX_TRY(isl_.stats.reserve(2 * STATS_SET));
+    PHX_HIP(hipMemsetAsync(isl_.stats.p, 0, 2 * STATS_SET * sizeof(int), stream_));
+    PHX_TRY(isl_.visits.reserve(2 * VISITS_SET));               // per set: the slots + the solve's two time stamps
     {
         unsigned long long init[2 * VISITS_SET] = {0};
         init[ISL_STAT_SLOTS] = ~0ull; init[VISITS_SET + ISL_STAT_SLOTS] = ~0ull;
-        PHX_HIP(hipMemcpyAsync(isl_visits_.p, init, sizeof init, hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(isl_.visits.p, init, sizeof init, hipMemcpyHostToDevice, stream_));
         PHX_HIP(hipStreamSynchronize(stream_));
     }
-    PHX_TRY(isl_shards_.reserve(2 * SHARDS_SET));
-    PHX_HIP(hipMemsetAsync(isl_shards_.p, 0, 2 * SHARDS_SET * sizeof(unsigned long long), stream_));
+    PHX_TRY(isl_.shards.reserve(2 * SHARDS_SET));
+    PHX_HIP(hipMemsetAsync(isl_.shards.p, 0, 2 * SHARDS_SET * sizeof(unsigned long long), stream_));
     PHX_HIP(hipDeviceGetAttribute(&cu_count_, hipDeviceAttributeMultiprocessorCount, device_));
-    const char* np = getenv("PHX_NO_PARTS");              // "1": the interior classes of partitioned components one launch each (A/B, tests)
-    no_parts_ = np && np[0] == '1';
-    const char* nfv = getenv("PHX_NO_FUSED_VERIFY");      // "1": the topology hash pass in front of every solve on a cached schedule (A/B measurements)
-    no_fused_verify_ = nfv && nfv[0] == '1';
-    const char* wp = getenv("PHX_ISL_WAIT_POLLS");        // tests: 0 makes every workgroup of a verified launch give up, so that ISL_COMPLETE runs
-    isl_wait_polls_ = wp ? std::max(0, atoi(wp)) : ISL_WAIT_POLLS;
-    const char* g = getenv("PHX_GRAPHS");               // "1": replay the launch sequence from hipGraphs (measured: no gain on the
-    use_graphs_ = g && g[0] == '1';                      // HBM path, 7 us slower per solve on the island path) — off by default
-    const char* sb = getenv("PHX_SCHEDULE_BUILDER");      // "host" forces the host builder
-    gpu_builder_ = !(sb && sb[0] == 'h');
-    const char* sp = getenv("PHX_NO_SPECULATION");
-    speculate_ = !(sp && sp[0] == '1');
-    defer_build_check_ = speculate_;                     // (PHX_NO_SPECULATION=1 also waits for the device build's 'every bin fits' flag)
-    const char* ni = getenv("PHX_NO_ISLANDS");           // "1": ignore island modes, always the HBM colour path (A/B measurements)
-    no_islands_ = ni && ni[0] == '1';
-    const char* nsb = getenv("PHX_NO_SPEC_BINS");      // "1": every rebuild reads the component sizes back and bins them on the host
-    no_spec_bins_ = (nsb && nsb[0] == '1') || use_graphs_;
-    trace_schedule_ = getenv("PHX_TRACE_SCHEDULE") != nullptr;      // print the schedule builders' laps to stderr
+    opt_ = Options::from_env();
+    defer_build_check_ = opt_.speculate;                     // (PHX_NO_SPECULATION=1 also waits for the device build's 'every bin fits' flag)
     return PHX_OK;
 }
 
@@ -115,12 +117,12 @@ SolverView DeviceSolver::view() const
     SolverView v{};
     v.nb = nb_; v.nj = nj_; v.ncp = ncp_; v.nstatic = std::max(nstatic_, 1); v.ncolours = sched_.ncolours();
     v.fingerprint = hash_.p + hash_slot_; v.expected_fingerprint = gate_expected_;
-    v.sb_imp = sb_imp_.p; v.sb_disp = sb_disp_.p; v.sb_par = cur_.view.mpos;
-    v.q0 = q0_.p; v.q1 = q1_.p; v.q2 = q2_.p; v.q3 = q3_.p; v.acc = acc_.p; v.dd = dd_.p; v.qn = qn_.p;
-    v.order = order_.p;
-    v.sw_imp = sw_.p; v.sw_disp = sw_.p + 2 * (size_t)v.nstatic;
-    v.imp_active = flags_.p; v.disp_active = flags_.p + max_iters_;
-    v.stamps = isl_visits_.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS;
+    v.sb_imp = hbm_.sb_imp.p; v.sb_disp = hbm_.sb_disp.p; v.sb_par = cur_.view.mpos;
+    v.q0 = hbm_.q0.p; v.q1 = hbm_.q1.p; v.q2 = hbm_.q2.p; v.q3 = hbm_.q3.p; v.acc = hbm_.acc.p; v.dd = hbm_.dd.p; v.qn = hbm_.qn.p;
+    v.order = hbm_.order.p;
+    v.sw_imp = hbm_.sw.p; v.sw_disp = hbm_.sw.p + 2 * (size_t)v.nstatic;
+    v.imp_active = hbm_.flags.p; v.disp_active = hbm_.flags.p + max_iters_;
+    v.stamps = isl_.visits.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS;
     return v;
 }
 
@@ -138,18 +140,18 @@ int DeviceSolver::launch_fingerprint(const float4* d_mpos, int nb, const phx_con
     // the next solve (the two sets alternate)
     begin_set(true);
     ControlWords cw{};
-    cw.flags = flags_.p; cw.nflags = flags_.p ? 2 * max_iters_ : 0;
-    cw.sw = sw_.p; cw.nsw = sw_.p ? (int)std::min<size_t>(sw_.cap, 1u << 30) : 0;      // (the whole table: a rebuilt schedule may use more of it)
-    sw_cleared_ = sw_.p; sw_cleared_words_ = (size_t)cw.nsw;
+    cw.flags = hbm_.flags.p; cw.nflags = hbm_.flags.p ? 2 * max_iters_ : 0;
+    cw.sw = hbm_.sw.p; cw.nsw = hbm_.sw.p ? (int)std::min<size_t>(hbm_.sw.cap, 1u << 30) : 0;      // (the whole table: a rebuilt schedule may use more of it)
+    sw_cleared_ = hbm_.sw.p; sw_cleared_words_ = (size_t)cw.nsw;
     int next = hash_slot_ ^ 1;
     cw.next_ctl = hash_.p + next;
-    if (use_graphs_) {        // captured graphs have the control set's addresses baked in: always set 0 — its word cleared by a memset, its
+    if (opt_.use_graphs) {        // captured graphs have the control set's addresses baked in: always set 0 — its word cleared by a memset, its
         hash_slot_ = 0;       // counters by this kernel (nothing else touches them while it runs)
         PHX_HIP(hipMemsetAsync(hash_.p, 0, sizeof(unsigned long long), stream_));
         next = 0; cw.next_ctl = hash_.p + 1;
     }
-    cw.next_executed = isl_stats_.p + (size_t)next * STATS_SET; cw.next_visits = isl_visits_.p + (size_t)next * VISITS_SET;
-    cw.next_shards = isl_shards_.p + (size_t)next * SHARDS_SET;
+    cw.next_executed = isl_.stats.p + (size_t)next * STATS_SET; cw.next_visits = isl_.visits.p + (size_t)next * VISITS_SET;
+    cw.next_shards = isl_.shards.p + (size_t)next * SHARDS_SET;
     hipLaunchKernelGGL(k_topology_hash, dim3(std::max(1, std::min(div_up(std::max(nj, nb), HASH_T), HASH_BLOCKS))), dim3(HASH_T), 0, stream_, d_joints, nj, d_mpos, nb, ncp,
                        hash_.p + hash_slot_, cw);
     isl_mode_ = ISL_GATED;
@@ -162,7 +164,7 @@ int DeviceSolver::launch_fingerprint(const float4* d_mpos, int nb, const phx_con
 // puts it into its exchange header; graphs bake the launch arguments in).
 bool DeviceSolver::verify_eligible(int groups, bool big_shape) const
 {
-    if (no_fused_verify_ || !speculate_ || use_graphs_ || shard_count_ != 1 || xch_send_ || groups <= 0) return false;
+    if (opt_.no_fused_verify || !opt_.speculate || opt_.use_graphs || shard_count_ != 1 || xch_send_ || groups <= 0) return false;
     // (LDS — 37 / 50 KB — and the 128-register budget admit 4 / 2 workgroups per CU; asked of the runtime for the instantiation
     //  at hand rather than assumed, and never more than that: the occupancy query has been seen one block high)
     const int per_cu = std::min(island_blocks_per_cu(big_shape, half_state_), big_shape ? 2 : 4);
@@ -172,8 +174,8 @@ bool DeviceSolver::verify_eligible(int groups, bool big_shape) const
 // would a rebuild take the path without a host round trip (build_bins_speculative)?
 bool DeviceSolver::spec_build_applies(bool want_islands, int nj) const
 {
-    return spec_bins_ok_ && !no_spec_bins_ && want_islands && defer_build_check_ && shard_count_ == 1 && !xch_send_ && nj > 0 && nj < (1 << BINC_JOINT_BITS) &&
-           !trace_schedule_;
+    return spec_bins_ok_ && !opt_.no_spec_bins && want_islands && defer_build_check_ && shard_count_ == 1 && !xch_send_ && nj > 0 && nj < (1 << BINC_JOINT_BITS) &&
+           !opt_.trace_schedule;
 }
 
 // Arms the gate of a solve on the cached schedule.  ISL_VERIFY where the island launch can check the schedule itself — no kernel in
@@ -207,8 +209,8 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
     bool have_fp = false;
     // Single = one coupled system swept class by class out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
-    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
-    const bool device_builder = gpu_builder_ && !force_host_builder_;
+    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !opt_.no_islands;
+    const bool device_builder = opt_.gpu_builder && !force_host_builder_;
     const bool no_hash = known_changed && device_builder && spec_build_applies(want_islands, nj) && verify_eligible(spec_bins_guess_, spec_lanes_ > ISL_T);
     if (no_hash) begin_set(false);
     else PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
@@ -261,7 +263,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
     }
     const unsigned long long raw = fp;
     fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
-    const bool trace = trace_schedule_;
+    const bool trace = opt_.trace_schedule;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     DevBuf<int2> d_pairs;
@@ -312,17 +314,17 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
     for (int i = 0; i < nb; ++i) if (is_static[i]) h_static_slot_[i] = nstatic_++;
 
     nb_ = nb; nj_ = nj;
-    PHX_TRY(order_.reserve(std::max(nj, 1)));
-    PHX_TRY(static_slot_.reserve(std::max(nb, 1)));
-    PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
+    PHX_TRY(hbm_.order.reserve(std::max(nj, 1)));
+    PHX_TRY(hbm_.static_slot.reserve(std::max(nb, 1)));
+    PHX_TRY(hbm_.sw.reserve(4 * (size_t)std::max(nstatic_, 1)));
     // new table for this solve — already cleared by this solve's fingerprint kernel unless it has just been (re)allocated
-    if (sw_.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
-        PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
-    PHX_TRY(sb_imp_.reserve(nb)); PHX_TRY(sb_disp_.reserve(nb));
-    PHX_TRY(q0_.reserve(nj)); PHX_TRY(q1_.reserve(nj)); PHX_TRY(q2_.reserve(nj)); PHX_TRY(q3_.reserve(nj)); PHX_TRY(qn_.reserve(nj));
-    PHX_TRY(acc_.reserve(nj)); PHX_TRY(dd_.reserve(nj));
-    if (nj) PHX_HIP(hipMemcpyAsync(order_.p, sched_.order.data(), (size_t)nj * sizeof(int), hipMemcpyHostToDevice, stream_));
-    if (nb) PHX_HIP(hipMemcpyAsync(static_slot_.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (hbm_.sw.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
+        PHX_HIP(hipMemsetAsync(hbm_.sw.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
+    PHX_TRY(hbm_.sb_imp.reserve(nb)); PHX_TRY(hbm_.sb_disp.reserve(nb));
+    PHX_TRY(hbm_.q0.reserve(nj)); PHX_TRY(hbm_.q1.reserve(nj)); PHX_TRY(hbm_.q2.reserve(nj)); PHX_TRY(hbm_.q3.reserve(nj)); PHX_TRY(hbm_.qn.reserve(nj));
+    PHX_TRY(hbm_.acc.reserve(nj)); PHX_TRY(hbm_.dd.reserve(nj));
+    if (nj) PHX_HIP(hipMemcpyAsync(hbm_.order.p, sched_.order.data(), (size_t)nj * sizeof(int), hipMemcpyHostToDevice, stream_));
+    if (nb) PHX_HIP(hipMemcpyAsync(hbm_.static_slot.p, h_static_slot_.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, stream_));
     const int ng = sched_.lds_groups;
     std::vector<int4> desc(std::max(ng, 1));
     std::vector<int> ncol(std::max(ng, 1));
@@ -339,13 +341,13 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
             std::copy(sched_.group_bodies.begin() + sched_.group_body_offsets[g], sched_.group_bodies.begin() + sched_.group_body_offsets[g + 1], bodies_strided.begin() + (size_t)g * cap_bodies);
         }
         const size_t lds_slots = (size_t)sched_.group_offsets[ng];
-        PHX_TRY(grp_desc_.reserve(ng)); PHX_TRY(grp_ncol_.reserve(ng));
-        PHX_TRY(grp_bodies_.reserve(bodies_strided.size())); PHX_TRY(slot_local_.reserve(lds_slots)); PHX_TRY(slot_colour_.reserve(lds_slots));
-        PHX_HIP(hipMemcpyAsync(grp_desc_.p, desc.data(), (size_t)ng * sizeof(int4), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(grp_ncol_.p, ncol.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(grp_bodies_.p, bodies_strided.data(), bodies_strided.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(slot_local_.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(slot_colour_.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
+        PHX_TRY(isl_.desc.reserve(ng)); PHX_TRY(isl_.ncol.reserve(ng));
+        PHX_TRY(isl_.bodies.reserve(bodies_strided.size())); PHX_TRY(isl_.slot_local.reserve(lds_slots)); PHX_TRY(isl_.slot_colour.reserve(lds_slots));
+        PHX_HIP(hipMemcpyAsync(isl_.desc.p, desc.data(), (size_t)ng * sizeof(int4), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(isl_.ncol.p, ncol.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(isl_.bodies.p, bodies_strided.data(), bodies_strided.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(isl_.slot_local.p, sched_.slot_local.data(), lds_slots * sizeof(unsigned), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(isl_.slot_colour.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
         // the units, class-major, at a fixed stride of one workgroup's lanes per group
         std::vector<int> units(ng);
         std::vector<int4> unit_recs(2 * (size_t)ng * lanes, make_int4(0, -1, 0, 0));
@@ -362,13 +364,13 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
                 unit_recs[2 * ((size_t)g * lanes + u) + 1] = make_int4((int)sched_.slot_local[ls], (int)sched_.slot_colour[ls], ls, fs);
             }
         }
-        PHX_TRY(grp_units_.reserve(ng)); PHX_TRY(unit_recs_.reserve(unit_recs.size()));
-        PHX_HIP(hipMemcpyAsync(grp_units_.p, units.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
-        PHX_HIP(hipMemcpyAsync(unit_recs_.p, unit_recs.data(), unit_recs.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
+        PHX_TRY(isl_.units.reserve(ng)); PHX_TRY(isl_.unit_recs.reserve(unit_recs.size()));
+        PHX_HIP(hipMemcpyAsync(isl_.units.p, units.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(isl_.unit_recs.p, unit_recs.data(), unit_recs.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
     }
-    PHX_TRY(hbm_body_list_.reserve(std::max<size_t>(sched_.hbm_bodies.size(), 1)));
+    PHX_TRY(hbm_.hbm_body_list.reserve(std::max<size_t>(sched_.hbm_bodies.size(), 1)));
     if (!sched_.hbm_bodies.empty())
-        PHX_HIP(hipMemcpyAsync(hbm_body_list_.p, sched_.hbm_bodies.data(), sched_.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        PHX_HIP(hipMemcpyAsync(hbm_.hbm_body_list.p, sched_.hbm_bodies.data(), sched_.hbm_bodies.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
     PHX_TRY(upload_part_tables());
     PHX_HIP(hipStreamSynchronize(stream_));
     lap("upload");
@@ -393,20 +395,20 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     RoctxRange range("GatherIslands + PrepareIndices (schedule build)");          // ref: Solver.cpp:77, 135, 217, 285
     // the topology fingerprint (already queued on the stream) rides along with the first readback of the build
     auto with_fingerprint = [&]() -> int { if (fp_wanted_) { PHX_TRY(rb_.add(fp_wanted_, hash_.p + hash_slot_, sizeof *fp_wanted_, stream_)); fp_wanted_ = nullptr; } return PHX_OK; };
-    const bool trace = trace_schedule_;
+    const bool trace = opt_.trace_schedule;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     const int nbs = std::max(nb, 1), njs = std::max(nj, 1);
-    PHX_TRY(cc_parent_.reserve(nbs)); PHX_TRY(cc_static_.reserve(nbs)); PHX_TRY(cc_flags_.reserve(nbs + 1)); PHX_TRY(comp_size_.reserve(nbs + 1));
-    PHX_TRY(joint_comp_.reserve(njs)); PHX_TRY(sb_small_.reserve(8));
-    for (int k = 0; k < 2; ++k) { PHX_TRY(sort_keys_[k].reserve(njs)); PHX_TRY(sort_vals_[k].reserve(njs)); }
-    PHX_TRY(sort_hist_.reserve(radix_hist_words(nj)));
-    PHX_TRY(order_.reserve(njs));
+    PHX_TRY(bld_.cc_parent.reserve(nbs)); PHX_TRY(bld_.cc_static.reserve(nbs)); PHX_TRY(bld_.cc_flags.reserve(nbs + 1)); PHX_TRY(bld_.comp_size.reserve(nbs + 1));
+    PHX_TRY(bld_.joint_comp.reserve(njs)); PHX_TRY(bld_.sb_small.reserve(8));
+    for (int k = 0; k < 2; ++k) { PHX_TRY(bld_.sort_keys[k].reserve(njs)); PHX_TRY(bld_.sort_vals[k].reserve(njs)); }
+    PHX_TRY(bld_.sort_hist.reserve(radix_hist_words(nj)));
+    PHX_TRY(hbm_.order.reserve(njs));
 
     // units (schedule.h): contact point -> first joint carrying it (reset by k_cc_init); the partners are found by the first hook
-    PHX_TRY(partner_.reserve(njs)); PHX_TRY(partner_first_.reserve(std::max(ncp_, 1))); PHX_TRY(comp_units_.reserve(nbs + 1));
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, ncp_))), dim3(256), 0, stream_, d_bodies, nb, cc_parent_.p, cc_static_.p, sb_small_.p, partner_first_.p, ncp_);
-    hipLaunchKernelGGL(k_partner_first, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, partner_first_.p);
+    PHX_TRY(bld_.partner.reserve(njs)); PHX_TRY(bld_.partner_first.reserve(std::max(ncp_, 1))); PHX_TRY(bld_.comp_units.reserve(nbs + 1));
+    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, ncp_))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p, bld_.partner_first.p, ncp_);
+    hipLaunchKernelGGL(k_partner_first, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, bld_.partner_first.p);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -435,29 +437,29 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     for (int round = 0;; round += 2) {
         if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
         int changed = 0;
-        if (round) PHX_HIP(hipMemsetAsync(sb_small_.p, 0, sizeof(int), stream_));        // (the first pair's flag was cleared by k_cc_init)
+        if (round) PHX_HIP(hipMemsetAsync(bld_.sb_small.p, 0, sizeof(int), stream_));        // (the first pair's flag was cleared by k_cc_init)
         // (the first batch runs as many hook + compress pairs as the previous build needed: a merged world needs four, and
         //  finding that out two at a time costs a round trip and a second numbering)
         const int pairs = round == 0 ? std::max(2, std::min(cc_pairs_guess_, 16)) : 2;
         for (int k = 0; k < pairs; ++k) {
             const bool pairing = round == 0 && k == 0;      // the first hook also pairs the joints into units
-            hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p,
-                               (const int*)partner_first_.p, ncp_, pairing ? partner_.p : (int*)nullptr);
-            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == pairs - 2 ? sb_small_.p : (int*)nullptr);
+            hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, bld_.sb_small.p,
+                               (const int*)bld_.partner_first.p, ncp_, pairing ? bld_.partner.p : (int*)nullptr);
+            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, k == pairs - 2 ? bld_.sb_small.p : (int*)nullptr);
         }
         pairs_run += pairs;
-        PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)cc_parent_.p, nb, comp_size_.p, comp_units_.p}, cc_flags_.p, nb + 1,
-                                         reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
-        hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
-                           (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p, (int*)nullptr);
+        PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
+                                         reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
+        hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
+                           (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, (int*)nullptr);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
         comp_size.assign(std::max(guess, 1), 0u); comp_units.assign(std::max(guess, 1), 0u);
         PHX_TRY(with_fingerprint());
         int pair[2] = {0, 0};                              // {changed, component count}: adjacent words, one copy
-        PHX_TRY(rb_.add(pair, sb_small_.p, sizeof pair, stream_));
-        PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, (size_t)guess * sizeof(unsigned), stream_));
-        PHX_TRY(rb_.add(comp_units.data(), comp_units_.p, (size_t)guess * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(pair, bld_.sb_small.p, sizeof pair, stream_));
+        PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, (size_t)guess * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_units.data(), bld_.comp_units.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
         changed = pair[0]; ncomp_u = (unsigned)pair[1];
         if (!changed) { cc_pairs_guess_ = pairs_run; break; }
@@ -467,8 +469,8 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     ncomp_total = ncomp;
     if (ncomp > guess) {
         comp_size.resize(ncomp); comp_units.resize(ncomp);
-        PHX_TRY(rb_.add(comp_size.data() + guess, comp_size_.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
-        PHX_TRY(rb_.add(comp_units.data() + guess, comp_units_.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_size.data() + guess, bld_.comp_size.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_units.data() + guess, bld_.comp_units.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
     }
     comp_size.resize(std::max(ncomp, 1)); comp_units.resize(std::max(ncomp, 1));
@@ -512,43 +514,43 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     sc.lds_groups = nbins;
     // one upload: component -> bin, component -> rank inside its bin, bin -> first slot
     const size_t nc1 = (size_t)std::max(ncomp, 1), table_words = 2 * nc1 + (size_t)nbins + 2;
-    PHX_TRY(bin_tables_.reserve(table_words)); PHX_TRY(bin_tables_host_.reserve(table_words));
-    std::copy(bin_of.begin(), bin_of.end(), bin_tables_host_.p);
-    std::copy(rank_of.begin(), rank_of.end(), bin_tables_host_.p + nc1);
-    std::copy(sc.group_offsets.begin(), sc.group_offsets.begin() + nbins + 1, bin_tables_host_.p + 2 * nc1);
+    PHX_TRY(bld_.bin_tables.reserve(table_words)); PHX_TRY(bld_.bin_tables_host.reserve(table_words));
+    std::copy(bin_of.begin(), bin_of.end(), bld_.bin_tables_host.p);
+    std::copy(rank_of.begin(), rank_of.end(), bld_.bin_tables_host.p + nc1);
+    std::copy(sc.group_offsets.begin(), sc.group_offsets.begin() + nbins + 1, bld_.bin_tables_host.p + 2 * nc1);
     if (table_words <= 65536)
         hipLaunchKernelGGL(k_upload_words, dim3(std::max(1, std::min(div_up((int)table_words, 256), 64))), dim3(256), 0, stream_,
-                           reinterpret_cast<unsigned*>(bin_tables_.p), reinterpret_cast<const unsigned*>(bin_tables_host_.p), (int)table_words);
-    else PHX_HIP(hipMemcpyAsync(bin_tables_.p, bin_tables_host_.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
-    const int* bin_of_comp = bin_tables_.p; const int* rank_of_comp = bin_tables_.p + nc1; const int* grp_goff = bin_tables_.p + 2 * nc1;
+                           reinterpret_cast<unsigned*>(bld_.bin_tables.p), reinterpret_cast<const unsigned*>(bld_.bin_tables_host.p), (int)table_words);
+    else PHX_HIP(hipMemcpyAsync(bld_.bin_tables.p, bld_.bin_tables_host.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
+    const int* bin_of_comp = bld_.bin_tables.p; const int* rank_of_comp = bld_.bin_tables.p + nc1; const int* grp_goff = bld_.bin_tables.p + 2 * nc1;
     lap("bin");
 
     // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
     if (nbins) {
-        hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, bin_of_comp, nj, nbins,
-                           sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2, std::max(ncomp, 1));
+        hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, bin_of_comp, nj, nbins,
+                           bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, std::max(ncomp, 1));
         int bits = 1;
         while ((1 << bits) <= nbins) ++bits;
-        PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_, stream_, &where));
+        PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where));
     } else {                                    // no bins (Single mode, or nothing fits a workgroup): the HBM group is every joint, in joint order
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, sort_vals_[0].p, nj);
-        PHX_HIP(hipMemsetAsync(sb_small_.p + 2, 0, sizeof(int), stream_));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, bld_.sort_vals[0].p, nj);
+        PHX_HIP(hipMemsetAsync(bld_.sb_small.p + 2, 0, sizeof(int), stream_));
     }
     lap("sort");
 
     // 5. one workgroup per bin: body table, colouring, slot arrays
-    PHX_TRY(grp_desc_.reserve(std::max(nbins, 1))); PHX_TRY(grp_ncol_.reserve(std::max(nbins, 1)));
-    PHX_TRY(grp_bodies_.reserve((size_t)std::max(nbins, 1) * cap_bodies));
-    PHX_TRY(slot_local_.reserve(std::max(lds_slots, 1))); PHX_TRY(slot_colour_.reserve(std::max(lds_slots, 1)));
+    PHX_TRY(isl_.desc.reserve(std::max(nbins, 1))); PHX_TRY(isl_.ncol.reserve(std::max(nbins, 1)));
+    PHX_TRY(isl_.bodies.reserve((size_t)std::max(nbins, 1) * cap_bodies));
+    PHX_TRY(isl_.slot_local.reserve(std::max(lds_slots, 1))); PHX_TRY(isl_.slot_colour.reserve(std::max(lds_slots, 1)));
     if (nbins) {
         BinBuildView bv{};
-        PHX_TRY(grp_units_.reserve(nbins)); PHX_TRY(unit_recs_.reserve(2 * (size_t)nbins * cap_units));
-        bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.partner = partner_.p; bv.is_static = cc_static_.p;
-        bv.joint_comp = joint_comp_.p; bv.comp_rank = rank_of_comp;
+        PHX_TRY(isl_.units.reserve(nbins)); PHX_TRY(isl_.unit_recs.reserve(2 * (size_t)nbins * cap_units));
+        bv.sorted_joints = bld_.sort_vals[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.partner = bld_.partner.p; bv.is_static = bld_.cc_static.p;
+        bv.joint_comp = bld_.joint_comp.p; bv.comp_rank = rank_of_comp;
         bv.nb = nb; bv.max_static = 1 << 30;
-        bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
-        bv.units = grp_units_.p; bv.unit_recs = unit_recs_.p;
-        bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2; bv.poison = hash_.p + hash_slot_;
+        bv.order = hbm_.order.p; bv.slot_local = isl_.slot_local.p; bv.slot_colour = isl_.slot_colour.p; bv.desc = isl_.desc.p; bv.ncol = isl_.ncol.p;
+        bv.units = isl_.units.p; bv.unit_recs = isl_.unit_recs.p;
+        bv.bodies = isl_.bodies.p; bv.rejected = bld_.sb_small.p + 2; bv.poison = hash_.p + hash_slot_;
         if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(2 * ISL_T_BIG), 0, stream_, bv);
         else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(2 * ISL_T), 0, stream_, bv);
     }
@@ -563,9 +565,9 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         int rejected = 0;
         std::vector<int> ncol(nbins, 0);
         std::vector<int4> desc(nbins);
-        PHX_TRY(rb_.add(&rejected, sb_small_.p + 2, sizeof rejected, stream_));
-        PHX_TRY(rb_.add(ncol.data(), grp_ncol_.p, (size_t)nbins * sizeof(int), stream_));
-        PHX_TRY(rb_.add(desc.data(), grp_desc_.p, (size_t)nbins * sizeof(int4), stream_));
+        PHX_TRY(rb_.add(&rejected, bld_.sb_small.p + 2, sizeof rejected, stream_));
+        PHX_TRY(rb_.add(ncol.data(), isl_.ncol.p, (size_t)nbins * sizeof(int), stream_));
+        PHX_TRY(rb_.add(desc.data(), isl_.desc.p, (size_t)nbins * sizeof(int4), stream_));
         PHX_TRY(rb_.wait(stream_));
         lap("bins");
         if (rejected) { *fallback = true; return PHX_OK; }      // some bin exceeds the LDS caps: let the host builder sort it out
@@ -583,24 +585,24 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     nstatic_ = 0;
     sc.hbm_body_count = 0;
     if (rest > 0) {
-        const unsigned* ids = sort_vals_[where].p + lds_slots;
-        PHX_TRY(jp_used_.reserve(nbs)); PHX_TRY(jp_used_b_.reserve(nbs)); PHX_TRY(jp_touched_.reserve(nbs + 1)); PHX_TRY(jp_degree_.reserve(nbs + 1));
-        PHX_TRY(jp_offset_.reserve(nbs + 1)); PHX_TRY(jp_cursor_.reserve(nbs));
-        PHX_TRY(jp_small_.reserve(2 * JP_MAX_COLOURS + 8)); PHX_TRY(jp_kind_.reserve(njs)); PHX_TRY(jp_counts_.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
-        PHX_TRY(jp_seen_.reserve(3 * ((size_t)ncomp_total + 1))); PHX_TRY(jp_bad_b_.reserve((size_t)ncomp_total + 1));
+        const unsigned* ids = bld_.sort_vals[where].p + lds_slots;
+        PHX_TRY(bld_.jp_used.reserve(nbs)); PHX_TRY(bld_.jp_used_b.reserve(nbs)); PHX_TRY(bld_.jp_touched.reserve(nbs + 1)); PHX_TRY(bld_.jp_degree.reserve(nbs + 1));
+        PHX_TRY(bld_.jp_offset.reserve(nbs + 1)); PHX_TRY(bld_.jp_cursor.reserve(nbs));
+        PHX_TRY(bld_.jp_small.reserve(2 * JP_MAX_COLOURS + 8)); PHX_TRY(bld_.jp_kind.reserve(njs)); PHX_TRY(bld_.jp_counts.reserve((size_t)(JP_ROUNDS_MAX + 2) * JP_SUBLISTS));
+        PHX_TRY(bld_.jp_seen.reserve(3 * ((size_t)ncomp_total + 1))); PHX_TRY(bld_.jp_bad_b.reserve((size_t)ncomp_total + 1));
         // (sized by the joint count, not by the group's: while a world settles the HBM group grows every step, and regrowing a score
         //  of arrays — hipMalloc + hipFree each — cost 3 ms whenever it crossed a capacity)
-        PHX_TRY(jp_ent_.reserve(njs)); PHX_TRY(jp_succ_.reserve(njs)); PHX_TRY(jp_pred_.reserve(njs)); PHX_TRY(jp_colour_b_.reserve(njs));
-        for (int k = 0; k < 2; ++k) { PHX_TRY(jp_keys_[k].reserve(njs)); PHX_TRY(jp_vals_[k].reserve(njs)); PHX_TRY(jp_list_[k].reserve((size_t)njs * JP_SUBLISTS)); }
-        PHX_TRY(jp_adj_.reserve(2 * (size_t)njs)); PHX_TRY(jp_ent_comp_.reserve(njs));
+        PHX_TRY(bld_.jp_ent.reserve(njs)); PHX_TRY(bld_.jp_succ.reserve(njs)); PHX_TRY(bld_.jp_pred.reserve(njs)); PHX_TRY(bld_.jp_colour_b.reserve(njs));
+        for (int k = 0; k < 2; ++k) { PHX_TRY(bld_.jp_keys[k].reserve(njs)); PHX_TRY(bld_.jp_vals[k].reserve(njs)); PHX_TRY(bld_.jp_list[k].reserve((size_t)njs * JP_SUBLISTS)); }
+        PHX_TRY(bld_.jp_adj.reserve(2 * (size_t)njs)); PHX_TRY(bld_.jp_ent_comp.reserve(njs));
         JpView jv{};
-        jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = cc_static_.p; jv.nb = nb;
-        jv.ent = jp_ent_.p; jv.offset = jp_offset_.p; jv.cursor = jp_cursor_.p; jv.adj = jp_adj_.p; jv.ent_comp = jp_ent_comp_.p;
-        jv.succ = jp_succ_.p; jv.pred = jp_pred_.p;
-        jv.used = jp_used_.p; jv.used_b = jp_used_b_.p; jv.colour = jp_keys_[0].p; jv.colour_b = jp_colour_b_.p; jv.touched = jp_touched_.p;
-        jv.joint_comp = joint_comp_.p; jv.partner = partner_.p; jv.kind = jp_kind_.p; jv.ncomp = ncomp_total; jv.comp_size = comp_size_.p;
-        jv.seen_a = jp_seen_.p; jv.seen_b = jp_seen_.p + ncomp_total + 1; jv.seen_c = jp_seen_.p + 2 * ((size_t)ncomp_total + 1); jv.bad_b = jp_bad_b_.p;
-        jv.counts = jp_counts_.p; jv.flags = jp_small_.p; jv.hist = reinterpret_cast<unsigned*>(jp_small_.p + 4);
+        jv.ids = ids; jv.count = rest; jv.joints = d_joints; jv.is_static = bld_.cc_static.p; jv.nb = nb;
+        jv.ent = bld_.jp_ent.p; jv.offset = bld_.jp_offset.p; jv.cursor = bld_.jp_cursor.p; jv.adj = bld_.jp_adj.p; jv.ent_comp = bld_.jp_ent_comp.p;
+        jv.succ = bld_.jp_succ.p; jv.pred = bld_.jp_pred.p;
+        jv.used = bld_.jp_used.p; jv.used_b = bld_.jp_used_b.p; jv.colour = bld_.jp_keys[0].p; jv.colour_b = bld_.jp_colour_b.p; jv.touched = bld_.jp_touched.p;
+        jv.joint_comp = bld_.joint_comp.p; jv.partner = bld_.partner.p; jv.kind = bld_.jp_kind.p; jv.ncomp = ncomp_total; jv.comp_size = bld_.comp_size.p;
+        jv.seen_a = bld_.jp_seen.p; jv.seen_b = bld_.jp_seen.p + ncomp_total + 1; jv.seen_c = bld_.jp_seen.p + 2 * ((size_t)ncomp_total + 1); jv.bad_b = bld_.jp_bad_b.p;
+        jv.counts = bld_.jp_counts.p; jv.flags = bld_.jp_small.p; jv.hist = reinterpret_cast<unsigned*>(bld_.jp_small.p + 4);
         const unsigned* perm = nullptr;                     // the entries sorted by part (partitioned components only)
         const int parts = parts_total(nb);                    // over both levels (schedule.h)
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
@@ -610,28 +612,28 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         // the interior units of partitioned components take their classes inside their parts (k_colour_parts): entries sorted by
         // part (everything else behind them), the parts' ranges, one workgroup per part — out of the global walk below altogether
         if (any_partitioned) {
-            for (int k = 0; k < 2; ++k) { PHX_TRY(part_keys_[k].reserve(njs)); PHX_TRY(part_vals_[k].reserve(njs)); }
-            PHX_TRY(part_begin_.reserve((size_t)parts + 2));
-            hipLaunchKernelGGL(k_part_sort_keys, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (unsigned)parts, part_keys_[0].p, part_vals_[0].p);
+            for (int k = 0; k < 2; ++k) { PHX_TRY(parts_.keys[k].reserve(njs)); PHX_TRY(parts_.vals[k].reserve(njs)); }
+            PHX_TRY(parts_.begin.reserve((size_t)parts + 2));
+            hipLaunchKernelGGL(k_part_sort_keys, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (unsigned)parts, parts_.keys[0].p, parts_.vals[0].p);
             int bits = 1;
             while ((1 << bits) <= parts) ++bits;                 // keys 0 .. parts
             int wherep = 0;
-            PHX_TRY(device_radix_sort_pairs(part_keys_[0].p, part_vals_[0].p, part_keys_[1].p, part_vals_[1].p, rest, bits, sort_hist_.p, sort_scan_, stream_, &wherep));
-            hipLaunchKernelGGL(k_lower_bounds, dim3(grid_for(parts + 1)), dim3(256), 0, stream_, (const unsigned*)part_keys_[wherep].p, rest, parts, part_begin_.p);
-            hipLaunchKernelGGL(k_colour_parts, dim3(parts), dim3(CP_T), 0, stream_, jv, (const unsigned*)part_vals_[wherep].p, (const int*)part_begin_.p);
-            perm = part_vals_[wherep].p;
+            PHX_TRY(device_radix_sort_pairs(parts_.keys[0].p, parts_.vals[0].p, parts_.keys[1].p, parts_.vals[1].p, rest, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &wherep));
+            hipLaunchKernelGGL(k_lower_bounds, dim3(grid_for(parts + 1)), dim3(256), 0, stream_, (const unsigned*)parts_.keys[wherep].p, rest, parts, parts_.begin.p);
+            hipLaunchKernelGGL(k_colour_parts, dim3(parts), dim3(CP_T), 0, stream_, jv, (const unsigned*)parts_.vals[wherep].p, (const int*)parts_.begin.p);
+            perm = parts_.vals[wherep].p;
             // the parts' slot ranges per interior class, left by k_jp_place below
-            PHX_TRY(part_ranges_.reserve((size_t)parts * JP_MAX_COLOURS));
-            PHX_HIP(hipMemsetAsync(part_ranges_.p, 0, (size_t)parts * JP_MAX_COLOURS * sizeof(int4), stream_));
+            PHX_TRY(parts_.ranges.reserve((size_t)parts * JP_MAX_COLOURS));
+            PHX_HIP(hipMemsetAsync(parts_.ranges.p, 0, (size_t)parts * JP_MAX_COLOURS * sizeof(int4), stream_));
         }
-        PHX_TRY(device_exclusive_scan(jp_offset_.p, nb + 1, nullptr, sort_scan_, stream_));
+        PHX_TRY(device_exclusive_scan(bld_.jp_offset.p, nb + 1, nullptr, bld_.sort_scan, stream_));
         hipLaunchKernelGGL(k_jp_fill, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);
         hipLaunchKernelGGL(k_jp_lists, dim3(std::max(1, std::min(div_up(2 * rest, 256), 8192))), dim3(256), 0, stream_, jv);
         {   // round 0's frontier: flags, scan, compaction
-            PHX_TRY(jp_seed_.reserve((size_t)njs + 1));
-            hipLaunchKernelGGL(k_jp_seed_flags, dim3(grid_for(rest + 1)), dim3(256), 0, stream_, jv, jp_seed_.p);
-            PHX_TRY(device_exclusive_scan(jp_seed_.p, rest + 1, nullptr, sort_scan_, stream_));
-            hipLaunchKernelGGL(k_jp_seed, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_seed_.p, jp_list_[0].p);
+            PHX_TRY(bld_.jp_seed.reserve((size_t)njs + 1));
+            hipLaunchKernelGGL(k_jp_seed_flags, dim3(grid_for(rest + 1)), dim3(256), 0, stream_, jv, bld_.jp_seed.p);
+            PHX_TRY(device_exclusive_scan(bld_.jp_seed.p, rest + 1, nullptr, bld_.sort_scan, stream_));
+            hipLaunchKernelGGL(k_jp_seed, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)bld_.jp_seed.p, bld_.jp_list[0].p);
         }
         // the rounds: as many as the previous build needed (+2) before the first look at the frontier, then in small batches
         int round = 0;
@@ -639,12 +641,12 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
             const int batch = round == 0 ? std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX) : JP_BATCH;
             if (round + batch > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }           // pathological dependency chain: host builder
             for (int k = 0; k < batch; ++k, ++round)
-                hipLaunchKernelGGL(k_jp_front, dim3(JP_SUBLISTS * std::max(1, std::min(div_up(rest, JP_FRONT_T * JP_ITEMS * JP_SUBLISTS), 64))), dim3(JP_FRONT_T), 0, stream_, jv, round, (const unsigned*)jp_list_[round & 1].p, jp_list_[(round + 1) & 1].p);
+                hipLaunchKernelGGL(k_jp_front, dim3(JP_SUBLISTS * std::max(1, std::min(div_up(rest, JP_FRONT_T * JP_ITEMS * JP_SUBLISTS), 64))), dim3(JP_FRONT_T), 0, stream_, jv, round, (const unsigned*)bld_.jp_list[round & 1].p, bld_.jp_list[(round + 1) & 1].p);
             int flags = 0;
             std::vector<int> sizes(((size_t)batch + 1) * JP_SUBLISTS, 0);                      // the frontiers of this batch's rounds and of the next one
             PHX_TRY(with_fingerprint());
-            PHX_TRY(rb_.add(sizes.data(), jp_counts_.p + (size_t)(round - batch) * JP_SUBLISTS, sizes.size() * sizeof(int), stream_));
-            PHX_TRY(rb_.add(&flags, jp_small_.p, sizeof(int), stream_));
+            PHX_TRY(rb_.add(sizes.data(), bld_.jp_counts.p + (size_t)(round - batch) * JP_SUBLISTS, sizes.size() * sizeof(int), stream_));
+            PHX_TRY(rb_.add(&flags, bld_.jp_small.p, sizeof(int), stream_));
             PHX_TRY(rb_.wait(stream_));
             if (flags & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
             if (flags & 6) { *fallback = true; return PHX_OK; }                               // > 64 colours or a body in thousands of joints: host builder
@@ -660,32 +662,32 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         hipLaunchKernelGGL(k_jp_choose, dim3(grid_for(rest)), dim3(256), 0, stream_, jv);          // sort keys (class, kind) + their histogram
         // bodies touched, static slots: two small scans; one readback with the histogram
         unsigned* hist = jv.hist;
-        PHX_TRY(device_exclusive_scan(jp_touched_.p, nb + 1, nullptr, sort_scan_, stream_));
-        PHX_TRY(hbm_body_list_.reserve(nbs));
-        hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned*)jp_touched_.p, nb, hbm_body_list_.p);
+        PHX_TRY(device_exclusive_scan(bld_.jp_touched.p, nb + 1, nullptr, bld_.sort_scan, stream_));
+        PHX_TRY(hbm_.hbm_body_list.reserve(nbs));
+        hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned*)bld_.jp_touched.p, nb, hbm_.hbm_body_list.p);
         // leaders sorted by (class, kind), stable in joint order (followers behind them all); then every leader places itself
         // and its follower
         // (the sort's input is gathered in part order where there are parts: one 8-bit pass then leaves the interior classes laid out
-        //  part by part; jv.colour IS jp_keys_[0], so the gather goes to the other pair)
+        //  part by part; jv.colour IS bld_.jp_keys[0], so the gather goes to the other pair)
         int where2 = 0;
-        hipLaunchKernelGGL(k_jp_sort_input, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, perm, jp_keys_[1].p, jp_vals_[1].p);
-        PHX_TRY(device_radix_sort_pairs(jp_keys_[1].p, jp_vals_[1].p, jp_keys_[0].p, jp_vals_[0].p, rest, 8, sort_hist_.p, sort_scan_, stream_, &where2));
-        hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)jp_keys_[where2 ^ 1].p, (const unsigned*)jp_vals_[where2 ^ 1].p,
-                           order_.p + lds_slots, lds_slots, perm ? reinterpret_cast<int*>(part_ranges_.p) : (int*)nullptr);
+        hipLaunchKernelGGL(k_jp_sort_input, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, perm, bld_.jp_keys[1].p, bld_.jp_vals[1].p);
+        PHX_TRY(device_radix_sort_pairs(bld_.jp_keys[1].p, bld_.jp_vals[1].p, bld_.jp_keys[0].p, bld_.jp_vals[0].p, rest, 8, bld_.sort_hist.p, bld_.sort_scan, stream_, &where2));
+        hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)bld_.jp_keys[where2 ^ 1].p, (const unsigned*)bld_.jp_vals[where2 ^ 1].p,
+                           hbm_.order.p + lds_slots, lds_slots, perm ? reinterpret_cast<int*>(parts_.ranges.p) : (int*)nullptr);
         unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0;
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
-        PHX_TRY(rb_.add(&h_touched, jp_touched_.p + nb, sizeof h_touched, stream_));
+        PHX_TRY(rb_.add(&h_touched, bld_.jp_touched.p + nb, sizeof h_touched, stream_));
         // static slots (only the HBM path indexes the global static-tag tables)
-        // (a table of its own: the readback batch reads its sources at wait(), so jp_touched_ must stay as it is until then)
-        PHX_TRY(static_slot_.reserve(nbs));
-        unsigned* sflags = jp_degree_.p;                       // per body + 1; the colouring is done with it
-        hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, nb, sflags);
-        PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, sort_scan_, stream_));
-        hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)cc_static_.p, (const unsigned*)sflags, nb, static_slot_.p);
+        // (a table of its own: the readback batch reads its sources at wait(), so bld_.jp_touched must stay as it is until then)
+        PHX_TRY(hbm_.static_slot.reserve(nbs));
+        unsigned* sflags = bld_.jp_degree.p;                       // per body + 1; the colouring is done with it
+        hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)bld_.cc_static.p, nb, sflags);
+        PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, bld_.sort_scan, stream_));
+        hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)bld_.cc_static.p, (const unsigned*)sflags, nb, hbm_.static_slot.p);
         unsigned h_nstatic = 0;
         int h_flags[3] = {0, 0, 0};                            // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI0; [2] KI1
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
-        PHX_TRY(rb_.add(h_flags, jp_small_.p, sizeof h_flags, stream_));
+        PHX_TRY(rb_.add(h_flags, bld_.jp_small.p, sizeof h_flags, stream_));
         PHX_TRY(rb_.wait(stream_));
         if (h_flags[0] & 2) { *fallback = true; return PHX_OK; }
         sc.hbm_interior_classes = h_flags[1] + h_flags[2]; sc.hbm_interior_classes0 = h_flags[1];
@@ -702,22 +704,22 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         if (sc.hbm_colour_offsets.back() != nj) { set_error("HBM group colouring lost joints"); return PHX_ERR_STATE; }
         sc.group_offsets.push_back(nj);
         // k_solve_parts' tables: the classes' slot layout; the parts' ranges were left by k_jp_place, their unit counts by the sort by part
-        part_count_ = 0;
+        parts_.count = 0;
         if (sc.hbm_interior_classes > 0) {
             const int ki = sc.hbm_interior_classes;
             if (!perm || ki >= (int)sc.hbm_class_leaders.size() + 1 || ki > JP_MAX_COLOURS) { set_error("interior classes out of range"); return PHX_ERR_STATE; }
             int interior_leaders = 0;
             PHX_TRY(upload_class_tab(sc, &interior_leaders));
-            part_count_ = parts;
+            parts_.count = parts;
         }
-        PHX_TRY(sb_imp_.reserve(nbs)); PHX_TRY(sb_disp_.reserve(nbs));
-        PHX_TRY(q0_.reserve(njs)); PHX_TRY(q1_.reserve(njs)); PHX_TRY(q2_.reserve(njs)); PHX_TRY(q3_.reserve(njs)); PHX_TRY(qn_.reserve(njs));
-        PHX_TRY(acc_.reserve(njs)); PHX_TRY(dd_.reserve(njs));
+        PHX_TRY(hbm_.sb_imp.reserve(nbs)); PHX_TRY(hbm_.sb_disp.reserve(nbs));
+        PHX_TRY(hbm_.q0.reserve(njs)); PHX_TRY(hbm_.q1.reserve(njs)); PHX_TRY(hbm_.q2.reserve(njs)); PHX_TRY(hbm_.q3.reserve(njs)); PHX_TRY(hbm_.qn.reserve(njs));
+        PHX_TRY(hbm_.acc.reserve(njs)); PHX_TRY(hbm_.dd.reserve(njs));
     }
-    PHX_TRY(sw_.reserve(4 * (size_t)std::max(nstatic_, 1)));
+    PHX_TRY(hbm_.sw.reserve(4 * (size_t)std::max(nstatic_, 1)));
     // new table for this solve — already cleared by this solve's fingerprint kernel unless it has just been (re)allocated
-    if (sw_.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
-        PHX_HIP(hipMemsetAsync(sw_.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
+    if (hbm_.sw.p != sw_cleared_ || 4 * (size_t)std::max(nstatic_, 1) > sw_cleared_words_)
+        PHX_HIP(hipMemsetAsync(hbm_.sw.p, 0, 4 * (size_t)std::max(nstatic_, 1) * sizeof(unsigned), stream_));
     lap("rest");
     // the next rebuild may skip the host altogether (build_bins_speculative) if this one was nothing but bins of one shape
     spec_bins_ok_ = want_islands && rest == 0 && nbins > 0 && ncomp_total <= BINC_MAX;
@@ -740,14 +742,14 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     // every joint's bodies ended up under one label is checked by k_joint_components, which reads those labels anyway
     const int pairs = std::max(1, std::min(cc_pairs_guess_, 16) - 1);
     for (int k = 0; k < pairs; ++k) {
-        hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, cc_parent_.p, sb_small_.p,
-                           (const int*)partner_first_.p, ncp_, k == 0 ? partner_.p : (int*)nullptr);
-        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, cc_parent_.p, nb, k == pairs - 1 ? sb_small_.p : (int*)nullptr);
+        hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, bld_.sb_small.p,
+                           (const int*)bld_.partner_first.p, ncp_, k == 0 ? bld_.partner.p : (int*)nullptr);
+        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, k == pairs - 1 ? bld_.sb_small.p : (int*)nullptr);
     }
-    PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)cc_parent_.p, nb, comp_size_.p, comp_units_.p}, cc_flags_.p, nb + 1,
-                                     reinterpret_cast<unsigned*>(sb_small_.p + 1), sort_scan_, stream_));
-    hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)cc_parent_.p,
-                       (const unsigned*)cc_flags_.p, (const int*)partner_.p, joint_comp_.p, comp_size_.p, comp_units_.p, sb_small_.p);
+    PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
+                                     reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
+    hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
+                       (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
     // (workgroups beyond the real bin count leave at once, and a settling world doubles its bins within a few steps — columns
     //  break in two: a roomy grid costs nothing, a grid too small costs a repeated solve)
     // (up to 2047 bins the joints are grouped by ONE 11-bit radix pass — three launches instead of six — so a grid just above
@@ -755,34 +757,34 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     int grid = 2 * spec_bins_guess_ + 64;
     if (grid > 2047 && spec_bins_guess_ + spec_bins_guess_ / 4 + 16 <= 2047) grid = 2047;
     const int cap_units = spec_lanes_, cap_bodies = cap_units > ISL_T ? ISL_B_BIG : ISL_B;
-    PHX_TRY(bin_tables_.reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
-    PHX_TRY(bin_result_.reserve(16));
+    PHX_TRY(bld_.bin_tables.reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
+    PHX_TRY(bld_.bin_result.reserve(16));
     BinCompView cv{};
-    cv.comp_size = comp_size_.p; cv.comp_units = comp_units_.p; cv.cc_small = sb_small_.p; cv.nj = nj;
+    cv.comp_size = bld_.comp_size.p; cv.comp_units = bld_.comp_units.p; cv.cc_small = bld_.sb_small.p; cv.nj = nj;
     cv.cap_units = cap_units; cv.small_units = ISL_T; cv.max_bins = grid;
-    cv.bin_of = bin_tables_.p; cv.rank_of = bin_tables_.p + BINC_MAX; cv.goff = bin_tables_.p + 2 * BINC_MAX;
-    cv.result = bin_result_.p;
-    cv.fingerprint = hash_.p + hash_slot_; cv.hash_out = reinterpret_cast<unsigned long long*>(bin_result_.p + 8);
+    cv.bin_of = bld_.bin_tables.p; cv.rank_of = bld_.bin_tables.p + BINC_MAX; cv.goff = bld_.bin_tables.p + 2 * BINC_MAX;
+    cv.result = bld_.bin_result.p;
+    cv.fingerprint = hash_.p + hash_slot_; cv.hash_out = reinterpret_cast<unsigned long long*>(bld_.bin_result.p + 8);
     gate_expected_ = 0x5EED000000000000ull | (++gate_serial_ & 0xFFFFFFFFFFFFull);
     cv.gate = gate_expected_;
     hipLaunchKernelGGL(k_bin_components, dim3(1), dim3(BINC_T), 0, stream_, cv);
-    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)joint_comp_.p, (const int*)cv.bin_of, nj, grid,
-                       sort_keys_[0].p, sort_vals_[0].p, sb_small_.p + 2, BINC_MAX);
+    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
+                       bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX);
     int bits = 1, where = 0;
     while ((1 << bits) <= grid) ++bits;
-    PHX_TRY(device_radix_sort_pairs(sort_keys_[0].p, sort_vals_[0].p, sort_keys_[1].p, sort_vals_[1].p, nj, bits, sort_hist_.p, sort_scan_, stream_, &where));
-    PHX_TRY(grp_desc_.reserve(grid)); PHX_TRY(grp_ncol_.reserve(grid));
-    PHX_TRY(grp_bodies_.reserve((size_t)grid * cap_bodies));
-    PHX_TRY(slot_local_.reserve(nj)); PHX_TRY(slot_colour_.reserve(nj));
-    PHX_TRY(grp_units_.reserve(grid)); PHX_TRY(unit_recs_.reserve(2 * (size_t)grid * cap_units));
+    PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where));
+    PHX_TRY(isl_.desc.reserve(grid)); PHX_TRY(isl_.ncol.reserve(grid));
+    PHX_TRY(isl_.bodies.reserve((size_t)grid * cap_bodies));
+    PHX_TRY(isl_.slot_local.reserve(nj)); PHX_TRY(isl_.slot_colour.reserve(nj));
+    PHX_TRY(isl_.units.reserve(grid)); PHX_TRY(isl_.unit_recs.reserve(2 * (size_t)grid * cap_units));
     BinBuildView bv{};
-    bv.sorted_joints = sort_vals_[where].p; bv.group_offsets = cv.goff; bv.joints = d_joints; bv.partner = partner_.p; bv.is_static = cc_static_.p;
-    bv.joint_comp = joint_comp_.p; bv.comp_rank = cv.rank_of;
+    bv.sorted_joints = bld_.sort_vals[where].p; bv.group_offsets = cv.goff; bv.joints = d_joints; bv.partner = bld_.partner.p; bv.is_static = bld_.cc_static.p;
+    bv.joint_comp = bld_.joint_comp.p; bv.comp_rank = cv.rank_of;
     bv.nb = nb; bv.max_static = 1 << 30;
-    bv.order = order_.p; bv.slot_local = slot_local_.p; bv.slot_colour = slot_colour_.p; bv.desc = grp_desc_.p; bv.ncol = grp_ncol_.p;
-    bv.units = grp_units_.p; bv.unit_recs = unit_recs_.p;
-    bv.bodies = grp_bodies_.p; bv.rejected = sb_small_.p + 2; bv.poison = hash_.p + hash_slot_;
-    bv.nbins_dev = bin_result_.p;
+    bv.order = hbm_.order.p; bv.slot_local = isl_.slot_local.p; bv.slot_colour = isl_.slot_colour.p; bv.desc = isl_.desc.p; bv.ncol = isl_.ncol.p;
+    bv.units = isl_.units.p; bv.unit_recs = isl_.unit_recs.p;
+    bv.bodies = isl_.bodies.p; bv.rejected = bld_.sb_small.p + 2; bv.poison = hash_.p + hash_slot_;
+    bv.nbins_dev = bld_.bin_result.p;
     if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(grid), dim3(2 * ISL_T_BIG), 0, stream_, bv);
     else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(grid), dim3(2 * ISL_T), 0, stream_, bv);
     PHX_HIP(hipGetLastError());
@@ -793,7 +795,7 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     sc.lds_colours = sched_.lds_colours; sc.hbm_body_count = 0;
     grp_body_count_.clear();
     nstatic_ = 0;
-    PHX_TRY(sw_.reserve(4));      // (the HBM path's static-tag table: a schedule of nothing but LDS groups never reads it — no clearing dispatch)
+    PHX_TRY(hbm_.sw.reserve(4));      // (the HBM path's static-tag table: a schedule of nothing but LDS groups never reads it — no clearing dispatch)
     build_unverified_ = true;
     unverified_bins_ = grid;
     spec_bins_pending_ = true;
@@ -810,10 +812,10 @@ int DeviceSolver::materialise_schedule()
     std::vector<int> order(std::max(nj_, 1)), ncol(std::max(lg, 1));
     std::vector<unsigned char> colour(std::max(lds_slots, 1));
     PHX_TRY(use_device(device_));
-    if (nj_) PHX_HIP(hipMemcpy(order.data(), order_.p, (size_t)nj_ * sizeof(int), hipMemcpyDeviceToHost));
+    if (nj_) PHX_HIP(hipMemcpy(order.data(), hbm_.order.p, (size_t)nj_ * sizeof(int), hipMemcpyDeviceToHost));
     if (lds_slots) {
-        PHX_HIP(hipMemcpy(colour.data(), slot_colour_.p, (size_t)lds_slots, hipMemcpyDeviceToHost));
-        PHX_HIP(hipMemcpy(ncol.data(), grp_ncol_.p, (size_t)lg * sizeof(int), hipMemcpyDeviceToHost));
+        PHX_HIP(hipMemcpy(colour.data(), isl_.slot_colour.p, (size_t)lds_slots, hipMemcpyDeviceToHost));
+        PHX_HIP(hipMemcpy(ncol.data(), isl_.ncol.p, (size_t)lg * sizeof(int), hipMemcpyDeviceToHost));
     }
     sched_.order.assign(order.begin(), order.begin() + nj_);
     sched_.colour_offsets.assign(1, 0);
@@ -840,7 +842,7 @@ int DeviceSolver::materialise_schedule()
 // class_tab[c] = {first slot, leaders, followers, leaders of the classes before c} of the HBM group's classes (k_solve_parts)
 int DeviceSolver::upload_class_tab(const Schedule& sc, int* interior_leaders)
 {
-    std::vector<int4>& tab = class_tab_host_;          // (a member: the copy below is asynchronous)
+    std::vector<int4>& tab = parts_.class_tab_host;          // (a member: the copy below is asynchronous)
     tab.assign(sc.hbm_class_leaders.size(), make_int4(0, 0, 0, 0));
     int before = 0;
     *interior_leaders = 0;
@@ -850,26 +852,26 @@ int DeviceSolver::upload_class_tab(const Schedule& sc, int* interior_leaders)
         before += lead;
         if ((int)c < sc.hbm_interior_classes) *interior_leaders = before;
     }
-    PHX_TRY(hbm_class_tab_.reserve(std::max<size_t>(tab.size(), 64)));
-    PHX_HIP(hipMemcpyAsync(hbm_class_tab_.p, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
+    PHX_TRY(parts_.class_tab.reserve(std::max<size_t>(tab.size(), 64)));
+    PHX_HIP(hipMemcpyAsync(parts_.class_tab.p, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
     return PHX_OK;
 }
 
 // host-built schedules: the interior units by part as the builder left them (schedule.hip build_part_tables)
 int DeviceSolver::upload_part_tables()
 {
-    part_count_ = 0;
+    parts_.count = 0;
     const int ki = sched_.hbm_interior_classes;
     if (ki <= 0 || sched_.part_begin.empty()) return PHX_OK;      // (more than 64 interior classes: no tables, one launch per class)
     int interior_leaders = 0;
     PHX_TRY(upload_class_tab(sched_, &interior_leaders));
     if (interior_leaders != sched_.part_begin.back()) { set_error("part tables do not match the interior classes"); return PHX_ERR_STATE; }
     const size_t parts = sched_.part_begin.size() - 1;
-    PHX_TRY(part_ranges_.reserve(parts * PARTS_CLASS_STRIDE)); PHX_TRY(part_begin_.reserve(parts + 2));
-    PHX_HIP(hipMemcpyAsync(part_ranges_.p, sched_.part_ranges.data(), sched_.part_ranges.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-    PHX_HIP(hipMemcpyAsync(part_begin_.p, sched_.part_begin.data(), sched_.part_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_TRY(parts_.ranges.reserve(parts * PARTS_CLASS_STRIDE)); PHX_TRY(parts_.begin.reserve(parts + 2));
+    PHX_HIP(hipMemcpyAsync(parts_.ranges.p, sched_.part_ranges.data(), sched_.part_ranges.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PHX_HIP(hipMemcpyAsync(parts_.begin.p, sched_.part_begin.data(), sched_.part_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
     PHX_HIP(hipStreamSynchronize(stream_));
-    part_count_ = (int)parts;
+    parts_.count = (int)parts;
     return PHX_OK;
 }
 
@@ -882,10 +884,10 @@ int DeviceSolver::enqueue_pre(const BodyView& d_bodies, int nb, const phx_contac
     // PreStep class by class.  Groups solved in LDS read and write the caller's records directly.
     const int hbm_bodies = sched_.hbm_body_count;
     if (nj && owns_hbm_group()) {
-        hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, d_bodies, (const int*)hbm_body_list_.p,
-                           hbm_bodies, sb_imp_.p, sb_disp_.p, v.stamps);
+        hipLaunchKernelGGL(k_unpack_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, d_bodies, (const int*)hbm_.hbm_body_list.p,
+                           hbm_bodies, hbm_.sb_imp.p, hbm_.sb_disp.p, v.stamps);
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
-        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, static_slot_.p);
+        hipLaunchKernelGGL(k_pack_refresh, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints, d_cps, hbm_.static_slot.p);
         size_t c0 = 0;
         if (parts_in_use()) {          // the interior classes of partitioned components: one launch per level, a workgroup per part
             for (int level = 0; level < part_levels(); ++level) {
@@ -916,42 +918,42 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
     if (mine) {   // every LDS group: Refresh + PreStep + all sweeps in one launch, one workgroup per group
         IslandView iv{};
         iv.group_list = shard_count_ > 1 ? grp_mine_.p : nullptr;
-        iv.ngroups_dev = spec_bins_pending_ ? bin_result_.p : nullptr;
+        iv.ngroups_dev = spec_bins_pending_ ? bld_.bin_result.p : nullptr;
         iv.stamp_begin = iv.stamp_end = owns_hbm_group() ? 0 : 1;      // (with an HBM group, its first and last kernels leave the stamps)
-        iv.desc = grp_desc_.p; iv.ncol = grp_ncol_.p; iv.units = grp_units_.p; iv.unit_recs = unit_recs_.p; iv.bodies = grp_bodies_.p;
-        iv.executed = isl_stats_.p + (size_t)hash_slot_ * STATS_SET; iv.visits = isl_visits_.p + (size_t)hash_slot_ * VISITS_SET;
+        iv.desc = isl_.desc.p; iv.ncol = isl_.ncol.p; iv.units = isl_.units.p; iv.unit_recs = isl_.unit_recs.p; iv.bodies = isl_.bodies.p;
+        iv.executed = isl_.stats.p + (size_t)hash_slot_ * STATS_SET; iv.visits = isl_.visits.p + (size_t)hash_slot_ * VISITS_SET;
         iv.trace = nullptr; iv.wave_trace = nullptr;
         // how the launch is gated (island_view.h).  A launch whose grid is only an upper bound of the group count (speculative
         // binning) is gated by the build it follows.
         iv.mode = mode_override >= 0 ? mode_override : isl_mode_;
         iv.nexpect = isl_nexpect_; iv.ctl = hash_.p + hash_slot_; iv.epoch = solve_epoch_;
-        iv.shards = isl_shards_.p + (size_t)hash_slot_ * SHARDS_SET;
-        iv.wait_polls = isl_wait_polls_;
+        iv.shards = isl_.shards.p + (size_t)hash_slot_ * SHARDS_SET;
+        iv.wait_polls = opt_.isl_wait_polls;
         if (iv.mode != ISL_GATED) {
-            if (isl_done_.cap < (size_t)lg) {      // (a new table: no group carries any epoch)
-                if (isl_done_.reserve((size_t)std::max(lg, 1)) != PHX_OK) return PHX_ERR_HIP;
-                PHX_HIP(hipMemsetAsync(isl_done_.p, 0, isl_done_.cap * sizeof(unsigned), stream_));
+            if (isl_.done.cap < (size_t)lg) {      // (a new table: no group carries any epoch)
+                if (isl_.done.reserve((size_t)std::max(lg, 1)) != PHX_OK) return PHX_ERR_HIP;
+                PHX_HIP(hipMemsetAsync(isl_.done.p, 0, isl_.done.cap * sizeof(unsigned), stream_));
             }
-            iv.done = isl_done_.p;
+            iv.done = isl_.done.p;
         }
         if (island_clears_next_) {                 // no hash pass in front: this launch is the solve's first kernel
             const int next = hash_slot_ ^ 1;
-            iv.next_ctl = hash_.p + next; iv.next_executed = isl_stats_.p + (size_t)next * STATS_SET; iv.next_visits = isl_visits_.p + (size_t)next * VISITS_SET;
-            iv.next_shards = isl_shards_.p + (size_t)next * SHARDS_SET;
+            iv.next_ctl = hash_.p + next; iv.next_executed = isl_.stats.p + (size_t)next * STATS_SET; iv.next_visits = isl_.visits.p + (size_t)next * VISITS_SET;
+            iv.next_shards = isl_.shards.p + (size_t)next * SHARDS_SET;
             island_clears_next_ = false;
         }
         if (trace_islands_) {
             // 8 words per group, then 8 words per wave (16 waves at most) of every group
-            if (isl_trace_.reserve((size_t)std::max(lg, 1) * (8 + 128)) != PHX_OK) return PHX_ERR_HIP;
-            PHX_HIP(hipMemsetAsync(isl_trace_.p, 0, (size_t)lg * (8 + 128) * sizeof(unsigned long long), stream_));
-            iv.trace = isl_trace_.p;
-            iv.wave_trace = isl_trace_.p + (size_t)lg * 8;
+            if (isl_.trace.reserve((size_t)std::max(lg, 1) * (8 + 128)) != PHX_OK) return PHX_ERR_HIP;
+            PHX_HIP(hipMemsetAsync(isl_.trace.p, 0, (size_t)lg * (8 + 128) * sizeof(unsigned long long), stream_));
+            iv.trace = isl_.trace.p;
+            iv.wave_trace = isl_.trace.p + (size_t)lg * 8;
         }
         const bool big = sched_.lds_lanes > ISL_T;
         // A schedule with LDS islands AND an HBM group (a world that is merging, or settled around a few loose stacks): the island
         // launch is one group's chain of class steps — ~90 us whatever the group count — and touches nothing the HBM group's
         // classes x sweeps launches touch, so it runs beside them on a second stream: fork here, join behind the sweeps.
-        forked = owns_hbm_group() && !use_graphs_ && !no_side_stream_ && !trace_islands_ && side_stream_;
+        forked = owns_hbm_group() && !opt_.use_graphs && !opt_.no_side_stream && !trace_islands_ && side_stream_;
         if (forked) {
             PHX_HIP(hipEventRecord(ev_fork_, stream_));
             PHX_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
@@ -1004,7 +1006,7 @@ int DeviceSolver::enqueue_post(const BodyView& d_bodies, int nb, phx_contact_joi
         const int hb = sched_.hbm_begin(), he = sched_.hbm_end();
         const int hbm_bodies = sched_.hbm_body_count;
         hipLaunchKernelGGL(k_finish_joints, dim3(grid_for(he - hb)), dim3(256), 0, stream_, v, hb, he, d_joints);
-        hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, v, (const int*)hbm_body_list_.p, hbm_bodies, d_bodies);
+        hipLaunchKernelGGL(k_finish_bodies, dim3(grid_for(hbm_bodies)), dim3(256), 0, stream_, v, (const int*)hbm_.hbm_body_list.p, hbm_bodies, d_bodies);
     }
     (void)nb;
     PHX_HIP(hipGetLastError());
@@ -1049,10 +1051,10 @@ int DeviceSolver::enqueue(const Arrays& arrays, int nb, const phx_contact_point*
     if (shard_count_ > 1) PHX_TRY(ensure_partition());       // which groups this rank solves (before anything asks owns_hbm_group())
     const int ci = cfg.contact_iterations, pi = cfg.penetration_iterations;
     const int iters = std::max(ci, pi);
-    if (iters + 1 > max_iters_ || !flags_.p) {
+    if (iters + 1 > max_iters_ || !hbm_.flags.p) {
         max_iters_ = std::max(iters + 1, 64);
-        PHX_TRY(flags_.reserve(2 * (size_t)max_iters_));
-        PHX_HIP(hipMemsetAsync(flags_.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
+        PHX_TRY(hbm_.flags.reserve(2 * (size_t)max_iters_));
+        PHX_HIP(hipMemsetAsync(hbm_.flags.p, 0, 2 * (size_t)max_iters_ * sizeof(int), stream_));
         drop_graphs();
     }
     GraphKey key;
@@ -1060,7 +1062,7 @@ int DeviceSolver::enqueue(const Arrays& arrays, int nb, const phx_contact_point*
     key.schedule_version = schedule_version_; key.valid = true;
     // graphs pay off from the second solve of an unchanged (schedule, buffers, iteration counts) tuple on
     const bool have = graph_key_.valid && graph_key_ == key;
-    if (!have && use_graphs_ && last_key_.valid && last_key_ == key) PHX_TRY(capture_graphs(key, d_bodies, d_cps, d_joints));
+    if (!have && opt_.use_graphs && last_key_.valid && last_key_ == key) PHX_TRY(capture_graphs(key, d_bodies, d_cps, d_joints));
     last_key_ = key;
     const bool replay = graph_key_.valid && graph_key_ == key;
 
@@ -1174,10 +1176,10 @@ int DeviceSolver::solve_common(const Arrays& a, int nb, const void* d_cps, int n
     cur_ = a;
     const float4* mpos = a.view.mpos;
     const phx_contact_joint* joints = static_cast<const phx_contact_joint*>(d_joints);
-    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !no_islands_;
+    const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !opt_.no_islands;
     if (!reuse_schedule_) topology_changed = true;       // live-topology measurements: rebuild like the reference does every call (ref: Solver.cpp:77, 135)
     bool armed = false;
-    if (!topology_changed && speculate_ && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
+    if (!topology_changed && opt_.speculate && sched_.valid && nb == nb_ && nj == nj_ && ncp == ncp_ && sched_.islands == want_islands) {
         // Same sizes as the schedule in hand: run on it without a host round trip.  Every kernel that writes to the caller's
         // arrays commits only behind the solve's gate — the island launch's own check of the schedule against the arrays
         // (ISL_VERIFY, island_view.h), or the topology hash pass queued in front (ISL_GATED) — and synchronize() reads the
@@ -1243,17 +1245,17 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
         if (spec_bins_pending_) {                      // speculative binning: what the build's round trip would have brought
             goff.assign((size_t)unverified_bins_ + 1, 0);
             comp_size.assign((size_t)std::min(std::min(BINC_MAX, nb_), std::max(1024, ncomp_guess_ + ncomp_guess_ / 4)), 0u);
-            PHX_TRY(rb_.add(spec, bin_result_.p, sizeof spec, stream_));
-            PHX_TRY(rb_.add(goff.data(), bin_tables_.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
-            if (!comp_size.empty()) PHX_TRY(rb_.add(comp_size.data(), comp_size_.p, comp_size.size() * sizeof(unsigned), stream_));
+            PHX_TRY(rb_.add(spec, bld_.bin_result.p, sizeof spec, stream_));
+            PHX_TRY(rb_.add(goff.data(), bld_.bin_tables.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
+            if (!comp_size.empty()) PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, comp_size.size() * sizeof(unsigned), stream_));
         }
-        return rb_.add(ncol.data(), grp_ncol_.p, ncol.size() * sizeof(int), stream_);
+        return rb_.add(ncol.data(), isl_.ncol.p, ncol.size() * sizeof(int), stream_);
     };
     auto rest_of_sizes = [&]() -> int {                // more components than last time (+ 25 %): fetch the rest
         if (!build_unverified_ || !spec_bins_pending_ || spec[4] != 0 || (size_t)spec[5] <= comp_size.size()) return PHX_OK;
         const size_t have = comp_size.size();
         comp_size.resize((size_t)spec[5], 0u);
-        PHX_TRY(rb_.add(comp_size.data() + have, comp_size_.p + have, (comp_size.size() - have) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_size.data() + have, bld_.comp_size.p + have, (comp_size.size() - have) * sizeof(unsigned), stream_));
         return rb_.wait(stream_);
     };
     auto settle_build = [&]() {
@@ -1263,7 +1265,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
         if (spec_bins_pending_) {
             spec_bins_pending_ = false;
             spec_bins_failed_ = spec[4] != 0;
-            if ((trace_schedule_ || getenv("PHX_TRACE_SPEC")) && spec_bins_failed_) fprintf(stderr, "[schedule/gpu] speculative binning spoiled: bits %d (%d components, %d bins, grid %d)\n", spec[4], spec[5], spec[6], unverified_bins_);
+            if ((opt_.trace_schedule || getenv("PHX_TRACE_SPEC")) && spec_bins_failed_) fprintf(stderr, "[schedule/gpu] speculative binning spoiled: bits %d (%d components, %d bins, grid %d)\n", spec[4], spec[5], spec[6], unverified_bins_);
             if (spec_bins_failed_) { spec_bins_ok_ = false; return; }      // (the fingerprint word is spoiled: synchronize() rebuilds)
             const int nbins = std::min(spec[0], unverified_bins_);
             unsigned long long hash = 0;
@@ -1304,11 +1306,11 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     int isl_slots[2 * ISL_STAT_SLOTS] = {0};
     unsigned long long visit_slots[ISL_STAT_SLOTS] = {0};
     if (extra) PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_));
-    PHX_TRY(rb_.add(flags.data(), flags_.p, flags.size() * sizeof(int), stream_));
-    PHX_TRY(rb_.add(isl_slots, isl_stats_.p + (size_t)hash_slot_ * STATS_SET, sizeof isl_slots, stream_));
+    PHX_TRY(rb_.add(flags.data(), hbm_.flags.p, flags.size() * sizeof(int), stream_));
+    PHX_TRY(rb_.add(isl_slots, isl_.stats.p + (size_t)hash_slot_ * STATS_SET, sizeof isl_slots, stream_));
     unsigned long long stamps[2] = {0, 0};
-    PHX_TRY(rb_.add(visit_slots, isl_visits_.p + (size_t)hash_slot_ * VISITS_SET, sizeof visit_slots, stream_));
-    PHX_TRY(rb_.add(stamps, isl_visits_.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS, sizeof stamps, stream_));
+    PHX_TRY(rb_.add(visit_slots, isl_.visits.p + (size_t)hash_slot_ * VISITS_SET, sizeof visit_slots, stream_));
+    PHX_TRY(rb_.add(stamps, isl_.visits.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS, sizeof stamps, stream_));
     PHX_TRY(with_build());
     PHX_TRY(rb_.wait(stream_));
     PHX_TRY(rest_of_sizes());
@@ -1373,7 +1375,7 @@ int DeviceSolver::synchronize()
             // every workgroup arrived and found the schedule correct, but some gave up waiting for the others: finish their groups
             // (and stop checking the schedule inside the launch on this handle: whatever delayed them — a GPU shared with somebody
             //  else's kernels — makes every such solve a ~20 ms cliff; the hash-gated form has no wait between workgroups)
-            no_fused_verify_ = true;
+            opt_.no_fused_verify = true;
             stats_pending_ = true;
             ++replays_;                                // (callers that queued work behind the solve's gate repeat it)
             pending_ = p;
@@ -1436,9 +1438,9 @@ int DeviceSolver::get_island_trace(unsigned long long* out, int cap_groups, int*
     const int lg = sched_.valid ? sched_.lds_groups : 0;
     if (groups) *groups = lg;
     if (!out) return PHX_OK;
-    if (!trace_islands_ || !isl_trace_.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
+    if (!trace_islands_ || !isl_.trace.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
     if (cap_groups < lg) { set_error("island trace buffer too small"); return PHX_ERR_CAPACITY; }
-    if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p, (size_t)lg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (lg) PHX_HIP(hipMemcpy(out, isl_.trace.p, (size_t)lg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
 
@@ -1449,9 +1451,9 @@ int DeviceSolver::get_wave_trace(unsigned long long* out, int cap_words, int* wa
     const int wpg = sched_.lds_lanes > ISL_T ? ISL_T_BIG / 64 : ISL_T / 64;
     if (waves_per_group) *waves_per_group = wpg;
     if (!out) return PHX_OK;
-    if (!trace_islands_ || !isl_trace_.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
+    if (!trace_islands_ || !isl_.trace.p) { set_error("island trace is off (phx_solver_set_trace)"); return PHX_ERR_STATE; }
     if (cap_words < lg * wpg * 8) { set_error("wave trace buffer too small"); return PHX_ERR_CAPACITY; }
-    if (lg) PHX_HIP(hipMemcpy(out, isl_trace_.p + (size_t)lg * 8, (size_t)lg * wpg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (lg) PHX_HIP(hipMemcpy(out, isl_.trace.p + (size_t)lg * 8, (size_t)lg * wpg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PHX_OK;
 }
 
@@ -1503,12 +1505,12 @@ int DeviceSolver::get_refreshed(int joint, float out[30])
         return PHX_ERR_STATE;
     }
     float4 a, f, c; int4 k; float2 acc, d;
-    PHX_HIP(hipMemcpy(&a, q0_.p + slot, sizeof a, hipMemcpyDeviceToHost));
-    PHX_HIP(hipMemcpy(&f, q1_.p + slot, sizeof f, hipMemcpyDeviceToHost));
-    PHX_HIP(hipMemcpy(&c, q2_.p + slot, sizeof c, hipMemcpyDeviceToHost));
-    PHX_HIP(hipMemcpy(&k, q3_.p + slot, sizeof k, hipMemcpyDeviceToHost));
-    PHX_HIP(hipMemcpy(&acc, acc_.p + slot, sizeof acc, hipMemcpyDeviceToHost));
-    PHX_HIP(hipMemcpy(&d, dd_.p + slot, sizeof d, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&a, hbm_.q0.p + slot, sizeof a, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&f, hbm_.q1.p + slot, sizeof f, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&c, hbm_.q2.p + slot, sizeof c, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&k, hbm_.q3.p + slot, sizeof k, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&acc, hbm_.acc.p + slot, sizeof acc, hipMemcpyDeviceToHost));
+    PHX_HIP(hipMemcpy(&d, hbm_.dd.p + slot, sizeof d, hipMemcpyDeviceToHost));
     float ii2; std::memcpy(&ii2, &k.x, 4);
     const float im1 = c.y, ii1 = c.z, im2 = c.w;
     const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
@@ -1602,7 +1604,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     } sweep_events(*this);
     int st = PHX_OK;
     struct InLoop { DeviceSolver& s; explicit InLoop(DeviceSolver& s_) : s(s_) { s.in_bench_loop_ = true; } ~InLoop() { s.in_bench_loop_ = false; } } in_loop(*this);
-    struct Trusted { DeviceSolver& s; Trusted(DeviceSolver& s_, bool on) : s(s_) { s.bench_trusted_ = on; } ~Trusted() { s.bench_trusted_ = false; } } trusted(*this, staged && reuse_schedule_ && speculate_);
+    struct Trusted { DeviceSolver& s; Trusted(DeviceSolver& s_, bool on) : s(s_) { s.bench_trusted_ = on; } ~Trusted() { s.bench_trusted_ = false; } } trusted(*this, staged && reuse_schedule_ && opt_.speculate);
     PHX_HIP(hipEventRecord(bench_events_[2 * steps], stream_));
     // HIP events bracket the sweep launches of every 4th step only: an event record is a barrier packet of its own (~3 us of idle
     // queue), and bracketing every step's sweeps cost 6.4 us per step — 7 % of the value being measured (tools/exp_events.py)
