@@ -3,7 +3,7 @@
 // The schedule is a pure function of the joints' body pairs and of which bodies are static (schedule.h).  The
 // host builder (schedule.hip) is the specification; this file produces the SAME schedule — same groups, same
 // colours, same slot order (tests compare the two) — without pulling the joint list over PCIe:
-//   connected components   min-label hooking + pointer jumping over the joint list
+//   connected components   one linking pass over the joint list (atomicMin chains) + one flattening pass
 //                          (the device form of the union-find of ref: Solver.cpp:275-323)
 //   numbering              components numbered by their smallest body index (= body order, ref: Solver.cpp:344-356)
 //   binning                greedy over consecutive components — ncomp integers, done on the host
@@ -34,8 +34,7 @@ static __global__ void __launch_bounds__(256) k_cc_init(const float4* __restrict
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncp; i += gridDim.x * blockDim.x) first[i] = 0x7f7f7f7f;
 }
 
-// every joint between two dynamic bodies hooks the larger of the two current labels under the smaller
-// (`first` / `partner`, if not null — the first round: also pairs the joints into units, schedule.h; the table is complete, k_partner_first ran)
+// (`first` / `partner`: the joints are paired into units on the way, schedule.h; the table is complete, k_partner_first ran)
 __device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ joints, int j, const phx_contact_joint& me, int ncp, const int* __restrict__ first)
 {
     const unsigned id = (unsigned)me.contact_point_index;
@@ -46,27 +45,43 @@ __device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ 
     return (o.body1 == me.body1 && o.body2 == me.body2) ? other : -1;
 }
 
-static __global__ void __launch_bounds__(256) k_cc_hook(const phx_contact_joint* __restrict__ joints, int nj, int nb, int* parent, int* __restrict__ changed,
-                                                        const int* __restrict__ first, int ncp, int* __restrict__ partner)
+// Connected components in ONE pass over the joint list: link(hi, lo) = atomicMin(&parent[hi], lo).  If that returns hi, hi was a
+// root and hangs under lo now; if it returns some p < hi, hi hung under p already — it now hangs under min(p, lo) and the thread
+// goes on to link max(p, lo) under min(p, lo), a strictly smaller pair, so it ends.  parent[x] <= x throughout (no cycles), every
+// joint's bodies end in one tree, and a tree's root is its smallest body whatever order the joints ran in — the labels the serial
+// union of ref: Solver.cpp:275-323 has after its numbering by smallest body.  Everything a thread learns about other threads'
+// work it learns from the values its atomics return (the coherent level), never from a cached load: on eight XCDs a find() that
+// walks parent[] by loads either reads stale lines or pays an agent-scope load per hop (measured: 100 us at cfg 2).  Rounds 1-3
+// alternated min-label hooking of the two current ROOTS with full compression until nothing hooked any more: two pairs of
+// launches for stacks, five for a merged world, plus the 'did it converge' readback.
+static __global__ void __launch_bounds__(256) k_cc_link(const phx_contact_joint* __restrict__ joints, int nj, int nb, int* parent,
+                                                        const unsigned char* __restrict__ is_static, const int* __restrict__ first, int ncp, int* __restrict__ partner)
 {
-    bool any = false;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
-        if (partner) partner[j] = partner_of(joints, j, joints[j], ncp, first);
-        const unsigned u = (unsigned)joints[j].body1, v = (unsigned)joints[j].body2;
-        if (u >= (unsigned)nb || v >= (unsigned)nb) continue;          // reported by the fingerprint / validation path
-        const int pu = parent[u], pv = parent[v];
-        if (pu < 0 || pv < 0 || pu == pv) continue;
-        atomicMin(&parent[pu > pv ? pu : pv], pu > pv ? pv : pu);
-        any = true;
+        const phx_contact_joint me = joints[j];
+        const int mate = partner_of(joints, j, me, ncp, first);
+        partner[j] = mate;
+        if (mate >= 0 && (me.contact_point_index & 1)) continue;           // the follower of a unit: its leader links the same two bodies
+        const unsigned u = (unsigned)me.body1, v = (unsigned)me.body2;
+        if (u >= (unsigned)nb || v >= (unsigned)nb || u == v) continue;     // reported by the fingerprint / validation path
+        if (is_static[u] || is_static[v]) continue;                        // a static body joins nothing (ref: Solver.cpp:304)
+        int hi = (int)(u > v ? u : v), lo = (int)(u > v ? v : u);
+        while (true) {
+            const int old = atomicMin(parent + hi, lo);
+            if (old == hi || old == lo) break;
+            hi = old > lo ? old : lo; lo = old > lo ? lo : old;
+        }
     }
-    if (__any(any) && (threadIdx.x & 63) == 0) *changed = 1;
 }
 
-// full path compression: afterwards parent[b] is the representative (smallest label reached so far)
-// (`clear`, if not null: the 'hooked anything' flag, zeroed for the NEXT round's hook — this round's hook has run)
+// full path compression: afterwards parent[b] is the representative (the component's smallest body)
+// (`clear`: the 'labels disagree' flag k_joint_components may raise, zeroed on the way)
+// (Walks that cross read entries their owners are overwriting — old parent or root, an ancestor either way, and mostly the
+//  root: that race is what keeps a 200-box chain from costing 200 loads per box.  Jumping pointers in LDS first, a workgroup
+//  per 1024 consecutive bodies, measured no faster: 14 against 11 us at cfg 2, 26 against 29 at cfg 4.)
 static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb, int* __restrict__ clear)
 {
-    if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         int p = parent[i];
         if (p < 0) continue;

@@ -226,7 +226,7 @@ private:
         return level == 0 ? PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, 0, P, 0, ki0}
                           : PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, P, P + 1, ki0, ki};
     }
-    int jp_rounds_guess_ = 0, cc_pairs_guess_ = 2;
+    int jp_rounds_guess_ = 0;
     // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;
@@ -239,7 +239,6 @@ private:
     const unsigned* sw_cleared_ = nullptr;          // the static-tag table launch_fingerprint's kernel cleared for the solve in flight
     size_t sw_cleared_words_ = 0;
     unsigned replays_ = 0;                          // solves repeated because nothing could be committed (stale or spoiled schedule)
-    unsigned cc_builds_ = 0;
     phx_step_hook step_hook_ = nullptr;  // bench(): called with phase 1 between a step's local preparation and its sweeps
     void* step_hook_user_ = nullptr;
     int step_hook_step_ = 0;

@@ -423,46 +423,30 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     {
     // (Single mode needs the components too: the colouring candidate is chosen per component, schedule.h — it then sends
     //  every component to the HBM group)
-    // 1. connected components: two hook + compress rounds (stacks converge in two, the second one only confirms it), and
-    // 2. the components numbered in body order with their joints counted — queued behind them OPTIMISTICALLY: the 'did the
-    //    last round still hook anything' flag comes back in the same round trip as the component count and sizes, and only
-    //    if it is set (deep island graphs) are more rounds run and the numbering redone.
+    // 1. connected components: one linking pass + one flattening pass (schedule_kernels.h), and
+    // 2. the components numbered in body order with their joints counted; count and sizes come back in one round trip
     unsigned ncomp_u = 0;
     std::vector<unsigned> comp_size, comp_units;
     int guess = 0;
-    int pairs_run = 0;
-    // every 32nd build tries one pair fewer than the last one needed, so that the guess can come down again
-    const bool probe_fewer = (++cc_builds_ & 31) == 0 && cc_pairs_guess_ > 2;
-    if (probe_fewer) --cc_pairs_guess_;
-    for (int round = 0;; round += 2) {
-        if (round > 4 * 32) { set_error("connected components did not converge"); return PHX_ERR_STATE; }
-        int changed = 0;
-        if (round) PHX_HIP(hipMemsetAsync(bld_.sb_small.p, 0, sizeof(int), stream_));        // (the first pair's flag was cleared by k_cc_init)
-        // (the first batch runs as many hook + compress pairs as the previous build needed: a merged world needs four, and
-        //  finding that out two at a time costs a round trip and a second numbering)
-        const int pairs = round == 0 ? std::max(2, std::min(cc_pairs_guess_, 16)) : 2;
-        for (int k = 0; k < pairs; ++k) {
-            const bool pairing = round == 0 && k == 0;      // the first hook also pairs the joints into units
-            hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, bld_.sb_small.p,
-                               (const int*)bld_.partner_first.p, ncp_, pairing ? bld_.partner.p : (int*)nullptr);
-            hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, k == pairs - 2 ? bld_.sb_small.p : (int*)nullptr);
-        }
-        pairs_run += pairs;
+    {
+        hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
+                           (const int*)bld_.partner_first.p, ncp_, bld_.partner.p);
+        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
-                           (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, (int*)nullptr);
+                           (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
         comp_size.assign(std::max(guess, 1), 0u); comp_units.assign(std::max(guess, 1), 0u);
         PHX_TRY(with_fingerprint());
-        int pair[2] = {0, 0};                              // {changed, component count}: adjacent words, one copy
+        int pair[2] = {0, 0};                              // {labels disagree, component count}: adjacent words, one copy
         PHX_TRY(rb_.add(pair, bld_.sb_small.p, sizeof pair, stream_));
         PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.add(comp_units.data(), bld_.comp_units.p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
-        changed = pair[0]; ncomp_u = (unsigned)pair[1];
-        if (!changed) { cc_pairs_guess_ = pairs_run; break; }
+        if (pair[0]) { set_error("connected components: a joint's bodies carry different labels"); return PHX_ERR_STATE; }
+        ncomp_u = (unsigned)pair[1];
     }
     lap("components+count");
     const int ncomp = (int)ncomp_u;
@@ -738,14 +722,9 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
 // (`gate_expected_`), which is what the solve's kernels compare the word with; the hash itself comes back with the results.
 int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
 {
-    // the hook + compress pairs the last build needed, less the one that only confirmed that nothing hooks any more: whether
-    // every joint's bodies ended up under one label is checked by k_joint_components, which reads those labels anyway
-    const int pairs = std::max(1, std::min(cc_pairs_guess_, 16) - 1);
-    for (int k = 0; k < pairs; ++k) {
-        hipLaunchKernelGGL(k_cc_hook, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, bld_.sb_small.p,
-                           (const int*)bld_.partner_first.p, ncp_, k == 0 ? bld_.partner.p : (int*)nullptr);
-        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, k == pairs - 1 ? bld_.sb_small.p : (int*)nullptr);
-    }
+    hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
+                       (const int*)bld_.partner_first.p, ncp_, bld_.partner.p);
+    hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
     PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                      reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
     hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
