@@ -405,13 +405,18 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __syncthreads();
 
     const bool live = tid < count;
-    int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1, cpi = 0;
-    bool follower = false;
+    int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1, cpi = 0, comp = 0;
+    bool follower = false, stat[2] = {false, false};
     if (live) {
+        // (everything the lane will want from memory is asked for here, three dependent levels deep, and arrives while the
+        //  body table is built: fetched where it is used, each of the later loads cost the whole workgroup a trip to memory)
         j = (int)v.sorted_joints[begin + tid];
         const phx_contact_joint jt = v.joints[j];
-        b[0] = jt.body1; b[1] = jt.body2; cpi = jt.contact_point_index;
         mate = v.partner[j];
+        const int jc = v.joint_comp[j];
+        b[0] = jt.body1; b[1] = jt.body2; cpi = jt.contact_point_index;
+        stat[0] = v.is_static[b[0]] != 0; stat[1] = v.is_static[b[1]] != 0;
+        comp = v.comp_rank[jc];
         follower = mate >= 0 && (jt.contact_point_index & 1) != 0;
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s
             unsigned p = ((unsigned)b[s] * 2654435761u) & (HT - 1);
@@ -426,12 +431,11 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     }
     __syncthreads();
     // table leaders = first occurrences; local index = rank among static ones, or n_static + rank among dynamic ones
-    bool lead[2] = {false, false}, stat[2] = {false, false};
+    bool lead[2] = {false, false};
     unsigned mine = 0;                                   // static first occurrences << 16 | dynamic ones
     if (live)
         for (int s = 0; s < 2; ++s) {
             lead[s] = ht_val[hs[s]] == 2 * tid + s;
-            stat[s] = v.is_static[b[s]] != 0;
             if (lead[s]) mine += stat[s] ? 0x10000u : 1u;
         }
     // block exclusive scan of `mine`; the units are counted on the side
@@ -467,11 +471,10 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     for (int i = tid; i < NB; i += LANES) best[i] = 0ull;
     __syncthreads();
     const bool dyn0 = loc[0] >= n_static, dyn1 = loc[1] >= n_static;                  // static bodies sit first in the table
-    const unsigned long long key = unit ? colour_priority((unsigned)v.joints[j].contact_point_index, (unsigned)j) : 0ull;
+    const unsigned long long key = unit ? colour_priority((unsigned)cpi, (unsigned)j) : 0ull;
     bool pending = unit;
     int mycol = 0, mycol_b = 0;
     const bool from_top = ((b[0] < b[1] ? b[0] : b[1]) & 1) != 0;
-    const int comp = live ? v.comp_rank[v.joint_comp[j]] : 0;
     for (;;) {
         if (pending) { if (dyn0) atomicMax(&best[loc[0]], key); if (dyn1) atomicMax(&best[loc[1]], key); }
         __syncthreads();
