@@ -182,8 +182,15 @@ struct MailArgs { MailItem it[16]; int count; unsigned seq; unsigned long long* 
 
 static __global__ void __launch_bounds__(1024) k_post_mail(MailArgs a, unsigned* __restrict__ host_words, unsigned* __restrict__ host_seq)
 {
-    for (int i = 0; i < a.count; ++i)
-        for (unsigned w = threadIdx.x; w < a.it[i].words; w += blockDim.x) host_words[a.it[i].off + w] = a.it[i].src[w];
+    for (int i = 0; i < a.count; ++i) {
+        const unsigned* src = a.it[i].src;
+        unsigned* dst = host_words + a.it[i].off;             // (16-byte aligned: Readback::add)
+        const unsigned words = a.it[i].words;
+        // 16 bytes per store where the source allows it: a table of a few thousand words went over the link one dword per lane
+        const unsigned quads = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 ? words / 4 : 0;
+        for (unsigned q = threadIdx.x; q < quads; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(src)[q];
+        for (unsigned w = 4 * quads + threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    }
     if (a.stamp && threadIdx.x == 0) atomicMax(a.stamp, (unsigned long long)wall_clock64());      // 'the stream got this far at ...' (device timing without events)
     __threadfence_system();
     __syncthreads();
@@ -231,7 +238,7 @@ public:
             MailArgs a;
             a.count = count_; a.seq = ++seq_; a.stamp = stamp;
             for (int i = 0; i < count_; ++i) a.it[i] = MailItem{static_cast<const unsigned*>(items_[i].src), (unsigned)(items_[i].off / 4), (unsigned)(items_[i].bytes / 4)};
-            hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(used_ > 1024 ? 1024 : 64), 0, stream, a, reinterpret_cast<unsigned*>(pin_), seq_word());
+            hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(used_ > 4096 ? 1024 : (used_ > 1024 ? 256 : 64)), 0, stream, a, reinterpret_cast<unsigned*>(pin_), seq_word());
             PHX_HIP(hipGetLastError());
             PHX_TRY(poll(stream));
         } else {
