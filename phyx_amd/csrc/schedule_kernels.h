@@ -173,39 +173,6 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
     }
 }
 
-// The joints grouped by bin WITHOUT a sort (speculative binning): k_bin_components has left every bin's first slot, so a joint's
-// place is that + a ticket from the bin's cursor — one wave-aggregated atomic per distinct bin of a wave (a wave's 64 consecutive
-// joints belong to two or three bins).  The order inside a bin is whatever the tickets gave; k_build_bin ranks its <= 1024 joint
-// indices in LDS, which restores joint order.  (The stable radix sort by bin this replaces was four launches, 32 us at cfg 2.)
-// Everything read here may be stale if the binning spoiled the build (nobody runs on its output then): indices are checked.
-static __global__ void __launch_bounds__(256) k_joint_bin_scatter(const int* __restrict__ joint_comp, const int* __restrict__ bin_of, const int* __restrict__ goff,
-                                                                  int* __restrict__ cursor, int nj, int max_bins, int ncomp_cap, unsigned* __restrict__ out,
-                                                                  int* __restrict__ rejected)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
-    const int lane = threadIdx.x & 63;
-    for (int j0 = blockIdx.x * blockDim.x; j0 < nj; j0 += gridDim.x * blockDim.x) {      // (workgroup-uniform trip count)
-        const int j = j0 + (int)threadIdx.x;
-        int bin = -1;
-        if (j < nj) {
-            const int c = joint_comp[j];
-            if (c >= 0 && c < ncomp_cap) { const int b = bin_of[c]; if ((unsigned)b < (unsigned)max_bins) bin = b; }
-        }
-        int leader = 0, rank = 0, cnt = 0;
-        for (unsigned long long todo = __ballot(bin >= 0); todo;) {
-            const int l = __builtin_ctzll(todo);
-            const int k = __shfl(bin, l);
-            const unsigned long long same = __ballot(bin == k);
-            if (bin == k) { leader = l; rank = __popcll(same & ((1ull << lane) - 1ull)); cnt = __popcll(same); }
-            todo &= ~same;
-        }
-        int base = 0;
-        if (bin >= 0 && lane == leader) base = goff[bin] + atomicAdd(&cursor[bin], cnt);
-        base = __shfl(base, leader);
-        if (bin >= 0) { const unsigned pos = (unsigned)(base + rank); if (pos < (unsigned)nj) out[pos] = (unsigned)j; }
-    }
-}
-
 // ---- binning on the device -------------------------------------------------------------------------------------------
 // The binning rule (schedule.h BIN_CHUNK; host: schedule.hip::build_island_schedule and DeviceSolver::build_device) restated for
 // ONE workgroup, so that a rebuild needs no host round trip between the connected components and the bins: the host launches
@@ -235,7 +202,6 @@ struct BinCompView {
     int max_bins;                     // grid of the launches behind this kernel
     int* bin_of; int* rank_of;        // out: per component (BINC_MAX each)
     int* goff;                        // out: first slot of every bin, max_bins + 1 words
-    int* cursor;                      // out: zeroed, max_bins + 1 words (k_joint_bin_scatter's tickets)
     int* result;                      // out: [0] bins (0 if spoiled), [1] slots in bins, [4] fail bits, [5] components, [6] bins found
     unsigned long long* fingerprint;  // the solve's topology fingerprint word: saved to `hash_out`, then replaced by `gate`
     unsigned long long* hash_out;     //   (the host does not know the hash yet: the solve's kernels compare the word with a constant
@@ -263,7 +229,6 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
     const int nchunks = (n_total + BIN_CHUNK - 1) / BIN_CHUNK;
     if (tid == 0) { s_fail = (v.cc_small[0] ? BINC_FAIL_CC : 0) | (n_all > BINC_MAX ? BINC_FAIL_COUNT : 0); s_needs_big = 0; }
     chunk_bins[tid] = 0u; chunk_slots[tid] = 0u; head_mask[tid] = 0ull;
-    for (int i = tid; i <= v.max_bins; i += BINC_T) v.cursor[i] = 0;
     __syncthreads();
     const unsigned cap_s = 2u * (unsigned)v.cap_units, cap_u = (unsigned)v.cap_units;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -366,7 +331,7 @@ static __global__ void __launch_bounds__(256) k_partner_first(const phx_contact_
 
 // ---- one workgroup builds one bin ------------------------------------------------------------------------------
 struct BinBuildView {
-    const unsigned* sorted_joints;    // joint indices grouped by bin, in any order inside a bin (the bin's workgroup ranks them)
+    const unsigned* sorted_joints;    // joint indices grouped by bin, joint order inside a bin
     const int* group_offsets;         // slots of bin g = [group_offsets[g], group_offsets[g+1])
     const phx_contact_joint* joints;
     const int* partner;               // joint -> the other joint of its unit, or -1
@@ -432,25 +397,6 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     const int g = blockIdx.x, tid = threadIdx.x;
     if (v.nbins_dev && g >= *v.nbins_dev) return;
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
-    // the bin's joints in joint order: every lane counts the indices below its own (they are distinct) — count / 4 broadcast
-    // reads of 16 bytes; k_joint_bin_scatter hands them over in ticket order
-    int j_sorted = 0;
-    {
-        int* raw = reinterpret_cast<int*>(used);
-        int* ranked = reinterpret_cast<int*>(used_b);
-        static_assert((size_t)NB * 8 >= (size_t)LANES * 4, "the colour masks' space holds the joint indices");
-        const int n = count < LANES ? count : LANES;
-        const int mine = tid < n ? (int)v.sorted_joints[begin + tid] : 0x7fffffff;
-        raw[tid] = mine;
-        __syncthreads();
-        int rank = 0;
-        const int4* raw4 = reinterpret_cast<const int4*>(raw);
-        for (int i = 0; i < (n + 3) / 4; ++i) { const int4 r = raw4[i]; rank += (r.x < mine) + (r.y < mine) + (r.z < mine) + (r.w < mine); }
-        if (tid < n) ranked[rank] = mine;
-        __syncthreads();
-        if (tid < n) j_sorted = ranked[tid];
-        __syncthreads();
-    }
     for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
     for (int i = tid; i < NB; i += LANES) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
     if (tid < T) { seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0; }
@@ -464,7 +410,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     if (live) {
         // (everything the lane will want from memory is asked for here, three dependent levels deep, and arrives while the
         //  body table is built: fetched where it is used, each of the later loads cost the whole workgroup a trip to memory)
-        j = j_sorted;
+        j = (int)v.sorted_joints[begin + tid];
         const phx_contact_joint jt = v.joints[j];
         mate = v.partner[j];
         const int jc = v.joint_comp[j];

@@ -736,22 +736,22 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     int grid = 2 * spec_bins_guess_ + 64;
     if (grid > 2047 && spec_bins_guess_ + spec_bins_guess_ / 4 + 16 <= 2047) grid = 2047;
     const int cap_units = spec_lanes_, cap_bodies = cap_units > ISL_T ? ISL_B_BIG : ISL_B;
-    PHX_TRY(bld_.bin_tables.reserve(2 * (size_t)BINC_MAX + 2 * ((size_t)grid + 2)));
+    PHX_TRY(bld_.bin_tables.reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
     PHX_TRY(bld_.bin_result.reserve(16));
     BinCompView cv{};
     cv.comp_size = bld_.comp_size.p; cv.comp_units = bld_.comp_units.p; cv.cc_small = bld_.sb_small.p; cv.nj = nj;
     cv.cap_units = cap_units; cv.small_units = ISL_T; cv.max_bins = grid;
     cv.bin_of = bld_.bin_tables.p; cv.rank_of = bld_.bin_tables.p + BINC_MAX; cv.goff = bld_.bin_tables.p + 2 * BINC_MAX;
-    cv.cursor = cv.goff + grid + 2;
     cv.result = bld_.bin_result.p;
     cv.fingerprint = hash_.p + hash_slot_; cv.hash_out = reinterpret_cast<unsigned long long*>(bld_.bin_result.p + 8);
     gate_expected_ = 0x5EED000000000000ull | (++gate_serial_ & 0xFFFFFFFFFFFFull);
     cv.gate = gate_expected_;
     hipLaunchKernelGGL(k_bin_components, dim3(1), dim3(BINC_T), 0, stream_, cv);
-    // the joints grouped by bin (ticket order inside a bin; k_build_bin ranks them)
-    hipLaunchKernelGGL(k_joint_bin_scatter, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, (const int*)cv.goff, cv.cursor,
-                       nj, grid, BINC_MAX, bld_.sort_vals[0].p, bld_.sb_small.p + 2);
-    const int where = 0;
+    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
+                       bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX);
+    int bits = 1, where = 0;
+    while ((1 << bits) <= grid) ++bits;
+    PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where));
     PHX_TRY(isl_.desc.reserve(grid)); PHX_TRY(isl_.ncol.reserve(grid));
     PHX_TRY(isl_.bodies.reserve((size_t)grid * cap_bodies));
     PHX_TRY(isl_.slot_local.reserve(nj)); PHX_TRY(isl_.slot_colour.reserve(nj));
