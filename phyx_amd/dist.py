@@ -290,9 +290,11 @@ class Group:
         """Host-side all-gather of equal-length uint8 arrays -> one array, rank-major (the gloo transport of Exchange)."""
         torch, dist = self.torch, self.dist
         mine = np.ascontiguousarray(mine, dtype=np.uint8)
-        parts = [torch.zeros(len(mine), dtype=torch.uint8) for _ in range(self.world_size)]
-        dist.all_gather(parts, torch.from_numpy(mine))
-        return np.concatenate([p.numpy() for p in parts])
+        dev = self.device if self.backend == "nccl" else torch.device("cpu")      # (ProcessGroupNCCL takes device tensors only)
+        parts = [torch.zeros(len(mine), dtype=torch.uint8, device=dev) for _ in range(self.world_size)]
+        dist.all_gather(parts, torch.from_numpy(mine).to(dev))
+        self._sync()
+        return np.concatenate([p.cpu().numpy() for p in parts])
 
     def exchange(self, solver, capacity_bytes, device=None):
         return Exchange(self, solver, capacity_bytes, self.local_rank if device is None and self.backend in ("nccl", "rccl") else (device or 0))
@@ -421,8 +423,14 @@ def shard_columns(total_columns, rank, world_size):
 # as no dynamic body reaches across a slab boundary, no contact, hence no island, spans two ranks: the ranks' worlds are
 # independent sub-problems of the reference's island loop (ref: Solver.cpp:86-91), the per-step collective is a 4-byte
 # all-reduce, and nothing else ever crosses xGMI.  The guard (SlabWorld.check) watches that condition on the device
-# (phx_world_x_extent) and every rank learns of a violation at the same step; re-slabbing with a hand-off of the contact cache
-# is not implemented — a violated guard is reported, never ignored.  gather_bodies() assembles the full world on demand.
+# (phx_world_x_extent) and every rank learns of a violation at the same step.  The answer to a violation is a RE-SLAB
+# (SlabWorld.reslab): the ranks all-gather their worlds' states — bodies, manifolds with their contact points, joints with their
+# warm-start impulses, i.e. what phx_world_set_state restores — cut the x axis anew in the gaps no dynamic body's AABB covers
+# (slab_cuts: bodies that touch, or share a manifold, always stay together), and every rank restores the sub-world of its new slab.
+# Islands may so wander, merge and topple across the old boundaries; the hand-over happens between two steps, before the broadphase
+# could have missed a pair (the guard looks at the AABBs the NEXT step's broadphase will sweep).  A world that has merged into one
+# island leaves no gap to cut in: it ends up on one rank, and replica mode (Exchange above) is the mode for it.
+# gather_bodies() assembles the full world on demand.
 #
 # A slab world is bit-exact against the oracle of ITS OWN slab scene (tests/test_world_gpu.py), not against the unsharded world:
 # colouring priorities hash the contact-point index, which is local to a world, so the two sweep the same islands in different
@@ -453,33 +461,200 @@ def slab_partition(scene, nranks):
     return out
 
 
+def slab_cuts(lo, hi, nranks, margin=0.0):
+    """Island-safe slabs for dynamic bodies whose AABBs span [lo[i], hi[i]] on the x axis.  Bodies whose (margin-widened) intervals
+    overlap form a block that is never split; the nranks - 1 cuts sit in the middle of the gaps between blocks, chosen so that
+    the slabs hold nearly equal numbers of bodies.  Returns (owner, bounds): the rank of every body and the ranks' open x-intervals
+    (a rank may end up with no body at all if there are fewer blocks than ranks)."""
+    lo = np.asarray(lo, dtype=np.float64); hi = np.asarray(hi, dtype=np.float64)
+    n = len(lo)
+    owner = np.zeros(n, dtype=np.int64)
+    if n == 0:
+        return owner, [(-np.inf, np.inf)] * nranks
+    order = np.argsort(lo, kind="stable")
+    slo, shi = lo[order] - margin, hi[order] + margin
+    reach = np.maximum.accumulate(shi)
+    starts = np.flatnonzero(np.concatenate([[True], slo[1:] > reach[:-1]]))          # first sorted position of every block
+    ends = np.concatenate([starts[1:], [n]])                                           # one past its last
+    cut_at = [0]                                                                       # indices into `starts`: block where each slab begins
+    for r in range(1, nranks):
+        k = int(np.argmin(np.abs(ends - n * r / nranks)))                              # the block end nearest to the ideal count
+        cut_at.append(min(max(k + 1, cut_at[-1]), len(starts)))
+    cut_at.append(len(starts))
+    true_hi = np.maximum.accumulate(hi[order])
+    bounds = []
+    for r in range(nranks):
+        b0, b1 = cut_at[r], cut_at[r + 1]
+        if b0 >= b1:
+            bounds.append((np.inf, np.inf) if b0 >= len(starts) else (np.nan, np.nan))
+            continue
+        first, last = starts[b0], ends[b1 - 1]
+        owner[order[first:last]] = r
+        left = -np.inf if first == 0 else 0.5 * (float(true_hi[first - 1]) + float(lo[order[first]]))
+        right = np.inf if last == n else 0.5 * (float(true_hi[last - 1]) + float(lo[order[last]]))
+        bounds.append((left, right))
+    # a rank without bodies gets an empty interval at its neighbour's edge (nothing lives there, nothing can violate it)
+    bounds = [(b if not (np.isnan(b[0]) or b[0] == np.inf) else (np.inf, np.inf)) for b in bounds]
+    return owner, bounds
+
+
+def _blob(*arrays):
+    """numpy arrays -> one uint8 array: int64 count + int64 byte sizes + the arrays' bytes (8-byte aligned)"""
+    parts = [np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in arrays]
+    head = np.array([len(parts)] + [len(q) for q in parts], dtype=np.int64).view(np.uint8)
+    out = [head]
+    for q in parts:
+        out.append(q)
+        out.append(np.zeros((-len(q)) % 8, dtype=np.uint8))
+    return np.concatenate(out)
+
+
+def _unblob(blob, dtypes):
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    k = int(blob[:8].view(np.int64)[0])
+    sizes = blob[8:8 + 8 * k].view(np.int64)
+    at, out = 8 + 8 * k, []
+    for size, dt in zip(sizes, dtypes):
+        out.append(blob[at:at + int(size)].view(dt).copy())
+        at += int(size) + (-int(size)) % 8
+    return out
+
+
+def all_gather_blobs(group, mine):
+    """all-gather of byte strings of different lengths -> list of uint8 arrays, one per rank"""
+    mine = np.ascontiguousarray(mine, dtype=np.uint8)
+    if group.world_size == 1:
+        return [mine]
+    longest = int(group.reduce_max(len(mine)))
+    buf = np.zeros(8 + longest + (-longest) % 8, dtype=np.uint8)
+    buf[:8] = np.array([len(mine)], dtype=np.int64).view(np.uint8)
+    buf[8:8 + len(mine)] = mine
+    rows = group.all_gather_bytes(buf).reshape(group.world_size, -1)
+    return [rows[r, 8:8 + int(rows[r, :8].view(np.int64)[0])] for r in range(group.world_size)]
+
+
 class SlabWorld:
     """One rank of an ownership-sharded world (see the comment above)."""
 
-    def __init__(self, group, scene, device=0, gravity=0.0, check_every=1):
+    def __init__(self, group, scene, device=0, gravity=0.0, check_every=1, auto_reslab=True, reslab_every=0, margin=1.0):
+        """`auto_reslab`: a violated guard re-slabs the world (reslab()) instead of raising; `reslab_every` > 0 re-slabs every
+        so many steps whatever the guard says (load balance; tests); `margin`: how far beyond a body's AABB a cut keeps away."""
         import phyx_amd
         self.group = group
         sub, self.global_index, self.bounds = slab_partition(scene, group.world_size)[group.rank]
         self.scene_size = len(scene["px"])
+        self.device, self.gravity = device, gravity
         self.world = phyx_amd.World(device, gravity=gravity)
         self.world.add_scene(sub)
         self.check_every, self.steps = check_every, 0
+        self.auto_reslab, self.reslab_every, self.margin, self.reslabs = auto_reslab, reslab_every, margin, 0
 
     def step(self, dt, configuration):
-        """World::Update of this rank's slab, then the per-step barrier (a 4-byte all-reduce that carries the guard's verdict)."""
+        """World::Update of this rank's slab, then the per-step barrier (a 4-byte all-reduce that carries the guard's verdict);
+        a violated guard — on any rank — is answered by a re-slab on every rank, before the next step."""
         self.world.Update(dt, configuration)
         self.steps += 1
         bad = 0
         if self.steps % self.check_every == 0:
             bad = 0 if self.inside() else 1
         flag = self.group.step_barrier_value(bad) if hasattr(self.group, "step_barrier_value") else bad
-        if flag:
+        if flag and not self.auto_reslab:
             raise RuntimeError("ownership-sharded world: a body reached the boundary of its slab (rank %d, slab %s); the islands of two "
-                               "ranks may now touch — re-slab the world (gather_bodies) before going on" % (self.group.rank, self.bounds))
+                               "ranks may now touch — re-slab the world (reslab) before going on" % (self.group.rank, self.bounds))
+        if flag or (self.reslab_every > 0 and self.steps % self.reslab_every == 0):
+            self.reslab()
+
+    # ---- re-slab: hand the worlds' states over to new owners -----------------------------------------------------------------
+    _STATE_DTYPES = None
+
+    def reslab_pack(self):
+        """This rank's share of a re-slab: its world's state with body ids in the full scene's numbering, as one byte string."""
+        import phyx_amd
+        bodies, manifolds, cps, joints = self.world.state()
+        gi = np.asarray(self.global_index, dtype=np.int64)
+        m = manifolds.copy(); j = joints.copy()
+        if len(m):
+            m["body1"] = gi[m["body1"]]; m["body2"] = gi[m["body2"]]
+        if len(j):
+            j["body1"] = gi[j["body1"]]; j["body2"] = gi[j["body2"]]
+        return _blob(gi, bodies, m, cps, j)
+
+    def reslab_apply(self, blobs):
+        """Every rank's reslab_pack() -> this rank's new slab: the union world is assembled (bodies in scene order; manifolds, contact
+        points and joints rank after rank), cut anew (slab_cuts on the dynamic bodies' AABBs, bodies sharing a manifold kept
+        together), and the part of it that lives in this rank's new slab is restored into a fresh World."""
+        import phyx_amd
+        dts = (np.int64, phyx_amd.rigid_body_dtype, phyx_amd.manifold_dtype, phyx_amd.contact_point_dtype, phyx_amd.contact_joint_dtype)
+        full = np.zeros(self.scene_size, dtype=phyx_amd.rigid_body_dtype)
+        seen = np.zeros(self.scene_size, dtype=bool)
+        ms, cs, js = [], [], []
+        m_off = j_off = 0
+        for blob in blobs:
+            gi, b, m, c, j = _unblob(blob, dts)
+            full[gi] = b; seen[gi] = True
+            m = m.copy(); c = c.copy(); j = j.copy()
+            m["point_index"] = 2 * (np.arange(len(m), dtype=np.int32) + m_off)
+            j["contact_point_index"] += 2 * m_off
+            ms.append(m); cs.append(c); js.append(j)
+            m_off += len(m); j_off += len(j)
+        if not seen.all():
+            raise RuntimeError("re-slab: %d bodies of the scene are on no rank" % int((~seen).sum()))
+        M = np.concatenate(ms) if ms else np.zeros(0, dtype=phyx_amd.manifold_dtype)
+        Cp = np.concatenate(cs) if cs else np.zeros(0, dtype=phyx_amd.contact_point_dtype)
+        J = np.concatenate(js) if js else np.zeros(0, dtype=phyx_amd.contact_joint_dtype)
+        static = (full["inv_mass"] == 0) & (full["inv_inertia"] == 0)
+        dyn = np.flatnonzero(~static)
+        lo = full["aabb_min"]["x"].astype(np.float64); hi = full["aabb_max"]["x"].astype(np.float64)
+        if len(M):                                           # two dynamic bodies that share a manifold cover each other's interval
+            both = ~static[M["body1"]] & ~static[M["body2"]]
+            for _ in range(2):
+                a, b = M["body1"][both], M["body2"][both]
+                l = np.minimum(lo[a], lo[b]); h = np.maximum(hi[a], hi[b])
+                np.minimum.at(lo, a, l); np.minimum.at(lo, b, l); np.maximum.at(hi, a, h); np.maximum.at(hi, b, h)
+        owner_dyn, bounds = slab_cuts(lo[dyn], hi[dyn], self.group.world_size, self.margin)
+        owner = np.full(self.scene_size, -1, dtype=np.int64)
+        owner[dyn] = owner_dyn
+        me = self.group.rank
+        keep = np.flatnonzero(static | (owner == me))
+        local_of = np.full(self.scene_size, -1, dtype=np.int64)
+        local_of[keep] = np.arange(len(keep))
+        if len(M):
+            m_owner = np.where(static[M["body1"]], owner[M["body2"]], owner[M["body1"]])
+            both = ~static[M["body1"]] & ~static[M["body2"]]
+            if np.any(owner[M["body1"]][both] != owner[M["body2"]][both]):
+                raise RuntimeError("re-slab: a manifold spans two slabs")
+            sel = np.flatnonzero(m_owner == me)
+        else:
+            sel = np.zeros(0, dtype=np.int64)
+        new_m_of = np.full(len(M), -1, dtype=np.int64)
+        new_m_of[sel] = np.arange(len(sel))
+        m = M[sel].copy()
+        if len(m):
+            m["body1"] = local_of[m["body1"]]; m["body2"] = local_of[m["body2"]]
+            m["point_index"] = 2 * np.arange(len(m), dtype=np.int32)
+        c = Cp.reshape(-1, 2)[sel].reshape(-1).copy() if len(sel) else np.zeros(0, dtype=phyx_amd.contact_point_dtype)
+        jsel = np.flatnonzero(new_m_of[J["contact_point_index"] // 2] >= 0) if len(J) else np.zeros(0, dtype=np.int64)
+        j = J[jsel].copy()
+        if len(j):                                           # (slots no joint points at keep their bytes: the step never reads them)
+            j["contact_point_index"] = (2 * new_m_of[j["contact_point_index"] // 2] + j["contact_point_index"] % 2).astype(np.int32)
+            j["body1"] = local_of[j["body1"]]; j["body2"] = local_of[j["body2"]]
+            c["solver_index"][j["contact_point_index"]] = np.arange(len(j), dtype=np.int32)
+        b = full[keep].copy()
+        b["index"] = np.arange(len(keep), dtype=np.uint32)
+        world = phyx_amd.World(self.device, gravity=self.gravity)
+        world.set_state(b, m, c, j)
+        self.world, self.global_index, self.bounds = world, keep, (float(bounds[me][0]), float(bounds[me][1]))
+        self.reslabs += 1
+
+    def reslab(self):
+        """Collective: every rank of the group must call it at the same step (step() does, on the all-reduced verdict)."""
+        self.reslab_apply(all_gather_blobs(self.group, self.reslab_pack()))
 
     def inside(self):
         """True iff every dynamic body's AABB lies strictly inside this rank's slab: then no AABB of this rank overlaps one of
         another rank, the broadphase of the whole world would find no pair between them, and no island spans two ranks."""
+        if self.bounds[0] == np.inf:                        # (a re-slab left this rank without dynamic bodies)
+            return True
         lo, hi = self.world.x_extent()
         return lo > self.bounds[0] and hi < self.bounds[1]
 

@@ -87,6 +87,19 @@ def falling(n, seed=1, half=4.0, width=500.0, ymin=50.0, ymax=1000.0, ground_hal
     return _scene(px, py, np.zeros(n + 1), sx, sy, static)
 
 
+def piles(clusters, per_cluster, pitch=110.0, spread=25.0, seed=11, ymax=600.0):
+    """Ground + `clusters` groups of `per_cluster` falling boxes, the groups `pitch` apart and each scattered over +-`spread`:
+    separate piles that widen as they settle and grow into their neighbours — islands that wander across any fixed cut of the
+    x axis (the re-slab case of an ownership-sharded world, phyx_amd.dist.SlabWorld)."""
+    px, py = [0.0], [0.0]
+    for k in range(clusters):
+        sc = falling(per_cluster, seed=seed + k, half=4.0, width=spread, ymin=40.0, ymax=ymax)
+        px += list(sc["px"][1:] + np.float32((k - (clusters - 1) / 2.0) * pitch))
+        py += list(sc["py"][1:])
+    n = clusters * per_cluster
+    return _scene(px, py, np.zeros(n + 1), [clusters * pitch + 1000.0] + [4.0] * n, [10.0] + [4.0] * n, [True] + [False] * n)
+
+
 def tilted(n, seed=7):
     """Small scene of rotated boxes dropped on the ground — exercises the vertex/edge contact cases
     (ref: Collider.cpp:94-209) that axis-aligned stacks never reach."""

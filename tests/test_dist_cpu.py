@@ -2,6 +2,7 @@
 the 8-GPU run belongs to the driver).  Covers rendezvous on 127.0.0.1, the per-step barrier, max/sum reductions
 and the slab partition each rank derives for itself."""
 import os
+import numpy as np
 import socket
 import subprocess
 import sys
@@ -130,3 +131,41 @@ def test_slab_partition_cuts_between_columns():
         assert np.all(seen[~scene["static"]] == 1)                            # every dynamic body in exactly one slab
     sizes = [len(p[1]) - 1 for p in slab_partition(scenes.stack(1000, 3), 8)]
     assert max(sizes) - min(sizes) <= 3                                       # whole columns: at most one column of imbalance
+
+
+def test_slab_cuts_keep_touching_bodies_together():
+    """dist.slab_cuts (the re-slab's partition): bodies whose x-intervals overlap are never separated, the cuts sit inside the gaps,
+    every body has exactly one owner, counts are as even as the gaps allow, and fewer blocks than ranks leaves ranks empty."""
+    from phyx_amd import dist as pdist
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n = int(rng.integers(1, 60)); ranks = int(rng.integers(1, 6)); margin = float(rng.choice([0.0, 0.5, 2.0]))
+        lo = np.sort(rng.uniform(0, 300, n)) if trial % 2 else rng.uniform(0, 300, n)
+        hi = lo + rng.uniform(1, 12, n)
+        owner, bounds = pdist.slab_cuts(lo, hi, ranks, margin)
+        assert len(bounds) == ranks and owner.min() >= 0 and owner.max() < ranks
+        for i in range(n):
+            a, b = bounds[owner[i]]
+            assert a < lo[i] - margin / 2 or a == -np.inf
+            assert b > hi[i] + margin / 2 or b == np.inf
+            touching = (lo - margin <= hi[i] + margin) & (hi + margin >= lo[i] - margin)
+            assert np.all(owner[touching] == owner[i])
+        live = [b for b in bounds if b[0] != np.inf]
+        assert live[0][0] == -np.inf and live[-1][1] == np.inf
+        for (a0, b0), (a1, b1) in zip(live, live[1:]):
+            assert b0 == a1                                        # the slabs tile the axis
+    owner, bounds = pdist.slab_cuts([0.0, 100.0], [5.0, 105.0], 4)
+    assert sorted(set(owner)) == [0, 1] or len(set(owner)) == 2
+    assert sum(1 for b in bounds if b[0] == np.inf) == 2
+
+
+def test_state_blobs_round_trip():
+    from phyx_amd import dist as pdist
+    import phyx_amd
+    arrays = (np.arange(5, dtype=np.int64), np.zeros(3, dtype=phyx_amd.rigid_body_dtype), np.zeros(0, dtype=phyx_amd.manifold_dtype),
+              np.ones(7, dtype=phyx_amd.contact_joint_dtype))
+    arrays[1]["pos"]["x"] = [1.5, 2.5, -3.0]
+    back = pdist._unblob(pdist._blob(*arrays), [a.dtype for a in arrays])
+    for a, b in zip(arrays, back):
+        assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
+    assert [len(x) for x in pdist.all_gather_blobs(pdist.Single(), pdist._blob(*arrays))] == [len(pdist._blob(*arrays))]

@@ -405,10 +405,99 @@ def test_slab_worlds_are_exact_sub_worlds_and_the_guard_trips(oracle, built_lib)
     # bodies of both ranks share the same stretch of the x axis: not a slab-shardable world, and the guard says so
     mixed = scenes.falling(120, width=20.0, ymax=400.0)
     g = types.SimpleNamespace(rank=0, world_size=2, step_barrier_value=lambda v: v)
-    sw = pdist.SlabWorld(g, mixed, device=0, gravity=-200.0)
+    sw = pdist.SlabWorld(g, mixed, device=0, gravity=-200.0, auto_reslab=False)
     with pytest.raises(RuntimeError):
         for _ in range(30):
             sw.step(1.0 / 60.0, cfg)
+
+
+def _emulated_slabs(scene, n, **kw):
+    import types
+    from phyx_amd import dist as pdist
+    return [pdist.SlabWorld(types.SimpleNamespace(rank=r, world_size=n, step_barrier_value=lambda v: v), scene, device=0, gravity=-200.0, **kw) for r in range(n)]
+
+
+def test_reslab_with_unchanged_cuts_hands_every_world_back_as_it_was(built_lib):
+    """Re-slab (dist.SlabWorld.reslab: all-gather of the ranks' world states, new cuts, phx_world_set_state), three ranks emulated in
+    one process.  On a stack the island-safe cuts fall where the first partition put them, so every rank must get back exactly the
+    world it gave away — bodies, manifolds, contact points, joints, byte for byte, through global numbering, concatenation and
+    re-indexing — and must then step byte for byte like a twin that never re-slabbed."""
+    scene = scenes.stack(12, 20)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 12, 8)
+    a, b = _emulated_slabs(scene, 3), _emulated_slabs(scene, 3)
+    for _ in range(4):
+        for sw in a + b:
+            sw.world.Update(1.0 / 60.0, cfg)
+    before = [sw.world.state() for sw in a]
+    blobs = [sw.reslab_pack() for sw in a]
+    for sw in a:
+        sw.reslab_apply(blobs)
+    for sw, twin, old in zip(a, b, before):
+        assert sw.reslabs == 1 and np.array_equal(sw.global_index, twin.global_index)
+        assert sw.bounds[0] <= twin.bounds[0] + 10 and sw.inside()
+        for got, want, what in zip(sw.world.state(), old, ("bodies", "manifolds", "contact points", "joints")):
+            assert got.tobytes() == want.tobytes(), what
+    for step in range(5):
+        for sw, twin in zip(a, b):
+            sw.world.Update(1.0 / 60.0, cfg); twin.world.Update(1.0 / 60.0, cfg)
+            _same_world(sw.world, twin.world, "re-slabbed rank %d at step %d" % (sw.group.rank, step))
+
+
+def test_reslab_follows_piles_that_grow_into_each_other(built_lib):
+    """Six separate piles on three ranks (scenes.piles): they widen as they settle, reach across the cuts between the ranks' slabs and
+    merge — the guard trips, the ranks re-slab, and the world goes on.  After every hand-over each guard holds, every dynamic body is
+    on exactly one rank, the union of the ranks' bodies (gather order) is what the ranks held before it, and nothing blows up; a
+    rank may end up without bodies (fewer separable piles than ranks) and keeps stepping."""
+    scene = scenes.piles(6, 60, pitch=64.0, ymax=220.0)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 10, 6)
+    slabs = _emulated_slabs(scene, 3)
+    n_dyn = int(np.count_nonzero(~scene["static"]))
+    tripped = 0
+    for step in range(160):
+        for sw in slabs:
+            sw.world.Update(1.0 / 60.0, cfg)
+        bad = [not sw.inside() for sw in slabs]
+        if any(bad) or step % 32 == 31:
+            tripped += any(bad)
+            union_before = np.zeros(len(scene["px"]), dtype=phyx_amd.rigid_body_dtype)
+            for sw in slabs:
+                union_before[sw.global_index] = sw.world.bodies
+            blobs = [sw.reslab_pack() for sw in slabs]
+            for sw in slabs:
+                sw.reslab_apply(blobs)
+            owners = np.zeros(len(scene["px"]), dtype=int)
+            union_after = np.zeros_like(union_before)
+            for sw in slabs:
+                mine = sw.world.bodies
+                owners[sw.global_index[mine["inv_mass"] > 0]] += 1
+                union_after[sw.global_index] = mine
+                assert sw.inside(), (step, sw.group.rank, sw.bounds)
+            assert np.array_equal(owners[~scene["static"]], np.ones(n_dyn, dtype=int))
+            union_before["index"] = 0; union_after["index"] = 0          # (a body's own index is local to its world)
+            assert union_after.tobytes() == union_before.tobytes()
+            assert sum(sw.world.counts()[3] for sw in slabs) > 0
+    assert tripped >= 1, "the piles never reached a slab boundary: the scene does not exercise the guard"
+    for sw in slabs:
+        pos = sw.world.bodies["pos"]
+        assert np.isfinite(pos["x"]).all() and np.isfinite(pos["y"]).all() and float(pos["y"].min()) > -50.0
+
+
+@pytest.mark.parametrize("ranks,every", [(2, 0), (3, 5)])
+def test_reslab_across_processes(built_lib, ranks, every):
+    """The same hand-over between real processes (tools/reslab_ranks.py: one process per rank, all on GPU 0, collectives over gloo):
+    the guard's verdict is all-reduced, the states are all-gathered, every rank restores its new slab."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "reslab_ranks.py"), "--ranks", str(ranks), "--backend", "gloo", "--steps", "160", "--every", str(every)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ranks"] == ranks and out["steps"] == 160 and out["reslabs"] >= 1
+    assert out["dynamic_bodies_total"] == out["dynamic_bodies_scene"] and out["every_guard_holds"] and out["finite"]
 
 
 def test_world_state_save_and_restore_is_exact(built_lib):
