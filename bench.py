@@ -44,7 +44,13 @@ BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visi
 # impulse update (normal: 6 subtractions, multiply, clamp, 2-op body update; friction the same: ~26 dependent ops x ~4
 # cycles), the LDS write-back (~13 cycles issue for 16 bytes) and one workgroup barrier (~128 cycles measured for an empty
 # step, tools/probe/colour_step.hip)
-COLOUR_STEP_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
+# round 3's floor priced the class step as the unit's dependent chain: LDS read 64 + 2 x 26 dependent fp32 ops x 4 + LDS write 13 +
+# barrier 128.  Round 4 measured what one wave can do (profiles/r04_unit_issue_probe.txt, profiles/r04_sq_islands.json): a wave64
+# issues ONE instruction per ~4 cycles whether or not it depends on the last one, and the working wave of a class step issues
+# ~222 VALU instructions (SQ_INSTS_VALU per group and class step) — so the floor of a class step is that many issue slots.
+COLOUR_STEP_CHAIN_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
+COLOUR_STEP_VALU_INSTRUCTIONS = 222
+COLOUR_STEP_FLOOR_CYCLES = 64 + COLOUR_STEP_VALU_INSTRUCTIONS * 4 + 13 + 128
 
 
 def pmc_file(name):
@@ -314,7 +320,10 @@ def run_bench(args, pdist):
             steps_crit = ncol_max * (st.impulse_iterations + 1)
             model = {"colour_steps_on_critical_path": steps_crit, "colours_of_the_slowest_group": ncol_max,
                      "floor_cycles_per_colour_step": COLOUR_STEP_FLOOR_CYCLES,
-                     "floor_what": "class step = the two joints of a unit: LDS read 64 + 2 x 26 dependent fp32 ops x 4 + LDS write 13 + barrier 128 cycles"}
+                     "floor_what": "class step of the one working wave: LDS read 64 + %d VALU instructions x 4 cycles of issue (measured: one wave64 issues an "
+                                   "instruction per ~4 cycles dependent or not, profiles/r04_unit_issue_probe.txt; instructions per class step from "
+                                   "SQ_INSTS_VALU, profiles/r04_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
+                     "dependent_chain_floor_cycles_round3": COLOUR_STEP_CHAIN_FLOOR_CYCLES}
             if phases:
                 sweep_us = max(launch_us - phases["setup_prestep_writeback_us"], 0.0)
                 cyc0 = sweep_us * 1e-6 * SHADER_CLOCK_HZ / max(ncol_max * st.impulse_iterations, 1)
@@ -334,6 +343,7 @@ def run_bench(args, pdist):
                                          % (st.impulse_iterations, phases["half_sweeps"], dsw, ncol_max)})
                 model.update({"sweeps_us": sweep_us, "setup_prestep_writeback_us": max(launch_us - sweep_us, 0.0),
                               "achieved_cycles_per_colour_step": cyc, "frac_of_latency_floor": COLOUR_STEP_FLOOR_CYCLES / cyc if cyc > 0 else None,
+                              "frac_of_dependent_chain_floor_round3": COLOUR_STEP_CHAIN_FLOOR_CYCLES / cyc if cyc > 0 else None,
                               "setup_writeback_GBps": (tbytes / (max(launch_us - sweep_us, 1e-3) * 1e-6) / 1e9) if tbytes else None})
             roof["latency_model"] = model
         out = {
