@@ -15,7 +15,9 @@ public:
     // its AABB's min x, which the velocity step does not touch — and the step's four counters are cleared on the way: a dispatch fewer
     struct StepPrologue { float gravity, dt; unsigned* counters; float4* vel; const float4* mpos; const float4* accel; };      // (resident arrays, body_view.h)
     // the resident form: one float4 {min.x, min.y, max.x, max.y} per body (what the World keeps, body_view.h)
-    int update_resident(const float4* d_aabb, int n, const StepPrologue* prologue = nullptr);
+    // `while_waiting` (may be null): queued-work hook of the update's one host round trip (Readback::wait) — called at most once;
+    // the caller checks whether it ran
+    int update_resident(const float4* d_aabb, int n, const StepPrologue* prologue = nullptr, const std::function<int()>* while_waiting = nullptr);
     // the C-ABI edge: 128-byte records (their AABBs are extracted into a scratch array first)
     int update_device(const phx_rigid_body* d_bodies, int n);
     int update_host(const phx_rigid_body* bodies, int n, uint32_t* new_pairs, int cap, int* count);

@@ -500,7 +500,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     return update_resident(st_aabb_.p, n);
 }
 
-int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepPrologue* prologue)
+int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepPrologue* prologue, const std::function<int()>* while_waiting)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(n >= 0 && (n == 0 || d_bodies), "bad body array");
@@ -588,7 +588,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         PHX_TRY(rb_.add(host_small, small_.p, sizeof host_small, stream_));
         unsigned max_bucket = 0;
         if (split) PHX_TRY(rb_.add(&max_bucket, ss_stats_.p, sizeof max_bucket, stream_));
-        PHX_TRY(rb_.wait(stream_, stamps_.p + 1));
+        PHX_TRY(rb_.wait(stream_, stamps_.p + 1, attempt == 0 ? while_waiting : nullptr));
         PHX_TRY(settle_erase_check(erased));
         if (split && max_bucket > (unsigned)(4 * ss_stride(n))) split_unbalanced_ = true;      // (stale splitters: the next update sorts the long way and takes fresh ones)
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);

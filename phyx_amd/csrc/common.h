@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -228,7 +229,9 @@ public:
         return PHX_OK;
     }
     // `stamp` (device pointer, may be null): the post kernel also leaves the clock there (atomicMax) — see k_post_mail
-    int wait(hipStream_t stream, unsigned long long* stamp = nullptr)
+    // `while_waiting` (may be null): called once the batch is on its way and before the host starts to wait — whatever it queues
+    // on the stream runs while the post crosses the link and the host digests it, instead of the GPU idling through the round trip
+    int wait(hipStream_t stream, unsigned long long* stamp = nullptr, const std::function<int()>* while_waiting = nullptr)
     {
         // the batch is over however this function leaves: a failed wait must not keep destinations on a dead caller's stack
         struct Reset { Readback& r; ~Reset() { r.count_ = 0; r.used_ = 0; r.odd_ = false; r.dma_ = false;
@@ -240,9 +243,11 @@ public:
             for (int i = 0; i < count_; ++i) a.it[i] = MailItem{static_cast<const unsigned*>(items_[i].src), (unsigned)(items_[i].off / 4), (unsigned)(items_[i].bytes / 4)};
             hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(used_ > 4096 ? 1024 : (used_ > 1024 ? 256 : 64)), 0, stream, a, reinterpret_cast<unsigned*>(pin_), seq_word());
             PHX_HIP(hipGetLastError());
+            if (while_waiting) PHX_TRY((*while_waiting)());
             PHX_TRY(poll(stream));
         } else {
             for (int i = 0; i < count_; ++i) PHX_HIP(hipMemcpyAsync(pin_ + items_[i].off, items_[i].src, items_[i].bytes, hipMemcpyDeviceToHost, stream));
+            if (while_waiting) PHX_TRY((*while_waiting)());
             PHX_HIP(hipStreamSynchronize(stream));
         }
         for (int i = 0; i < count_; ++i) std::memcpy(items_[i].dst, pin_ + items_[i].off, items_[i].bytes);

@@ -67,6 +67,7 @@ private:
     int update_pairs();
     bool fuse_velocity_ = false; float step_dt_ = 0.f;      // IntegrateVelocity rides on the broadphase's key build (update_pairs)
     int fresh_manifolds_ = 0;           // pairs UpdatePairs found this step: their manifolds are created by UpdateManifolds' kernel
+    int manifolds_updated_ = 0;         // manifolds [0, this) were updated during update_pairs' round trip (update_manifolds() does the rest)
     int update_manifolds();
     int finish_pack(int dead, int dropped);
     int pack_manifolds();
@@ -220,7 +221,22 @@ int World::scratch_for(int n)
 int World::update_pairs()                                                   // ref: Collider.cpp:251-345
 {
     const DeviceBroadphase::StepPrologue prologue{gravity, step_dt_, counters_.p, vel_.p, mpos_.p, accel_pending_ ? (const float4*)accel_.p : nullptr};
-    PHX_TRY(broadphase_.update_resident(aabb_.p, nb(), fuse_velocity_ ? &prologue : nullptr));      // same stream; returns once the new-pair count is known
+    // UpdateManifolds of the manifolds that exist already needs nothing from this update (positions, rotations and AABBs do not
+    // change in it): it is queued behind the mailbox post of the new-pair count and runs while that round trip is under way — the
+    // GPU used to idle through it.  The new pairs' manifolds follow in update_manifolds().  (Not with per-phase timing: the phases
+    // would overlap.)
+    manifolds_updated_ = 0;
+    const std::function<int()> old_manifolds = [this]() -> int {
+        if (!nm) return PHX_OK;
+        PHX_TRY(scratch_for(nm));
+        PHX_TRY(pack_flags_.reserve((size_t)nm + 2));
+        hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
+                           pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm, (const uint2*)nullptr, 0);
+        PHX_HIP(hipGetLastError());
+        manifolds_updated_ = nm;
+        return PHX_OK;
+    };
+    PHX_TRY(broadphase_.update_resident(aabb_.p, nb(), fuse_velocity_ ? &prologue : nullptr, phase_timing ? nullptr : &old_manifolds));      // same stream; returns once the new-pair count is known
     fuse_velocity_ = false;
     if (accel_pending_) {                  // IntegrateVelocity of this step has consumed the uploaded accelerations (ref: World.cpp:50, 53)
         accel_pending_ = false;
@@ -238,11 +254,13 @@ int World::update_pairs()                                                   // r
 
 int World::update_manifolds()                                               // ref: Collider.cpp:368-377
 {
-    if (!nm) return PHX_OK;
+    const int first = manifolds_updated_;                                   // (the old manifolds may have been updated during update_pairs' round trip)
+    manifolds_updated_ = 0;
+    if (nm <= first) { fresh_manifolds_ = 0; return PHX_OK; }
     PHX_TRY(scratch_for(nm));
-    PHX_TRY(pack_flags_.reserve((size_t)nm + 2));                           // (only here: a pending pack keeps its scan in it until refresh_contact_joints settles it)
-    hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
-                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device());
+    PHX_TRY(pack_flags_.reserve_keep((size_t)nm + 2, (size_t)first, stream_));      // (a pending pack keeps its scan in it until refresh_contact_joints settles it)
+    hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm - first)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
+                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device(), first);
     fresh_manifolds_ = 0;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
@@ -328,10 +346,9 @@ int World::refresh_contact_joints()                                         // r
         if (!fresh) hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)dead_flags_.p, (const unsigned*)(counters_.p + 1), total, old,
                                        mover_pos_.p);
         hipLaunchKernelGGL(k_joints_fill, dim3(wgrid(total)), dim3(256), 0, stream_, d_joints_.p, total, old, (const unsigned*)dead_flags_.p,
-                           (const unsigned*)(counters_.p + 1), (const int*)mover_pos_.p);
+                           (const unsigned*)(counters_.p + 1), (const int*)mover_pos_.p, d_cps_.p);
     }
     nj = total - dead;
-    if (nj) hipLaunchKernelGGL(k_joints_publish, dim3(wgrid(nj)), dim3(256), 0, stream_, (const phx_contact_joint*)d_joints_.p, nj, d_cps_.p);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -595,7 +612,7 @@ int World::set_state(const phx_rigid_body* bodies, int body_count, const phx_man
     for (int i = 0; i < nm; ++i) pairs[i] = make_uint2((unsigned)manifolds[i].body1, (unsigned)manifolds[i].body2);
     PHX_TRY(broadphase_.reset_pairs(pairs.data(), nm));
     // nothing of the old world's bookkeeping survives
-    joints_changed_ = true; pack_pending_ = false; expect_no_dead_manifolds_ = false; fresh_manifolds_ = 0; fuse_velocity_ = false;
+    joints_changed_ = true; pack_pending_ = false; expect_no_dead_manifolds_ = false; fresh_manifolds_ = 0; manifolds_updated_ = 0; fuse_velocity_ = false;
     if (joint_seen_.p) { PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_)); }
     joint_epoch_ = 0;
     PHX_HIP(hipStreamSynchronize(stream_));

@@ -143,9 +143,11 @@ __device__ __forceinline__ NpBody np_load(const WorldBodies& w, int i)
 // by an append kernel of their own in front of this one.
 static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, WorldBodies bodies,
                                                                  phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped,
-                                                                 int nm_old, const uint2* __restrict__ new_pairs)
+                                                                 int nm_old, const uint2* __restrict__ new_pairs, int first)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+    // (`first`: manifolds [first, nm) — the old manifolds are updated while the host waits for the new-pair count, the new ones
+    //  in a launch of their own once it is known, world.hip)
+    for (int i = first + blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
         phx_manifold m;
         if (i >= nm_old) {
             const uint2 pr = new_pairs[i - nm_old];
@@ -267,8 +269,12 @@ static __global__ void __launch_bounds__(256) k_joints_create(const phx_manifold
 }
 
 // Cleanup (ref: World.cpp:125-143): holes take movers
+// (a joint that moves takes its contact point's back-pointer along, ref: World.cpp:139 — every other live joint's contact point
+//  points at it already: the match re-attached it, or k_joints_create has just made it.  Rounds 1-3 rewrote all nj back-pointers
+//  in a kernel of their own behind this one: 8 us at cfg 2, 24 us at cfg 4, for a few hundred moved joints.)
 static __global__ void __launch_bounds__(256) k_joints_fill(phx_contact_joint* __restrict__ joints, int nj, int n_flagged, const unsigned* __restrict__ dead_before,
-                                                            const unsigned* __restrict__ dead_total, const int* __restrict__ mover_pos)
+                                                            const unsigned* __restrict__ dead_total, const int* __restrict__ mover_pos,
+                                                            phx_contact_point* __restrict__ cps)
 {
     const int D = (int)*dead_total, live = nj - D;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < live; i += gridDim.x * blockDim.x) {
@@ -276,13 +282,10 @@ static __global__ void __launch_bounds__(256) k_joints_fill(phx_contact_joint* _
         const int h = (int)dead_before[i];
         const int next = (i + 1 < n_flagged) ? (int)dead_before[i + 1] : D;
         if (next == h) continue;
-        joints[i] = joints[mover_pos[h]];
+        const phx_contact_joint moved = joints[mover_pos[h]];
+        joints[i] = moved;
+        cps[moved.contact_point_index].solver_index = i;
     }
-}
-
-static __global__ void __launch_bounds__(256) k_joints_publish(const phx_contact_joint* __restrict__ joints, int nj, phx_contact_point* __restrict__ cps)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) cps[joints[i].contact_point_index].solver_index = i;
 }
 
 } // namespace phx
