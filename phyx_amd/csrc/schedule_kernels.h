@@ -19,10 +19,15 @@
 namespace phx {
 
 // ---- connected components over dynamic bodies --------------------------------------------------------------
-// (`clear`: a word to zero on the way — the 'hooked anything' flag of the first round; saves a memset dispatch)
-// (`first`: the contact point -> first joint table of the unit pairing below, reset to 'nobody' on the same way: ncp words)
+// (`clear`: a word to zero on the way — saves a memset dispatch)
+// The same launch fills the contact point -> first joint table of the unit pairing below (schedule.h): first[id] = the smallest
+// joint index carrying contact point id, kept as `tag << 32 | joint` under atomicMin.  The tag COUNTS DOWN from build to build,
+// so this build's entries undercut whatever older builds left and the table never has to be reset (a reset was a pass over ncp
+// words that had to finish before the first atomicMin: a launch of its own); an entry whose tag is not this build's reads as
+// 'nobody'.  The host clears the table when it is new or the tag runs out.
 static __global__ void __launch_bounds__(256) k_cc_init(const float4* __restrict__ mpos, int nb, int* __restrict__ parent,
-                                                        unsigned char* __restrict__ is_static, int* __restrict__ clear, int* __restrict__ first, int ncp)
+                                                        unsigned char* __restrict__ is_static, int* __restrict__ clear,
+                                                        const phx_contact_joint* __restrict__ joints, int nj, int ncp, unsigned long long* __restrict__ first, unsigned tag)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
@@ -31,16 +36,21 @@ static __global__ void __launch_bounds__(256) k_cc_init(const float4* __restrict
         is_static[i] = st ? 1 : 0;
         parent[i] = st ? -1 : i;
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncp; i += gridDim.x * blockDim.x) first[i] = 0x7f7f7f7f;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        const unsigned id = (unsigned)joints[j].contact_point_index;
+        if (id < (unsigned)ncp) atomicMin(&first[id], ((unsigned long long)tag << 32) | (unsigned)j);
+    }
 }
 
-// (`first` / `partner`: the joints are paired into units on the way, schedule.h; the table is complete, k_partner_first ran)
-__device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ joints, int j, const phx_contact_joint& me, int ncp, const int* __restrict__ first)
+// (`first` / `partner`: the joints are paired into units on the way, schedule.h; the table is complete, k_cc_init filled it)
+__device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ joints, int j, const phx_contact_joint& me, int ncp,
+                                          const unsigned long long* __restrict__ first, unsigned tag)
 {
     const unsigned id = (unsigned)me.contact_point_index;
-    if (id >= (unsigned)ncp || first[id] != j || (id ^ 1u) >= (unsigned)ncp) return -1;
-    const int other = first[id ^ 1u];
-    if (other == 0x7f7f7f7f) return -1;
+    if (id >= (unsigned)ncp || first[id] != (((unsigned long long)tag << 32) | (unsigned)j) || (id ^ 1u) >= (unsigned)ncp) return -1;
+    const unsigned long long mate = first[id ^ 1u];
+    if ((unsigned)(mate >> 32) != tag) return -1;                       // nobody carries that contact point in this build
+    const int other = (int)(unsigned)mate;
     const phx_contact_joint o = joints[other];
     return (o.body1 == me.body1 && o.body2 == me.body2) ? other : -1;
 }
@@ -55,11 +65,12 @@ __device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ 
 // alternated min-label hooking of the two current ROOTS with full compression until nothing hooked any more: two pairs of
 // launches for stacks, five for a merged world, plus the 'did it converge' readback.
 static __global__ void __launch_bounds__(256) k_cc_link(const phx_contact_joint* __restrict__ joints, int nj, int nb, int* parent,
-                                                        const unsigned char* __restrict__ is_static, const int* __restrict__ first, int ncp, int* __restrict__ partner)
+                                                        const unsigned char* __restrict__ is_static, const unsigned long long* __restrict__ first, unsigned tag, int ncp,
+                                                        int* __restrict__ partner)
 {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
         const phx_contact_joint me = joints[j];
-        const int mate = partner_of(joints, j, me, ncp, first);
+        const int mate = partner_of(joints, j, me, ncp, first, tag);
         partner[j] = mate;
         if (mate >= 0 && (me.contact_point_index & 1)) continue;           // the follower of a unit: its leader links the same two bodies
         const unsigned u = (unsigned)me.body1, v = (unsigned)me.body2;
@@ -316,16 +327,6 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
         v.result[1] = slots_all; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
         *v.hash_out = *v.fingerprint;
         *v.fingerprint = s_fail ? v.gate + BINC_POISON : v.gate;
-    }
-}
-
-// ---- units (schedule.h): partner[j] = the other joint of j's unit, or -1 ---------------------------------------------
-// first[id] = smallest joint index carrying contact point id (table of ncp words, 0x7f7f7f7f = nobody)
-static __global__ void __launch_bounds__(256) k_partner_first(const phx_contact_joint* __restrict__ joints, int nj, int ncp, int* __restrict__ first)
-{
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
-        const unsigned id = (unsigned)joints[j].contact_point_index;
-        if (id < (unsigned)ncp) atomicMin(&first[id], j);
     }
 }
 

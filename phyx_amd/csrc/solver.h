@@ -203,7 +203,9 @@ private:
         DevBuf<unsigned char> cc_static;
         DevBuf<unsigned> cc_flags, comp_size, comp_units, sort_keys[2], sort_vals[2], sort_hist;
         ScanScratch sort_scan;
-        DevBuf<int> partner, partner_first;   // joint -> the other joint of its unit (schedule.h); contact point -> first joint carrying it
+        DevBuf<int> partner;                  // joint -> the other joint of its unit (schedule.h)
+        DevBuf<unsigned long long> partner_first;      // contact point -> tag << 32 | first joint carrying it (k_cc_init)
+        unsigned partner_tag = 0;             // this build's tag: counts down, 0 = the table has to be cleared first
         DevBuf<int> bin_result;               // k_bin_components' results: 8 ints, then the topology hash (8 bytes)
         DevBuf<unsigned long long> jp_used, jp_used_b, jp_seen;
         DevBuf<uint4> jp_ent, jp_adj;

@@ -406,9 +406,17 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     PHX_TRY(hbm_.order.reserve(njs));
 
     // units (schedule.h): contact point -> first joint carrying it (reset by k_cc_init); the partners are found by the first hook
-    PHX_TRY(bld_.partner.reserve(njs)); PHX_TRY(bld_.partner_first.reserve(std::max(ncp_, 1))); PHX_TRY(bld_.comp_units.reserve(nbs + 1));
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, ncp_))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p, bld_.partner_first.p, ncp_);
-    hipLaunchKernelGGL(k_partner_first, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, ncp_, bld_.partner_first.p);
+    PHX_TRY(bld_.partner.reserve(njs)); PHX_TRY(bld_.comp_units.reserve(nbs + 1));
+    {
+        const size_t had = bld_.partner_first.cap;
+        PHX_TRY(bld_.partner_first.reserve(std::max(ncp_, 1)));
+        if (bld_.partner_first.cap != had || bld_.partner_tag <= 1) {          // a new table, or the tags ran out: every entry reads 'nobody' again
+            PHX_HIP(hipMemsetAsync(bld_.partner_first.p, 0xFF, bld_.partner_first.cap * sizeof(unsigned long long), stream_));
+            bld_.partner_tag = 0xFFFFFFFEu;
+        } else --bld_.partner_tag;
+    }
+    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, nj))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p,
+                       d_joints, nj, ncp_, bld_.partner_first.p, bld_.partner_tag);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -430,7 +438,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     int guess = 0;
     {
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                           (const int*)bld_.partner_first.p, ncp_, bld_.partner.p);
+                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
@@ -723,7 +731,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
 int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
 {
     hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                       (const int*)bld_.partner_first.p, ncp_, bld_.partner.p);
+                       (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p);
     hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
     PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                      reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
