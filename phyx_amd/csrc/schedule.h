@@ -61,6 +61,8 @@ constexpr int COLOUR_B_MAX_JOINTS = 1024;
 // chain 'a bin ends where the next component would overflow it' into independent pieces, which is what lets the device make the
 // bins in a few microseconds (schedule_kernels.h k_bin_components) at the price of one partly filled bin per 64 components.
 constexpr int BIN_CHUNK = 64;
+constexpr int BINC_MAX = 65536;          // speculative binning (schedule_kernels.h k_bin_components): components at most (tables, indices)
+constexpr int BINC_JOINT_BITS = 30;      // ... and solves of < 2^30 joints (the lanes' scan packs bins << 32 | slots)
 
 // PARTITIONED COMPONENTS.  A component of more than COLOUR_B_MAX_JOINTS joints (a settled pile: one island of 1e5-1e6 joints)
 // is swept class by class out of HBM, one launch per class and sweep — a solve is classes x sweeps dependent launches.  Most of

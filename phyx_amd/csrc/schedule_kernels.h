@@ -197,9 +197,8 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
 // GatherIslands' published numbers (ref: Solver.cpp:400, 414, 449) are statistics: the host computes them from the component
 // sizes when it settles the solve.  Whatever the host would have decided differently poisons the solve's fingerprint word
 // (`fail` bits below), which makes every kernel of the solve commit nothing; the host then rebuilds the slow way.
-constexpr int BINC_MAX = 65536, BINC_T = BINC_MAX / BIN_CHUNK;      // components at most (tables, indices); lanes = chunks
+constexpr int BINC_T = BINC_MAX / BIN_CHUNK;      // lanes = chunks (BINC_MAX, BINC_JOINT_BITS: schedule.h)
 static_assert(BINC_T == 1024 && BIN_CHUNK == 64, "one lane per chunk of 64 components, one workgroup");
-constexpr int BINC_JOINT_BITS = 30;      // speculative binning is for solves of < 2^30 joints (the lanes' scan packs bins << 32 | slots)
 constexpr int BINC_FAIL_CC = 1, BINC_FAIL_COUNT = 2, BINC_FAIL_FIT = 4, BINC_FAIL_SHAPE = 8, BINC_FAIL_REST = 16, BINC_FAIL_GRID = 32;
 constexpr unsigned long long BINC_POISON = 0x9E3779B97F4A7C15ull;
 

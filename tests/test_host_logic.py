@@ -288,7 +288,7 @@ BIN_CHUNK = 64          # csrc/schedule.h: a bin never spans a multiple of BIN_C
 
 
 def _greedy_bins(sizes, units, cap_units):
-    """The host loop of the schedule builder (csrc/solver.hip, step 3; csrc/schedule.hip): consecutive components packed greedily,
+    """The host loop of the schedule builder (csrc/solver_build.hip, step 3; csrc/schedule.hip): consecutive components packed greedily,
     every chunk of BIN_CHUNK component numbers starting a fresh bin."""
     bin_of, rank_of, goff = [-1] * len(sizes), [0] * len(sizes), [0]
     size = unit = rank = 0
