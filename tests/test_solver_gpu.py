@@ -383,7 +383,7 @@ def test_full_size_500k_boxes_fp16_body_state(oracle, built_lib):
 
 
 def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
-    """Schedules are built on the device (connected components by label hooking, per-bin colouring in LDS, the HBM
+    """Schedules are built on the device (connected components by atomicMin linking, per-bin colouring in LDS, the HBM
     group coloured by Jones-Plassmann rounds in HBM); the host builder is the specification.  Both must produce the
     very same schedule, in the island modes and in Single mode."""
     import os
