@@ -160,7 +160,8 @@ __global__ void __launch_bounds__(256) k_ps_rehash(const unsigned long long* __r
 constexpr int STAT_SLOTS = 64;     // same-address atomics serialise (~10 ns each): 31k of them cost 0.3 ms of a 0.4 ms kernel
 constexpr int ROW_CACHE = 4;        // new pairs remembered per row by the count pass (rows with more are rescanned by the emit pass)
 constexpr int HUB_LEN = 2048;      // rows scanning more candidates than this are cut into chunks
-constexpr int HUB_CHUNK = 2048;    // candidates per chunk = one 256-lane workgroup x 8 tiles
+constexpr int HUB_CHUNK = 512;     // candidates per chunk = one 256-lane workgroup x 2 tiles (2048: the ground row of the 200k-box scene was 98 workgroups
+                                   // walking eight dependent tiles each, 10 us per pass; 391 workgroups of two are done in a third of that)
 
 struct SweepView {
     const float4* entries;
@@ -219,16 +220,24 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
         // hub iff the candidate HUB_LEN places ahead still starts at or before this row's maxx.  Only hub rows pay the
         // binary search for their end; every other row finds it by scanning (ref: Collider.cpp:300-303 breaks the same way).
         const bool hub = in_range && i + 1 + HUB_LEN < v.n && !(v.entries[i + 1 + HUB_LEN].x > a.y);
-        if (hub && !EMIT) {
-            // hand the row to the chunk kernels: its chunks sit contiguously and in j order in the list
-            const int end = scan_end(v.entries, v.n, i, a.y);
-            const int len = end - i - 1;
-            const int nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
-            const int first = atomicAdd(v.n_chunks, nc);
-            for (int k = 0; k < nc && first + k < v.chunk_cap; ++k)
-                v.chunks[first + k] = make_int4(i, i + 1 + k * HUB_CHUNK, min(end, i + 1 + (k + 1) * HUB_CHUNK), first);
-            v.row_count[i] = 0;
-            tests += (unsigned long long)len;
+        if (!EMIT) {
+            // hand a hub row to the chunk kernels: its chunks sit contiguously and in j order in the list.  The row's lane finds the
+            // end and takes the list positions; the WAVE writes the descriptors (the ground row of the 1M-box scene is 1954 of them).
+            int end = 0, nc = 0, first = 0;
+            if (hub) {
+                end = scan_end(v.entries, v.n, i, a.y);
+                const int len = end - i - 1;
+                nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
+                first = atomicAdd(v.n_chunks, nc);
+                v.row_count[i] = 0;
+                tests += (unsigned long long)len;
+            }
+            for (unsigned long long hubs = __ballot(hub); hubs; hubs &= hubs - 1ull) {
+                const int l = __builtin_ctzll(hubs);
+                const int hi = __shfl(i, l), hend = __shfl(end, l), hnc = __shfl(nc, l), hfirst = __shfl(first, l);
+                for (int k = lane; k < hnc && hfirst + k < v.chunk_cap; k += 64)
+                    v.chunks[hfirst + k] = make_int4(hi, hi + 1 + k * HUB_CHUNK, min(hend, hi + 1 + (k + 1) * HUB_CHUNK), hfirst);
+            }
         }
         bool scanning = in_range && !hub;
         const unsigned dst = EMIT && scanning ? row_offset[i] : 0u;
@@ -354,12 +363,32 @@ __global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigne
     __shared__ unsigned running;
     const int total = min(*v.n_chunks, v.chunk_cap);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long overlaps_all = 0;
     for (int c = blockIdx.x; c < total; c += gridDim.x) {
         const int4 ch = v.chunks[c];
         const float4 a = v.entries[ch.x];
         const unsigned ia = v.idx[ch.x];
-        if (threadIdx.x == 0) running = EMIT ? row_offset[ch.x] + v.chunk_count[c] : 0u;
         unsigned long long overlaps = 0;
+        if constexpr (!EMIT) {
+            // the count pass only wants the chunk's number of new pairs: every lane counts its own candidates over all tiles (their
+            // loads and lookups in flight together) and the workgroup adds up once — no per-tile ordering, one barrier pair per chunk
+            unsigned mine = 0;
+            for (int j = ch.y + (int)threadIdx.x; j < ch.z; j += 256) {
+                const float4 b = v.entries[j];
+                if (fabsf(b.z - a.z) <= a.w + b.w) {
+                    ++overlaps;
+                    if (!ps_contains(v.table, v.mask, ((unsigned long long)ia << 32) | v.idx[j])) ++mine;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+            if (lane == 0) wave_cnt[wave] = mine;
+            __syncthreads();
+            if (threadIdx.x == 0) v.chunk_count[c] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            overlaps_all += overlaps;
+            __syncthreads();
+            continue;
+        }
+        if (threadIdx.x == 0) running = row_offset[ch.x] + v.chunk_count[c];
         __syncthreads();
         for (int j0 = ch.y; j0 < ch.z; j0 += 256) {
             const int j = j0 + threadIdx.x;
@@ -384,18 +413,17 @@ __global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigne
             if (threadIdx.x == 0) running = base + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             __syncthreads();
         }
-        if (!EMIT) {
-            if (threadIdx.x == 0) v.chunk_count[c] = running;
-            for (int off = 32; off > 0; off >>= 1) overlaps += __shfl_down(overlaps, off);
-            if (lane == 0 && overlaps) atomicAdd(&v.counters[2 * ((blockIdx.x * 4 + wave) % STAT_SLOTS) + 1], overlaps);
-        }
         __syncthreads();
+    }
+    if (!EMIT) {                                           // one statistics atomic per wave for the whole launch, not per chunk
+        for (int off = 32; off > 0; off >>= 1) overlaps_all += __shfl_down(overlaps_all, off);
+        if (lane == 0 && overlaps_all) atomicAdd(&v.counters[2 * ((blockIdx.x * 4 + wave) % STAT_SLOTS) + 1], overlaps_all);
     }
 }
 
 // per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  A row's chunks are contiguous in the
 // list, so differences of the exclusive scan of the counts give both.  The list is short (the ground row of the 200k-box
-// scene is 98 chunks), so ONE workgroup scans it tile by tile with a running carry and then takes the differences — one
+// scene is 391 chunks, of the 1M-box scene 1954), so ONE workgroup scans it tile by tile with a running carry and then takes the differences — one
 // dispatch where a copy, a second copy, a scan and a difference kernel used to be four.
 __global__ void __launch_bounds__(1024) k_chunk_bases(SweepView v, unsigned* __restrict__ scanned)
 {
