@@ -149,20 +149,27 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
         }
         // one table insert per distinct component of the wave (in a merged world every lane carries the SAME component: a
         // thousand same-address LDS atomics per workgroup made this the slowest kernel of the schedule build)
-        for (unsigned long long todo = __ballot(mine >= 0); todo;) {
+        // (... and a world that has been running for a while keeps its joints in no particular order: a wave's 64 joints then belong
+        //  to dozens of components and the leader loop — one serial round of LDS atomics per distinct component — was most of this
+        //  kernel's 18 us at cfg 2.  Three rounds take care of waves with a few components, merged worlds included; whoever is left
+        //  inserts for himself, all at once: different components, different slots.)
+        auto insert = [&](int comp, unsigned joints_n, unsigned leads_n) {
+            unsigned h = ((unsigned)comp * 2654435761u) >> 21;                             // 11 bits
+            for (;; h = (h + 1) & (JC_TABLE - 1)) {                                        // <= JC_T distinct keys in a table of 2 * JC_T
+                const int seen = atomicCAS(&table_key[h], -1, comp);
+                if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], joints_n); if (leads_n) atomicAdd(&table_units[h], leads_n); break; }
+            }
+        };
+        unsigned long long todo = __ballot(mine >= 0);
+        for (int round = 0; round < 3 && todo; ++round) {
             const int leader = __builtin_ctzll(todo);
             const int comp = __shfl(mine, leader);
             const unsigned long long same = __ballot(mine == comp);
             const unsigned nlead = (unsigned)__popcll(__ballot(mine == comp && lead_one));
-            if ((int)(threadIdx.x & 63) == leader) {
-                unsigned h = ((unsigned)comp * 2654435761u) >> 21;                         // 11 bits
-                for (;; h = (h + 1) & (JC_TABLE - 1)) {                                    // <= JC_T distinct keys in a table of 2 * JC_T
-                    const int seen = atomicCAS(&table_key[h], -1, comp);
-                    if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], (unsigned)__popcll(same)); if (nlead) atomicAdd(&table_units[h], nlead); break; }
-                }
-            }
+            if ((int)(threadIdx.x & 63) == leader) insert(comp, (unsigned)__popcll(same), nlead);
             todo &= ~same;
         }
+        if ((todo >> (threadIdx.x & 63)) & 1ull) insert(mine, 1u, lead_one);
         __syncthreads();
         for (int i = threadIdx.x; i < JC_TABLE; i += JC_T)
             if (table_key[i] >= 0) { atomicAdd(&comp_size[table_key[i]], table_cnt[i]); if (table_units[i]) atomicAdd(&comp_units[table_key[i]], table_units[i]); }
