@@ -35,15 +35,17 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
 {
     // 1. fingerprint of the joint topology (8 bytes over PCIe).  A caller that KNOWS the topology changed (the World, when
     //    joints were created or destroyed this step) does not wait for it: the value rides along with the builder's first
-    //    readback — and a rebuild that needs no host round trip (build_bins_speculative) whose solves the island kernel can
-    //    check itself (ISL_VERIFY) skips the hash pass altogether: nobody would ever compare it with anything.
+    //    readback — and a rebuild that needs no host round trip (build_bins_speculative) skips the hash pass altogether: its
+    //    solve is gated by the constant k_bin_components leaves, and a later solve on unchanged joints either checks the schedule
+    //    inside the island launch (ISL_VERIFY) or, where that does not apply (more groups than are resident at once: the 1M-box
+    //    scene), finds no hash on record and rebuilds ONCE with one — instead of every changing step paying the pass (18 us there).
     unsigned long long fp = 0;
     bool have_fp = false;
     // Single = one coupled system swept class by class out of HBM; every other island mode lets the schedule
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !opt_.no_islands;
     const bool device_builder = opt_.gpu_builder && !force_host_builder_;
-    const bool no_hash = known_changed && device_builder && spec_build_applies(want_islands, nj) && verify_eligible(spec_bins_guess_, spec_lanes_ > ISL_T);
+    const bool no_hash = known_changed && device_builder && spec_build_applies(want_islands, nj);
     if (no_hash) begin_set(false);
     else PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
     isl_mode_ = ISL_GATED;
