@@ -220,6 +220,8 @@ struct BinCompView {
     int* bin_of; int* rank_of;        // out: per component (BINC_MAX each)
     int* goff;                        // out: first slot of every bin, max_bins + 1 words
     int* result;                      // out: [0] bins (0 if spoiled), [1] slots in bins, [4] fail bits, [5] components, [6] bins found
+    unsigned long long* scratch;      // launches of more than one workgroup: [0, BINC_T) head masks, [BINC_T, 2 BINC_T) bins << 32 | slots per chunk,
+                                      // [2 BINC_T] arrival counter, [2 BINC_T + 1] fail bits | needs-big << 8 — both left zero for the next launch
     unsigned long long* fingerprint;  // the solve's topology fingerprint word: saved to `hash_out`, then replaced by `gate`
     unsigned long long* hash_out;     //   (the host does not know the hash yet: the solve's kernels compare the word with a constant
     unsigned long long gate;          //    it does know) — or by a spoiled `gate` if the build cannot be used
@@ -228,6 +230,10 @@ struct BinCompView {
 // (a wave's own LDS operations are ordered; the compiler only has to be told that other lanes' stores count)
 #define PHX_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+// One workgroup packs 16 chunks at a time (a wave each, ~2000 cycles a chunk); the 157 chunks of the 1M-box scene were ten such
+// rounds, 31 us on one CU.  A launch of several workgroups deals the chunks out, every workgroup leaves its chunks' results in
+// `scratch`, and the LAST one to arrive (a counter) does what is left — the scan over the chunks and the tables — alone: that part
+// is a few hundred cycles a chunk.  What the workgroups tell each other goes through agent-scope stores and loads (different XCDs).
 static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
 {
     // a WAVE packs a chunk, a lane per component: prefix sums of joints and units by shuffles, then the chain of bin heads — the next
@@ -239,8 +245,9 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
     __shared__ unsigned long long wave_sum[BINC_T / 64];
     __shared__ unsigned pre_s[BINC_T / 64][64], pre_u[BINC_T / 64][64];      // a wave's chunk: inclusive prefixes of joints / units
     __shared__ unsigned char jump[BINC_T / 64][64], reach[BINC_T / 64][64];
-    __shared__ int s_fail, s_needs_big;
+    __shared__ int s_fail, s_needs_big, s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int groups = (int)gridDim.x, waves_all = groups * (BINC_T / 64);
     const int n_all = v.cc_small[1];
     const int n_total = n_all < BINC_MAX ? n_all : BINC_MAX;
     const int nchunks = (n_total + BIN_CHUNK - 1) / BIN_CHUNK;
@@ -250,7 +257,7 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
     const unsigned cap_s = 2u * (unsigned)v.cap_units, cap_u = (unsigned)v.cap_units;
     const unsigned long long below = (1ull << lane) - 1ull;
     bool misfit = false, wants_big = false;
-    for (int ch = wave; ch < nchunks; ch += BINC_T / 64) {      // (wave-uniform)
+    for (int ch = (int)blockIdx.x * (BINC_T / 64) + wave; ch < nchunks; ch += waves_all) {      // (wave-uniform)
         const int c = ch * BIN_CHUNK + lane;
         const unsigned n = c < n_total ? v.comp_size[c] : 0u, u = n ? v.comp_units[c] : 0u;
         if (n && (n > cap_s || u > cap_u)) misfit = true;
@@ -291,6 +298,33 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
     if (misfit) atomicOr(&s_fail, BINC_FAIL_FIT);
     if (wants_big) s_needs_big = 1;
     __syncthreads();
+    if (groups > 1) {
+        unsigned long long* masks = v.scratch, * counts = v.scratch + BINC_T, * arrived = v.scratch + 2 * BINC_T, * flags = arrived + 1;
+        for (int ch = (int)blockIdx.x * (BINC_T / 64) + wave; ch < nchunks; ch += waves_all)
+            if (lane == 0) {
+                __hip_atomic_store(&masks[ch], head_mask[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&counts[ch], ((unsigned long long)chunk_bins[ch] << 32) | chunk_slots[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        if (tid == 0 && (s_fail || s_needs_big)) atomicOr(flags, (unsigned long long)(unsigned)s_fail | (s_needs_big ? 256ull : 0ull));
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(arrived, 1ull) == (unsigned long long)(groups - 1) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        if (tid < nchunks) {
+            head_mask[tid] = __hip_atomic_load(&masks[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w = __hip_atomic_load(&counts[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chunk_bins[tid] = (unsigned)(w >> 32); chunk_slots[tid] = (unsigned)w;
+        }
+        if (tid == 0) {
+            const unsigned long long f = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_fail |= (int)(f & 255ull); if (f & 256ull) s_needs_big = 1;
+            __hip_atomic_store(flags, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(arrived, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     // exclusive scan over the chunks (one per lane of the workgroup): bins << 32 | slots
     const unsigned long long mine = ((unsigned long long)chunk_bins[tid] << 32) | chunk_slots[tid];
     unsigned long long incl = mine;

@@ -207,6 +207,7 @@ private:
         DevBuf<unsigned long long> partner_first;      // contact point -> tag << 32 | first joint carrying it (k_cc_init)
         unsigned partner_tag = 0;             // this build's tag: counts down, 0 = the table has to be cleared first
         DevBuf<int> bin_result;               // k_bin_components' results: 8 ints, then the topology hash (8 bytes)
+        DevBuf<unsigned long long> bin_scratch;        // k_bin_components launched as several workgroups: what they hand to the last one
         DevBuf<unsigned long long> jp_used, jp_used_b, jp_seen;
         DevBuf<uint4> jp_ent, jp_adj;
         DevBuf<uint2> jp_succ;

@@ -549,11 +549,15 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     std::vector<int> ncol, goff;
     std::vector<unsigned> comp_size;
     int spec[16] = {0};
+    int fetched_bins = 0;
     auto with_build = [&]() -> int {
         if (!build_unverified_) return PHX_OK;
-        ncol.assign((size_t)unverified_bins_, 0);
+        // (a speculative build's grid is twice last build's bin count: the tables are fetched up to last count + 25 %, the rest —
+        //  if this build really made that many more — in a second trip; at 1M boxes the whole grid's tables were 130 KB per step)
+        fetched_bins = spec_bins_pending_ ? std::min(unverified_bins_, spec_bins_guess_ + spec_bins_guess_ / 4 + 64) : unverified_bins_;
+        ncol.assign((size_t)fetched_bins, 0);
         if (spec_bins_pending_) {                      // speculative binning: what the build's round trip would have brought
-            goff.assign((size_t)unverified_bins_ + 1, 0);
+            goff.assign((size_t)fetched_bins + 1, 0);
             comp_size.assign((size_t)std::min(std::min(BINC_MAX, nb_), std::max(1024, ncomp_guess_ + ncomp_guess_ / 4)), 0u);
             PHX_TRY(rb_.add(spec, bld_.bin_result.p, sizeof spec, stream_));
             PHX_TRY(rb_.add(goff.data(), bld_.bin_tables.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
@@ -561,12 +565,25 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
         }
         return rb_.add(ncol.data(), isl_.ncol.p, ncol.size() * sizeof(int), stream_);
     };
-    auto rest_of_sizes = [&]() -> int {                // more components than last time (+ 25 %): fetch the rest
-        if (!build_unverified_ || !spec_bins_pending_ || spec[4] != 0 || (size_t)spec[5] <= comp_size.size()) return PHX_OK;
-        const size_t have = comp_size.size();
-        comp_size.resize((size_t)spec[5], 0u);
-        PHX_TRY(rb_.add(comp_size.data() + have, bld_.comp_size.p + have, (comp_size.size() - have) * sizeof(unsigned), stream_));
-        return rb_.wait(stream_);
+    auto rest_of_sizes = [&]() -> int {                // more components or bins than last time (+ 25 %): fetch the rest
+        if (!build_unverified_ || !spec_bins_pending_ || spec[4] != 0) return PHX_OK;
+        bool more = false;
+        if ((size_t)spec[5] > comp_size.size()) {
+            const size_t have = comp_size.size();
+            comp_size.resize((size_t)spec[5], 0u);
+            PHX_TRY(rb_.add(comp_size.data() + have, bld_.comp_size.p + have, (comp_size.size() - have) * sizeof(unsigned), stream_));
+            more = true;
+        }
+        const int nbins = std::min(spec[0], unverified_bins_);
+        if (nbins > fetched_bins) {
+            const size_t have = (size_t)fetched_bins;
+            ncol.resize((size_t)nbins, 0); goff.resize((size_t)nbins + 1, 0);
+            PHX_TRY(rb_.add(ncol.data() + have, isl_.ncol.p + have, ((size_t)nbins - have) * sizeof(int), stream_));
+            PHX_TRY(rb_.add(goff.data() + have + 1, bld_.bin_tables.p + 2 * BINC_MAX + have + 1, ((size_t)nbins - have) * sizeof(int), stream_));
+            fetched_bins = nbins;
+            more = true;
+        }
+        return more ? rb_.wait(stream_) : PHX_OK;
     };
     auto settle_build = [&]() {
         if (!build_unverified_) return;
