@@ -272,7 +272,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     int guess = 0;
     {
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p);
+                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
@@ -565,7 +565,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
 int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
 {
     hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                       (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p);
+                       (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
     hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
     PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                      reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
