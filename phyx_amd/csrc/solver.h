@@ -236,6 +236,9 @@ private:
     // speculative binning (build_bins_speculative): the bins are made on the device and the build has no host round trip at all;
     // what the host would have read — bin count, offsets, GatherIslands' numbers, the topology hash — comes back when the solve is settled
     bool spec_bins_ok_ = false, spec_bins_pending_ = false, spec_bins_failed_ = false;
+    bool tables_pending_ = false;         // the last speculative build's tables are still on the device only (fetch_build_tables)
+    int tables_bins_ = 0, tables_comps_ = 0;
+    int fetch_build_tables();
     int spec_bins_guess_ = 0, spec_lanes_ = 0;
     unsigned long long gate_expected_ = 0, gate_serial_ = 0;      // what the gates of the solve in flight compare the fingerprint word with
     bool time_sweeps_ = false, timed_sweeps_ = false;   // bench(): the event pair brackets the sweeps instead of the whole solve

@@ -546,45 +546,18 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
 {
     // an unverified device build (build_schedule_device): the classes per group ride along; whether a bin was rejected shows in
     // the fingerprint the caller compares
-    std::vector<int> ncol, goff;
-    std::vector<unsigned> comp_size;
+    // (a SPECULATIVE build brings only its 64 bytes of results here; its tables — first slots and classes of every bin, component
+    //  sizes: 16 KB at cfg 2, 100 KB at 1M boxes — are what the query API and the statistics want, not the next step: they are
+    //  fetched when somebody asks, fetch_build_tables())
+    std::vector<int> ncol;
     int spec[16] = {0};
-    int fetched_bins = 0;
     auto with_build = [&]() -> int {
         if (!build_unverified_) return PHX_OK;
-        // (a speculative build's grid is twice last build's bin count: the tables are fetched up to last count + 25 %, the rest —
-        //  if this build really made that many more — in a second trip; at 1M boxes the whole grid's tables were 130 KB per step)
-        fetched_bins = spec_bins_pending_ ? std::min(unverified_bins_, spec_bins_guess_ + spec_bins_guess_ / 4 + 64) : unverified_bins_;
-        ncol.assign((size_t)fetched_bins, 0);
-        if (spec_bins_pending_) {                      // speculative binning: what the build's round trip would have brought
-            goff.assign((size_t)fetched_bins + 1, 0);
-            comp_size.assign((size_t)std::min(std::min(BINC_MAX, nb_), std::max(1024, ncomp_guess_ + ncomp_guess_ / 4)), 0u);
-            PHX_TRY(rb_.add(spec, bld_.bin_result.p, sizeof spec, stream_));
-            PHX_TRY(rb_.add(goff.data(), bld_.bin_tables.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
-            if (!comp_size.empty()) PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, comp_size.size() * sizeof(unsigned), stream_));
-        }
+        if (spec_bins_pending_) return rb_.add(spec, bld_.bin_result.p, sizeof spec, stream_);
+        ncol.assign((size_t)unverified_bins_, 0);
         return rb_.add(ncol.data(), isl_.ncol.p, ncol.size() * sizeof(int), stream_);
     };
-    auto rest_of_sizes = [&]() -> int {                // more components or bins than last time (+ 25 %): fetch the rest
-        if (!build_unverified_ || !spec_bins_pending_ || spec[4] != 0) return PHX_OK;
-        bool more = false;
-        if ((size_t)spec[5] > comp_size.size()) {
-            const size_t have = comp_size.size();
-            comp_size.resize((size_t)spec[5], 0u);
-            PHX_TRY(rb_.add(comp_size.data() + have, bld_.comp_size.p + have, (comp_size.size() - have) * sizeof(unsigned), stream_));
-            more = true;
-        }
-        const int nbins = std::min(spec[0], unverified_bins_);
-        if (nbins > fetched_bins) {
-            const size_t have = (size_t)fetched_bins;
-            ncol.resize((size_t)nbins, 0); goff.resize((size_t)nbins + 1, 0);
-            PHX_TRY(rb_.add(ncol.data() + have, isl_.ncol.p + have, ((size_t)nbins - have) * sizeof(int), stream_));
-            PHX_TRY(rb_.add(goff.data() + have + 1, bld_.bin_tables.p + 2 * BINC_MAX + have + 1, ((size_t)nbins - have) * sizeof(int), stream_));
-            fetched_bins = nbins;
-            more = true;
-        }
-        return more ? rb_.wait(stream_) : PHX_OK;
-    };
+    auto rest_of_sizes = [&]() -> int { return PHX_OK; };
     auto settle_build = [&]() {
         if (!build_unverified_) return;
         build_unverified_ = false;
@@ -600,22 +573,10 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
             raw_fingerprint_ = hash; have_hash_ = spec_hash_ran_;
             sched_.fingerprint = hash ^ ((unsigned long long)(unsigned)nj_ << 32) ^ (unsigned)nb_;
             sched_.lds_groups = nbins;
-            sched_.group_offsets.assign(goff.begin(), goff.begin() + nbins + 1);
-            {   // GatherIslands' published numbers from the component sizes, as the builder's long way computes them
-                const int ncomp = spec[5];
-                int run = 0, count = 0, mx = 0;
-                for (int c = 0; c < ncomp; ++c) {
-                    run += (int)comp_size[c];
-                    if (run >= 256 || (run > 0 && c == ncomp - 1)) { ++count; mx = std::max(mx, run); run = 0; }
-                }
-                sched_.island_count = count; sched_.island_max_size = mx;
-            }
-            ncol.resize((size_t)nbins);
             spec_bins_guess_ = nbins; ncomp_guess_ = spec[5];
             stats_.lds_islands = nbins;
-            const bool split = last_island_mode_ == PHX_ISLAND_MULTIPLE || last_island_mode_ == PHX_ISLAND_MULTIPLE_SLOPPY;
-            stats_.island_count = split ? sched_.island_count : 1;
-            stats_.island_max_size = split ? sched_.island_max_size : nj_;
+            tables_pending_ = true; tables_bins_ = nbins; tables_comps_ = std::min(spec[5], std::min(BINC_MAX, nb_));
+            return;
         }
         sched_.lds_colours = 0;
         for (int n : ncol) sched_.lds_colours += n;
@@ -736,11 +697,44 @@ int DeviceSolver::synchronize()
     return collect_stats();
 }
 
+// The tables of the last speculative build, on demand (collect_stats): what a build with a host round trip would have left in
+// sched_ and stats_.  Callers have settled the solve (synchronize()), so nothing queued since can have overwritten them.
+int DeviceSolver::fetch_build_tables()
+{
+    if (!tables_pending_) return PHX_OK;
+    PHX_TRY(use_device(device_));
+    const int nbins = tables_bins_, ncomp = tables_comps_;
+    std::vector<int> goff((size_t)nbins + 1, 0), ncol((size_t)std::max(nbins, 1), 0);
+    std::vector<unsigned> comp_size((size_t)std::max(ncomp, 1), 0u);
+    PHX_TRY(rb_.add(goff.data(), bld_.bin_tables.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
+    if (nbins) PHX_TRY(rb_.add(ncol.data(), isl_.ncol.p, (size_t)nbins * sizeof(int), stream_));
+    if (ncomp) PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, (size_t)ncomp * sizeof(unsigned), stream_));
+    PHX_TRY(rb_.wait(stream_));
+    tables_pending_ = false;
+    sched_.group_offsets.assign(goff.begin(), goff.end());
+    {   // GatherIslands' published numbers from the component sizes, as the builder's long way computes them
+        int run = 0, count = 0, mx = 0;
+        for (int c = 0; c < ncomp; ++c) {
+            run += (int)comp_size[c];
+            if (run >= 256 || (run > 0 && c == ncomp - 1)) { ++count; mx = std::max(mx, run); run = 0; }
+        }
+        sched_.island_count = count; sched_.island_max_size = mx;
+    }
+    sched_.lds_colours = 0;
+    for (int g = 0; g < nbins; ++g) sched_.lds_colours += ncol[(size_t)g];
+    const bool split = last_island_mode_ == PHX_ISLAND_MULTIPLE || last_island_mode_ == PHX_ISLAND_MULTIPLE_SLOPPY;
+    stats_.island_count = split ? sched_.island_count : 1;
+    stats_.island_max_size = split ? sched_.island_max_size : nj_;
+    stats_.colour_count = sched_.ncolours();
+    return PHX_OK;
+}
+
 int DeviceSolver::get_stats(phx_solve_stats* out)
 {
     PHX_REQUIRE(out, "null out");
     if (!have_solve_) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
     PHX_TRY(synchronize());
+    PHX_TRY(fetch_build_tables());
     *out = stats_;
     return PHX_OK;
 }

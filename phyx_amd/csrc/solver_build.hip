@@ -65,6 +65,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
         }
     }
 
+    tables_pending_ = false;      // (a rebuild: whatever the last speculative build left unfetched on the device is about to be overwritten)
     // 2. topology changed.  Schedules are built on the device (only component sizes cross PCIe); the host builder below is
     //    the specification and the fallback (bins that exceed the caps, more than 64 colours, ...).
     if (device_builder) {
@@ -636,6 +637,7 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
 // schedule through the oracle) need them on the host.
 int DeviceSolver::materialise_schedule()
 {
+    PHX_TRY(fetch_build_tables());
     if (sched_.lds_on_host) return PHX_OK;
     const int lg = sched_.lds_groups;
     const int lds_slots = lg ? sched_.group_offsets[lg] : 0;
