@@ -12,7 +12,10 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o trace 
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o main -- python $R/bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_main.json 2> $O/main.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o pmc_fetch -- python $R/bench.py $ARGS > $O/bench_pmc_fetch.json 2> $O/pmc_fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o pmc_write -- python $R/bench.py $ARGS > $O/bench_pmc_write.json 2> $O/pmc_write.err
-timeout 600 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $O -o world -- python $R/tools/steady.py 12 --no-phase-timing > $O/world_steady.txt 2> $O/world.err
+# (two passes: with the markers traced, every roctx range costs the host microseconds and the kernel timeline grows gaps that a plain run does not have)
+timeout 600 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $O -o worldm -- python $R/tools/steady.py 12 --no-phase-timing > $O/world_steady_markers.txt 2> $O/worldm.err
+cp $O/worldm_marker_api_stats.csv $O/world_marker_api_stats.csv 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o world -- python $R/tools/steady.py 12 --no-phase-timing > $O/world_steady.txt 2> $O/world.err
 python $R/tools/timeline.py $O/world_kernel_trace.csv k_keys_buckets -v > $O/world_step_timeline.txt 2>&1
 for c in cfg4 cfg5; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${c}_trace -- python $R/tools/prof_cfg.py $c > $O/${c}_trace.txt 2> $O/${c}_trace.err
