@@ -411,6 +411,40 @@ def test_slab_worlds_are_exact_sub_worlds_and_the_guard_trips(oracle, built_lib)
             sw.step(1.0 / 60.0, cfg)
 
 
+def test_build_tables_are_fetched_on_demand(built_lib):
+    """A speculative schedule build leaves its tables (bin offsets, classes per bin, component sizes) on the device and the step's
+    settle brings back 64 bytes; the query API and the statistics fetch them when asked.  A world nobody asks must step byte for
+    byte like a twin that is asked every step, and answer the same when it finally is — also right after steps whose builds
+    nobody looked at."""
+    scene = scenes.stack(40, 30)
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 12, 8)
+    a, b = phyx_amd.World(0, gravity=-200.0), phyx_amd.World(0, gravity=-200.0)
+    a.add_scene(scene); b.add_scene(scene)
+    asked = 0
+    for step in range(11):
+        a.Update(1.0 / 60.0, cfg); b.Update(1.0 / 60.0, cfg)
+        sa, (ga, la), (oa, ca) = a.solver.stats(), a.solver.groups(), a.solver.schedule()
+        if step in (0, 5, 6, 10):
+            sb, (gb, lb), (ob, cb) = b.solver.stats(), b.solver.groups(), b.solver.schedule()
+            for f in ("lds_islands", "colour_count", "island_count", "island_max_size", "impulse_iterations", "joint_visits", "recoloured"):
+                assert getattr(sa, f) == getattr(sb, f), (step, f, getattr(sa, f), getattr(sb, f))
+            assert la == lb and np.array_equal(ga, gb) and np.array_equal(oa, ob) and np.array_equal(ca, cb), step
+            assert step == 0 or sb.recoloured == 2                          # (the path under test: a speculative rebuild; the first build reads its sizes back)
+            asked += 1
+        _same_world(b, a, "unasked world at step %d" % step)
+    assert asked == 4
+
+
+def test_world_lockstep_without_the_in_kernel_check(oracle, built_lib, monkeypatch):
+    """PHX_NO_FUSED_VERIFY=1: no solve may check its cached schedule inside the island launch, so the world takes the paths a scene
+    with more groups than fit the chip at once takes — speculative rebuilds that skip the topology-hash pass, and a rebuild with
+    one when a step's joints turn out unchanged and no hash is on record.  Byte for byte against the oracle all the same."""
+    monkeypatch.setenv("PHX_NO_FUSED_VERIFY", "1")
+    cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 12, 8)
+    _lockstep(oracle, scenes.stack(8, 30), 14, cfg)
+    _lockstep(oracle, scenes.falling(300, width=200.0, ymax=260.0), 40, cfg, check_every=4)
+
+
 def _emulated_slabs(scene, n, **kw):
     import types
     from phyx_amd import dist as pdist
