@@ -54,7 +54,9 @@ public:
     int solve_device(void* d_bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
     // the resident form (what the World and bench() use): reads vel / dvel / mpos, writes vel / dvel in place
     int solve_resident(const BodyView& bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
-    int synchronize();
+    // (`while_waiting`, may be null: queued-work hook of the settling round trip, Readback::wait — called at most once, and only if a
+    //  solve is pending; the caller checks whether it ran)
+    int synchronize(const std::function<int()>* while_waiting = nullptr);
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
     int set_body_state_bits(int bits);
@@ -139,7 +141,7 @@ private:
     int enqueue_post(const BodyView& bodies, int nb, phx_contact_joint* d_joints, int nj);
     int capture_graphs(const GraphKey& key, const BodyView& bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
     void drop_graphs();
-    int collect_stats(unsigned long long* extra = nullptr, const unsigned long long* extra_src = nullptr);
+    int collect_stats(unsigned long long* extra = nullptr, const unsigned long long* extra_src = nullptr, const std::function<int()>* while_waiting = nullptr);
     SolverView view() const;
 
     int device_;

@@ -542,7 +542,7 @@ int DeviceSolver::solve_host(phx_rigid_body* bodies, int nb, const phx_contact_p
 }
 
 // `extra`/`extra_src`: one more 8-byte value to fetch in the same round trip (the fingerprint of a speculative solve)
-int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long long* extra_src)
+int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long long* extra_src, const std::function<int()>* while_waiting)
 {
     // an unverified device build (build_schedule_device): the classes per group ride along; whether a bin was rejected shows in
     // the fingerprint the caller compares
@@ -585,7 +585,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     if (!stats_pending_) {
         if (extra) { PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_)); }
         PHX_TRY(with_build());
-        PHX_TRY(rb_.wait(stream_));
+        PHX_TRY(rb_.wait(stream_, nullptr, while_waiting));
         PHX_TRY(rest_of_sizes());
         settle_build();
         return PHX_OK;
@@ -600,7 +600,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     PHX_TRY(rb_.add(visit_slots, isl_.visits.p + (size_t)hash_slot_ * VISITS_SET, sizeof visit_slots, stream_));
     PHX_TRY(rb_.add(stamps, isl_.visits.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS, sizeof stamps, stream_));
     PHX_TRY(with_build());
-    PHX_TRY(rb_.wait(stream_));
+    PHX_TRY(rb_.wait(stream_, nullptr, while_waiting));
     PHX_TRY(rest_of_sizes());
     settle_build();
     int isl[2] = {0, 0};
@@ -646,13 +646,13 @@ int DeviceSolver::complete_partial()
     return PHX_OK;
 }
 
-int DeviceSolver::synchronize()
+int DeviceSolver::synchronize(const std::function<int()>* while_waiting)
 {
     PHX_TRY(use_device(device_));
     if (pending_.active) {
         // one round trip: the speculative solve's control word and its counters together
         unsigned long long fp = 0;
-        PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_));
+        PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_, while_waiting));
         const Pending p = pending_;
         pending_.active = false;
         const bool spoiled_build = build_was_unverified_ && fp != gate_expected_;      // a bin did not fit: the device build spoiled the control word

@@ -374,11 +374,20 @@ int World::solve_and_integrate(float dt, const phx_config& cfg)
     RoctxRange r("IntegratePosition");                                      // ref: World.cpp:57-70
     const bool pending = solver_.has_pending();
     const unsigned replays = solver_.replays();
-    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt,
-                                 pending ? solver_.fingerprint_word() : (const unsigned long long*)nullptr, solver_.expected_fingerprint());
-    PHX_HIP(hipGetLastError());
+    // (what the settle reads is final when the solve's last kernel ends, so its mailbox post goes in FRONT of the integrator and the
+    //  integrator is queued while the post crosses the link: the host wakes up a kernel earlier)
+    bool integrated = false;
+    const std::function<int()> integrate = [&]() -> int {
+        integrated = true;
+        if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt,
+                                     pending ? solver_.fingerprint_word() : (const unsigned long long*)nullptr, solver_.expected_fingerprint());
+        PHX_HIP(hipGetLastError());
+        return PHX_OK;
+    };
+    if (!pending) PHX_TRY(integrate());
     if (pending) {
-        PHX_TRY(solver_.synchronize());
+        PHX_TRY(solver_.synchronize(&integrate));
+        if (!integrated) { set_error("the settle did not queue the integrator"); return PHX_ERR_STATE; }
         if (solver_.replays() != replays && nb())
             hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);
         PHX_HIP(hipGetLastError());
