@@ -341,9 +341,9 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
     }
 }
 // emit pass for every row with at most ROW_CACHE new pairs: straight from what the count pass remembered
-__global__ void __launch_bounds__(256) k_emit_cached(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total)
+__device__ __forceinline__ void emit_cached_rows(const SweepView& v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total, int block, int blocks)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
+    for (int i = block * (int)blockDim.x + (int)threadIdx.x; i < v.n; i += blocks * (int)blockDim.x) {
         const unsigned dst = row_offset[i];
         const unsigned count = (i + 1 < v.n ? row_offset[i + 1] : total) - dst;
         if (count == 0 || count > (unsigned)ROW_CACHE) continue;     // nothing new, or a rescanned row
@@ -357,14 +357,14 @@ __global__ void __launch_bounds__(256) k_emit_cached(SweepView v, const unsigned
 
 // one workgroup per hub chunk; tiles of 256 candidates in j order, a running base keeps the emission order
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out)
+__device__ __forceinline__ void sweep_chunks(const SweepView& v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, int block, int blocks)
 {
     __shared__ unsigned wave_cnt[4];
     __shared__ unsigned running;
     const int total = min(*v.n_chunks, v.chunk_cap);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned long long overlaps_all = 0;
-    for (int c = blockIdx.x; c < total; c += gridDim.x) {
+    for (int c = block; c < total; c += blocks) {
         const int4 ch = v.chunks[c];
         const float4 a = v.entries[ch.x];
         const unsigned ia = v.idx[ch.x];
@@ -417,8 +417,19 @@ __global__ void __launch_bounds__(256) k_sweep_chunks(SweepView v, const unsigne
     }
     if (!EMIT) {                                           // one statistics atomic per wave for the whole launch, not per chunk
         for (int off = 32; off > 0; off >>= 1) overlaps_all += __shfl_down(overlaps_all, off);
-        if (lane == 0 && overlaps_all) atomicAdd(&v.counters[2 * ((blockIdx.x * 4 + wave) % STAT_SLOTS) + 1], overlaps_all);
+        if (lane == 0 && overlaps_all) atomicAdd(&v.counters[2 * ((block * 4 + wave) % STAT_SLOTS) + 1], overlaps_all);
     }
+}
+
+// the count pass over the hub rows' chunks
+__global__ void __launch_bounds__(256) k_sweep_chunks_count(SweepView v) { sweep_chunks<false>(v, nullptr, nullptr, (int)blockIdx.x, (int)gridDim.x); }
+
+// The emit pass, ONE launch: the first `row_blocks` workgroups emit the ordinary rows' new pairs from what the count pass remembered,
+// the others the hub rows' chunks — different rows, different places in the list (two launches of ~5 us each at the dispatch floor).
+__global__ void __launch_bounds__(256) k_emit_pairs(SweepView v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total, int row_blocks)
+{
+    if ((int)blockIdx.x < row_blocks) emit_cached_rows(v, row_offset, out, total, (int)blockIdx.x, row_blocks);
+    else sweep_chunks<true>(v, row_offset, out, (int)blockIdx.x - row_blocks, (int)gridDim.x - row_blocks);
 }
 
 // per hub row: chunk counts -> chunk bases inside the row, row_count[row] = sum.  A row's chunks are contiguous in the
@@ -605,7 +616,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         v.chunks = chunks_.p; v.chunk_count = chunk_count_.p; v.chunk_cap = chunk_cap;
         chunk_grid = std::min(chunk_cap, 2048);
         hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr, 0u);
-        hipLaunchKernelGGL((k_sweep_chunks<false>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr);
+        hipLaunchKernelGGL(k_sweep_chunks_count, dim3(chunk_grid), dim3(256), 0, stream_, v);
         // chunk counts -> per-row bases and the hub rows' totals (one small workgroup)
         PHX_TRY(chunk_scan_.reserve(chunk_cap + 1));
         hipLaunchKernelGGL(k_chunk_bases, dim3(1), dim3(1024), 0, stream_, v, chunk_scan_.p);
@@ -640,10 +651,12 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         if ((unsigned long long)(set_size_ + tombstones_ + (long long)total) * 2 > table_cap_)
             PHX_TRY(resize_table((unsigned)std::min<long long>(4ll * (set_size_ + (long long)total), 1ll << 30)));
         v.table = table_.p; v.mask = table_cap_ - 1;
-        hipLaunchKernelGGL(k_emit_cached, dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p, total);
+        {
+            const int row_blocks = grid_for(n), chunk_blocks = (host_small[2] & 0xFFFFFFFFull) ? std::min((int)(host_small[2] & 0xFFFFFFFFull), chunk_grid) : 0;
+            hipLaunchKernelGGL(k_emit_pairs, dim3(row_blocks + chunk_blocks), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p, total, row_blocks);
+        }
         if (host_small[4] & 0xFFFFFFFFull)      // some row found more than ROW_CACHE new pairs: those rows are rescanned
             hipLaunchKernelGGL((k_sweep_rows<true>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p, total);
-        if (host_small[2] & 0xFFFFFFFFull) hipLaunchKernelGGL((k_sweep_chunks<true>), dim3(chunk_grid), dim3(256), 0, stream_, v, (const unsigned*)row_count_.p, new_pairs_.p);
         // ref: Collider.cpp:313 / :341 — the emitted pairs join the persistent set
         hipLaunchKernelGGL(k_ps_insert, dim3(grid_for((int)total)), dim3(256), 0, stream_, table_.p, table_cap_ - 1, (const uint2*)new_pairs_.p, (int)total, stamps_.p + 1);
         PHX_HIP(hipGetLastError());
