@@ -102,8 +102,13 @@ static __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const unsig
 // hist scratch: radix_hist_words(n) words; scan scratch: ceil(that / SCAN_TILE) words.
 static inline size_t radix_hist_words(int n) { return (size_t)RS_WIDE_BINS * (size_t)std::max(1, div_up(n, RS_TILE)); }
 
+// digit width the sort will use for keys of `bits` bits (a caller that takes the first pass's histogram itself needs to know)
+static inline int radix_digit_bits(int bits) { return std::max(1, div_up(bits, RS_WIDE_BITS)) < std::max(1, div_up(bits, 8)) ? RS_WIDE_BITS : 8; }
+
+// (`first_hist_done`: hist already holds the first pass's per-workgroup digit counts in k_radix_hist's layout — the caller's key
+//  kernel counted them while it wrote the keys)
 static inline int device_radix_sort_pairs(unsigned* k0, unsigned* v0, unsigned* k1, unsigned* v1, int n, int bits,
-                                          unsigned* hist, ScanScratch& scan_scratch, hipStream_t stream, int* result_buffer)
+                                          unsigned* hist, ScanScratch& scan_scratch, hipStream_t stream, int* result_buffer, bool first_hist_done = false)
 {
     unsigned* kb[2] = {k0, k1};
     unsigned* vb[2] = {v0, v1};
@@ -115,8 +120,9 @@ static inline int device_radix_sort_pairs(unsigned* k0, unsigned* v0, unsigned* 
     if (n > 0)
         for (int pass = 0; pass < passes; ++pass) {
             const int shift = pass * width;
-            if (wide) hipLaunchKernelGGL((k_radix_hist<RS_WIDE_BITS>), dim3(nblocks), dim3(RS_THREADS), 0, stream, (const unsigned*)kb[src], n, shift, nblocks, hist);
-            else      hipLaunchKernelGGL((k_radix_hist<8>), dim3(nblocks), dim3(RS_THREADS), 0, stream, (const unsigned*)kb[src], n, shift, nblocks, hist);
+            if (pass == 0 && first_hist_done) {}
+            else if (wide) hipLaunchKernelGGL((k_radix_hist<RS_WIDE_BITS>), dim3(nblocks), dim3(RS_THREADS), 0, stream, (const unsigned*)kb[src], n, shift, nblocks, hist);
+            else           hipLaunchKernelGGL((k_radix_hist<8>), dim3(nblocks), dim3(RS_THREADS), 0, stream, (const unsigned*)kb[src], n, shift, nblocks, hist);
             PHX_TRY(device_exclusive_scan(hist, (wide ? RS_WIDE_BINS : RS_BINS) * nblocks, nullptr, scan_scratch, stream));
             if (wide) hipLaunchKernelGGL((k_radix_scatter<RS_WIDE_BITS>), dim3(nblocks), dim3(RS_THREADS), 0, stream, (const unsigned*)kb[src], (const unsigned*)vb[src],
                                          kb[src ^ 1], vb[src ^ 1], n, shift, nblocks, (const unsigned*)hist);

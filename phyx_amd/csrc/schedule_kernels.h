@@ -15,6 +15,7 @@
 #include "common.h"
 #include "schedule.h"
 #include "device_scan.h"
+#include "device_radix.h"
 
 namespace phx {
 
@@ -200,6 +201,33 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
         keys[j] = (unsigned)((c < 0 || c >= ncomp_cap) ? rest_key : bin_of_comp[c]);
         vals[j] = (unsigned)j;
     }
+}
+
+// k_joint_bin_keys and the first k_radix_hist of the sort behind it in one launch (device_radix.h's tile shape and histogram layout):
+// the keys are counted where they are made.
+template <int BITS>
+static __global__ void __launch_bounds__(RS_THREADS) k_joint_bin_keys_hist(const int* __restrict__ joint_comp, const int* __restrict__ bin_of_comp, int nj, int rest_key,
+                                                                           unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ rejected, int ncomp_cap,
+                                                                           int nblocks, unsigned* __restrict__ hist)
+{
+    constexpr int BINS = 1 << BITS;
+    __shared__ unsigned h[BINS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
+    for (int d = threadIdx.x; d < BINS; d += RS_THREADS) h[d] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int j = base + i * RS_THREADS + threadIdx.x;
+        if (j < nj) {
+            const int c = joint_comp[j];
+            const unsigned key = (unsigned)((c < 0 || c >= ncomp_cap) ? rest_key : bin_of_comp[c]);
+            keys[j] = key; vals[j] = (unsigned)j;
+            atomicAdd(&h[key & (unsigned)(BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < BINS; d += RS_THREADS) hist[d * nblocks + blockIdx.x] = h[d];
 }
 
 // ---- binning on the device -------------------------------------------------------------------------------------------

@@ -599,11 +599,18 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     }
     cv.scratch = bld_.bin_scratch.p;
     hipLaunchKernelGGL(k_bin_components, dim3(bin_groups), dim3(BINC_T), 0, stream_, cv);
-    hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
-                       bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX);
     int bits = 1, where = 0;
     while ((1 << bits) <= grid) ++bits;
-    PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where));
+    {   // the keys, counted for the sort's first pass where they are made
+        const int key_blocks = std::max(1, div_up(nj, RS_TILE));
+        if (radix_digit_bits(bits) == RS_WIDE_BITS)
+            hipLaunchKernelGGL((k_joint_bin_keys_hist<RS_WIDE_BITS>), dim3(key_blocks), dim3(RS_THREADS), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
+                               bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX, key_blocks, bld_.sort_hist.p);
+        else
+            hipLaunchKernelGGL((k_joint_bin_keys_hist<8>), dim3(key_blocks), dim3(RS_THREADS), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
+                               bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX, key_blocks, bld_.sort_hist.p);
+    }
+    PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where, true));
     PHX_TRY(isl_.desc.reserve(grid)); PHX_TRY(isl_.ncol.reserve(grid));
     PHX_TRY(isl_.bodies.reserve((size_t)grid * cap_bodies));
     PHX_TRY(isl_.slot_local.reserve(nj)); PHX_TRY(isl_.slot_colour.reserve(nj));
