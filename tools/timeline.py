@@ -16,14 +16,13 @@ for r in step:
     prev_end = max(prev_end, e)
 span = (prev_end - t0) / 1e3
 print("step span %.1f us, kernels %d, busy %.1f us, idle %.1f us" % (span, len(step), busy / 1e3, span - busy / 1e3))
-# the step proper ends with the settle's mailbox post behind k_integrate_position; what follows in the cut is the measuring script
-# reading statistics (round trips of its own)
+# the step proper ends with k_integrate_position (the settle's mailbox post sits in front of it); what follows in the cut is the
+# measuring script reading statistics (round trips of its own)
 names = [r["Kernel_Name"] for r in step]
 ip = [i for i, n in enumerate(names) if "k_integrate_position" in n]
 if ip:
-    tail = [i for i in range(ip[-1] + 1, len(step)) if "k_post_mail" in names[i]]
-    last = tail[0] if tail else ip[-1]
-    print("step proper (up to the settle's post): %.1f us, %d kernels" % ((int(step[last]["End_Timestamp"]) - t0) / 1e3, last + 1))
+    last = ip[-1]
+    print("step proper (up to IntegratePosition): %.1f us, %d kernels" % ((int(step[last]["End_Timestamp"]) - t0) / 1e3, last + 1))
 print("gaps > 3 us (gap us, at us, next kernel):")
 for g in sorted(gaps, reverse=True)[:25]: print("  %.1f  @%.1f  %s" % g)
 if "-v" in sys.argv:
