@@ -231,7 +231,7 @@ int World::update_pairs()                                                   // r
         PHX_TRY(scratch_for(nm));
         PHX_TRY(pack_flags_.reserve((size_t)nm + 2));
         hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
-                           pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm, (const uint2*)nullptr, 0);
+                           pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm, (const uint2*)nullptr, 0, counters_.p + 2);
         PHX_HIP(hipGetLastError());
         manifolds_updated_ = nm;
         return PHX_OK;
@@ -260,7 +260,7 @@ int World::update_manifolds()                                               // r
     PHX_TRY(scratch_for(nm));
     PHX_TRY(pack_flags_.reserve_keep((size_t)nm + 2, (size_t)first, stream_));      // (a pending pack keeps its scan in it until refresh_contact_joints settles it)
     hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm - first)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
-                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device(), first);
+                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device(), first, counters_.p + 2);
     fresh_manifolds_ = 0;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
@@ -270,8 +270,11 @@ int World::pack_manifolds()                                                 // r
 {
     pack_pending_ = false;
     if (!nm) return PHX_OK;
+    // counters_[2] holds the number of dead manifolds already (k_update_manifolds counts them); the scan of their flags — what the
+    // clean-up places its movers by — runs only when there are any: at once if the last step had some, else (the bet) after
+    // refresh_contact_joints' round trip has shown the count
+    if (expect_no_dead_manifolds_ && !phase_timing) { pack_pending_ = true; return PHX_OK; }
     PHX_TRY(device_exclusive_scan(pack_flags_.p, nm, counters_.p + 2, scan_tiles_, stream_));
-    if (expect_no_dead_manifolds_ && !phase_timing) { pack_pending_ = true; return PHX_OK; }      // settled by refresh_contact_joints' round trip
     unsigned host[2] = {0, 0};                                              // [0] dead manifolds, [1] dropped points
     PHX_TRY(rb_.add(host, counters_.p + 2, sizeof host, stream_));
     PHX_TRY(rb_.wait(stream_));
@@ -327,6 +330,7 @@ int World::refresh_contact_joints()                                         // r
         pack_pending_ = false;
         const int nm_before = nm;
         ++deferred_packs;
+        if (host[2]) PHX_TRY(device_exclusive_scan(pack_flags_.p, nm, counters_.p + 2, scan_tiles_, stream_));      // (the bet was lost: now the flags are scanned)
         PHX_TRY(finish_pack((int)host[2], (int)host[3]));
         if (nm == nm_before) break;
         ++deferred_pack_retries;                                            // the bet was lost: match again under a new epoch (one more pass: nothing is pending now)

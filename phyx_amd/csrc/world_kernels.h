@@ -143,8 +143,10 @@ __device__ __forceinline__ NpBody np_load(const WorldBodies& w, int i)
 // by an append kernel of their own in front of this one.
 static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, WorldBodies bodies,
                                                                  phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped,
-                                                                 int nm_old, const uint2* __restrict__ new_pairs, int first)
+                                                                 int nm_old, const uint2* __restrict__ new_pairs, int first, unsigned* __restrict__ dead_count)
 {
+    // (`dead_count`: the step's dead-manifold counter, world.hip — dead manifolds are rare, and a count taken here lets PackManifolds'
+    //  scan over all manifolds run only in the steps that have one)
     // (`first`: manifolds [first, nm) — the old manifolds are updated while the host waits for the new-pair count, the new ones
     //  in a launch of their own once it is known, world.hip)
     for (int i = first + blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
@@ -161,7 +163,9 @@ static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* _
         const NpBody b1 = np_load(bodies, m.body1), b2 = np_load(bodies, m.body2);
         if (update_manifold(m, b1, b2, cps + m.point_index)) atomicAdd(dropped, 1);
         manifolds[i] = m;
-        dead[i] = (m.point_count == 0 && !aabb_intersects(bodies.aabb[m.body1], bodies.aabb[m.body2])) ? 1u : 0u;
+        const bool gone = m.point_count == 0 && !aabb_intersects(bodies.aabb[m.body1], bodies.aabb[m.body2]);
+        dead[i] = gone ? 1u : 0u;
+        if (gone) atomicAdd(dead_count, 1u);
     }
 }
 
