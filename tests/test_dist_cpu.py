@@ -29,6 +29,12 @@ WORKER = textwrap.dedent("""
     allb = g.all_gather_bytes(seg)
     assert allb.shape == (1024,) and (allb[4:512] == 10).all() and (allb[516:] == 11).all()
     assert allb[:4].tobytes() == allb[512:516].tobytes() == b"PHXE"
+    blobs = pdist.all_gather_blobs(g, pdist._blob(np.arange(3 + 5 * g.rank, dtype=np.int64), np.full(2, g.rank, dtype=np.float32)))   # the re-slab's all-gather: byte strings of different lengths
+    for r, b in enumerate(blobs):
+        idx, tag = pdist._unblob(b, (np.int64, np.float32))
+        assert len(idx) == 3 + 5 * r and idx[-1] == 2 + 5 * r and (tag == r).all()
+    verdicts = [g.step_barrier_value(1 if (g.rank == 1 and k == 1) else 0) for k in range(3)]   # the slab guard's verdict reaches every rank
+    assert verdicts == [0, 1, 0]
     t = g.reduce_max(1.0 + g.rank)                          # max over ranks (timing)
     units = g.reduce_sum(float(n))                          # whole-job units
     print(json.dumps({"rank": g.rank, "world": g.world_size, "first": first, "n": n, "t": t, "units": units, "flags": flags}))
