@@ -475,6 +475,15 @@ def test_reslab_with_unchanged_cuts_hands_every_world_back_as_it_was(built_lib):
         for sw, twin in zip(a, b):
             sw.world.Update(1.0 / 60.0, cfg); twin.world.Update(1.0 / 60.0, cfg)
             _same_world(sw.world, twin.world, "re-slabbed rank %d at step %d" % (sw.group.rank, step))
+    # one rank: the collective form (reslab(): pack, all-gather, apply) over the single-process group is the identity too
+    from phyx_amd import dist as pdist
+    one = pdist.SlabWorld(pdist.Single(), scene, device=0, gravity=-200.0, reslab_every=2)
+    twin = phyx_amd.World(0, gravity=-200.0)
+    twin.add_scene(scene)
+    for step in range(5):
+        one.step(1.0 / 60.0, cfg); twin.Update(1.0 / 60.0, cfg)
+        _same_world(one.world, twin, "single-rank slab world at step %d" % step)
+    assert one.reslabs == 2 and one.inside()
 
 
 def test_reslab_follows_piles_that_grow_into_each_other(built_lib):
