@@ -88,6 +88,15 @@ typedef struct { uint32_t value, index; } phx_sort_entry;                       
 /* ---------------------------------------------------------------------------------------------- */
 /* library                                                                                         */
 int          phx_abi_version(void);
+/* The arithmetic of the sweeps (PreStepJoints, SolveJointsImpulses, SolveJointsDisplacement; ref: src/Solver.cpp:697-1018), fixed
+ * when the library is built.  The reference writes `dV -= projector * velocity` / `velocity += compMass * dImpulse` and ships
+ * -ffast-math -mfma (ref: Makefile:11, 17-24), which leaves fusing those pairs to its compiler; this backend states it:
+ *   PHX_ARITH_FUSED   every such multiply-add pair is one fused multiply-add (fmaf), in the reference's source order — the default;
+ *   PHX_ARITH_SOURCE  a rounded product and a rounded sum, as the source spells it (`PHX_ARITH=source python -m phyx_amd.build`).
+ * RefreshJoints and everything outside the sweeps is source order in both.  oracle/ has both forms; parity is bit-exact against
+ * the matching one, and the two forms stay within SURVEY.md section 8(c)'s tolerances of each other (tests/test_arith_modes.py). */
+enum { PHX_ARITH_SOURCE = 0, PHX_ARITH_FUSED = 1 };
+int          phx_arith_mode(void);
 const char*  phx_last_error(void);
 int          phx_device_count(void);              /* >=0, or a negative phx_status */
 /* name / CU count / LDS per workgroup of `device`; name_cap bytes incl. NUL */

@@ -70,7 +70,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        # PHX_ORACLE_SAN=1: the ASan + UBSan build (`make -C oracle asan`; run under LD_PRELOAD of libasan, `make -C oracle asan_test`)
+        L = C.CDLL(os.path.join(_HERE, "liboracle_asan.so" if os.environ.get("PHX_ORACLE_SAN") == "1" else "liboracle.so"))
         L.phxo_radix_float.restype = C.c_uint32
         L.phxo_radix_float.argtypes = [C.c_float]
         L.phxo_pair_hash.restype = C.c_uint32
@@ -87,6 +88,8 @@ def lib():
         L.phxo_project_point_to_line.argtypes = [C.c_float] * 8 + [C.c_void_p]
         L.phxo_flipsign.restype = C.c_float
         L.phxo_flipsign.argtypes = [C.c_float, C.c_float, C.c_int]
+        L.phxo_set_arith.argtypes = [C.c_int]
+        L.phxo_get_arith.restype = C.c_int
         L.phxo_max.restype = C.c_float
         L.phxo_max.argtypes = [C.c_float, C.c_float]
         L.phxo_aabb_intersects.restype = C.c_int
@@ -175,6 +178,21 @@ def ref_lib():
                 getattr(R, name).argtypes = [C.c_int, C.c_float, C.c_float]
         _ref = R
     return _ref
+
+
+ARITH_SOURCE, ARITH_FUSED = 0, 1
+
+
+def set_arith(fused):
+    """The sweeps' arithmetic form of every later oracle solve (phx_oracle.c mul_add / mul_sub): ARITH_SOURCE = rounded product +
+    rounded sum, ARITH_FUSED = one fmaf per multiply-add pair.  Process-wide; returns the previous form."""
+    prev = lib().phxo_get_arith()
+    lib().phxo_set_arith(int(fused))
+    return prev
+
+
+def get_arith():
+    return lib().phxo_get_arith()
 
 
 class OracleWorld:
@@ -351,6 +369,8 @@ def baseline_lib(kind="fast"):
     """kind: 'fast' (-O3 -ffast-math -mavx2 -mfma, the reference's Makefile flags) or 'strict' (the oracle's flags)."""
     if kind not in _baseline:
         so = os.path.join(_HERE, "libcpubaseline_%s.so" % kind)
+        if os.environ.get("PHX_ORACLE_SAN") == "1":
+            so = os.path.join(_HERE, "libcpubaseline_%s_asan.so" % kind)
         src = os.path.join(_HERE, "cpu_baseline.c")
         if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
             subprocess.check_call(["make", "-C", _HERE, os.path.basename(so)], stdout=subprocess.DEVNULL)

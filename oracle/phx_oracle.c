@@ -434,15 +434,29 @@ void phxo_refresh_joint(const phxo_body* bodies, const phxo_contact_point* cps, 
     memcpy(out + 17, &J.f, 13 * sizeof(float));
 }
 
+/* ---- the sweeps' arithmetic form ------------------------------------------------------------------------------------
+ * The reference writes `dV -= projector * velocity` and `velocity += compMass * dImpulse` (ref: Solver.cpp:736-750, 833-858,
+ * 866-889, 973-996) and is built -ffast-math -mfma (ref: Makefile:11, 17-24): whether such a pair is one fused multiply-add
+ * or a rounded product and a rounded sum is its compiler's choice.  The oracle restates both, in the reference's source order:
+ *   PHXO_ARITH_SOURCE (0, default)  product and sum rounded separately — what this file's -ffp-contract=off gives the plain text;
+ *   PHXO_ARITH_FUSED  (1)           every such pair is one fmaf() (correctly rounded once, C99 7.12.13.1).
+ * Nothing else differs (RefreshJoints, the clamps, the productive tests, the order of the joints).  Process-wide, set by the
+ * tests to the form the library under test reports (phx_arith_mode). */
+static int g_arith = 0;
+void phxo_set_arith(int fused) { g_arith = fused ? 1 : 0; }
+int phxo_get_arith(void) { return g_arith; }
+static inline float mul_add(float a, float b, float acc) { return g_arith ? fmaf(a, b, acc) : acc + a * b; }      /* acc + a * b */
+static inline float mul_sub(float a, float b, float acc) { return g_arith ? fmaf(-a, b, acc) : acc - a * b; }     /* acc - a * b */
+
 /* ref: Solver.cpp:697-758 PreStepJoints<1,1> body */
 static void prestep_one(const pjoint* J, sbody* imp, int half, const uint8_t* is_static)
 {
     sbody *b1 = &imp[J->b1], *b2 = &imp[J->b2];
     float v1x = b1->vx, v1y = b1->vy, w1 = b1->w, v2x = b2->vx, v2y = b2->vy, w2 = b2->w;
-    v1x += J->n.c1x * J->n_acc; v1y += J->n.c1y * J->n_acc; w1 += J->n.c1a * J->n_acc;
-    v2x += J->n.c2x * J->n_acc; v2y += J->n.c2y * J->n_acc; w2 += J->n.c2a * J->n_acc;
-    v1x += J->f.c1x * J->f_acc; v1y += J->f.c1y * J->f_acc; w1 += J->f.c1a * J->f_acc;
-    v2x += J->f.c2x * J->f_acc; v2y += J->f.c2y * J->f_acc; w2 += J->f.c2a * J->f_acc;
+    v1x = mul_add(J->n.c1x, J->n_acc, v1x); v1y = mul_add(J->n.c1y, J->n_acc, v1y); w1 = mul_add(J->n.c1a, J->n_acc, w1);
+    v2x = mul_add(J->n.c2x, J->n_acc, v2x); v2y = mul_add(J->n.c2y, J->n_acc, v2y); w2 = mul_add(J->n.c2a, J->n_acc, w2);
+    v1x = mul_add(J->f.c1x, J->f_acc, v1x); v1y = mul_add(J->f.c1y, J->f_acc, v1y); w1 = mul_add(J->f.c1a, J->f_acc, w1);
+    v2x = mul_add(J->f.c2x, J->f_acc, v2x); v2y = mul_add(J->f.c2y, J->f_acc, v2y); w2 = mul_add(J->f.c2a, J->f_acc, w2);
     /* a static body's compMass is 0, so its velocity is unchanged; the fp16 form (like the device) does not store it */
     if (!(half && is_static[J->b1])) { b1->vx = qh(half, v1x); b1->vy = qh(half, v1y); b1->w = qh(half, w1); }
     if (!(half && is_static[J->b2])) { b2->vx = qh(half, v2x); b2->vy = qh(half, v2y); b2->w = qh(half, w2); }
@@ -497,17 +511,17 @@ static int impulse_one(pjoint* J, sbody* imp, int simd_flipsign, float* out_dn, 
     const limiter *N = &J->n, *F = &J->f;
 
     float dv = J->n_dst;
-    dv -= N->p1x * v1x; dv -= N->p1y * v1y; dv -= N->a1 * w1;
-    dv -= N->p2x * v2x; dv -= N->p2y * v2y; dv -= N->a2 * w2;
+    dv = mul_sub(N->p1x, v1x, dv); dv = mul_sub(N->p1y, v1y, dv); dv = mul_sub(N->a1, w1, dv);
+    dv = mul_sub(N->p2x, v2x, dv); dv = mul_sub(N->p2y, v2y, dv); dv = mul_sub(N->a2, w2, dv);
     float dn = dv * N->cim;
     dn = maxf_ref(dn, -J->n_acc);
-    v1x += N->c1x * dn; v1y += N->c1y * dn; w1 += N->c1a * dn;
-    v2x += N->c2x * dn; v2y += N->c2y * dn; w2 += N->c2a * dn;
+    v1x = mul_add(N->c1x, dn, v1x); v1y = mul_add(N->c1y, dn, v1y); w1 = mul_add(N->c1a, dn, w1);
+    v2x = mul_add(N->c2x, dn, v2x); v2y = mul_add(N->c2y, dn, v2y); w2 = mul_add(N->c2a, dn, w2);
     J->n_acc += dn;
 
     float fv = 0.f;
-    fv -= F->p1x * v1x; fv -= F->p1y * v1y; fv -= F->a1 * w1;
-    fv -= F->p2x * v2x; fv -= F->p2y * v2y; fv -= F->a2 * w2;
+    fv = mul_sub(F->p1x, v1x, fv); fv = mul_sub(F->p1y, v1y, fv); fv = mul_sub(F->a1, w1, fv);
+    fv = mul_sub(F->p2x, v2x, fv); fv = mul_sub(F->p2y, v2y, fv); fv = mul_sub(F->a2, w2, fv);
     float df = fv * F->cim;
     float reaction = J->n_acc, acc = J->f_acc;
     float force = acc + df;
@@ -516,8 +530,8 @@ static int impulse_one(pjoint* J, sbody* imp, int simd_flipsign, float* out_dn, 
     float adjusted = signed_limit - acc;
     if (fabsf(force) > limit) df = adjusted;
     J->f_acc += df;
-    v1x += F->c1x * df; v1y += F->c1y * df; w1 += F->c1a * df;
-    v2x += F->c2x * df; v2y += F->c2y * df; w2 += F->c2a * df;
+    v1x = mul_add(F->c1x, df, v1x); v1y = mul_add(F->c1y, df, v1y); w1 = mul_add(F->c1a, df, w1);
+    v2x = mul_add(F->c2x, df, v2x); v2y = mul_add(F->c2y, df, v2y); w2 = mul_add(F->c2a, df, w2);
 
     if (!(half && is_static[J->b1])) { b1->vx = qh(half, v1x); b1->vy = qh(half, v1y); b1->w = qh(half, w1); }
     if (!(half && is_static[J->b2])) { b2->vx = qh(half, v2x); b2->vy = qh(half, v2y); b2->w = qh(half, w2); }
@@ -532,12 +546,12 @@ static int displacement_one(pjoint* J, sbody* disp, int half, const uint8_t* is_
     const limiter* N = &J->n;
     float v1x = b1->vx, v1y = b1->vy, w1 = b1->w, v2x = b2->vx, v2y = b2->vy, w2 = b2->w;
     float dv = J->n_dst_disp;
-    dv -= N->p1x * v1x; dv -= N->p1y * v1y; dv -= N->a1 * w1;
-    dv -= N->p2x * v2x; dv -= N->p2y * v2y; dv -= N->a2 * w2;
+    dv = mul_sub(N->p1x, v1x, dv); dv = mul_sub(N->p1y, v1y, dv); dv = mul_sub(N->a1, w1, dv);
+    dv = mul_sub(N->p2x, v2x, dv); dv = mul_sub(N->p2y, v2y, dv); dv = mul_sub(N->a2, w2, dv);
     float di = dv * N->cim;
     di = maxf_ref(di, -J->n_acc_disp);
-    v1x += N->c1x * di; v1y += N->c1y * di; w1 += N->c1a * di;
-    v2x += N->c2x * di; v2y += N->c2y * di; w2 += N->c2a * di;
+    v1x = mul_add(N->c1x, di, v1x); v1y = mul_add(N->c1y, di, v1y); w1 = mul_add(N->c1a, di, w1);
+    v2x = mul_add(N->c2x, di, v2x); v2y = mul_add(N->c2y, di, v2y); w2 = mul_add(N->c2a, di, w2);
     J->n_acc_disp += di;
     if (!(half && is_static[J->b1])) { b1->vx = qh(half, v1x); b1->vy = qh(half, v1y); b1->w = qh(half, w1); }
     if (!(half && is_static[J->b2])) { b2->vx = qh(half, v2x); b2->vy = qh(half, v2y); b2->w = qh(half, w2); }

@@ -102,6 +102,10 @@ void     phxo_contact_point_make(phxo_contact_point* out, float p1x, float p1y, 
 void     phxo_project_point_to_line(float px, float py, float qx, float qy, float nx, float ny, float dx, float dy, float out[2]); /* Vector2.h ProjectPointToLine */
 int      phxo_aabb_intersects(const phxo_body* a, const phxo_body* b);      /* AABB2.h:18-24 */
 float    phxo_flipsign(float x, float y, int simd);   /* simd = 0: SIMD_Scalar.h:265-268; 1: SIMD_SSE2.h / SIMD_AVX2.h:272-275 (sign-bit xor) */
+/* the sweeps' arithmetic form (phx_oracle.c: mul_add / mul_sub): 0 = PHXO_ARITH_SOURCE (default), 1 = PHXO_ARITH_FUSED.  Process-wide. */
+enum { PHXO_ARITH_SOURCE = 0, PHXO_ARITH_FUSED = 1 };
+void     phxo_set_arith(int fused);
+int      phxo_get_arith(void);
 float    phxo_max(float l, float r);                  /* SIMD_Scalar.h:275-278 = the SSE2 / AVX2 max on non-NaN inputs */
 
 /* ---- broadphase stages on raw arrays (Collider.cpp:251-366) ---- */

@@ -52,6 +52,7 @@ _vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
 STEP_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32)      # phx_step_hook(user, step, phase)
 _SIGNATURES = {
     "phx_abi_version": (C.c_int, []),
+    "phx_arith_mode": (C.c_int, []),
     "phx_last_error": (C.c_char_p, []),
     "phx_device_count": (C.c_int, []),
     "phx_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),

@@ -26,6 +26,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 FILE_FLAGS = {"islands.hip": ["-fno-slp-vectorize", "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}      # (it includes solver_kernels.h for the shared device helpers only)
 # roctx ranges (phase names of the reference's MICROPROFILE scopes) are resolved at run time with dlopen: no link dependency
 LINK = ["-shared", "-ldl"]
+# the sweeps' arithmetic contract (include/phyx_amd.h phx_arith_mode): fused multiply-adds unless PHX_ARITH=source
+if os.environ.get("PHX_ARITH", "fused") == "source":
+    FLAGS = FLAGS + ["-DPHX_ARITH_FMA=0"]
 
 
 def hipcc():
@@ -45,8 +48,14 @@ def _header_time():
     return max(os.path.getmtime(d) for d in deps)
 
 
+def _flags_changed():
+    """The objects on disk were compiled under other flags (PHX_ARITH): everything is stale."""
+    stamp = os.path.join(OBJ, "flags.txt")
+    return not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS)
+
+
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or _flags_changed():
         return True
     t = os.path.getmtime(OUT)
     return _header_time() > t or any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in _sources())
@@ -71,6 +80,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _flags_changed()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         results = list(pool.map(lambda s: _compile(s, force, verbose), _sources()))
     objs = [o for o, _ in results]
@@ -82,6 +92,8 @@ def build(force=False, verbose=False):
     if res.returncode != 0:
         sys.stderr.write(res.stdout)
         raise RuntimeError("hipcc failed linking libphyx_amd.so")
+    with open(os.path.join(OBJ, "flags.txt"), "w") as f:
+        f.write(" ".join(FLAGS))
     if verbose and (log + res.stdout).strip():
         print(log + res.stdout)
     return OUT

@@ -16,6 +16,11 @@
 
 #include "../../include/phyx_amd.h"
 
+// the sweeps' arithmetic contract (solver_kernels.h mul_add / mul_sub; phx_arith_mode): 1 = fused multiply-adds (default), 0 = source order
+#ifndef PHX_ARITH_FMA
+#define PHX_ARITH_FMA 1
+#endif
+
 static_assert(sizeof(phx_rigid_body) == 128, "RigidBody layout (ref: src/RigidBody.h:12-57)");
 static_assert(sizeof(phx_contact_point) == 32, "ContactPoint layout (ref: src/Manifold.h:12-43)");
 static_assert(sizeof(phx_manifold) == 16, "Manifold layout (ref: src/Manifold.h:45-67)");

@@ -77,10 +77,42 @@ __device__ __forceinline__ void isl_refresh(IslJoint& q, float d1x, float d1y, f
 __device__ __forceinline__ void isl_prestep(const IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2)
 {
     const float tx = -q.ny, ty = q.nx;
-    B1.x += (q.nx * im1) * q.accN; B1.y += (q.ny * im1) * q.accN; B1.z += (q.aN1 * ii1) * q.accN;
-    B1.x += (tx * im1) * q.accF; B1.y += (ty * im1) * q.accF; B1.z += (q.aF1 * ii1) * q.accF;
-    B2.x += ((-q.nx) * im2) * q.accN; B2.y += ((-q.ny) * im2) * q.accN; B2.z += (q.aN2 * ii2) * q.accN;
-    B2.x += ((-tx) * im2) * q.accF; B2.y += ((-ty) * im2) * q.accF; B2.z += (q.aF2 * ii2) * q.accF;
+    B1.x = mul_add(q.nx * im1, q.accN, B1.x); B1.y = mul_add(q.ny * im1, q.accN, B1.y); B1.z = mul_add(q.aN1 * ii1, q.accN, B1.z);
+    B1.x = mul_add(tx * im1, q.accF, B1.x); B1.y = mul_add(ty * im1, q.accF, B1.y); B1.z = mul_add(q.aF1 * ii1, q.accF, B1.z);
+    B2.x = mul_add((-q.nx) * im2, q.accN, B2.x); B2.y = mul_add((-q.ny) * im2, q.accN, B2.y); B2.z = mul_add(q.aN2 * ii2, q.accN, B2.z);
+    B2.x = mul_add((-tx) * im2, q.accF, B2.x); B2.y = mul_add((-ty) * im2, q.accF, B2.y); B2.z = mul_add(q.aF2 * ii2, q.accF, B2.z);
+}
+
+// the arithmetic of one impulse visit (ref: Solver.cpp:800-896) on the two bodies held in registers; returns whether the joint moved
+// (kProductiveImpulse, ref: Solver.cpp:8, 894-896).  The skip test and the tags are the caller's.
+__device__ __forceinline__ bool isl_impulse_eval(IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2)
+{
+    // (Measured and removed: the x / y halves of every body-wide step as v_pk_mul_f32 / v_pk_add_f32 on the register pairs a
+    //  ds_read_b128 leaves — 24 VALU instructions fewer per unit of ~145, no extra moves, bit-exact — is 3 % SLOWER: the step is a
+    //  dependent chain, a packed fp32 operation occupies the pipe twice as long as a plain one, and nothing waits to fill the slots
+    //  it frees.  DESIGN.md §4.2.)
+    const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
+    float dv = q.dstV;
+    dv = mul_sub(nx, B1.x, dv); dv = mul_sub(ny, B1.y, dv); dv = mul_sub(q.aN1, B1.z, dv);
+    dv = mul_sub(-nx, B2.x, dv); dv = mul_sub(-ny, B2.y, dv); dv = mul_sub(q.aN2, B2.z, dv);
+    float dn = dv * q.cimN;
+    dn = max_ref(dn, -q.accN);
+    B1.x = mul_add(nx * im1, dn, B1.x); B1.y = mul_add(ny * im1, dn, B1.y); B1.z = mul_add(q.aN1 * ii1, dn, B1.z);
+    B2.x = mul_add((-nx) * im2, dn, B2.x); B2.y = mul_add((-ny) * im2, dn, B2.y); B2.z = mul_add(q.aN2 * ii2, dn, B2.z);
+    q.accN += dn;
+    float fv = 0.f;
+    fv = mul_sub(tx, B1.x, fv); fv = mul_sub(ty, B1.y, fv); fv = mul_sub(q.aF1, B1.z, fv);
+    fv = mul_sub(-tx, B2.x, fv); fv = mul_sub(-ty, B2.y, fv); fv = mul_sub(q.aF2, B2.z, fv);
+    float df = fv * q.cimF;
+    const float force = q.accF + df;
+    const float limit = q.accN * 0.3f;
+    const float signed_limit = force < 0.f ? -limit : limit;
+    const float adjusted = signed_limit - q.accF;
+    if (fabsf(force) > limit) df = adjusted;
+    q.accF += df;
+    B1.x = mul_add(tx * im1, df, B1.x); B1.y = mul_add(ty * im1, df, B1.y); B1.z = mul_add(q.aF1 * ii1, df, B1.z);
+    B2.x = mul_add((-tx) * im2, df, B2.x); B2.y = mul_add((-ty) * im2, df, B2.y); B2.z = mul_add(q.aF2 * ii2, df, B2.z);
+    return max_ref(fabsf(dn), fabsf(df)) > 1e-4f;
 }
 
 // one impulse visit (ref: Solver.cpp:790-896); returns whether the joint was evaluated (not skipped), `productive` whether it moved.
@@ -93,33 +125,8 @@ __device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2,
     const bool p2 = st2 ? sp2 : (__float_as_int(B2.w) > it - 2);
     productive = false;
     if (!(p1 || p2)) return false;        // (a 'likely' hint on the evaluated path was measured 2 % slower)
-    // (Measured and removed: the x / y halves of every body-wide step as v_pk_mul_f32 / v_pk_add_f32 on the register pairs a
-    //  ds_read_b128 leaves — 24 VALU instructions fewer per unit of ~145, no extra moves, bit-exact — is 3 % SLOWER: the step is a
-    //  dependent chain, a packed fp32 operation occupies the pipe twice as long as a plain one, and nothing waits to fill the slots
-    //  it frees.  DESIGN.md §4.2.)
-    const float nx = q.nx, ny = q.ny, tx = -ny, ty = nx;
-    float dv = q.dstV;
-    dv -= nx * B1.x; dv -= ny * B1.y; dv -= q.aN1 * B1.z;
-    dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= q.aN2 * B2.z;
-    float dn = dv * q.cimN;
-    dn = max_ref(dn, -q.accN);
-    B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (q.aN1 * ii1) * dn;
-    B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (q.aN2 * ii2) * dn;
-    q.accN += dn;
-    float fv = 0.f;
-    fv -= tx * B1.x; fv -= ty * B1.y; fv -= q.aF1 * B1.z;
-    fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= q.aF2 * B2.z;
-    float df = fv * q.cimF;
-    const float force = q.accF + df;
-    const float limit = q.accN * 0.3f;
-    const float signed_limit = force < 0.f ? -limit : limit;
-    const float adjusted = signed_limit - q.accF;
-    if (fabsf(force) > limit) df = adjusted;
-    q.accF += df;
-    B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (q.aF1 * ii1) * df;
-    B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (q.aF2 * ii2) * df;
+    productive = isl_impulse_eval(q, B1, B2, im1, ii1, im2, ii2);
     // (the tags by select, not under a branch: an exec-mask region — save, two moves, restore — per joint was 1.3 % of the launch)
-    productive = max_ref(fabsf(dn), fabsf(df)) > 1e-4f;
     B1.w = productive ? __int_as_float(it) : B1.w; B2.w = productive ? __int_as_float(it) : B2.w;
     return true;
 }
@@ -134,12 +141,12 @@ __device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2
     if (!(p1 || p2)) return false;
     const float nx = q.nx, ny = q.ny;
     float dv = q.dstD;
-    dv -= nx * D1.x; dv -= ny * D1.y; dv -= q.aN1 * D1.z;
-    dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= q.aN2 * D2.z;
+    dv = mul_sub(nx, D1.x, dv); dv = mul_sub(ny, D1.y, dv); dv = mul_sub(q.aN1, D1.z, dv);
+    dv = mul_sub(-nx, D2.x, dv); dv = mul_sub(-ny, D2.y, dv); dv = mul_sub(q.aN2, D2.z, dv);
     float di = dv * q.cimN;
     di = max_ref(di, -q.accD);
-    D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (q.aN1 * ii1) * di;
-    D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (q.aN2 * ii2) * di;
+    D1.x = mul_add(nx * im1, di, D1.x); D1.y = mul_add(ny * im1, di, D1.y); D1.z = mul_add(q.aN1 * ii1, di, D1.z);
+    D2.x = mul_add((-nx) * im2, di, D2.x); D2.y = mul_add((-ny) * im2, di, D2.y); D2.z = mul_add(q.aN2 * ii2, di, D2.z);
     q.accD += di;
     productive = fabsf(di) > 1e-4f;
     D1.w = productive ? __int_as_float(it) : D1.w; D2.w = productive ? __int_as_float(it) : D2.w;
@@ -309,6 +316,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         // class step of sweep it - 1 has put a barrier in between — so the sweep needs no barrier of its own at its end
         const int slot = it % 3;
         if (tid == 0) { const int next = slot == 2 ? 0 : slot + 1; flag_imp[next] = 0; flag_disp[next] = 0; }
+        const bool hot = imp_on && !disp_on;      // (workgroup-uniform, fixed for the sweep)
         for (int c = 0; c < ncol; ++c) {
             const unsigned long long ts0 = TRACE ? __builtin_readcyclecounter() : 0ull;
             const bool working = TRACE && __any(col == c);
@@ -360,7 +368,45 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                         if (!s2) body_store(disp, l2, D2);
                     }
                 };
-                if (wave_static) {
+                // THE HOT FORM of a class step: impulses only (the displacement sweeps of a resting scene end after the first: nothing is
+                // deeper than the allowed penetration, ref: Solver.cpp:672-680, 210).  One skip test per unit — the follower's test equals
+                // its leader's: a skipped leader changes no tag, and an evaluated one either leaves the tags as they were or raises
+                // them to `it` — and one tag update; straight-line but for the follower's mask: a class step is one wave's instruction
+                // stream, and every taken branch in it is ~20 cycles.  `ws` = some unit of the wave touches a static body (wave-uniform):
+                // only then the static tags are looked up and raised, the static records restored between the joints and left unstored —
+                // same results as imp_step (the general form keeps the first sweep, where the displacement half runs too).
+                auto imp_fast = [&](const bool ws) {
+                    float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
+                    // (both records in ONE LDS round trip: left alone, the compiler reads the two tags, tests, and only then — under the
+                    //  branch — the six velocity words: two dependent round trips on the critical path of every class step)
+                    if (!HALF) asm volatile("" : "+v"(B1.x), "+v"(B1.y), "+v"(B1.z), "+v"(B1.w), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(B2.w));
+                    bool active = max(__float_as_int(B1.w), __float_as_int(B2.w)) > it - 2;
+                    if (ws) {
+                        const bool sp1 = st1 && static_productive_lds(swi, l1, it, c), sp2 = st2 && static_productive_lds(swi, l2, it, c);
+                        active = (st1 ? sp1 : (__float_as_int(B1.w) > it - 2)) || (st2 ? sp2 : (__float_as_int(B2.w) > it - 2));
+                    }
+                    if (active) {
+                        const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
+                        bool prod = isl_impulse_eval(q0, B1, B2, im1, ii1, im2, ii2);
+                        if (has2) {
+                            if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
+                            if (ws) { if (st1) B1 = S1; if (st2) B2 = S2; }
+                            prod |= isl_impulse_eval(q1, B1, B2, im1, ii1, im2, ii2);
+                        }
+                        B1.w = prod ? __int_as_float(it) : B1.w; B2.w = prod ? __int_as_float(it) : B2.w;
+                        if (prod) {
+                            flag_imp[slot] = 1;
+                            if (ws) {
+                                if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
+                                if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+                            }
+                        }
+                        if (!ws || !st1) body_store(imp, l1, B1);
+                        if (!ws || !st2) body_store(imp, l2, B2);
+                    }
+                };
+                if (hot) { if (wave_static) imp_fast(true); else imp_fast(false); }
+                else if (wave_static) {
                     if (imp_on) imp_step(st1, st2, has2);
                     if (disp_on) disp_step(st1, st2, has2);
                 } else {

@@ -64,6 +64,7 @@ int use_device(int device)
 extern "C" {
 
 int phx_abi_version(void) { return PHX_ABI_VERSION; }
+int phx_arith_mode(void) { return PHX_ARITH_FMA ? PHX_ARITH_FUSED : PHX_ARITH_SOURCE; }
 const char* phx_last_error(void) { return phx::last_error(); }
 
 int phx_device_count(void)

@@ -23,7 +23,8 @@
 //   multiplies, so they are recomputed in registers from 16 stored words — bit-identical, 44 % fewer bytes.
 //
 // Arithmetic contract: every expression below is written in the reference's operation order and the
-// file is compiled with -ffp-contract=off, so results equal the strict-IEEE oracle bit for bit.
+// file is compiled with -ffp-contract=off, so results equal the strict-IEEE oracle bit for bit.  The sweeps
+// (PreStep, impulses, displacement) come in two stated forms, chosen when the library is built (mul_add below).
 #pragma once
 
 #include "solver.h"
@@ -52,6 +53,22 @@ __device__ __forceinline__ bool static_productive(const unsigned* sw, int nstati
 }
 
 __device__ __forceinline__ float max_ref(float l, float r) { return l > r ? l : r; }      // ref: base/SIMD_Scalar.h:275-278
+
+// ---- the sweeps' arithmetic contract ---------------------------------------------------------------------------------
+// The reference writes `dV -= projector * velocity` and `velocity += compMass * dImpulse` (ref: Solver.cpp:833-858 and its
+// siblings) and ships -ffast-math -mfma (ref: Makefile:11, 17-24): whether such a pair is one fused multiply-add or a rounded
+// product and a rounded sum is the reference compiler's choice, not the source's.  This backend states its choice:
+//   PHX_ARITH_FMA = 1 (default)  every such pair is ONE fmaf, in the reference's source order — half the instructions of the class
+//                                step, which is what bounds the island kernel;
+//   PHX_ARITH_FMA = 0            a rounded product and a rounded sum (rounds 1-4; `PHX_ARITH=source python -m phyx_amd.build`).
+// compMass = projector * invMass stays one rounded product of its own in both (the reference stores it, ref: Solver.cpp:573-580).
+// The oracle has both forms and the tests ask the library which one it was built with (phx_arith_mode): every
+// parity test is bit-exact against the matching form, and the two forms are held within SURVEY.md §8(c)'s tolerances of each other.
+#ifndef PHX_ARITH_FMA
+#define PHX_ARITH_FMA 1
+#endif
+__device__ __forceinline__ float mul_add(float a, float b, float acc) { return PHX_ARITH_FMA ? __builtin_fmaf(a, b, acc) : acc + a * b; }      // acc + a * b
+__device__ __forceinline__ float mul_sub(float a, float b, float acc) { return PHX_ARITH_FMA ? __builtin_fmaf(-a, b, acc) : acc - a * b; }     // acc - a * b
 
 __device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i >= n ? (n > 0 ? n - 1 : 0) : i); }
 
@@ -214,12 +231,12 @@ __device__ __forceinline__ void prestep_one(const SolverView& v, int s, float4& 
     const float2 acc = v.acc[s];
     const float nx = a.x, ny = a.y, tx = -ny, ty = nx;
     if (!st1) {
-        B1.x += (nx * im1) * acc.x; B1.y += (ny * im1) * acc.x; B1.z += (a.z * ii1) * acc.x;
-        B1.x += (tx * im1) * acc.y; B1.y += (ty * im1) * acc.y; B1.z += (b.x * ii1) * acc.y;
+        B1.x = mul_add(nx * im1, acc.x, B1.x); B1.y = mul_add(ny * im1, acc.x, B1.y); B1.z = mul_add(a.z * ii1, acc.x, B1.z);
+        B1.x = mul_add(tx * im1, acc.y, B1.x); B1.y = mul_add(ty * im1, acc.y, B1.y); B1.z = mul_add(b.x * ii1, acc.y, B1.z);
     }
     if (!st2) {
-        B2.x += ((-nx) * im2) * acc.x; B2.y += ((-ny) * im2) * acc.x; B2.z += (a.w * ii2) * acc.x;
-        B2.x += ((-tx) * im2) * acc.y; B2.y += ((-ty) * im2) * acc.y; B2.z += (b.y * ii2) * acc.y;
+        B2.x = mul_add((-nx) * im2, acc.x, B2.x); B2.y = mul_add((-ny) * im2, acc.x, B2.y); B2.z = mul_add(a.w * ii2, acc.x, B2.z);
+        B2.x = mul_add((-tx) * im2, acc.y, B2.x); B2.y = mul_add((-ty) * im2, acc.y, B2.y); B2.z = mul_add(b.y * ii2, acc.y, B2.z);
     }
 }
 
@@ -298,17 +315,17 @@ __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& 
             float2 acc = q.acc;
             // normal limiter (ref: :833-858)
             float dv = f.w;
-            dv -= nx * B1.x; dv -= ny * B1.y; dv -= a.z * B1.z;
-            dv -= (-nx) * B2.x; dv -= (-ny) * B2.y; dv -= a.w * B2.z;
+            dv = mul_sub(nx, B1.x, dv); dv = mul_sub(ny, B1.y, dv); dv = mul_sub(a.z, B1.z, dv);
+            dv = mul_sub(-nx, B2.x, dv); dv = mul_sub(-ny, B2.y, dv); dv = mul_sub(a.w, B2.z, dv);
             float dn = dv * c.x;
             dn = max_ref(dn, -acc.x);
-            B1.x += (nx * im1) * dn; B1.y += (ny * im1) * dn; B1.z += (a.z * ii1) * dn;
-            B2.x += ((-nx) * im2) * dn; B2.y += ((-ny) * im2) * dn; B2.z += (a.w * ii2) * dn;
+            B1.x = mul_add(nx * im1, dn, B1.x); B1.y = mul_add(ny * im1, dn, B1.y); B1.z = mul_add(a.z * ii1, dn, B1.z);
+            B2.x = mul_add((-nx) * im2, dn, B2.x); B2.y = mul_add((-ny) * im2, dn, B2.y); B2.z = mul_add(a.w * ii2, dn, B2.z);
             acc.x += dn;
             // friction limiter (ref: :860-889)
             float fv = 0.f;
-            fv -= tx * B1.x; fv -= ty * B1.y; fv -= f.x * B1.z;
-            fv -= (-tx) * B2.x; fv -= (-ty) * B2.y; fv -= f.y * B2.z;
+            fv = mul_sub(tx, B1.x, fv); fv = mul_sub(ty, B1.y, fv); fv = mul_sub(f.x, B1.z, fv);
+            fv = mul_sub(-tx, B2.x, fv); fv = mul_sub(-ty, B2.y, fv); fv = mul_sub(f.y, B2.z, fv);
             float df = fv * f.z;
             const float force = acc.y + df;
             const float limit = acc.x * 0.3f;
@@ -316,8 +333,8 @@ __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& 
             const float adjusted = signed_limit - acc.y;
             if (fabsf(force) > limit) df = adjusted;
             acc.y += df;
-            B1.x += (tx * im1) * df; B1.y += (ty * im1) * df; B1.z += (f.x * ii1) * df;
-            B2.x += ((-tx) * im2) * df; B2.y += ((-ty) * im2) * df; B2.z += (f.y * ii2) * df;
+            B1.x = mul_add(tx * im1, df, B1.x); B1.y = mul_add(ty * im1, df, B1.y); B1.z = mul_add(f.x * ii1, df, B1.z);
+            B2.x = mul_add((-tx) * im2, df, B2.x); B2.y = mul_add((-ty) * im2, df, B2.y); B2.z = mul_add(f.y * ii2, df, B2.z);
             v.acc[s] = acc;
             const bool productive = max_ref(fabsf(dn), fabsf(df)) > 1e-4f;      // ref: :894-896
             if (productive) {
@@ -334,12 +351,12 @@ __device__ __forceinline__ void solve_one(const SolverView& v, int s, HbmJoint& 
         if (p1 || p2) {
             float2 d = q.d;
             float dv = d.x;                                                      // ref: :973-981
-            dv -= nx * D1.x; dv -= ny * D1.y; dv -= a.z * D1.z;
-            dv -= (-nx) * D2.x; dv -= (-ny) * D2.y; dv -= a.w * D2.z;
+            dv = mul_sub(nx, D1.x, dv); dv = mul_sub(ny, D1.y, dv); dv = mul_sub(a.z, D1.z, dv);
+            dv = mul_sub(-nx, D2.x, dv); dv = mul_sub(-ny, D2.y, dv); dv = mul_sub(a.w, D2.z, dv);
             float di = dv * c.x;
             di = max_ref(di, -d.y);
-            D1.x += (nx * im1) * di; D1.y += (ny * im1) * di; D1.z += (a.z * ii1) * di;
-            D2.x += ((-nx) * im2) * di; D2.y += ((-ny) * im2) * di; D2.z += (a.w * ii2) * di;
+            D1.x = mul_add(nx * im1, di, D1.x); D1.y = mul_add(ny * im1, di, D1.y); D1.z = mul_add(a.z * ii1, di, D1.z);
+            D2.x = mul_add((-nx) * im2, di, D2.x); D2.y = mul_add((-ny) * im2, di, D2.y); D2.z = mul_add(a.w * ii2, di, D2.z);
             d.y += di;
             v.dd[s] = d;
             const bool productive = fabsf(di) > 1e-4f;                           // ref: :999

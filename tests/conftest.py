@@ -48,3 +48,17 @@ def built_lib():
     from phyx_amd import build, _lib
     build.build()
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _oracle_arith_matches_library(request):
+    """`gpu` tests compare the library with the oracle bit for bit: the oracle sweeps in the arithmetic form the library was
+    built with (include/phyx_amd.h phx_arith_mode; oracle/phx_oracle.c mul_add).  Everything else keeps the source form."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from oracle import binding
+    from phyx_amd import _lib
+    prev = binding.set_arith(_lib.load().phx_arith_mode())
+    yield
+    binding.set_arith(prev)

@@ -6,6 +6,8 @@ import numpy as np
 import phyx_amd
 from phyx_amd import Configuration
 from oracle import binding as ob
+from phyx_amd import _lib as _phx_lib
+ob.set_arith(_phx_lib.load().phx_arith_mode())      # the oracle sweeps in the library's arithmetic form
 
 
 BIG = "--big" in sys.argv        # thousands of bodies: many bins, 1024-lane groups, an HBM group once piles form

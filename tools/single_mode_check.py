@@ -2,6 +2,8 @@ import sys, os; R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.in
 import numpy as np, phyx_amd
 from phyx_amd import scenes, Configuration
 from oracle import binding as oracle
+from phyx_amd import _lib as _phx_lib
+oracle.set_arith(_phx_lib.load().phx_arith_mode())      # the oracle sweeps in the library's arithmetic form
 from helpers import oracle_world
 scene = scenes.stack(10, 100)
 for iters in (15, 20):

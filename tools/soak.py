@@ -6,6 +6,8 @@ import numpy as np
 import phyx_amd
 from phyx_amd import scenes, Configuration
 from oracle import binding as ob
+from phyx_amd import _lib as _phx_lib
+ob.set_arith(_phx_lib.load().phx_arith_mode())      # the oracle sweeps in the library's arithmetic form
 
 def run(name, scene, steps, mode, every=10):
     cfg = Configuration(0, mode, 15, 15)
