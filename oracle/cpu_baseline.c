@@ -486,7 +486,10 @@ static void pool_run(pool* p, int* phase_counter, phase_fn fn, int batches)
     atomic_store_explicit(&p->done, 0, memory_order_relaxed);
     atomic_store_explicit(&p->ticket, ((unsigned long long)(phase & 0xFFFFu) << 48) | ((unsigned long long)(unsigned)batches << 24), memory_order_release);
     if (p->threads > 1) {
-        atomic_store_explicit(&p->phase_word, (int)phase, memory_order_release);
+        /* sequentially consistent store, then the (seq_cst) load of `sleepers`: with a release store the load could pass it (x86
+         * store -> load reordering), main would read sleepers == 0 while a worker that has just counted itself in still sees the
+         * old phase word and sleeps through the phase — never a deadlock (phases complete by batches), but silently fewer threads */
+        atomic_store(&p->phase_word, (int)phase);
         if (atomic_load(&p->sleepers)) syscall(SYS_futex, &p->phase_word, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
     }
     pool_pull(p, 0);

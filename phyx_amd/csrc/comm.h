@@ -18,6 +18,12 @@ public:
     int barrier(hipStream_t stream);
     int barrier_async(hipStream_t stream);
     int async_error(int* out);
+    // The agreement of a step whose collective's size depends on the step: one 16-byte all-reduce (max) of {status, bytes, -bytes}.
+    // agree_post only QUEUES it on `stream` (no host wait, no host copy: the words are kernel arguments); agree_read waits for it
+    // (bounded) and reads the result.  A rank that failed posts {1, 0, -(2^31 - 1)}: neutral for the sizes, so that it learns its
+    // healthy peers' size from the result.  agree = post + read.
+    int agree_post(int status, long long bytes, hipStream_t stream);
+    int agree_read(int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream);
     int agree(int status, long long bytes, int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream);
     int wait_stream(hipStream_t stream, const char* what);      // hipStreamSynchronize with the communicator's time bound
     static int version();                             // ncclGetVersion (0 if RCCL is not available)

@@ -130,18 +130,28 @@ int Comm::init(const void* unique_id, int rank, int nranks)
     // another id) would hang this rank — and its launcher — for good.  It runs on a helper thread that is waited for with a
     // bound; a rank that gives up leaves the thread behind (it cannot be cancelled) and reports.
     struct Result { ncclComm_t comm = nullptr; int rc = ncclSuccess; };
-    auto done = std::make_shared<std::promise<Result>>();
-    std::future<Result> fut = done->get_future();
+    // (`abandoned`: the caller gave up.  Should the peers arrive after all, the helper owns the communicator it gets and aborts it
+    //  at once — nobody else ever will, and a live communicator nobody drives would hold the device and its peers' bootstrap.)
+    struct Pending { std::promise<Result> done; std::mutex m; bool abandoned = false, finished = false; };
+    auto pend = std::make_shared<Pending>();
+    std::future<Result> fut = pend->done.get_future();
     const int device = device_;
-    std::thread([done, device, nranks, id, rank] {
+    std::thread([pend, device, nranks, id, rank] {
         Result res;
         (void)hipSetDevice(device);
         res.rc = rccl().CommInitRank(&res.comm, nranks, id, rank);
-        done->set_value(res);
+        bool orphan;
+        { std::lock_guard<std::mutex> g(pend->m); pend->finished = true; orphan = pend->abandoned; }
+        if (orphan) { if (res.rc == ncclSuccess && res.comm && rccl().CommAbort) (void)rccl().CommAbort(res.comm); return; }
+        pend->done.set_value(res);
     }).detach();
     if (fut.wait_for(std::chrono::duration<double>(comm_timeout_s())) != std::future_status::ready) {
-        set_error("ncclCommInitRank: rank %d of %d still waits for its peers after %.0f s (PHX_COMM_TIMEOUT_S) — a rank is missing or holds another communicator id", rank, nranks, comm_timeout_s());
-        return PHX_ERR_STATE;
+        bool late;
+        { std::lock_guard<std::mutex> g(pend->m); late = pend->finished; if (!late) pend->abandoned = true; }
+        if (!late) {
+            set_error("ncclCommInitRank: rank %d of %d still waits for its peers after %.0f s (PHX_COMM_TIMEOUT_S) — a rank is missing or holds another communicator id", rank, nranks, comm_timeout_s());
+            return PHX_ERR_STATE;
+        }      // (else it finished while the bound ran out: its result is on the way)
     }
     const Result res = fut.get();
     if (res.rc != ncclSuccess) return rccl_fail("ncclCommInitRank", res.rc);
@@ -169,21 +179,45 @@ int Comm::wait_stream(hipStream_t stream, const char* what)
 }
 
 // what every rank must know before a collective whose size depends on the step: did a peer fail, and do all ranks mean the same
-// byte count?  One all-reduce (max) of {status, bytes, -bytes} on `stream`, waited for (bounded).
-int Comm::agree(int status, long long bytes, int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream)
+// byte count?  One all-reduce (max) of {status, bytes, -bytes} on `stream`.  Posting it costs the host nothing (the words travel as
+// kernel arguments; round 4 staged them through a host copy and waited for the result in EVERY step, which put a host round trip
+// back into a step that was stream-ordered end to end); reading it is the bounded wait.
+static __global__ void k_agree_words(int* w, int a, int b, int c) { w[0] = a; w[1] = b; w[2] = c; w[3] = 0; }
+
+int Comm::agree_post(int status, long long bytes, hipStream_t stream)
 {
     PHX_REQUIRE(impl_ && impl_->comm, "communicator not initialised");
-    PHX_REQUIRE(bytes >= 0 && bytes < (1ll << 31), "segment size out of range");
     PHX_TRY(use_device(device_));
-    int h[4] = {status, (int)bytes, -(int)bytes, 0};
-    PHX_HIP(hipMemcpyAsync(flag_ + 4, h, sizeof h, hipMemcpyHostToDevice, stream));
+    // (an out-of-range size is this rank's failure, reported INSIDE the collective: returning before it would leave the peers
+    //  waiting out their whole time bound)
+    const bool bad = bytes < 0 || bytes >= (1ll << 31);
+    const bool failed = status != 0 || bad;
+    hipLaunchKernelGGL(k_agree_words, dim3(1), dim3(1), 0, stream, flag_ + 4, failed ? (status ? status : 1) : 0, failed ? 0 : (int)bytes, failed ? -0x7FFFFFFF : -(int)bytes);
+    PHX_HIP(hipGetLastError());
     PHX_RCCL(rccl().AllReduce(flag_ + 4, flag_ + 4, 4, ncclInt32, ncclMax, impl_->comm, stream), "ncclAllReduce");
+    if (bad) { set_error("segment size out of range"); return PHX_ERR_INVALID; }
+    return PHX_OK;
+}
+
+int Comm::agree_read(int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream)
+{
+    PHX_REQUIRE(impl_ && impl_->comm, "communicator not initialised");
+    PHX_TRY(use_device(device_));
     PHX_TRY(wait_stream(stream, "agreement before the all-gather"));
+    int h[4] = {0, 0, 0, 0};
     PHX_HIP(hipMemcpy(h, flag_ + 4, sizeof h, hipMemcpyDeviceToHost));
     if (worst_status) *worst_status = h[0];
     if (max_bytes) *max_bytes = h[1];
-    if (min_bytes) *min_bytes = -(long long)h[2];
+    if (min_bytes) *min_bytes = -(long long)h[2];      // (2^31 - 1 if every rank failed)
     return PHX_OK;
+}
+
+int Comm::agree(int status, long long bytes, int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream)
+{
+    const int posted = agree_post(status, bytes, stream);
+    if (posted != PHX_OK && posted != PHX_ERR_INVALID) return posted;      // (INVALID: the collective was entered, with a failure status)
+    PHX_TRY(agree_read(worst_status, min_bytes, max_bytes, stream));
+    return posted;
 }
 
 int Comm::version()

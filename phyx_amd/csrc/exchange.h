@@ -53,6 +53,10 @@ inline void exchange_partition(const int* group_slots, int ngroups, int shard_co
     }
 }
 
+// The common segment length is padded to 64 KB: in a running world the joint list changes a little in every step, and so would an
+// exactly fitted length — and with it the byte count of the all-gather, which the ranks must agree on before they enter it (a host
+// wait, world.hip step_sharded).  Padded, the length changes rarely; the pad is <= 6 % of a cfg-2 segment at eight ranks.
+constexpr int XCH_SEGMENT_GRANULE_WORDS = 16384;
 // Pure host function (unit-tested on CPU through phx_exchange_layout): word offset of every group inside its owner's
 // segment (header included; a rank's groups in ascending group order) and the common padded segment length.
 inline long long exchange_layout(const int* group_bodies, const int* group_slots, int ngroups, int shard_count, const int* owner, long long* group_offset_words,
@@ -66,7 +70,7 @@ inline long long exchange_layout(const int* group_bodies, const int* group_slots
     }
     long long longest = XCH_HEADER_WORDS;
     for (int r = 0; r < shard_count; ++r) { if (rank_words) rank_words[r] = used[r]; longest = std::max(longest, used[r]); }
-    return (longest + 63) & ~63ll;
+    return (longest + XCH_SEGMENT_GRANULE_WORDS - 1) & ~(long long)(XCH_SEGMENT_GRANULE_WORDS - 1);
 }
 
 struct ExchangeView {

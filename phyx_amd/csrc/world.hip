@@ -107,6 +107,7 @@ private:
     DevBuf<unsigned> xch_send_, xch_recv_;
     size_t xch_capacity_ = 0;
     unsigned sharded_steps_ = 0;
+    size_t agreed_seg_ = 0;                  // segment bytes of the last host-read agreement (0: none): step_sharded
     int ensure_exchange_capacity(size_t bytes);
 };
 
@@ -467,6 +468,7 @@ int World::set_comm(Comm* c)
 {
     PHX_TRY(use_device(device_));
     comm_ = c;
+    agreed_seg_ = 0;
     if (!c) return PHX_OK;
     shard = c->rank(); shard_count = c->size();
     PHX_TRY(solver_.set_shard(shard, shard_count));
@@ -486,17 +488,41 @@ int World::step_sharded(float dt, const phx_config& cfg)
         const BodyView bodies = resident().s;
         st = solver_.exchange_pack_resident(&bodies, d_joints_.p, &seg);
     }
-    // Before the collective every rank learns whether a peer failed in this step and whether all ranks mean the same segment size
-    // (a pure function of the schedule, hence equal on replicas that agree): one 16-byte all-reduce, waited for with the
-    // communicator's time bound.  A failed or diverged step ends HERE on every rank, with an error, and nobody enters an all-gather
-    // with a byte count its peers do not share (which would hang or corrupt instead of reporting).
+    // Before the collective the ranks agree on {did anybody fail in this step, the segment size} — one 16-byte all-reduce (max) QUEUED
+    // on the stream in every step.  Its result is waited for on the host only by a rank that NEEDS it: one whose segment size is
+    // not the size of the last agreement (the layout pads segments to 64 KB, exchange.h: in a running world that is rare), or one
+    // that failed.  The steady step is therefore stream-ordered end to end again (round 4 waited for the agreement in every step);
+    // healthy replicas all wait or all do not (the size is a pure function of the schedule), and:
+    //   * a rank that failed learns its healthy peers' size from the result, hence whether THEY waited: if they did, they have seen
+    //     its failure and nobody enters the all-gather; if they did not, they are in the all-gather already and it joins them with a
+    //     header-only segment of the agreed size that carries its status (the unpack and check_exchange report it) — either way the
+    //     step ends on every rank with an error and no collective is left half-entered;
+    //   * sizes that differ among healthy ranks (replicas that diverged) end the step on every rank that waited.
     const std::string why = st != PHX_OK ? last_error() : std::string();
-    int worst = 0; long long lo = 0, hi = 0;
-    const int agreed = comm_->agree(st != PHX_OK ? 1 : 0, st != PHX_OK ? 0ll : (long long)seg, &worst, &lo, &hi, stream_);
-    if (st != PHX_OK) { set_error("%s", why.c_str()); return st; }
-    PHX_TRY(agreed);
-    if (worst) { set_error("island-sharded step: a peer failed before the exchange (this rank's half of the step is done, nothing was exchanged)"); return PHX_ERR_STATE; }
-    if (lo != hi) { set_error("island-sharded step: the ranks' segment sizes differ (%lld .. %lld bytes): the replicas diverged", lo, hi); return PHX_ERR_STATE; }
+    const bool failed = st != PHX_OK;
+    const int posted = comm_->agree_post(failed ? 1 : 0, failed ? 0ll : (long long)seg, stream_);
+    if (posted != PHX_OK && posted != PHX_ERR_INVALID) return posted;      // (the collective itself could not be queued)
+    if (failed || posted == PHX_ERR_INVALID) {
+        const std::string cause = failed ? why : std::string(last_error());
+        int worst = 0; long long lo = 0, hi = 0;
+        PHX_TRY(comm_->agree_read(&worst, &lo, &hi, stream_));
+        const bool peers_waited = lo != hi || hi != (long long)agreed_seg_;      // (no healthy peer at all: lo = 2^31 - 1, hi = 0)
+        if (!peers_waited && agreed_seg_ > 0) {
+            size_t hdr = 0;
+            (void)solver_.exchange_pack_resident(nullptr, nullptr, &hdr, 1);      // header only: magic, serial, status
+            (void)comm_->all_gather(xch_send_.p, xch_recv_.p, agreed_seg_, stream_);
+        }
+        set_error("%s", cause.c_str());
+        return failed ? st : PHX_ERR_INVALID;
+    }
+    if (seg != agreed_seg_) {
+        int worst = 0; long long lo = 0, hi = 0;
+        agreed_seg_ = 0;
+        PHX_TRY(comm_->agree_read(&worst, &lo, &hi, stream_));
+        if (worst) { set_error("island-sharded step: a peer failed before the exchange (this rank's half of the step is done, nothing was exchanged)"); return PHX_ERR_STATE; }
+        if (lo != hi) { set_error("island-sharded step: the ranks' segment sizes differ (%lld .. %lld bytes): the replicas diverged", lo, hi); return PHX_ERR_STATE; }
+        agreed_seg_ = seg;
+    }
     { RoctxRange r("Exchange: all-gather (RCCL)"); PHX_TRY(comm_->all_gather(xch_send_.p, xch_recv_.p, seg, stream_)); }
     PHX_TRY(step_end(dt));
     if ((++sharded_steps_ & 15u) == 0) PHX_TRY(check_exchange());

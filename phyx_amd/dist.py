@@ -66,7 +66,7 @@ class Exchange:
         """Upper bound of a segment: one rank owning every group (6 floats per body, 2 per joint, header, padding)."""
         # (a body may appear in one dynamic group; static bodies appear in every group that touches them: <= 2 bodies per joint)
         n = 32 + 24 * (int(body_count) + 2 * int(joint_count)) + 8 * int(joint_count) + 16 * (int(joint_count) + 2) + 256
-        return (n + 255) // 256 * 256
+        return (n + 65535) // 65536 * 65536          # (segments are padded to 64 KB, csrc/exchange.h)
 
     def all_gather(self, segment_bytes):
         seg = int(segment_bytes)

@@ -255,8 +255,8 @@ def test_exchange_layout_partitions_the_groups_over_the_ranks():
         gb = rng.integers(1, 769, ngroups).astype(np.int32)
         gs = rng.integers(1, 513, ngroups).astype(np.int32)
         off, rank_words, seg, owner = phyx_amd.exchange_layout(gb, gs, n)
-        assert seg % 64 == 0 and seg >= 8 and len(rank_words) == n
-        assert int(rank_words.max()) <= seg < int(rank_words.max()) + 64
+        assert seg % 16384 == 0 and seg >= 8 and len(rank_words) == n          # padded to 64 KB (exchange.h XCH_SEGMENT_GRANULE_WORDS)
+        assert int(rank_words.max()) <= seg < int(rank_words.max()) + 16384
         # longest processing time first, restated: decreasing joint count (ties: group number), to the least loaded rank (ties: lowest)
         load = [0] * n
         want = [0] * ngroups
