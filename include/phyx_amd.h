@@ -165,7 +165,8 @@ int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on);
 /* Diagnostics: with tracing on, every workgroup of the island kernel stamps the 100 MHz wall clock at its phase boundaries.
  * phx_solver_get_island_trace copies 8 words per LDS group of the last solve: [0] start, [1] records loaded, [2] refreshed,
  * [3] pre-stepped, [4] swept, [5] written back, [6] XCC id, [7] colours << 32 | impulse sweeps executed.  *groups receives
- * the group count (out may be NULL to query it). */
+ * the group count (out may be NULL to query it).  on: 0 = off, 1 = the phase stamps only (a few stores per workgroup: the kernel
+ * keeps its speed), any other value = also the per-wave cycle counts of every class step (phx_solver_get_wave_trace; ~15 % slower). */
 int phx_solver_set_trace(phx_solver* s, int32_t on);
 int phx_solver_get_island_trace(phx_solver* s, uint64_t* out, int32_t cap_groups, int32_t* groups);
 /* per wave of every LDS group (groups x *waves_per_group x 8 words): shader cycles spent in colour steps in which the wave

@@ -255,8 +255,10 @@ class Solver:
         """False: rebuild the schedule on every solve (the reference rebuilds its grouping every call)."""
         check(self.L.phx_solver_set_schedule_reuse(self.h, 1 if on else 0))
 
-    def set_trace(self, on=True):
-        check(self.L.phx_solver_set_trace(self.h, 1 if on else 0))
+    def set_trace(self, on=True, waves=True):
+        """Phase stamps of the island kernel's workgroups (island_trace); waves=True also counts every wave's class-step cycles
+        (wave_trace), which slows the sweeps by ~15 %."""
+        check(self.L.phx_solver_set_trace(self.h, (2 if waves else 1) if on else 0))
 
     def island_trace(self):
         """(groups, 8) uint64: phase stamps of the island kernel's workgroups in the last solve (set_trace first)."""

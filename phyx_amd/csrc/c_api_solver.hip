@@ -108,7 +108,7 @@ int phx_solver_set_schedule_reuse(phx_solver* s, int32_t on)
 int phx_solver_set_trace(phx_solver* s, int32_t on)
 {
     PHX_REQUIRE(s, "null handle");
-    s->impl.set_trace(on != 0);
+    s->impl.set_trace(on);
     return PHX_OK;
 }
 

@@ -318,8 +318,9 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         if (tid == 0) { const int next = slot == 2 ? 0 : slot + 1; flag_imp[next] = 0; flag_disp[next] = 0; }
         const bool hot = imp_on && !disp_on;      // (workgroup-uniform, fixed for the sweep)
         for (int c = 0; c < ncol; ++c) {
-            const unsigned long long ts0 = TRACE ? __builtin_readcyclecounter() : 0ull;
-            const bool working = TRACE && __any(col == c);
+            const bool wt = TRACE && iv.wave_trace;            // (phx_solver_set_trace level 2: per-wave cycle counts of every class step — ~15 % slower)
+            const unsigned long long ts0 = wt ? __builtin_readcyclecounter() : 0ull;
+            const bool working = wt && __any(col == c);
             if (col == c) {
                 // one unit, one sweep half: `s1` / `s2` = the unit's bodies are static.  Called twice below: with the lane's real
                 // flags, and — for a wave none of whose units touches a static body, i.e. almost every wave — with constants,
@@ -377,12 +378,20 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                 // same results as imp_step (the general form keeps the first sweep, where the displacement half runs too).
                 auto imp_fast = [&](const bool ws) {
                     float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-                    // (both records in ONE LDS round trip: left alone, the compiler reads the two tags, tests, and only then — under the
+                    // (`ws`: the static tags' words travel with the body records — every lane of the wave reads them, a dynamic body's
+                    //  are zero — instead of two more dependent LDS round trips for the one lane that needs them: static_productive_lds)
+                    unsigned pw1 = 0u, cw1 = 0u, pw2 = 0u, cw2 = 0u;
+                    if (ws) { pw1 = swi[(it - 1) & 1][l1]; cw1 = swi[it & 1][l1]; pw2 = swi[(it - 1) & 1][l2]; cw2 = swi[it & 1][l2]; }
+                    // (everything in ONE LDS round trip: left alone, the compiler reads the two tags, tests, and only then — under the
                     //  branch — the six velocity words: two dependent round trips on the critical path of every class step)
                     if (!HALF) asm volatile("" : "+v"(B1.x), "+v"(B1.y), "+v"(B1.z), "+v"(B1.w), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(B2.w));
+                    if (ws) asm volatile("" : "+v"(pw1), "+v"(cw1), "+v"(pw2), "+v"(cw2));
                     bool active = max(__float_as_int(B1.w), __float_as_int(B2.w)) > it - 2;
                     if (ws) {
-                        const bool sp1 = st1 && static_productive_lds(swi, l1, it, c), sp2 = st2 && static_productive_lds(swi, l2, it, c);
+                        auto sp = [&](unsigned pw, unsigned cw) {      // static_productive_lds on the words already here
+                            return it == 0 || (pw >> 16) == (unsigned)it || ((cw >> 16) == (unsigned)(it + 1) && (0xFFFFu - (cw & 0xFFFFu)) < (unsigned)c);
+                        };
+                        const bool sp1 = st1 && sp(pw1, cw1), sp2 = st2 && sp(pw2, cw2);
                         active = (st1 ? sp1 : (__float_as_int(B1.w) > it - 2)) || (st2 ? sp2 : (__float_as_int(B2.w) > it - 2));
                     }
                     if (active) {
@@ -414,9 +423,9 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                     if (disp_on) disp_step(false, false, has2);
                 }
             }
-            const unsigned long long ts1 = TRACE ? __builtin_readcyclecounter() : 0ull;
+            const unsigned long long ts1 = wt ? __builtin_readcyclecounter() : 0ull;
             __syncthreads();
-            if (TRACE) {
+            if (wt) {
                 const unsigned long long ts2 = __builtin_readcyclecounter();
                 if (working) {
                     if (__popcll(__ballot(col == c)) > 32) { tw_work_big += ts1 - ts0; ++tw_nbig; } else { tw_work += ts1 - ts0; ++tw_nwork; }

@@ -62,7 +62,7 @@ public:
     int set_body_state_bits(int bits);
     int set_shard(int shard, int count);
     void set_schedule_reuse(bool on) { reuse_schedule_ = on; }
-    void set_trace(bool on) { trace_islands_ = on; drop_graphs(); }
+    void set_trace(int level) { trace_islands_ = level != 0; trace_waves_ = level != 1; drop_graphs(); }      // 1: phase stamps only; else also per-wave step cycles
     int get_island_trace(unsigned long long* out, int cap_groups, int* groups);
     int get_wave_trace(unsigned long long* out, int cap_words, int* waves_per_group);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
@@ -317,7 +317,7 @@ private:
     DevBuf<long long> xch_off_;
     std::vector<long long> xch_off_host_;
     DevBuf<int> xch_err_;
-    bool trace_islands_ = false;
+    bool trace_islands_ = false, trace_waves_ = true;
     std::vector<hipEvent_t> bench_events_;
 };
 

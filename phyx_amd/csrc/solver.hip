@@ -257,7 +257,7 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
             if (isl_.trace.reserve((size_t)std::max(lg, 1) * (8 + 128)) != PHX_OK) return PHX_ERR_HIP;
             PHX_HIP(hipMemsetAsync(isl_.trace.p, 0, (size_t)lg * (8 + 128) * sizeof(unsigned long long), stream_));
             iv.trace = isl_.trace.p;
-            iv.wave_trace = isl_.trace.p + (size_t)lg * 8;
+            iv.wave_trace = trace_waves_ ? isl_.trace.p + (size_t)lg * 8 : nullptr;
         }
         const bool big = sched_.lds_lanes > ISL_T;
         // A schedule with LDS islands AND an HBM group (a world that is merging, or settled around a few loose stacks): the island

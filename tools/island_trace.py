@@ -19,10 +19,10 @@ s = phyx_amd.Solver(0)
 db, dc, dj = (phyx_amd.DeviceArray(a) for a in (b, cp, j))
 if shards > 1: s.set_shard(0, shards)
 r = s.bench(db, dc, dj, cfg, 3, 10)
-plain_us = 1e3 * r.impulse_kernel_ms / 10
-s.set_trace(True)
+plain_us = 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1)
+s.set_trace(True, waves=False)                         # phase stamps only: the kernel keeps its speed
 r = s.bench(db, dc, dj, cfg, 2, 5)
-traced_us = 1e3 * r.impulse_kernel_ms / 5
+traced_us = 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1)
 t = s.island_trace().astype(np.int64)
 t = t[t[:, 0] != 0]                                   # groups of other shards never ran
 t0 = t[:, 0].min()
@@ -53,6 +53,8 @@ for x in range(8):
     m = t[:, 6] == x
     if m.any(): print("  XCC %d: %4d workgroups, start median %.1f us, end median %.1f us" % (x, m.sum(), np.median((t[m, 0] - t0) / tick_us), np.median((t[m, 5] - t0) / tick_us)))
 
+s.set_trace(True, waves=True)                          # ... and once more with every wave's class-step cycle counts (~15 % slower)
+s.bench(db, dc, dj, cfg, 1, 2)
 raw = s.wave_trace()
 wt = raw.astype(np.float64)
 nsmall = (raw[:, :, 3] >> np.uint64(32)).astype(np.float64); nidle = (raw[:, :, 3] & np.uint64(0xffffffff)).astype(np.float64); nbig = wt[:, :, 5]

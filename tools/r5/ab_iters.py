@@ -15,4 +15,4 @@ for ci, pi in ((20, 20), (20, 0), (0, 20), (0, 0), (1, 1), (20, 20)):
     c = Configuration(2, 2, ci, pi)
     r = s.bench(db, dc, dj, c, 3, 10)
     st = s.stats()
-    print("ci %2d pi %2d  island launch %.2f us  total %.2f us/step  imp sweeps %d disp sweeps %d" % (ci, pi, 1e3 * r.impulse_kernel_ms / 10, 1e3 * r.total_ms / 10, st.impulse_iterations, st.displacement_iterations))
+    print("ci %2d pi %2d  island launch %.2f us  total %.2f us/step  imp sweeps %d disp sweeps %d" % (ci, pi, 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1), 1e3 * r.total_ms / 10, st.impulse_iterations, st.displacement_iterations))
