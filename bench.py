@@ -49,7 +49,7 @@ BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visi
 # issues ONE instruction per ~4 cycles whether or not it depends on the last one, and the working wave of a class step issues
 # ~222 VALU instructions (SQ_INSTS_VALU per group and class step) — so the floor of a class step is that many issue slots.
 COLOUR_STEP_CHAIN_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
-COLOUR_STEP_VALU_INSTRUCTIONS = 222
+COLOUR_STEP_VALU_INSTRUCTIONS = 112          # round 5: the hot form of a class step in fused arithmetic (island_kernel.h imp_fast): ~105 VALU + moves
 COLOUR_STEP_FLOOR_CYCLES = 64 + COLOUR_STEP_VALU_INSTRUCTIONS * 4 + 13 + 128
 
 
@@ -58,20 +58,48 @@ def pmc_file(name):
     path = os.path.join(ROOT, "profiles", name + ".json")
     try:
         d = json.load(open(path))
+        if d.get("kernel_source_sha256") != kernel_source_sha256():      # taken of another version of the island kernel: not quoted
+            return {}
         return {"file": "profiles/%s.json" % name, "kernels": {k: v["hbm_bytes_per_launch_corrected"] for k, v in d.get("kernels", {}).items()}}
+    except Exception:
+        return {}
+
+
+def kernel_source_sha256():
+    """Fingerprint of the island kernel's source (what a committed PMC pass was taken of): island_kernel.h + solver_kernels.h."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("island_kernel.h", "solver_kernels.h"):
+        with open(os.path.join(ROOT, "phyx_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def steady_step_file(name):
+    """profiles/<name>.json (tools/steady_step_summary.py): per kernel of ONE profiled steady World::Update its launches, time and HBM bytes."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
+    try:
+        d = json.load(open(path))
+        d["file"] = "profiles/%s.json" % name
+        return d
     except Exception:
         return {}
 
 
 def pmc_traffic():
     """HBM bytes per launch of the solve kernels from the committed PMC passes (tools/gpu_prof.sh -> tools/pmc_summary.py):
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same script, read side corrected x2 as MI355X_MICROARCH.md §HBM says."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same script, read side corrected x2 as MI355X_MICROARCH.md §HBM says.
+    A pass is only as good as the kernel it profiled: the file records the source fingerprint and the commit it was taken at, and a
+    file taken of another island_kernel.h / solver_kernels.h is REFUSED (`stale`) rather than quoted."""
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
         if os.path.exists(path):
             try:
                 d = json.load(open(path))
-                out = {"file": "profiles/%s_pmc_traffic.json" % tag}
+                if d.get("kernel_source_sha256") != kernel_source_sha256():
+                    return {"stale": "profiles/%s_pmc_traffic.json was taken of another version of the island kernel (commit %s): not quoted"
+                                     % (tag, d.get("commit", "unrecorded"))}
+                out = {"file": "profiles/%s_pmc_traffic.json" % tag, "commit": d.get("commit")}
                 for name, k in d.get("kernels", {}).items():
                     if "k_solve_islands<256" in name:
                         out["k_solve_islands"] = k["hbm_bytes_per_launch_corrected"]
@@ -96,7 +124,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--scene-steps", type=int, default=3, help="world steps run before the solver input is captured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed side measurements (Single mode, live topology, other configs)")
+    ap.add_argument("--secondary", action="store_true", help="also run the long side measurements (Single mode, the island kernel's phases, one rank of N, "
+                    "the settled world, cfg 4, cfg 5): minutes; the builder's full line is kept under profiles/")
+    ap.add_argument("--no-secondary", action="store_true", help="skip every side measurement, also the two a default run keeps (live topology, cfg 2 World::Update)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one rank")
     ap.add_argument("--mode", default="slab", choices=("slab", "replica"),
@@ -153,6 +183,8 @@ def run_bench(args, pdist):
     from phyx_amd import scenes, Configuration
 
     info = phyx_amd.device_info(device)
+    # side measurements: 0 = none, 1 = the two that say what a running world pays (live topology, cfg 2 World::Update; default), 2 = all
+    side = 0 if args.no_secondary else (2 if args.secondary else 1)
     # N=1: BASELINE config 2 (Single Sloppy).  N>1: config 3 (Multiple island mode, islands sharded across the GPUs).
     island_mode = phyx_amd.ISLAND_SINGLE_SLOPPY if world == 1 else phyx_amd.ISLAND_MULTIPLE
     cfg = Configuration(phyx_amd.SOLVE_AVX2, island_mode, args.iters, args.iters)
@@ -186,6 +218,9 @@ def run_bench(args, pdist):
         """`repeats` timed blocks of `steps` solves of the resident input under `config`; returns the median block."""
         for _ in range(max(warmup, 1)):                               # untimed: builds the schedule
             slv.bench(d_bodies, d_cps, d_joints, config, 0, 1, hook=hk)
+        # what the timed solves must compute: the checksum of the warm-up solve's results (velocities, displacing velocities, impulses)
+        want_sum = slv.bench_checksum()
+        sums = []
         blocks = []
         for _ in range(max(repeats, 1)):
             slv.bench_stage(d_bodies, d_joints, steps)                    # K copies of the input, resident in HBM before the clock starts
@@ -198,6 +233,7 @@ def run_bench(args, pdist):
             slv.synchronize()
             group.barrier()
             el = time.perf_counter() - t0
+            sums.append(slv.bench_checksum())                             # (outside the clock: the last timed step's results)
             blocks.append(dict(elapsed=el, total_ms=r.total_ms, sweep_ms=r.impulse_kernel_ms, launches=r.impulse_launches, bracketed=r.bracketed_launches,
                                visits=r.joint_visits, iterations=r.impulse_iterations))
         # the block every rank reports must be the same one: rank by the max-over-ranks time
@@ -207,6 +243,11 @@ def run_bench(args, pdist):
         tot["elapsed_max"] = times[mid]
         tot["all_blocks_ms_per_step"] = [1e3 * t / max(steps, 1) for t in times]
         tot["stats"] = slv.stats()
+        tot["result_check"] = {"what": "64-bit checksum of the last timed step's velocities, displacing velocities and accumulated impulses against the "
+                                       "warm-up solve's, every timed block, outside the clock (same input, same schedule: bit-equal)",
+                               "checksum": "%016x" % want_sum, "blocks_checked": len(sums), "equal": all(x == want_sum for x in sums)}
+        if not tot["result_check"]["equal"]:
+            raise RuntimeError("bench: a timed block's results differ from the warm-up solve's (checksums %s, expected %016x)" % (["%016x" % x for x in sums], want_sum))
         return tot
 
     def algorithmic_bytes(tot, steps):
@@ -230,7 +271,7 @@ def run_bench(args, pdist):
 
     # ---- the island kernel's phases, measured live: a 0-iteration solve is set-up + PreStep + write-back only
     phases = None
-    if world == 1 and lds and not args.no_secondary:
+    if world == 1 and lds and side >= 2:
         zero = run(Configuration(phyx_amd.SOLVE_AVX2, island_mode, 0, 0), 2, 10, 3)
         phases = {"setup_prestep_writeback_us": 1e3 * zero["sweep_ms"] / max(zero["bracketed"], 1)}
         # ... and the cost of a class step as a SLOPE: the same solve with half the impulse sweeps.  (The 0-iteration launch is not
@@ -244,12 +285,13 @@ def run_bench(args, pdist):
 
     # ---- secondary (N=1 only, untimed by the driver): strict Single island mode = the general-case (big island) path
     single_tot = live_tot = unbracketed = None
-    if world == 1 and not args.no_secondary:
+    if world == 1 and side >= 2:
         os.environ["PHX_BENCH_BRACKET_STRIDE"] = "0"               # the same block with no HIP event inside the timed region at all
         unbracketed = run(cfg, 1, args.steps, 3)
         del os.environ["PHX_BENCH_BRACKET_STRIDE"]
         single_cfg = Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_SINGLE, args.iters, args.iters)
         single_tot = run(single_cfg, 2, max(5, args.steps // 2), 3)
+    if world == 1 and side >= 1:
         # live topology: the schedule is rebuilt inside the timed region on every solve, like the reference rebuilds
         # PrepareIndices / GatherIslands on every call (ref: Solver.cpp:77, 135)
         solver.set_schedule_reuse(False)
@@ -258,13 +300,13 @@ def run_bench(args, pdist):
 
     # ---- N > 1 side measurement: the OTHER sharding mode on the same 200k-box world (slab <-> replica), same strong-scaling accounting
     other_mode = None
-    if world > 1 and not args.no_secondary:
+    if world > 1 and side >= 2:
         other_mode = measure_other_mode(phyx_amd, scenes, Configuration, pdist, group, device, args, cfg, "replica" if mode == "slab" else "slab", full_scene)
 
     # ---- N > 1 side measurement (round-1 headline, kept for comparison): weak scaling — every rank solves its OWN slab of 1000
     #      columns of one N*1000-column world, no data crosses ranks, the ranks meet at a 4-byte all-reduce per step
     weak = None
-    if world > 1 and not args.no_secondary:
+    if world > 1 and side >= 2:
         first_col, ncols = pdist.shard_columns(args.columns * world, rank, world)
         wslab = phyx_amd.World(device, gravity=-200.0)
         wslab.add_scene(scenes.stack(ncols, args.rows, x_offset_columns=first_col))
@@ -292,9 +334,9 @@ def run_bench(args, pdist):
         alg = algorithmic_bytes(main_tot, args.steps) / launches
         kname = "k_solve_islands" if lds else "k_solve_colour"
         tbytes = traffic.get(kname)
-        tsource = traffic.get("file")
-        if tsource:
-            tsource += " (a committed rocprofv3 --pmc pass of this script; NOT measured in this run)"
+        tsource = traffic.get("file") or traffic.get("stale")
+        if traffic.get("file"):
+            tsource += " (a committed rocprofv3 --pmc pass of this script at commit %s; NOT measured in this run)" % traffic.get("commit")
         # the PMC passes profiled the default workload at N = 1: a launch of rank 0 at N > 1 covers only its own groups (its share
         # of the joint visits), and any other scene size was not profiled at all
         if (args.columns, args.rows) != (1000, 200):
@@ -423,13 +465,22 @@ def run_bench(args, pdist):
                              "achieved": s_alg / (s_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": s_alg / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": s_alg,
                              "traffic": s_tr, "traffic_frac": (s_tr / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if s_tr else None}}
-        if world == 1 and not args.no_secondary:
+        # what a RUNNING cfg 2 world pays, next to `value` (which is the solve on a cached, in-kernel-verified schedule — the one state a
+        # running world's changing contact graph never reaches): the solve with the schedule rebuilt every step, and the whole World::Update
+        out["live_topology_ms_per_step"] = out["live_topology"]["ms_per_step"] if live_tot is not None else None
+        out["world_step_ms_per_step"] = None
+        out["contacts_resolved_per_sec"] = None
+        if world == 1 and side >= 1:
+            ws = cfg2_world_step(world_obj, cfg)
+            out["cfg2_world_step"] = ws
+            out["world_step_ms_per_step"] = ws["ms_per_step"]
+            if (args.columns, args.rows) == (1000, 200):
+                out["contacts_resolved_per_sec"] = ws["counts"]["joints"] / (1e-3 * ws["ms_per_step"])
+                out["extra"]["contacts_resolved_per_sec"] = out["contacts_resolved_per_sec"]
+        if world == 1 and side >= 2:
             out["extra"]["cfg3_one_rank_of_n"] = one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run)
             out["extra"]["cfg3_slab_one_rank_of_n"] = slab_one_rank_of_n(phyx_amd, scenes, Configuration, pdist, device, args, full_scene)
             out["extra"]["other_configs"] = other_configs(phyx_amd, scenes, Configuration, device, world_obj, cfg)
-            ws = out["extra"]["other_configs"].get("cfg2_world_step") or {}
-            if ws.get("ms_per_step") and (args.columns, args.rows) == (1000, 200):
-                out["extra"]["contacts_resolved_per_sec"] = ws["counts"]["joints"] / (1e-3 * ws["ms_per_step"])
             if (args.columns, args.rows) == (1000, 200):
                 out["extra"]["four_times_the_world_one_rank_of_n"] = four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, device, args)
         if not args.no_cpu_baseline and world == 1:
@@ -569,12 +620,9 @@ def four_times_the_world_one_rank_of_n(phyx_amd, scenes, Configuration, group, d
     return res
 
 
-def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
-    """Untimed-by-the-driver side measurements of the other BASELINE.json configs (N=1): the whole device-resident
-    World::Update at cfg 2 size, the broadphase at cfg 4 size (1M boxes) and the solver at cfg 5 size (500k boxes,
-    50 iterations).  They are parity-test cases first (tests/test_*_gpu.py); the numbers here are informational."""
-    res = {}
-    # cfg 2, whole step (ref: World.cpp:19-37), topology still changing (new contacts every step)
+def cfg2_world_step(cfg2_world, cfg2):
+    """The whole device-resident World::Update of the bench's own 200k-box world (ref: World.cpp:19-37), topology still changing (new
+    contacts every step): median of 5 synchronised steps + one step with per-phase host timers."""
     t = []
     for _ in range(5):
         t0 = time.perf_counter(); cfg2_world.FinishStep(1.0 / 60.0, cfg2); cfg2_world.PreSolve(1.0 / 60.0); cfg2_world.sync()
@@ -583,8 +631,17 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     cfg2_world.FinishStep(1.0 / 60.0, cfg2); cfg2_world.PreSolve(1.0 / 60.0)
     ph = cfg2_world.phase_ms()
     cfg2_world.set_phase_timing(False)
-    res["cfg2_world_step"] = {"ms_per_step": 1e3 * float(np.median(t)), "phases_ms": {k: round(v, 3) for k, v in ph.items()},
-                              "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), cfg2_world.counts()))}
+    return {"what": "World::Update (IntegrateVelocity, UpdateBroadphase, UpdatePairs, UpdateManifolds, PackManifolds, RefreshContactJoints, SolveJoints with "
+                    "the schedule rebuilt, IntegratePosition) of the 200k-box world, synchronised per step",
+            "ms_per_step": 1e3 * float(np.median(t)), "phases_ms": {k: round(v, 3) for k, v in ph.items()},
+            "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), cfg2_world.counts()))}
+
+
+def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
+    """Untimed-by-the-driver side measurements of the other BASELINE.json configs (N=1, --secondary): the settled 200k-box world,
+    the broadphase at cfg 4 size (1M boxes) and the solver at cfg 5 size (500k boxes, 50 iterations).  They are parity-test cases
+    first (tests/test_*_gpu.py); the numbers here are informational."""
+    res = {}
     # the same world once it has settled: around step 30 the columns' islands merge into ONE island of ~7e5 joints that no workgroup
     # holds — the steady state a user of a long-running stack sees, solved class by class out of HBM (DESIGN.md §10)
     cfg2_world.FinishStep(1.0 / 60.0, cfg2)                           # (the loop above left the world behind a PreSolve)
@@ -613,9 +670,13 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     # algorithmic bytes: 112 B per body for key build + radix sort + gather, 20 B per candidate test.  The sweep
     # is an L1-resident latency loop (PMC: ~6 % of its algorithmic bytes reach HBM), so this is NOT quoted against the HBM peak.
     alg = 112.0 * w4.counts()[0] + 20.0 * bs.candidate_tests
-    pm4 = pmc_file("r04_pmc_traffic_cfg4") or pmc_file("r03_pmc_traffic_cfg4")
-    bp_kernels = ("k_build_keys", "k_keys_buckets", "k_bucket_scatter", "k_bucket_sort", "k_radix_hist", "k_radix_scatter", "k_scan_", "k_gather_entries", "k_sweep_rows", "k_sweep_chunks", "k_emit", "k_ps_insert")
-    bp_traffic = sum(v * launches_per_update(k) for k, v in pm4.get("kernels", {}).items() if any(n in k for n in bp_kernels)) or None
+    # measured traffic: ONLY the kernels of one profiled steady update, each weighted by its launches in that update and listed with its
+    # time (tools/steady_step_summary.py: kernel trace + the two PMC passes of the same step) — round 4 summed every kernel name in
+    # the PMC file, one-off first-update kernels included, and its 'traffic = algorithmic' was a coincidence
+    pm4 = steady_step_file("r05_cfg4_steady_step")
+    bp_rows = [r for r in pm4.get("kernels", []) if r.get("phase") == "broadphase"]
+    bp_traffic = sum(r["hbm_bytes"] for r in bp_rows) or None
+    bp_us = sum(r["us"] for r in bp_rows) or None
     res["cfg4_broadphase_1M"] = {"device_ms": bs.device_ms, "candidate_tests": bs.candidate_tests, "new_pairs": bs.new_pairs,
                                  "candidate_tests_per_sec": bs.candidate_tests / (bs.device_ms * 1e-3),
                                  "algorithmic_GBps_cache_resident": alg / (bs.device_ms * 1e-3) / 1e9, "world_step_ms": 1e3 * step4,
@@ -625,7 +686,10 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
                                               "achieved": alg / (bs.device_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": alg / (bs.device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                               "traffic": bp_traffic, "traffic_source": pm4.get("file"),
-                                              "traffic_frac": (bp_traffic / (bs.device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if bp_traffic else None,
+                                              "traffic_frac": (bp_traffic / (bp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if bp_traffic and bp_us else None,
+                                              "traffic_frac_what": "measured HBM bytes of the broadphase kernels of one profiled steady update over the sum of "
+                                                                   "their kernel times in that update (both from the file; per kernel below)",
+                                              "per_kernel": [{"kernel": r["kernel"], "launches": r["launches"], "us": r["us"], "hbm_bytes": r["hbm_bytes"]} for r in bp_rows] or None,
                                               "note": "the sweep re-reads neighbouring entries out of L1/L2 (one 20-byte entry serves ~50 tests): measured HBM "
                                                       "traffic is a small fraction of the no-reuse algorithmic figure, and the update is dispatch- and latency-bound"}}
     del w4
@@ -642,7 +706,7 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     t0 = time.perf_counter(); r = s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 0, 10); el = time.perf_counter() - t0
     st = s5.stats()
     launch5_us = 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1)
-    pm5 = pmc_file("r04_pmc_traffic_cfg5") or pmc_file("r03_pmc_traffic_cfg5")
+    pm5 = pmc_file("r05_pmc_traffic_cfg5")
     tr5 = next((v for k, v in pm5.get("kernels", {}).items() if "k_solve_islands<512" in k), None)
     alg5 = (BYTES_IMPULSE_VISIT * r.joint_visits + BYTES_DISPLACEMENT_VISIT * st.displacement_iterations * arrs[2].count * 10) / max(r.impulse_launches, 1)
     res["cfg5_500k_tall_50it_fp32"] = {"ms_per_step": 1e3 * el / 10, "joint_visits_per_sec": r.joint_visits / el, "joints": arrs[2].count,
@@ -670,13 +734,6 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
         "mean_abs_velocity_diff_vs_fp32": float(np.abs(b16["velocity"]["y"] - b32["velocity"]["y"]).mean()),
         "max_abs_impulse_diff_vs_fp32": float(np.abs(j16["normal_acc"] - j32["normal_acc"]).max())}
     return res
-
-
-def launches_per_update(kernel_name):
-    """how often a kernel of the broadphase runs per update (3 radix passes of histogram / scan / scatter)"""
-    if "k_radix_hist" in kernel_name or "k_radix_scatter" in kernel_name:
-        return 3
-    return 1
 
 
 def cpu_baseline(bodies, cps, joints, iters, budget_s):

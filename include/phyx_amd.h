@@ -426,6 +426,10 @@ int phx_solver_bench_stage(phx_solver* s, const void* d_bodies, int32_t body_cou
 int phx_solver_bench(phx_solver* s, const void* d_bodies, int32_t body_count, const void* d_contact_points,
                      int32_t contact_point_count, const void* d_joints, int32_t joint_count,
                      const phx_config* config, int32_t warmup, int32_t steps, phx_bench_result* out);
+/* 64-bit position-sensitive checksum of what the LAST step of the last phx_solver_bench call left in its copy of the input
+ * (velocities, displacing velocities, accumulated impulses): identical input + identical schedule => identical checksum, which is
+ * how bench.py checks, outside its clock, that the timed solves computed what the warm-up solve computed. */
+int phx_solver_bench_checksum(phx_solver* s, uint64_t* out);
 /* Same, with a host callback around every step so that a multi-GPU caller can keep its ranks in lock step without the host
  * ever waiting inside the timed region.  hook(user, step, phase) is called
  *   phase 0  right after step `step` has been queued on the handle's stream (phx_solver_stream): start the per-step

@@ -346,6 +346,12 @@ class Solver:
         arrays solves copy k in step k instead of restoring a working copy in front of every step."""
         check(self.L.phx_solver_bench_stage(self.h, d_bodies.ptr, d_bodies.count, d_joints.ptr, d_joints.count, steps))
 
+    def bench_checksum(self):
+        """64-bit checksum of the results of the last bench() step (velocities, displacing velocities, impulses)."""
+        out = C.c_uint64(0)
+        check(self.L.phx_solver_bench_checksum(self.h, C.byref(out)))
+        return int(out.value)
+
     def bench(self, d_bodies, d_contact_points, d_joints, configuration, warmup, steps, hook=None):
         """`steps` solves of the same resident input, queued back to back.  hook(step, phase) (optional) runs on the host:
         phase 0 after step `step` has been queued (start the per-step exchange on stream_ptr()), phase 1 when the local

@@ -55,6 +55,7 @@ private:
     DevBuf<unsigned short> bucket_of_;
     int splitters_n_ = -1;                    // body count the splitters on record were taken for
     bool split_unbalanced_ = false, split_sorted_ = false;
+    unsigned ss_last_max_ = 0u;          // the largest bucket of the last split-sorted update (0: none above twice the stride): picks k_bucket_sort's LDS shape
     DevBuf<int> erase_count_;                 // pairs really tombstoned since the last settle_erase_check()
     unsigned table_cap_ = 0;
     long long set_size_ = 0, tombstones_ = 0, erase_unchecked_ = 0;

@@ -582,13 +582,22 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         sv.aabb = d_bodies; sv.n = n; sv.buckets = buckets; sv.stride = ss_stride(n); sv.splitters = splitters_.p; sv.keys = keys_[0].p; sv.bucket_of = bucket_of_.p;
         sv.count = ss_count_.p; sv.cursor = ss_count_.p + SS_MAX_BUCKETS; sv.base = ss_base_.p; sv.bucketed = bucketed_.p;
         sv.keys_out = keys_[1].p; sv.idx_out = idx_[1].p; sv.entries = entries_.p; sv.next_splitters = splitters_.p; sv.max_bucket = ss_stats_.p;
-        const dim3 tiles(div_up(n, SS_TILE));
-        if (prologue) hipLaunchKernelGGL((k_keys_buckets<true>), tiles, dim3(SS_TILE_T), 0, stream_, sv, prologue->vel, prologue->mpos, small_.p, 16 + 2 * STAT_SLOTS,
-                                         chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters, prologue->accel);
-        else hipLaunchKernelGGL((k_keys_buckets<false>), tiles, dim3(SS_TILE_T), 0, stream_, sv, (float4*)nullptr, (const float4*)nullptr, small_.p, 16 + 2 * STAT_SLOTS,
-                                chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr, (const float4*)nullptr);
-        hipLaunchKernelGGL(k_bucket_scatter, tiles, dim3(SS_TILE_T), 0, stream_, sv);
-        hipLaunchKernelGGL(k_bucket_sort, dim3(buckets), dim3(SS_SORT_T), 0, stream_, sv);
+        const int items = ss_tile_items(buckets);
+        const dim3 tiles(div_up(n, SS_TILE_T * items));
+#define PHX_KEYS_BUCKETS(INTEGRATE, ITEMS, ...) hipLaunchKernelGGL((k_keys_buckets<INTEGRATE, ITEMS>), tiles, dim3(SS_TILE_T), 0, stream_, sv, __VA_ARGS__)
+        if (prologue) {
+            if (items == SS_ITEMS_LARGE) PHX_KEYS_BUCKETS(true, SS_ITEMS_LARGE, prologue->vel, prologue->mpos, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters, prologue->accel);
+            else PHX_KEYS_BUCKETS(true, SS_ITEMS_SMALL, prologue->vel, prologue->mpos, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap, stamps_.p, prologue->gravity, prologue->dt, prologue->counters, prologue->accel);
+        } else {
+            if (items == SS_ITEMS_LARGE) PHX_KEYS_BUCKETS(false, SS_ITEMS_LARGE, (float4*)nullptr, (const float4*)nullptr, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr, (const float4*)nullptr);
+            else PHX_KEYS_BUCKETS(false, SS_ITEMS_SMALL, (float4*)nullptr, (const float4*)nullptr, small_.p, 16 + 2 * STAT_SLOTS, chunk_count_.p, chunk_cap, stamps_.p, 0.f, 0.f, (unsigned*)nullptr, (const float4*)nullptr);
+        }
+#undef PHX_KEYS_BUCKETS
+        if (items == SS_ITEMS_LARGE) hipLaunchKernelGGL((k_bucket_scatter<SS_ITEMS_LARGE>), tiles, dim3(SS_TILE_T), 0, stream_, sv);
+        else hipLaunchKernelGGL((k_bucket_scatter<SS_ITEMS_SMALL>), tiles, dim3(SS_TILE_T), 0, stream_, sv);
+        // (the small LDS shape while the last update's largest bucket left room: all buckets resident at once)
+        if (ss_last_max_ <= (unsigned)SS_LDS_SMALL_LIMIT) hipLaunchKernelGGL((k_bucket_sort<SS_LDS_SMALL>), dim3(buckets), dim3(SS_SORT_T), 0, stream_, sv);
+        else hipLaunchKernelGGL((k_bucket_sort<SS_LDS_RECORDS>), dim3(buckets), dim3(SS_SORT_T), 0, stream_, sv);
         src = 1;
     } else {
         if (prologue) hipLaunchKernelGGL((k_build_keys<true>), dim3(grid_for(n)), dim3(256), 0, stream_, d_bodies, prologue->vel, prologue->mpos, n, keys_[0].p, idx_[0].p, small_.p, 16 + 2 * STAT_SLOTS,
@@ -629,6 +638,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         if (split) PHX_TRY(rb_.add(&max_bucket, ss_stats_.p, sizeof max_bucket, stream_));
         PHX_TRY(rb_.wait(stream_, stamps_.p + 1, attempt == 0 ? while_waiting : nullptr));
         PHX_TRY(settle_erase_check(erased));
+        ss_last_max_ = split ? max_bucket : 0u;
         if (split && max_bucket > (unsigned)(4 * ss_stride(n))) split_unbalanced_ = true;      // (stale splitters: the next update sorts the long way and takes fresh ones)
         const int needed = (int)(host_small[2] & 0xFFFFFFFFull);
         if (needed <= chunk_cap) break;

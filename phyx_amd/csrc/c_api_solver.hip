@@ -163,6 +163,15 @@ int phx_solver_bench_hooked(phx_solver* s, const void* d_bodies, int32_t nb, con
     return s->impl.bench(d_bodies, nb, d_cps, ncp, d_joints, nj, *cfg, warmup, steps, out, hook, user);
 }
 
+int phx_solver_bench_checksum(phx_solver* s, uint64_t* out)
+{
+    PHX_REQUIRE(s && out, "null handle / output");
+    unsigned long long v = 0;
+    const int st = s->impl.bench_checksum(&v);
+    *out = v;
+    return st;
+}
+
 void* phx_solver_stream(phx_solver* s) { return s ? (void*)s->impl.stream() : nullptr; }
 
 uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index) { return phx::colour_priority(priority_id, joint_index); }

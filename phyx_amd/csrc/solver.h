@@ -78,6 +78,9 @@ public:
     int bench_stage(const void* d_bodies, int nb, const void* d_joints, int nj, int steps);
     int bench(const void* d_bodies, int nb, const void* d_cps, int ncp, const void* d_joints, int nj,
               const phx_config& cfg, int warmup, int steps, phx_bench_result* out, phx_step_hook hook = nullptr, void* user = nullptr);
+    // 64-bit checksum of what the LAST step of the last bench() left in its copy of the input: velocities, displacing velocities and
+    // accumulated impulses, position-sensitive (bench.py compares the timed blocks' with the warm-up solve's, outside its clock)
+    int bench_checksum(unsigned long long* out);
 
     // island-sharded solves: pack this rank's results / scatter the other ranks' (exchange.h); the all-gather in between
     // belongs to the caller (RCCL on stream())
@@ -268,6 +271,7 @@ private:
     // bench snapshots (resident form)
     DevBuf<float4> snap_vel_, snap_dvel_, snap_mpos_;
     DevBuf<phx_contact_joint> snap_joints_;
+    BodyView bench_last_b_{}; phx_contact_joint* bench_last_j_ = nullptr; int bench_last_nb_ = 0, bench_last_nj_ = 0;      // bench_checksum
     // bench_stage(): private copies of the input, one per timed step, made BEFORE the timed region (the input of every step is
     // then resident in HBM — in the resident layout — when the clock starts, and no restore copy runs between the solves)
     DevBuf<float4> stage_vel_, stage_dvel_, stage_mpos_;      // (mpos is read-only: one copy serves every step)

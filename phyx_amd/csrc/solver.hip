@@ -895,6 +895,7 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
             if (nj) PHX_HIP(hipMemcpyAsync(j, d_joints, (size_t)nj * sizeof(phx_contact_joint), hipMemcpyDeviceToDevice, stream_));
         }
         PHX_TRY(solve_resident(b, nb, d_cps, ncp, j, nj, cfg));
+        bench_last_b_ = b; bench_last_j_ = j; bench_last_nb_ = nb; bench_last_nj_ = nj;
         if (xch_send_) {       // island-sharded solve: pack, the caller's all-gather (hook phase 2), unpack — all on the stream
             PHX_TRY(exchange_pack_resident(&b, j, nullptr));
             if (comm_) PHX_TRY(exchange_all_gather());      // native transport: RCCL on this stream, no callback
@@ -964,6 +965,44 @@ int DeviceSolver::bench(const void* d_bodies, int nb, const void* d_cps, int ncp
     out->bracketed_launches = bracket_any ? (long long)sweep_launches_ * ((steps + bracket_stride - 1) / bracket_stride) : 0;
     out->impulse_iterations = (long long)stats_.impulse_iterations * steps;
     out->joint_visits = stats_.joint_visits * steps;
+    return PHX_OK;
+}
+
+// position-sensitive sum of the result words (order of the threads does not matter: a sum of mixed (index, bits) terms)
+static __global__ void __launch_bounds__(256) k_result_checksum(BodyView b, int nb, const phx_contact_joint* __restrict__ joints, int nj, unsigned long long* out)
+{
+    unsigned long long h = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const float4 v = b.vel[i], d = b.dvel[i];
+        const unsigned w[6] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z)};
+        for (int k = 0; k < 6; ++k) h += mix64(((unsigned long long)(6u * (unsigned)i + k + 1u) << 32) | w[k]);
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += gridDim.x * blockDim.x) {
+        const phx_contact_joint j = joints[i];
+        h += mix64(0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1) + __float_as_uint(j.normal_accumulated_impulse));
+        h += mix64(0xC2B2AE3D27D4EB4Full * (unsigned long long)(i + 1) + __float_as_uint(j.friction_accumulated_impulse));
+    }
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+
+int DeviceSolver::bench_checksum(unsigned long long* out)
+{
+    PHX_REQUIRE(out, "null output");
+    PHX_TRY(use_device(device_));
+    PHX_TRY(synchronize());
+    if (!bench_last_j_ && !bench_last_b_.vel) { set_error("bench_checksum: no bench step has run"); return PHX_ERR_STATE; }
+    unsigned long long* d = nullptr;
+    PHX_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, stream_);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_result_checksum, dim3(512), dim3(256), 0, stream_, bench_last_b_, bench_last_nb_, bench_last_j_, bench_last_nj_, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof *out, hipMemcpyDeviceToHost, stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    (void)hipFree(d);
+    if (e != hipSuccess) { set_error("bench_checksum: %s", hipGetErrorString(e)); return PHX_ERR_HIP; }
     return PHX_OK;
 }
 

@@ -23,9 +23,16 @@ namespace phx {
 
 constexpr int SS_STRIDE = 256;                 // records per bucket the splitters aim at (the bucket sort is by rank: quadratic in that)
 constexpr int SS_MAX_BUCKETS = 4096;           // (LDS: the splitters, 8 bytes each, + a counter each)
-constexpr int SS_TILE_T = 256, SS_TILE_ITEMS = 2, SS_TILE = SS_TILE_T * SS_TILE_ITEMS;      // (small tiles: 2e5 bodies must still be a few hundred workgroups)
+// bodies per lane of the two tile kernels: every tile starts by loading the splitters (8 bytes per bucket) and clearing a counter per
+// bucket, whatever it then does — at 1e6 bodies that is 31 KB + 16 KB of set-up in front of TWO bodies per lane (round 4: 31 + 28 us
+// for 70 + 14 MB of traffic).  Small tiles where the table is small (2e5 bodies must still be a few hundred workgroups), eight
+// bodies per lane where it is large.
+constexpr int SS_TILE_T = 256, SS_ITEMS_SMALL = 2, SS_ITEMS_LARGE = 8, SS_LARGE_BUCKETS = 1024;
+static inline int ss_tile_items(int buckets) { return buckets > SS_LARGE_BUCKETS ? SS_ITEMS_LARGE : SS_ITEMS_SMALL; }
 constexpr int SS_SORT_T = 256;
-constexpr int SS_LDS_RECORDS = 4096;           // a bucket of at most that many records is sorted in LDS (32 KB)
+// a bucket of at most that many records is sorted in LDS: 1024 (8 KB: every bucket's workgroup resident at once) while the last
+// update's largest bucket stayed below SS_LDS_SMALL_LIMIT, else 4096 (32 KB: five workgroups per CU); larger buckets: in HBM
+constexpr int SS_LDS_RECORDS = 4096, SS_LDS_SMALL = 1024, SS_LDS_SMALL_LIMIT = 768;
 
 // the stride of a body count: SS_STRIDE while that makes at most SS_MAX_BUCKETS buckets, wider (in steps of 64) beyond
 static inline int ss_stride(int n) { return std::max(SS_STRIDE, div_up(div_up(std::max(n, 1), SS_MAX_BUCKETS), 64) * 64); }
@@ -66,7 +73,7 @@ __device__ __forceinline__ int ss_bucket(const unsigned long long* spl, int nspl
 }
 
 // INTEGRATE: IntegrateVelocity (ref: World.cpp:39-55) rides along exactly as in k_build_keys (broadphase.hip)
-template <bool INTEGRATE>
+template <bool INTEGRATE, int ITEMS>
 __global__ void __launch_bounds__(SS_TILE_T) k_keys_buckets(SplitSortView v, float4* __restrict__ vel, const float4* __restrict__ mpos,
                                                             unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
                                                             unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters, const float4* __restrict__ accel)
@@ -81,11 +88,11 @@ __global__ void __launch_bounds__(SS_TILE_T) k_keys_buckets(SplitSortView v, flo
     for (int i = threadIdx.x; i < nspl; i += SS_TILE_T) spl[i] = v.splitters[i];
     for (int i = threadIdx.x; i < v.buckets; i += SS_TILE_T) hist[i] = 0u;
     __syncthreads();
-    const int tile0 = blockIdx.x * SS_TILE;
+    const int tile0 = blockIdx.x * (SS_TILE_T * ITEMS);
     int steps = 0;
     while ((1 << steps) <= nspl) ++steps;
 #pragma unroll
-    for (int k = 0; k < SS_TILE_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int i = tile0 + k * SS_TILE_T + threadIdx.x;
         if (i >= v.n) continue;
         const unsigned key = ss_radix_float(v.aabb[i].x);
@@ -107,6 +114,7 @@ __global__ void __launch_bounds__(SS_TILE_T) k_keys_buckets(SplitSortView v, flo
     for (int b = threadIdx.x; b < v.buckets; b += SS_TILE_T) if (hist[b]) atomicAdd(&v.count[b], hist[b]);
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(SS_TILE_T) k_bucket_scatter(SplitSortView v)
 {
     __shared__ unsigned base[SS_MAX_BUCKETS];      // first position of every bucket, then + this tile's range inside it
@@ -132,10 +140,10 @@ __global__ void __launch_bounds__(SS_TILE_T) k_bucket_scatter(SplitSortView v)
     }
     if (blockIdx.x == 0 && threadIdx.x == SS_TILE_T - 1) v.base[v.buckets] = before;
     __syncthreads();
-    const int tile0 = blockIdx.x * SS_TILE;
-    unsigned key[SS_TILE_ITEMS], off[SS_TILE_ITEMS]; int bk[SS_TILE_ITEMS];
+    const int tile0 = blockIdx.x * (SS_TILE_T * ITEMS);
+    unsigned key[ITEMS], off[ITEMS]; int bk[ITEMS];
 #pragma unroll
-    for (int k = 0; k < SS_TILE_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int i = tile0 + k * SS_TILE_T + threadIdx.x;
         bk[k] = -1;
         if (i >= v.n) continue;
@@ -146,7 +154,7 @@ __global__ void __launch_bounds__(SS_TILE_T) k_bucket_scatter(SplitSortView v)
     for (int b = threadIdx.x; b < v.buckets; b += SS_TILE_T) if (local[b]) base[b] += atomicAdd(&v.cursor[b], local[b]);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SS_TILE_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int i = tile0 + k * SS_TILE_T + threadIdx.x;
         if (bk[k] >= 0) v.bucketed[base[bk[k]] + off[k]] = ((unsigned long long)key[k] << 32) | (unsigned)i;
     }
@@ -195,16 +203,19 @@ struct SsHbm { unsigned long long* d; __device__ unsigned long long get(int i) c
                __device__ void sync() const { __threadfence(); __syncthreads(); }
                __device__ void wave_sync() const { sync(); } };
 
+template <int LDS_RECORDS>
 __global__ void __launch_bounds__(SS_SORT_T) k_bucket_sort(SplitSortView v)
 {
-    __shared__ __align__(16) unsigned long long rec[SS_LDS_RECORDS];
+    __shared__ __align__(16) unsigned long long rec[LDS_RECORDS];
     const int b = blockIdx.x;
     const unsigned first = v.base[b], m = v.base[b + 1] - first;
-    if (threadIdx.x == 0) { v.count[b] = 0u; v.cursor[b] = 0u; if (m > (unsigned)(4 * v.stride)) atomicMax(v.max_bucket, m); }
+    // (the largest bucket, for the host: unbalanced splitters, and which LDS shape the next update's launch takes; buckets of the
+    //  usual size stay away from the counter)
+    if (threadIdx.x == 0) { v.count[b] = 0u; v.cursor[b] = 0u; if (m > (unsigned)(2 * v.stride)) atomicMax(v.max_bucket, m); }
     if (m == 0) return;
     int P = 2;
     while ((unsigned)P < m) P <<= 1;
-    const bool in_lds = m <= (unsigned)SS_LDS_RECORDS;
+    const bool in_lds = m <= (unsigned)LDS_RECORDS;
     unsigned long long* src = v.bucketed + first;
     if (in_lds) {
         // by RANK: the composites are distinct, so a record's sorted position is the number of records of the bucket below it — m

@@ -54,7 +54,19 @@ def main(tag, dominant):
         kernels[k] = {"launches": max(nf, nw), "grid_size": grid, "fetch_bytes_per_launch_raw": f, "write_bytes_per_launch_raw": w,
                       "hbm_bytes_per_launch_raw": f + w, "hbm_bytes_per_launch_corrected": 2 * f + w}
     dom = [k for k in kernels if dominant in k]
+    import hashlib, subprocess
+    h = hashlib.sha256()
+    for f in ("island_kernel.h", "solver_kernels.h"):
+        h.update(open(os.path.join(ROOT, "phyx_amd", "csrc", f), "rb").read())
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "phyx_amd/csrc"], text=True).strip():
+            commit += "+uncommitted csrc changes"
+    except Exception:
+        commit = "unrecorded"
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline",
+           # bench.py refuses this file once island_kernel.h / solver_kernels.h differ from what was profiled (kernel_source_sha256)
+           "commit": commit, "kernel_source_sha256": h.hexdigest(),
            "correction": "read side x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported",
            "dominant_kernel": dom[0] if dom else None,
            "hbm_bytes_per_launch": kernels[dom[0]]["hbm_bytes_per_launch_corrected"] if dom else None,
