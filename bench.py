@@ -426,6 +426,7 @@ def run_bench(args, pdist):
                       "all_blocks_ms_per_step": [round(x, 5) for x in main_tot["all_blocks_ms_per_step"]],
                       "joint_visits_per_sec_sweeps_only": main_tot["visits"] / (main_tot["sweep_ms"] * main_tot["launches"] / max(main_tot["bracketed"], 1) * 1e-3) if main_tot["sweep_ms"] > 0 else None},
             "roofline": roof,
+            "result_check": main_tot["result_check"],
         }
         if unbracketed is not None:
             out["extra"]["ms_per_step_without_event_brackets"] = 1e3 * unbracketed["elapsed_max"] / max(args.steps, 1)

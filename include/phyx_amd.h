@@ -403,6 +403,10 @@ int  phx_world_x_extent(phx_world* w, float out2[2]);
  * [1] those of them that lost the bet (pack run late, joint match repeated), [2] solves repeated because the cached schedule was
  * stale or a group was left uncommitted, [3] third contact points dropped (ref: Collider.cpp:241-242 would overflow) */
 int  phx_world_debug_counters(phx_world* w, int64_t out4[4]);
+/* diagnostics of the schedule rebuild: [0] rebuilds that KEPT the connected components of the build before (incremental: the step's joint
+ * changes neither joined two components nor removed a unit — counted on the device), [1] rebuilds that recomputed them.  The schedule
+ * is the same pure function of the joints either way; PHX_NO_INCREMENTAL=1 forces [0] to stay 0. */
+int  phx_world_build_counts(phx_world* w, int64_t out2[2]);
 /* per-phase host timers cost one stream synchronisation per phase; off by default (get_phase_ms then returns the last
  * values measured while it was on) */
 int  phx_world_set_phase_timing(phx_world* w, int32_t on);

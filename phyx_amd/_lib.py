@@ -147,6 +147,7 @@ _SIGNATURES = {
     "phx_world_get_phase_ms": (C.c_int, [_vp, _vp]),
     "phx_world_set_phase_timing": (C.c_int, [_vp, _i32]),
     "phx_world_debug_counters": (C.c_int, [_vp, _vp]),
+    "phx_world_build_counts": (C.c_int, [_vp, _vp]),
     "phx_world_x_extent": (C.c_int, [_vp, _vp]),
     "phx_world_synchronize": (C.c_int, [_vp]),
 }

@@ -620,6 +620,12 @@ class World:
         check(self.L.phx_world_x_extent(self.h, _ptr(out)))
         return float(out[0]), float(out[1])
 
+    def build_counts(self):
+        """(incremental rebuilds, full rebuilds) of the schedule so far (phx_world_build_counts)."""
+        out = np.zeros(2, dtype=np.int64)
+        check(self.L.phx_world_build_counts(self.h, _ptr(out)))
+        return int(out[0]), int(out[1])
+
     def debug_counters(self):
         """{deferred_packs, deferred_pack_retries, solve_replays, dropped_points} (phx_world_debug_counters)."""
         out = np.zeros(4, dtype=np.int64)

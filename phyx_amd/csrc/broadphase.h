@@ -17,7 +17,9 @@ public:
     // the resident form: one float4 {min.x, min.y, max.x, max.y} per body (what the World keeps, body_view.h)
     // `while_waiting` (may be null): queued-work hook of the update's one host round trip (Readback::wait) — called at most once;
     // the caller checks whether it ran
-    int update_resident(const float4* d_aabb, int n, const StepPrologue* prologue = nullptr, const std::function<int()>* while_waiting = nullptr);
+    // `carrier` (may be null): the kernel `while_waiting` would queue takes the round trip's post along (Readback::wait)
+    int update_resident(const float4* d_aabb, int n, const StepPrologue* prologue = nullptr, const std::function<int()>* while_waiting = nullptr,
+                        const MailCarrier* carrier = nullptr);
     // the C-ABI edge: 128-byte records (their AABBs are extracted into a scratch array first)
     int update_device(const phx_rigid_body* d_bodies, int n);
     int update_host(const phx_rigid_body* bodies, int n, uint32_t* new_pairs, int cap, int* count);

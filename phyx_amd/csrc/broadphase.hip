@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_build_keys(const float4* __restrict__ a
                                                     unsigned long long* __restrict__ small, int nsmall, unsigned* __restrict__ chunk_count, int nchunks,
                                                     unsigned long long* __restrict__ stamps, float gravity, float dt, unsigned* __restrict__ counters, const float4* __restrict__ accel)
 {
-    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;      // (the World's step counters)
+    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0u;      // (the World's step counters)
     // the update's device time without HIP events (an event record is a barrier packet of its own: ~5 us of idle queue): this, its
     // first kernel, leaves the 100 MHz clock in stamps[0]; the count pass's mailbox post and the insert kernel raise stamps[1]
     if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = (unsigned long long)wall_clock64(); stamps[1] = 0ull; }
@@ -539,7 +539,7 @@ int DeviceBroadphase::update_device(const phx_rigid_body* d_bodies, int n)
     return update_resident(st_aabb_.p, n);
 }
 
-int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepPrologue* prologue, const std::function<int()>* while_waiting)
+int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepPrologue* prologue, const std::function<int()>* while_waiting, const MailCarrier* carrier)
 {
     PHX_TRY(use_device(device_));
     PHX_REQUIRE(n >= 0 && (n == 0 || d_bodies), "bad body array");
@@ -559,7 +559,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
 
     PHX_TRY(stamps_.reserve(2));
     if (n == 0) {
-        if (prologue) PHX_HIP(hipMemsetAsync(prologue->counters, 0, 4 * sizeof(unsigned), stream_));
+        if (prologue) PHX_HIP(hipMemsetAsync(prologue->counters, 0, 8 * sizeof(unsigned), stream_));
         PHX_HIP(hipMemsetAsync(stamps_.p, 0, 2 * sizeof(unsigned long long), stream_));
         PHX_HIP(hipStreamSynchronize(stream_));
         stats_.candidate_tests = 0; stats_.overlapping_pairs = 0; stats_.new_pairs = 0; last_new_ = 0;
@@ -636,7 +636,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
         PHX_TRY(rb_.add(host_small, small_.p, sizeof host_small, stream_));
         unsigned max_bucket = 0;
         if (split) PHX_TRY(rb_.add(&max_bucket, ss_stats_.p, sizeof max_bucket, stream_));
-        PHX_TRY(rb_.wait(stream_, stamps_.p + 1, attempt == 0 ? while_waiting : nullptr));
+        PHX_TRY(rb_.wait(stream_, stamps_.p + 1, attempt == 0 ? while_waiting : nullptr, attempt == 0 ? carrier : nullptr));
         PHX_TRY(settle_erase_check(erased));
         ss_last_max_ = split ? max_bucket : 0u;
         if (split && max_bucket > (unsigned)(4 * ss_stride(n))) split_unbalanced_ = true;      // (stale splitters: the next update sorts the long way and takes fresh ones)

@@ -186,6 +186,29 @@ struct RoctxRange {
 struct MailItem { const unsigned* src; unsigned off, words; };
 struct MailArgs { MailItem it[16]; int count; unsigned seq; unsigned long long* stamp; };      // stamp (may be null): receives max(itself, the 100 MHz clock)
 
+// the post itself, by ONE whole workgroup (k_post_mail, or the first workgroup of a CARRIER kernel: a kernel the caller was going to
+// queue behind the post anyway takes the batch along in its arguments and posts it before its own work — a launch fewer per round trip;
+// a post is a 4-5 us dispatch that moves a few words)
+__device__ __forceinline__ void post_mail_block(const MailArgs& a, unsigned* __restrict__ host_words, unsigned* __restrict__ host_seq)
+{
+    for (int i = 0; i < a.count; ++i) {
+        const unsigned* src = a.it[i].src;
+        unsigned* dst = host_words + a.it[i].off;
+        const unsigned words = a.it[i].words;
+        const unsigned quads = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 ? words / 4 : 0;
+        for (unsigned q = threadIdx.x; q < quads; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(src)[q];
+        for (unsigned w = 4 * quads + threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    }
+    if (a.stamp && threadIdx.x == 0) atomicMax(a.stamp, (unsigned long long)wall_clock64());
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// what a carrier kernel takes: the batch (count == 0: nothing to post) and where it goes
+struct MailRide { MailArgs args; unsigned* host_words; unsigned* host_seq; };
+// Readback::wait's carrier: queues the kernel that carries `ride` (null: this batch goes by DMA, queue the kernel without a post)
+using MailCarrier = std::function<int(const MailRide* ride)>;
+
 static __global__ void __launch_bounds__(1024) k_post_mail(MailArgs a, unsigned* __restrict__ host_words, unsigned* __restrict__ host_seq)
 {
     for (int i = 0; i < a.count; ++i) {
@@ -236,7 +259,8 @@ public:
     // `stamp` (device pointer, may be null): the post kernel also leaves the clock there (atomicMax) — see k_post_mail
     // `while_waiting` (may be null): called once the batch is on its way and before the host starts to wait — whatever it queues
     // on the stream runs while the post crosses the link and the host digests it, instead of the GPU idling through the round trip
-    int wait(hipStream_t stream, unsigned long long* stamp = nullptr, const std::function<int()>* while_waiting = nullptr)
+    // `carrier` (may be null; then `while_waiting` is not looked at): the kernel the caller queues behind the post takes the post along
+    int wait(hipStream_t stream, unsigned long long* stamp = nullptr, const std::function<int()>* while_waiting = nullptr, const MailCarrier* carrier = nullptr)
     {
         // the batch is over however this function leaves: a failed wait must not keep destinations on a dead caller's stack
         struct Reset { Readback& r; ~Reset() { r.count_ = 0; r.used_ = 0; r.odd_ = false; r.dma_ = false;
@@ -246,13 +270,20 @@ public:
             MailArgs a;
             a.count = count_; a.seq = ++seq_; a.stamp = stamp;
             for (int i = 0; i < count_; ++i) a.it[i] = MailItem{static_cast<const unsigned*>(items_[i].src), (unsigned)(items_[i].off / 4), (unsigned)(items_[i].bytes / 4)};
-            hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(used_ > 4096 ? 1024 : (used_ > 1024 ? 256 : 64)), 0, stream, a, reinterpret_cast<unsigned*>(pin_), seq_word());
-            PHX_HIP(hipGetLastError());
-            if (while_waiting) PHX_TRY((*while_waiting)());
+            if (carrier && used_ <= 16384 && !no_carrier()) {      // (batches of a few KB: the carrier's first workgroup is whatever size its kernel has)
+                MailRide ride{a, reinterpret_cast<unsigned*>(pin_), seq_word()};
+                PHX_TRY((*carrier)(&ride));
+            } else {
+                hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(used_ > 4096 ? 1024 : (used_ > 1024 ? 256 : 64)), 0, stream, a, reinterpret_cast<unsigned*>(pin_), seq_word());
+                PHX_HIP(hipGetLastError());
+                if (carrier) PHX_TRY((*carrier)(nullptr));
+                else if (while_waiting) PHX_TRY((*while_waiting)());
+            }
             PHX_TRY(poll(stream));
         } else {
             for (int i = 0; i < count_; ++i) PHX_HIP(hipMemcpyAsync(pin_ + items_[i].off, items_[i].src, items_[i].bytes, hipMemcpyDeviceToHost, stream));
-            if (while_waiting) PHX_TRY((*while_waiting)());
+            if (carrier) PHX_TRY((*carrier)(nullptr));
+            else if (while_waiting) PHX_TRY((*while_waiting)());
             PHX_HIP(hipStreamSynchronize(stream));
         }
         for (int i = 0; i < count_; ++i) std::memcpy(items_[i].dst, pin_ + items_[i].off, items_[i].bytes);
@@ -264,6 +295,7 @@ private:
     struct Item { void* dst; const void* src; size_t off, bytes; };
     unsigned* seq_word() const { return reinterpret_cast<unsigned*>(pin_ + cap_); }
     static bool no_mail() { static const bool off = std::getenv("PHX_NO_MAILBOX") != nullptr; return off; }
+    static bool no_carrier() { static const bool off = std::getenv("PHX_NO_MAIL_CARRIER") != nullptr; return off; }
     int poll(hipStream_t stream)
     {
         volatile unsigned* word = seq_word();

@@ -43,6 +43,24 @@ static __global__ void __launch_bounds__(256) k_cc_init(const float4* __restrict
     }
 }
 
+// INCREMENTAL REBUILD (round 5): the body labels of the last build are still the connected components of this joint list when no
+// joint joins two of them and no unit has vanished since — a running world's usual step: contact points come and go inside body
+// pairs that touch already (the caller vouches for it, solver.h set_labels_hint; the World counts bridging pairs and vanished units
+// on the device, world_kernels.h).  Then the linking pass, the flattening pass and the numbering scan are skipped: this kernel does what
+// is left of k_cc_init (the unit pairing's table) and of the scan's loader (the per-component counters), k_joint_components pairs
+// the joints itself and still raises `unconverged` if some joint's bodies carry different labels (the build is spoiled then and the
+// caller rebuilds the long way).  The schedule is the same pure function of the joints either way (tests: PHX_NO_INCREMENTAL twins).
+static __global__ void __launch_bounds__(256) k_cc_init_lite(int nb, int* __restrict__ clear, const phx_contact_joint* __restrict__ joints, int nj, int ncp,
+                                                             unsigned long long* __restrict__ first, unsigned tag, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) { comp_size[i] = 0u; comp_units[i] = 0u; }
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+        const unsigned id = (unsigned)joints[j].contact_point_index;
+        if (id < (unsigned)ncp) atomicMin(&first[id], ((unsigned long long)tag << 32) | (unsigned)j);
+    }
+}
+
 // (`first` / `partner`: the joints are paired into units on the way, schedule.h; the table is complete, k_cc_init filled it)
 __device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ joints, int j, const phx_contact_joint& me, int ncp,
                                           const unsigned long long* __restrict__ first, unsigned tag)
@@ -132,10 +150,11 @@ struct RootFlagLoad {
 // memory was fine while every column was its own island, but once a settling scene has merged into one island every
 // wave fired at the SAME counter: 1e4 same-address device atomics were 115 us of this 13 us kernel.
 constexpr int JC_T = 1024, JC_TABLE = 2048;
+// (`first` non-null — the incremental rebuild, k_cc_init_lite: no linking pass has paired the joints; they are paired here, into `partner`)
 static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_contact_joint* __restrict__ joints, int nj, int nb, const int* __restrict__ parent,
-                                                                  const unsigned* __restrict__ root_number, const int* __restrict__ partner,
+                                                                  const unsigned* __restrict__ root_number, int* __restrict__ partner,
                                                                   int* __restrict__ joint_comp, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units,
-                                                                  int* __restrict__ unconverged)
+                                                                  int* __restrict__ unconverged, const unsigned long long* __restrict__ first = nullptr, unsigned tag = 0u, int ncp = 0)
 {
     // (`unconverged`, may be null: raised if some joint's two dynamic bodies still carry different labels — a caller that skipped
     //  the hook round which only confirms convergence, solver.hip's speculative build, finds out here instead)
@@ -148,8 +167,11 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
         int mine = -1;
         unsigned lead_one = 0;
         if (j < nj) {
-            const unsigned u = (unsigned)joints[j].body1, v = (unsigned)joints[j].body2;
-            const bool leads = !(partner[j] >= 0 && (joints[j].contact_point_index & 1));      // not the follower of a unit
+            const phx_contact_joint me = joints[j];
+            const unsigned u = (unsigned)me.body1, v = (unsigned)me.body2;
+            int mate;
+            if (first) { mate = partner_of(joints, j, me, ncp, first, tag); partner[j] = mate; } else mate = partner[j];
+            const bool leads = !(mate >= 0 && (me.contact_point_index & 1));      // not the follower of a unit
             int comp = -1;
             if (u < (unsigned)nb && v < (unsigned)nb) {
                 const int pu = parent[u], pv = parent[v];

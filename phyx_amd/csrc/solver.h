@@ -56,7 +56,15 @@ public:
     int solve_resident(const BodyView& bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
     // (`while_waiting`, may be null: queued-work hook of the settling round trip, Readback::wait — called at most once, and only if a
     //  solve is pending; the caller checks whether it ran)
-    int synchronize(const std::function<int()>* while_waiting = nullptr);
+    // INCREMENTAL REBUILD (schedule_kernels.h k_cc_init_lite).  labels_device(): the body labels of the last device build (root body of a
+    // dynamic body's connected component, -1 for a static body) while they are known to be good, else null — a caller that tracks what
+    // changes in the joint list checks new joints against them.  set_labels_hint(true) vouches, for the NEXT rebuild only, that since the
+    // build those labels come from no joint has appeared between two components, no unit has vanished and no body changed its
+    // static-ness: the rebuild then keeps the labels instead of recomputing the components (PHX_NO_INCREMENTAL=1: never).
+    const int* labels_device() const { return labels_valid_ ? bld_.cc_parent.p : nullptr; }
+    void set_labels_hint(bool on) { labels_hint_ = on; }
+    void build_counts(int64_t out2[2]) const { out2[0] = lite_builds_; out2[1] = full_builds_; }      // device rebuilds that kept / recomputed the components
+    int synchronize(const std::function<int()>* while_waiting = nullptr, const MailCarrier* carrier = nullptr);      // (`carrier`: Readback::wait)
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
     int set_body_state_bits(int bits);
@@ -144,7 +152,8 @@ private:
     int enqueue_post(const BodyView& bodies, int nb, phx_contact_joint* d_joints, int nj);
     int capture_graphs(const GraphKey& key, const BodyView& bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints);
     void drop_graphs();
-    int collect_stats(unsigned long long* extra = nullptr, const unsigned long long* extra_src = nullptr, const std::function<int()>* while_waiting = nullptr);
+    int collect_stats(unsigned long long* extra = nullptr, const unsigned long long* extra_src = nullptr, const std::function<int()>* while_waiting = nullptr,
+                      const MailCarrier* carrier = nullptr);
     SolverView view() const;
 
     int device_;
@@ -165,6 +174,7 @@ private:
         bool speculate = true;            // PHX_NO_SPECULATION=1 clears it
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
+        bool no_incremental = false;      // PHX_NO_INCREMENTAL=1: every rebuild recomputes the connected components
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
         int isl_wait_polls = 0;           // PHX_ISL_WAIT_POLLS
         static Options from_env();
@@ -271,6 +281,9 @@ private:
     // bench snapshots (resident form)
     DevBuf<float4> snap_vel_, snap_dvel_, snap_mpos_;
     DevBuf<phx_contact_joint> snap_joints_;
+    bool labels_valid_ = false, labels_hint_ = false, build_lite_ = false;      // incremental rebuild: labels_device() / set_labels_hint(); the build in flight kept the labels
+    int labels_nb_ = 0;
+    long long lite_builds_ = 0, full_builds_ = 0;                                  // (statistics: device builds that kept / recomputed the components)
     BodyView bench_last_b_{}; phx_contact_joint* bench_last_j_ = nullptr; int bench_last_nb_ = 0, bench_last_nj_ = 0;      // bench_checksum
     // bench_stage(): private copies of the input, one per timed step, made BEFORE the timed region (the input of every step is
     // then resident in HBM — in the resident layout — when the clock starts, and no restore copy runs between the solves)

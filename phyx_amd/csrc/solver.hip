@@ -58,6 +58,7 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     o.gpu_builder = !(sb && sb[0] == 'h');
     o.speculate = !on("PHX_NO_SPECULATION");
     o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
+    o.no_incremental = on("PHX_NO_INCREMENTAL");
     o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
     o.trace_schedule = getenv("PHX_TRACE_SCHEDULE") != nullptr;  // print the schedule builders' laps to stderr
     return o;
@@ -542,7 +543,7 @@ int DeviceSolver::solve_host(phx_rigid_body* bodies, int nb, const phx_contact_p
 }
 
 // `extra`/`extra_src`: one more 8-byte value to fetch in the same round trip (the fingerprint of a speculative solve)
-int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long long* extra_src, const std::function<int()>* while_waiting)
+int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long long* extra_src, const std::function<int()>* while_waiting, const MailCarrier* carrier)
 {
     // an unverified device build (build_schedule_device): the classes per group ride along; whether a bin was rejected shows in
     // the fingerprint the caller compares
@@ -566,7 +567,8 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
             spec_bins_pending_ = false;
             spec_bins_failed_ = spec[4] != 0;
             if ((opt_.trace_schedule || getenv("PHX_TRACE_SPEC")) && spec_bins_failed_) fprintf(stderr, "[schedule/gpu] speculative binning spoiled: bits %d (%d components, %d bins, grid %d)\n", spec[4], spec[5], spec[6], unverified_bins_);
-            if (spec_bins_failed_) { spec_bins_ok_ = false; return; }      // (the fingerprint word is spoiled: synchronize() rebuilds)
+            if (spec_bins_failed_) { spec_bins_ok_ = false; return; }      // (the fingerprint word is spoiled: synchronize() rebuilds — and recomputes the components)
+            labels_valid_ = true; labels_nb_ = nb_;                         // the components this build used (computed, or kept and confirmed joint by joint) stand
             const int nbins = std::min(spec[0], unverified_bins_);
             unsigned long long hash = 0;
             std::memcpy(&hash, spec + 8, sizeof hash);
@@ -585,7 +587,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     if (!stats_pending_) {
         if (extra) { PHX_TRY(rb_.add(extra, extra_src, sizeof *extra, stream_)); }
         PHX_TRY(with_build());
-        PHX_TRY(rb_.wait(stream_, nullptr, while_waiting));
+        PHX_TRY(rb_.wait(stream_, nullptr, while_waiting, carrier));
         PHX_TRY(rest_of_sizes());
         settle_build();
         return PHX_OK;
@@ -600,7 +602,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
     PHX_TRY(rb_.add(visit_slots, isl_.visits.p + (size_t)hash_slot_ * VISITS_SET, sizeof visit_slots, stream_));
     PHX_TRY(rb_.add(stamps, isl_.visits.p + (size_t)hash_slot_ * VISITS_SET + ISL_STAT_SLOTS, sizeof stamps, stream_));
     PHX_TRY(with_build());
-    PHX_TRY(rb_.wait(stream_, nullptr, while_waiting));
+    PHX_TRY(rb_.wait(stream_, nullptr, while_waiting, carrier));
     PHX_TRY(rest_of_sizes());
     settle_build();
     int isl[2] = {0, 0};
@@ -646,13 +648,13 @@ int DeviceSolver::complete_partial()
     return PHX_OK;
 }
 
-int DeviceSolver::synchronize(const std::function<int()>* while_waiting)
+int DeviceSolver::synchronize(const std::function<int()>* while_waiting, const MailCarrier* carrier)
 {
     PHX_TRY(use_device(device_));
     if (pending_.active) {
         // one round trip: the speculative solve's control word and its counters together
         unsigned long long fp = 0;
-        PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_, while_waiting));
+        PHX_TRY(collect_stats(&fp, hash_.p + hash_slot_, while_waiting, carrier));
         const Pending p = pending_;
         pending_.active = false;
         const bool spoiled_build = build_was_unverified_ && fp != gate_expected_;      // a bin did not fit: the device build spoiled the control word

@@ -250,8 +250,16 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
             bld_.partner_tag = 0xFFFFFFFEu;
         } else --bld_.partner_tag;
     }
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, nj))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p,
-                       d_joints, nj, ncp_, bld_.partner_first.p, bld_.partner_tag);
+    // incremental rebuild (schedule_kernels.h k_cc_init_lite): the caller vouches that the last build's labels still are the components;
+    // only where the rebuild needs no host round trip (every stack scene) — the long way recomputes them
+    const bool hinted = labels_hint_;
+    labels_hint_ = false;                                   // (the hint is for this rebuild only)
+    build_lite_ = hinted && labels_valid_ && labels_nb_ == nb && !opt_.no_incremental && spec_build_applies(want_islands, nj);
+    labels_valid_ = false;                                  // (until this build is settled)
+    if (build_lite_) hipLaunchKernelGGL(k_cc_init_lite, dim3(grid_for(std::max(nb + 1, nj))), dim3(256), 0, stream_, nb, bld_.sb_small.p, d_joints, nj, ncp_, bld_.partner_first.p,
+                                        bld_.partner_tag, bld_.comp_size.p, bld_.comp_units.p);
+    else hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, nj))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p,
+                            d_joints, nj, ncp_, bld_.partner_first.p, bld_.partner_tag);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -278,7 +286,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
-                           (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
+                           (const unsigned*)bld_.cc_flags.p, bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
         comp_size.assign(std::max(guess, 1), 0u); comp_units.assign(std::max(guess, 1), 0u);
@@ -552,6 +560,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     spec_bins_ok_ = want_islands && rest == 0 && nbins > 0 && ncomp_total <= BINC_MAX;
     spec_bins_guess_ = nbins; spec_lanes_ = sc.lds_lanes;
     sched_ = std::move(sc);
+    labels_valid_ = true; labels_nb_ = nb;                  // (the long way: the components were computed and their convergence read back)
     return PHX_OK;
 }
 
@@ -565,13 +574,22 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
 // (`gate_expected_`), which is what the solve's kernels compare the word with; the hash itself comes back with the results.
 int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
 {
+    if (build_lite_) {
+        // the labels, the root numbers and the component count stand (k_cc_init_lite has cleared the counters): three launches fewer
+        ++lite_builds_;
+        hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
+                           (const unsigned*)bld_.cc_flags.p, bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p,
+                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_);
+    } else {
+    ++full_builds_;
     hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
                        (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
     hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
     PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
                                      reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
     hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
-                       (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
+                       (const unsigned*)bld_.cc_flags.p, bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
+    }
     // (workgroups beyond the real bin count leave at once, and a settling world doubles its bins within a few steps — columns
     //  break in two: a roomy grid costs nothing, a grid too small costs a repeated solve)
     // (up to 2047 bins the joints are grouped by ONE 11-bit radix pass — three launches instead of six — so a grid just above

@@ -80,34 +80,45 @@ __global__ void __launch_bounds__(SS_TILE_T) k_keys_buckets(SplitSortView v, flo
 {
     __shared__ unsigned long long spl[SS_MAX_BUCKETS];
     __shared__ unsigned hist[SS_MAX_BUCKETS];
-    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
+    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = (unsigned long long)wall_clock64(); stamps[1] = 0ull; *v.max_bucket = 0u; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nsmall; i += gridDim.x * blockDim.x) small[i] = 0ull;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) chunk_count[i] = 0u;
+    const int tile0 = blockIdx.x * (SS_TILE_T * ITEMS);
+    // every load of the lane's ITEMS bodies is issued before anything is done with one of them — and before the splitters are fetched: body after body, a lane of the
+    // eight-body shape made eight dependent trips to memory (26 us at 1e6 bodies for 70 MB)
+    float minx[ITEMS]; float4 w[ITEMS]; float im[ITEMS]; float4 acc[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int i = tile0 + k * SS_TILE_T + threadIdx.x;
+        minx[k] = 0.f; w[k] = make_float4(0.f, 0.f, 0.f, 0.f); im[k] = 0.f; acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < v.n) {
+            minx[k] = v.aabb[i].x;
+            if (INTEGRATE) { w[k] = vel[i]; im[k] = mpos[i].x; if (accel) acc[k] = accel[i]; }
+        }
+    }
     const int nspl = v.buckets - 1;
     for (int i = threadIdx.x; i < nspl; i += SS_TILE_T) spl[i] = v.splitters[i];
     for (int i = threadIdx.x; i < v.buckets; i += SS_TILE_T) hist[i] = 0u;
     __syncthreads();
-    const int tile0 = blockIdx.x * (SS_TILE_T * ITEMS);
     int steps = 0;
     while ((1 << steps) <= nspl) ++steps;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const int i = tile0 + k * SS_TILE_T + threadIdx.x;
         if (i >= v.n) continue;
-        const unsigned key = ss_radix_float(v.aabb[i].x);
+        const unsigned key = ss_radix_float(minx[k]);
         const int b = ss_bucket(spl, nspl, steps, ((unsigned long long)key << 32) | (unsigned)i);
         v.keys[i] = key;
         v.bucket_of[i] = (unsigned short)b;
         atomicAdd(&hist[b], 1u);
         if (INTEGRATE) {
-            float4 w = vel[i];
-            float ax = 0.f, ay = 0.f, aa = 0.f;
-            if (accel) { const float4 a = accel[i]; ax = a.x; ay = a.y; aa = a.z; }
-            if (mpos[i].x > 0.0f) ay += gravity;
-            w.x += ax * dt; w.y += ay * dt;
-            w.z += aa * dt;
-            vel[i] = w;
+            float4 u = w[k];
+            float ax = acc[k].x, ay = acc[k].y, aa = acc[k].z;
+            if (im[k] > 0.0f) ay += gravity;
+            u.x += ax * dt; u.y += ay * dt;
+            u.z += aa * dt;
+            vel[i] = u;
         }
     }
     __syncthreads();

@@ -97,6 +97,10 @@ private:
     // only if a manifold did die is the pack run then and the match repeated (a new epoch makes the first one void)
     bool pack_pending_ = false, expect_no_dead_manifolds_ = false;
     unsigned joint_epoch_ = 0;
+    bool bodies_changed_ = true;             // bodies were uploaded since the last schedule rebuild (static-ness is part of the labels)
+    bool packed_this_step_ = false;          // PackManifolds moved manifolds in this step
+    bool topo_unchanged_ = false;            // refresh_contact_joints: this step's joint changes left the connected components alone (solver.h set_labels_hint)
+    const MailRide* old_ride_ = nullptr;     // update_pairs: the post the old manifolds' UpdateManifolds launch carries
     ScanScratch scan_tiles_;     // counters_: [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
     Readback rb_;
     bool joints_changed_ = true;          // joints were created / destroyed (or a body's mass changed) since the last solve
@@ -127,7 +131,7 @@ int World::init()
     // host waits only where it needs a count to size the next launch
     stream_ = broadphase_.stream();
     PHX_TRY(solver_.adopt_stream(stream_));
-    PHX_TRY(counters_.reserve(4));
+    PHX_TRY(counters_.reserve(8));
     return PHX_OK;
 }
 
@@ -200,6 +204,7 @@ int World::sync_bodies_to_device()
     PHX_HIP(hipStreamSynchronize(stream_));
     bodies_dirty_ = false;
     records_stale_ = false;
+    bodies_changed_ = true;                                                 // (masses may have changed: no incremental rebuild on the old labels)
     return PHX_OK;
 }
 
@@ -227,17 +232,21 @@ int World::update_pairs()                                                   // r
     // GPU used to idle through it.  The new pairs' manifolds follow in update_manifolds().  (Not with per-phase timing: the phases
     // would overlap.)
     manifolds_updated_ = 0;
+    packed_this_step_ = false; topo_unchanged_ = false;
     const std::function<int()> old_manifolds = [this]() -> int {
         if (!nm) return PHX_OK;
         PHX_TRY(scratch_for(nm));
         PHX_TRY(pack_flags_.reserve((size_t)nm + 2));
         hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
-                           pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm, (const uint2*)nullptr, 0, counters_.p + 2);
+                           pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm, (const uint2*)nullptr, 0, counters_.p + 2, old_ride_ ? *old_ride_ : MailRide{});
         PHX_HIP(hipGetLastError());
         manifolds_updated_ = nm;
         return PHX_OK;
     };
-    PHX_TRY(broadphase_.update_resident(aabb_.p, nb(), fuse_velocity_ ? &prologue : nullptr, phase_timing ? nullptr : &old_manifolds));      // same stream; returns once the new-pair count is known
+    // (that launch also CARRIES the post of the new-pair count: its first workgroup posts before it updates — a dispatch fewer per step)
+    const MailCarrier old_manifolds_with = [&](const MailRide* ride) -> int { old_ride_ = ride; const int st = old_manifolds(); old_ride_ = nullptr; return st; };
+    PHX_TRY(broadphase_.update_resident(aabb_.p, nb(), fuse_velocity_ ? &prologue : nullptr, phase_timing ? nullptr : &old_manifolds,
+                                        phase_timing || !nm ? nullptr : &old_manifolds_with));      // same stream; returns once the new-pair count is known
     fuse_velocity_ = false;
     if (accel_pending_) {                  // IntegrateVelocity of this step has consumed the uploaded accelerations (ref: World.cpp:50, 53)
         accel_pending_ = false;
@@ -261,7 +270,7 @@ int World::update_manifolds()                                               // r
     PHX_TRY(scratch_for(nm));
     PHX_TRY(pack_flags_.reserve_keep((size_t)nm + 2, (size_t)first, stream_));      // (a pending pack keeps its scan in it until refresh_contact_joints settles it)
     hipLaunchKernelGGL(k_update_manifolds, dim3(wgrid(nm - first)), dim3(256), 0, stream_, d_manifolds_.p, nm, resident(), d_cps_.p,
-                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device(), first, counters_.p + 2);
+                       pack_flags_.p, reinterpret_cast<int*>(counters_.p + 3), nm - fresh_manifolds_, broadphase_.new_pairs_device(), first, counters_.p + 2, MailRide{});
     fresh_manifolds_ = 0;
     PHX_HIP(hipGetLastError());
     return PHX_OK;
@@ -287,6 +296,7 @@ int World::finish_pack(int dead, int dropped)
     dropped_points += dropped;
     expect_no_dead_manifolds_ = dead == 0;
     if (!dead) return PHX_OK;
+    packed_this_step_ = true;
     PHX_TRY(erased_.reserve(dead));
     hipLaunchKernelGGL(k_compact_movers, dim3(wgrid(dead)), dim3(256), 0, stream_, (const unsigned*)pack_flags_.p, (const unsigned*)(counters_.p + 2), nm, nm, mover_pos_.p);
     hipLaunchKernelGGL(k_pack_manifolds, dim3(wgrid(nm)), dim3(256), 0, stream_, d_manifolds_.p, d_cps_.p, nm, (const unsigned*)pack_flags_.p,
@@ -308,7 +318,8 @@ int World::refresh_contact_joints()                                         // r
     }
     // One host round trip for the counts.  A joint is dead iff no contact point re-attached it (the match), which is
     // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
-    unsigned host[4] = {0, 0, 0, 0};                                        // [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
+    unsigned host[5] = {0, 0, 0, 0, 0};                                     // [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points, [4] topology bits (k_joints_match)
+    const int* labels = solver_.labels_device();                            // (null: the solver has no labels it trusts — no incremental rebuild this step)
     for (;;) {
         if (++joint_epoch_ == 0) {                                          // the epoch wrapped: stale stamps could alias
             PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
@@ -316,13 +327,18 @@ int World::refresh_contact_joints()                                         // r
         }
         if (nm) {
             hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
-                               d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p);
+                               d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p, labels, nb(), counters_.p + 4);
             PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
         }
-        if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_}, dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
-        if (nm || nj || pack_pending_) {                                    // counters_[0 .. 3]: adjacent words, one copy
-            PHX_TRY(rb_.add(host, counters_.p, pack_pending_ ? sizeof host : 2 * sizeof(unsigned), stream_));
+        if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_, (const phx_contact_joint*)d_joints_.p, (const phx_manifold*)d_manifolds_.p, nm,
+                                                               labels ? counters_.p + 4 : (unsigned*)nullptr},
+                                                 dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
+        if (nm || nj || pack_pending_) {                                    // counters_[0 .. 4]: adjacent words, one copy
+            unsigned got[5] = {0, 0, 0, 0, 0};
+            PHX_TRY(rb_.add(got, counters_.p, sizeof got, stream_));
             PHX_TRY(rb_.wait(stream_));
+            host[0] = got[0]; host[1] = got[1]; host[4] = got[4];
+            if (pack_pending_) { host[2] = got[2]; host[3] = got[3]; }      // (else PackManifolds has settled them already)
             if (!nm) host[0] = 0;                                           // (not written this step)
             if (!nj) host[1] = 0;
         }
@@ -338,6 +354,12 @@ int World::refresh_contact_joints()                                         // r
     }
     const int fresh = (int)host[0], dead = (int)host[1], old = nj;
     const int total = nj + fresh;
+    // the incremental rebuild's hint (solver.h set_labels_hint): the solver's labels were there to test against, no new joint bridges
+    // two components, no unit vanished, and PackManifolds moved nothing this step (a dead joint's manifold was looked up by its index)
+    topo_unchanged_ = labels != nullptr && host[4] == 0 && !packed_this_step_;
+    static const bool trace_topo = getenv("PHX_TRACE_TOPO") != nullptr;
+    if (trace_topo) fprintf(stderr, "[topology] labels %d bits %u (1 = a new joint bridges two components, 2 = a unit vanished) packed %d new joints %d dead joints %d\n",
+                            labels != nullptr, host[4], (int)packed_this_step_, fresh, dead);
     if (dead) PHX_TRY(mover_pos_.reserve((size_t)total + 2));
     if (fresh) {
         joints_changed_ = true;
@@ -362,6 +384,9 @@ int World::solve(const phx_config& cfg, bool settle)                        // r
 {
     // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
     // keep their velocities here
+    solver_.set_labels_hint(joints_changed_ && topo_unchanged_ && !bodies_changed_);
+    topo_unchanged_ = false;
+    if (joints_changed_) bodies_changed_ = false;                           // (this solve rebuilds: its labels know the bodies as they are now)
     PHX_TRY(solver_.solve_resident(resident().s, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
     joints_changed_ = false;
     // a solve that is still unverified (it ran speculatively on the cached schedule, or on a device-built schedule whose 'every
@@ -382,19 +407,21 @@ int World::solve_and_integrate(float dt, const phx_config& cfg)
     // (what the settle reads is final when the solve's last kernel ends, so its mailbox post goes in FRONT of the integrator and the
     //  integrator is queued while the post crosses the link: the host wakes up a kernel earlier)
     bool integrated = false;
-    const std::function<int()> integrate = [&]() -> int {
+    // (the integrator also CARRIES the settle's post: its first workgroup posts before it integrates — a dispatch fewer per step)
+    const MailCarrier integrate_with = [&](const MailRide* ride) -> int {
         integrated = true;
         if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt,
-                                     pending ? solver_.fingerprint_word() : (const unsigned long long*)nullptr, solver_.expected_fingerprint());
+                                     pending ? solver_.fingerprint_word() : (const unsigned long long*)nullptr, solver_.expected_fingerprint(), ride ? *ride : MailRide{});
         PHX_HIP(hipGetLastError());
         return PHX_OK;
     };
+    const std::function<int()> integrate = [&]() -> int { return integrate_with(nullptr); };
     if (!pending) PHX_TRY(integrate());
     if (pending) {
-        PHX_TRY(solver_.synchronize(&integrate));
+        PHX_TRY(solver_.synchronize(&integrate, nb() ? &integrate_with : nullptr));
         if (!integrated) { set_error("the settle did not queue the integrator"); return PHX_ERR_STATE; }
         if (solver_.replays() != replays && nb())
-            hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);
+            hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull, MailRide{});
         PHX_HIP(hipGetLastError());
     }
     return PHX_OK;
@@ -446,7 +473,7 @@ int World::step_end(float dt)
     { RoctxRange r("Exchange: unpack"); PHX_TRY(solver_.exchange_unpack_resident(resident().s, d_joints_.p)); }
     RoctxRange r("IntegratePosition");
     records_stale_ = true;
-    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);            // ref: World.cpp:57-70
+    if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull, MailRide{});            // ref: World.cpp:57-70
     PHX_HIP(hipGetLastError());
     return PHX_OK;
 }
@@ -574,7 +601,7 @@ int World::finish_step(float dt, const phx_config& cfg)
     if (phase_timing) {                                                     // (per-phase host timing: settle the solve before the integrator)
         { RoctxRange r("SolveJoints"); PHX_TRY(solve(cfg, true)); lap(6); }
         RoctxRange r("IntegratePosition");
-        if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull);
+        if (nb()) hipLaunchKernelGGL(k_integrate_position, dim3(wgrid(nb())), dim3(256), 0, stream_, resident(), nb(), dt, (const unsigned long long*)nullptr, 0ull, MailRide{});
         PHX_HIP(hipGetLastError());
     } else PHX_TRY(solve_and_integrate(dt, cfg));
     records_stale_ = true;
@@ -818,6 +845,13 @@ int phx_world_debug_counters(phx_world* w, int64_t out4[4])
     PHX_REQUIRE(w && out4, "null handle / buffer");
     out4[0] = w->impl.deferred_packs; out4[1] = w->impl.deferred_pack_retries;
     out4[2] = (int64_t)w->impl.solver().replays(); out4[3] = (int64_t)w->impl.dropped_points;
+    return PHX_OK;
+}
+
+int phx_world_build_counts(phx_world* w, int64_t out2[2])
+{
+    PHX_REQUIRE(w && out2, "null handle / buffer");
+    w->impl.solver().build_counts(out2);
     return PHX_OK;
 }
 

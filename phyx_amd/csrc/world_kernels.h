@@ -58,7 +58,7 @@ static __global__ void __launch_bounds__(256) k_world_to_bodies(WorldBodies w, i
 static __global__ void __launch_bounds__(256) k_integrate_velocity(float4* __restrict__ vel, const float4* __restrict__ mpos, int n, float gravity, float dt,
                                                                    unsigned* __restrict__ counters, const float4* __restrict__ accel)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = vel[i];
         float ax = 0.f, ay = 0.f, aa = 0.f;
@@ -89,9 +89,11 @@ __device__ __forceinline__ void rotate_vec(float& vx, float& vy, float c, float 
 // IntegratePosition (ref: World.cpp:57-70) on the resident arrays: reads 72 bytes per body, writes 64.
 // `gate` (may be null): the control word of the solve queued in front; if it differs from `expected` that solve
 // committed nothing (stale or spoiled schedule, solver.hip) and neither does this — the host repeats both.
+// `ride`: the settle's mailbox post, taken along by the first workgroup (common.h post_mail_block) — before the gate: the settle reads it.
 static __global__ void __launch_bounds__(256) k_integrate_position(WorldBodies w, int n, float dt,
-                                                                   const unsigned long long* __restrict__ gate, unsigned long long expected)
+                                                                   const unsigned long long* __restrict__ gate, unsigned long long expected, MailRide ride)
 {
+    if (ride.args.count && blockIdx.x == 0) post_mail_block(ride.args, ride.host_words, ride.host_seq);
     if (gate && *gate != expected) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 v = w.s.vel[i], d = w.s.dvel[i];
@@ -143,8 +145,11 @@ __device__ __forceinline__ NpBody np_load(const WorldBodies& w, int i)
 // by an append kernel of their own in front of this one.
 static __global__ void __launch_bounds__(256) k_update_manifolds(phx_manifold* __restrict__ manifolds, int nm, WorldBodies bodies,
                                                                  phx_contact_point* __restrict__ cps, unsigned* __restrict__ dead, int* __restrict__ dropped,
-                                                                 int nm_old, const uint2* __restrict__ new_pairs, int first, unsigned* __restrict__ dead_count)
+                                                                 int nm_old, const uint2* __restrict__ new_pairs, int first, unsigned* __restrict__ dead_count,
+                                                                 MailRide ride)
 {
+    // (`ride`: the broadphase's new-pair count goes to the host with this launch's first workgroup — common.h post_mail_block)
+    if (ride.args.count && blockIdx.x == 0) post_mail_block(ride.args, ride.host_words, ride.host_seq);
     // (`dead_count`: the step's dead-manifold counter, world.hip — dead manifolds are rare, and a count taken here lets PackManifolds'
     //  scan over all manifolds run only in the steps that have one)
     // (`first`: manifolds [first, nm) — the old manifolds are updated while the host waits for the new-pair count, the new ones
@@ -221,9 +226,12 @@ static __global__ void __launch_bounds__(256) k_pack_manifolds(phx_manifold* __r
 // Match, pass 1: matched points re-attach their joint and stamp it; count the points that need a new joint.  (A kernel of its
 // own: as the loader of its scan it was slower — 25 us against 9 + 5 at 2e5 manifolds, 112 us at 1e6: a scan workgroup is 1024
 // lanes of four items each, too few lanes in flight for this chain of dependent gathers.)
+// `labels` / `topo` (labels may be null): what the solver's incremental schedule rebuild needs to know (solver.h set_labels_hint) —
+// does a NEW joint connect two connected components of the last build?  labels[b] = root body of b's component, -1 for a static body;
+// topo bit 0 = some manifold that gets new joints joins two components (a conservative test: it may have joints already).
 static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold* __restrict__ manifolds, int nm, const phx_contact_point* __restrict__ cps,
                                                              phx_contact_joint* __restrict__ joints, unsigned* __restrict__ seen, unsigned epoch,
-                                                             unsigned* __restrict__ new_count)
+                                                             unsigned* __restrict__ new_count, const int* __restrict__ labels, int nb, unsigned* __restrict__ topo)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
         const phx_manifold m = manifolds[i];
@@ -234,14 +242,30 @@ static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold*
             else { joints[si].contact_point_index = m.point_index + k; seen[si] = epoch; }
         }
         new_count[i] = fresh;
+        if (fresh && labels && (unsigned)m.body1 < (unsigned)nb && (unsigned)m.body2 < (unsigned)nb) {
+            const int l1 = labels[m.body1], l2 = labels[m.body2];
+            if (l1 >= 0 && l2 >= 0 && l1 != l2) atomicOr(topo, 1u);
+        }
     }
 }
 
 // loader of the 'dead joints before joint i' scan (queued behind the match)
+// (`topo` bit 1, for the incremental rebuild: a dead joint whose manifold has no contact point left — a unit that vanished may have
+//  been the only link between two parts of its component.  The joint still carries last step's contact point index, and with it its
+//  manifold: valid in steps in which PackManifolds moved nothing, and the others are not incremental, world.hip.)
 struct JointDeadLoad {
     static constexpr bool in_place = false;
     const unsigned* seen; unsigned epoch;
-    __device__ unsigned operator()(int i) const { return seen[i] != epoch ? 1u : 0u; }
+    const phx_contact_joint* joints; const phx_manifold* manifolds; int nm; unsigned* topo;
+    __device__ unsigned operator()(int i) const
+    {
+        const bool dead = seen[i] != epoch;
+        if (dead && topo) {
+            const unsigned m = (unsigned)joints[i].contact_point_index >> 1;
+            if (m >= (unsigned)nm || manifolds[m].point_count == 0) atomicOr(topo, 2u);
+        }
+        return dead ? 1u : 0u;
+    }
 };
 
 // Match, pass 2: new joints appended in manifold order, then point order (ref: World.cpp:108-114)

@@ -191,9 +191,21 @@ class Group:
         # (device_id binds the communicator to this rank's GPU up front: no 'guessing device ID' and no lazy init in the first collective)
         kw = {"device_id": self.device} if backend == "nccl" else {}
         pg_backend = "gloo" if backend == "rccl" else backend       # native transport: torch only does the rendezvous, on the CPU
-        # (a rank that never shows up must not hang the others for torch's default half hour: PHX_COMM_TIMEOUT_S, like csrc/comm.hip)
+        # Two bounds.  A rank that never shows up must not hang the others for torch's default half hour: the RENDEZVOUS (an explicit
+        # TCPStore that waits for every rank) is bounded by PHX_COMM_TIMEOUT_S, like csrc/comm.hip's.  The process group's own timeout —
+        # which bounds every LATER collective of the group too — is the generous PHX_COLLECTIVE_TIMEOUT_S (default 1800 s): ranks are
+        # legitimately out of step for minutes (rank 0 builds the library or a scene, runs the CPU baseline) and must not be
+        # aborted for it.
         import datetime
-        kw["timeout"] = datetime.timedelta(seconds=comm_timeout_s())
+        kw["timeout"] = datetime.timedelta(seconds=collective_timeout_s())
+        store = None
+        try:
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), self.world_size, is_master=self.rank == 0,
+                                  timeout=datetime.timedelta(seconds=comm_timeout_s()), wait_for_workers=True)
+        except TypeError:                                   # a torch whose TCPStore has other arguments: env rendezvous under the short bound
+            kw["timeout"] = datetime.timedelta(seconds=comm_timeout_s())
+        if store is not None:
+            kw["store"] = store
         try:
             dist.init_process_group(backend=pg_backend, rank=self.rank, world_size=self.world_size, **kw)
         except TypeError:                                   # a torch without the device_id argument
@@ -317,6 +329,15 @@ class Group:
             self.dist.destroy_process_group()
         except Exception:
             pass
+
+
+def collective_timeout_s():
+    """seconds a collective of the torch process group may take before it is aborted (PHX_COLLECTIVE_TIMEOUT_S, default 1800)"""
+    try:
+        v = float(os.environ.get("PHX_COLLECTIVE_TIMEOUT_S", "0"))
+    except ValueError:
+        v = 0.0
+    return v if v > 0 else 1800.0
 
 
 def comm_timeout_s():
@@ -646,8 +667,54 @@ class SlabWorld:
         self.world, self.global_index, self.bounds = world, keep, (float(bounds[me][0]), float(bounds[me][1]))
         self.reslabs += 1
 
+    def reslab_intervals(self):
+        """This rank's share of the re-slab's FIRST phase: {scene index, x-interval} of its dynamic bodies — the intervals reslab_apply
+        computes from the union world (two bodies that share a manifold cover each other's interval: a manifold never spans two
+        ranks, so every rank widens its own), 24 bytes per body instead of the world's whole state."""
+        bodies, manifolds, _, _ = self.world.state()
+        static = (bodies["inv_mass"] == 0) & (bodies["inv_inertia"] == 0)
+        lo = bodies["aabb_min"]["x"].astype(np.float64); hi = bodies["aabb_max"]["x"].astype(np.float64)
+        if len(manifolds):
+            both = ~static[manifolds["body1"]] & ~static[manifolds["body2"]]
+            for _ in range(2):
+                a, b = manifolds["body1"][both], manifolds["body2"][both]
+                l = np.minimum(lo[a], lo[b]); h = np.maximum(hi[a], hi[b])
+                np.minimum.at(lo, a, l); np.minimum.at(lo, b, l); np.maximum.at(hi, a, h); np.maximum.at(hi, b, h)
+        dyn = np.flatnonzero(~static)
+        return _blob(np.asarray(self.global_index, dtype=np.int64)[dyn], lo[dyn], hi[dyn])
+
+    def reslab_plan(self, interval_blobs):
+        """Every rank's reslab_intervals() -> (the new owner of every dynamic body of the scene in scene order, their scene indices, the
+        ranks' new bounds): the same slab_cuts on the same intervals as reslab_apply, computed without the worlds' states."""
+        gis, los, his = [], [], []
+        for blob in interval_blobs:
+            gi, lo, hi = _unblob(blob, (np.int64, np.float64, np.float64))
+            gis.append(gi); los.append(lo); his.append(hi)
+        gi = np.concatenate(gis); lo = np.concatenate(los); hi = np.concatenate(his)
+        order = np.argsort(gi, kind="stable")
+        gi, lo, hi = gi[order], lo[order], hi[order]
+        owner, bounds = slab_cuts(lo, hi, self.group.world_size, self.margin)
+        return owner, gi, bounds
+
     def reslab(self):
-        """Collective: every rank of the group must call it at the same step (step() does, on the all-reduced verdict)."""
+        """Collective: every rank of the group must call it at the same step (step() does, on the all-reduced verdict).
+        Two phases.  First the ranks all-gather only their dynamic bodies' x-intervals (24 bytes per body) and cut the axis anew; if no
+        body changes its owner — the usual case of a guard hit: a pile leaned over its old cut but the gaps are where they were —
+        every rank KEEPS its World (allocations, cached schedule, broadphase splitters and all) and only takes its new bounds.  Only
+        when some body does move are the worlds' states gathered and restored (reslab_apply): that costs O(whole world) per rank
+        (the blobs, their padding to the longest one and the union arrays: several hundred MB at 1e6 bodies), a price paid per
+        migration, not per guard hit."""
+        owner, gi, bounds = self.reslab_plan(all_gather_blobs(self.group, self.reslab_intervals()))
+        me = self.group.rank
+        mine_now = np.sort(np.asarray(self.global_index, dtype=np.int64)[np.isin(np.asarray(self.global_index, dtype=np.int64), gi)])
+        mine_new = np.sort(gi[owner == me])
+        moved = 0 if np.array_equal(mine_now, mine_new) else 1
+        moved = int(self.group.reduce_max(moved)) if self.group.world_size > 1 else moved
+        if not moved:
+            self.bounds = (float(bounds[me][0]), float(bounds[me][1]))
+            self.reslabs += 1
+            self.reslabs_in_place = getattr(self, "reslabs_in_place", 0) + 1
+            return
         self.reslab_apply(all_gather_blobs(self.group, self.reslab_pack()))
 
     def inside(self):

@@ -58,6 +58,30 @@ def test_bit_exact_vs_oracle_in_device_order(solver, oracle, name, iters, island
     assert sb.tobytes() == gb.tobytes() and sj.tobytes() == gj.tobytes()
 
 
+def test_the_library_states_its_arithmetic_form_and_the_other_form_is_within_tolerance(solver, oracle, built_lib):
+    """phx_arith_mode (include/phyx_amd.h): the library reports the arithmetic form of its sweeps; the oracle's MATCHING form replays it
+    bit for bit (every test of this file), the OTHER form — the same order, the other rounding — does not, and stays within SURVEY.md
+    section 8(c)'s T1 of it (|dvel| <= 1e-3 after one SolveJoints).  A parity suite that could not tell the forms apart would pin neither."""
+    form = built_lib.phx_arith_mode()
+    assert form in (oracle.ARITH_SOURCE, oracle.ARITH_FUSED) and oracle.get_arith() == form      # (conftest set the oracle to the library's form)
+    make, warm = SMALL_SCENES["stack10x100"]
+    state = presolve_state(make(), warm)
+    cfg = Configuration(phyx_amd.SOLVE_SCALAR, phyx_amd.ISLAND_MULTIPLE, 15, 15)
+    gb, gj, sched, offs, st = _device_solve(solver, state, cfg)
+    same_b, same_j, _ = _oracle_in_device_order(oracle, state, sched, offs, cfg, oracle.STAG_COLOUR_SYNC)
+    assert gb.tobytes() == same_b.tobytes() and gj.tobytes() == same_j.tobytes()
+    prev = oracle.set_arith(oracle.ARITH_SOURCE if form == oracle.ARITH_FUSED else oracle.ARITH_FUSED)
+    try:
+        other_b, other_j, _ = _oracle_in_device_order(oracle, state, sched, offs, cfg, oracle.STAG_COLOUR_SYNC)
+    finally:
+        oracle.set_arith(prev)
+    assert gb.tobytes() != other_b.tobytes()
+    for f in ("velocity", "displacing_velocity"):
+        for n in ("x", "y"):
+            assert np.max(np.abs(gb[f][n].astype(np.float64) - other_b[f][n])) <= 1e-3
+    assert np.max(np.abs(gb["angular_velocity"].astype(np.float64) - other_b["angular_velocity"])) <= 1e-3
+
+
 def test_every_config_mode_is_accepted_and_deterministic(solver, oracle):
     state = presolve_state(scenes.stack(10, 100), 3)
     ref = None

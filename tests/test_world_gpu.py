@@ -463,9 +463,19 @@ def test_reslab_with_unchanged_cuts_hands_every_world_back_as_it_was(built_lib):
         for sw in a + b:
             sw.world.Update(1.0 / 60.0, cfg)
     before = [sw.world.state() for sw in a]
+    # the re-slab's first phase (24 bytes per dynamic body): the plan made from the ranks' intervals alone must be the cut the full
+    # hand-over makes from the union world — same owners, same bounds — which is what lets a rank keep its World when nobody moves
+    intervals = [sw.reslab_intervals() for sw in a]
+    plans = [sw.reslab_plan(intervals) for sw in a]
     blobs = [sw.reslab_pack() for sw in a]
     for sw in a:
         sw.reslab_apply(blobs)
+    for sw, (owner, gi, bounds) in zip(a, plans):
+        r = sw.group.rank
+        st = sw.world.bodies
+        dyn = ~((st["inv_mass"] == 0) & (st["inv_inertia"] == 0))
+        assert np.array_equal(np.sort(gi[owner == r]), np.sort(np.asarray(sw.global_index)[dyn]))
+        assert (float(bounds[r][0]), float(bounds[r][1])) == sw.bounds
     for sw, twin, old in zip(a, b, before):
         assert sw.reslabs == 1 and np.array_equal(sw.global_index, twin.global_index)
         assert sw.bounds[0] <= twin.bounds[0] + 10 and sw.inside()
@@ -483,7 +493,7 @@ def test_reslab_with_unchanged_cuts_hands_every_world_back_as_it_was(built_lib):
     for step in range(5):
         one.step(1.0 / 60.0, cfg); twin.Update(1.0 / 60.0, cfg)
         _same_world(one.world, twin, "single-rank slab world at step %d" % step)
-    assert one.reslabs == 2 and one.inside()
+    assert one.reslabs == 2 and one.reslabs_in_place == 2 and one.inside()      # (nobody moved: the World was kept both times)
 
 
 def test_reslab_follows_piles_that_grow_into_each_other(built_lib):
@@ -650,7 +660,7 @@ def test_debugging_knobs_do_not_change_results(built_lib):
     """The readback mailbox, the speculative solve / deferred build check and the device schedule builder are performance
     mechanisms — like the fused launches of partitioned components, the second stream and the in-kernel schedule check: with each of
     them switched off (PHX_NO_MAILBOX, PHX_NO_SPECULATION, PHX_SCHEDULE_BUILDER=host, PHX_NO_SPEC_BINS, PHX_NO_PARTS, PHX_NO_SIDE_STREAM,
-    PHX_NO_FUSED_VERIFY, PHX_NO_SPLIT_SORT) a world that
+    PHX_NO_FUSED_VERIFY, PHX_NO_SPLIT_SORT, PHX_NO_MAIL_CARRIER — the mailbox posts riding in the next kernel's first workgroup) a world that
     rebuilds its schedule every step, merges islands and falls back to the host builder (a 90-box clique) must produce the very
     same bytes."""
     import os
@@ -669,5 +679,34 @@ def test_debugging_knobs_do_not_change_results(built_lib):
         want = digest({}, mode)
         assert len(want) == 64
         for knob in ({"PHX_NO_MAILBOX": "1"}, {"PHX_NO_SPECULATION": "1"}, {"PHX_SCHEDULE_BUILDER": "host"}, {"PHX_NO_SPEC_BINS": "1"},
-                     {"PHX_NO_PARTS": "1"}, {"PHX_NO_SIDE_STREAM": "1"}, {"PHX_NO_FUSED_VERIFY": "1"}, {"PHX_NO_SPLIT_SORT": "1"}):
+                     {"PHX_NO_PARTS": "1"}, {"PHX_NO_SIDE_STREAM": "1"}, {"PHX_NO_FUSED_VERIFY": "1"}, {"PHX_NO_SPLIT_SORT": "1"}, {"PHX_NO_MAIL_CARRIER": "1"}):
             assert digest(knob, mode) == want, (knob, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["stack", "merge", "falling", "tilted"])
+def test_incremental_rebuild_builds_the_same_schedule(built_lib, scene):
+    """The incremental schedule rebuild (a step whose joint changes neither join two connected components nor remove a unit keeps the
+    last build's body labels: csrc/schedule_kernels.h k_cc_init_lite, world_kernels.h k_joints_match / JointDeadLoad) must build the
+    schedule the full rebuild builds — the schedule is a pure function of the joints.  tools/incremental_twin.py hashes the schedule
+    (slot order, class offsets, groups) and every array after every step; with PHX_NO_INCREMENTAL=1 the digest is the same, and
+    without it the stacks' steps really are incremental most of the time."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "incremental_twin.py"), scene, "45"], cwd=root, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        digest, lite, full = r.stdout.strip().splitlines()[-1].split()
+        return digest, int(lite), int(full)
+    d_inc, lite, full = run({})
+    d_full, lite0, full0 = run({"PHX_NO_INCREMENTAL": "1"})
+    assert d_inc == d_full
+    assert lite0 == 0 and full0 >= lite + full - 2
+    if scene in ("stack", "merge"):
+        assert lite >= 10, (lite, full)
