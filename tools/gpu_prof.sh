@@ -6,8 +6,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --repeats 3 --no-cpu-baseline"
-timeout 900 python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+ARGS="--steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --secondary"
+timeout 900 python $R/bench.py --secondary > $O/bench_plain.json 2> $O/bench_plain.err
+timeout 600 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o trace -- python $R/bench.py $ARGS > $O/bench_trace.json 2> $O/trace.err
 # the main measurement alone (no secondary runs): every launch of the island kernel in this trace is a full-grid, 20-sweep launch,
 # so its average is the number bench.py's HIP events must agree with
