@@ -123,6 +123,21 @@ def main(tag, dominant):
     print("dominant:", out["dominant_kernel"], "->", out["hbm_bytes_per_launch"], "B per launch")
 
 
+def source_stamp():
+    """(commit, sha256 of island_kernel.h + solver_kernels.h): bench.py refuses a file taken of another version of the kernels"""
+    import hashlib, subprocess
+    h = hashlib.sha256()
+    for f in ("island_kernel.h", "solver_kernels.h"):
+        h.update(open(os.path.join(ROOT, "phyx_amd", "csrc", f), "rb").read())
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "phyx_amd/csrc"], text=True).strip():
+            commit += "+uncommitted csrc changes"
+    except Exception:
+        commit = "unrecorded"
+    return commit, h.hexdigest()
+
+
 def side_config(tag, name, dominant):
     """profiles/<tag>_pmc_traffic_<name>.json + kernel stats + (cfg4) the step timeline of a tools/prof_cfg.py workload"""
     fetch = per_kernel(os.path.join(SRC, name + "_pmc_fetch_counter_collection.csv"))
@@ -136,7 +151,9 @@ def side_config(tag, name, dominant):
         kernels[k] = {"launches": max(nf, nw), "grid_size": grid, "fetch_bytes_per_launch_raw": f, "write_bytes_per_launch_raw": w,
                       "hbm_bytes_per_launch_raw": f + w, "hbm_bytes_per_launch_corrected": 2 * f + w}
     dom = [k for k in kernels if dominant in k]
+    commit, sha = source_stamp()
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/prof_cfg.py " + name,
+           "commit": commit, "kernel_source_sha256": sha,
            "correction": "read side x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported",
            "dominant_kernel": dom[0] if dom else None,
            "hbm_bytes_per_launch": kernels[dom[0]]["hbm_bytes_per_launch_corrected"] if dom else None, "kernels": kernels}
