@@ -48,6 +48,8 @@ BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visi
 # barrier 128.  Round 4 measured what one wave can do (profiles/r04_unit_issue_probe.txt, profiles/r04_sq_islands.json): a wave64
 # issues ONE instruction per ~4 cycles whether or not it depends on the last one, and the working wave of a class step issues
 # ~222 VALU instructions (SQ_INSTS_VALU per group and class step) — so the floor of a class step is that many issue slots.
+# Round 5 (profiles/r05_sq_islands.json): 164 VALU instructions per group and class step, all four waves and the first sweep's
+# displacement half included; the working wave of an impulse-only step issues ~112 of them.
 COLOUR_STEP_CHAIN_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
 COLOUR_STEP_VALU_INSTRUCTIONS = 112          # round 5: the hot form of a class step in fused arithmetic (island_kernel.h imp_fast): ~105 VALU + moves
 COLOUR_STEP_FLOOR_CYCLES = 64 + COLOUR_STEP_VALU_INSTRUCTIONS * 4 + 13 + 128
@@ -363,8 +365,8 @@ def run_bench(args, pdist):
             model = {"colour_steps_on_critical_path": steps_crit, "colours_of_the_slowest_group": ncol_max,
                      "floor_cycles_per_colour_step": COLOUR_STEP_FLOOR_CYCLES,
                      "floor_what": "class step of the one working wave: LDS read 64 + %d VALU instructions x 4 cycles of issue (measured: one wave64 issues an "
-                                   "instruction per ~4 cycles dependent or not, profiles/r04_unit_issue_probe.txt; instructions per class step from "
-                                   "SQ_INSTS_VALU, profiles/r04_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
+                                   "instruction per ~4 cycles dependent or not, profiles/r04_unit_issue_probe.txt; instructions of the hot form of a class step, "
+                                   "island_kernel.h imp_fast; all waves, all sweeps: 164 per group and class step, profiles/r05_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
                      "dependent_chain_floor_cycles_round3": COLOUR_STEP_CHAIN_FLOOR_CYCLES}
             if phases:
                 sweep_us = max(launch_us - phases["setup_prestep_writeback_us"], 0.0)
