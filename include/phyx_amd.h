@@ -295,6 +295,17 @@ int phx_schedule_colours(const int32_t* body1, const int32_t* body2, int32_t joi
 int phx_schedule_islands(const int32_t* body1, const int32_t* body2, int32_t joint_count,
                          const uint8_t* is_static, int32_t body_count,
                          int32_t* joint_island, int32_t* island_size, int32_t island_cap);
+/* Host-only: the island-mode schedule (ref: Solver.cpp:285-454 GatherIslands + :217-273 PrepareIndices) as the workgroup-sized groups
+ * this backend solves out of LDS: connected components binned into groups of at most `lanes` units / 2 * lanes joints / body_cap
+ * bodies (whatever does not fit goes to one trailing group); the classes of a group are coloured like phx_schedule_colours colours a
+ * component.  order / colour_offsets as there; group_offsets (slots) and group_first_colour have groups + 1 entries, *lds_groups of
+ * the groups are LDS groups; per unit of the LDS groups (class-major, group by group; the return value is their number): the slot of
+ * its leader and its lane in the island kernel — the classes' lane ranges are placed on wave boundaries where the lanes allow it
+ * (a class costs one pass of every wave it has a lane in); lanes are execution detail, no result depends on them. */
+int phx_schedule_groups(const int32_t* body1, const int32_t* body2, int32_t joint_count, const uint8_t* is_static, int32_t body_count,
+                        const int32_t* priority_ids, int32_t lanes, int32_t body_cap, int32_t* order, int32_t* colour_offsets,
+                        int32_t offsets_cap, int32_t* colour_count, int32_t* group_offsets, int32_t* group_first_colour,
+                        int32_t groups_cap, int32_t* lds_groups, int32_t* unit_lane, int32_t* unit_leader_slot);
 uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index);
 
 /* ---------------------------------------------------------------------------------------------- */

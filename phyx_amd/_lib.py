@@ -115,6 +115,7 @@ _SIGNATURES = {
     "phx_schedule_priority": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_schedule_islands": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32]),
+    "phx_schedule_groups": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "phx_broadphase_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "phx_broadphase_destroy": (None, [_vp]),
     "phx_broadphase_clear": (C.c_int, [_vp]),

@@ -102,6 +102,27 @@ def schedule_colours(body1, body2, is_static, priority_ids=None):
     return order[:len(b1)], offs[:nc.value + 1]
 
 
+def schedule_groups(body1, body2, is_static, priority_ids=None, lanes=256, body_cap=768):
+    """Host-only: the island-mode schedule as workgroup-sized LDS groups (include/phyx_amd.h phx_schedule_groups) -> dict with
+    order, colour_offsets, group_offsets, group_first_colour, lds_groups, unit_lane, unit_leader_slot."""
+    L = _lib.load()
+    pid = None if priority_ids is None else np.ascontiguousarray(priority_ids, dtype=np.int32)
+    b1 = np.ascontiguousarray(body1, dtype=np.int32)
+    b2 = np.ascontiguousarray(body2, dtype=np.int32)
+    st = np.ascontiguousarray(is_static, dtype=np.uint8)
+    n = len(b1)
+    order = np.zeros(max(n, 1), dtype=np.int32)
+    offs = np.zeros(n + 2, dtype=np.int32)
+    goff = np.zeros(n + 3, dtype=np.int32); gfc = np.zeros(n + 3, dtype=np.int32)
+    ulane = np.zeros(max(n, 1), dtype=np.int32); uslot = np.zeros(max(n, 1), dtype=np.int32)
+    nc = C.c_int32(0); lg = C.c_int32(0)
+    nu = check(L.phx_schedule_groups(_ptr(b1), _ptr(b2), n, _ptr(st), len(st), None if pid is None else _ptr(pid), int(lanes), int(body_cap), _ptr(order), _ptr(offs),
+                                     len(offs), C.byref(nc), _ptr(goff), _ptr(gfc), len(goff), C.byref(lg), _ptr(ulane), _ptr(uslot)))
+    ng = lg.value + (1 if lg.value == 0 or goff[lg.value] < n else 0)
+    return dict(order=order[:n], colour_offsets=offs[:nc.value + 1], lds_groups=lg.value, group_offsets=goff[:ng + 1], group_first_colour=gfc[:ng + 1],
+                unit_lane=ulane[:nu], unit_leader_slot=uslot[:nu])
+
+
 def schedule_islands(body1, body2, is_static):
     """Host-only: GatherIslands semantics (ref: Solver.cpp:285-454) -> (joint_island, island_size)."""
     L = _lib.load()

@@ -190,6 +190,31 @@ int phx_schedule_colours(const int32_t* b1, const int32_t* b2, int32_t nj, const
     return PHX_OK;
 }
 
+int phx_schedule_groups(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb, const int32_t* priority_ids,
+                        int32_t lanes, int32_t body_cap, int32_t* order, int32_t* offsets, int32_t offsets_cap, int32_t* ncolours,
+                        int32_t* group_offsets, int32_t* group_first_colour, int32_t groups_cap, int32_t* lds_groups,
+                        int32_t* unit_lane, int32_t* unit_leader_slot)
+{
+    PHX_REQUIRE(nj >= 0 && nb >= 0 && (nj == 0 || (b1 && b2 && order && unit_lane && unit_leader_slot)) && (nb == 0 || is_static) && offsets && ncolours
+                && group_offsets && group_first_colour && lds_groups && lanes > 0 && body_cap > 0, "bad arguments");
+    for (int j = 0; j < nj; ++j) PHX_REQUIRE((unsigned)b1[j] < (unsigned)nb && (unsigned)b2[j] < (unsigned)nb, "body index out of range");
+    phx::Schedule s;
+    phx::LdsCaps caps;
+    caps.max_units = lanes; caps.max_joints = 2 * lanes; caps.max_bodies = body_cap; caps.max_colours = 64;
+    phx::build_island_schedule(b1, b2, nj, is_static, nb, caps, s, nullptr, priority_ids);
+    *ncolours = (int)s.colour_offsets.size() - 1;
+    *lds_groups = s.lds_groups;
+    if ((int)s.colour_offsets.size() > offsets_cap) { phx::set_error("colour_offsets too small"); return PHX_ERR_CAPACITY; }
+    if (s.ngroups() + 1 > groups_cap) { phx::set_error("group arrays too small"); return PHX_ERR_CAPACITY; }
+    std::copy(s.order.begin(), s.order.end(), order);
+    std::copy(s.colour_offsets.begin(), s.colour_offsets.end(), offsets);
+    std::copy(s.group_offsets.begin(), s.group_offsets.end(), group_offsets);
+    std::copy(s.group_first_colour.begin(), s.group_first_colour.end(), group_first_colour);
+    std::copy(s.unit_lane.begin(), s.unit_lane.end(), unit_lane);
+    std::copy(s.unit_leader.begin(), s.unit_leader.end(), unit_leader_slot);
+    return (int)s.unit_leader.size();
+}
+
 int phx_schedule_islands(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb,
                          int32_t* joint_island, int32_t* island_size, int32_t island_cap)
 {

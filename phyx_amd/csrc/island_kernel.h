@@ -195,10 +195,10 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     for (int k = 0; k < BI; ++k) body_id[k] = tid + k * T < NB ? iv.bodies[(size_t)group * NB + tid + k * T] : -1;      // (entries past the group's count: unused words of its table)
     const int4 ua = iv.unit_recs[2 * ((size_t)group * T + tid)], ub = iv.unit_recs[2 * ((size_t)group * T + tid) + 1];
     const int4 d = iv.desc[group];
-    const int ncol = iv.ncol[group];
     const int units_word = iv.units[group];
-    const int nunits = units_word & 0xFFFF, nstatic = units_word >> 16;
-    const bool live = tid < nunits;
+    // (schedule.h LANES: the classes' lane ranges sit on wave boundaries where the lanes allow it — a lane has a unit or it has not)
+    const int ncol = island_word_classes(units_word), nstatic = island_word_static(units_word);
+    const bool live = ua.x >= 0;
 #pragma unroll
     for (int k = 0; k < BI; ++k) if (tid + k * T >= d.w) body_id[k] = -1;
     const bool has2 = live && ua.y >= 0;
@@ -277,6 +277,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     for (int i = tid; i < 4 * NB; i += T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
     const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
     const bool wave_static = __any(live && (st1 || st2));      // (wave-uniform, fixed for the solve)
+    int sm1 = st1 ? -1 : 0, sm2 = st2 ? -1 : 0;                // (as masks: the hot form selects with them instead of branching)
+    asm volatile("" : "+v"(sm1), "+v"(sm2));
     __syncthreads();
     PHX_ISL_STAMP(2);
 
@@ -306,116 +308,139 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
     bool imp_alive = ci > 0, disp_alive = pi > 0;
     const int iters = ci > pi ? ci : pi;
     unsigned early_ctl = 0u;                               // (lane 0) the control word as read a few sweeps in: by then every workgroup has long arrived
-    for (int it = 0; it < iters; ++it) {
+    int it = 0, c = 0, slot = 0;                           // the sweep, the class and the flag slot the step forms below work on
+    // ISL_VERIFY: look at the control word a few sweeps in, off the critical path (the load returns while the sweeps run); the commit
+    // decision at the end then needs no memory round trip of its own unless some workgroup really is that late
+    auto peek_ctl = [&]() { if (verify && it == 3 && tid == 0 && iv.wait_polls > 0) early_ctl = (unsigned)__hip_atomic_load(iv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // three flag slots in rotation: the one cleared for the next sweep was read last at the end of sweep it - 2, and every class
+    // step of sweep it - 1 has put a barrier in between — so a sweep needs no barrier of its own at its end
+    auto next_slot = [&]() { slot = it % 3; if (tid == 0) { const int next = slot == 2 ? 0 : slot + 1; flag_imp[next] = 0; flag_disp[next] = 0; } };
+    // TRACE level 2 (phx_solver_set_trace: per-wave cycle counts of every class step — ~15 % slower)
+    const bool wt = TRACE && iv.wave_trace;
+    unsigned long long ts0 = 0ull, ts1 = 0ull; bool working = false;
+    auto step_begin = [&]() { if (wt) { ts0 = __builtin_readcyclecounter(); working = __any(col == c); } };
+    auto step_work_done = [&]() { if (wt) ts1 = __builtin_readcyclecounter(); };
+    auto step_end = [&]() {
+        if (!wt) return;
+        const unsigned long long ts2 = __builtin_readcyclecounter();
+        if (working) {
+            if (__popcll(__ballot(col == c)) > 32) { tw_work_big += ts1 - ts0; ++tw_nbig; } else { tw_work += ts1 - ts0; ++tw_nwork; }
+            tw_bar += ts2 - ts1;
+        } else { tw_idle += ts2 - ts0; ++tw_nidle; }
+    };
+    // THE GENERAL FORM of a class step — one unit, one sweep half: `s1` / `s2` = the unit's bodies are static.  Called twice below: with the lane's real
+    // flags, and — for a wave none of whose units touches a static body, i.e. almost every wave — with constants,
+    // which folds the tag lookups, the restore copies, their selects and a dozen exec-mask branches away.
+    auto imp_step = [&](const bool s1, const bool s2, const bool two) {
+        float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
+        bool prod0 = false, prod1 = false;
+        const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
+        const bool sp1 = s1 && static_productive_lds(swi, l1, it, c), sp2 = s2 && static_productive_lds(swi, l2, it, c);
+        bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
+        if (two) {
+            if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
+            if (s1) B1 = S1;
+            if (s2) B2 = S2;
+            touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
+        }
+        if (prod0 || prod1) {
+            flag_imp[slot] = 1;
+            if (s1) atomicMax(&swi[it & 1][l1], static_word(it, c));
+            if (s2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+        }
+        if (touched) {
+            if (!s1) body_store(imp, l1, B1);
+            if (!s2) body_store(imp, l2, B2);
+        }
+    };
+    auto disp_step = [&](const bool s1, const bool s2, const bool two) {
+        float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
+        bool prod0 = false, prod1 = false;
+        const float4 S1 = D1, S2 = D2;
+        const bool sp1 = s1 && static_productive_lds(swd, l1, it, c), sp2 = s2 && static_productive_lds(swd, l2, it, c);
+        bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
+        if (two) {
+            if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
+            if (s1) D1 = S1;
+            if (s2) D2 = S2;
+            touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
+        }
+        if (prod0 || prod1) {
+            flag_disp[slot] = 1;
+            if (s1) atomicMax(&swd[it & 1][l1], static_word(it, c));
+            if (s2) atomicMax(&swd[it & 1][l2], static_word(it, c));
+        }
+        if (touched) {
+            if (!s1) body_store(disp, l1, D1);
+            if (!s2) body_store(disp, l2, D2);
+        }
+    };
+    // THE HOT FORM of a class step: impulses only (the displacement sweeps of a resting scene end after the first: nothing is
+    // deeper than the allowed penetration, ref: Solver.cpp:672-680, 210).  One skip test per unit — the follower's test equals
+    // its leader's: a skipped leader changes no tag, and an evaluated one either leaves the tags as they were or raises
+    // them to `it` — and one tag update; straight-line but for the follower's mask: a class step is one wave's instruction
+    // stream, and every taken branch in it is ~20 cycles.  `ws` = some unit of the wave touches a static body (wave-uniform):
+    // only then the static tags are looked up and raised, the static records restored between the joints and left unstored —
+    // same results as imp_step (the general form keeps the first sweep, where the displacement half runs too).
+    auto imp_fast = [&](const bool ws) {
+        float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
+        // (`ws`: the static tags' words travel with the body records — every lane of the wave reads them, a dynamic body's
+        //  are zero — instead of two more dependent LDS round trips for the one lane that needs them: static_productive_lds)
+        unsigned pw1 = 0u, cw1 = 0u, pw2 = 0u, cw2 = 0u;
+        if (ws) { pw1 = swi[(it - 1) & 1][l1]; cw1 = swi[it & 1][l1]; pw2 = swi[(it - 1) & 1][l2]; cw2 = swi[it & 1][l2]; }
+        // (everything in ONE LDS round trip: left alone, the compiler reads the two tags, tests, and only then — under the
+        //  branch — the six velocity words: two dependent round trips on the critical path of every class step)
+        if (!HALF) asm volatile("" : "+v"(B1.x), "+v"(B1.y), "+v"(B1.z), "+v"(B1.w), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(B2.w));
+        if (ws) asm volatile("" : "+v"(pw1), "+v"(cw1), "+v"(pw2), "+v"(cw2));
+        bool active = max(__float_as_int(B1.w), __float_as_int(B2.w)) > it - 2;
+        if (ws) {
+            // static_productive_lds on the words already here — every lane evaluates both bodies' tests and selects (no
+            // short-circuit: as `st1 && sp(..)` this was four exec-mask regions in the one wave whose step everybody waits for)
+            const unsigned itu = (unsigned)it, clu = (unsigned)c;
+            auto sp = [&](unsigned pw, unsigned cw) {
+                return (int)(it == 0) | (int)((pw >> 16) == itu) | ((int)((cw >> 16) == itu + 1u) & (int)((0xFFFFu - (cw & 0xFFFFu)) < clu));
+            };
+            const int a1 = (sp(pw1, cw1) & sm1) | ((int)(__float_as_int(B1.w) > it - 2) & ~sm1);
+            const int a2 = (sp(pw2, cw2) & sm2) | ((int)(__float_as_int(B2.w) > it - 2) & ~sm2);
+            active = ((a1 | a2) & 1) != 0;
+        }
+        if (active) {
+            const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
+            bool prod = isl_impulse_eval(q0, B1, B2, im1, ii1, im2, ii2);
+            if (has2) {
+                if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
+                if (ws) {
+                    B1.x = sm1 ? S1.x : B1.x; B1.y = sm1 ? S1.y : B1.y; B1.z = sm1 ? S1.z : B1.z; B1.w = sm1 ? S1.w : B1.w;
+                    B2.x = sm2 ? S2.x : B2.x; B2.y = sm2 ? S2.y : B2.y; B2.z = sm2 ? S2.z : B2.z; B2.w = sm2 ? S2.w : B2.w;
+                }
+                prod |= isl_impulse_eval(q1, B1, B2, im1, ii1, im2, ii2);
+            }
+            B1.w = prod ? __int_as_float(it) : B1.w; B2.w = prod ? __int_as_float(it) : B2.w;
+            if (prod) {
+                flag_imp[slot] = 1;
+                if (ws) {
+                    if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
+                    if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+                }
+            }
+            if (!ws || !st1) body_store(imp, l1, B1);
+            if (!ws || !st2) body_store(imp, l2, B2);
+        }
+    };
+    // The sweeps, in two loops: the general form while the displacement half still runs, then the hot form alone — once over, the
+    // displacement sweeps stay over (disp_alive only falls, `it` only grows).  (One loop with both forms in it cost the hot form a
+    // dozen register copies per class step: the accumulators' values flowed through every form's exits.)
+    bool hot_from_here = false;
+    for (; it < iters; ++it) {
         const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
         if (!imp_on && !disp_on) break;
-        // ISL_VERIFY: look at the control word NOW, off the critical path (the load returns while the sweeps run); the commit
-        // decision at the end then needs no memory round trip of its own unless some workgroup really is that late
-        if (verify && it == 3 && tid == 0 && iv.wait_polls > 0) early_ctl = (unsigned)__hip_atomic_load(iv.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // three slots in rotation: the one cleared here for the next sweep was read last at the end of sweep it - 2, and every
-        // class step of sweep it - 1 has put a barrier in between — so the sweep needs no barrier of its own at its end
-        const int slot = it % 3;
-        if (tid == 0) { const int next = slot == 2 ? 0 : slot + 1; flag_imp[next] = 0; flag_disp[next] = 0; }
-        const bool hot = imp_on && !disp_on;      // (workgroup-uniform, fixed for the sweep)
-        for (int c = 0; c < ncol; ++c) {
-            const bool wt = TRACE && iv.wave_trace;            // (phx_solver_set_trace level 2: per-wave cycle counts of every class step — ~15 % slower)
-            const unsigned long long ts0 = wt ? __builtin_readcyclecounter() : 0ull;
-            const bool working = wt && __any(col == c);
+        if (imp_on && !disp_on) { hot_from_here = true; break; }
+        peek_ctl();
+        next_slot();
+        for (c = 0; c < ncol; ++c) {
+            step_begin();
             if (col == c) {
-                // one unit, one sweep half: `s1` / `s2` = the unit's bodies are static.  Called twice below: with the lane's real
-                // flags, and — for a wave none of whose units touches a static body, i.e. almost every wave — with constants,
-                // which folds the tag lookups, the restore copies, their selects and a dozen exec-mask branches away.
-                auto imp_step = [&](const bool s1, const bool s2, const bool two) {
-                    float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-                    bool prod0 = false, prod1 = false;
-                    const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-                    const bool sp1 = s1 && static_productive_lds(swi, l1, it, c), sp2 = s2 && static_productive_lds(swi, l2, it, c);
-                    bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
-                    if (two) {
-                        if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
-                        if (s1) B1 = S1;
-                        if (s2) B2 = S2;
-                        touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
-                    }
-                    if (prod0 || prod1) {
-                        flag_imp[slot] = 1;
-                        if (s1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                        if (s2) atomicMax(&swi[it & 1][l2], static_word(it, c));
-                    }
-                    if (touched) {
-                        if (!s1) body_store(imp, l1, B1);
-                        if (!s2) body_store(imp, l2, B2);
-                    }
-                };
-                auto disp_step = [&](const bool s1, const bool s2, const bool two) {
-                    float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
-                    bool prod0 = false, prod1 = false;
-                    const float4 S1 = D1, S2 = D2;
-                    const bool sp1 = s1 && static_productive_lds(swd, l1, it, c), sp2 = s2 && static_productive_lds(swd, l2, it, c);
-                    bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
-                    if (two) {
-                        if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
-                        if (s1) D1 = S1;
-                        if (s2) D2 = S2;
-                        touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
-                    }
-                    if (prod0 || prod1) {
-                        flag_disp[slot] = 1;
-                        if (s1) atomicMax(&swd[it & 1][l1], static_word(it, c));
-                        if (s2) atomicMax(&swd[it & 1][l2], static_word(it, c));
-                    }
-                    if (touched) {
-                        if (!s1) body_store(disp, l1, D1);
-                        if (!s2) body_store(disp, l2, D2);
-                    }
-                };
-                // THE HOT FORM of a class step: impulses only (the displacement sweeps of a resting scene end after the first: nothing is
-                // deeper than the allowed penetration, ref: Solver.cpp:672-680, 210).  One skip test per unit — the follower's test equals
-                // its leader's: a skipped leader changes no tag, and an evaluated one either leaves the tags as they were or raises
-                // them to `it` — and one tag update; straight-line but for the follower's mask: a class step is one wave's instruction
-                // stream, and every taken branch in it is ~20 cycles.  `ws` = some unit of the wave touches a static body (wave-uniform):
-                // only then the static tags are looked up and raised, the static records restored between the joints and left unstored —
-                // same results as imp_step (the general form keeps the first sweep, where the displacement half runs too).
-                auto imp_fast = [&](const bool ws) {
-                    float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-                    // (`ws`: the static tags' words travel with the body records — every lane of the wave reads them, a dynamic body's
-                    //  are zero — instead of two more dependent LDS round trips for the one lane that needs them: static_productive_lds)
-                    unsigned pw1 = 0u, cw1 = 0u, pw2 = 0u, cw2 = 0u;
-                    if (ws) { pw1 = swi[(it - 1) & 1][l1]; cw1 = swi[it & 1][l1]; pw2 = swi[(it - 1) & 1][l2]; cw2 = swi[it & 1][l2]; }
-                    // (everything in ONE LDS round trip: left alone, the compiler reads the two tags, tests, and only then — under the
-                    //  branch — the six velocity words: two dependent round trips on the critical path of every class step)
-                    if (!HALF) asm volatile("" : "+v"(B1.x), "+v"(B1.y), "+v"(B1.z), "+v"(B1.w), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(B2.w));
-                    if (ws) asm volatile("" : "+v"(pw1), "+v"(cw1), "+v"(pw2), "+v"(cw2));
-                    bool active = max(__float_as_int(B1.w), __float_as_int(B2.w)) > it - 2;
-                    if (ws) {
-                        auto sp = [&](unsigned pw, unsigned cw) {      // static_productive_lds on the words already here
-                            return it == 0 || (pw >> 16) == (unsigned)it || ((cw >> 16) == (unsigned)(it + 1) && (0xFFFFu - (cw & 0xFFFFu)) < (unsigned)c);
-                        };
-                        const bool sp1 = st1 && sp(pw1, cw1), sp2 = st2 && sp(pw2, cw2);
-                        active = (st1 ? sp1 : (__float_as_int(B1.w) > it - 2)) || (st2 ? sp2 : (__float_as_int(B2.w) > it - 2));
-                    }
-                    if (active) {
-                        const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-                        bool prod = isl_impulse_eval(q0, B1, B2, im1, ii1, im2, ii2);
-                        if (has2) {
-                            if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
-                            if (ws) { if (st1) B1 = S1; if (st2) B2 = S2; }
-                            prod |= isl_impulse_eval(q1, B1, B2, im1, ii1, im2, ii2);
-                        }
-                        B1.w = prod ? __int_as_float(it) : B1.w; B2.w = prod ? __int_as_float(it) : B2.w;
-                        if (prod) {
-                            flag_imp[slot] = 1;
-                            if (ws) {
-                                if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                                if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
-                            }
-                        }
-                        if (!ws || !st1) body_store(imp, l1, B1);
-                        if (!ws || !st2) body_store(imp, l2, B2);
-                    }
-                };
-                if (hot) { if (wave_static) imp_fast(true); else imp_fast(false); }
-                else if (wave_static) {
+                if (wave_static) {
                     if (imp_on) imp_step(st1, st2, has2);
                     if (disp_on) disp_step(st1, st2, has2);
                 } else {
@@ -423,19 +448,26 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
                     if (disp_on) disp_step(false, false, has2);
                 }
             }
-            const unsigned long long ts1 = wt ? __builtin_readcyclecounter() : 0ull;
+            step_work_done();
             __syncthreads();
-            if (wt) {
-                const unsigned long long ts2 = __builtin_readcyclecounter();
-                if (working) {
-                    if (__popcll(__ballot(col == c)) > 32) { tw_work_big += ts1 - ts0; ++tw_nbig; } else { tw_work += ts1 - ts0; ++tw_nwork; }
-                    tw_bar += ts2 - ts1;
-                } else { tw_idle += ts2 - ts0; ++tw_nidle; }
-            }
+            step_end();
         }
         if (imp_on) { done_imp = it + 1; imp_alive = flag_imp[slot] != 0; }        // (behind the last class step's barrier)
         if (disp_on) { done_disp = it + 1; disp_alive = flag_disp[slot] != 0; }
     }
+    if (hot_from_here)
+        for (; it < ci && imp_alive; ++it) {
+            peek_ctl();
+            next_slot();
+            for (c = 0; c < ncol; ++c) {
+                step_begin();
+                if (col == c) { if (wave_static) imp_fast(true); else imp_fast(false); }
+                step_work_done();
+                __syncthreads();
+                step_end();
+            }
+            done_imp = it + 1; imp_alive = flag_imp[slot] != 0;
+        }
 
     PHX_ISL_STAMP(4);
     // results go straight back into the caller's records (commit-gated like k_finish_*); the refreshed constants

@@ -32,16 +32,23 @@ constexpr int ISL_SHARDS = 16, ISL_SHARD_STRIDE = 16;      // arrival counters o
 constexpr unsigned long long ISL_TIMEOUT = 1ull << 40;     // control-word bit: some workgroup gave up waiting and left its group uncommitted
 constexpr int ISL_WAIT_POLLS = 20000;               // bounded wait for the other workgroups' arrival (~1 us per poll); PHX_ISL_WAIT_POLLS overrides (tests)
 
+// IslandView::units
+__host__ __device__ inline int island_units_word(int units, int classes, int nstatic) { return units | (classes << 12) | (nstatic << 20); }
+__host__ __device__ inline int island_word_units(int w) { return w & 0xFFF; }
+__host__ __device__ inline int island_word_classes(int w) { return (w >> 12) & 0xFF; }
+__host__ __device__ inline int island_word_static(int w) { return (int)((unsigned)w >> 20); }
+
 constexpr int ISL_T = 256, ISL_B = 768;        // lanes = unit capacity of a group (joints: twice that); body capacity (dynamic + touched static)
 constexpr int ISL_T_BIG = 512, ISL_B_BIG = 1024;
 
 struct IslandView {
     const int4* desc;                 // per group {slot_begin, slot_count, body_begin, body_count}
     const int* ncol;                  // per group: classes
-    const int* units;                 // per group: units | static bodies of its table << 16 (they sit first in the table)
-    // per group g, unit u (class-major): two 16-byte words at [2 * (g * T + u)] = {leader joint, follower joint or -1, leader's contact
-    // point, follower's contact point}, {local body1 | local body2 << 16, class, -, -}: everything a lane needs to start its joint
-    // and contact-point loads after ONE round trip (round 2's chain was descriptor -> unit -> order -> joint -> contact point)
+    const int* units;                 // per group: island_units_word(units, classes, static bodies of its table — they sit first in the table)
+    // per group g and LANE l (schedule.h LANES): two 16-byte words at [2 * (g * T + l)] = {leader joint or -1 (nobody's lane), follower
+    // joint or -1, leader's contact point, follower's contact point}, {local body1 | local body2 << 16, class, leader slot, follower
+    // slot}: everything a lane needs to start its joint and contact-point loads after ONE round trip (round 2's chain was descriptor ->
+    // unit -> order -> joint -> contact point)
     const int4* unit_recs;
     const int* bodies;                // global body ids, group-local order, group g's table at [g * NB]
     int* executed;                    // per slot (group % ISL_STAT_SLOTS): [2 * slot] max impulse sweeps run by a group, [2 * slot + 1] displacement

@@ -55,6 +55,31 @@ __host__ __device__ inline unsigned long long colour_priority(unsigned id, unsig
 // or one kernel launch (HBM group) of every sweep, so the largest class count sets the solve time.
 constexpr int COLOUR_B_MAX_JOINTS = 1024;
 
+// LANES of an LDS group (execution only: no result depends on them).  The island kernel gives every unit of a group a lane for the
+// whole solve and sweeps class by class, so a class costs one pass of every WAVE it has a lane in — with four groups on a CU the
+// sweeps are bound by the waves' instruction issue, not by the chain of steps.  The classes' lane ranges are therefore placed so
+// that they straddle as few waves as the workgroup's lanes allow: in class order, a class that would straddle one wave more than
+// its size needs starts on the next wave boundary if the remaining classes still fit behind it, and a small class goes into the gap
+// such a move left.  (A stacked column of cfg 2: classes of 100, 96, 5 and 4 units = 2 + 2 + 1 + 1 wave passes per sweep instead
+// of the 2 + 3 + 1 + 1 of back-to-back ranges.)  A unit's lane = its class's first lane + its position among the class's leaders.
+// (`total` = the sum of units[]; at most one gap is kept: a later one replaces it)
+__host__ __device__ inline void layout_classes(const unsigned short* units, int ncol, int total, int T, unsigned short* begin)
+{
+    int remaining = total, cursor = 0, gap_at = 0, gap_n = 0;
+    for (int c = 0; c < ncol; ++c) {
+        const int n = units[c];
+        if (n <= gap_n) { begin[c] = (unsigned short)gap_at; gap_at += n; gap_n -= n; }      // a small class into the gap an aligned one left (inside one wave)
+        else {
+            int at = cursor;
+            const int aligned = (at + 63) & ~63;
+            if ((at & 63) + n > ((n + 63) & ~63) && aligned + remaining <= T) { gap_at = cursor; gap_n = aligned - cursor; at = aligned; }      // straddles one wave more than it has to, and there is room
+            begin[c] = (unsigned short)at;                                 // (cursor + remaining <= T holds throughout: the units fit the lanes)
+            cursor = at + n;
+        }
+        remaining -= n;
+    }
+}
+
 // BINNING.  Groups run in parallel workgroups and share nothing, so WHICH components share a group changes no result — only how
 // well the workgroups are filled.  Consecutive components (body order) are packed greedily into a bin until the next one would
 // overflow the workgroup shape's joints or units, and a bin never spans a multiple of BIN_CHUNK component numbers: that cuts the
@@ -136,6 +161,7 @@ struct Schedule {
     // units of the LDS groups, in class order: slots of a unit's leader and follower (-1: none); group g's units are
     // [group_unit_offsets[g], group_unit_offsets[g + 1])
     std::vector<int> group_unit_offsets, unit_leader, unit_follower;
+    std::vector<int> unit_lane;           // ... and the unit's lane in the island kernel (LANES above)
     // A schedule built on the device keeps the LDS groups' order / colours in HBM only; `lds_on_host` says whether
     // order[], colour_offsets[], group_first_colour[] above already cover the LDS groups (DeviceSolver::materialise).
     bool lds_on_host = true;

@@ -380,6 +380,7 @@ struct BinOut {
     std::vector<uint32_t> slot_local;
     std::vector<uint8_t> slot_colour;
     std::vector<int> unit_leader, unit_follower;   // per unit, in class order: its slots relative to the bin's first slot (follower: -1 if none)
+    std::vector<int> unit_lane;                    // per unit: its lane in the island kernel (schedule.h LANES)
     std::vector<int> bodies;              // local body table, static first
     bool rejected = false;                // does not fit the caps: its joints go to the HBM group
 };
@@ -484,8 +485,11 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
     out.colour_sizes.resize(ncol);
     for (int c = 0; c < ncol; ++c) out.colour_sizes[c] = begin[c + 1] - begin[c];
     out.order.resize(joints.size()); out.slot_local.resize(joints.size()); out.slot_colour.resize(joints.size());
-    out.unit_leader.resize(leaders.size()); out.unit_follower.resize(leaders.size());
+    out.unit_leader.resize(leaders.size()); out.unit_follower.resize(leaders.size()); out.unit_lane.resize(leaders.size());
     std::vector<int> cur_with(ncol, 0), cur_single(ncol, 0);
+    unsigned short units_c[64], lane_begin[64];
+    for (int c = 0; c < ncol; ++c) units_c[c] = (unsigned short)(with[c] + single[c]);
+    layout_classes(units_c, ncol, (int)leaders.size(), caps.max_units, lane_begin);
     for (size_t k = 0; k < leaders.size(); ++k) {
         const int c = colour[k], j = leaders[k];
         int at, unit;
@@ -502,6 +506,7 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
         }
         out.order[at] = j; out.slot_local[at] = local[k]; out.slot_colour[at] = (uint8_t)c;
         out.unit_leader[unit] = at;
+        out.unit_lane[unit] = lane_begin[c] + (unit - unit_begin[c]);
     }
 }
 
@@ -595,6 +600,7 @@ void build_island_schedule(const int* body1, const int* body2, int nj, const uns
             out.unit_leader.push_back(base + b.unit_leader[u]);
             out.unit_follower.push_back(b.unit_follower[u] < 0 ? -1 : base + b.unit_follower[u]);
         }
+        out.unit_lane.insert(out.unit_lane.end(), b.unit_lane.begin(), b.unit_lane.end());
         out.group_unit_offsets.push_back((int)out.unit_leader.size());
         int at = base;
         for (int n : b.colour_sizes) { at += n; out.colour_offsets.push_back(at); }

@@ -448,7 +448,7 @@ struct BinBuildView {
     int4* desc;                       // out: {slot_begin, slot_count, body_begin, body_count}
     int* ncol;                        // out: classes
     int* units;                       // out: units | static bodies of the bin's table << 16
-    int4* unit_recs;                  // out: two words per unit at [2 * (g * T + unit)], class-major (island_view.h): {leader joint, follower joint or -1,
+    int4* unit_recs;                  // out: two words per LANE at [2 * (g * T + lane)] (island_view.h; schedule.h LANES): {leader joint or -1: nobody's lane, follower joint or -1,
                                       //      leader's contact point, follower's}, {local body1 | local body2 << 16, class, leader slot, follower slot or -1}
     int* bodies;                      // out: body table of bin g at [g * NB, g * NB + body_count)
     const int* nbins_dev;             // (may be null) the bin count, if the launch grid is only an upper bound of it (speculative binning, solver.hip)
@@ -494,6 +494,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __shared__ unsigned scan_lds[LANES / 64];
     __shared__ unsigned with_n[64], single_n[64];        // per class: leaders that have a follower / single leaders
     __shared__ unsigned class_begin[64], unit_begin[64]; // per class: first slot (relative), first unit
+    __shared__ unsigned cls_span[64];                    // per class: its first lane in the island kernel | its units << 16 (schedule.h LANES)
     __shared__ unsigned short wave_with[(LANES / 64) * 64], wave_single[(LANES / 64) * 64];
     __shared__ int n_static, n_bodies, n_col, n_units, bad;
 
@@ -641,7 +642,25 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         for (int off = 1; off < 64; off <<= 1) { const unsigned ys = __shfl_up(xs, off), yu = __shfl_up(xu, off); if (lane >= off) { xs += ys; xu += yu; } }
         class_begin[tid] = xs - slots_c; unit_begin[tid] = xu - units_c;
         const unsigned long long nonempty = __ballot(units_c != 0);
-        if (tid == 0) n_col = nonempty ? 64 - __builtin_clzll(nonempty) : 0;
+        const int ncol_here = nonempty ? 64 - __builtin_clzll(nonempty) : 0;
+        if (tid == 0) n_col = ncol_here;
+        // the classes' lane ranges (schedule.h layout_classes, restated on the wave's scalar unit: lane c holds class c's count, the
+        // running state is wave-uniform)
+        int remaining = __builtin_amdgcn_readlane((int)xu, 63), cursor = 0, gap_at = 0, gap_n = 0, my_begin = 0;
+        for (int c = 0; c < ncol_here; ++c) {
+            const int n = __builtin_amdgcn_readlane((int)units_c, c);
+            int at;
+            if (n <= gap_n) { at = gap_at; gap_at += n; gap_n -= n; }
+            else {
+                at = cursor;
+                const int aligned = (at + 63) & ~63;
+                if ((at & 63) + n > ((n + 63) & ~63) && aligned + remaining <= T) { gap_at = cursor; gap_n = aligned - cursor; at = aligned; }
+                cursor = at + n;
+            }
+            if (lane == c) my_begin = at;
+            remaining -= n;
+        }
+        cls_span[tid] = (unsigned)my_begin | (units_c << 16);
     }
     __syncthreads();
     if (!fits || bad) { if (tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); } return; }
@@ -658,11 +677,16 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
             v.order[fslot] = mate; v.slot_local[fslot] = local; v.slot_colour[fslot] = (unsigned char)c;
         }
         // (a follower's contact point is its leader's + 1: the two ids of a unit differ in the lowest bit and the leader carries the even one)
-        const size_t at = 2 * ((size_t)g * T + unit_begin[c] + in_class);
+        const size_t at = 2 * ((size_t)g * T + (cls_span[c] & 0xFFFFu) + in_class);      // (its lane: schedule.h LANES)
         v.unit_recs[at] = make_int4(j, paired ? mate : -1, cpi, cpi ^ 1);
         v.unit_recs[at + 1] = make_int4((int)local, c, slot, fslot);
     }
-    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = n_units | (n_static << 16); }      // (static bodies sit first in the table: the island kernel checks exactly that)
+    if (tid < T) {                                       // the lanes no class covers are nobody's (gaps of the layout, the tail)
+        bool taken = false;
+        for (int c = 0; c < n_col; ++c) { const unsigned sp = cls_span[c]; taken |= (unsigned)(tid - (int)(sp & 0xFFFFu)) < (sp >> 16); }
+        if (!taken) v.unit_recs[2 * ((size_t)g * T + tid)] = make_int4(-1, -1, 0, 0);
+    }
+    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = island_units_word(n_units, n_col, n_static); }      // (static bodies sit first in the table: the island kernel checks exactly that)
 }
 
 // ---- the HBM group (islands too big for a workgroup, or everything in Single mode): the same colouring in HBM ----------

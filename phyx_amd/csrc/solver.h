@@ -175,6 +175,7 @@ private:
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
         bool no_incremental = false;      // PHX_NO_INCREMENTAL=1: every rebuild recomputes the connected components
+        bool force_big = false;           // PHX_ISL_SHAPE=big: the roomier workgroup shape whether or not a component needs it (measurements)
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
         int isl_wait_polls = 0;           // PHX_ISL_WAIT_POLLS
         static Options from_env();

@@ -131,7 +131,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
         caps.max_units = ISL_T; caps.max_joints = 2 * ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
         LdsCaps big;
         big.max_units = ISL_T_BIG; big.max_joints = 2 * ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
-        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, &big, prio_id.data());
+        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, opt_.force_big ? big : caps, sched_, &big, prio_id.data());
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_, prio_id.data());
     }
@@ -185,18 +185,19 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
         PHX_HIP(hipMemcpyAsync(isl_.slot_colour.p, sched_.slot_colour.data(), lds_slots, hipMemcpyHostToDevice, stream_));
         // the units, class-major, at a fixed stride of one workgroup's lanes per group
         std::vector<int> units(ng);
-        std::vector<int4> unit_recs(2 * (size_t)ng * lanes, make_int4(0, -1, 0, 0));
+        std::vector<int4> unit_recs(2 * (size_t)ng * lanes, make_int4(-1, -1, 0, 0));      // (leader -1: nobody's lane)
         for (int g = 0; g < ng; ++g) {
             const int nunits = sched_.group_unit_offsets[g + 1] - sched_.group_unit_offsets[g];
             int nstatic_g = 0;                                   // (the group's static bodies sit first in its table)
             for (int k = sched_.group_body_offsets[g]; k < sched_.group_body_offsets[g + 1] && is_static[sched_.group_bodies[k]]; ++k) ++nstatic_g;
-            units[g] = nunits | (nstatic_g << 16);
+            units[g] = island_units_word(nunits, ncol[g], nstatic_g);
             for (int u = 0; u < nunits; ++u) {
                 const int at = sched_.group_unit_offsets[g] + u;
                 const int ls = sched_.unit_leader[at], fs = sched_.unit_follower[at];
                 const int lj = sched_.order[ls], fj = fs >= 0 ? sched_.order[fs] : -1;
-                unit_recs[2 * ((size_t)g * lanes + u)] = make_int4(lj, fj, prio_id[lj], fj >= 0 ? prio_id[fj] : 0);
-                unit_recs[2 * ((size_t)g * lanes + u) + 1] = make_int4((int)sched_.slot_local[ls], (int)sched_.slot_colour[ls], ls, fs);
+                const size_t lane = (size_t)g * lanes + sched_.unit_lane[at];      // (schedule.h LANES)
+                unit_recs[2 * lane] = make_int4(lj, fj, prio_id[lj], fj >= 0 ? prio_id[fj] : 0);
+                unit_recs[2 * lane + 1] = make_int4((int)sched_.slot_local[ls], (int)sched_.slot_colour[ls], ls, fs);
             }
         }
         PHX_TRY(isl_.units.reserve(ng)); PHX_TRY(isl_.unit_recs.reserve(unit_recs.size()));
@@ -327,6 +328,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     int cap_units = ISL_T, cap_bodies = ISL_B;
     auto fits = [&](int c, int units) { return (int)comp_size[c] <= 2 * units && (int)comp_units[c] <= units; };
     for (int c = 0; c < ncomp; ++c) if (comp_size[c] && !fits(c, ISL_T) && fits(c, ISL_T_BIG)) { cap_units = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
+    if (opt_.force_big) { cap_units = ISL_T_BIG; cap_bodies = ISL_B_BIG; }
     sc.lds_lanes = cap_units;
     std::vector<int> bin_of(std::max(ncomp, 1), -1), rank_of(std::max(ncomp, 1), 0);     // rank of a component inside its bin (schedule.h: the colouring candidate is chosen per component)
     {

@@ -1,0 +1,21 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r5s; rm -rf $O; mkdir -p $O
+export PYTHONUNBUFFERED=1
+cd /tmp && export TMPDIR=/tmp
+for V in base new; do
+  if [ $V = base ]; then D=$R/_base; else D=$R; fi
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o w_$V -- python $D/tools/world_quick.py 12 > $O/wq_$V.txt 2> $O/w_$V.err
+  echo "== $V"; head -1 $O/wq_$V.txt
+  python - <<P
+import csv
+rows=list(csv.DictReader(open('$O/w_${V}_kernel_stats.csv')))
+for r in rows:
+    if any(k in r['Name'] for k in ('k_build_bin','k_solve_islands','k_bin_components')):
+        print('%-50s calls %5s avg %8.1f us' % (r['Name'][:50], r['Calls'], float(r['AverageNs'])/1e3))
+P
+done
+cd $R/_base; timeout 300 python tools/world_quick.py 30 | head -1
+cd $R; timeout 300 python tools/world_quick.py 30 | head -1
+cd $R/_base; timeout 300 python tools/world_quick.py 30 | head -1
+cd $R; timeout 300 python tools/world_quick.py 30 | head -1
