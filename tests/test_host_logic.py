@@ -362,3 +362,79 @@ def test_binning_by_chunks_equals_the_greedy_loop():
     # the price of the chunk boundaries: the 1e4 columns of the 1M-box world (206-joint components, two to a bin)
     sizes, units = [206] * 10000, [103] * 10000
     assert len(_greedy_bins(sizes, units, 256)[2]) - 1 == 5000
+
+
+def _layout_classes(units, T):
+    """csrc/schedule.h layout_classes, restated: classes in order; one that would straddle a wave more than its size needs starts on
+    the next wave boundary if everything behind it still fits; a small class goes into the gap such a move left."""
+    remaining, cursor, gap_at, gap_n, begin = sum(units), 0, 0, 0, []
+    for n in units:
+        if n <= gap_n:
+            begin.append(gap_at); gap_at += n; gap_n -= n
+        else:
+            at = cursor
+            aligned = (at + 63) & ~63
+            if (at & 63) + n > ((n + 63) & ~63) and aligned + remaining <= T:
+                gap_at, gap_n, at = cursor, aligned - cursor, aligned
+            begin.append(at); cursor = at + n
+        remaining -= n
+    return begin
+
+
+def _wave_passes(begin, units):
+    return sum((b + n - 1) // 64 - b // 64 + 1 for b, n in zip(begin, units) if n)
+
+
+@pytest.mark.parametrize("name,lanes,body_cap", [("stack10x100", 256, 768), ("stack2x10", 256, 768), ("falling600", 256, 768), ("stack3x500", 512, 1024)])
+def test_island_groups_and_their_lanes(built_lib, name, lanes, body_cap):
+    """phx_schedule_groups (host-only): the island-mode schedule as workgroup-sized groups — groups are body-disjoint and respect the
+    caps, every group's classes are body-disjoint sets of units in the layout of a class, and the LANES the island kernel gives the
+    units (csrc/schedule.h LANES, restated above): one lane per unit, a class's units on consecutive lanes in slot order, the classes'
+    ranges where layout_classes puts them — never more wave passes per sweep than back-to-back ranges, and 6 instead of 7 for the
+    200-box column of BASELINE config 2."""
+    if name == "stack3x500":
+        bodies, _, joints = presolve_state(scenes.stack(3, 500), 3, iters=30)
+    else:
+        make, warm = SMALL_SCENES[name]
+        bodies, _, joints = presolve_state(make(), warm)
+    static = is_static(bodies)
+    nj = len(joints)
+    b1, b2 = joints["body1"], joints["body2"]
+    r = phyx_amd.schedule_groups(b1, b2, static, joints["contact_point_index"], lanes=lanes, body_cap=body_cap)
+    order, offs, goff, gfc, lg = r["order"], r["colour_offsets"], r["group_offsets"], r["group_first_colour"], r["lds_groups"]
+    assert sorted(order.tolist()) == list(range(nj)) and offs[0] == 0 and offs[-1] == nj and goff[0] == 0 and goff[-1] == nj
+    assert lg >= 1 and len(goff) in (lg + 1, lg + 2)
+    owner = {}
+    lane_of = dict(zip(r["unit_leader_slot"].tolist(), r["unit_lane"].tolist()))
+    seen_units = 0
+    for g in range(lg):
+        slots = range(goff[g], goff[g + 1])
+        touched = set()
+        for s in slots:
+            for body in (int(b1[order[s]]), int(b2[order[s]])):
+                touched.add(body)
+                if not static[body]:
+                    assert owner.setdefault(body, g) == g, "a dynamic body in two groups"
+        assert len(slots) <= 2 * lanes and len(touched) <= body_cap
+        units, lanes_of_class = [], []
+        for c in range(gfc[g], gfc[g + 1]):
+            sl = list(range(offs[c], offs[c + 1]))
+            leaders = [s for s in sl if s in lane_of]
+            assert leaders == sl[:len(leaders)] and len(leaders) >= len(sl) - len(leaders)      # leaders first, then the followers
+            dyn = [b for s in leaders for b in (int(b1[order[s]]), int(b2[order[s]])) if not static[b]]
+            assert len(dyn) == len(set(dyn)), "two units of a class share a dynamic body"
+            units.append(len(leaders))
+            lanes_of_class.append([lane_of[s] for s in leaders])
+        seen_units += sum(units)
+        begin = _layout_classes(units, lanes)
+        flat = [l for ls in lanes_of_class for l in ls]
+        assert len(set(flat)) == len(flat) and max(flat) < lanes and sum(units) <= lanes
+        for b, ls in zip(begin, lanes_of_class):
+            assert ls == list(range(b, b + len(ls)))
+        plain = [sum(units[:c]) for c in range(len(units))]
+        assert _wave_passes(begin, units) <= _wave_passes(plain, units)
+    assert seen_units == len(lane_of)
+    assert _layout_classes([100, 96, 5, 4], 256) == [0, 128, 100, 105]
+    assert _wave_passes([0, 128, 100, 105], [100, 96, 5, 4]) == 6 and _wave_passes([0, 100, 196, 201], [100, 96, 5, 4]) == 7
+    assert _layout_classes([250, 246, 8, 6], 512) == [0, 250, 496, 504]                      # (a 500-box column fills its 512 lanes: nothing to move)
+    assert _layout_classes([250, 240, 8, 6], 512) == [0, 256, 496, 250]                      # (the gap of 6 lanes takes the class that fits it)
