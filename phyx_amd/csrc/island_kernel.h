@@ -4,6 +4,8 @@
 
 #include "solver_kernels.h"
 
+#include <type_traits>
+
 namespace phx {
 
 // ---- island kernel: one workgroup solves one GROUP of the schedule entirely out of LDS -----------------
@@ -20,15 +22,6 @@ namespace phx {
 // phase stamps of the island kernel (tools/island_trace.py; the constant 100 MHz clock all XCDs share): 0 start, 1 records loaded, 2 refreshed, 3 pre-stepped, 4 swept,
 // 5 written back; word 6 = XCC id | s_memtime ticks of the whole workgroup << 4, word 7 = classes << 32 | impulse sweeps executed
 #define PHX_ISL_STAMP(k) do { if (TRACE && threadIdx.x == 0) iv.trace[(size_t)group * 8 + (k)] = wall_clock64(); } while (0)
-
-template <int B>
-__device__ __forceinline__ bool static_productive_lds(const unsigned (*sw)[B], int body, int iter, int colour)
-{
-    if (iter == 0) return true;
-    if ((sw[(iter - 1) & 1][body] >> 16) == (unsigned)iter) return true;
-    const unsigned cur = sw[iter & 1][body];
-    return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
-}
 
 // ---- body-state storage of the island kernel: fp32 (default) or the fp16 ablation ------------------------------
 template <bool HALF> struct BodyStore { using type = float4; };
@@ -115,30 +108,10 @@ __device__ __forceinline__ bool isl_impulse_eval(IslJoint& q, float4& B1, float4
     return max_ref(fabsf(dn), fabsf(df)) > 1e-4f;
 }
 
-// one impulse visit (ref: Solver.cpp:790-896); returns whether the joint was evaluated (not skipped), `productive` whether it moved.
-// sp1 / sp2: 'the static body was productive' (static_productive_lds) — the same for both joints of a unit: a class step
-// cannot change what it returns for that class (tags raised in it carry the class itself, which is not 'earlier').
-__device__ __forceinline__ bool isl_impulse(IslJoint& q, float4& B1, float4& B2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
-                                            bool sp1, bool sp2, int it, bool& productive)
+// the arithmetic of one displacement visit (ref: Solver.cpp:960-1005) on the two bodies' displacing velocities held in registers;
+// returns whether the joint moved.  The skip test and the tags are the caller's.
+__device__ __forceinline__ bool isl_displace_eval(IslJoint& q, float4& D1, float4& D2, float im1, float ii1, float im2, float ii2)
 {
-    const bool p1 = st1 ? sp1 : (__float_as_int(B1.w) > it - 2);
-    const bool p2 = st2 ? sp2 : (__float_as_int(B2.w) > it - 2);
-    productive = false;
-    if (!(p1 || p2)) return false;        // (a 'likely' hint on the evaluated path was measured 2 % slower)
-    productive = isl_impulse_eval(q, B1, B2, im1, ii1, im2, ii2);
-    // (the tags by select, not under a branch: an exec-mask region — save, two moves, restore — per joint was 1.3 % of the launch)
-    B1.w = productive ? __int_as_float(it) : B1.w; B2.w = productive ? __int_as_float(it) : B2.w;
-    return true;
-}
-
-// one displacement visit (ref: Solver.cpp:960-1005)
-__device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2, float im1, float ii1, float im2, float ii2, bool st1, bool st2,
-                                             bool sp1, bool sp2, int it, bool& productive)
-{
-    const bool p1 = st1 ? sp1 : (__float_as_int(D1.w) > it - 2);
-    const bool p2 = st2 ? sp2 : (__float_as_int(D2.w) > it - 2);
-    productive = false;
-    if (!(p1 || p2)) return false;
     const float nx = q.nx, ny = q.ny;
     float dv = q.dstD;
     dv = mul_sub(nx, D1.x, dv); dv = mul_sub(ny, D1.y, dv); dv = mul_sub(q.aN1, D1.z, dv);
@@ -148,9 +121,7 @@ __device__ __forceinline__ bool isl_displace(IslJoint& q, float4& D1, float4& D2
     D1.x = mul_add(nx * im1, di, D1.x); D1.y = mul_add(ny * im1, di, D1.y); D1.z = mul_add(q.aN1 * ii1, di, D1.z);
     D2.x = mul_add((-nx) * im2, di, D2.x); D2.y = mul_add((-ny) * im2, di, D2.y); D2.z = mul_add(q.aN2 * ii2, di, D2.z);
     q.accD += di;
-    productive = fabsf(di) > 1e-4f;
-    D1.w = productive ? __int_as_float(it) : D1.w; D2.w = productive ? __int_as_float(it) : D2.w;
-    return true;
+    return fabsf(di) > 1e-4f;
 }
 
 template <int T, int NB, bool HALF, bool TRACE = false>
@@ -328,73 +299,31 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
             tw_bar += ts2 - ts1;
         } else { tw_idle += ts2 - ts0; ++tw_nidle; }
     };
-    // THE GENERAL FORM of a class step — one unit, one sweep half: `s1` / `s2` = the unit's bodies are static.  Called twice below: with the lane's real
-    // flags, and — for a wave none of whose units touches a static body, i.e. almost every wave — with constants,
-    // which folds the tag lookups, the restore copies, their selects and a dozen exec-mask branches away.
-    auto imp_step = [&](const bool s1, const bool s2, const bool two) {
-        float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
-        bool prod0 = false, prod1 = false;
-        const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-        const bool sp1 = s1 && static_productive_lds(swi, l1, it, c), sp2 = s2 && static_productive_lds(swi, l2, it, c);
-        bool touched = isl_impulse(q0, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
-        if (two) {
-            if (HALF && touched) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
-            if (s1) B1 = S1;
-            if (s2) B2 = S2;
-            touched |= isl_impulse(q1, B1, B2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
-        }
-        if (prod0 || prod1) {
-            flag_imp[slot] = 1;
-            if (s1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-            if (s2) atomicMax(&swi[it & 1][l2], static_word(it, c));
-        }
-        if (touched) {
-            if (!s1) body_store(imp, l1, B1);
-            if (!s2) body_store(imp, l2, B2);
-        }
-    };
-    auto disp_step = [&](const bool s1, const bool s2, const bool two) {
-        float4 D1 = body_load(disp, l1), D2 = body_load(disp, l2);
-        bool prod0 = false, prod1 = false;
-        const float4 S1 = D1, S2 = D2;
-        const bool sp1 = s1 && static_productive_lds(swd, l1, it, c), sp2 = s2 && static_productive_lds(swd, l2, it, c);
-        bool touched = isl_displace(q0, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod0);
-        if (two) {
-            if (HALF && touched) { D1 = body_round<HALF>(D1); D2 = body_round<HALF>(D2); }
-            if (s1) D1 = S1;
-            if (s2) D2 = S2;
-            touched |= isl_displace(q1, D1, D2, im1, ii1, im2, ii2, s1, s2, sp1, sp2, it, prod1);
-        }
-        if (prod0 || prod1) {
-            flag_disp[slot] = 1;
-            if (s1) atomicMax(&swd[it & 1][l1], static_word(it, c));
-            if (s2) atomicMax(&swd[it & 1][l2], static_word(it, c));
-        }
-        if (touched) {
-            if (!s1) body_store(disp, l1, D1);
-            if (!s2) body_store(disp, l2, D2);
-        }
-    };
-    // THE HOT FORM of a class step: impulses only (the displacement sweeps of a resting scene end after the first: nothing is
-    // deeper than the allowed penetration, ref: Solver.cpp:672-680, 210).  One skip test per unit — the follower's test equals
-    // its leader's: a skipped leader changes no tag, and an evaluated one either leaves the tags as they were or raises
-    // them to `it` — and one tag update; straight-line but for the follower's mask: a class step is one wave's instruction
-    // stream, and every taken branch in it is ~20 cycles.  `ws` = some unit of the wave touches a static body (wave-uniform):
-    // only then the static tags are looked up and raised, the static records restored between the joints and left unstored —
-    // same results as imp_step (the general form keeps the first sweep, where the displacement half runs too).
-    auto imp_fast = [&](const bool ws) {
-        float4 B1 = body_load(imp, l1), B2 = body_load(imp, l2);
+    // A CLASS STEP of one sweep half (IMP: the impulses on the velocities, ref: Solver.cpp:790-896; else the displacement on the displacing
+    // velocities, ref: Solver.cpp:960-1005) for the lane's unit: both body records in one LDS round trip, ONE skip test per unit — the
+    // follower's test equals its leader's: a skipped leader changes no tag, and an evaluated one either leaves the tags as they were or
+    // raises them to `it` — and one tag update; straight-line but for the follower's mask: a class step is one wave's instruction
+    // stream, and every taken branch in it is ~20 cycles.  `ws` = some unit of the wave touches a static body (wave-uniform, fixed for
+    // the solve): only then the static tags are looked up and raised (they are class-synchronous: solver_kernels.h), the static records
+    // restored between the joints (a static body's record is never stored: the follower must see it untouched) and left unstored.
+    // (Rounds 2-4 had a general form beside this one — a skip test and a tag update per joint, two dependent LDS round trips — which
+    //  every first sweep still took: same results, ~2.5 x the cycles.)
+    auto half_step = [&](auto IMPC, const bool ws) {
+        constexpr bool IMP = decltype(IMPC)::value;
+        BodyT* const rec = IMP ? imp : disp;
+        unsigned (*const sw)[NB] = IMP ? swi : swd;
+        float4 B1 = body_load(rec, l1), B2 = body_load(rec, l2);
         // (`ws`: the static tags' words travel with the body records — every lane of the wave reads them, a dynamic body's
-        //  are zero — instead of two more dependent LDS round trips for the one lane that needs them: static_productive_lds)
+        //  are zero — instead of two more dependent LDS round trips for the one lane that needs them)
         unsigned pw1 = 0u, cw1 = 0u, pw2 = 0u, cw2 = 0u;
-        if (ws) { pw1 = swi[(it - 1) & 1][l1]; cw1 = swi[it & 1][l1]; pw2 = swi[(it - 1) & 1][l2]; cw2 = swi[it & 1][l2]; }
+        if (ws) { pw1 = sw[(it - 1) & 1][l1]; cw1 = sw[it & 1][l1]; pw2 = sw[(it - 1) & 1][l2]; cw2 = sw[it & 1][l2]; }
         // (everything in ONE LDS round trip: left alone, the compiler reads the two tags, tests, and only then — under the
         //  branch — the six velocity words: two dependent round trips on the critical path of every class step)
         if (!HALF) asm volatile("" : "+v"(B1.x), "+v"(B1.y), "+v"(B1.z), "+v"(B1.w), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(B2.w));
         if (ws) asm volatile("" : "+v"(pw1), "+v"(cw1), "+v"(pw2), "+v"(cw2));
         bool active = max(__float_as_int(B1.w), __float_as_int(B2.w)) > it - 2;
         if (ws) {
-            // static_productive_lds on the words already here — every lane evaluates both bodies' tests and selects (no
+            // solver_kernels.h static_productive on the words already here — every lane evaluates both bodies' tests and selects (no
             // short-circuit: as `st1 && sp(..)` this was four exec-mask regions in the one wave whose step everybody waits for)
             const unsigned itu = (unsigned)it, clu = (unsigned)c;
             auto sp = [&](unsigned pw, unsigned cw) {
@@ -405,31 +334,33 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
             active = ((a1 | a2) & 1) != 0;
         }
         if (active) {
-            const float4 S1 = B1, S2 = B2;         // a static body's record is never stored: the follower must see it untouched
-            bool prod = isl_impulse_eval(q0, B1, B2, im1, ii1, im2, ii2);
+            const float4 S1 = B1, S2 = B2;
+            bool prod = IMP ? isl_impulse_eval(q0, B1, B2, im1, ii1, im2, ii2) : isl_displace_eval(q0, B1, B2, im1, ii1, im2, ii2);
             if (has2) {
-                if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }
+                if (HALF) { B1 = body_round<HALF>(B1); B2 = body_round<HALF>(B2); }      // (the ablation rounds on every joint's store)
                 if (ws) {
                     B1.x = sm1 ? S1.x : B1.x; B1.y = sm1 ? S1.y : B1.y; B1.z = sm1 ? S1.z : B1.z; B1.w = sm1 ? S1.w : B1.w;
                     B2.x = sm2 ? S2.x : B2.x; B2.y = sm2 ? S2.y : B2.y; B2.z = sm2 ? S2.z : B2.z; B2.w = sm2 ? S2.w : B2.w;
                 }
-                prod |= isl_impulse_eval(q1, B1, B2, im1, ii1, im2, ii2);
+                prod |= IMP ? isl_impulse_eval(q1, B1, B2, im1, ii1, im2, ii2) : isl_displace_eval(q1, B1, B2, im1, ii1, im2, ii2);
             }
             B1.w = prod ? __int_as_float(it) : B1.w; B2.w = prod ? __int_as_float(it) : B2.w;
             if (prod) {
-                flag_imp[slot] = 1;
+                if (IMP) flag_imp[slot] = 1; else flag_disp[slot] = 1;
                 if (ws) {
-                    if (st1) atomicMax(&swi[it & 1][l1], static_word(it, c));
-                    if (st2) atomicMax(&swi[it & 1][l2], static_word(it, c));
+                    if (st1) atomicMax(&sw[it & 1][l1], static_word(it, c));
+                    if (st2) atomicMax(&sw[it & 1][l2], static_word(it, c));
                 }
             }
-            if (!ws || !st1) body_store(imp, l1, B1);
-            if (!ws || !st2) body_store(imp, l2, B2);
+            if (!ws || !st1) body_store(rec, l1, B1);
+            if (!ws || !st2) body_store(rec, l2, B2);
         }
     };
-    // The sweeps, in two loops: the general form while the displacement half still runs, then the hot form alone — once over, the
-    // displacement sweeps stay over (disp_alive only falls, `it` only grows).  (One loop with both forms in it cost the hot form a
-    // dozen register copies per class step: the accumulators' values flowed through every form's exits.)
+    const std::true_type IMPULSES{}; const std::false_type DISPLACEMENT{};
+    // The sweeps, in two loops: both halves while the displacement half still runs (the displacement sweeps of a resting scene end
+    // after the first: nothing is deeper than the allowed penetration, ref: Solver.cpp:672-680, 210), then the impulses alone — once
+    // over, the displacement sweeps stay over (disp_alive only falls, `it` only grows).  (One loop for both cost the impulse-only step
+    // a dozen register copies: the displacement accumulators' values flowed through its exits.)
     bool hot_from_here = false;
     for (; it < iters; ++it) {
         const bool imp_on = imp_alive && it < ci, disp_on = disp_alive && it < pi;
@@ -441,11 +372,11 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
             step_begin();
             if (col == c) {
                 if (wave_static) {
-                    if (imp_on) imp_step(st1, st2, has2);
-                    if (disp_on) disp_step(st1, st2, has2);
+                    if (imp_on) half_step(IMPULSES, true);
+                    if (disp_on) half_step(DISPLACEMENT, true);
                 } else {
-                    if (imp_on) imp_step(false, false, has2);
-                    if (disp_on) disp_step(false, false, has2);
+                    if (imp_on) half_step(IMPULSES, false);
+                    if (disp_on) half_step(DISPLACEMENT, false);
                 }
             }
             step_work_done();
@@ -461,7 +392,7 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
             next_slot();
             for (c = 0; c < ncol; ++c) {
                 step_begin();
-                if (col == c) { if (wave_static) imp_fast(true); else imp_fast(false); }
+                if (col == c) { if (wave_static) half_step(IMPULSES, true); else half_step(IMPULSES, false); }
                 step_work_done();
                 __syncthreads();
                 step_end();
