@@ -51,7 +51,12 @@ BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visi
 # Round 5 (profiles/r05_sq_islands.json): 164 VALU instructions per group and class step, all four waves and the first sweep's
 # displacement half included; the working wave of an impulse-only step issues ~112 of them.
 COLOUR_STEP_CHAIN_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
-COLOUR_STEP_VALU_INSTRUCTIONS = 112          # round 5: the hot form of a class step in fused arithmetic (island_kernel.h imp_fast): ~105 VALU + moves
+COLOUR_STEP_VALU_INSTRUCTIONS = 105          # round 5: a class step of the impulse half in fused arithmetic (island_kernel.h half_step)
+# ... and what bounds the sweeps with four groups on every CU (round 5, tools/probe/twin_units.diff.txt): not the chain of steps but the
+# SIMDs' instruction issue — a class costs one pass (~COLOUR_STEP_VALU_INSTRUCTIONS wave64 instructions at one per ~4.5 cycles) of every
+# WAVE it has a lane in, whatever the number of lanes at work
+ISSUE_CYCLES_PER_INSTRUCTION = 4.5
+SIMDS = 1024
 COLOUR_STEP_FLOOR_CYCLES = 64 + COLOUR_STEP_VALU_INSTRUCTIONS * 4 + 13 + 128
 
 
@@ -366,8 +371,26 @@ def run_bench(args, pdist):
                      "floor_cycles_per_colour_step": COLOUR_STEP_FLOOR_CYCLES,
                      "floor_what": "class step of the one working wave: LDS read 64 + %d VALU instructions x 4 cycles of issue (measured: one wave64 issues an "
                                    "instruction per ~4 cycles dependent or not, profiles/r04_unit_issue_probe.txt; instructions of the hot form of a class step, "
-                                   "island_kernel.h imp_fast; all waves, all sweeps: 164 per group and class step, profiles/r05_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
+                                   "island_kernel.h half_step; SQ counters of the whole launch: profiles/r05_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
                      "dependent_chain_floor_cycles_round3": COLOUR_STEP_CHAIN_FLOOR_CYCLES}
+            try:
+                # wave passes per sweep over all groups, from the host-side statement of the same schedule (phx_schedule_groups: classes
+                # and lanes are a pure function of the joints; the device builder is tested equal to it)
+                hs = phyx_amd.schedule_groups(joints["body1"], joints["body2"], ((bodies["inv_mass"] == 0) & (bodies["inv_inertia"] == 0)).astype(np.uint8),
+                                              joints["contact_point_index"])
+                cls_of_slot = np.searchsorted(hs["colour_offsets"], hs["unit_leader_slot"], side="right") - 1
+                grp_of_slot = np.searchsorted(hs["group_offsets"], hs["unit_leader_slot"], side="right") - 1
+                waves = np.unique(np.stack([grp_of_slot, cls_of_slot, hs["unit_lane"] // 64], axis=1), axis=0)
+                passes = int(len(waves))
+                floor_us = passes * COLOUR_STEP_VALU_INSTRUCTIONS * ISSUE_CYCLES_PER_INSTRUCTION / SIMDS / SHADER_CLOCK_HZ * 1e6
+                model["issue_model"] = {"wave_passes_per_sweep_all_groups": passes, "groups": int(hs["lds_groups"]),
+                                        "wave_passes_per_sweep_of_a_group": passes / max(int(hs["lds_groups"]), 1),
+                                        "valu_instructions_per_pass": COLOUR_STEP_VALU_INSTRUCTIONS, "cycles_per_issue": ISSUE_CYCLES_PER_INSTRUCTION, "simds": SIMDS,
+                                        "issue_floor_us_per_sweep": floor_us, "issue_floor_us_all_sweeps": floor_us * st.impulse_iterations,
+                                        "what": "every class is one pass of each wave it has a lane in: passes x instructions x cycles per issue, spread over the "
+                                                "chip's SIMDs at the guide's clock — the sweeps' floor when every CU holds four groups"}
+            except Exception as e:      # (a diagnostic: never the reason a bench line is missing)
+                model["issue_model"] = {"error": str(e)}
             if phases:
                 sweep_us = max(launch_us - phases["setup_prestep_writeback_us"], 0.0)
                 cyc0 = sweep_us * 1e-6 * SHADER_CLOCK_HZ / max(ncol_max * st.impulse_iterations, 1)
