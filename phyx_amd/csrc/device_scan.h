@@ -3,6 +3,9 @@
 
 #include "common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace phx {
 
 // ---- exclusive prefix sum over `count` words, in place ---------------------------------------------------
@@ -37,6 +40,9 @@ __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsign
 // would otherwise run in front of the scan as a dispatch of its own (3-5 us each at the dispatch floor).
 struct ScanInPlace { static constexpr bool in_place = true; __device__ unsigned operator()(int) const { return 0u; } };
 
+template <typename Load, typename = void> struct scan_has_load4 : std::false_type {};
+template <typename Load> struct scan_has_load4<Load, std::void_t<decltype(std::declval<const Load&>().load4(0, std::declval<uint4&>()))>> : std::true_type {};
+
 template <typename Load>
 __device__ __forceinline__ uint4 scan_load4(const Load& load, const unsigned* __restrict__ data, int base, int count)
 {
@@ -50,6 +56,9 @@ __device__ __forceinline__ uint4 scan_load4(const Load& load, const unsigned* __
             if (base + 3 < count) v.w = data[base + 3];
         }
     } else {
+        // (a loader may offer `bool load4(int base, uint4& out) const`: words base .. base + 3 in one go — 16-byte loads of what it
+        //  reads instead of four 4-byte ones — returning false where it cannot: a ragged end, an unaligned array)
+        if constexpr (scan_has_load4<Load>::value) { if (base + 3 < count && load.load4(base, v)) return v; }
         if (base < count) v.x = load(base);
         if (base + 1 < count) v.y = load(base + 1);
         if (base + 2 < count) v.z = load(base + 2);

@@ -80,7 +80,8 @@ __host__ __device__ inline void layout_classes(const unsigned short* units, int 
     }
 }
 
-// BINNING.  Groups run in parallel workgroups and share nothing, so WHICH components share a group changes no result — only how
+// BINNING.  Groups run in parallel workgroups and share nothing but their private copies of the static bodies' tags (a group's components
+// share ITS copy: solver_kernels.h), so WHICH components share a group changes no result beyond that skip rule — only how
 // well the workgroups are filled.  Consecutive components (body order) are packed greedily into a bin until the next one would
 // overflow the workgroup shape's joints or units, and a bin never spans a multiple of BIN_CHUNK component numbers: that cuts the
 // chain 'a bin ends where the next component would overflow it' into independent pieces, which is what lets the device make the

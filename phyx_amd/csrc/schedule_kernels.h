@@ -142,6 +142,15 @@ struct RootFlagLoad {
         comp_size[i] = 0u; comp_units[i] = 0u;
         return (i < nb && parent[i] == i) ? 1u : 0u;
     }
+    __device__ bool load4(int base, uint4& out) const      // (base is a multiple of four: device_scan.h)
+    {
+        if (base + 3 >= nb || ((reinterpret_cast<uintptr_t>(parent) | reinterpret_cast<uintptr_t>(comp_size) | reinterpret_cast<uintptr_t>(comp_units)) & 15u)) return false;
+        *reinterpret_cast<uint4*>(comp_size + base) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(comp_units + base) = make_uint4(0u, 0u, 0u, 0u);
+        const int4 p = *reinterpret_cast<const int4*>(parent + base);
+        out = make_uint4(p.x == base ? 1u : 0u, p.y == base + 1 ? 1u : 0u, p.z == base + 2 ? 1u : 0u, p.w == base + 3 ? 1u : 0u);
+        return true;
+    }
 };
 
 // joint -> component number (-1 if both bodies are static), and joints and units (schedule.h) per component.

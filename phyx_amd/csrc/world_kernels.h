@@ -266,6 +266,14 @@ struct JointDeadLoad {
         }
         return dead ? 1u : 0u;
     }
+    __device__ bool load4(int base, uint4& out) const      // (base is a multiple of four: device_scan.h; a dead joint is the rare case)
+    {
+        if (reinterpret_cast<uintptr_t>(seen) & 15u) return false;
+        const uint4 s = *reinterpret_cast<const uint4*>(seen + base);
+        if (s.x == epoch && s.y == epoch && s.z == epoch && s.w == epoch) { out = make_uint4(0u, 0u, 0u, 0u); return true; }
+        out = make_uint4((*this)(base), (*this)(base + 1), (*this)(base + 2), (*this)(base + 3));
+        return true;
+    }
 };
 
 // Match, pass 2: new joints appended in manifold order, then point order (ref: World.cpp:108-114)
