@@ -267,6 +267,10 @@ int phx_solver_get_groups(phx_solver* s, int32_t* group_offsets, int32_t offsets
  * block, `parts` of them over both levels; 0 when the schedule has no such component or PHX_NO_PARTS=1).  `sweep_launches`:
  * kernel launches of the last solve's sweeps. */
 int phx_solver_get_partition(phx_solver* s, int32_t* interior_classes, int32_t* parts, int32_t* sweep_launches);
+/* The lanes the island kernel gave the units of the last solve's LDS groups (execution detail, for tests and diagnostics: the classes'
+ * lane ranges are placed on wave boundaries where the lanes allow it, see phx_schedule_groups): per unit the slot of its leader in
+ * phx_solver_get_schedule's order and its lane inside its group's workgroup; *count = units (pass NULL arrays to ask for it). */
+int phx_solver_get_lanes(phx_solver* s, int32_t* leader_slot, int32_t* lane, int32_t cap, int32_t* count);
 
 /* RefreshJoints output for joint `joint_index` of the last solve (ref: Solver.cpp:592-695), expanded
  * to the reference's 30-float ContactJointPacked<1> order: normal limiter 13, 0, dstVelocity,

@@ -106,6 +106,7 @@ _SIGNATURES = {
     "phx_solver_get_schedule": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_get_groups": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "phx_solver_get_partition": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "phx_solver_get_lanes": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_solver_get_refreshed": (C.c_int, [_vp, _i32, _vp]),
     "phx_solver_bench": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, C.POINTER(BenchResult)]),
     "phx_solver_bench_stage": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32]),

@@ -351,6 +351,14 @@ class Solver:
         check(self.L.phx_solver_get_groups(self.h, _ptr(offs), len(offs), C.byref(n), C.byref(lds)))
         return offs, lds.value
 
+    def lanes(self):
+        """(leader_slot, lane) per unit of the last solve's LDS groups (phx_solver_get_lanes)."""
+        n = C.c_int32(0)
+        check(self.L.phx_solver_get_lanes(self.h, None, None, 0, C.byref(n)))
+        slot = np.zeros(max(n.value, 1), dtype=np.int32); lane = np.zeros(max(n.value, 1), dtype=np.int32)
+        check(self.L.phx_solver_get_lanes(self.h, _ptr(slot), _ptr(lane), len(slot), C.byref(n)))
+        return slot[:n.value], lane[:n.value]
+
     def partition(self):
         """(interior_classes, parts, sweep_launches) of the last solve: the partitioned-component path (phx_solver_get_partition)."""
         ki, parts, launches = C.c_int32(0), C.c_int32(0), C.c_int32(0)

@@ -131,6 +131,12 @@ int phx_solver_get_groups(phx_solver* s, int32_t* offsets, int32_t cap, int32_t*
     return s->impl.get_groups(offsets, cap, count, lds_count);
 }
 
+int phx_solver_get_lanes(phx_solver* s, int32_t* leader_slot, int32_t* lane, int32_t cap, int32_t* count)
+{
+    PHX_REQUIRE(s, "null handle");
+    return s->impl.get_lanes(leader_slot, lane, cap, count);
+}
+
 int phx_solver_get_partition(phx_solver* s, int32_t* interior_classes, int32_t* parts, int32_t* sweep_launches)
 {
     PHX_REQUIRE(s, "null handle");

@@ -74,6 +74,7 @@ public:
     int get_island_trace(unsigned long long* out, int cap_groups, int* groups);
     int get_wave_trace(unsigned long long* out, int cap_words, int* waves_per_group);
     int get_groups(int* offsets, int cap, int* count, int* lds_count);
+    int get_lanes(int* leader_slot, int* lane, int cap, int* count);      // the LDS groups' units: leader slot -> lane of the island kernel (schedule.h LANES)
     int get_partition(int* interior_classes, int* parts, int* sweep_launches)
     {
         PHX_TRY(synchronize());

@@ -817,6 +817,30 @@ int DeviceSolver::get_groups(int* offsets, int cap, int* count, int* lds_count)
     return PHX_OK;
 }
 
+int DeviceSolver::get_lanes(int* leader_slot, int* lane, int cap, int* count)
+{
+    if (!sched_.valid) { set_error("no solve has run yet"); return PHX_ERR_STATE; }
+    PHX_TRY(synchronize());
+    PHX_TRY(materialise_schedule());
+    const int lg = sched_.lds_groups, lanes = sched_.lds_lanes;
+    std::vector<int4> recs(2 * (size_t)std::max(lg, 1) * std::max(lanes, 1));
+    PHX_TRY(use_device(device_));
+    if (lg) PHX_HIP(hipMemcpy(recs.data(), isl_.unit_recs.p, 2 * (size_t)lg * lanes * sizeof(int4), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int g = 0; g < lg; ++g)
+        for (int l = 0; l < lanes; ++l) {
+            const int4 a = recs[2 * ((size_t)g * lanes + l)], b = recs[2 * ((size_t)g * lanes + l) + 1];
+            if (a.x < 0) continue;                                      // nobody's lane
+            if (leader_slot && lane) {
+                if (n >= cap) { set_error("lane arrays too small"); return PHX_ERR_CAPACITY; }
+                leader_slot[n] = b.z; lane[n] = l;
+            }
+            ++n;
+        }
+    if (count) *count = n;
+    return PHX_OK;
+}
+
 int DeviceSolver::get_refreshed(int joint, float out[30])
 {
     if (!have_solve_) { set_error("no solve has run yet"); return PHX_ERR_STATE; }

@@ -7,7 +7,7 @@ import pytest
 
 import phyx_amd
 from phyx_amd import scenes, Configuration
-from helpers import SMALL_SCENES, presolve_state
+from helpers import SMALL_SCENES, is_static, presolve_state
 
 pytestmark = pytest.mark.gpu
 
@@ -431,6 +431,37 @@ def test_device_schedule_builder_equals_host_builder(oracle, built_lib):
         assert np.array_equal(hs.groups, ds.groups) and hs.lds_groups == ds.lds_groups
         assert (hst.island_count, hst.island_max_size, hst.colour_count) == (dst.island_count, dst.island_max_size, dst.colour_count)
         assert hb.tobytes() == db.tobytes() and hj.tobytes() == dj.tobytes()
+
+
+def test_device_lanes_are_the_host_builders(built_lib):
+    """The lanes the device builder (k_build_bin: the classes' ranges laid out on the wave's scalar unit) gives the units of the LDS groups
+    are the ones the host builder's layout_classes gives them (phx_schedule_groups, restated in tests/test_host_logic.py): one lane per
+    unit, classes on wave boundaries where the lanes allow it — for the small shape (stack columns of 100), the 512-lane shape (columns
+    of 500) and a scene of several components per group."""
+    solver = phyx_amd.Solver(0)
+    cfg = Configuration(0, phyx_amd.ISLAND_MULTIPLE, 15, 15)
+    for scene, warm, iters, lanes, cap in ((scenes.stack(10, 100), 3, 15, 256, 768), (scenes.stack(3, 500), 3, 30, 512, 1024), (scenes.stack(40, 60), 4, 15, 256, 768)):
+        state = presolve_state(scene, warm, iters=iters)
+        bodies, _, joints = state
+        _, _, sched, _, st = _device_solve(solver, state, cfg)
+        slot, lane = solver.lanes()
+        hs = phyx_amd.schedule_groups(joints["body1"], joints["body2"], is_static(bodies), joints["contact_point_index"], lanes=lanes, body_cap=cap)
+        assert hs["lds_groups"] == sched.lds_groups and np.array_equal(hs["order"], sched.order)
+        want = dict(zip(hs["unit_leader_slot"].tolist(), hs["unit_lane"].tolist()))
+        got = dict(zip(slot.tolist(), lane.tolist()))
+        assert len(got) == len(slot) and got == want
+        # ... and they do what they are for: no class straddles a wave more than back-to-back ranges would make it
+        grp = np.searchsorted(np.asarray(sched.groups), slot, side="right") - 1
+        cls = np.searchsorted(np.asarray(sched.colours), slot, side="right") - 1
+        passes = len(np.unique(np.stack([grp, cls, lane // 64], axis=1), axis=0))
+        plain = 0
+        for g in range(sched.lds_groups):
+            at = 0
+            for c in np.unique(cls[grp == g]):
+                n = int(((grp == g) & (cls == c)).sum())
+                plain += (at + n - 1) // 64 - at // 64 + 1
+                at += n
+        assert passes <= plain
 
 
 @pytest.mark.parametrize("island_mode", [phyx_amd.ISLAND_MULTIPLE, phyx_amd.ISLAND_SINGLE])
