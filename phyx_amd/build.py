@@ -23,7 +23,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # round 3: the machine scheduler's iterative-ilp strategy (orders each block for instruction-level parallelism instead of register
 # pressure — the class step is one wave's dependent chain, and the kernel has registers to spare at 4 waves per SIMD): launch
 # 76.6 -> 74.1 us together with the select-based tag update (tools/build_variants.sh A/B: max-ilp 75.5, max-memory-clause 75.0)
-FILE_FLAGS = {"islands.hip": ["-fno-slp-vectorize", "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}      # (it includes solver_kernels.h for the shared device helpers only)
+# round 5: with ONE straight-line form of the class step (island_kernel.h half_step) the default scheduler is the better one again: island
+# launch 61.5 us under iterative-ilp, 60.5 under the default, 60.4 under max-ilp, 61.5 / 62.0 under max-memory-clause / iterative-minreg
+FILE_FLAGS = {"islands.hip": ["-fno-slp-vectorize", "-Wno-unused-function"]}      # (it includes solver_kernels.h for the shared device helpers only)
 # roctx ranges (phase names of the reference's MICROPROFILE scopes) are resolved at run time with dlopen: no link dependency
 LINK = ["-shared", "-ldl"]
 # the sweeps' arithmetic contract (include/phyx_amd.h phx_arith_mode): fused multiply-adds unless PHX_ARITH=source
