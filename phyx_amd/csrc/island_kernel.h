@@ -244,7 +244,22 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         if (has2) isl_refresh(q1, da1.x, da1.y, da1.z, da1.w, p1, p2);
         im1 = p1.x; ii1 = p1.y; im2 = p2.x; ii2 = p2.y;
     }
-    __syncthreads();
+    // THE DISPLACEMENT HALF OF A GROUP THAT HAS NOTHING TO PUSH APART IS A NO-OP, bit for bit: if every displacing velocity of the group
+    // is +0, no joint is deeper than the allowed penetration (dstD = +0, ref: Solver.cpp:672-680) and everything a visit multiplies is
+    // finite, then a visit (ref: Solver.cpp:960-1005) computes dv = +0 - (+-0) ... = +0, di = max(+-0, -accD = -0) = -0, adds (finite x -0)
+    // to +0 velocities (= +0) and -0 to accD = +0 (= +0), and is not productive — in either arithmetic form.  So the reference's first
+    // displacement sweep finds nothing productive and is its last (ref: Solver.cpp:210); the group skips it and reports the one sweep
+    // (a resting stack's every solve: 1.5 us of cfg 2's launch).
+    auto finite_bits = [](float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; };
+    auto joint_quiet = [&](const IslJoint& q) {
+        return __float_as_uint(q.dstD) == 0u && finite_bits(q.nx) && finite_bits(q.ny) && finite_bits(q.aN1) && finite_bits(q.aN2) && finite_bits(q.cimN)
+               && finite_bits(im1) && finite_bits(ii1) && finite_bits(im2) && finite_bits(ii2);
+    };
+    bool stirs = live && !(joint_quiet(q0) && (!has2 || joint_quiet(q1)));
+#pragma unroll
+    for (int k = 0; k < BI; ++k)
+        if (body_id[k] >= 0) stirs |= (__float_as_uint(rec_disp[k].x) | __float_as_uint(rec_disp[k].y) | __float_as_uint(rec_disp[k].z)) != 0u;
+    const bool disp_quiet = __syncthreads_or(stirs ? 1 : 0) == 0;      // (the barrier that was here anyway)
     for (int i = tid; i < 4 * NB; i += T) sw_raw[i] = 0;     // the parameter table is dead: now the tag words
     const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
     const bool wave_static = __any(live && (st1 || st2));      // (wave-uniform, fixed for the solve)
@@ -275,8 +290,8 @@ __global__ void __launch_bounds__(T, 4) k_solve_islands(SolverView v, IslandView
         if ((now & ISL_ARRIVE_MASK) == want) atomicAdd(iv.ctl, now >= ISL_BAD ? (unsigned long long)(1u + ISL_BAD) : 1ull);
     }
     PHX_ISL_STAMP(3);
-    int done_imp = 0, done_disp = 0;
-    bool imp_alive = ci > 0, disp_alive = pi > 0;
+    int done_imp = 0, done_disp = (pi > 0 && disp_quiet) ? 1 : 0;      // (a quiet group's one displacement sweep: see above)
+    bool imp_alive = ci > 0, disp_alive = pi > 0 && !disp_quiet;
     const int iters = ci > pi ? ci : pi;
     unsigned early_ctl = 0u;                               // (lane 0) the control word as read a few sweeps in: by then every workgroup has long arrived
     int it = 0, c = 0, slot = 0;                           // the sweep, the class and the flag slot the step forms below work on
