@@ -116,6 +116,40 @@ static __global__ void __launch_bounds__(256) k_cc_link(const phx_contact_joint*
     }
 }
 
+// The components WITHOUT the joints (round 5, the World's step): a manifold that has a contact point has a joint on its two bodies, so the
+// manifolds say which bodies hang together as soon as UpdateManifolds is through — while RefreshContactJoints still matches, creates and
+// compacts the joints.  DeviceSolver::prelabel_components queues these two kernels, the flattening pass and the roots' scan on the side
+// stream; the rebuild then takes the label-keeping path (k_cc_init_lite), whose k_joint_components still spoils the build if some joint's
+// bodies carry different labels.  Same edges, same smallest-body roots, same labels as k_cc_init + k_cc_link make from the joints.
+static __global__ void __launch_bounds__(256) k_cc_init_bodies(const float4* __restrict__ mpos, int nb, int* __restrict__ parent, unsigned char* __restrict__ is_static)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const float4 p = mpos[i];
+        const bool st = p.x == 0.f && p.y == 0.f;                       // ref: Solver.cpp:304
+        is_static[i] = st ? 1 : 0;
+        parent[i] = st ? -1 : i;
+    }
+}
+
+// (manifolds that PackManifolds is moving while this runs are read at their old place, their new one or both: the same link twice; a
+//  dead manifold has no contact point wherever it is read)
+static __global__ void __launch_bounds__(256) k_cc_link_manifolds(const phx_manifold* __restrict__ manifolds, int nm, int nb, int* parent, const unsigned char* __restrict__ is_static)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+        const phx_manifold m = manifolds[i];
+        if (m.point_count <= 0) continue;
+        const unsigned u = (unsigned)m.body1, v = (unsigned)m.body2;
+        if (u >= (unsigned)nb || v >= (unsigned)nb || u == v) continue;
+        if (is_static[u] || is_static[v]) continue;                        // a static body joins nothing (ref: Solver.cpp:304)
+        int hi = (int)(u > v ? u : v), lo = (int)(u > v ? v : u);
+        while (true) {                                                     // (k_cc_link's linking step)
+            const int old = atomicMin(parent + hi, lo);
+            if (old == hi || old == lo) break;
+            hi = old > lo ? old : lo; lo = old > lo ? lo : old;
+        }
+    }
+}
+
 // full path compression: afterwards parent[b] is the representative (the component's smallest body)
 // (`clear`: the 'labels disagree' flag k_joint_components may raise, zeroed on the way)
 // (Walks that cross read entries their owners are overwriting — old parent or root, an ancestor either way, and mostly the

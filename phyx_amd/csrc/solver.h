@@ -63,6 +63,11 @@ public:
     // static-ness: the rebuild then keeps the labels instead of recomputing the components (PHX_NO_INCREMENTAL=1: never).
     const int* labels_device() const { return labels_valid_ ? bld_.cc_parent.p : nullptr; }
     void set_labels_hint(bool on) { labels_hint_ = on; }
+    // The components from the MANIFOLDS, on the side stream, while the caller still works on its joint list (schedule_kernels.h
+    // k_cc_link_manifolds): the next rebuild waits for them and keeps them (PHX_NO_PRELABEL=1: never).  cancel_prelabel(): no rebuild followed.
+    int prelabel_components(const float4* d_mpos, int nb, const phx_manifold* d_manifolds, int nm);
+    int cancel_prelabel();
+    bool prelabel_pending() const { return prelabel_pending_; }
     void build_counts(int64_t out2[2]) const { out2[0] = lite_builds_; out2[1] = full_builds_; }      // device rebuilds that kept / recomputed the components
     int synchronize(const std::function<int()>* while_waiting = nullptr, const MailCarrier* carrier = nullptr);      // (`carrier`: Readback::wait)
     int get_stats(phx_solve_stats* out);
@@ -161,6 +166,8 @@ private:
     hipStream_t stream_ = nullptr;
     hipStream_t side_stream_ = nullptr;      // the LDS islands of a schedule that also has an HBM group (enqueue_sweeps)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipEvent_t ev_pre_fork_ = nullptr, ev_pre_join_ = nullptr;      // prelabel_components: stream_ -> side stream, side stream -> the rebuild
+    bool prelabel_pending_ = false; int prelabel_nb_ = 0;
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
 
 
@@ -175,6 +182,7 @@ private:
         bool speculate = true;            // PHX_NO_SPECULATION=1 clears it
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
+        bool no_prelabel = false;         // PHX_NO_PRELABEL=1: the World's rebuilds take their components from the joints (A/B, tests)
         bool no_incremental = false;      // PHX_NO_INCREMENTAL=1: every rebuild recomputes the connected components
         bool force_big = false;           // PHX_ISL_SHAPE=big: the roomier workgroup shape whether or not a component needs it (measurements)
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
@@ -219,7 +227,7 @@ private:
         PinnedBuf<int> bin_tables_host;
         DevBuf<unsigned char> cc_static;
         DevBuf<unsigned> cc_flags, comp_size, comp_units, sort_keys[2], sort_vals[2], sort_hist;
-        ScanScratch sort_scan;
+        ScanScratch sort_scan, prelabel_scan;      // (the side stream's scan keeps its own state: it runs beside the joint list's scans)
         DevBuf<int> partner;                  // joint -> the other joint of its unit (schedule.h)
         DevBuf<unsigned long long> partner_first;      // contact point -> tag << 32 | first joint carrying it (k_cc_init)
         unsigned partner_tag = 0;             // this build's tag: counts down, 0 = the table has to be cleared first

@@ -24,6 +24,8 @@ DeviceSolver::~DeviceSolver()
     // (every device buffer is a DevBuf member: freed with the object, after this body — the device is selected above)
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_pre_fork_) (void)hipEventDestroy(ev_pre_fork_);
+    if (ev_pre_join_) (void)hipEventDestroy(ev_pre_join_);
     if (side_stream_) { (void)hipStreamSynchronize(side_stream_); (void)hipStreamDestroy(side_stream_); }
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (ev_end_) (void)hipEventDestroy(ev_end_);
@@ -59,6 +61,7 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     o.speculate = !on("PHX_NO_SPECULATION");
     o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
     o.no_incremental = on("PHX_NO_INCREMENTAL");
+    o.no_prelabel = on("PHX_NO_PRELABEL");
     { const char* sh = getenv("PHX_ISL_SHAPE"); o.force_big = sh && sh[0] == 'b'; }
     o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
     o.trace_schedule = getenv("PHX_TRACE_SCHEDULE") != nullptr;  // print the schedule builders' laps to stderr
@@ -77,6 +80,8 @@ int DeviceSolver::init()
     PHX_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
     PHX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     PHX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    PHX_HIP(hipEventCreateWithFlags(&ev_pre_fork_, hipEventDisableTiming));
+    PHX_HIP(hipEventCreateWithFlags(&ev_pre_join_, hipEventDisableTiming));
     // two control sets alternate between consecutive solves; the first kernel of a solve clears the other one (solver_kernels.h)
     PHX_TRY(hash_.reserve(2));
     PHX_HIP(hipMemsetAsync(hash_.p, 0, 2 * sizeof(unsigned long long), stream_));

@@ -385,6 +385,7 @@ int World::solve(const phx_config& cfg, bool settle)                        // r
     // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
     // keep their velocities here
     solver_.set_labels_hint(joints_changed_ && topo_unchanged_ && !bodies_changed_);
+    if (!joints_changed_) PHX_TRY(solver_.cancel_prelabel());              // (no rebuild will pick the side stream's labels up)
     topo_unchanged_ = false;
     if (joints_changed_) bodies_changed_ = false;                           // (this solve rebuilds: its labels know the bodies as they are now)
     PHX_TRY(solver_.solve_resident(resident().s, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
@@ -450,6 +451,9 @@ int World::pre_solve(float dt)
     phase_ms[1] = 0.0;
     { RoctxRange r("UpdateBroadphase + UpdatePairs"); PHX_TRY(update_pairs()); lap(2); }            // ref: Collider.cpp:253, 288
     { RoctxRange r("UpdateManifolds"); PHX_TRY(update_manifolds()); lap(3); }                        // ref: Collider.cpp:370
+    // the manifolds say which bodies hang together: the solver labels the connected components on its side stream while the joint
+    // list is still being matched, extended and compacted (solver.h prelabel_components) — not with per-phase timing: the phases overlap
+    if (!phase_timing) PHX_TRY(solver_.prelabel_components((const float4*)mpos_.p, nb(), (const phx_manifold*)d_manifolds_.p, nm));
     { RoctxRange r("PackManifolds"); PHX_TRY(pack_manifolds()); lap(4); }                            // ref: Collider.cpp:381
     { RoctxRange r("RefreshContactJoints"); PHX_TRY(refresh_contact_joints()); lap(5); }             // ref: World.cpp:74
     return PHX_OK;

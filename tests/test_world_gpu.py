@@ -679,7 +679,8 @@ def test_debugging_knobs_do_not_change_results(built_lib):
         want = digest({}, mode)
         assert len(want) == 64
         for knob in ({"PHX_NO_MAILBOX": "1"}, {"PHX_NO_SPECULATION": "1"}, {"PHX_SCHEDULE_BUILDER": "host"}, {"PHX_NO_SPEC_BINS": "1"},
-                     {"PHX_NO_PARTS": "1"}, {"PHX_NO_SIDE_STREAM": "1"}, {"PHX_NO_FUSED_VERIFY": "1"}, {"PHX_NO_SPLIT_SORT": "1"}, {"PHX_NO_MAIL_CARRIER": "1"}):
+                     {"PHX_NO_PARTS": "1"}, {"PHX_NO_SIDE_STREAM": "1"}, {"PHX_NO_FUSED_VERIFY": "1"}, {"PHX_NO_SPLIT_SORT": "1"}, {"PHX_NO_MAIL_CARRIER": "1"},
+                     {"PHX_NO_PRELABEL": "1"}):
             assert digest(knob, mode) == want, (knob, mode)
 
 
