@@ -65,6 +65,9 @@ public:
     void set_labels_hint(bool on) { labels_hint_ = on; }
     // The components from the MANIFOLDS, on the side stream, while the caller still works on its joint list (schedule_kernels.h
     // k_cc_link_manifolds): the next rebuild waits for them and keeps them (PHX_NO_PRELABEL=1: never).  cancel_prelabel(): no rebuild followed.
+    // prelabel_mark(): the manifolds are final from HERE on the stream (an event); prelabel_components(): queue the labelling behind that
+    // point — called later, once the stream has the caller's next kernels to run while the host queues these.
+    int prelabel_mark();
     int prelabel_components(const float4* d_mpos, int nb, const phx_manifold* d_manifolds, int nm);
     int cancel_prelabel();
     bool prelabel_pending() const { return prelabel_pending_; }
@@ -167,7 +170,7 @@ private:
     hipStream_t side_stream_ = nullptr;      // the LDS islands of a schedule that also has an HBM group (enqueue_sweeps)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     hipEvent_t ev_pre_fork_ = nullptr, ev_pre_join_ = nullptr;      // prelabel_components: stream_ -> side stream, side stream -> the rebuild
-    bool prelabel_pending_ = false; int prelabel_nb_ = 0;
+    bool prelabel_marked_ = false, prelabel_pending_ = false; int prelabel_nb_ = 0;
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
 
 

@@ -225,18 +225,30 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
 constexpr int JP_BATCH = 8;          // colouring rounds queued between two looks at the frontier sizes
 constexpr int JP_ROUNDS_MAX = 512;
 
-int DeviceSolver::prelabel_components(const float4* d_mpos, int nb, const phx_manifold* d_manifolds, int nm)
+int DeviceSolver::prelabel_mark()
 {
-    if (opt_.no_prelabel || opt_.no_incremental || !opt_.gpu_builder || !side_stream_ || nb <= 0 || nm <= 0 || !d_mpos || !d_manifolds) return PHX_OK;
+    prelabel_marked_ = false;
+    if (opt_.no_prelabel || opt_.no_incremental || !opt_.gpu_builder || !side_stream_) return PHX_OK;
     // only where the next rebuild would keep them: the path without a host round trip (spec_build_applies), on an island-mode schedule
     if (!sched_.valid || !sched_.islands || sched_.has_hbm_group() || !spec_build_applies(true, 1)) return PHX_OK;
+    PHX_TRY(use_device(device_));
+    PHX_HIP(hipEventRecord(ev_pre_fork_, stream_));          // behind everything that wrote the manifolds and last read the labels
+    prelabel_marked_ = true;
+    labels_valid_ = false;                                   // (nobody reads the labels while they are being made)
+    return PHX_OK;
+}
+
+int DeviceSolver::prelabel_components(const float4* d_mpos, int nb, const phx_manifold* d_manifolds, int nm)
+{
+    if (!prelabel_marked_) return PHX_OK;
+    prelabel_marked_ = false;
+    if (nb <= 0 || nm <= 0 || !d_mpos || !d_manifolds) return PHX_OK;
     PHX_TRY(use_device(device_));
     const int nbs = std::max(nb, 1);
     // (the sizes the rebuild asks for, so that it finds these very arrays)
     PHX_TRY(bld_.cc_parent.reserve(nbs)); PHX_TRY(bld_.cc_static.reserve(nbs)); PHX_TRY(bld_.cc_flags.reserve(nbs + 1)); PHX_TRY(bld_.comp_size.reserve(nbs + 1));
     PHX_TRY(bld_.comp_units.reserve(nbs + 1)); PHX_TRY(bld_.sb_small.reserve(8));
     RoctxRange range("GatherIslands (components from the manifolds, side stream)");
-    PHX_HIP(hipEventRecord(ev_pre_fork_, stream_));          // behind everything that wrote the manifolds and last read the labels
     PHX_HIP(hipStreamWaitEvent(side_stream_, ev_pre_fork_, 0));
     hipLaunchKernelGGL(k_cc_init_bodies, dim3(grid_for(nb)), dim3(256), 0, side_stream_, d_mpos, nb, bld_.cc_parent.p, bld_.cc_static.p);
     hipLaunchKernelGGL(k_cc_link_manifolds, dim3(grid_for(nm)), dim3(256), 0, side_stream_, d_manifolds, nm, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p);
@@ -246,7 +258,6 @@ int DeviceSolver::prelabel_components(const float4* d_mpos, int nb, const phx_ma
     PHX_HIP(hipGetLastError());
     PHX_HIP(hipEventRecord(ev_pre_join_, side_stream_));
     prelabel_pending_ = true; prelabel_nb_ = nb;
-    labels_valid_ = false;                                   // (nobody reads the labels while they are being made)
     return PHX_OK;
 }
 

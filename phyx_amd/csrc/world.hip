@@ -336,6 +336,7 @@ int World::refresh_contact_joints()                                         // r
         if (nm || nj || pack_pending_) {                                    // counters_[0 .. 4]: adjacent words, one copy
             unsigned got[5] = {0, 0, 0, 0, 0};
             PHX_TRY(rb_.add(got, counters_.p, sizeof got, stream_));
+            PHX_TRY(solver_.prelabel_components((const float4*)mpos_.p, nb(), (const phx_manifold*)d_manifolds_.p, nm));      // (once: the mark is consumed)
             PHX_TRY(rb_.wait(stream_));
             host[0] = got[0]; host[1] = got[1]; host[4] = got[4];
             if (pack_pending_) { host[2] = got[2]; host[3] = got[3]; }      // (else PackManifolds has settled them already)
@@ -453,7 +454,9 @@ int World::pre_solve(float dt)
     { RoctxRange r("UpdateManifolds"); PHX_TRY(update_manifolds()); lap(3); }                        // ref: Collider.cpp:370
     // the manifolds say which bodies hang together: the solver labels the connected components on its side stream while the joint
     // list is still being matched, extended and compacted (solver.h prelabel_components) — not with per-phase timing: the phases overlap
-    if (!phase_timing) PHX_TRY(solver_.prelabel_components((const float4*)mpos_.p, nb(), (const phx_manifold*)d_manifolds_.p, nm));
+    // (marked here — the manifolds are final from this point of the stream on — and queued from refresh_contact_joints, once the stream has
+    //  the match and its scans to run while the host queues the side stream's kernels)
+    if (!phase_timing) PHX_TRY(solver_.prelabel_mark());
     { RoctxRange r("PackManifolds"); PHX_TRY(pack_manifolds()); lap(4); }                            // ref: Collider.cpp:381
     { RoctxRange r("RefreshContactJoints"); PHX_TRY(refresh_contact_joints()); lap(5); }             // ref: World.cpp:74
     return PHX_OK;
