@@ -278,9 +278,16 @@ def run_bench(args, pdist):
 
     # ---- the island kernel's phases, measured live: a 0-iteration solve is set-up + PreStep + write-back only
     phases = None
-    if world == 1 and lds and side >= 2:
+    rank_of_8 = None
+    if world == 1 and lds and side >= 1:
         zero = run(Configuration(phyx_amd.SOLVE_AVX2, island_mode, 0, 0), 2, 10, 3)
         phases = {"setup_prestep_writeback_us": 1e3 * zero["sweep_ms"] / max(zero["bracketed"], 1)}
+        # one rank of eight on this GPU (an eighth of the groups, <= 1 per CU, an eighth of the instructions): if the launch hardly gets
+        # shorter, the chain of class steps bounds it, not the SIMDs' issue and not HBM
+        try:
+            rank_of_8 = one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run, ns=(8,))["n=8"]
+        except Exception as e:      # (a diagnostic: never the reason a bench line is missing)
+            rank_of_8 = {"error": str(e)}
         # ... and the cost of a class step as a SLOPE: the same solve with half the impulse sweeps.  (The 0-iteration launch is not
         # "the full launch minus its sweeps": its workgroups all reach the write-back together, and under in-kernel verification
         # they wait there for the last arrival, which a full launch hides behind its sweeps.)
@@ -412,7 +419,26 @@ def run_bench(args, pdist):
                               "achieved_cycles_per_colour_step": cyc, "frac_of_latency_floor": COLOUR_STEP_FLOOR_CYCLES / cyc if cyc > 0 else None,
                               "frac_of_dependent_chain_floor_round3": COLOUR_STEP_CHAIN_FLOOR_CYCLES / cyc if cyc > 0 else None,
                               "setup_writeback_GBps": (tbytes / (max(launch_us - sweep_us, 1e-3) * 1e-6) / 1e9) if tbytes else None})
+            if "issue_model" in model:
+                model["issue_model"]["status"] = ("a diagnostic, NOT the bound (round 6): one rank of eight — an eighth of the instructions — launches hardly faster "
+                                                  "(roofline.chain.one_rank_of_8_launch_us), so the chain of class steps bounds the sweeps; cycles_per_issue 4.5 is this "
+                                                  "builder's own probe of a wave64 on a SIMD-16-wide fp32 pipe (profiles/r04_unit_issue_probe.txt: 4.2 plain), the guide's "
+                                                  "'2 cycles per VALU instruction' is its figure for packed / SIMD-32 issue")
             roof["latency_model"] = model
+            # what bounds the dominant kernel: the dependent chain of class steps of the slowest group (the live half-sweep slope)
+            if phases and "half_sweeps_launch_us" in phases and model.get("achieved_cycles_per_colour_step"):
+                cyc = model["achieved_cycles_per_colour_step"]
+                roof["chain"] = {"class_steps": int(ncol_max * st.impulse_iterations), "classes_of_the_slowest_group": ncol_max, "sweeps": int(st.impulse_iterations),
+                                 "us_per_step": cyc / SHADER_CLOCK_HZ * 1e6, "cycles_per_step": cyc,
+                                 "sweeps_us": model["sweeps_us"], "launch_us": launch_us, "chain_share_of_launch": model["sweeps_us"] / launch_us if launch_us else None,
+                                 "lone_wave_floor_cycles": COLOUR_STEP_FLOOR_CYCLES,
+                                 "lone_wave_floor_what": "one wave alone on its SIMD: LDS read 64 + %d VALU x 4 cycles of issue + LDS write 13 + s_barrier 128" % COLOUR_STEP_VALU_INSTRUCTIONS,
+                                 "frac_of_lone_wave_floor": COLOUR_STEP_FLOOR_CYCLES / cyc if cyc > 0 else None,
+                                 "one_rank_of_8_launch_us": rank_of_8.get("island_launch_us") if rank_of_8 else None,
+                                 "one_rank_of_8": rank_of_8,
+                                 "what": "the launch is bound by the DEPENDENT CHAIN of class steps of its slowest group (classes x sweeps, one barrier-separated "
+                                         "step each), measured as a slope between two sweep counts; measured HBM traffic (roofline.frac) and instruction issue "
+                                         "(latency_model.issue_model) are both far from their limits"}
         out = {
             "metric": "solver joint-visits/s (contacts/sec) on the 200k-box stack scene; solver iterations/s in extra",
             "value": visits_all / elapsed_max,
@@ -561,7 +587,7 @@ def world_groups_max_colours(solver):
     return best
 
 
-def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run):
+def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joints, args, nb, nj, run, ns=(1, 2, 4, 8)):
     """What ONE rank of an n-GPU config-3 run spends per step, measured on this GPU: shard 0 of n of the Multiple-mode
     schedule + pack + (the all-gather replaced by a local copy of the rank's own segment) + unpack.  The RCCL time is not in
     it; it bounds the strong scaling the driver's multi-GPU run can show."""
@@ -570,7 +596,7 @@ def one_rank_of_n(phyx_amd, Configuration, group, solver, d_bodies, d_cps, d_joi
     res = {}
     slv = phyx_amd.Solver(solver.device)
     xch = pdist.Exchange(group, slv, pdist.Exchange.capacity_for(nb, nj), solver.device)
-    for n in (1, 2, 4, 8):
+    for n in ns:
         slv.set_shard(0, n)
         tot = run(cfg3, 2, 10, 3, slv=slv, hk=xch.hook())
         res["n=%d" % n] = {"ms_per_step": 1e3 * tot["elapsed_max"] / 10, "island_launch_us": 1e3 * tot["sweep_ms"] / max(tot["bracketed"], 1),
@@ -762,6 +788,23 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     return res
 
 
+def physical_cores():
+    """cores among the CPUs this process may use: CPUs that lead their thread_siblings_list (oracle/cpu_baseline.c pool_cpus orders its workers the same way)"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+    n = 0
+    for cpu in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+                first = int(f.read().replace("-", ",").split(",")[0])
+        except (OSError, ValueError):
+            first = cpu
+        n += 1 if first == cpu else 0
+    return max(n, 1)
+
+
 def cpu_baseline(bodies, cps, joints, iters, budget_s):
     """The host-CPU baseline beside the GPU number, timed in this run on this host: oracle/cpu_baseline.c, an
     8-wide AVX2-order restatement of Solver::SolveJoints<8> (greedy 8-grouping ref: Solver.cpp:217-273, group-granular skip
@@ -776,6 +819,7 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
         ncpu = len(os.sched_getaffinity(0))            # the cores this process may really use (a container's share), not the box's
     except AttributeError:
         ncpu = os.cpu_count() or 1
+    cores = physical_cores()
     b = bodies.view(ob.body_dtype); cp = cps.view(ob.contact_point_dtype); j = joints.view(ob.joint_dtype)
     t_begin = time.perf_counter()
     names = ("prepare_bodies", "prepare_indices", "prepare_joints", "refresh", "prestep", "impulse", "displacement", "finish", "total")
@@ -787,7 +831,7 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
     # `value` is taken on ALL host threads; a short probe over smaller counts rides along, because the racy
     # 512-joint sweep stops scaling long before all cores and the best count says so
     probe = {}
-    for t in sorted({1, 4, 8, 16, 32, 64, 128, ncpu}):
+    for t in sorted({1, 4, 8, 16, 32, 64, 128, cores, ncpu}):
         if t > ncpu or time.perf_counter() - t_begin > 0.5 * budget_s:
             continue
         solve(t)
@@ -827,11 +871,16 @@ def cpu_baseline(bodies, cps, joints, iters, budget_s):
     # the scalar (N = 1) restatement, impulse loop only (the round-1 baseline)
     sec, v = ob.time_impulse_loop(b, cp, j, iters, 1)
     ms = lambda d: {k: round(1e3 * x, 3) for k, x in d.items()}
-    return {"value": vm / many["impulse"], "unit": "joint-visits/s", "cores": best, "host_threads": ncpu, "kind": "port",
+    return {"value": vm / many["impulse"], "unit": "joint-visits/s", "cores": best, "host_threads": ncpu, "host_cores": cores, "kind": "port",
+            "threads": best, "cores_used": min(best, cores),
+            "pinning": "worker w pinned to the w-th allowed CPU, one hardware thread of every core first (up to %d workers sit on different cores); every worker "
+                       "sweeps the same contiguous share of the 512-joint batches in every phase — the packs it touched first — and steals from the "
+                       "others' shares only when it has finished its own" % cores,
+            "probe_M_visits_per_s_by_threads": {str(k): round(x / 1e6) for k, x in sorted(probe.items())},
             "all_host_threads": all_threads,
             "sample": "%d x one full SolveJoints<8> of the same %d-joint solver input (%d impulse sweeps run), AVX2-order baseline built "
-                      "-O3 -ffast-math -mavx2 -mfma, %d threads (the better of: every host thread / the probe's best count), 512-joint batches "
-                      "pulled from one shared counter (Single Sloppy; probe %s M visits/s by thread count; %d host threads); value = joints x "
+                      "-O3 -ffast-math -mavx2 -mfma, %d pinned threads (the better of: every host thread / the probe's best count), 512-joint batches "
+                      "in contiguous per-worker shares with stealing (Single Sloppy; probe %s M visits/s by thread count; %d host threads); value = joints x "
                       "sweeps / median impulse-loop time" % (nm, len(j), swm, best, {k: round(x / 1e6) for k, x in probe.items()}, ncpu),
             "solve_ms_per_step": 1e3 * many["total"], "phases_ms": ms(many),
             "single_thread": {"value": v1 / one["impulse"], "solve_ms_per_step": 1e3 * one["total"], "phases_ms": ms(one), "samples": n1,

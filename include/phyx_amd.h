@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 1
+#define PHX_ABI_VERSION 2
 
 typedef enum {
     PHX_OK = 0,
@@ -283,9 +283,10 @@ int phx_solver_get_refreshed(phx_solver* s, int32_t joint_index, float out30[30]
  * differ in the lowest bit only (contact points 2m and 2m + 1 of manifold m) and whose bodies are the
  * same form a unit, led by the even id; every other joint is a unit of its own.  The units are
  * partitioned into classes that share no dynamic body (is_static[b] != 0 exempts body b): they take
- * their class first-fit in order of DECREASING phx_schedule_priority(priority_ids[j], j) of their
- * leader j — a fixed pseudo-random order, chosen because the device reaches the same classes in a few
- * dozen parallel rounds, whereas joint-index order needs one round per box of a stacked column — with
+ * their class first-fit in order of DECREASING phx_schedule_priority(priority_ids[j], j, min(body1[j],
+ * body2[j])) of their leader j — units whose lower body index is even first, inside a parity a fixed
+ * pseudo-random order: the device reaches the same classes in a few parallel rounds (two on a stacked
+ * column), whereas joint-index order needs one round per box of a stacked column — with
  * two candidates per connected component (smallest free class / two-ended) of which the component keeps
  * the one that needs fewer classes.  The layout of a class is described at phx_solver_get_schedule.
  * priority_ids may be NULL (the joint index is used); the solver passes each joint's
@@ -310,7 +311,7 @@ int phx_schedule_groups(const int32_t* body1, const int32_t* body2, int32_t join
                         const int32_t* priority_ids, int32_t lanes, int32_t body_cap, int32_t* order, int32_t* colour_offsets,
                         int32_t offsets_cap, int32_t* colour_count, int32_t* group_offsets, int32_t* group_first_colour,
                         int32_t groups_cap, int32_t* lds_groups, int32_t* unit_lane, int32_t* unit_leader_slot);
-uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index);
+uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index, uint32_t lower_body);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Broadphase — replaces Collider::UpdateBroadphase + UpdatePairs                                   */
@@ -418,9 +419,9 @@ int  phx_world_x_extent(phx_world* w, float out2[2]);
  * [1] those of them that lost the bet (pack run late, joint match repeated), [2] solves repeated because the cached schedule was
  * stale or a group was left uncommitted, [3] third contact points dropped (ref: Collider.cpp:241-242 would overflow) */
 int  phx_world_debug_counters(phx_world* w, int64_t out4[4]);
-/* diagnostics of the schedule rebuild: [0] rebuilds that KEPT the connected components of the build before (incremental: the step's joint
- * changes neither joined two components nor removed a unit — counted on the device), [1] rebuilds that recomputed them.  The schedule
- * is the same pure function of the joints either way; PHX_NO_INCREMENTAL=1 forces [0] to stay 0. */
+/* diagnostics of the schedule rebuild: [0] rebuilds whose connected components, joint counts and bins came from the MANIFOLDS (made on a
+ * side stream while the joint list was refreshed), [1] rebuilds that took them from the joints.  The schedule is the same pure function of
+ * the joints either way; PHX_NO_PRELABEL=1 forces [0] to stay 0. */
 int  phx_world_build_counts(phx_world* w, int64_t out2[2]);
 /* per-phase host timers cost one stream synchronisation per phase; off by default (get_phase_ms then returns the last
  * values measured while it was on) */

@@ -113,7 +113,7 @@ _SIGNATURES = {
     "phx_solver_bench_checksum": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "phx_solver_bench_hooked": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, C.POINTER(Config), _i32, _i32, STEP_HOOK, _vp, C.POINTER(BenchResult)]),
     "phx_solver_stream": (C.c_void_p, [_vp]),
-    "phx_schedule_priority": (C.c_uint64, [C.c_uint32, C.c_uint32]),
+    "phx_schedule_priority": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "phx_schedule_colours": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
     "phx_schedule_islands": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32]),
     "phx_schedule_groups": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

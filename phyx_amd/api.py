@@ -82,9 +82,9 @@ def exchange_layout(group_bodies, group_slots, shard_count):
     return off[:len(gb)], rw, seg.value, own[:len(gb)]
 
 
-def schedule_priority(priority_id, joint_index):
+def schedule_priority(priority_id, joint_index, lower_body=0):
     """Colouring priority of a joint (higher = coloured earlier); see include/phyx_amd.h."""
-    return int(_lib.load().phx_schedule_priority(int(priority_id), int(joint_index)))
+    return int(_lib.load().phx_schedule_priority(int(priority_id), int(joint_index), int(lower_body)))
 
 
 def schedule_colours(body1, body2, is_static, priority_ids=None):

@@ -65,6 +65,8 @@ private:
     bool have_update_ = false, ms_pending_ = false;
     phx_broadphase_stats stats_{};
     Readback rb_;
+public:
+    void set_wait_timeout(double seconds) { rb_.set_timeout(seconds); }      // (a sharded World: the stream carries collectives, common.h Readback)
 };
 
 } // namespace phx

@@ -180,7 +180,7 @@ int phx_solver_bench_checksum(phx_solver* s, uint64_t* out)
 
 void* phx_solver_stream(phx_solver* s) { return s ? (void*)s->impl.stream() : nullptr; }
 
-uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index) { return phx::colour_priority(priority_id, joint_index); }
+uint64_t phx_schedule_priority(uint32_t priority_id, uint32_t joint_index, uint32_t lower_body) { return phx::colour_priority(priority_id, joint_index, lower_body); }
 
 int phx_schedule_colours(const int32_t* b1, const int32_t* b2, int32_t nj, const uint8_t* is_static, int32_t nb, const int32_t* priority_ids,
                          int32_t* order, int32_t* offsets, int32_t offsets_cap, int32_t* ncolours)

@@ -27,6 +27,7 @@ public:
     int agree(int status, long long bytes, int* worst_status, long long* min_bytes, long long* max_bytes, hipStream_t stream);
     int wait_stream(hipStream_t stream, const char* what);      // hipStreamSynchronize with the communicator's time bound
     static int version();                             // ncclGetVersion (0 if RCCL is not available)
+    static double timeout_s();                        // PHX_COMM_TIMEOUT_S: the bound of every host wait on a stream that carries collectives
     int rank() const { return rank_; }
     int size() const { return nranks_; }
     int device() const { return device_; }

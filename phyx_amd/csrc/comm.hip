@@ -220,6 +220,8 @@ int Comm::agree(int status, long long bytes, int* worst_status, long long* min_b
     return posted;
 }
 
+double Comm::timeout_s() { return comm_timeout_s(); }
+
 int Comm::version()
 {
     int v = 0;

@@ -256,6 +256,10 @@ public:
         if ((bytes & 3u) || (reinterpret_cast<uintptr_t>(src) & 3u)) odd_ = true;
         return PHX_OK;
     }
+    // A handle whose stream carries collectives (a sharded World, world.hip set_comm) bounds every host wait: a peer that died or stopped
+    // stepping leaves the stream blocked behind an all-reduce / all-gather for good, and the waits below would spin with it
+    // (ADVICE r5).  0 = unbounded (no collective can be queued on this handle's stream).
+    void set_timeout(double seconds) { timeout_s_ = seconds; }
     // `stamp` (device pointer, may be null): the post kernel also leaves the clock there (atomicMax) — see k_post_mail
     // `while_waiting` (may be null): called once the batch is on its way and before the host starts to wait — whatever it queues
     // on the stream runs while the post crosses the link and the host digests it, instead of the GPU idling through the round trip
@@ -284,7 +288,16 @@ public:
             for (int i = 0; i < count_; ++i) PHX_HIP(hipMemcpyAsync(pin_ + items_[i].off, items_[i].src, items_[i].bytes, hipMemcpyDeviceToHost, stream));
             if (carrier) PHX_TRY((*carrier)(nullptr));
             else if (while_waiting) PHX_TRY((*while_waiting)());
-            PHX_HIP(hipStreamSynchronize(stream));
+            if (timeout_s_ > 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spins = 0;; ++spins) {
+                    const hipError_t q = hipStreamQuery(stream);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) { set_error("readback: %s", hipGetErrorString(q)); return PHX_ERR_HIP; }
+                    if ((spins & 0xFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s_) return timed_out();
+                    __builtin_ia32_pause();
+                }
+            } else PHX_HIP(hipStreamSynchronize(stream));
         }
         for (int i = 0; i < count_; ++i) std::memcpy(items_[i].dst, pin_ + items_[i].off, items_[i].bytes);
         return PHX_OK;
@@ -303,12 +316,16 @@ private:
         static const bool clocked = getenv("PHX_WAIT_CLOCK") != nullptr;
         const auto t0 = clocked ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         struct Stop { bool on; std::chrono::steady_clock::time_point t0; ~Stop() { if (on) { wait_clock_ns() += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++wait_clock_calls(); } } } stop{clocked, t0};
+        const auto t_begin = timeout_s_ > 0 ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         for (unsigned long long spins = 1;; ++spins) {
             if (__atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq_) return PHX_OK;
             __builtin_ia32_pause();
             if ((spins & 0xFFFFu) == 0) {                // every ~65k polls: did the stream fail, or finish without posting?
                 const hipError_t q = hipStreamQuery(stream);
-                if (q == hipErrorNotReady) continue;
+                if (q == hipErrorNotReady) {
+                    if (timeout_s_ > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > timeout_s_) return timed_out();
+                    continue;
+                }
                 if (q != hipSuccess) { set_error("readback: %s", hipGetErrorString(q)); return PHX_ERR_HIP; }
                 if (__atomic_load_n(const_cast<unsigned*>(word), __ATOMIC_ACQUIRE) == seq_) return PHX_OK;
                 set_error("readback: the stream drained without posting batch %u", seq_);
@@ -316,6 +333,12 @@ private:
             }
         }
     }
+    int timed_out() const
+    {
+        set_error("readback: the stream is still busy after %.0f s (PHX_COMM_TIMEOUT_S) — it carries collectives, and a peer never entered one of them", timeout_s_);
+        return PHX_ERR_STATE;
+    }
+    double timeout_s_ = 0.0;
     char* pin_ = nullptr;
     size_t cap_ = 0, used_ = 0, want_ = 0;
     int count_ = 0;

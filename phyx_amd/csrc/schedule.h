@@ -19,15 +19,26 @@
 
 namespace phx {
 
-// Colouring priority of joint j whose priority id is `id` (the colouring rule is stated below).  The solver uses the
-// joint's contactPointIndex as the id: unlike the joint's position it survives compacting the joint list (island
-// sharding solves a subset of the joints and must reach the same colours).  The joint index only breaks ties between
+// Colouring priority of joint j whose priority id is `id` and whose LOWER body index is `lower` (the colouring rule is stated
+// below).  The solver uses the joint's contactPointIndex as the id: unlike the joint's position it survives compacting the joint
+// list (island sharding solves a subset of the joints and must reach the same colours).  The joint index only breaks ties between
 // equal ids, so keys are unique; they are never zero (zero means "nobody" in the builders' tables).
-__host__ __device__ inline unsigned long long colour_priority(unsigned id, unsigned j)
+// PARITY-MAJOR (round 6): every unit whose lower body index is EVEN ranks above every unit whose lower body index is odd; inside a
+// parity the order is the fixed pseudo-random one of the hash.  First fit in priority order is a dependency graph whose depth is the
+// number of parallel rounds the device builders need (a unit takes its class once every higher-priority unit on its dynamic bodies
+// has one): under the hash alone a stacked column — a path — is ~7 rounds deep; with the parity in front the even units of a path
+// conflict with nobody of their parity and the odd ones only wait for them: two rounds, plus one per duplicate manifold in the way.
+// On irregular piles the depth is that of two hash orders in sequence.  Like every order it is one more legal Gauss-Seidel order
+// and a pure function of the joints.
+__host__ __device__ inline unsigned colour_hash31(unsigned id)
 {
     unsigned x = id * 0x9E3779B1u;
     x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
-    return (((unsigned long long)x << 32) | j) + 1ull;
+    return x >> 1;
+}
+__host__ __device__ inline unsigned long long colour_priority(unsigned id, unsigned j, unsigned lower)
+{
+    return ((((unsigned long long)(~lower & 1u)) << 63) | ((unsigned long long)colour_hash31(id) << 32) | j) + 1ull;
 }
 
 // UNITS.  The joints of one body pair (the two contact points of a manifold) conflict with each other and with nobody
@@ -182,10 +193,10 @@ struct LdsCaps { int max_joints = 512, max_units = 256, max_bodies = 768, max_co
 //  slot in the group's small static-tag table)
 
 // Colouring rule (every group, host and device builders alike; stated in full above): UNITS take their class FIRST-FIT IN ORDER
-// OF DECREASING colour_priority(id, joint index) of their leader — a fixed pseudo-random order.  Sequentially that is one pass
-// over the sorted units; in parallel it is a dependency graph a few dozen rounds deep (a unit takes its class once every
-// higher-priority unit on its dynamic bodies has one), where joint-index order would need one round per body of a stacked
-// column.  The layout of a class: the leaders that have a follower, the single leaders, the followers in their leaders' order.
+// OF DECREASING colour_priority(id, joint index, lower body index) of their leader — parity of the lower body first, then a fixed
+// pseudo-random order.  Sequentially that is one pass over the sorted units; in parallel it is a dependency graph a few rounds deep
+// (a unit takes its class once every higher-priority unit on its dynamic bodies has one), where joint-index order would need one
+// round per body of a stacked column.  The layout of a class: the leaders that have a follower, the single leaders, the followers in their leaders' order.
 
 // One HBM group holding every joint.  `prio_id` (optional, per joint): priority ids; the joint index itself if null.
 void build_colour_schedule(const int* body1, const int* body2, int nj, const unsigned char* is_static, int nb, Schedule& out,

@@ -24,11 +24,11 @@ static void parallel_chunks(int count, int min_per_thread, F&& fn)
 }
 
 // positions of `joints` in colouring order: decreasing colour_priority (schedule.h)
-static void priority_order(const std::vector<int>& joints, const int* prio_id, std::vector<int>& perm)
+static void priority_order(const std::vector<int>& joints, const int* prio_id, const int* body1, const int* body2, std::vector<int>& perm)
 {
     std::vector<std::pair<unsigned long long, int>> keyed(joints.size());
     for (size_t k = 0; k < joints.size(); ++k)
-        keyed[k] = {colour_priority((unsigned)(prio_id ? prio_id[joints[k]] : joints[k]), (unsigned)joints[k]), (int)k};
+        keyed[k] = {colour_priority((unsigned)(prio_id ? prio_id[joints[k]] : joints[k]), (unsigned)joints[k], (unsigned)std::min(body1[joints[k]], body2[joints[k]])), (int)k};
     std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
     perm.resize(joints.size());
     for (size_t k = 0; k < joints.size(); ++k) perm[k] = keyed[k].second;
@@ -79,7 +79,7 @@ static int colour_joints(const std::vector<int>& joints, const int* body1, const
     colour.assign(joints.size(), 0);
     if (interior_classes) { interior_classes[0] = 0; interior_classes[1] = 0; }
     std::vector<int> perm;
-    priority_order(joints, prio_id, perm);
+    priority_order(joints, prio_id, body1, body2, perm);
     // components, densely numbered; the big ones are PARTITIONED: their interior units form a kind of their own (schedule.h)
     std::vector<unsigned char> comp_bad;                       // per dense component (also set for components too big for B)
     std::vector<int> dense(joints.size());
@@ -435,7 +435,7 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
     std::vector<int> col_a(leaders.size()), col_b(leaders.size());
     std::vector<uint32_t> local(leaders.size());
     std::vector<int> perm;
-    priority_order(leaders, prio_id, perm);
+    priority_order(leaders, prio_id, body1, body2, perm);
     for (size_t k = 0; k < leaders.size(); ++k) {
         bool fresh;
         const int a = *map.find_or_insert(body1[leaders[k]], fresh), b = *map.find_or_insert(body2[leaders[k]], fresh);

@@ -43,24 +43,6 @@ static __global__ void __launch_bounds__(256) k_cc_init(const float4* __restrict
     }
 }
 
-// INCREMENTAL REBUILD (round 5): the body labels of the last build are still the connected components of this joint list when no
-// joint joins two of them and no unit has vanished since — a running world's usual step: contact points come and go inside body
-// pairs that touch already (the caller vouches for it, solver.h set_labels_hint; the World counts bridging pairs and vanished units
-// on the device, world_kernels.h).  Then the linking pass, the flattening pass and the numbering scan are skipped: this kernel does what
-// is left of k_cc_init (the unit pairing's table) and of the scan's loader (the per-component counters), k_joint_components pairs
-// the joints itself and still raises `unconverged` if some joint's bodies carry different labels (the build is spoiled then and the
-// caller rebuilds the long way).  The schedule is the same pure function of the joints either way (tests: PHX_NO_INCREMENTAL twins).
-static __global__ void __launch_bounds__(256) k_cc_init_lite(int nb, int* __restrict__ clear, const phx_contact_joint* __restrict__ joints, int nj, int ncp,
-                                                             unsigned long long* __restrict__ first, unsigned tag, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nb; i += gridDim.x * blockDim.x) { comp_size[i] = 0u; comp_units[i] = 0u; }
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
-        const unsigned id = (unsigned)joints[j].contact_point_index;
-        if (id < (unsigned)ncp) atomicMin(&first[id], ((unsigned long long)tag << 32) | (unsigned)j);
-    }
-}
-
 // (`first` / `partner`: the joints are paired into units on the way, schedule.h; the table is complete, k_cc_init filled it)
 __device__ __forceinline__ int partner_of(const phx_contact_joint* __restrict__ joints, int j, const phx_contact_joint& me, int ncp,
                                           const unsigned long long* __restrict__ first, unsigned tag)
@@ -121,8 +103,9 @@ static __global__ void __launch_bounds__(256) k_cc_link(const phx_contact_joint*
 // compacts the joints.  DeviceSolver::prelabel_components queues these two kernels, the flattening pass and the roots' scan on the side
 // stream; the rebuild then takes the label-keeping path (k_cc_init_lite), whose k_joint_components still spoils the build if some joint's
 // bodies carry different labels.  Same edges, same smallest-body roots, same labels as k_cc_init + k_cc_link make from the joints.
-static __global__ void __launch_bounds__(256) k_cc_init_bodies(const float4* __restrict__ mpos, int nb, int* __restrict__ parent, unsigned char* __restrict__ is_static)
+static __global__ void __launch_bounds__(256) k_cc_init_bodies(const float4* __restrict__ mpos, int nb, int* __restrict__ parent, unsigned char* __restrict__ is_static, int* __restrict__ clear)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         const float4 p = mpos[i];
         const bool st = p.x == 0.f && p.y == 0.f;                       // ref: Solver.cpp:304
@@ -188,32 +171,70 @@ struct RootFlagLoad {
 };
 
 // joint -> component number (-1 if both bodies are static), and joints and units (schedule.h) per component.
-// The counts are accumulated in a per-workgroup LDS hash table (every lane inserts its own joint: LDS atomics on distinct
+// The counts are accumulated in a per-workgroup LDS hash table (every lane inserts its own item: LDS atomics on distinct
 // slots run in parallel, on one slot they cost a few cycles each) and flushed once per workgroup.  Counting straight into
 // memory was fine while every column was its own island, but once a settling scene has merged into one island every
 // wave fired at the SAME counter: 1e4 same-address device atomics were 115 us of this 13 us kernel.
 constexpr int JC_T = 1024, JC_TABLE = 2048;
-// (`first` non-null — the incremental rebuild, k_cc_init_lite: no linking pass has paired the joints; they are paired here, into `partner`)
+struct CompCountTable { int key[JC_TABLE]; unsigned cnt[JC_TABLE], units[JC_TABLE]; };
+__device__ __forceinline__ void comp_count_clear(CompCountTable& t)
+{
+    for (int i = threadIdx.x; i < JC_TABLE; i += JC_T) { t.key[i] = -1; t.cnt[i] = 0; t.units[i] = 0; }
+    __syncthreads();
+}
+// every lane adds (1 + extra_joint joints, is_unit units) to component `mine` (< 0: nothing)
+// one table insert per distinct component of the wave (in a merged world every lane carries the SAME component: a
+// thousand same-address LDS atomics per workgroup made this the slowest kernel of the schedule build)
+// (... and a world that has been running for a while keeps its joints in no particular order: a wave's 64 joints then belong
+//  to dozens of components and the leader loop — one serial round of LDS atomics per distinct component — was most of this
+//  kernel's 18 us at cfg 2.  Three rounds take care of waves with a few components, merged worlds included; whoever is left
+//  inserts for himself, all at once: different components, different slots.)
+__device__ __forceinline__ void comp_count_add(CompCountTable& t, int mine, bool extra_joint, bool is_unit)
+{
+    auto insert = [&](int comp, unsigned jn, unsigned un) {
+        unsigned h = ((unsigned)comp * 2654435761u) >> 21;                             // 11 bits
+        for (;; h = (h + 1) & (JC_TABLE - 1)) {                                        // <= JC_T distinct keys in a table of 2 * JC_T
+            const int seen = atomicCAS(&t.key[h], -1, comp);
+            if (seen == -1 || seen == comp) { atomicAdd(&t.cnt[h], jn); if (un) atomicAdd(&t.units[h], un); break; }
+        }
+    };
+    unsigned long long todo = __ballot(mine >= 0);
+    for (int round = 0; round < 3 && todo; ++round) {
+        const int leader = __builtin_ctzll(todo);
+        const int comp = __shfl(mine, leader);
+        const unsigned long long same = __ballot(mine == comp);
+        const unsigned sj = (unsigned)__popcll(same) + (unsigned)__popcll(__ballot(mine == comp && extra_joint));
+        const unsigned su = (unsigned)__popcll(__ballot(mine == comp && is_unit));
+        if ((int)(threadIdx.x & 63) == leader) insert(comp, sj, su);
+        todo &= ~same;
+    }
+    if ((todo >> (threadIdx.x & 63)) & 1ull) insert(mine, extra_joint ? 2u : 1u, is_unit ? 1u : 0u);
+}
+__device__ __forceinline__ void comp_count_flush(CompCountTable& t, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
+{
+    __syncthreads();
+    for (int i = threadIdx.x; i < JC_TABLE; i += JC_T)
+        if (t.key[i] >= 0) { atomicAdd(&comp_size[t.key[i]], t.cnt[i]); if (t.units[i]) atomicAdd(&comp_units[t.key[i]], t.units[i]); }
+    __syncthreads();
+}
+
 static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_contact_joint* __restrict__ joints, int nj, int nb, const int* __restrict__ parent,
-                                                                  const unsigned* __restrict__ root_number, int* __restrict__ partner,
+                                                                  const unsigned* __restrict__ root_number, const int* __restrict__ partner,
                                                                   int* __restrict__ joint_comp, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units,
-                                                                  int* __restrict__ unconverged, const unsigned long long* __restrict__ first = nullptr, unsigned tag = 0u, int ncp = 0)
+                                                                  int* __restrict__ unconverged)
 {
     // (`unconverged`, may be null: raised if some joint's two dynamic bodies still carry different labels — a caller that skipped
     //  the hook round which only confirms convergence, solver.hip's speculative build, finds out here instead)
-    __shared__ int table_key[JC_TABLE];
-    __shared__ unsigned table_cnt[JC_TABLE], table_units[JC_TABLE];
+    __shared__ CompCountTable table;
     for (int j0 = blockIdx.x * blockDim.x; j0 < nj; j0 += gridDim.x * blockDim.x) {       // uniform trip count per workgroup
-        for (int i = threadIdx.x; i < JC_TABLE; i += JC_T) { table_key[i] = -1; table_cnt[i] = 0; table_units[i] = 0; }
-        __syncthreads();
+        comp_count_clear(table);
         const int j = j0 + (int)threadIdx.x;
         int mine = -1;
         unsigned lead_one = 0;
         if (j < nj) {
             const phx_contact_joint me = joints[j];
             const unsigned u = (unsigned)me.body1, v = (unsigned)me.body2;
-            int mate;
-            if (first) { mate = partner_of(joints, j, me, ncp, first, tag); partner[j] = mate; } else mate = partner[j];
+            const int mate = partner[j];
             const bool leads = !(mate >= 0 && (me.contact_point_index & 1));      // not the follower of a unit
             int comp = -1;
             if (u < (unsigned)nb && v < (unsigned)nb) {
@@ -225,33 +246,39 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
             joint_comp[j] = comp;
             mine = comp; lead_one = leads ? 1u : 0u;
         }
-        // one table insert per distinct component of the wave (in a merged world every lane carries the SAME component: a
-        // thousand same-address LDS atomics per workgroup made this the slowest kernel of the schedule build)
-        // (... and a world that has been running for a while keeps its joints in no particular order: a wave's 64 joints then belong
-        //  to dozens of components and the leader loop — one serial round of LDS atomics per distinct component — was most of this
-        //  kernel's 18 us at cfg 2.  Three rounds take care of waves with a few components, merged worlds included; whoever is left
-        //  inserts for himself, all at once: different components, different slots.)
-        auto insert = [&](int comp, unsigned joints_n, unsigned leads_n) {
-            unsigned h = ((unsigned)comp * 2654435761u) >> 21;                             // 11 bits
-            for (;; h = (h + 1) & (JC_TABLE - 1)) {                                        // <= JC_T distinct keys in a table of 2 * JC_T
-                const int seen = atomicCAS(&table_key[h], -1, comp);
-                if (seen == -1 || seen == comp) { atomicAdd(&table_cnt[h], joints_n); if (leads_n) atomicAdd(&table_units[h], leads_n); break; }
+        comp_count_add(table, mine, false, lead_one != 0);
+        comp_count_flush(table, comp_size, comp_units);
+    }
+}
+
+// The same counts WITHOUT the joints (round 6, the World's step): after RefreshContactJoints every contact point of a live manifold has
+// exactly one joint (ref: World.cpp:92-118 creates the missing ones, :125-143 deletes the orphans), so a manifold with n contact points
+// is n joints and one unit of its bodies' component — known as soon as UpdateManifolds is through.  The side stream counts here and
+// bins (k_bin_components) while the joint list is still being matched, extended and compacted; the rebuild proper is then two
+// launches (k_joint_scatter, k_build_bin).  `flags` |= 1: a manifold with contact points between two static bodies, or a body out of
+// range — such joints belong to no component (the HBM group's business): the build is spoiled and the caller rebuilds the long way.
+static __global__ void __launch_bounds__(JC_T) k_manifold_components(const phx_manifold* __restrict__ manifolds, int nm, int nb, const int* __restrict__ parent,
+                                                                     const unsigned* __restrict__ root_number, unsigned* __restrict__ comp_size,
+                                                                     unsigned* __restrict__ comp_units, int* __restrict__ flags)
+{
+    __shared__ CompCountTable table;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < nm; i0 += gridDim.x * blockDim.x) {
+        comp_count_clear(table);
+        const int i = i0 + (int)threadIdx.x;
+        int mine = -1;
+        unsigned points = 0;
+        if (i < nm) {
+            const phx_manifold m = manifolds[i];
+            if (m.point_count > 0) {
+                const unsigned u = (unsigned)m.body1, v = (unsigned)m.body2;
+                int r = -1;
+                if (u < (unsigned)nb && v < (unsigned)nb && m.point_count <= 2) { const int pu = parent[u], pv = parent[v]; r = pu >= 0 ? pu : pv; }
+                if (r >= 0) { mine = (int)root_number[r]; points = (unsigned)m.point_count; }
+                else atomicOr(flags, 1);
             }
-        };
-        unsigned long long todo = __ballot(mine >= 0);
-        for (int round = 0; round < 3 && todo; ++round) {
-            const int leader = __builtin_ctzll(todo);
-            const int comp = __shfl(mine, leader);
-            const unsigned long long same = __ballot(mine == comp);
-            const unsigned nlead = (unsigned)__popcll(__ballot(mine == comp && lead_one));
-            if ((int)(threadIdx.x & 63) == leader) insert(comp, (unsigned)__popcll(same), nlead);
-            todo &= ~same;
         }
-        if ((todo >> (threadIdx.x & 63)) & 1ull) insert(mine, 1u, lead_one);
-        __syncthreads();
-        for (int i = threadIdx.x; i < JC_TABLE; i += JC_T)
-            if (table_key[i] >= 0) { atomicAdd(&comp_size[table_key[i]], table_cnt[i]); if (table_units[i]) atomicAdd(&comp_units[table_key[i]], table_units[i]); }
-        __syncthreads();
+        comp_count_add(table, mine, points == 2u, true);
+        comp_count_flush(table, comp_size, comp_units);
     }
 }
 
@@ -267,33 +294,6 @@ static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __rest
         keys[j] = (unsigned)((c < 0 || c >= ncomp_cap) ? rest_key : bin_of_comp[c]);
         vals[j] = (unsigned)j;
     }
-}
-
-// k_joint_bin_keys and the first k_radix_hist of the sort behind it in one launch (device_radix.h's tile shape and histogram layout):
-// the keys are counted where they are made.
-template <int BITS>
-static __global__ void __launch_bounds__(RS_THREADS) k_joint_bin_keys_hist(const int* __restrict__ joint_comp, const int* __restrict__ bin_of_comp, int nj, int rest_key,
-                                                                           unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ rejected, int ncomp_cap,
-                                                                           int nblocks, unsigned* __restrict__ hist)
-{
-    constexpr int BINS = 1 << BITS;
-    __shared__ unsigned h[BINS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
-    for (int d = threadIdx.x; d < BINS; d += RS_THREADS) h[d] = 0;
-    __syncthreads();
-    const int base = blockIdx.x * RS_TILE;
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
-        const int j = base + i * RS_THREADS + threadIdx.x;
-        if (j < nj) {
-            const int c = joint_comp[j];
-            const unsigned key = (unsigned)((c < 0 || c >= ncomp_cap) ? rest_key : bin_of_comp[c]);
-            keys[j] = key; vals[j] = (unsigned)j;
-            atomicAdd(&h[key & (unsigned)(BINS - 1)], 1u);
-        }
-    }
-    __syncthreads();
-    for (int d = threadIdx.x; d < BINS; d += RS_THREADS) hist[d * nblocks + blockIdx.x] = h[d];
 }
 
 // ---- binning on the device -------------------------------------------------------------------------------------------
@@ -324,10 +324,12 @@ struct BinCompView {
     int max_bins;                     // grid of the launches behind this kernel
     int* bin_of; int* rank_of;        // out: per component (BINC_MAX each)
     int* goff;                        // out: first slot of every bin, max_bins + 1 words
-    int* result;                      // out: [0] bins (0 if spoiled), [1] slots in bins, [4] fail bits, [5] components, [6] bins found
+    int* result;                      // out: [0] bins (0 if spoiled), [1] slots in bins, [4] fail bits, [5] components, [6] bins found, [7] = 0 (k_joint_scatter's spoil bits)
+    unsigned* cursor;                 // out: max_bins + 1 zeros — the bins' fill counts of k_joint_scatter
     unsigned long long* scratch;      // launches of more than one workgroup: [0, BINC_T) head masks, [BINC_T, 2 BINC_T) bins << 32 | slots per chunk,
                                       // [2 BINC_T] arrival counter, [2 BINC_T + 1] fail bits | needs-big << 8 — both left zero for the next launch
     unsigned long long* fingerprint;  // the solve's topology fingerprint word: saved to `hash_out`, then replaced by `gate`
+                                      //   (null — the bins are made on the side stream, from the manifolds' counts: k_joint_scatter arms the gate; nj < 0 then: it checks the total too)
     unsigned long long* hash_out;     //   (the host does not know the hash yet: the solve's kernels compare the word with a constant
     unsigned long long gate;          //    it does know) — or by a spoiled `gate` if the build cannot be used
 };
@@ -465,25 +467,162 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
         // components that fit no shape go to the HBM group, which this path does not build
         const int nbins = (int)(total >> 32), slots_all = (int)(unsigned)total;
         if ((s_needs_big != 0) != (v.cap_units > v.small_units)) s_fail |= BINC_FAIL_SHAPE;
-        if (slots_all != v.nj) s_fail |= BINC_FAIL_REST;
+        if (v.nj >= 0 && slots_all != v.nj) s_fail |= BINC_FAIL_REST;
         if (nbins <= v.max_bins) v.goff[nbins] = slots_all;
         if (nbins > v.max_bins) s_fail |= BINC_FAIL_GRID;
         v.result[0] = s_fail ? 0 : nbins;                      // (a spoiled build's tables may be incomplete: nobody runs on them)
-        v.result[1] = slots_all; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins;
-        *v.hash_out = *v.fingerprint;
-        *v.fingerprint = s_fail ? v.gate + BINC_POISON : v.gate;
+        v.result[1] = slots_all; v.result[4] = s_fail; v.result[5] = n_all; v.result[6] = nbins; v.result[7] = 0;
+        if (v.fingerprint) {
+            *v.hash_out = *v.fingerprint;
+            *v.fingerprint = s_fail ? v.gate + BINC_POISON : v.gate;
+        }
+    }
+    for (int i = tid; i <= v.max_bins; i += BINC_T) v.cursor[i] = 0u;
+}
+
+// ---- the joints, bin by bin ---------------------------------------------------------------------------------------------
+// Rounds 2-5 grouped the joints by bin with a stable radix sort of (bin, joint) — keys + histogram, scan, scatter: 29 us in three
+// launches at cfg 2.  A bin's builder does not need the joints of OTHER bins in any order; it needs its own, and it can put ITS few
+// hundred in joint order itself (k_build_bin: a bitonic network in LDS).  So one pass deals every joint to its bin through a fill
+// counter per bin (the bins' first slots are known: k_bin_components), as a RECORD of everything k_build_bin wants of the joint —
+// which the dealing lane holds in registers anyway — instead of an index the builder would have to chase through three levels of
+// memory.  The position inside the bin is whatever the atomic returns; nothing depends on it once the builder has sorted.
+// Whatever cannot be dealt (a body or contact point out of range, labels that disagree, a component outside the tables, a bin that is
+// full) raises a bit of result[7]; k_build_bin then spoils the solve's control word and the caller rebuilds the long way.
+struct BinRecord { int4 a; int2 b; };      // a = {joint, partner or -1, body1, body2}, b = {contact point, rank of the component in its bin | body1 static << 30 | body2 static << 31}
+constexpr int SCAT_FAIL_RANGE = 1, SCAT_FAIL_LABELS = 2, SCAT_FAIL_COMP = 4, SCAT_FAIL_FULL = 8, SCAT_FAIL_UNIT = 16, SCAT_FAIL_TOTAL = 32, SCAT_FAIL_SIDE = 64;
+
+struct ScatterView {
+    const phx_contact_joint* joints; int nj, nb;
+    const int* parent;                // body -> root body of its component (-1: static)
+    const unsigned* root_number;      // root body -> component number
+    // the units (schedule.h).  From the World (manifolds non-null): contact point ids are unique and a contact point knows its joint
+    // (ContactPoint::solverIndex, ref: World.cpp:100, 139), so the partner of the joint on contact point p of a two-point manifold is
+    // cps[p ^ 1].solver_index — checked here: the joint's contact point must name it back, and its bodies must be the manifold's.
+    // Otherwise: `partner` as the linking pass left it (k_cc_link).
+    const phx_manifold* manifolds; int nm;
+    const phx_contact_point* cps; int ncp;
+    const int* partner;
+    const int* bin_of; const int* rank_of; const int* goff;      // k_bin_components' tables
+    int* result;                      // k_bin_components' results; [7] |= SCAT_FAIL_*
+    int max_bins;
+    unsigned* cursor;                 // per bin: records dealt so far (zero on entry)
+    int4* rec_a; int2* rec_b;         // out: the records, bin by bin
+    int* rejected;                    // the 'a bin was rejected' flag k_build_bin may raise: cleared here
+    const int* side_flags;            // (manifolds) k_manifold_components' flags
+    // (manifolds) the solve's gate, which k_bin_components could not arm from the side stream
+    unsigned long long* fingerprint; unsigned long long* hash_out; unsigned long long gate;
+};
+
+template <bool FROM_MANIFOLDS>
+static __global__ void __launch_bounds__(256) k_joint_scatter(ScatterView v)
+{
+    int fail = v.result[4];
+    if (FROM_MANIFOLDS) {
+        if (*v.side_flags) fail |= BINC_FAIL_REST;
+        if (v.result[1] != v.nj) fail |= BINC_FAIL_REST;      // the manifolds' contact points and the joints do not add up
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *v.rejected = 0;
+        if (FROM_MANIFOLDS) {
+            *v.hash_out = *v.fingerprint;
+            *v.fingerprint = fail ? v.gate + BINC_POISON : v.gate;
+            if (fail) { v.result[0] = 0; v.result[4] = fail; }
+        }
+    }
+    if (fail) return;                                         // (uniform: the tables may be incomplete — nobody runs on this build)
+    const int nbins = v.result[6];
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    for (int j0 = blockIdx.x * blockDim.x; j0 < v.nj; j0 += gridDim.x * blockDim.x) {      // (wave-uniform trip count)
+        const int j = j0 + (int)threadIdx.x;
+        int bin = -1, mate = -1, rank = 0;
+        phx_contact_joint me{};
+        bool st1 = false, st2 = false;
+        if (j < v.nj) {
+            me = v.joints[j];
+            const unsigned a = (unsigned)me.body1, b = (unsigned)me.body2;
+            if (a >= (unsigned)v.nb || b >= (unsigned)v.nb || a == b) bad |= SCAT_FAIL_RANGE;
+            else {
+                const int pa = v.parent[a], pb = v.parent[b];
+                st1 = pa < 0; st2 = pb < 0;
+                if (pa >= 0 && pb >= 0 && pa != pb) bad |= SCAT_FAIL_LABELS;
+                const int r = pa >= 0 ? pa : pb;
+                if (r < 0) bad |= SCAT_FAIL_COMP;                 // both static: the HBM group's business
+                else {
+                    const unsigned comp = v.root_number[r];
+                    if (comp >= (unsigned)BINC_MAX) bad |= SCAT_FAIL_COMP;
+                    else {
+                        bin = v.bin_of[comp]; rank = v.rank_of[comp];
+                        if ((unsigned)bin >= (unsigned)nbins || bin > v.max_bins) { bad |= SCAT_FAIL_COMP; bin = -1; }
+                    }
+                }
+                if (FROM_MANIFOLDS) {
+                    const unsigned p = (unsigned)me.contact_point_index;
+                    if (p >= (unsigned)v.ncp || (p >> 1) >= (unsigned)v.nm) { bad |= SCAT_FAIL_UNIT; bin = -1; }
+                    else {
+                        const phx_manifold m = v.manifolds[p >> 1];
+                        if (m.body1 != me.body1 || m.body2 != me.body2 || (int)(p & 1u) >= m.point_count || v.cps[p].solver_index != j) { bad |= SCAT_FAIL_UNIT; bin = -1; }
+                        else if (m.point_count == 2) {
+                            mate = v.cps[p ^ 1u].solver_index;
+                            if ((unsigned)mate >= (unsigned)v.nj || (unsigned)v.joints[mate].contact_point_index != (p ^ 1u)) { bad |= SCAT_FAIL_UNIT; bin = -1; }
+                        }
+                    }
+                } else mate = v.partner[j];
+            }
+        }
+        // one fill-counter atomic per distinct bin of the wave (three rounds; whoever is left goes alone — k_joint_components' scheme)
+        unsigned pos = 0;
+        unsigned long long todo = __ballot(bin >= 0);
+        for (int round = 0; round < 3 && todo; ++round) {
+            const int leader = __builtin_ctzll(todo);
+            const int lb = __shfl(bin, leader);
+            const unsigned long long same = __ballot(bin == lb);
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&v.cursor[lb], (unsigned)__popcll(same));
+            base = __shfl(base, leader);
+            if (bin == lb) pos = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if ((todo >> lane) & 1ull) pos = atomicAdd(&v.cursor[bin], 1u);
+        if (bin >= 0) {
+            const int first = v.goff[bin], room = v.goff[bin + 1] - first;
+            if (pos >= (unsigned)room || (unsigned)(first + (int)pos) >= (unsigned)v.nj) bad |= SCAT_FAIL_FULL;
+            else {
+                const int at = first + (int)pos;
+                v.rec_a[at] = make_int4(j, mate, me.body1, me.body2);
+                v.rec_b[at] = make_int2(me.contact_point_index, rank | (st1 ? 1 << 30 : 0) | (st2 ? (int)(1u << 31) : 0));
+            }
+        }
+    }
+    if (__any(bad != 0)) {
+        int all = bad;
+        for (int off = 32; off > 0; off >>= 1) all |= __shfl_xor(all, off);
+        if (lane == 0) atomicOr(&v.result[7], all);
+    }
+}
+
+// the records of a schedule whose joints WERE sorted by bin (the builder's long way: a stable radix sort that also leaves the HBM
+// group's joints in joint order behind the bins): slot s of the bins holds joint sorted[s]
+static __global__ void __launch_bounds__(256) k_bin_records(const unsigned* __restrict__ sorted, int slots, const phx_contact_joint* __restrict__ joints, const int* __restrict__ partner,
+                                                            const unsigned char* __restrict__ is_static, const int* __restrict__ joint_comp, const int* __restrict__ comp_rank,
+                                                            int4* __restrict__ rec_a, int2* __restrict__ rec_b, int* __restrict__ rejected)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
+        const int j = (int)sorted[s];
+        const phx_contact_joint me = joints[j];
+        rec_a[s] = make_int4(j, partner[j], me.body1, me.body2);
+        rec_b[s] = make_int2(me.contact_point_index, comp_rank[joint_comp[j]] | (is_static[me.body1] ? 1 << 30 : 0) | (is_static[me.body2] ? (int)(1u << 31) : 0));
     }
 }
 
 // ---- one workgroup builds one bin ------------------------------------------------------------------------------
 struct BinBuildView {
-    const unsigned* sorted_joints;    // joint indices grouped by bin, joint order inside a bin
+    const int4* rec_a; const int2* rec_b;      // the joints' records, bin by bin, in any order inside a bin (BinRecord: k_joint_scatter / k_bin_records)
     const int* group_offsets;         // slots of bin g = [group_offsets[g], group_offsets[g+1])
-    const phx_contact_joint* joints;
-    const int* partner;               // joint -> the other joint of its unit, or -1
-    const unsigned char* is_static;
-    const int* joint_comp;            // joint -> connected component number
-    const int* comp_rank;             // component -> its rank among the components of its bin (< joints of the bin)
+    const unsigned* cursor;           // (may be null) records k_joint_scatter dealt to each bin: must equal the bin's slot count
+    const int* spoil;                 // (may be null) k_joint_scatter's fail bits: nobody builds on a spoiled deal
     int nb, max_static;
     int* order;                       // out: slot -> joint
     unsigned* slot_local;             // out: local body1 | local body2 << 16
@@ -526,9 +665,11 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
 {
     constexpr int LANES = 2 * T;
     constexpr int HT = 4 * LANES;                        // open-addressing table, <= 2 LANES distinct bodies
-    __shared__ __align__(8) int ht_key[HT];              // later reused as the per-body priority table of the colouring
+    __shared__ __align__(8) int pool[2 * HT];            // the records' sort and staging, then the hash table
+    int* ht_key = pool;                                  // later reused as the per-body priority table of the colouring
     static_assert((size_t)NB * 8 <= (size_t)HT * 4, "priority table must fit the hash table");
-    __shared__ int ht_val[HT];                          // first occurrence position, later the local index
+    int* ht_val = pool + HT;                             // first occurrence position, later the local index
+    static_assert(6 * LANES <= 2 * HT, "record staging must fit the hash table");
     __shared__ unsigned long long used[NB];              // candidate A (smallest free colour): colours taken per local body
     __shared__ unsigned long long used_b[NB];            // candidate B (two-ended, schedule.h)
     __shared__ int degree[NB];                           // units of the bin on each local body
@@ -542,29 +683,58 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __shared__ int n_static, n_bodies, n_col, n_units, bad;
 
     const int g = blockIdx.x, tid = threadIdx.x;
+    if (v.spoil && *v.spoil) { if (g == 0 && tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); } return; }
     if (v.nbins_dev && g >= *v.nbins_dev) return;
     const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
-    for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
+    if (count < 0 || count > LANES || (v.cursor && v.cursor[g] != (unsigned)count)) {      // the deal does not match the bins: nobody runs on this build
+        if (tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); }
+        return;
+    }
     for (int i = tid; i < NB; i += LANES) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
     if (tid < T) { seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0; }
     for (int i = tid; i < (LANES / 64) * 64; i += LANES) { wave_with[i] = 0; wave_single[i] = 0; }
     if (tid == 0) { bad = 0; n_col = 0; }
     __syncthreads();
 
-    const bool live = tid < count;
+    // the bin's records, put in joint order: a record per lane, a bitonic network over (joint, lane) — strides below 64 by shuffles inside the
+    // wave, the few above through LDS — then every lane fetches the record of the lane that held the tid-th smallest joint
     int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1, cpi = 0, comp = 0;
     bool follower = false, stat[2] = {false, false};
+    {
+        int4 ra = make_int4(0, -1, 0, 0); int2 rb = make_int2(0, 0);
+        if (tid < count) { ra = v.rec_a[begin + tid]; rb = v.rec_b[begin + tid]; }
+        unsigned key = tid < count ? (unsigned)ra.x : 0x80000000u + (unsigned)tid;      // (the lanes beyond the bin sort behind it)
+        int src = tid;
+        unsigned* skey = reinterpret_cast<unsigned*>(pool); int* ssrc = pool + LANES;
+#pragma unroll
+        for (int k = 2; k <= LANES; k <<= 1) {
+#pragma unroll
+            for (int st = k >> 1; st > 0; st >>= 1) {
+                unsigned okey; int osrc;
+                if (st >= 64) {
+                    skey[tid] = key; ssrc[tid] = src;
+                    __syncthreads();
+                    okey = skey[tid ^ st]; osrc = ssrc[tid ^ st];
+                    __syncthreads();
+                } else { okey = (unsigned)__shfl_xor((int)key, st); osrc = __shfl_xor(src, st); }
+                const bool take_min = ((tid & st) == 0) == ((tid & k) == 0);
+                if (take_min ? okey < key : okey > key) { key = okey; src = osrc; }
+            }
+        }
+        // (staging: six words per lane, in the words the hash table takes next)
+        int* stage = pool;
+        stage[tid] = ra.x; stage[LANES + tid] = ra.y; stage[2 * LANES + tid] = ra.z; stage[3 * LANES + tid] = ra.w; stage[4 * LANES + tid] = rb.x; stage[5 * LANES + tid] = rb.y;
+        __syncthreads();
+        j = stage[src]; mate = stage[LANES + src]; b[0] = stage[2 * LANES + src]; b[1] = stage[3 * LANES + src]; cpi = stage[4 * LANES + src];
+        const int info = stage[5 * LANES + src];
+        comp = info & 0x3FFFFFFF; stat[0] = (info >> 30) & 1; stat[1] = (info >> 31) & 1;
+        __syncthreads();
+    }
+    for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
+    __syncthreads();
+    const bool live = tid < count;
     if (live) {
-        // (everything the lane will want from memory is asked for here, three dependent levels deep, and arrives while the
-        //  body table is built: fetched where it is used, each of the later loads cost the whole workgroup a trip to memory)
-        j = (int)v.sorted_joints[begin + tid];
-        const phx_contact_joint jt = v.joints[j];
-        mate = v.partner[j];
-        const int jc = v.joint_comp[j];
-        b[0] = jt.body1; b[1] = jt.body2; cpi = jt.contact_point_index;
-        stat[0] = v.is_static[b[0]] != 0; stat[1] = v.is_static[b[1]] != 0;
-        comp = v.comp_rank[jc];
-        follower = mate >= 0 && (jt.contact_point_index & 1) != 0;
+        follower = mate >= 0 && (cpi & 1) != 0;
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s
             unsigned p = ((unsigned)b[s] * 2654435761u) & (HT - 1);
             for (;;) {
@@ -613,24 +783,34 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __syncthreads();
     // First-fit colouring of the units in priority order by Jones-Plassmann rounds (schedule.h): every round, an uncoloured
     // unit that holds the highest priority on both its dynamic bodies takes the smallest colour free on them.  One winner
-    // per body per round, so the mask updates do not race.  ~log(count) rounds of three barriers each.
+    // per body per round, so the mask updates do not race.  A few rounds (two on a plain column: schedule.h colour_priority) of
+    // TWO barriers each: the keys carry the round in their top bits, so a round's maxima outrank whatever earlier rounds left in the
+    // table and nothing has to be cleared between rounds (round 5 cleared the winners' entries behind a third barrier).
+    // The key inside the bin: round | parity of the lower body | the hash's 31 bits | the lane (lanes are in joint order: the joint
+    // index's tie-break) — the order of colour_priority among the bin's units.
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ht_key);        // the hash table is dead by now (NB * 8 <= HT * 4)
     for (int i = tid; i < NB; i += LANES) best[i] = 0ull;
-    __syncthreads();
     const bool dyn0 = loc[0] >= n_static, dyn1 = loc[1] >= n_static;                  // static bodies sit first in the table
-    const unsigned long long key = unit ? colour_priority((unsigned)cpi, (unsigned)j) : 0ull;
+    const unsigned long long key0 = ((unsigned long long)(~(unsigned)(b[0] < b[1] ? b[0] : b[1]) & 1u) << 57) | ((unsigned long long)colour_hash31((unsigned)cpi) << 26) | ((unsigned long long)tid << 16) | 1ull;
     bool pending = unit;
     int mycol = 0, mycol_b = 0;
     const bool from_top = ((b[0] < b[1] ? b[0] : b[1]) & 1) != 0;
-    for (;;) {
+    const int d0 = dyn0 ? degree[loc[0]] : 0, d1 = dyn1 ? degree[loc[1]] : 0;      // (complete: behind the barrier above)
+    __syncthreads();
+    for (int round = 0;; ++round) {
+        const unsigned tag = (unsigned)(round % 62) + 1u;                                 // 6 bits; the table is wiped when the tags wrap (a bin of hundreds of rounds: never a stack)
+        if (round > 0 && tag == 1u) {
+            for (int i = tid; i < NB; i += LANES) best[i] = 0ull;
+            __syncthreads();
+        }
+        const unsigned long long key = ((unsigned long long)tag << 58) | key0;
         if (pending) { if (dyn0) atomicMax(&best[loc[0]], key); if (dyn1) atomicMax(&best[loc[1]], key); }
         __syncthreads();
         const bool win = pending && (!dyn0 || best[loc[0]] == key) && (!dyn1 || best[loc[1]] == key);
-        __syncthreads();
         if (win) {
-            unsigned long long m = 0;
-            if (dyn0) m |= used[loc[0]];
-            if (dyn1) m |= used[loc[1]];
+            unsigned long long m = 0, mb = 0;
+            if (dyn0) { m |= used[loc[0]]; mb |= used_b[loc[0]]; }
+            if (dyn1) { m |= used[loc[1]]; mb |= used_b[loc[1]]; }
             if (!~m) bad = 1;
             else {
                 mycol = __builtin_ctzll(~m);
@@ -638,22 +818,15 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
                 if (dyn1) used[loc[1]] |= 1ull << mycol;
                 atomicOr(&seen_a[comp], 1ull << mycol);
             }
-            {                                            // candidate B: the same winner, the two-ended choice
-                unsigned long long mb = 0;
-                if (dyn0) mb |= used_b[loc[0]];
-                if (dyn1) mb |= used_b[loc[1]];
-                const int d0 = dyn0 ? degree[loc[0]] : 0, d1 = dyn1 ? degree[loc[1]] : 0;
-                const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, from_top);
-                if (cb < 0) bad_b[comp] = 1;
-                else {
-                    mycol_b = cb;
-                    if (dyn0) used_b[loc[0]] |= 1ull << cb;
-                    if (dyn1) used_b[loc[1]] |= 1ull << cb;
-                    atomicOr(&seen_b[comp], 1ull << cb);
-                }
+            // candidate B: the same winner, the two-ended choice
+            const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, from_top);
+            if (cb < 0) bad_b[comp] = 1;
+            else {
+                mycol_b = cb;
+                if (dyn0) used_b[loc[0]] |= 1ull << cb;
+                if (dyn1) used_b[loc[1]] |= 1ull << cb;
+                atomicOr(&seen_b[comp], 1ull << cb);
             }
-            if (dyn0) best[loc[0]] = 0ull;
-            if (dyn1) best[loc[1]] = 0ull;
             pending = false;
         }
         if (!__syncthreads_or(pending ? 1 : 0)) break;
@@ -811,7 +984,7 @@ static __global__ void __launch_bounds__(256) k_jp_prepare(JpView v)
         const unsigned j = v.ids[k];
         const phx_contact_joint jt = v.joints[j];
         unsigned a = (unsigned)jt.body1, b = (unsigned)jt.body2;
-        const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j);
+        const unsigned long long key = colour_priority((unsigned)jt.contact_point_index, j, a < b ? a : b);
         v.pred[k] = 0u; v.colour_b[k] = 0u; v.colour[k] = JP_NONE;
         { const int jc = v.joint_comp[j]; v.ent_comp[k] = jc < 0 ? (unsigned)v.ncomp : (unsigned)jc; }
         v.succ[k] = make_uint2(JP_NONE, JP_NONE);

@@ -56,22 +56,17 @@ public:
     int solve_resident(const BodyView& bodies, int nb, const void* d_cps, int ncp, void* d_joints, int nj, const phx_config& cfg, bool topology_changed = false);
     // (`while_waiting`, may be null: queued-work hook of the settling round trip, Readback::wait — called at most once, and only if a
     //  solve is pending; the caller checks whether it ran)
-    // INCREMENTAL REBUILD (schedule_kernels.h k_cc_init_lite).  labels_device(): the body labels of the last device build (root body of a
-    // dynamic body's connected component, -1 for a static body) while they are known to be good, else null — a caller that tracks what
-    // changes in the joint list checks new joints against them.  set_labels_hint(true) vouches, for the NEXT rebuild only, that since the
-    // build those labels come from no joint has appeared between two components, no unit has vanished and no body changed its
-    // static-ness: the rebuild then keeps the labels instead of recomputing the components (PHX_NO_INCREMENTAL=1: never).
-    const int* labels_device() const { return labels_valid_ ? bld_.cc_parent.p : nullptr; }
-    void set_labels_hint(bool on) { labels_hint_ = on; }
-    // The components from the MANIFOLDS, on the side stream, while the caller still works on its joint list (schedule_kernels.h
-    // k_cc_link_manifolds): the next rebuild waits for them and keeps them (PHX_NO_PRELABEL=1: never).  cancel_prelabel(): no rebuild followed.
-    // prelabel_mark(): the manifolds are final from HERE on the stream (an event); prelabel_components(): queue the labelling behind that
-    // point — called later, once the stream has the caller's next kernels to run while the host queues these.
+    // The components, their joint counts and the BINS from the MANIFOLDS, on the side stream, while the caller still works on its joint
+    // list (schedule_kernels.h k_cc_link_manifolds, k_manifold_components, k_bin_components): a manifold with n contact points has n
+    // joints once RefreshContactJoints is through.  The next rebuild waits for them and is then two launches — the joints dealt to their
+    // bins, the bins built (PHX_NO_PRELABEL=1: never).  cancel_prelabel(): no rebuild followed, or the manifolds moved under the side stream.
+    // prelabel_mark(): the manifolds are final from HERE on the stream (an event); prelabel_components(): queue the side stream's work
+    // behind that point — called later, once the stream has the caller's next kernels to run while the host queues these.
     int prelabel_mark();
     int prelabel_components(const float4* d_mpos, int nb, const phx_manifold* d_manifolds, int nm);
     int cancel_prelabel();
     bool prelabel_pending() const { return prelabel_pending_; }
-    void build_counts(int64_t out2[2]) const { out2[0] = lite_builds_; out2[1] = full_builds_; }      // device rebuilds that kept / recomputed the components
+    void build_counts(int64_t out2[2]) const { out2[0] = lite_builds_; out2[1] = full_builds_; }      // device rebuilds whose components and bins came from the manifolds (side stream) / from the joints
     int synchronize(const std::function<int()>* while_waiting = nullptr, const MailCarrier* carrier = nullptr);      // (`carrier`: Readback::wait)
     int get_stats(phx_solve_stats* out);
     int get_schedule(int* order, int order_cap, int* offsets, int offsets_cap, int* ncolours);
@@ -112,6 +107,7 @@ public:
     void set_comm(Comm* c) { comm_ = c; }              // bench(): the all-gather between pack and unpack runs natively (comm.hip)
     int exchange_all_gather();                        // the segment of the last pack, every rank's into the recv buffer, on stream()
 
+    void set_wait_timeout(double seconds) { rb_.set_timeout(seconds); }      // (a sharded World: the stream carries collectives, common.h Readback)
     hipStream_t stream() const { return stream_; }
     // run on a caller-owned stream from now on (the World puts broadphase, step kernels and solver on one stream so that
     // consecutive phases need no host synchronisation)
@@ -133,7 +129,8 @@ private:
     int ensure_schedule(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp, const phx_config& cfg, bool force_rebuild,
                         bool known_changed = false);
     int build_schedule_device(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback);
-    int build_bins_speculative(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc);
+    int build_bins_speculative(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc, bool from_manifolds);
+    int spec_grid() const;                // the launch grid of a speculative build's per-bin kernels
     int materialise_schedule();
     int launch_fingerprint(const float4* d_mpos, int nb, const phx_contact_joint* d_joints, int nj, int ncp);
     // How the solve being queued is gated (island_view.h): by the hash pass / the build (ISL_GATED) or by the island kernel's own
@@ -171,6 +168,8 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     hipEvent_t ev_pre_fork_ = nullptr, ev_pre_join_ = nullptr;      // prelabel_components: stream_ -> side stream, side stream -> the rebuild
     bool prelabel_marked_ = false, prelabel_pending_ = false; int prelabel_nb_ = 0;
+    const phx_manifold* pre_manifolds_ = nullptr; int pre_nm_ = 0, pre_grid_ = 0, pre_lanes_ = 0;      // what the side stream binned from, and for which launch grid / shape
+    const phx_contact_point* build_cps_ = nullptr;      // the contact points of the solve being queued (the manifold build pairs the joints through them)
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr, ev_sweep_begin_ = nullptr, ev_sweep_end_ = nullptr;
 
 
@@ -186,7 +185,6 @@ private:
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
         bool no_prelabel = false;         // PHX_NO_PRELABEL=1: the World's rebuilds take their components from the joints (A/B, tests)
-        bool no_incremental = false;      // PHX_NO_INCREMENTAL=1: every rebuild recomputes the connected components
         bool force_big = false;           // PHX_ISL_SHAPE=big: the roomier workgroup shape whether or not a component needs it (measurements)
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
         int isl_wait_polls = 0;           // PHX_ISL_WAIT_POLLS
@@ -226,10 +224,23 @@ private:
     } parts_;
     // scratch of the device schedule builder (schedule_kernels.h): components, units, binning, the sort by bin, the colouring of the HBM group
     struct ScheduleBuilder {
-        DevBuf<int> cc_parent, joint_comp, bin_tables, sb_small;      // bin_tables: component -> bin | component -> rank in its bin | bin -> first slot
+        DevBuf<int> cc_parent, joint_comp, sb_small;
+        // The per-component counters and the bin tables (component -> bin | component -> rank in its bin | bin -> first slot) exist TWICE:
+        // the side stream fills the set the last build did NOT use, so that what the last build left for the statistics
+        // (fetch_build_tables) stands until a rebuild really replaces it (a prelabel that no rebuild followed zeroed them).
+        DevBuf<int> bin_tables_s[2];
+        DevBuf<unsigned> comp_size_s[2], comp_units_s[2];
+        int cur = 0;                          // the set of the build in hand
+        DevBuf<int>& bin_tables() { return bin_tables_s[cur]; }
+        DevBuf<unsigned>& comp_size() { return comp_size_s[cur]; }
+        DevBuf<unsigned>& comp_units() { return comp_units_s[cur]; }
         PinnedBuf<int> bin_tables_host;
         DevBuf<unsigned char> cc_static;
-        DevBuf<unsigned> cc_flags, comp_size, comp_units, sort_keys[2], sort_vals[2], sort_hist;
+        DevBuf<unsigned> cc_flags, sort_keys[2], sort_vals[2], sort_hist;
+        DevBuf<int4> rec_a;                   // the joints' records, bin by bin (schedule_kernels.h BinRecord)
+        DevBuf<int2> rec_b;
+        DevBuf<unsigned> bin_cursor;          // per bin: records dealt (k_joint_scatter)
+        DevBuf<int> side_flags;               // k_manifold_components' flags
         ScanScratch sort_scan, prelabel_scan;      // (the side stream's scan keeps its own state: it runs beside the joint list's scans)
         DevBuf<int> partner;                  // joint -> the other joint of its unit (schedule.h)
         DevBuf<unsigned long long> partner_first;      // contact point -> tag << 32 | first joint carrying it (k_cc_init)
@@ -265,7 +276,7 @@ private:
     // what the host would have read — bin count, offsets, GatherIslands' numbers, the topology hash — comes back when the solve is settled
     bool spec_bins_ok_ = false, spec_bins_pending_ = false, spec_bins_failed_ = false;
     bool tables_pending_ = false;         // the last speculative build's tables are still on the device only (fetch_build_tables)
-    int tables_bins_ = 0, tables_comps_ = 0;
+    int tables_bins_ = 0, tables_comps_ = 0, tables_set_ = 0;
     int fetch_build_tables();
     int spec_bins_guess_ = 0, spec_lanes_ = 0;
     unsigned long long gate_expected_ = 0, gate_serial_ = 0;      // what the gates of the solve in flight compare the fingerprint word with
@@ -294,9 +305,7 @@ private:
     // bench snapshots (resident form)
     DevBuf<float4> snap_vel_, snap_dvel_, snap_mpos_;
     DevBuf<phx_contact_joint> snap_joints_;
-    bool labels_valid_ = false, labels_hint_ = false, build_lite_ = false;      // incremental rebuild: labels_device() / set_labels_hint(); the build in flight kept the labels
-    int labels_nb_ = 0;
-    long long lite_builds_ = 0, full_builds_ = 0;                                  // (statistics: device builds that kept / recomputed the components)
+    long long lite_builds_ = 0, full_builds_ = 0;                                  // (statistics: device builds from the manifolds / from the joints)
     BodyView bench_last_b_{}; phx_contact_joint* bench_last_j_ = nullptr; int bench_last_nb_ = 0, bench_last_nj_ = 0;      // bench_checksum
     // bench_stage(): private copies of the input, one per timed step, made BEFORE the timed region (the input of every step is
     // then resident in HBM — in the resident layout — when the clock starts, and no restore copy runs between the solves)

@@ -60,7 +60,6 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     o.gpu_builder = !(sb && sb[0] == 'h');
     o.speculate = !on("PHX_NO_SPECULATION");
     o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
-    o.no_incremental = on("PHX_NO_INCREMENTAL");
     o.no_prelabel = on("PHX_NO_PRELABEL");
     { const char* sh = getenv("PHX_ISL_SHAPE"); o.force_big = sh && sh[0] == 'b'; }
     o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
@@ -513,6 +512,7 @@ int DeviceSolver::solve_common(const Arrays& a, int nb, const void* d_cps, int n
         if (!bench_trusted_) register_pending(a, nb, d_cps, ncp, d_joints, nj, cfg, true);
         stats_.recoloured = 0;
     } else {
+        build_cps_ = static_cast<const phx_contact_point*>(d_cps);
         PHX_TRY(ensure_schedule(mpos, nb, joints, nj, ncp, cfg, false, topology_changed));
         // like a speculative solve: verified (and replayed on a host-built schedule if a bin was rejected) by synchronize()
         if (build_unverified_) register_pending(a, nb, d_cps, ncp, d_joints, nj, cfg, false);
@@ -571,10 +571,9 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
         build_was_unverified_ = true;                  // (read by synchronize() if the fingerprint does not match)
         if (spec_bins_pending_) {
             spec_bins_pending_ = false;
-            spec_bins_failed_ = spec[4] != 0;
-            if ((opt_.trace_schedule || getenv("PHX_TRACE_SPEC")) && spec_bins_failed_) fprintf(stderr, "[schedule/gpu] speculative binning spoiled: bits %d (%d components, %d bins, grid %d)\n", spec[4], spec[5], spec[6], unverified_bins_);
+            spec_bins_failed_ = spec[4] != 0 || spec[7] != 0;      // (k_bin_components' / k_joint_scatter's fail bits)
+            if ((opt_.trace_schedule || getenv("PHX_TRACE_SPEC")) && spec_bins_failed_) fprintf(stderr, "[schedule/gpu] speculative binning spoiled: bits %d, deal bits %d (%d components, %d bins, grid %d)\n", spec[4], spec[7], spec[5], spec[6], unverified_bins_);
             if (spec_bins_failed_) { spec_bins_ok_ = false; return; }      // (the fingerprint word is spoiled: synchronize() rebuilds — and recomputes the components)
-            labels_valid_ = true; labels_nb_ = nb_;                         // the components this build used (computed, or kept and confirmed joint by joint) stand
             const int nbins = std::min(spec[0], unverified_bins_);
             unsigned long long hash = 0;
             std::memcpy(&hash, spec + 8, sizeof hash);
@@ -583,7 +582,7 @@ int DeviceSolver::collect_stats(unsigned long long* extra, const unsigned long l
             sched_.lds_groups = nbins;
             spec_bins_guess_ = nbins; ncomp_guess_ = spec[5];
             stats_.lds_islands = nbins;
-            tables_pending_ = true; tables_bins_ = nbins; tables_comps_ = std::min(spec[5], std::min(BINC_MAX, nb_));
+            tables_pending_ = true; tables_bins_ = nbins; tables_comps_ = std::min(spec[5], std::min(BINC_MAX, nb_)); tables_set_ = bld_.cur;
             return;
         }
         sched_.lds_colours = 0;
@@ -686,6 +685,7 @@ int DeviceSolver::synchronize(const std::function<int()>* while_waiting, const M
             const bool keep_defer = defer_build_check_;
             defer_build_check_ = false;
             cur_ = p.arrays;
+            build_cps_ = static_cast<const phx_contact_point*>(p.cps);
             const int rebuilt = ensure_schedule(p.arrays.view.mpos, p.nb, static_cast<const phx_contact_joint*>(p.joints), p.nj, p.ncp, p.cfg, true);
             defer_build_check_ = keep_defer;
             PHX_TRY(rebuilt);
@@ -714,9 +714,9 @@ int DeviceSolver::fetch_build_tables()
     const int nbins = tables_bins_, ncomp = tables_comps_;
     std::vector<int> goff((size_t)nbins + 1, 0), ncol((size_t)std::max(nbins, 1), 0);
     std::vector<unsigned> comp_size((size_t)std::max(ncomp, 1), 0u);
-    PHX_TRY(rb_.add(goff.data(), bld_.bin_tables.p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
+    PHX_TRY(rb_.add(goff.data(), bld_.bin_tables_s[tables_set_].p + 2 * BINC_MAX, goff.size() * sizeof(int), stream_));
     if (nbins) PHX_TRY(rb_.add(ncol.data(), isl_.ncol.p, (size_t)nbins * sizeof(int), stream_));
-    if (ncomp) PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, (size_t)ncomp * sizeof(unsigned), stream_));
+    if (ncomp) PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size_s[tables_set_].p, (size_t)ncomp * sizeof(unsigned), stream_));
     PHX_TRY(rb_.wait(stream_));
     tables_pending_ = false;
     sched_.group_offsets.assign(goff.begin(), goff.end());

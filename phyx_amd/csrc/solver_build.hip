@@ -45,6 +45,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
     // exploit body-disjoint islands (groups solved out of LDS)
     const bool want_islands = cfg.island_mode != PHX_ISLAND_SINGLE && !opt_.no_islands;
     const bool device_builder = opt_.gpu_builder && !force_host_builder_;
+    if (prelabel_pending_ && !(known_changed && device_builder)) PHX_TRY(cancel_prelabel());      // (nobody will pick the side stream's bins up: they must not survive into a later step)
     const bool no_hash = known_changed && device_builder && spec_build_applies(want_islands, nj);
     if (no_hash) begin_set(false);
     else PHX_TRY(launch_fingerprint(d_bodies, nb, d_joints, nj, ncp));
@@ -225,16 +226,21 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
 constexpr int JP_BATCH = 8;          // colouring rounds queued between two looks at the frontier sizes
 constexpr int JP_ROUNDS_MAX = 512;
 
+// the launch grid of a speculative build's per-bin kernels: last build's bin count with slack
+// (workgroups beyond the real bin count leave at once, and a settling world doubles its bins within a few steps — columns
+//  break in two: a roomy grid costs nothing, a grid too small costs a repeated solve)
+int DeviceSolver::spec_grid() const { return 2 * spec_bins_guess_ + 64; }
+
 int DeviceSolver::prelabel_mark()
 {
     prelabel_marked_ = false;
-    if (opt_.no_prelabel || opt_.no_incremental || !opt_.gpu_builder || !side_stream_) return PHX_OK;
-    // only where the next rebuild would keep them: the path without a host round trip (spec_build_applies), on an island-mode schedule
+    if (prelabel_pending_) PHX_TRY(cancel_prelabel());          // (a mark without a rebuild in between: the old side work is void)
+    if (opt_.no_prelabel || !opt_.gpu_builder || !side_stream_) return PHX_OK;
+    // only where the next rebuild would use them: the path without a host round trip (spec_build_applies), on an island-mode schedule
     if (!sched_.valid || !sched_.islands || sched_.has_hbm_group() || !spec_build_applies(true, 1)) return PHX_OK;
     PHX_TRY(use_device(device_));
-    PHX_HIP(hipEventRecord(ev_pre_fork_, stream_));          // behind everything that wrote the manifolds and last read the labels
+    PHX_HIP(hipEventRecord(ev_pre_fork_, stream_));          // behind everything that wrote the manifolds
     prelabel_marked_ = true;
-    labels_valid_ = false;                                   // (nobody reads the labels while they are being made)
     return PHX_OK;
 }
 
@@ -245,24 +251,47 @@ int DeviceSolver::prelabel_components(const float4* d_mpos, int nb, const phx_ma
     if (nb <= 0 || nm <= 0 || !d_mpos || !d_manifolds) return PHX_OK;
     PHX_TRY(use_device(device_));
     const int nbs = std::max(nb, 1);
-    // (the sizes the rebuild asks for, so that it finds these very arrays)
-    PHX_TRY(bld_.cc_parent.reserve(nbs)); PHX_TRY(bld_.cc_static.reserve(nbs)); PHX_TRY(bld_.cc_flags.reserve(nbs + 1)); PHX_TRY(bld_.comp_size.reserve(nbs + 1));
-    PHX_TRY(bld_.comp_units.reserve(nbs + 1)); PHX_TRY(bld_.sb_small.reserve(8));
-    RoctxRange range("GatherIslands (components from the manifolds, side stream)");
+    const int set = bld_.cur ^ 1;                            // (the set the last build did not use: solver.h)
+    const int grid = spec_grid();
+    PHX_TRY(bld_.cc_parent.reserve(nbs)); PHX_TRY(bld_.cc_static.reserve(nbs)); PHX_TRY(bld_.cc_flags.reserve(nbs + 1)); PHX_TRY(bld_.comp_size_s[set].reserve(nbs + 1));
+    PHX_TRY(bld_.comp_units_s[set].reserve(nbs + 1)); PHX_TRY(bld_.sb_small.reserve(8)); PHX_TRY(bld_.side_flags.reserve(4));
+    PHX_TRY(bld_.bin_tables_s[set].reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
+    PHX_TRY(bld_.bin_result.reserve(16)); PHX_TRY(bld_.bin_cursor.reserve((size_t)grid + 2));
+    if (!bld_.bin_scratch.p) {
+        PHX_TRY(bld_.bin_scratch.reserve(2 * (size_t)BINC_T + 2));
+        PHX_HIP(hipMemsetAsync(bld_.bin_scratch.p, 0, bld_.bin_scratch.cap * sizeof(unsigned long long), stream_));
+        PHX_HIP(hipEventRecord(ev_pre_fork_, stream_));      // (the side stream must see the cleared scratch)
+    }
+    RoctxRange range("GatherIslands (components, counts and bins from the manifolds, side stream)");
     PHX_HIP(hipStreamWaitEvent(side_stream_, ev_pre_fork_, 0));
-    hipLaunchKernelGGL(k_cc_init_bodies, dim3(grid_for(nb)), dim3(256), 0, side_stream_, d_mpos, nb, bld_.cc_parent.p, bld_.cc_static.p);
+    hipLaunchKernelGGL(k_cc_init_bodies, dim3(grid_for(nb)), dim3(256), 0, side_stream_, d_mpos, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.side_flags.p);
     hipLaunchKernelGGL(k_cc_link_manifolds, dim3(grid_for(nm)), dim3(256), 0, side_stream_, d_manifolds, nm, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p);
     hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, side_stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
-    PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
+    PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size_s[set].p, bld_.comp_units_s[set].p}, bld_.cc_flags.p, nb + 1,
                                      reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.prelabel_scan, side_stream_));
+    hipLaunchKernelGGL(k_manifold_components, dim3(std::max(1, std::min(div_up(nm, JC_T), 1024))), dim3(JC_T), 0, side_stream_, d_manifolds, nm, nb, (const int*)bld_.cc_parent.p,
+                       (const unsigned*)bld_.cc_flags.p, bld_.comp_size_s[set].p, bld_.comp_units_s[set].p, bld_.side_flags.p);
+    // the bins: k_bin_components, as the rebuild would launch it — but the solve's gate is armed later, by k_joint_scatter (the control word belongs to the main stream)
+    BinCompView cv{};
+    cv.comp_size = bld_.comp_size_s[set].p; cv.comp_units = bld_.comp_units_s[set].p; cv.cc_small = bld_.sb_small.p; cv.nj = -1;
+    cv.cap_units = spec_lanes_; cv.small_units = ISL_T; cv.max_bins = grid;
+    cv.bin_of = bld_.bin_tables_s[set].p; cv.rank_of = bld_.bin_tables_s[set].p + BINC_MAX; cv.goff = bld_.bin_tables_s[set].p + 2 * BINC_MAX;
+    cv.result = bld_.bin_result.p; cv.cursor = bld_.bin_cursor.p;
+    cv.fingerprint = nullptr; cv.hash_out = nullptr; cv.gate = 0;
+    cv.scratch = bld_.bin_scratch.p;
+    const int bin_chunks = div_up(ncomp_guess_ + ncomp_guess_ / 4, BIN_CHUNK);
+    const int bin_groups = bin_chunks <= 3 * (BINC_T / 64) ? 1 : std::min(16, div_up(bin_chunks, BINC_T / 64));
+    hipLaunchKernelGGL(k_bin_components, dim3(bin_groups), dim3(BINC_T), 0, side_stream_, cv);
     PHX_HIP(hipGetLastError());
     PHX_HIP(hipEventRecord(ev_pre_join_, side_stream_));
     prelabel_pending_ = true; prelabel_nb_ = nb;
+    pre_manifolds_ = d_manifolds; pre_nm_ = nm; pre_grid_ = grid; pre_lanes_ = spec_lanes_;
     return PHX_OK;
 }
 
 int DeviceSolver::cancel_prelabel()
 {
+    prelabel_marked_ = false;
     if (!prelabel_pending_) return PHX_OK;
     prelabel_pending_ = false;
     PHX_HIP(hipStreamWaitEvent(stream_, ev_pre_join_, 0));   // (whatever the stream does to the builder's arrays next comes behind them)
@@ -271,10 +300,11 @@ int DeviceSolver::cancel_prelabel()
 
 int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, bool want_islands, bool* fallback)
 {
-    if (prelabel_pending_) {                                 // the components are on their way (prelabel_components): wait for them and keep them
+    bool from_manifolds = false;
+    if (prelabel_pending_) {                                 // the components and the bins are on their way (prelabel_components): wait for them and use them
         prelabel_pending_ = false;
         PHX_HIP(hipStreamWaitEvent(stream_, ev_pre_join_, 0));
-        if (prelabel_nb_ == nb) { labels_valid_ = true; labels_nb_ = nb; labels_hint_ = true; }
+        from_manifolds = prelabel_nb_ == nb && build_cps_ && pre_manifolds_ && spec_build_applies(want_islands, nj) && pre_grid_ == spec_grid() && pre_lanes_ == spec_lanes_;
     }
     *fallback = false;
     RoctxRange range("GatherIslands + PrepareIndices (schedule build)");          // ref: Solver.cpp:77, 135, 217, 285
@@ -284,32 +314,23 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!trace) return; (void)hipStreamSynchronize(stream_); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[schedule/gpu] %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count()); t0 = n; };
     const int nbs = std::max(nb, 1), njs = std::max(nj, 1);
-    PHX_TRY(bld_.cc_parent.reserve(nbs)); PHX_TRY(bld_.cc_static.reserve(nbs)); PHX_TRY(bld_.cc_flags.reserve(nbs + 1)); PHX_TRY(bld_.comp_size.reserve(nbs + 1));
+    if (from_manifolds) bld_.cur ^= 1;                       // (the side stream filled the other set of counters and bin tables)
+    PHX_TRY(bld_.cc_parent.reserve(nbs)); PHX_TRY(bld_.cc_static.reserve(nbs)); PHX_TRY(bld_.cc_flags.reserve(nbs + 1)); PHX_TRY(bld_.comp_size().reserve(nbs + 1));
     PHX_TRY(bld_.joint_comp.reserve(njs)); PHX_TRY(bld_.sb_small.reserve(8));
-    for (int k = 0; k < 2; ++k) { PHX_TRY(bld_.sort_keys[k].reserve(njs)); PHX_TRY(bld_.sort_vals[k].reserve(njs)); }
-    PHX_TRY(bld_.sort_hist.reserve(radix_hist_words(nj)));
+    PHX_TRY(bld_.rec_a.reserve(njs)); PHX_TRY(bld_.rec_b.reserve(njs));
     PHX_TRY(hbm_.order.reserve(njs));
-
-    // units (schedule.h): contact point -> first joint carrying it (reset by k_cc_init); the partners are found by the first hook
-    PHX_TRY(bld_.partner.reserve(njs)); PHX_TRY(bld_.comp_units.reserve(nbs + 1));
-    {
+    PHX_TRY(bld_.partner.reserve(njs)); PHX_TRY(bld_.comp_units().reserve(nbs + 1));
+    if (!from_manifolds) {
+        // units (schedule.h): contact point -> first joint carrying it (reset by k_cc_init); the partners are found by the linking pass
         const size_t had = bld_.partner_first.cap;
         PHX_TRY(bld_.partner_first.reserve(std::max(ncp_, 1)));
         if (bld_.partner_first.cap != had || bld_.partner_tag <= 1) {          // a new table, or the tags ran out: every entry reads 'nobody' again
             PHX_HIP(hipMemsetAsync(bld_.partner_first.p, 0xFF, bld_.partner_first.cap * sizeof(unsigned long long), stream_));
             bld_.partner_tag = 0xFFFFFFFEu;
         } else --bld_.partner_tag;
+        hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, nj))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p,
+                           d_joints, nj, ncp_, bld_.partner_first.p, bld_.partner_tag);
     }
-    // incremental rebuild (schedule_kernels.h k_cc_init_lite): the caller vouches that the last build's labels still are the components;
-    // only where the rebuild needs no host round trip (every stack scene) — the long way recomputes them
-    const bool hinted = labels_hint_;
-    labels_hint_ = false;                                   // (the hint is for this rebuild only)
-    build_lite_ = hinted && labels_valid_ && labels_nb_ == nb && !opt_.no_incremental && spec_build_applies(want_islands, nj);
-    labels_valid_ = false;                                  // (until this build is settled)
-    if (build_lite_) hipLaunchKernelGGL(k_cc_init_lite, dim3(grid_for(std::max(nb + 1, nj))), dim3(256), 0, stream_, nb, bld_.sb_small.p, d_joints, nj, ncp_, bld_.partner_first.p,
-                                        bld_.partner_tag, bld_.comp_size.p, bld_.comp_units.p);
-    else hipLaunchKernelGGL(k_cc_init, dim3(grid_for(std::max(nb, nj))), dim3(256), 0, stream_, d_bodies, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.sb_small.p,
-                            d_joints, nj, ncp_, bld_.partner_first.p, bld_.partner_tag);
     Schedule sc;
     sc.colour_offsets.assign(1, 0); sc.group_offsets.assign(1, 0); sc.group_first_colour.assign(1, 0); sc.group_body_offsets.assign(1, 0);
     sc.islands = want_islands; sc.lds_on_host = false;
@@ -317,7 +338,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     bool any_partitioned = false;        // some component has more than COLOUR_B_MAX_JOINTS joints (schedule.h)
     spec_bins_pending_ = false;
     if (spec_build_applies(want_islands, nj)) {
-        PHX_TRY(build_bins_speculative(d_bodies, nb, d_joints, nj, sc));
+        PHX_TRY(build_bins_speculative(d_bodies, nb, d_joints, nj, sc, from_manifolds));
         sched_ = std::move(sc);
         return PHX_OK;
     }
@@ -329,22 +350,24 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     unsigned ncomp_u = 0;
     std::vector<unsigned> comp_size, comp_units;
     int guess = 0;
+    for (int k = 0; k < 2; ++k) { PHX_TRY(bld_.sort_keys[k].reserve(njs)); PHX_TRY(bld_.sort_vals[k].reserve(njs)); }
+    PHX_TRY(bld_.sort_hist.reserve(radix_hist_words(nj)));
     {
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
                            (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
-        PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
+        PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size().p, bld_.comp_units().p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
         hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
-                           (const unsigned*)bld_.cc_flags.p, bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
+                           (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size().p, bld_.comp_units().p, bld_.sb_small.p);
         // fetch as many sizes as the previous build needed (+25 %); the rest, if any, in a second trip
         guess = std::min(nb, std::max(1024, ncomp_guess_ + ncomp_guess_ / 4));
         comp_size.assign(std::max(guess, 1), 0u); comp_units.assign(std::max(guess, 1), 0u);
         PHX_TRY(with_fingerprint());
         int pair[2] = {0, 0};                              // {labels disagree, component count}: adjacent words, one copy
         PHX_TRY(rb_.add(pair, bld_.sb_small.p, sizeof pair, stream_));
-        PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size.p, (size_t)guess * sizeof(unsigned), stream_));
-        PHX_TRY(rb_.add(comp_units.data(), bld_.comp_units.p, (size_t)guess * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_size.data(), bld_.comp_size().p, (size_t)guess * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_units.data(), bld_.comp_units().p, (size_t)guess * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
         if (pair[0]) { set_error("connected components: a joint's bodies carry different labels"); return PHX_ERR_STATE; }
         ncomp_u = (unsigned)pair[1];
@@ -354,8 +377,8 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     ncomp_total = ncomp;
     if (ncomp > guess) {
         comp_size.resize(ncomp); comp_units.resize(ncomp);
-        PHX_TRY(rb_.add(comp_size.data() + guess, bld_.comp_size.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
-        PHX_TRY(rb_.add(comp_units.data() + guess, bld_.comp_units.p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_size.data() + guess, bld_.comp_size().p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
+        PHX_TRY(rb_.add(comp_units.data() + guess, bld_.comp_units().p + guess, (size_t)(ncomp - guess) * sizeof(unsigned), stream_));
         PHX_TRY(rb_.wait(stream_));
     }
     comp_size.resize(std::max(ncomp, 1)); comp_units.resize(std::max(ncomp, 1));
@@ -400,15 +423,15 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     sc.lds_groups = nbins;
     // one upload: component -> bin, component -> rank inside its bin, bin -> first slot
     const size_t nc1 = (size_t)std::max(ncomp, 1), table_words = 2 * nc1 + (size_t)nbins + 2;
-    PHX_TRY(bld_.bin_tables.reserve(table_words)); PHX_TRY(bld_.bin_tables_host.reserve(table_words));
+    PHX_TRY(bld_.bin_tables().reserve(table_words)); PHX_TRY(bld_.bin_tables_host.reserve(table_words));
     std::copy(bin_of.begin(), bin_of.end(), bld_.bin_tables_host.p);
     std::copy(rank_of.begin(), rank_of.end(), bld_.bin_tables_host.p + nc1);
     std::copy(sc.group_offsets.begin(), sc.group_offsets.begin() + nbins + 1, bld_.bin_tables_host.p + 2 * nc1);
     if (table_words <= 65536)
         hipLaunchKernelGGL(k_upload_words, dim3(std::max(1, std::min(div_up((int)table_words, 256), 64))), dim3(256), 0, stream_,
-                           reinterpret_cast<unsigned*>(bld_.bin_tables.p), reinterpret_cast<const unsigned*>(bld_.bin_tables_host.p), (int)table_words);
-    else PHX_HIP(hipMemcpyAsync(bld_.bin_tables.p, bld_.bin_tables_host.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
-    const int* bin_of_comp = bld_.bin_tables.p; const int* rank_of_comp = bld_.bin_tables.p + nc1; const int* grp_goff = bld_.bin_tables.p + 2 * nc1;
+                           reinterpret_cast<unsigned*>(bld_.bin_tables().p), reinterpret_cast<const unsigned*>(bld_.bin_tables_host.p), (int)table_words);
+    else PHX_HIP(hipMemcpyAsync(bld_.bin_tables().p, bld_.bin_tables_host.p, table_words * sizeof(int), hipMemcpyHostToDevice, stream_));
+    const int* bin_of_comp = bld_.bin_tables().p; const int* rank_of_comp = bld_.bin_tables().p + nc1; const int* grp_goff = bld_.bin_tables().p + 2 * nc1;
     lap("bin");
 
     // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
@@ -431,8 +454,10 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     if (nbins) {
         BinBuildView bv{};
         PHX_TRY(isl_.units.reserve(nbins)); PHX_TRY(isl_.unit_recs.reserve(2 * (size_t)nbins * cap_units));
-        bv.sorted_joints = bld_.sort_vals[where].p; bv.group_offsets = grp_goff; bv.joints = d_joints; bv.partner = bld_.partner.p; bv.is_static = bld_.cc_static.p;
-        bv.joint_comp = bld_.joint_comp.p; bv.comp_rank = rank_of_comp;
+        // (the sort left the bins' joints in joint order: their records, slot by slot — k_build_bin's own sort then finds them in order)
+        hipLaunchKernelGGL(k_bin_records, dim3(grid_for(lds_slots)), dim3(256), 0, stream_, (const unsigned*)bld_.sort_vals[where].p, lds_slots, d_joints, (const int*)bld_.partner.p,
+                           (const unsigned char*)bld_.cc_static.p, (const int*)bld_.joint_comp.p, rank_of_comp, bld_.rec_a.p, bld_.rec_b.p, bld_.sb_small.p + 2);
+        bv.rec_a = bld_.rec_a.p; bv.rec_b = bld_.rec_b.p; bv.group_offsets = grp_goff; bv.cursor = nullptr; bv.spoil = nullptr;
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = hbm_.order.p; bv.slot_local = isl_.slot_local.p; bv.slot_colour = isl_.slot_colour.p; bv.desc = isl_.desc.p; bv.ncol = isl_.ncol.p;
         bv.units = isl_.units.p; bv.unit_recs = isl_.unit_recs.p;
@@ -486,7 +511,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         jv.ent = bld_.jp_ent.p; jv.offset = bld_.jp_offset.p; jv.cursor = bld_.jp_cursor.p; jv.adj = bld_.jp_adj.p; jv.ent_comp = bld_.jp_ent_comp.p;
         jv.succ = bld_.jp_succ.p; jv.pred = bld_.jp_pred.p;
         jv.used = bld_.jp_used.p; jv.used_b = bld_.jp_used_b.p; jv.colour = bld_.jp_keys[0].p; jv.colour_b = bld_.jp_colour_b.p; jv.touched = bld_.jp_touched.p;
-        jv.joint_comp = bld_.joint_comp.p; jv.partner = bld_.partner.p; jv.kind = bld_.jp_kind.p; jv.ncomp = ncomp_total; jv.comp_size = bld_.comp_size.p;
+        jv.joint_comp = bld_.joint_comp.p; jv.partner = bld_.partner.p; jv.kind = bld_.jp_kind.p; jv.ncomp = ncomp_total; jv.comp_size = bld_.comp_size().p;
         jv.seen_a = bld_.jp_seen.p; jv.seen_b = bld_.jp_seen.p + ncomp_total + 1; jv.seen_c = bld_.jp_seen.p + 2 * ((size_t)ncomp_total + 1); jv.bad_b = bld_.jp_bad_b.p;
         jv.counts = bld_.jp_counts.p; jv.flags = bld_.jp_small.p; jv.hist = reinterpret_cast<unsigned*>(bld_.jp_small.p + 4);
         const unsigned* perm = nullptr;                     // the entries sorted by part (partitioned components only)
@@ -611,7 +636,6 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     spec_bins_ok_ = want_islands && rest == 0 && nbins > 0 && ncomp_total <= BINC_MAX;
     spec_bins_guess_ = nbins; spec_lanes_ = sc.lds_lanes;
     sched_ = std::move(sc);
-    labels_valid_ = true; labels_nb_ = nb;                  // (the long way: the components were computed and their convergence read back)
     return PHX_OK;
 }
 
@@ -623,70 +647,60 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
 // spoils the solve's fingerprint word like a rejected bin does: the solve commits nothing, synchronize() rebuilds the
 // long way and repeats it.  The topology hash the host has not seen is replaced on the device by a constant it knows
 // (`gate_expected_`), which is what the solve's kernels compare the word with; the hash itself comes back with the results.
-int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc)
+int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const phx_contact_joint* d_joints, int nj, Schedule& sc, bool from_manifolds)
 {
-    if (build_lite_) {
-        // the labels, the root numbers and the component count stand (k_cc_init_lite has cleared the counters): three launches fewer
-        ++lite_builds_;
-        hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
-                           (const unsigned*)bld_.cc_flags.p, bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p,
-                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_);
-    } else {
-    ++full_builds_;
-    hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                       (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
-    hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
-    PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size.p, bld_.comp_units.p}, bld_.cc_flags.p, nb + 1,
-                                     reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
-    hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
-                       (const unsigned*)bld_.cc_flags.p, bld_.partner.p, bld_.joint_comp.p, bld_.comp_size.p, bld_.comp_units.p, bld_.sb_small.p);
-    }
-    // (workgroups beyond the real bin count leave at once, and a settling world doubles its bins within a few steps — columns
-    //  break in two: a roomy grid costs nothing, a grid too small costs a repeated solve)
-    // (up to 2047 bins the joints are grouped by ONE 11-bit radix pass — three launches instead of six — so a grid just above
-    //  that is capped there while it still leaves a quarter of slack)
-    int grid = 2 * spec_bins_guess_ + 64;
-    if (grid > 2047 && spec_bins_guess_ + spec_bins_guess_ / 4 + 16 <= 2047) grid = 2047;
+    const int grid = spec_grid();
     const int cap_units = spec_lanes_, cap_bodies = cap_units > ISL_T ? ISL_B_BIG : ISL_B;
-    PHX_TRY(bld_.bin_tables.reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
-    PHX_TRY(bld_.bin_result.reserve(16));
-    BinCompView cv{};
-    cv.comp_size = bld_.comp_size.p; cv.comp_units = bld_.comp_units.p; cv.cc_small = bld_.sb_small.p; cv.nj = nj;
-    cv.cap_units = cap_units; cv.small_units = ISL_T; cv.max_bins = grid;
-    cv.bin_of = bld_.bin_tables.p; cv.rank_of = bld_.bin_tables.p + BINC_MAX; cv.goff = bld_.bin_tables.p + 2 * BINC_MAX;
-    cv.result = bld_.bin_result.p;
-    cv.fingerprint = hash_.p + hash_slot_; cv.hash_out = reinterpret_cast<unsigned long long*>(bld_.bin_result.p + 8);
+    PHX_TRY(bld_.bin_tables().reserve(2 * (size_t)BINC_MAX + (size_t)grid + 2));
+    PHX_TRY(bld_.bin_result.reserve(16)); PHX_TRY(bld_.bin_cursor.reserve((size_t)grid + 2)); PHX_TRY(bld_.side_flags.reserve(4));
     gate_expected_ = 0x5EED000000000000ull | (++gate_serial_ & 0xFFFFFFFFFFFFull);
-    cv.gate = gate_expected_;
-    // (a workgroup packs 16 chunks of 64 components at a time: as many workgroups as last build's component count asks for — from
-    //  four rounds on; below that the hand-over through memory costs more than it saves: 15.7 against 9.6 us at cfg 2's 16 chunks)
-    const int bin_chunks = div_up(ncomp_guess_ + ncomp_guess_ / 4, BIN_CHUNK);
-    const int bin_groups = bin_chunks <= 3 * (BINC_T / 64) ? 1 : std::min(16, div_up(bin_chunks, BINC_T / 64));
-    if (!bld_.bin_scratch.p) {
-        PHX_TRY(bld_.bin_scratch.reserve(2 * (size_t)BINC_T + 2));
-        PHX_HIP(hipMemsetAsync(bld_.bin_scratch.p, 0, bld_.bin_scratch.cap * sizeof(unsigned long long), stream_));
+    int* const bin_of = bld_.bin_tables().p; int* const rank_of = bld_.bin_tables().p + BINC_MAX; int* const goff = bld_.bin_tables().p + 2 * BINC_MAX;
+    ScatterView sv{};
+    sv.joints = d_joints; sv.nj = nj; sv.nb = nb; sv.parent = bld_.cc_parent.p; sv.root_number = bld_.cc_flags.p;
+    sv.bin_of = bin_of; sv.rank_of = rank_of; sv.goff = goff; sv.result = bld_.bin_result.p; sv.max_bins = grid; sv.cursor = bld_.bin_cursor.p;
+    sv.rec_a = bld_.rec_a.p; sv.rec_b = bld_.rec_b.p; sv.rejected = bld_.sb_small.p + 2; sv.side_flags = bld_.side_flags.p;
+    const int scatter_grid = std::max(1, std::min(div_up(nj, 256), 2048));
+    if (from_manifolds) {
+        // components, counts and bins stand (side stream): the joints are dealt to their bins and the bins built — two launches
+        ++lite_builds_;
+        sv.manifolds = pre_manifolds_; sv.nm = pre_nm_; sv.cps = build_cps_; sv.ncp = ncp_;
+        sv.fingerprint = hash_.p + hash_slot_; sv.hash_out = reinterpret_cast<unsigned long long*>(bld_.bin_result.p + 8); sv.gate = gate_expected_;
+        hipLaunchKernelGGL((k_joint_scatter<true>), dim3(scatter_grid), dim3(256), 0, stream_, sv);
+    } else {
+        ++full_builds_;
+        hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
+                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
+        hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
+        PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size().p, bld_.comp_units().p}, bld_.cc_flags.p, nb + 1,
+                                         reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
+        hipLaunchKernelGGL(k_joint_components, dim3(std::max(1, std::min(div_up(nj, JC_T), 1024))), dim3(JC_T), 0, stream_, d_joints, nj, nb, (const int*)bld_.cc_parent.p,
+                           (const unsigned*)bld_.cc_flags.p, (const int*)bld_.partner.p, bld_.joint_comp.p, bld_.comp_size().p, bld_.comp_units().p, bld_.sb_small.p);
+        BinCompView cv{};
+        cv.comp_size = bld_.comp_size().p; cv.comp_units = bld_.comp_units().p; cv.cc_small = bld_.sb_small.p; cv.nj = nj;
+        cv.cap_units = cap_units; cv.small_units = ISL_T; cv.max_bins = grid;
+        cv.bin_of = bin_of; cv.rank_of = rank_of; cv.goff = goff;
+        cv.result = bld_.bin_result.p; cv.cursor = bld_.bin_cursor.p;
+        cv.fingerprint = hash_.p + hash_slot_; cv.hash_out = reinterpret_cast<unsigned long long*>(bld_.bin_result.p + 8);
+        cv.gate = gate_expected_;
+        // (a workgroup packs 16 chunks of 64 components at a time: as many workgroups as last build's component count asks for — from
+        //  four rounds on; below that the hand-over through memory costs more than it saves: 15.7 against 9.6 us at cfg 2's 16 chunks)
+        const int bin_chunks = div_up(ncomp_guess_ + ncomp_guess_ / 4, BIN_CHUNK);
+        const int bin_groups = bin_chunks <= 3 * (BINC_T / 64) ? 1 : std::min(16, div_up(bin_chunks, BINC_T / 64));
+        if (!bld_.bin_scratch.p) {
+            PHX_TRY(bld_.bin_scratch.reserve(2 * (size_t)BINC_T + 2));
+            PHX_HIP(hipMemsetAsync(bld_.bin_scratch.p, 0, bld_.bin_scratch.cap * sizeof(unsigned long long), stream_));
+        }
+        cv.scratch = bld_.bin_scratch.p;
+        hipLaunchKernelGGL(k_bin_components, dim3(bin_groups), dim3(BINC_T), 0, stream_, cv);
+        sv.partner = bld_.partner.p;
+        hipLaunchKernelGGL((k_joint_scatter<false>), dim3(scatter_grid), dim3(256), 0, stream_, sv);
     }
-    cv.scratch = bld_.bin_scratch.p;
-    hipLaunchKernelGGL(k_bin_components, dim3(bin_groups), dim3(BINC_T), 0, stream_, cv);
-    int bits = 1, where = 0;
-    while ((1 << bits) <= grid) ++bits;
-    {   // the keys, counted for the sort's first pass where they are made
-        const int key_blocks = std::max(1, div_up(nj, RS_TILE));
-        if (radix_digit_bits(bits) == RS_WIDE_BITS)
-            hipLaunchKernelGGL((k_joint_bin_keys_hist<RS_WIDE_BITS>), dim3(key_blocks), dim3(RS_THREADS), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
-                               bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX, key_blocks, bld_.sort_hist.p);
-        else
-            hipLaunchKernelGGL((k_joint_bin_keys_hist<8>), dim3(key_blocks), dim3(RS_THREADS), 0, stream_, (const int*)bld_.joint_comp.p, (const int*)cv.bin_of, nj, grid,
-                               bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, BINC_MAX, key_blocks, bld_.sort_hist.p);
-    }
-    PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where, true));
     PHX_TRY(isl_.desc.reserve(grid)); PHX_TRY(isl_.ncol.reserve(grid));
     PHX_TRY(isl_.bodies.reserve((size_t)grid * cap_bodies));
     PHX_TRY(isl_.slot_local.reserve(nj)); PHX_TRY(isl_.slot_colour.reserve(nj));
     PHX_TRY(isl_.units.reserve(grid)); PHX_TRY(isl_.unit_recs.reserve(2 * (size_t)grid * cap_units));
     BinBuildView bv{};
-    bv.sorted_joints = bld_.sort_vals[where].p; bv.group_offsets = cv.goff; bv.joints = d_joints; bv.partner = bld_.partner.p; bv.is_static = bld_.cc_static.p;
-    bv.joint_comp = bld_.joint_comp.p; bv.comp_rank = cv.rank_of;
+    bv.rec_a = bld_.rec_a.p; bv.rec_b = bld_.rec_b.p; bv.group_offsets = goff; bv.cursor = bld_.bin_cursor.p; bv.spoil = bld_.bin_result.p + 7;
     bv.nb = nb; bv.max_static = 1 << 30;
     bv.order = hbm_.order.p; bv.slot_local = isl_.slot_local.p; bv.slot_colour = isl_.slot_colour.p; bv.desc = isl_.desc.p; bv.ncol = isl_.ncol.p;
     bv.units = isl_.units.p; bv.unit_recs = isl_.unit_recs.p;

@@ -37,6 +37,7 @@ public:
     int step_end(float dt);
     int set_comm(Comm* c);
     int step_sharded(float dt, const phx_config& cfg);
+    int step_sharded_inner(float dt, const phx_config& cfg);
     int check_exchange();
     int x_extent(float out[2]);
     hipStream_t stream() const { return stream_; }
@@ -97,9 +98,7 @@ private:
     // only if a manifold did die is the pack run then and the match repeated (a new epoch makes the first one void)
     bool pack_pending_ = false, expect_no_dead_manifolds_ = false;
     unsigned joint_epoch_ = 0;
-    bool bodies_changed_ = true;             // bodies were uploaded since the last schedule rebuild (static-ness is part of the labels)
     bool packed_this_step_ = false;          // PackManifolds moved manifolds in this step
-    bool topo_unchanged_ = false;            // refresh_contact_joints: this step's joint changes left the connected components alone (solver.h set_labels_hint)
     const MailRide* old_ride_ = nullptr;     // update_pairs: the post the old manifolds' UpdateManifolds launch carries
     ScanScratch scan_tiles_;     // counters_: [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
     Readback rb_;
@@ -204,7 +203,6 @@ int World::sync_bodies_to_device()
     PHX_HIP(hipStreamSynchronize(stream_));
     bodies_dirty_ = false;
     records_stale_ = false;
-    bodies_changed_ = true;                                                 // (masses may have changed: no incremental rebuild on the old labels)
     return PHX_OK;
 }
 
@@ -232,7 +230,7 @@ int World::update_pairs()                                                   // r
     // GPU used to idle through it.  The new pairs' manifolds follow in update_manifolds().  (Not with per-phase timing: the phases
     // would overlap.)
     manifolds_updated_ = 0;
-    packed_this_step_ = false; topo_unchanged_ = false;
+    packed_this_step_ = false;
     const std::function<int()> old_manifolds = [this]() -> int {
         if (!nm) return PHX_OK;
         PHX_TRY(scratch_for(nm));
@@ -318,8 +316,7 @@ int World::refresh_contact_joints()                                         // r
     }
     // One host round trip for the counts.  A joint is dead iff no contact point re-attached it (the match), which is
     // known before the new joints exist; the new joints are appended behind the old ones and are alive by construction.
-    unsigned host[5] = {0, 0, 0, 0, 0};                                     // [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points, [4] topology bits (k_joints_match)
-    const int* labels = solver_.labels_device();                            // (null: the solver has no labels it trusts — no incremental rebuild this step)
+    unsigned host[4] = {0, 0, 0, 0};                                        // [0] new joints, [1] dead joints, [2] dead manifolds, [3] dropped points
     for (;;) {
         if (++joint_epoch_ == 0) {                                          // the epoch wrapped: stale stamps could alias
             PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
@@ -327,18 +324,16 @@ int World::refresh_contact_joints()                                         // r
         }
         if (nm) {
             hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
-                               d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p, labels, nb(), counters_.p + 4);
+                               d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p);
             PHX_TRY(device_exclusive_scan(flags_.p, nm, counters_.p, scan_tiles_, stream_));
         }
-        if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_, (const phx_contact_joint*)d_joints_.p, (const phx_manifold*)d_manifolds_.p, nm,
-                                                               labels ? counters_.p + 4 : (unsigned*)nullptr},
-                                                 dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
-        if (nm || nj || pack_pending_) {                                    // counters_[0 .. 4]: adjacent words, one copy
-            unsigned got[5] = {0, 0, 0, 0, 0};
+        if (nj) PHX_TRY(device_exclusive_scan_of(JointDeadLoad{(const unsigned*)joint_seen_.p, joint_epoch_}, dead_flags_.p, nj, counters_.p + 1, scan_tiles_, stream_));
+        if (nm || nj || pack_pending_) {                                    // counters_[0 .. 3]: adjacent words, one copy
+            unsigned got[4] = {0, 0, 0, 0};
             PHX_TRY(rb_.add(got, counters_.p, sizeof got, stream_));
             PHX_TRY(solver_.prelabel_components((const float4*)mpos_.p, nb(), (const phx_manifold*)d_manifolds_.p, nm));      // (once: the mark is consumed)
             PHX_TRY(rb_.wait(stream_));
-            host[0] = got[0]; host[1] = got[1]; host[4] = got[4];
+            host[0] = got[0]; host[1] = got[1];
             if (pack_pending_) { host[2] = got[2]; host[3] = got[3]; }      // (else PackManifolds has settled them already)
             if (!nm) host[0] = 0;                                           // (not written this step)
             if (!nj) host[1] = 0;
@@ -348,19 +343,18 @@ int World::refresh_contact_joints()                                         // r
         pack_pending_ = false;
         const int nm_before = nm;
         ++deferred_packs;
-        if (host[2]) PHX_TRY(device_exclusive_scan(pack_flags_.p, nm, counters_.p + 2, scan_tiles_, stream_));      // (the bet was lost: now the flags are scanned)
+        if (host[2]) {
+            // the bet was lost: now the flags are scanned, and the manifolds MOVE — under the side stream, which is reading them to count
+            // and bin the components: what it makes of them is void, and this step's rebuild takes its components from the joints
+            PHX_TRY(solver_.cancel_prelabel());
+            PHX_TRY(device_exclusive_scan(pack_flags_.p, nm, counters_.p + 2, scan_tiles_, stream_));
+        }
         PHX_TRY(finish_pack((int)host[2], (int)host[3]));
         if (nm == nm_before) break;
         ++deferred_pack_retries;                                            // the bet was lost: match again under a new epoch (one more pass: nothing is pending now)
     }
     const int fresh = (int)host[0], dead = (int)host[1], old = nj;
     const int total = nj + fresh;
-    // the incremental rebuild's hint (solver.h set_labels_hint): the solver's labels were there to test against, no new joint bridges
-    // two components, no unit vanished, and PackManifolds moved nothing this step (a dead joint's manifold was looked up by its index)
-    topo_unchanged_ = labels != nullptr && host[4] == 0 && !packed_this_step_;
-    static const bool trace_topo = getenv("PHX_TRACE_TOPO") != nullptr;
-    if (trace_topo) fprintf(stderr, "[topology] labels %d bits %u (1 = a new joint bridges two components, 2 = a unit vanished) packed %d new joints %d dead joints %d\n",
-                            labels != nullptr, host[4], (int)packed_this_step_, fresh, dead);
     if (dead) PHX_TRY(mover_pos_.reserve((size_t)total + 2));
     if (fresh) {
         joints_changed_ = true;
@@ -385,10 +379,7 @@ int World::solve(const phx_config& cfg, bool settle)                        // r
 {
     // island sharding: the solver sweeps only this rank's groups (DeviceSolver::set_shard); the other groups' bodies
     // keep their velocities here
-    solver_.set_labels_hint(joints_changed_ && topo_unchanged_ && !bodies_changed_);
-    if (!joints_changed_) PHX_TRY(solver_.cancel_prelabel());              // (no rebuild will pick the side stream's labels up)
-    topo_unchanged_ = false;
-    if (joints_changed_) bodies_changed_ = false;                           // (this solve rebuilds: its labels know the bodies as they are now)
+    if (!joints_changed_) PHX_TRY(solver_.cancel_prelabel());              // (no rebuild will pick the side stream's bins up)
     PHX_TRY(solver_.solve_resident(resident().s, nb(), d_cps_.p, 2 * nm, d_joints_.p, nj, cfg, joints_changed_));
     joints_changed_ = false;
     // a solve that is still unverified (it ran speculatively on the cached schedule, or on a device-built schedule whose 'every
@@ -456,8 +447,10 @@ int World::pre_solve(float dt)
     // list is still being matched, extended and compacted (solver.h prelabel_components) — not with per-phase timing: the phases overlap
     // (marked here — the manifolds are final from this point of the stream on — and queued from refresh_contact_joints, once the stream has
     //  the match and its scans to run while the host queues the side stream's kernels)
-    if (!phase_timing) PHX_TRY(solver_.prelabel_mark());
     { RoctxRange r("PackManifolds"); PHX_TRY(pack_manifolds()); lap(4); }                            // ref: Collider.cpp:381
+    // (marked BEHIND PackManifolds: a pack that runs here moves manifolds, and the side stream must read them where they end up —
+    //  ADVICE r5; a pack that is only found necessary later, with the joint counts, voids the side stream's work: refresh_contact_joints)
+    if (!phase_timing) PHX_TRY(solver_.prelabel_mark());
     { RoctxRange r("RefreshContactJoints"); PHX_TRY(refresh_contact_joints()); lap(5); }             // ref: World.cpp:74
     return PHX_OK;
 }
@@ -503,6 +496,10 @@ int World::set_comm(Comm* c)
     PHX_TRY(use_device(device_));
     comm_ = c;
     agreed_seg_ = 0;
+    // from here on the stream carries collectives: every host wait on it is bounded (a peer that dies or stops stepping must end
+    // this rank's step with an error, not hang it — ADVICE r5)
+    const double bound = c ? Comm::timeout_s() : 0.0;
+    rb_.set_timeout(bound); solver_.set_wait_timeout(bound); broadphase_.set_wait_timeout(bound);
     if (!c) return PHX_OK;
     shard = c->rank(); shard_count = c->size();
     PHX_TRY(solver_.set_shard(shard, shard_count));
@@ -510,7 +507,16 @@ int World::set_comm(Comm* c)
     return ensure_exchange_capacity(1u << 20);
 }
 
+// (Any error return forgets the agreed segment size, on every rank alike — the failed one included: the next step's ranks then all
+//  wait for their agreement again, whatever this step left behind.)
 int World::step_sharded(float dt, const phx_config& cfg)
+{
+    const int st = step_sharded_inner(dt, cfg);
+    if (st != PHX_OK) agreed_seg_ = 0;
+    return st;
+}
+
+int World::step_sharded_inner(float dt, const phx_config& cfg)
 {
     if (!comm_) { set_error("phx_world_step_sharded needs a communicator (phx_world_set_comm)"); return PHX_ERR_STATE; }
     size_t seg = 0;
@@ -620,6 +626,7 @@ int World::synchronize()
 {
     PHX_TRY(use_device(device_));
     PHX_TRY(solver_.synchronize());
+    if (comm_) return comm_->wait_stream(stream_, "World::synchronize");      // (bounded: the stream carries collectives)
     PHX_HIP(hipStreamSynchronize(stream_));
     return PHX_OK;
 }

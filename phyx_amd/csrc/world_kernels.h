@@ -226,12 +226,9 @@ static __global__ void __launch_bounds__(256) k_pack_manifolds(phx_manifold* __r
 // Match, pass 1: matched points re-attach their joint and stamp it; count the points that need a new joint.  (A kernel of its
 // own: as the loader of its scan it was slower — 25 us against 9 + 5 at 2e5 manifolds, 112 us at 1e6: a scan workgroup is 1024
 // lanes of four items each, too few lanes in flight for this chain of dependent gathers.)
-// `labels` / `topo` (labels may be null): what the solver's incremental schedule rebuild needs to know (solver.h set_labels_hint) —
-// does a NEW joint connect two connected components of the last build?  labels[b] = root body of b's component, -1 for a static body;
-// topo bit 0 = some manifold that gets new joints joins two components (a conservative test: it may have joints already).
 static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold* __restrict__ manifolds, int nm, const phx_contact_point* __restrict__ cps,
                                                              phx_contact_joint* __restrict__ joints, unsigned* __restrict__ seen, unsigned epoch,
-                                                             unsigned* __restrict__ new_count, const int* __restrict__ labels, int nb, unsigned* __restrict__ topo)
+                                                             unsigned* __restrict__ new_count)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
         const phx_manifold m = manifolds[i];
@@ -242,30 +239,14 @@ static __global__ void __launch_bounds__(256) k_joints_match(const phx_manifold*
             else { joints[si].contact_point_index = m.point_index + k; seen[si] = epoch; }
         }
         new_count[i] = fresh;
-        if (fresh && labels && (unsigned)m.body1 < (unsigned)nb && (unsigned)m.body2 < (unsigned)nb) {
-            const int l1 = labels[m.body1], l2 = labels[m.body2];
-            if (l1 >= 0 && l2 >= 0 && l1 != l2) atomicOr(topo, 1u);
-        }
     }
 }
 
 // loader of the 'dead joints before joint i' scan (queued behind the match)
-// (`topo` bit 1, for the incremental rebuild: a dead joint whose manifold has no contact point left — a unit that vanished may have
-//  been the only link between two parts of its component.  The joint still carries last step's contact point index, and with it its
-//  manifold: valid in steps in which PackManifolds moved nothing, and the others are not incremental, world.hip.)
 struct JointDeadLoad {
     static constexpr bool in_place = false;
     const unsigned* seen; unsigned epoch;
-    const phx_contact_joint* joints; const phx_manifold* manifolds; int nm; unsigned* topo;
-    __device__ unsigned operator()(int i) const
-    {
-        const bool dead = seen[i] != epoch;
-        if (dead && topo) {
-            const unsigned m = (unsigned)joints[i].contact_point_index >> 1;
-            if (m >= (unsigned)nm || manifolds[m].point_count == 0) atomicOr(topo, 2u);
-        }
-        return dead ? 1u : 0u;
-    }
+    __device__ unsigned operator()(int i) const { return seen[i] != epoch ? 1u : 0u; }
     __device__ bool load4(int base, uint4& out) const      // (base is a multiple of four: device_scan.h; a dead joint is the rare case)
     {
         if (reinterpret_cast<uintptr_t>(seen) & 15u) return false;

@@ -39,7 +39,7 @@ def test_no_oracle_in_product():
 
 
 def test_abi_version_and_error_string(built_lib):
-    assert built_lib.phx_abi_version() == 1
+    assert built_lib.phx_abi_version() == 2
     assert isinstance(built_lib.phx_last_error(), bytes)
 
 

@@ -26,6 +26,16 @@ def test_falling_scene_is_reproducible():
     assert (np.abs(a["px"][1:]) <= 500).all() and (a["py"][1:] >= 50).all() and (a["py"][1:] <= 1000).all()
 
 
+def _priority(pid, j, lower):
+    """csrc/schedule.h colour_priority restated: units whose LOWER body index is even rank above the odd ones (bit 63), inside a parity
+    31 bits of a multiplicative hash of the priority id, the joint index breaks ties; never zero."""
+    x = (pid * 0x9E3779B1) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 13
+    return ((((~lower) & 1) << 63) | ((x >> 1) << 32) | j) + 1
+
+
 @pytest.mark.parametrize("ids", ["joint_index", "contact_point_index"])
 @pytest.mark.parametrize("name", list(SMALL_SCENES) + ["synthetic_units_and_near_misses", "wall48x60", "synthetic_one_big_component"])
 def test_colour_schedule_invariants(built_lib, name, ids):
@@ -79,7 +89,8 @@ def test_colour_schedule_invariants(built_lib, name, ids):
         assert len(np.unique(b)) == len(b), "class %d: two units touch a dynamic body" % c
     # the colouring rule: two first-fit candidates over the UNITS in priority order — A = smallest free colour, B = two-ended
     # — and every connected component keeps the one that gives it fewer colours
-    prio = {j: phyx_amd.schedule_priority(int(pid[j]), j) for j in leaders}
+    prio = {j: _priority(int(pid[j]), j, min(b1[j], b2[j])) for j in leaders}
+    assert all(prio[j] == phyx_amd.schedule_priority(int(pid[j]), j, min(b1[j], b2[j])) for j in leaders[:200])      # (the library states the same rule)
     assert len(set(prio.values())) == len(leaders) and min(prio.values()) > 0
     parent = list(range(len(bodies)))
 
@@ -232,7 +243,7 @@ def test_schedule_handles_hub_and_empty(built_lib):
     b1 = np.zeros(n, dtype=np.int32)
     b2 = np.arange(1, n + 1, dtype=np.int32)
     order, offs = phyx_amd.schedule_colours(b1, b2, np.zeros(n + 1, dtype=np.uint8))
-    prio = [phyx_amd.schedule_priority(j, j) for j in range(n)]
+    prio = [phyx_amd.schedule_priority(j, j, 0) for j in range(n)]
     assert len(offs) - 1 == n and list(order) == sorted(range(n), key=lambda j: -prio[j])      # one joint per colour, highest priority first
     # the same hub made static conflicts with nothing
     st = np.zeros(n + 1, dtype=np.uint8)

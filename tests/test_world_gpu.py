@@ -686,12 +686,13 @@ def test_debugging_knobs_do_not_change_results(built_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene", ["stack", "merge", "falling", "tilted"])
-def test_incremental_rebuild_builds_the_same_schedule(built_lib, scene):
-    """The incremental schedule rebuild (a step whose joint changes neither join two connected components nor remove a unit keeps the
-    last build's body labels: csrc/schedule_kernels.h k_cc_init_lite, world_kernels.h k_joints_match / JointDeadLoad) must build the
-    schedule the full rebuild builds — the schedule is a pure function of the joints.  tools/incremental_twin.py hashes the schedule
-    (slot order, class offsets, groups) and every array after every step; with PHX_NO_INCREMENTAL=1 the digest is the same, and
-    without it the stacks' steps really are incremental most of the time."""
+def test_rebuild_from_the_manifolds_builds_the_same_schedule(built_lib, scene):
+    """The World's schedule rebuild takes its connected components, their joint counts and the bins from the MANIFOLDS, on the side
+    stream, while the joint list is still being refreshed (csrc/schedule_kernels.h k_cc_link_manifolds, k_manifold_components), pairs the
+    joints into units through ContactPoint::solverIndex and deals them to their bins by a fill counter (k_joint_scatter<true>); it must
+    build the schedule the rebuild from the joints builds — the schedule is a pure function of the joints.  tools/build_twin.py hashes
+    the schedule (slot order, class offsets, groups) and every array after every step; with PHX_NO_PRELABEL=1 the digest is the same,
+    and without it the stacks' rebuilds really do come from the manifolds most of the time."""
     import os
     import subprocess
     import sys
@@ -700,13 +701,13 @@ def test_incremental_rebuild_builds_the_same_schedule(built_lib, scene):
     def run(extra):
         env = dict(os.environ)
         env.update(extra)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "incremental_twin.py"), scene, "45"], cwd=root, env=env, stdout=subprocess.PIPE,
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "build_twin.py"), scene, "45"], cwd=root, env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:]
         digest, lite, full = r.stdout.strip().splitlines()[-1].split()
         return digest, int(lite), int(full)
     d_inc, lite, full = run({})
-    d_full, lite0, full0 = run({"PHX_NO_INCREMENTAL": "1"})
+    d_full, lite0, full0 = run({"PHX_NO_PRELABEL": "1"})
     assert d_inc == d_full
     assert lite0 == 0 and full0 >= lite + full - 2
     if scene in ("stack", "merge"):

@@ -1,7 +1,9 @@
-"""The incremental schedule rebuild (csrc/schedule_kernels.h k_cc_init_lite) against the full one: a world is stepped and after every step
-the schedule the solver used (slot order, class offsets, groups) and every array are hashed; the digest must be the same with
-PHX_NO_INCREMENTAL=1 (every rebuild recomputes the connected components), and without it some rebuilds must have been incremental.
-usage: incremental_twin.py [scene=stack|falling|tilted|merge] [steps=40]   -> prints '<digest> <incremental builds> <full builds>'"""
+"""The schedule rebuild whose components, joint counts and bins come from the MANIFOLDS (side stream: csrc/schedule_kernels.h
+k_cc_link_manifolds, k_manifold_components, k_bin_components; the joints dealt by k_joint_scatter<true>) against the one that takes them from
+the joints: a world is stepped and after every step the schedule the solver used (slot order, class offsets, groups) and every array are
+hashed; the digest must be the same with PHX_NO_PRELABEL=1 (every rebuild from the joints), and without it some rebuilds must have come
+from the manifolds.
+usage: build_twin.py [scene=stack|falling|tilted|merge] [steps=40]   -> prints '<digest> <builds from the manifolds> <builds from the joints>'"""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

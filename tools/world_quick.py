@@ -16,7 +16,7 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 9):
     t0 = time.perf_counter(); w.Update(1/60, cfg); w.sync(); t.append(time.perf_counter() - t0)
 print("world step median %.3f ms (min %.3f, mean %.3f over %d), broadphase device %.3f ms" % (1e3 * float(np.median(t)), 1e3 * min(t), 1e3 * float(np.mean(t)), len(t), w.collider.stats().device_ms))
 lite, full = w.build_counts()
-print("schedule rebuilds: %d kept the connected components (incremental), %d recomputed them" % (lite, full))
+print("schedule rebuilds: %d took components and bins from the manifolds (side stream), %d from the joints" % (lite, full))
 if "-v" in sys.argv: print("per step ms:", " ".join("%.3f" % (1e3 * x) for x in t))
 ns1, c1 = C.c_longlong(0), C.c_longlong(0); L.phx_debug_wait_clock(C.byref(ns1), C.byref(c1))
 if c1.value > c0.value: print("host waits per step: %.1f, %.3f ms of the step spent waiting (PHX_WAIT_CLOCK)" % ((c1.value - c0.value) / len(t), 1e-6 * (ns1.value - ns0.value) / len(t)))
