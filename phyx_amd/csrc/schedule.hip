@@ -411,10 +411,12 @@ void build_bin(const std::vector<int>& joints, const int* body1, const int* body
 {
     out = BinOut{};
     map.reset((unsigned)joints.size() * 2u + 8u);
-    // local body table: static bodies first (their local index doubles as the slot in the group's static-tag table)
+    // local body table: static bodies first (their local index doubles as the slot in the group's static-tag table), each kind in
+    // the order the UNITS — in their leaders' joint order — first touch them (a follower shares its leader's bodies)
     for (int pass = 0; pass < 2; ++pass)
         for (int j : joints)
             for (int b : {body1[j], body2[j]}) {
+                if (is_follower(partner, prio_id, j)) continue;
                 if ((is_static[b] != 0) != (pass == 0)) continue;
                 bool fresh;
                 int* slot = map.find_or_insert(b, fresh);

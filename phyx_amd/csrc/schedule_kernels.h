@@ -282,17 +282,15 @@ static __global__ void __launch_bounds__(JC_T) k_manifold_components(const phx_m
     }
 }
 
-// (also clears the 'a bin was rejected' flag that k_build_bin may raise)
-// (`ncomp_cap`: entries of bin_of_comp — a speculative build, solver.hip, may meet more components than its table holds; it is
-//  spoiled then, but must not read past the table)
-static __global__ void __launch_bounds__(256) k_joint_bin_keys(const int* __restrict__ joint_comp, const int* __restrict__ bin_of_comp, int nj, int rest_key,
-                                                               unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ rejected, int ncomp_cap)
+// flags of the joints that belong to the HBM group (the builder's long way): their component fits no workgroup, or they join two static
+// bodies; n + 1 words (the last one 0) for the scan behind it
+static __global__ void __launch_bounds__(256) k_rest_flags(const int* __restrict__ joint_comp, const int* __restrict__ bin_of_comp, int nj, int nbins, int ncomp_cap,
+                                                           unsigned* __restrict__ flags)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
-        const int c = joint_comp[j];
-        keys[j] = (unsigned)((c < 0 || c >= ncomp_cap) ? rest_key : bin_of_comp[c]);
-        vals[j] = (unsigned)j;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= nj; j += gridDim.x * blockDim.x) {
+        unsigned f = 0u;
+        if (j < nj) { const int c = joint_comp[j]; f = (c < 0 || c >= ncomp_cap || bin_of_comp[c] >= nbins) ? 1u : 0u; }
+        flags[j] = f;
     }
 }
 
@@ -480,58 +478,63 @@ static __global__ void __launch_bounds__(BINC_T) k_bin_components(BinCompView v)
     for (int i = tid; i <= v.max_bins; i += BINC_T) v.cursor[i] = 0u;
 }
 
-// ---- the joints, bin by bin ---------------------------------------------------------------------------------------------
-// Rounds 2-5 grouped the joints by bin with a stable radix sort of (bin, joint) — keys + histogram, scan, scatter: 29 us in three
-// launches at cfg 2.  A bin's builder does not need the joints of OTHER bins in any order; it needs its own, and it can put ITS few
-// hundred in joint order itself (k_build_bin: a bitonic network in LDS).  So one pass deals every joint to its bin through a fill
-// counter per bin (the bins' first slots are known: k_bin_components), as a RECORD of everything k_build_bin wants of the joint —
-// which the dealing lane holds in registers anyway — instead of an index the builder would have to chase through three levels of
-// memory.  The position inside the bin is whatever the atomic returns; nothing depends on it once the builder has sorted.
+// ---- the units, bin by bin -----------------------------------------------------------------------------------------------
+// Rounds 2-5 grouped the JOINTS by bin with a stable radix sort of (bin, joint) — keys + histogram, scan, scatter: 29 us in three
+// launches at cfg 2 — and built a bin with a lane per joint.  A bin's builder does not need the joints of OTHER bins in any order; it
+// needs its own UNITS (schedule.h: the one or two joints of a body pair), and it can put its few hundred in joint order itself
+// (k_build_bin: a bitonic network over the leaders' joint indices).  So the units are DEALT to their bins through a fill counter per
+// bin (the bins' first slots are known: k_bin_components) — whatever order the atomics return, nothing depends on it once the
+// builder has sorted:
+//   * from the joints (k_joint_scatter): every leader leaves a RECORD of everything k_build_bin wants of the unit — which the dealing
+//     lane holds in registers anyway — instead of an index the builder would have to chase through three levels of memory;
+//   * in the World, from the MANIFOLDS, on the side stream (k_manifold_slots): a manifold with contact points IS a unit, its joints
+//     are its contact points' (ContactPoint::solverIndex, ref: World.cpp:100, 139), and k_build_bin reads them through the manifold —
+//     the rebuild proper is then ONE launch.
 // Whatever cannot be dealt (a body or contact point out of range, labels that disagree, a component outside the tables, a bin that is
-// full) raises a bit of result[7]; k_build_bin then spoils the solve's control word and the caller rebuilds the long way.
-struct BinRecord { int4 a; int2 b; };      // a = {joint, partner or -1, body1, body2}, b = {contact point, rank of the component in its bin | body1 static << 30 | body2 static << 31}
-constexpr int SCAT_FAIL_RANGE = 1, SCAT_FAIL_LABELS = 2, SCAT_FAIL_COMP = 4, SCAT_FAIL_FULL = 8, SCAT_FAIL_UNIT = 16, SCAT_FAIL_TOTAL = 32, SCAT_FAIL_SIDE = 64;
+// full) raises a bit of a flag word; k_build_bin then spoils the solve's control word and the caller rebuilds the long way.
+struct BinRecord { int4 a; int2 b; };      // a = {leader joint, follower joint or -1, body1, body2}, b = {leader's contact point, rank of the component in its bin | body1 static << 30 | body2 static << 31}
+constexpr int SCAT_FAIL_RANGE = 1, SCAT_FAIL_LABELS = 2, SCAT_FAIL_COMP = 4, SCAT_FAIL_FULL = 8, SCAT_FAIL_UNIT = 16, SCAT_FAIL_TOTAL = 32;
+
+// one fill-counter atomic per distinct bin of the wave (three rounds; whoever is left goes alone — k_joint_components' scheme);
+// returns the lane's position in its bin (bin < 0: no position)
+__device__ __forceinline__ unsigned deal_position(int bin, unsigned* __restrict__ cursor)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned pos = 0;
+    unsigned long long todo = __ballot(bin >= 0);
+    for (int round = 0; round < 3 && todo; ++round) {
+        const int leader = __builtin_ctzll(todo);
+        const int lb = __shfl(bin, leader);
+        const unsigned long long same = __ballot(bin == lb);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[lb], (unsigned)__popcll(same));
+        base = __shfl(base, leader);
+        if (bin == lb) pos = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) pos = atomicAdd(&cursor[bin], 1u);
+    return pos;
+}
 
 struct ScatterView {
     const phx_contact_joint* joints; int nj, nb;
     const int* parent;                // body -> root body of its component (-1: static)
-    const unsigned* root_number;      // root body -> component number
-    // the units (schedule.h).  From the World (manifolds non-null): contact point ids are unique and a contact point knows its joint
-    // (ContactPoint::solverIndex, ref: World.cpp:100, 139), so the partner of the joint on contact point p of a two-point manifold is
-    // cps[p ^ 1].solver_index — checked here: the joint's contact point must name it back, and its bodies must be the manifold's.
-    // Otherwise: `partner` as the linking pass left it (k_cc_link).
-    const phx_manifold* manifolds; int nm;
-    const phx_contact_point* cps; int ncp;
-    const int* partner;
-    const int* bin_of; const int* rank_of; const int* goff;      // k_bin_components' tables
-    int* result;                      // k_bin_components' results; [7] |= SCAT_FAIL_*
-    int max_bins;
-    unsigned* cursor;                 // per bin: records dealt so far (zero on entry)
-    int4* rec_a; int2* rec_b;         // out: the records, bin by bin
+    const int* joint_comp;            // joint -> component number (k_joint_components)
+    const int* partner;               // joint -> the other joint of its unit, or -1 (k_cc_link)
+    const int* bin_of; const int* rank_of; const int* goff;      // the bins' tables (k_bin_components, or the host's)
+    const int* result;                // (may be null: `nbins` counts) k_bin_components' results: [4] fail bits, [6] bins
+    int nbins, max_bins, ncomp_cap;
+    unsigned* cursor;                 // per bin: units dealt so far (zero on entry)
+    int4* rec_a; int2* rec_b;         // out: the units' records, bin by bin (a bin's records from its first slot on)
     int* rejected;                    // the 'a bin was rejected' flag k_build_bin may raise: cleared here
-    const int* side_flags;            // (manifolds) k_manifold_components' flags
-    // (manifolds) the solve's gate, which k_bin_components could not arm from the side stream
-    unsigned long long* fingerprint; unsigned long long* hash_out; unsigned long long gate;
+    int* spoil;                       // |= SCAT_FAIL_*
 };
 
-template <bool FROM_MANIFOLDS>
 static __global__ void __launch_bounds__(256) k_joint_scatter(ScatterView v)
 {
-    int fail = v.result[4];
-    if (FROM_MANIFOLDS) {
-        if (*v.side_flags) fail |= BINC_FAIL_REST;
-        if (v.result[1] != v.nj) fail |= BINC_FAIL_REST;      // the manifolds' contact points and the joints do not add up
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *v.rejected = 0;
-        if (FROM_MANIFOLDS) {
-            *v.hash_out = *v.fingerprint;
-            *v.fingerprint = fail ? v.gate + BINC_POISON : v.gate;
-            if (fail) { v.result[0] = 0; v.result[4] = fail; }
-        }
-    }
-    if (fail) return;                                         // (uniform: the tables may be incomplete — nobody runs on this build)
-    const int nbins = v.result[6];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *v.rejected = 0;
+    if (v.result && v.result[4]) return;                      // (uniform: the tables may be incomplete — nobody runs on this build)
+    const int nbins = v.result ? v.result[6] : v.nbins;
     const int lane = threadIdx.x & 63;
     int bad = 0;
     for (int j0 = blockIdx.x * blockDim.x; j0 < v.nj; j0 += gridDim.x * blockDim.x) {      // (wave-uniform trip count)
@@ -541,50 +544,22 @@ static __global__ void __launch_bounds__(256) k_joint_scatter(ScatterView v)
         bool st1 = false, st2 = false;
         if (j < v.nj) {
             me = v.joints[j];
+            mate = v.partner[j];
+            const int comp = v.joint_comp[j];
             const unsigned a = (unsigned)me.body1, b = (unsigned)me.body2;
+            const bool follower = mate >= 0 && (me.contact_point_index & 1);
             if (a >= (unsigned)v.nb || b >= (unsigned)v.nb || a == b) bad |= SCAT_FAIL_RANGE;
-            else {
-                const int pa = v.parent[a], pb = v.parent[b];
-                st1 = pa < 0; st2 = pb < 0;
-                if (pa >= 0 && pb >= 0 && pa != pb) bad |= SCAT_FAIL_LABELS;
-                const int r = pa >= 0 ? pa : pb;
-                if (r < 0) bad |= SCAT_FAIL_COMP;                 // both static: the HBM group's business
+            else if (!follower && comp >= 0) {                // (a joint between static bodies belongs to no bin: the HBM group's)
+                st1 = v.parent[a] < 0; st2 = v.parent[b] < 0;
+                if (comp >= v.ncomp_cap) bad |= SCAT_FAIL_COMP;
                 else {
-                    const unsigned comp = v.root_number[r];
-                    if (comp >= (unsigned)BINC_MAX) bad |= SCAT_FAIL_COMP;
-                    else {
-                        bin = v.bin_of[comp]; rank = v.rank_of[comp];
-                        if ((unsigned)bin >= (unsigned)nbins || bin > v.max_bins) { bad |= SCAT_FAIL_COMP; bin = -1; }
-                    }
+                    bin = v.bin_of[comp]; rank = v.rank_of[comp];
+                    if (bin > v.max_bins) { bad |= SCAT_FAIL_COMP; bin = -1; }
+                    else if ((unsigned)bin >= (unsigned)nbins) bin = -1;      // (a component too big for a workgroup: the HBM group's)
                 }
-                if (FROM_MANIFOLDS) {
-                    const unsigned p = (unsigned)me.contact_point_index;
-                    if (p >= (unsigned)v.ncp || (p >> 1) >= (unsigned)v.nm) { bad |= SCAT_FAIL_UNIT; bin = -1; }
-                    else {
-                        const phx_manifold m = v.manifolds[p >> 1];
-                        if (m.body1 != me.body1 || m.body2 != me.body2 || (int)(p & 1u) >= m.point_count || v.cps[p].solver_index != j) { bad |= SCAT_FAIL_UNIT; bin = -1; }
-                        else if (m.point_count == 2) {
-                            mate = v.cps[p ^ 1u].solver_index;
-                            if ((unsigned)mate >= (unsigned)v.nj || (unsigned)v.joints[mate].contact_point_index != (p ^ 1u)) { bad |= SCAT_FAIL_UNIT; bin = -1; }
-                        }
-                    }
-                } else mate = v.partner[j];
             }
         }
-        // one fill-counter atomic per distinct bin of the wave (three rounds; whoever is left goes alone — k_joint_components' scheme)
-        unsigned pos = 0;
-        unsigned long long todo = __ballot(bin >= 0);
-        for (int round = 0; round < 3 && todo; ++round) {
-            const int leader = __builtin_ctzll(todo);
-            const int lb = __shfl(bin, leader);
-            const unsigned long long same = __ballot(bin == lb);
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(&v.cursor[lb], (unsigned)__popcll(same));
-            base = __shfl(base, leader);
-            if (bin == lb) pos = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-            todo &= ~same;
-        }
-        if ((todo >> lane) & 1ull) pos = atomicAdd(&v.cursor[bin], 1u);
+        const unsigned pos = deal_position(bin, v.cursor);
         if (bin >= 0) {
             const int first = v.goff[bin], room = v.goff[bin + 1] - first;
             if (pos >= (unsigned)room || (unsigned)(first + (int)pos) >= (unsigned)v.nj) bad |= SCAT_FAIL_FULL;
@@ -598,31 +573,72 @@ static __global__ void __launch_bounds__(256) k_joint_scatter(ScatterView v)
     if (__any(bad != 0)) {
         int all = bad;
         for (int off = 32; off > 0; off >>= 1) all |= __shfl_xor(all, off);
-        if (lane == 0) atomicOr(&v.result[7], all);
+        if (lane == 0) atomicOr(v.spoil, all);
     }
 }
 
-// the records of a schedule whose joints WERE sorted by bin (the builder's long way: a stable radix sort that also leaves the HBM
-// group's joints in joint order behind the bins): slot s of the bins holds joint sorted[s]
-static __global__ void __launch_bounds__(256) k_bin_records(const unsigned* __restrict__ sorted, int slots, const phx_contact_joint* __restrict__ joints, const int* __restrict__ partner,
-                                                            const unsigned char* __restrict__ is_static, const int* __restrict__ joint_comp, const int* __restrict__ comp_rank,
-                                                            int4* __restrict__ rec_a, int2* __restrict__ rec_b, int* __restrict__ rejected)
+// The World's units, dealt on the side stream: manifold m with contact points is the unit of contact points 2m (and 2m + 1); its slot
+// holds m and what the builder wants of its component and bodies.  (`flags` |= 1: cannot be dealt — k_build_bin spoils the build.)
+struct ManifoldSlotsView {
+    const phx_manifold* manifolds; int nm, nb;
+    const int* parent; const unsigned* root_number;
+    const int* bin_of; const int* rank_of; const int* goff; const int* result; int max_bins;
+    unsigned* cursor;
+    int2* unit_m;                     // out, per slot: {manifold, rank of the component in its bin | body1 static << 30 | body2 static << 31}
+    int* flags;
+};
+
+static __global__ void __launch_bounds__(256) k_manifold_slots(ManifoldSlotsView v)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *rejected = 0;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
-        const int j = (int)sorted[s];
-        const phx_contact_joint me = joints[j];
-        rec_a[s] = make_int4(j, partner[j], me.body1, me.body2);
-        rec_b[s] = make_int2(me.contact_point_index, comp_rank[joint_comp[j]] | (is_static[me.body1] ? 1 << 30 : 0) | (is_static[me.body2] ? (int)(1u << 31) : 0));
+    if (v.result[4]) return;
+    const int nbins = v.result[6];
+    bool bad = false;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < v.nm; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + (int)threadIdx.x;
+        int bin = -1, info = 0;
+        if (i < v.nm) {
+            const phx_manifold m = v.manifolds[i];
+            if (m.point_count > 0) {
+                const unsigned a = (unsigned)m.body1, b = (unsigned)m.body2;
+                if (a >= (unsigned)v.nb || b >= (unsigned)v.nb || a == b || m.point_count > 2) bad = true;
+                else {
+                    const int pa = v.parent[a], pb = v.parent[b];
+                    const int r = pa >= 0 ? pa : pb;
+                    if (r < 0 || (pa >= 0 && pb >= 0 && pa != pb)) bad = true;
+                    else {
+                        const unsigned comp = v.root_number[r];
+                        if (comp >= (unsigned)BINC_MAX) bad = true;
+                        else {
+                            bin = v.bin_of[comp];
+                            info = v.rank_of[comp] | (pa < 0 ? 1 << 30 : 0) | (pb < 0 ? (int)(1u << 31) : 0);
+                            if ((unsigned)bin >= (unsigned)nbins || bin > v.max_bins) { bad = true; bin = -1; }
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned pos = deal_position(bin, v.cursor);
+        if (bin >= 0) {
+            const int first = v.goff[bin], room = v.goff[bin + 1] - first;
+            if (pos >= (unsigned)room) bad = true;
+            else v.unit_m[first + (int)pos] = make_int2(i, info);
+        }
     }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(v.flags, 1);
 }
 
 // ---- one workgroup builds one bin ------------------------------------------------------------------------------
 struct BinBuildView {
-    const int4* rec_a; const int2* rec_b;      // the joints' records, bin by bin, in any order inside a bin (BinRecord: k_joint_scatter / k_bin_records)
-    const int* group_offsets;         // slots of bin g = [group_offsets[g], group_offsets[g+1])
-    const unsigned* cursor;           // (may be null) records k_joint_scatter dealt to each bin: must equal the bin's slot count
-    const int* spoil;                 // (may be null) k_joint_scatter's fail bits: nobody builds on a spoiled deal
+    // the bin's units, in any order: records (k_joint_scatter) ...
+    const int4* rec_a; const int2* rec_b;
+    // ... or manifolds (k_manifold_slots; rec_a null): the unit's joints are its contact points' solver_index
+    const int2* unit_m; const phx_manifold* manifolds; const phx_contact_point* cps; const phx_contact_joint* joints; int nj;
+    const int* group_offsets;         // slots of bin g = [group_offsets[g], group_offsets[g+1]) — its units' records / manifolds from the first slot on
+    const unsigned* cursor;           // units dealt to each bin
+    const int* spoil;                 // (may be null) the dealers' fail bits: nobody builds on a spoiled deal
+    const int* side_flags;            // (manifolds) the side stream's flags
+    const int* result;                // (manifolds) k_bin_components' results: [1] the joints the manifolds add up to, [4] its fail bits
+    unsigned long long gate;          // (manifolds) what arms the solve's control word: added once, by this launch (k_bin_components could not, from the side stream)
     int nb, max_static;
     int* order;                       // out: slot -> joint
     unsigned* slot_local;             // out: local body1 | local body2 << 16
@@ -658,14 +674,14 @@ __device__ __forceinline__ int bin_wave_rank(bool want, int key, unsigned short*
     return rank;
 }
 
-// T = unit capacity = lanes of the island kernel; the builder runs one lane per JOINT (2 T lanes).  Followers (the second
-// joint of a unit) only help to build the body table; the colouring and the placement are done by the leaders.
+// T = unit capacity = lanes of the island kernel = lanes of this builder: a lane per UNIT (round 5 ran a lane per joint: twice the
+// waves, and with four bins on a CU the builder is bound by the instructions its waves issue).
 template <int T, int NB>
-static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
+static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
 {
-    constexpr int LANES = 2 * T;
-    constexpr int HT = 4 * LANES;                        // open-addressing table, <= 2 LANES distinct bodies
-    __shared__ __align__(8) int pool[2 * HT];            // the records' sort and staging, then the hash table
+    constexpr int LANES = T;
+    constexpr int HT = 8 * LANES;                        // open-addressing table, <= 2 LANES distinct bodies
+    __shared__ __align__(8) int pool[2 * HT];            // the units' sort and staging, then the hash table
     int* ht_key = pool;                                  // later reused as the per-body priority table of the colouring
     static_assert((size_t)NB * 8 <= (size_t)HT * 4, "priority table must fit the hash table");
     int* ht_val = pool + HT;                             // first occurrence position, later the local index
@@ -674,38 +690,56 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
     __shared__ unsigned long long used_b[NB];            // candidate B (two-ended, schedule.h)
     __shared__ int degree[NB];                           // units of the bin on each local body
     __shared__ unsigned long long seen_a[T], seen_b[T];  // per component of the bin (at most one per unit): classes in use under either candidate
-    __shared__ unsigned char bad_b[T];                    // (sized by T, not by the lanes: with them the small shape's LDS is < 40 KB = 4 workgroups per CU)
+    __shared__ unsigned char bad_b[T];
     __shared__ unsigned scan_lds[LANES / 64];
     __shared__ unsigned with_n[64], single_n[64];        // per class: leaders that have a follower / single leaders
     __shared__ unsigned class_begin[64], unit_begin[64]; // per class: first slot (relative), first unit
     __shared__ unsigned cls_span[64];                    // per class: its first lane in the island kernel | its units << 16 (schedule.h LANES)
     __shared__ unsigned short wave_with[(LANES / 64) * 64], wave_single[(LANES / 64) * 64];
-    __shared__ int n_static, n_bodies, n_col, n_units, bad;
+    __shared__ int n_static, n_bodies, n_col, bad;
 
     const int g = blockIdx.x, tid = threadIdx.x;
-    if (v.spoil && *v.spoil) { if (g == 0 && tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); } return; }
-    if (v.nbins_dev && g >= *v.nbins_dev) return;
-    const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;
-    if (count < 0 || count > LANES || (v.cursor && v.cursor[g] != (unsigned)count)) {      // the deal does not match the bins: nobody runs on this build
-        if (tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); }
-        return;
+    const bool from_manifolds = v.rec_a == nullptr;
+    auto spoil_build = [&]() { if (tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); } };
+    if (from_manifolds && g == 0 && tid == 0) {
+        // the gate of the solve queued behind this build: ADDED to the control word (zero: no hash pass runs in front of a World rebuild),
+        // so that it commutes with whatever other workgroups add to spoil it
+        atomicAdd(v.poison, v.gate);
+        if (v.result[4] || *v.side_flags || v.result[1] != v.nj) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); }
     }
+    if (v.spoil && *v.spoil) { if (g == 0) spoil_build(); return; }
+    if (from_manifolds && (v.result[4] || *v.side_flags || v.result[1] != v.nj)) return;      // (uniform; workgroup 0 has spoiled the word)
+    if (v.nbins_dev && g >= *v.nbins_dev) return;
+    const int begin = v.group_offsets[g], count = v.group_offsets[g + 1] - begin;      // the bin's joints
+    const int nu = (int)v.cursor[g];                                                  // ... and units
+    if (count < 0 || count > 2 * LANES || nu < 0 || nu > LANES || nu > count) { spoil_build(); return; }      // the deal does not match the bins: nobody runs on this build
     for (int i = tid; i < NB; i += LANES) { used[i] = 0ull; used_b[i] = 0ull; degree[i] = 0; }
-    if (tid < T) { seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0; }
+    seen_a[tid] = 0ull; seen_b[tid] = 0ull; bad_b[tid] = 0;
     for (int i = tid; i < (LANES / 64) * 64; i += LANES) { wave_with[i] = 0; wave_single[i] = 0; }
     if (tid == 0) { bad = 0; n_col = 0; }
-    __syncthreads();
 
-    // the bin's records, put in joint order: a record per lane, a bitonic network over (joint, lane) — strides below 64 by shuffles inside the
-    // wave, the few above through LDS — then every lane fetches the record of the lane that held the tid-th smallest joint
+    // the bin's units, put in the order of their leaders' joint indices: a unit per lane, a bitonic network over (leader joint, lane) —
+    // strides below 64 by shuffles inside the wave, the few above through LDS — then every lane fetches the unit of the lane that held the
+    // tid-th smallest leader
     int j = 0, b[2] = {0, 0}, hs[2] = {0, 0}, mate = -1, cpi = 0, comp = 0;
-    bool follower = false, stat[2] = {false, false};
+    bool stat[2] = {false, false}, mismatch = false;
     {
         int4 ra = make_int4(0, -1, 0, 0); int2 rb = make_int2(0, 0);
-        if (tid < count) { ra = v.rec_a[begin + tid]; rb = v.rec_b[begin + tid]; }
-        unsigned key = tid < count ? (unsigned)ra.x : 0x80000000u + (unsigned)tid;      // (the lanes beyond the bin sort behind it)
+        if (tid < nu) {
+            if (!from_manifolds) { ra = v.rec_a[begin + tid]; rb = v.rec_b[begin + tid]; }
+            else {
+                const int2 um = v.unit_m[begin + tid];
+                const phx_manifold m = v.manifolds[um.x];
+                const int j0 = v.cps[2 * um.x].solver_index, j1 = m.point_count == 2 ? v.cps[2 * um.x + 1].solver_index : -1;
+                ra = make_int4(j0, j1, m.body1, m.body2); rb = make_int2(2 * um.x, um.y);
+                // (the joints must name their contact points back — checked once the colouring is under way: the loads' latency hides there)
+                if ((unsigned)j0 >= (unsigned)v.nj || (j1 >= 0 && (unsigned)j1 >= (unsigned)v.nj)) { mismatch = true; ra.x = 0; ra.y = -1; }
+            }
+        }
+        unsigned key = tid < nu ? (unsigned)ra.x : 0x80000000u + (unsigned)tid;      // (the lanes beyond the bin's units sort behind them)
         int src = tid;
         unsigned* skey = reinterpret_cast<unsigned*>(pool); int* ssrc = pool + LANES;
+        __syncthreads();
 #pragma unroll
         for (int k = 2; k <= LANES; k <<= 1) {
 #pragma unroll
@@ -730,11 +764,13 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         comp = info & 0x3FFFFFFF; stat[0] = (info >> 30) & 1; stat[1] = (info >> 31) & 1;
         __syncthreads();
     }
+    const bool live = tid < nu;
+    // (manifolds) the unit's joints as the joint list has them: asked for here, looked at after the colouring
+    phx_contact_joint q0{}, q1{};
+    if (from_manifolds && live && !mismatch) { q0 = v.joints[j]; if (mate >= 0) q1 = v.joints[mate]; }
     for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
     __syncthreads();
-    const bool live = tid < count;
     if (live) {
-        follower = mate >= 0 && (cpi & 1) != 0;
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s
             unsigned p = ((unsigned)b[s] * 2654435761u) & (HT - 1);
             for (;;) {
@@ -755,17 +791,17 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
             lead[s] = ht_val[hs[s]] == 2 * tid + s;
             if (lead[s]) mine += stat[s] ? 0x10000u : 1u;
         }
-    // block exclusive scan of `mine`; the units are counted on the side
+    // block exclusive scan of `mine`; the joints are counted on the side
     unsigned x = mine;
     const int lane = tid & 63, wave = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
     if (lane == 63) scan_lds[wave] = x;
-    const int units_here = __syncthreads_count(live && !follower);
+    const int joints_here = nu + __syncthreads_count(live && mate >= 0);
     unsigned before = x - mine, total = 0;
     for (int w = 0; w < LANES / 64; ++w) { const unsigned t = scan_lds[w]; if (w < wave) before += t; total += t; }
-    if (tid == 0) { n_static = (int)(total >> 16); n_bodies = (int)(total >> 16) + (int)(total & 0xFFFFu); n_units = units_here; }
+    if (tid == 0) { n_static = (int)(total >> 16); n_bodies = (int)(total >> 16) + (int)(total & 0xFFFFu); }
     __syncthreads();                                     // every lane has read ht_val as "first position"
-    const bool fits = n_bodies <= NB && n_static <= v.max_static && units_here <= T;
+    const bool fits = n_bodies <= NB && n_static <= v.max_static && joints_here == count;      // (the units' joints must be the bin's)
     if (live && fits) {
         unsigned sb = before >> 16, db = before & 0xFFFFu;
         for (int s = 0; s < 2; ++s)
@@ -776,9 +812,9 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
             }
     }
     __syncthreads();
-    const bool unit = live && fits && !follower;         // this lane leads a unit
+    const bool unit = live && fits;                      // this lane has a unit
     int loc[2] = {0, 0};
-    if (live && fits) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; }
+    if (unit) { loc[0] = ht_val[hs[0]]; loc[1] = ht_val[hs[1]]; }
     if (unit) { atomicAdd(&degree[loc[0]], 1); atomicAdd(&degree[loc[1]], 1); }
     __syncthreads();
     // First-fit colouring of the units in priority order by Jones-Plassmann rounds (schedule.h): every round, an uncoloured
@@ -831,6 +867,10 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         }
         if (!__syncthreads_or(pending ? 1 : 0)) break;
     }
+    // (manifolds) the joints' side of the pairing: a joint that does not name its contact point, or sits on other bodies, spoils the build
+    if (from_manifolds && live && !mismatch)
+        mismatch = q0.contact_point_index != cpi || q0.body1 != b[0] || q0.body2 != b[1] || (mate >= 0 && (q1.contact_point_index != (cpi | 1) || q1.body1 != b[0] || q1.body2 != b[1]));
+    if (mismatch) bad = 1;
     // every component keeps the candidate that gives it fewer colours (A on a tie), renumbered densely in increasing order
     {
         const bool use_b = !bad_b[comp] && __popcll(seen_b[comp]) < __popcll(seen_a[comp]);
@@ -879,7 +919,7 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         cls_span[tid] = (unsigned)my_begin | (units_c << 16);
     }
     __syncthreads();
-    if (!fits || bad) { if (tid == 0) { *v.rejected = 1; atomicAdd(v.poison, 0x9E3779B97F4A7C15ull); } return; }
+    if (!fits || bad) { spoil_build(); return; }
     if (placed) {
         const int c = mycol;
         const int r = paired ? (int)wave_with[wave * 64 + c] + rank_with : (int)wave_single[wave * 64 + c] + rank_single;
@@ -897,12 +937,12 @@ static __global__ void __launch_bounds__(2 * T) k_build_bin(BinBuildView v)
         v.unit_recs[at] = make_int4(j, paired ? mate : -1, cpi, cpi ^ 1);
         v.unit_recs[at + 1] = make_int4((int)local, c, slot, fslot);
     }
-    if (tid < T) {                                       // the lanes no class covers are nobody's (gaps of the layout, the tail)
+    {                                                    // the lanes no class covers are nobody's (gaps of the layout, the tail)
         bool taken = false;
         for (int c = 0; c < n_col; ++c) { const unsigned sp = cls_span[c]; taken |= (unsigned)(tid - (int)(sp & 0xFFFFu)) < (sp >> 16); }
         if (!taken) v.unit_recs[2 * ((size_t)g * T + tid)] = make_int4(-1, -1, 0, 0);
     }
-    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = island_units_word(n_units, n_col, n_static); }      // (static bodies sit first in the table: the island kernel checks exactly that)
+    if (tid == 0) { v.desc[g] = make_int4(begin, count, g * NB, n_bodies); v.ncol[g] = n_col; v.units[g] = island_units_word(nu, n_col, n_static); }      // (static bodies sit first in the table: the island kernel checks exactly that)
 }
 
 // ---- the HBM group (islands too big for a workgroup, or everything in Single mode): the same colouring in HBM ----------

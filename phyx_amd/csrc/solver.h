@@ -239,7 +239,8 @@ private:
         DevBuf<unsigned> cc_flags, sort_keys[2], sort_vals[2], sort_hist;
         DevBuf<int4> rec_a;                   // the joints' records, bin by bin (schedule_kernels.h BinRecord)
         DevBuf<int2> rec_b;
-        DevBuf<unsigned> bin_cursor;          // per bin: records dealt (k_joint_scatter)
+        DevBuf<int2> unit_m;                  // the World's units, bin by bin: {manifold, component rank | static bits} (k_manifold_slots)
+        DevBuf<unsigned> bin_cursor;          // per bin: units dealt (k_joint_scatter / k_manifold_slots)
         DevBuf<int> side_flags;               // k_manifold_components' flags
         ScanScratch sort_scan, prelabel_scan;      // (the side stream's scan keeps its own state: it runs beside the joint list's scans)
         DevBuf<int> partner;                  // joint -> the other joint of its unit (schedule.h)

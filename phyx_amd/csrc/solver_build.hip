@@ -282,6 +282,13 @@ int DeviceSolver::prelabel_components(const float4* d_mpos, int nb, const phx_ma
     const int bin_chunks = div_up(ncomp_guess_ + ncomp_guess_ / 4, BIN_CHUNK);
     const int bin_groups = bin_chunks <= 3 * (BINC_T / 64) ? 1 : std::min(16, div_up(bin_chunks, BINC_T / 64));
     hipLaunchKernelGGL(k_bin_components, dim3(bin_groups), dim3(BINC_T), 0, side_stream_, cv);
+    // ... and the units dealt to them: a manifold with contact points is a unit (k_build_bin reads its joints through the contact points)
+    PHX_TRY(bld_.unit_m.reserve((size_t)2 * nm + 2));
+    ManifoldSlotsView mv{};
+    mv.manifolds = d_manifolds; mv.nm = nm; mv.nb = nb; mv.parent = bld_.cc_parent.p; mv.root_number = bld_.cc_flags.p;
+    mv.bin_of = cv.bin_of; mv.rank_of = cv.rank_of; mv.goff = cv.goff; mv.result = bld_.bin_result.p; mv.max_bins = grid;
+    mv.cursor = bld_.bin_cursor.p; mv.unit_m = bld_.unit_m.p; mv.flags = bld_.side_flags.p;
+    hipLaunchKernelGGL(k_manifold_slots, dim3(std::max(1, std::min(div_up(nm, 256), 2048))), dim3(256), 0, side_stream_, mv);
     PHX_HIP(hipGetLastError());
     PHX_HIP(hipEventRecord(ev_pre_join_, side_stream_));
     prelabel_pending_ = true; prelabel_nb_ = nb;
@@ -434,18 +441,29 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     const int* bin_of_comp = bld_.bin_tables().p; const int* rank_of_comp = bld_.bin_tables().p + nc1; const int* grp_goff = bld_.bin_tables().p + 2 * nc1;
     lap("bin");
 
-    // 4. joints grouped by bin, joint order inside a bin (stable sort), HBM-group joints last
+    // 4. the units dealt to their bins (k_joint_scatter: a fill counter per bin, k_build_bin sorts its own), and the HBM group's joints
+    //    — components too big for a workgroup, joints between static bodies — compacted in joint order behind the bins' slots
+    const int rest_n = nj - lds_slots;
+    PHX_TRY(bld_.bin_cursor.reserve((size_t)nbins + 2));
+    PHX_HIP(hipMemsetAsync(bld_.sb_small.p + 2, 0, 2 * sizeof(int), stream_));      // 'a bin was rejected', the dealer's fail bits
     if (nbins) {
-        hipLaunchKernelGGL(k_joint_bin_keys, dim3(grid_for(nj)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, bin_of_comp, nj, nbins,
-                           bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sb_small.p + 2, std::max(ncomp, 1));
-        int bits = 1;
-        while ((1 << bits) <= nbins) ++bits;
-        PHX_TRY(device_radix_sort_pairs(bld_.sort_keys[0].p, bld_.sort_vals[0].p, bld_.sort_keys[1].p, bld_.sort_vals[1].p, nj, bits, bld_.sort_hist.p, bld_.sort_scan, stream_, &where));
-    } else {                                    // no bins (Single mode, or nothing fits a workgroup): the HBM group is every joint, in joint order
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, bld_.sort_vals[0].p, nj);
-        PHX_HIP(hipMemsetAsync(bld_.sb_small.p + 2, 0, sizeof(int), stream_));
+        PHX_HIP(hipMemsetAsync(bld_.bin_cursor.p, 0, ((size_t)nbins + 1) * sizeof(unsigned), stream_));
+        ScatterView sv{};
+        sv.joints = d_joints; sv.nj = nj; sv.nb = nb; sv.parent = bld_.cc_parent.p; sv.joint_comp = bld_.joint_comp.p; sv.partner = bld_.partner.p;
+        sv.bin_of = bin_of_comp; sv.rank_of = rank_of_comp; sv.goff = grp_goff; sv.result = nullptr; sv.nbins = nbins; sv.max_bins = nbins; sv.ncomp_cap = std::max(ncomp, 1);
+        sv.cursor = bld_.bin_cursor.p; sv.rec_a = bld_.rec_a.p; sv.rec_b = bld_.rec_b.p; sv.rejected = bld_.sb_small.p + 2; sv.spoil = bld_.sb_small.p + 3;
+        hipLaunchKernelGGL(k_joint_scatter, dim3(std::max(1, std::min(div_up(nj, 256), 2048))), dim3(256), 0, stream_, sv);
     }
-    lap("sort");
+    if (rest_n > 0) {
+        if (nbins) {
+            PHX_TRY(bld_.sort_keys[0].reserve((size_t)njs + 1));
+            hipLaunchKernelGGL(k_rest_flags, dim3(grid_for(nj + 1)), dim3(256), 0, stream_, (const int*)bld_.joint_comp.p, bin_of_comp, nj, nbins, std::max(ncomp, 1), bld_.sort_keys[0].p);
+            PHX_TRY(device_exclusive_scan(bld_.sort_keys[0].p, nj + 1, nullptr, bld_.sort_scan, stream_));
+            hipLaunchKernelGGL(k_compact_flagged, dim3(grid_for(nj)), dim3(256), 0, stream_, (const unsigned*)bld_.sort_keys[0].p, nj, reinterpret_cast<int*>(bld_.sort_vals[0].p + lds_slots));
+        } else hipLaunchKernelGGL(k_iota, dim3(grid_for(nj)), dim3(256), 0, stream_, bld_.sort_vals[0].p, nj);      // (Single mode, or nothing fits a workgroup: every joint, in joint order)
+    }
+    where = 0;
+    lap("deal");
 
     // 5. one workgroup per bin: body table, colouring, slot arrays
     PHX_TRY(isl_.desc.reserve(std::max(nbins, 1))); PHX_TRY(isl_.ncol.reserve(std::max(nbins, 1)));
@@ -454,16 +472,13 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     if (nbins) {
         BinBuildView bv{};
         PHX_TRY(isl_.units.reserve(nbins)); PHX_TRY(isl_.unit_recs.reserve(2 * (size_t)nbins * cap_units));
-        // (the sort left the bins' joints in joint order: their records, slot by slot — k_build_bin's own sort then finds them in order)
-        hipLaunchKernelGGL(k_bin_records, dim3(grid_for(lds_slots)), dim3(256), 0, stream_, (const unsigned*)bld_.sort_vals[where].p, lds_slots, d_joints, (const int*)bld_.partner.p,
-                           (const unsigned char*)bld_.cc_static.p, (const int*)bld_.joint_comp.p, rank_of_comp, bld_.rec_a.p, bld_.rec_b.p, bld_.sb_small.p + 2);
-        bv.rec_a = bld_.rec_a.p; bv.rec_b = bld_.rec_b.p; bv.group_offsets = grp_goff; bv.cursor = nullptr; bv.spoil = nullptr;
+        bv.rec_a = bld_.rec_a.p; bv.rec_b = bld_.rec_b.p; bv.group_offsets = grp_goff; bv.cursor = bld_.bin_cursor.p; bv.spoil = bld_.sb_small.p + 3;
         bv.nb = nb; bv.max_static = 1 << 30;
         bv.order = hbm_.order.p; bv.slot_local = isl_.slot_local.p; bv.slot_colour = isl_.slot_colour.p; bv.desc = isl_.desc.p; bv.ncol = isl_.ncol.p;
         bv.units = isl_.units.p; bv.unit_recs = isl_.unit_recs.p;
         bv.bodies = isl_.bodies.p; bv.rejected = bld_.sb_small.p + 2; bv.poison = hash_.p + hash_slot_;
-        if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(2 * ISL_T_BIG), 0, stream_, bv);
-        else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(2 * ISL_T), 0, stream_, bv);
+        if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(nbins), dim3(ISL_T_BIG), 0, stream_, bv);
+        else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(nbins), dim3(ISL_T), 0, stream_, bv);
     }
     PHX_HIP(hipGetLastError());
     // Did every bin fit?  Normally NOT waited for here: a rejected bin spoils the solve's fingerprint word on the device, the
@@ -655,17 +670,12 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     PHX_TRY(bld_.bin_result.reserve(16)); PHX_TRY(bld_.bin_cursor.reserve((size_t)grid + 2)); PHX_TRY(bld_.side_flags.reserve(4));
     gate_expected_ = 0x5EED000000000000ull | (++gate_serial_ & 0xFFFFFFFFFFFFull);
     int* const bin_of = bld_.bin_tables().p; int* const rank_of = bld_.bin_tables().p + BINC_MAX; int* const goff = bld_.bin_tables().p + 2 * BINC_MAX;
-    ScatterView sv{};
-    sv.joints = d_joints; sv.nj = nj; sv.nb = nb; sv.parent = bld_.cc_parent.p; sv.root_number = bld_.cc_flags.p;
-    sv.bin_of = bin_of; sv.rank_of = rank_of; sv.goff = goff; sv.result = bld_.bin_result.p; sv.max_bins = grid; sv.cursor = bld_.bin_cursor.p;
-    sv.rec_a = bld_.rec_a.p; sv.rec_b = bld_.rec_b.p; sv.rejected = bld_.sb_small.p + 2; sv.side_flags = bld_.side_flags.p;
-    const int scatter_grid = std::max(1, std::min(div_up(nj, 256), 2048));
+    BinBuildView bv{};
     if (from_manifolds) {
-        // components, counts and bins stand (side stream): the joints are dealt to their bins and the bins built — two launches
+        // components, counts, bins and the units' slots stand (side stream): the bins are built — ONE launch
         ++lite_builds_;
-        sv.manifolds = pre_manifolds_; sv.nm = pre_nm_; sv.cps = build_cps_; sv.ncp = ncp_;
-        sv.fingerprint = hash_.p + hash_slot_; sv.hash_out = reinterpret_cast<unsigned long long*>(bld_.bin_result.p + 8); sv.gate = gate_expected_;
-        hipLaunchKernelGGL((k_joint_scatter<true>), dim3(scatter_grid), dim3(256), 0, stream_, sv);
+        bv.unit_m = bld_.unit_m.p; bv.manifolds = pre_manifolds_; bv.cps = build_cps_; bv.joints = d_joints; bv.nj = nj;
+        bv.side_flags = bld_.side_flags.p; bv.result = bld_.bin_result.p; bv.gate = gate_expected_;
     } else {
         ++full_builds_;
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
@@ -692,22 +702,25 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
         }
         cv.scratch = bld_.bin_scratch.p;
         hipLaunchKernelGGL(k_bin_components, dim3(bin_groups), dim3(BINC_T), 0, stream_, cv);
-        sv.partner = bld_.partner.p;
-        hipLaunchKernelGGL((k_joint_scatter<false>), dim3(scatter_grid), dim3(256), 0, stream_, sv);
+        ScatterView sv{};
+        sv.joints = d_joints; sv.nj = nj; sv.nb = nb; sv.parent = bld_.cc_parent.p; sv.joint_comp = bld_.joint_comp.p; sv.partner = bld_.partner.p;
+        sv.bin_of = bin_of; sv.rank_of = rank_of; sv.goff = goff; sv.result = bld_.bin_result.p; sv.nbins = 0; sv.max_bins = grid; sv.ncomp_cap = BINC_MAX;
+        sv.cursor = bld_.bin_cursor.p; sv.rec_a = bld_.rec_a.p; sv.rec_b = bld_.rec_b.p; sv.rejected = bld_.sb_small.p + 2; sv.spoil = bld_.bin_result.p + 7;
+        hipLaunchKernelGGL(k_joint_scatter, dim3(std::max(1, std::min(div_up(nj, 256), 2048))), dim3(256), 0, stream_, sv);
+        bv.rec_a = bld_.rec_a.p; bv.rec_b = bld_.rec_b.p; bv.spoil = bld_.bin_result.p + 7;
     }
     PHX_TRY(isl_.desc.reserve(grid)); PHX_TRY(isl_.ncol.reserve(grid));
     PHX_TRY(isl_.bodies.reserve((size_t)grid * cap_bodies));
     PHX_TRY(isl_.slot_local.reserve(nj)); PHX_TRY(isl_.slot_colour.reserve(nj));
     PHX_TRY(isl_.units.reserve(grid)); PHX_TRY(isl_.unit_recs.reserve(2 * (size_t)grid * cap_units));
-    BinBuildView bv{};
-    bv.rec_a = bld_.rec_a.p; bv.rec_b = bld_.rec_b.p; bv.group_offsets = goff; bv.cursor = bld_.bin_cursor.p; bv.spoil = bld_.bin_result.p + 7;
+    bv.group_offsets = goff; bv.cursor = bld_.bin_cursor.p;
     bv.nb = nb; bv.max_static = 1 << 30;
     bv.order = hbm_.order.p; bv.slot_local = isl_.slot_local.p; bv.slot_colour = isl_.slot_colour.p; bv.desc = isl_.desc.p; bv.ncol = isl_.ncol.p;
     bv.units = isl_.units.p; bv.unit_recs = isl_.unit_recs.p;
     bv.bodies = isl_.bodies.p; bv.rejected = bld_.sb_small.p + 2; bv.poison = hash_.p + hash_slot_;
     bv.nbins_dev = bld_.bin_result.p;
-    if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(grid), dim3(2 * ISL_T_BIG), 0, stream_, bv);
-    else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(grid), dim3(2 * ISL_T), 0, stream_, bv);
+    if (cap_units > ISL_T) hipLaunchKernelGGL((k_build_bin<ISL_T_BIG, ISL_B_BIG>), dim3(grid), dim3(ISL_T_BIG), 0, stream_, bv);
+    else hipLaunchKernelGGL((k_build_bin<ISL_T, ISL_B>), dim3(grid), dim3(ISL_T), 0, stream_, bv);
     PHX_HIP(hipGetLastError());
     // provisional: the launch grid stands in for the group count until the solve is settled (collect_stats)
     sc.lds_groups = grid; sc.lds_lanes = cap_units;
