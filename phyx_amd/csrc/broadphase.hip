@@ -200,6 +200,11 @@ __device__ __forceinline__ int scan_end(const float4* __restrict__ entries, int 
 // (Round 3 let every lane fetch its own window, eight loads in flight per lane: 20 M tests were 320 MB through the L1s and a
 // row's scan a chain of dependent gathers — 44 us at cfg 2, 95 us at cfg 4.)  A lane sees its candidates in the same increasing
 // order as before, so counts, caches and the emission order are unchanged.
+// (Round 6 built the transposed walk — the lanes hold a block of 64 CANDIDATES in registers, the wave tests them against one row after
+//  the other, row data by v_readlane, ballots give tests / overlaps / the row's end, the lane that holds an overlapping candidate looks
+//  the pair up — byte-equal lists and counts, and SLOWER: 50.1 against 38.7 us at cfg 2, 103.9 against 80.6 at cfg 4.  Both walks do
+//  one 64-wide step per (row block, candidate) resp. (row, candidate block) and the triangle of a tie column half fills either; the
+//  transposed step is ~27 mostly scalar instructions, this one ~15 vector ones.  tools/probe/sweep_tiles.hip.txt keeps it.)
 #define PHX_SWEEP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 template <bool EMIT>
@@ -340,137 +345,6 @@ __global__ void __launch_bounds__(256) k_sweep_rows(SweepView v, const unsigned*
         }
     }
 }
-// The COUNT pass (round 6): a wave takes a block of 64 sorted rows (a lane per row, as above) and walks the candidate blocks behind it, but
-// inside a block the lanes are the CANDIDATES: the 64 records of the block are loaded once, coalesced, into registers, and the wave
-// tests them against one row after the other — the row's maxx / centre / extent come from the row's lane by v_readlane, the tests are
-// three compares on 64 candidates at once, and ballots say how many candidates were tested, which overlap in y (already in j order:
-// bit order) and where the row ends.  On tie columns (a stack: the rows of a column share their minx) the lane-per-row walk above
-// predicated half of its lane-tests off (j <= i) and took its 'some lane overlaps' branch on almost every candidate: 38 us for the
-// 20 M tests of cfg 2, 80 us for the 50 M of cfg 4.  The lane that HOLDS a candidate which overlaps a row in y looks the pair up in
-// the pair set itself (it has the candidate's body index; the row's comes by shuffle), all lanes' lookups of a tile in flight together;
-// only new pairs — a few hundred per step of a running world — are then handed to their rows, row by row, in bit = j order.
-// Counts, the rows' first ROW_CACHE new partners, the statistics and the hub rows' chunk lists are the lane-per-row kernel's, which
-// stays as the EMIT pass of the few rows with more than ROW_CACHE new pairs.
-constexpr int TILE_HITS = 8;         // rows a candidate can overlap before the tile's lookups are made early
-
-__global__ void __launch_bounds__(256) k_sweep_tiles(SweepView v)
-{
-    __shared__ unsigned char hits[TILE_HITS][256];      // per lane (= candidate): the rows (0 .. 63 of the wave's block) it overlaps in y, not looked up yet
-    unsigned long long tests = 0, overlaps = 0;         // (wave-uniform: every lane counts the same)
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < v.n; base += gridDim.x * blockDim.x) {      // (wave-uniform)
-        const int i = base + lane;
-        const bool in_range = i < v.n;
-        const float4 a = in_range ? v.entries[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool hub = in_range && i + 1 + HUB_LEN < v.n && !(v.entries[i + 1 + HUB_LEN].x > a.y);      // (k_sweep_rows' probe)
-        {
-            int end = 0, nc = 0, first = 0;
-            if (hub) {
-                end = scan_end(v.entries, v.n, i, a.y);
-                const int len = end - i - 1;
-                nc = (len + HUB_CHUNK - 1) / HUB_CHUNK;
-                first = atomicAdd(v.n_chunks, nc);
-                v.row_count[i] = 0;
-            }
-            unsigned long long hub_tests = hub ? (unsigned long long)(end - i - 1) : 0ull;
-            for (int off = 32; off > 0; off >>= 1) hub_tests += __shfl_xor(hub_tests, off);
-            tests += hub_tests;
-            for (unsigned long long hubs = __ballot(hub); hubs; hubs &= hubs - 1ull) {
-                const int l = __builtin_ctzll(hubs);
-                const int hi = __shfl(i, l), hend = __shfl(end, l), hnc = __shfl(nc, l), hfirst = __shfl(first, l);
-                for (int k = lane; k < hnc && hfirst + k < v.chunk_cap; k += 64)
-                    v.chunks[hfirst + k] = make_int4(hi, hi + 1 + k * HUB_CHUNK, min(hend, hi + 1 + (k + 1) * HUB_CHUNK), hfirst);
-            }
-        }
-        const bool scanning = in_range && !hub;
-        const unsigned ia = in_range ? v.idx[i] : 0u;
-        unsigned found = 0;                              // (of the lane's ROW)
-        // rows as bits of wave-uniform 64-bit masks (scalar registers): `done` = the rows that have met a candidate which starts beyond
-        // their maxx (ref: Collider.cpp:300-303), hub rows and rows past the list included
-        unsigned long long done = ~__ballot(scanning);
-        const int base_u = __builtin_amdgcn_readfirstlane(base);
-        const int a_maxx = __float_as_int(a.y), a_cy = __float_as_int(a.z), a_ey = __float_as_int(a.w);
-        for (int c = base_u + 1; c < v.n; c += 64) {
-            const int j = c + lane;
-            const bool valid = j < v.n;
-            const float4 b = v.entries[valid ? j : v.n - 1];
-            const unsigned ib = v.idx[valid ? j : v.n - 1];
-            const float first_minx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(b.x)));
-            unsigned long long rows = ~done & __ballot(!(first_minx > a.y));      // (a row whose maxx the block's first candidate exceeds has ended: the entries are sorted by minx)
-            if (!rows) break;
-            const unsigned long long valid_m = __ballot(valid);
-            int nh = 0;
-            // the tile's lookups (every lane: its candidate against the rows it overlaps) and, if any pair is new, the hand-over to the rows
-            auto flush = [&]() {
-                unsigned newbits = 0;                    // bit k: hit k of this lane is a pair the set does not hold
-                for (int h = 0; h < TILE_HITS; h += SWEEP_LOOK) {
-                    if (!__any(nh > h)) break;
-                    unsigned ra[SWEEP_LOOK];
-                    unsigned long long first[SWEEP_LOOK];
-#pragma unroll
-                    for (int k = 0; k < SWEEP_LOOK; ++k) ra[k] = (unsigned)__shfl((int)ia, h + k < nh ? (int)hits[h + k][threadIdx.x] : 0);
-#pragma unroll
-                    for (int k = 0; k < SWEEP_LOOK; ++k) first[k] = h + k < nh ? v.table[ps_hash(((unsigned long long)ra[k] << 32) | ib) & v.mask] : 0ull;
-#pragma unroll
-                    for (int k = 0; k < SWEEP_LOOK; ++k) {
-                        if (h + k >= nh) break;
-                        const unsigned long long key = ((unsigned long long)ra[k] << 32) | ib;
-                        bool present = first[k] == key;
-                        if (!present && first[k] != PS_EMPTY) present = ps_contains(v.table, v.mask, key);       // a collision at the home slot: walk on
-                        if (!present) newbits |= 1u << (h + k);
-                    }
-                }
-                if (__any(newbits != 0u)) {
-                    unsigned long long mine = 0;         // the rows this lane's candidate is a new partner of
-                    for (int k = 0; k < nh; ++k) if ((newbits >> k) & 1u) mine |= 1ull << hits[k][threadIdx.x];
-                    unsigned long long any = mine;
-                    for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off);
-                    for (; any; any &= any - 1ull) {
-                        const int r = __builtin_ctzll(any);
-                        const bool has = (mine >> r) & 1ull;
-                        const unsigned long long bal = __ballot(has);       // the row's new partners of this tile, bit order = j order
-                        const unsigned at = (unsigned)__shfl((int)found, r) + (unsigned)__popcll(bal & below);
-                        if (has && at < (unsigned)ROW_CACHE) v.row_cache[(size_t)(base_u + r) * ROW_CACHE + at] = ib;
-                        if (lane == r) found += (unsigned)__popcll(bal);
-                    }
-                }
-                nh = 0;
-            };
-            const int shift = c - base_u;                // candidate lane l lies behind row r iff l + shift > r
-            for (; rows; rows &= rows - 1ull) {
-                const int r = __builtin_ctzll(rows);
-                const float r_maxx = __int_as_float(__builtin_amdgcn_readlane(a_maxx, r)), r_cy = __int_as_float(__builtin_amdgcn_readlane(a_cy, r)),
-                            r_ey = __int_as_float(__builtin_amdgcn_readlane(a_ey, r));
-                // (mask arithmetic on the scalar unit: the lanes behind the row, then those before the first candidate that starts beyond its maxx)
-                const int lo = r - shift + 1;            // lanes >= lo lie behind the row (lo <= 63: shift >= 1)
-                unsigned long long tested = lo > 0 ? valid_m & ~((1ull << lo) - 1ull) : valid_m;
-                const unsigned long long beyond = __ballot(b.x > r_maxx) & tested;
-                if (beyond) {                            // the row ends inside this block
-                    tested &= (beyond & (0ull - beyond)) - 1ull;
-                    done |= 1ull << r;
-                }
-                tests += (unsigned long long)__popcll(tested);
-                const unsigned long long ovs = __ballot(fabsf(b.z - r_cy) <= r_ey + b.w) & tested;
-                if (ovs) {
-                    overlaps += (unsigned long long)__popcll(ovs);
-                    if ((ovs >> lane) & 1ull) hits[nh++][threadIdx.x] = (unsigned char)r;
-                    if (__any(nh == TILE_HITS)) flush();
-                }
-            }
-            flush();
-        }
-        if (scanning) { v.row_count[i] = found; if (found > (unsigned)ROW_CACHE) *v.cache_overflow = 1; }
-    }
-    __shared__ unsigned long long part[2][4];
-    if (lane == 0) { part[0][threadIdx.x >> 6] = tests; part[1][threadIdx.x >> 6] = overlaps; }
-    __syncthreads();
-    if (threadIdx.x < 2) {                             // one atomic per workgroup per counter, 64 slots
-        const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-        if (t) atomicAdd(&v.counters[2 * (blockIdx.x % STAT_SLOTS) + threadIdx.x], t);
-    }
-}
-
 // emit pass for every row with at most ROW_CACHE new pairs: straight from what the count pass remembered
 __device__ __forceinline__ void emit_cached_rows(const SweepView& v, const unsigned* __restrict__ row_offset, uint2* __restrict__ out, unsigned total, int block, int blocks)
 {
@@ -755,9 +629,7 @@ int DeviceBroadphase::update_resident(const float4* d_bodies, int n, const StepP
     for (int attempt = 0;; ++attempt) {
         v.chunks = chunks_.p; v.chunk_count = chunk_count_.p; v.chunk_cap = chunk_cap;
         chunk_grid = std::min(chunk_cap, 2048);
-        static const bool lane_per_row = getenv("PHX_SWEEP_ROWS") != nullptr;      // (A/B: the round-5 count pass, a row per lane)
-        if (lane_per_row) hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr, 0u);
-        else hipLaunchKernelGGL(k_sweep_tiles, dim3(grid_for(n)), dim3(256), 0, stream_, v);
+        hipLaunchKernelGGL((k_sweep_rows<false>), dim3(grid_for(n)), dim3(256), 0, stream_, v, (const unsigned*)nullptr, (uint2*)nullptr, 0u);
         hipLaunchKernelGGL(k_sweep_chunks_count, dim3(chunk_grid), dim3(256), 0, stream_, v);
         // chunk counts -> per-row bases and the hub rows' totals (one small workgroup)
         PHX_TRY(chunk_scan_.reserve(chunk_cap + 1));
