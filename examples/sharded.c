@@ -11,8 +11,10 @@
  *                                                        the file, the others wait for it — any launcher will do
  *
  * Rank 0 also steps an UNSHARDED world beside the sharded one and compares every body after every step: the sharded step must
- * reproduce it bit for bit.  Exit status: 0 ok, 3 no usable device / no RCCL (there is no CPU fallback), 1 any other failure.
+ * reproduce it bit for bit.  A coda does the other sharding mode: every rank steps a world of its own x-slab of whole columns and the
+ * ranks re-slab once (phx_world_reslab) over the same communicator.  Exit status: 0 ok, 3 no usable device / no RCCL (there is no CPU fallback), 1 any other failure.
  */
+#define _DEFAULT_SOURCE      /* usleep */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -109,6 +111,41 @@ int main(int argc, char** argv)
         printf("rank 0 of %d: %d bodies, %d manifolds, %d joints, %d island groups, %d steps; RCCL async error %d\n", nranks, nbodies, nm, nj,
                st.lds_islands, steps, async_error);
         printf("sharded world vs unsharded world: %s\n", differing_steps ? "DIFFERENT" : "identical after every step");
+    }
+    /* ---- ownership sharding (slab mode): this rank's x-slab of the same scene — whole columns = whole islands, plus the
+     *      static ground — as a world of its own; the ranks meet only to RE-SLAB (phx_world_reslab: intervals first, states only if
+     *      somebody changes owner), here once, over the same communicator, collectives on device buffers */
+    {
+        const int first = (int)((long long)columns * rank / nranks), last = (int)((long long)columns * (rank + 1) / nranks);
+        phx_world* slab = NULL;
+        TRY(phx_world_create(&slab, device));
+        TRY(phx_world_set_gravity(slab, -200.0f));
+        int64_t* scene_index = (int64_t*)malloc((size_t)nb * sizeof *scene_index);
+        if (!scene_index) return 1;
+        int32_t mine = 0;
+        const int ground = phx_world_add_body(slab, 0.0f, 0.0f, 0.0f, 15.0f * (float)columns, 10.0f);
+        if (ground < 0 || phx_world_set_body_static(slab, ground) != PHX_OK) return 1;
+        scene_index[mine++] = 0;
+        for (int c = first; c < last; ++c)
+            for (int r = 0; r < rows; ++r) {
+                if (phx_world_add_body(slab, ((float)c - (float)columns / 2.0f) * 15.0f, 15.0f + 10.0f * (float)r, 0.0f, 5.0f, 5.0f) < 0) return 1;
+                scene_index[mine++] = 1 + (int64_t)c * rows + r;
+            }
+        for (int s = 0; s < 3; ++s) TRY(phx_world_update(slab, 1.0f / 60.0f, &cfg));
+        const phx_slab_transport transport = {rank, nranks, comm, NULL, NULL, NULL};
+        double bounds[2] = {0.0, 0.0};
+        int32_t moved = 0;
+        const int32_t before = mine;
+        TRY(phx_world_reslab(slab, &transport, scene_index, nb, &mine, nb, 1.0, bounds, &moved));
+        for (int s = 0; s < 2; ++s) TRY(phx_world_update(slab, 1.0f / 60.0f, &cfg));
+        float extent[2] = {0.f, 0.f};
+        TRY(phx_world_x_extent(slab, extent));
+        const int inside = mine <= 1 || ((double)extent[0] > bounds[0] && (double)extent[1] < bounds[1]);
+        printf("rank %d of %d, slab mode: %d bodies before the re-slab, %d after (%s), slab (%g, %g), bodies within it: %s\n", rank, nranks, before, mine,
+               moved ? "bodies changed owner" : "nobody moved: the world was kept", bounds[0], bounds[1], inside ? "yes" : "NO");
+        free(scene_index);
+        phx_world_destroy(slab);
+        if (!inside) return 1;
     }
     free(a); free(b);
     if (twin) phx_world_destroy(twin);

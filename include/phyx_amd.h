@@ -415,6 +415,31 @@ int  phx_world_get_phase_ms(phx_world* w, double out8[8]);
  * holding the islands of one x-slab: phyx_amd/dist.py SlabWorld) checks it against its slab: as long as no body
  * leaves its slab no island can span two ranks and the ranks need nothing from each other but the per-step barrier. */
 int  phx_world_x_extent(phx_world* w, float out2[2]);
+/* RE-SLAB of an ownership-sharded run (csrc/reslab.hip): the collective hand-over of bodies between the ranks' worlds
+ * when a body has reached its slab's boundary.  Every rank calls phx_world_reslab at the same step with the scene indices of its world's
+ * bodies (static bodies of the scene live on every rank).  Phase 1: the ranks all-gather {scene index, x-interval} of their dynamic bodies
+ * (two bodies that share a manifold cover each other's interval), cut the x axis anew in the gaps no interval covers (phx_reslab_cuts:
+ * blocks of overlapping intervals are never split, the cuts balance the body counts) and see whether anybody changes owner; if nobody
+ * does, only `bounds` changes (*moved = 0) and the world keeps its allocations, its cached schedule and its broadphase state.  Phase 2,
+ * only otherwise: the ranks all-gather their worlds' states (what phx_world_set_state restores, warm-start impulses included) and every
+ * rank restores the part of the union world that lives in its new slab (*moved = 1; global_index / *body_count describe the new world).
+ * The hand-over is lossless: with unchanged cuts every rank gets its world back byte for byte.
+ * Transport: `comm` — the library's RCCL communicator, collectives on device buffers — or, where none can exist (several ranks on one
+ * GPU, another process group), the two host callbacks; transport == NULL or size 1: one rank, nothing is exchanged. */
+typedef struct {
+    int32_t rank, size;
+    phx_comm* comm;                                                                        /* may be NULL: the callbacks are used */
+    int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank);  /* host buffers; rank r's share at r * bytes_per_rank; 0 = ok */
+    int (*all_reduce_max)(void* user, int64_t* value);                                    /* in place; 0 = ok */
+    void* user;
+} phx_slab_transport;
+int  phx_world_reslab(phx_world* w, const phx_slab_transport* transport, int64_t* global_index, int32_t capacity, int32_t* body_count, int32_t scene_size,
+                      double margin, double bounds[2], int32_t* moved);
+/* the phases on their own (no device needed for the second and third): this world's dynamic bodies' scene indices and widened x-intervals;
+ * every rank's intervals -> sorted by scene index, with the new owner of every body and the ranks' bounds (2 per rank); the cuts themselves */
+int  phx_world_reslab_intervals(phx_world* w, const int64_t* global_index, int32_t body_count, int64_t* gi, double* lo, double* hi, int32_t cap, int32_t* count);
+int  phx_reslab_plan(int64_t* gi, double* lo, double* hi, int32_t n, int32_t nranks, double margin, int32_t* owner, double* bounds);
+int  phx_reslab_cuts(const double* lo, const double* hi, int32_t n, int32_t nranks, double margin, int32_t* owner, double* bounds);
 /* diagnostics: [0] steps whose PackManifolds count was settled together with the joint counts (the bet that no manifold dies),
  * [1] those of them that lost the bet (pack run late, joint match repeated), [2] solves repeated because the cached schedule was
  * stale or a group was left uncommitted, [3] third contact points dropped (ref: Collider.cpp:241-242 would overflow) */

@@ -46,6 +46,16 @@ class BenchResult(C.Structure):
                 ("joint_visits", C.c_int64), ("impulse_iterations", C.c_int64), ("bracketed_launches", C.c_int64)]
 
 
+SLAB_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)      # (user, send, recv, bytes_per_rank), host buffers
+SLAB_ALL_REDUCE_MAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64))              # (user, value in place)
+
+
+class SlabTransport(C.Structure):
+    """phx_slab_transport: how the ranks of a re-slab talk (include/phyx_amd.h)."""
+    _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("comm", C.c_void_p), ("all_gather", SLAB_ALL_GATHER), ("all_reduce_max", SLAB_ALL_REDUCE_MAX),
+                ("user", C.c_void_p)]
+
+
 _lib = None
 
 _vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
@@ -151,6 +161,10 @@ _SIGNATURES = {
     "phx_world_debug_counters": (C.c_int, [_vp, _vp]),
     "phx_world_build_counts": (C.c_int, [_vp, _vp]),
     "phx_world_x_extent": (C.c_int, [_vp, _vp]),
+    "phx_world_reslab": (C.c_int, [_vp, C.POINTER(SlabTransport), _vp, _i32, C.POINTER(_i32), _i32, C.c_double, _vp, C.POINTER(_i32)]),
+    "phx_world_reslab_intervals": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "phx_reslab_plan": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.c_double, _vp, _vp]),
+    "phx_reslab_cuts": (C.c_int, [_vp, _vp, _i32, _i32, C.c_double, _vp, _vp]),
     "phx_world_synchronize": (C.c_int, [_vp]),
 }
 

@@ -649,8 +649,52 @@ class World:
         check(self.L.phx_world_x_extent(self.h, _ptr(out)))
         return float(out[0]), float(out[1])
 
+    def reslab(self, global_index, scene_size, bounds, margin=1.0, rank=0, size=1, comm=None, all_gather=None, all_reduce_max=None):
+        """phx_world_reslab: the collective hand-over of an ownership-sharded world's bodies (every rank calls it at the same step).
+        global_index: scene index of every body of this world.  comm: a phyx_amd.Comm (collectives on device buffers through RCCL), or
+        the two host callables all_gather(send: uint8 array) -> uint8 array of size * len(send) and all_reduce_max(int) -> int.
+        Returns (moved, global_index, (lo, hi)): moved = somebody changed owner and this world was rebuilt for its new slab."""
+        from ._lib import SlabTransport, SLAB_ALL_GATHER, SLAB_ALL_REDUCE_MAX
+        gi = np.zeros(int(scene_size), dtype=np.int64)
+        gi[:len(global_index)] = np.asarray(global_index, dtype=np.int64)
+        count = C.c_int32(len(global_index))
+        b = np.asarray([bounds[0], bounds[1]], dtype=np.float64)
+        moved = C.c_int32(0)
+        errors = []
+
+        def gather_cb(user, send, recv, nbytes):
+            try:
+                mine = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy()
+                out = np.ascontiguousarray(all_gather(mine), dtype=np.uint8).reshape(-1)
+                if out.size != nbytes * size:
+                    raise RuntimeError("all_gather returned %d bytes, expected %d" % (out.size, nbytes * size))
+                C.memmove(recv, out.ctypes.data, out.size)
+                return 0
+            except Exception as e:          # (an exception must not unwind through the C frames)
+                errors.append(e)
+                return 1
+
+        def max_cb(user, value):
+            try:
+                value[0] = int(all_reduce_max(int(value[0])))
+                return 0
+            except Exception as e:
+                errors.append(e)
+                return 1
+        tp = SlabTransport()
+        tp.rank, tp.size = int(rank), int(size)
+        tp.comm = comm.h if comm is not None else None
+        g_cb = SLAB_ALL_GATHER(gather_cb) if all_gather is not None else SLAB_ALL_GATHER()
+        m_cb = SLAB_ALL_REDUCE_MAX(max_cb) if all_reduce_max is not None else SLAB_ALL_REDUCE_MAX()
+        tp.all_gather, tp.all_reduce_max, tp.user = g_cb, m_cb, None
+        st = self.L.phx_world_reslab(self.h, C.byref(tp), _ptr(gi), len(gi), C.byref(count), int(scene_size), float(margin), _ptr(b), C.byref(moved))
+        if errors:
+            raise errors[0]
+        check(st)
+        return bool(moved.value), gi[:count.value].copy(), (float(b[0]), float(b[1]))
+
     def build_counts(self):
-        """(incremental rebuilds, full rebuilds) of the schedule so far (phx_world_build_counts)."""
+        """(rebuilds whose components and bins came from the manifolds, rebuilds from the joints) so far (phx_world_build_counts)."""
         out = np.zeros(2, dtype=np.int64)
         check(self.L.phx_world_build_counts(self.h, _ptr(out)))
         return int(out[0]), int(out[1])

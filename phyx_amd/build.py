@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libphyx_amd.so")
-SOURCES = ["runtime.hip", "schedule.hip", "solver.hip", "solver_build.hip", "islands.hip", "exchange.hip", "comm.hip", "c_api_solver.hip", "broadphase.hip", "world.hip"]
+SOURCES = ["runtime.hip", "schedule.hip", "solver.hip", "solver_build.hip", "islands.hip", "exchange.hip", "comm.hip", "c_api_solver.hip", "broadphase.hip", "world.hip", "reslab.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result"]
 # per-file extras.  islands.hip: the SLP vectoriser pairs the joint update's multiplies and adds into v_pk_mul_f32 / v_pk_add_f32

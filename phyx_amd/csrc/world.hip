@@ -8,6 +8,7 @@
 // order-preserving, world_kernels.h) -> SolveJoints (DeviceSolver) -> IntegratePosition (kernel).  What crosses
 // PCIe per step is a handful of counters (new pairs, dead manifolds, new / dead joints) and, only when the joint
 // topology changed, the body-pair list the host schedule builder needs.
+#include "reslab.h"
 #include "handles.h"
 #include "device_scan.h"
 #include "world_kernels.h"
@@ -47,6 +48,7 @@ public:
     int download_joints(phx_contact_joint* out, int cap);
     int set_state(const phx_rigid_body* bodies, int body_count, const phx_manifold* manifolds, int manifold_count,
                   const phx_contact_point* cps, int cp_count, const phx_contact_joint* joints, int joint_count);
+    int get_slab_state(const long long* global_index, int count, SlabState* out);      // this world as a re-slab hands it over (reslab.h)
 
     int nb() const { return (int)host_bodies_.size(); }
     int nm = 0, nj = 0;
@@ -699,6 +701,18 @@ int World::set_state(const phx_rigid_body* bodies, int body_count, const phx_man
     return PHX_OK;
 }
 
+int World::get_slab_state(const long long* global_index, int count, SlabState* out)
+{
+    if (count != nb()) { set_error("re-slab: %d scene indices for a world of %d bodies", count, nb()); return PHX_ERR_INVALID; }
+    out->global_index.assign(global_index, global_index + count);
+    out->bodies.resize((size_t)nb()); out->manifolds.resize((size_t)nm); out->cps.resize(2 * (size_t)nm); out->joints.resize((size_t)nj);
+    PHX_TRY(download_bodies(out->bodies.data(), nb()));
+    PHX_TRY(download_manifolds(out->manifolds.data(), nm));
+    PHX_TRY(download_contact_points(out->cps.data(), 2 * nm));
+    PHX_TRY(download_joints(out->joints.data(), nj));
+    return PHX_OK;
+}
+
 int World::download_bodies(phx_rigid_body* out, int cap)
 {
     const int n = nb();
@@ -840,6 +854,67 @@ int phx_world_set_state(phx_world* w, const phx_rigid_body* bodies, int32_t body
 {
     PHX_REQUIRE(w, "null handle");
     return w->impl.set_state(bodies, body_count, manifolds, manifold_count, contact_points, contact_point_count, joints, joint_count);
+}
+
+// ---- re-slab (reslab.hip) ----
+static int slab_transport(const phx_slab_transport* t, phx::World& world, phx::SlabTransport* out)
+{
+    out->rank = 0; out->size = 1; out->stream = world.stream();
+    if (!t) return PHX_OK;
+    PHX_REQUIRE(t->size >= 1 && t->rank >= 0 && t->rank < t->size, "bad rank / size");
+    out->rank = t->rank; out->size = t->size; out->user = t->user;
+    out->gather_fn = t->all_gather; out->max_fn = reinterpret_cast<int (*)(void*, long long*)>(t->all_reduce_max);
+    if (t->comm) {
+        PHX_REQUIRE(t->comm->impl.size() == t->size && t->comm->impl.rank() == t->rank, "the communicator's rank / size differ from the transport's");
+        out->comm = &t->comm->impl;
+    }
+    return PHX_OK;
+}
+
+int phx_world_reslab_intervals(phx_world* w, const int64_t* global_index, int32_t body_count, int64_t* gi, double* lo, double* hi, int32_t cap, int32_t* count)
+{
+    PHX_REQUIRE(w && global_index && count, "null handle / arguments");
+    phx::SlabState st;
+    PHX_TRY(w->impl.get_slab_state(reinterpret_cast<const long long*>(global_index), body_count, &st));
+    std::vector<long long> g; std::vector<double> l, h;
+    PHX_TRY(phx::reslab_intervals(st, g, l, h));
+    *count = (int32_t)g.size();
+    if ((int)g.size() > cap) { phx::set_error("re-slab: %zu dynamic bodies, room for %d", g.size(), cap); return PHX_ERR_CAPACITY; }
+    PHX_REQUIRE(g.empty() || (gi && lo && hi), "null output");
+    for (size_t k = 0; k < g.size(); ++k) { gi[k] = g[k]; lo[k] = l[k]; hi[k] = h[k]; }
+    return PHX_OK;
+}
+
+int phx_reslab_plan(int64_t* gi, double* lo, double* hi, int32_t n, int32_t nranks, double margin, int32_t* owner, double* bounds)
+{
+    PHX_REQUIRE(n >= 0 && nranks >= 1 && bounds && (n == 0 || (gi && lo && hi && owner)), "bad arguments");
+    std::vector<long long> g(gi, gi + n); std::vector<double> l(lo, lo + n), h(hi, hi + n), b;
+    std::vector<int> o;
+    phx::reslab_plan(g, l, h, nranks, margin, o, b);
+    for (int k = 0; k < n; ++k) { gi[k] = g[(size_t)k]; lo[k] = l[(size_t)k]; hi[k] = h[(size_t)k]; owner[k] = o[(size_t)k]; }
+    for (int r = 0; r < 2 * nranks; ++r) bounds[r] = b[(size_t)r];
+    return PHX_OK;
+}
+
+int phx_world_reslab(phx_world* w, const phx_slab_transport* transport, int64_t* global_index, int32_t capacity, int32_t* body_count, int32_t scene_size, double margin,
+                     double bounds[2], int32_t* moved)
+{
+    PHX_REQUIRE(w && global_index && body_count && bounds && moved, "null handle / arguments");
+    PHX_REQUIRE(scene_size >= *body_count && capacity >= *body_count, "bad sizes");
+    phx::SlabTransport tp;
+    PHX_TRY(slab_transport(transport, w->impl, &tp));
+    phx::SlabState st;
+    PHX_TRY(w->impl.get_slab_state(reinterpret_cast<const long long*>(global_index), *body_count, &st));
+    int mv = 0;
+    PHX_TRY(phx::reslab(tp, st, scene_size, margin, bounds, &mv));
+    *moved = mv;
+    if (!mv) return PHX_OK;                                   // nobody changes owner: the world stays as it is, only its slab's bounds are new
+    if ((int)st.bodies.size() > capacity) { phx::set_error("re-slab: the new slab holds %zu bodies, room for %d scene indices", st.bodies.size(), capacity); return PHX_ERR_CAPACITY; }
+    PHX_TRY(w->impl.set_state(st.bodies.data(), (int)st.bodies.size(), st.manifolds.data(), (int)st.manifolds.size(), st.cps.data(), (int)st.cps.size(),
+                              st.joints.data(), (int)st.joints.size()));
+    for (size_t k = 0; k < st.global_index.size(); ++k) global_index[k] = st.global_index[k];
+    *body_count = (int32_t)st.bodies.size();
+    return PHX_OK;
 }
 
 int phx_world_get_solve_stats(phx_world* w, phx_solve_stats* out) { PHX_REQUIRE(w, "null handle"); return w->impl.solver().get_stats(out); }

@@ -698,6 +698,25 @@ class SlabWorld:
 
     def reslab(self):
         """Collective: every rank of the group must call it at the same step (step() does, on the all-reduced verdict).
+        A caller of the library's phx_world_reslab (csrc/reslab.hip) since round 6: the planning is the library's host code, the
+        collectives run on device buffers through the group's native RCCL communicator — or, where the group has none (gloo: several
+        ranks on one GPU), through this group's own all-gather / all-reduce as the library's two host callbacks.  reslab_python() below is
+        the round-5 statement of the same hand-over in numpy; the tests hold the two against each other."""
+        if getattr(self, "python_reslab", False):
+            return self.reslab_python()
+        g = self.group
+        native = getattr(g, "comm", None)
+        kw = {"comm": native} if native is not None else ({"all_gather": g.all_gather_bytes, "all_reduce_max": lambda v: int(g.reduce_max(v))} if g.world_size > 1 else {})
+        world_before = self.world
+        moved, gi, bounds = self.world.reslab(self.global_index, self.scene_size, self.bounds, margin=self.margin, rank=g.rank, size=g.world_size, **kw)
+        self.global_index, self.bounds = gi, bounds
+        self.reslabs += 1
+        if not moved:
+            self.reslabs_in_place = getattr(self, "reslabs_in_place", 0) + 1
+        assert self.world is world_before
+
+    def reslab_python(self):
+        """The same hand-over stated in numpy over host-staged collectives (round 5).
         Two phases.  First the ranks all-gather only their dynamic bodies' x-intervals (24 bytes per body) and cut the axis anew; if no
         body changes its owner — the usual case of a guard hit: a pile leaned over its old cut but the gaps are where they were —
         every rank KEEPS its World (allocations, cached schedule, broadphase splitters and all) and only takes its new bounds.  Only

@@ -67,6 +67,8 @@ def test_sharded_example_runs_the_native_rccl_step(tmp_path, built_lib):
         pytest.skip("no RCCL communicator on this box: " + r.stderr[-300:])
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical after every step" in r.stdout and "RCCL async error 0" in r.stdout
+    # the coda: a world of this rank's x-slab, re-slabbed once through the C ABI (phx_world_reslab over the native communicator)
+    assert "slab mode" in r.stdout and "bodies within it: yes" in r.stdout
 
 
 @pytest.mark.gpu
@@ -86,3 +88,4 @@ def test_sharded_example_two_ranks_on_one_gpu(tmp_path, built_lib):
         pytest.skip("RCCL refuses two ranks on one device: " + outs[0][1][-300:] + outs[1][1][-300:])
     assert all(p.returncode == 0 for p in procs), str(outs)
     assert "identical after every step" in outs[0][0]
+    assert all("slab mode" in o[0] and "bodies within it: yes" in o[0] for o in outs)      # both ranks re-slabbed (device buffers through RCCL)

@@ -175,3 +175,30 @@ def test_state_blobs_round_trip():
     for a, b in zip(arrays, back):
         assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
     assert [len(x) for x in pdist.all_gather_blobs(pdist.Single(), pdist._blob(*arrays))] == [len(pdist._blob(*arrays))]
+
+
+def test_library_slab_cuts_and_plan_equal_the_numpy_statement(built_lib):
+    """csrc/reslab.hip's planning (host code: no device needed) against phyx_amd.dist.slab_cuts / SlabWorld.reslab_plan on random
+    intervals: ties, nested and touching intervals, fewer blocks than ranks, no body at all."""
+    import ctypes as C
+    from phyx_amd import dist
+    rng = np.random.default_rng(3)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for trial in range(400):
+        n = int(rng.integers(0, 60)); nr = int(rng.integers(1, 6)); margin = float(rng.choice([0.0, 0.5, 1.0]))
+        lo = rng.uniform(-100, 100, n)
+        if n and rng.random() < 0.4:
+            lo = np.round(lo / 10) * 10                                  # ties
+        hi = lo + rng.uniform(0.1, 15 if rng.random() < 0.8 else 120, n)
+        owner_py, bounds_py = dist.slab_cuts(lo, hi, nr, margin)
+        owner = np.zeros(max(n, 1), dtype=np.int32); bounds = np.zeros(2 * nr)
+        assert built_lib.phx_reslab_cuts(vp(lo), vp(hi), n, nr, margin, vp(owner), vp(bounds)) == 0
+        assert np.array_equal(owner_py, owner[:n]) and np.array_equal(np.array(bounds_py, dtype=np.float64).reshape(-1), bounds), trial
+        # the plan: every rank's intervals in any order -> sorted by scene index, owners aligned with that order
+        gi = rng.permutation(1000)[:n].astype(np.int64)
+        order = np.argsort(gi, kind="stable")
+        g2, l2, h2 = gi.copy(), lo.copy(), hi.copy()
+        assert built_lib.phx_reslab_plan(vp(g2), vp(l2), vp(h2), n, nr, margin, vp(owner), vp(bounds)) == 0
+        want_owner, want_bounds = dist.slab_cuts(lo[order], hi[order], nr, margin)
+        assert np.array_equal(g2, gi[order]) and np.array_equal(l2, lo[order]) and np.array_equal(owner[:n], want_owner)
+        assert np.array_equal(np.array(want_bounds, dtype=np.float64).reshape(-1), bounds)

@@ -551,6 +551,13 @@ def test_reslab_across_processes(built_lib, ranks, every):
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["ranks"] == ranks and out["steps"] == 160 and out["reslabs"] >= 1
     assert out["dynamic_bodies_total"] == out["dynamic_bodies_scene"] and out["every_guard_holds"] and out["finite"]
+    # the library's re-slab (phx_world_reslab, csrc/reslab.hip; here over the group's collectives as its host callbacks) against the numpy
+    # statement of the same hand-over: the whole world after 160 steps and every re-slab on the way, byte for byte
+    q = subprocess.run([sys.executable, os.path.join(root, "tools", "reslab_ranks.py"), "--ranks", str(ranks), "--backend", "gloo", "--steps", "160", "--every", str(every), "--python"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert q.returncode == 0, q.stdout[-1500:] + q.stderr[-3000:]
+    twin = json.loads([ln for ln in q.stdout.splitlines() if ln.startswith("{")][-1])
+    assert twin["digest"] == out["digest"] and twin["reslabs"] == out["reslabs"]
 
 
 def test_world_state_save_and_restore_is_exact(built_lib):

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--steps", type=int, default=160)
     ap.add_argument("--every", type=int, default=0, help="re-slab every K steps whatever the guards say")
     ap.add_argument("--per-cluster", type=int, default=60)
+    ap.add_argument("--python", action="store_true", help="re-slab through the numpy statement of the hand-over (dist.SlabWorld.reslab_python) instead of phx_world_reslab")
     args = ap.parse_args()
     from phyx_amd import dist as pdist
     if "WORLD_SIZE" not in os.environ and args.ranks > 1:
@@ -27,6 +28,7 @@ def main():
     scene = scenes.piles(2 * args.ranks, args.per_cluster, pitch=64.0, ymax=220.0)
     cfg = phyx_amd.Configuration(phyx_amd.SOLVE_AVX2, phyx_amd.ISLAND_MULTIPLE, 10, 6)
     sw = pdist.SlabWorld(group, scene, device=device, gravity=-200.0, reslab_every=args.every)
+    sw.python_reslab = args.python
     for _ in range(args.steps):
         sw.step(1.0 / 60.0, cfg)
     bodies = sw.world.bodies
@@ -34,8 +36,9 @@ def main():
     total = int(group.reduce_sum(dyn))
     worst = int(group.step_barrier_value(0 if sw.inside() else 1))
     full = sw.gather_bodies()
+    import hashlib
     if group.rank == 0:
-        print(json.dumps({"ranks": group.world_size, "steps": sw.steps, "reslabs": sw.reslabs, "dynamic_bodies_total": total,
+        print(json.dumps({"digest": hashlib.sha256(full.tobytes()).hexdigest(), "ranks": group.world_size, "steps": sw.steps, "reslabs": sw.reslabs, "dynamic_bodies_total": total,
                           "dynamic_bodies_scene": int(np.count_nonzero(~np.asarray(scene["static"], dtype=bool))),
                           "dynamic_bodies_rank0": dyn, "every_guard_holds": worst == 0,
                           "finite": bool(np.isfinite(full["pos"]["x"]).all() and np.isfinite(full["pos"]["y"]).all()),
