@@ -681,7 +681,7 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
 {
     constexpr int LANES = T;
     constexpr int HT = 8 * LANES;                        // open-addressing table, <= 2 LANES distinct bodies
-    __shared__ __align__(8) int pool[2 * HT];            // the units' sort and staging, then the hash table
+    __shared__ __align__(16) int pool[2 * HT];            // the units' sort and staging, then the hash table
     int* ht_key = pool;                                  // later reused as the per-body priority table of the colouring
     static_assert((size_t)NB * 8 <= (size_t)HT * 4, "priority table must fit the hash table");
     int* ht_val = pool + HT;                             // first occurrence position, later the local index
@@ -736,23 +736,47 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
                 if ((unsigned)j0 >= (unsigned)v.nj || (j1 >= 0 && (unsigned)j1 >= (unsigned)v.nj)) { mismatch = true; ra.x = 0; ra.y = -1; }
             }
         }
-        unsigned key = tid < nu ? (unsigned)ra.x : 0x80000000u + (unsigned)tid;      // (the lanes beyond the bin's units sort behind them)
         int src = tid;
         unsigned* skey = reinterpret_cast<unsigned*>(pool); int* ssrc = pool + LANES;
         __syncthreads();
+        constexpr int LANE_BITS = LANES > 256 ? 9 : 8;
+        static_assert(LANES <= (1 << LANE_BITS), "lane index must fit the packed sort key");
+        if (v.nj < (1 << (31 - LANE_BITS))) {
+            // joint indices below 2^(31 - LANE_BITS): (joint, lane) is ONE 32-bit key — a shuffle, a min and a max per step of the network
+            unsigned kv = tid < nu ? ((unsigned)ra.x << LANE_BITS) | (unsigned)tid : 0x80000000u | (unsigned)tid;      // (the lanes beyond the bin's units sort behind them)
 #pragma unroll
-        for (int k = 2; k <= LANES; k <<= 1) {
+            for (int k = 2; k <= LANES; k <<= 1) {
 #pragma unroll
-            for (int st = k >> 1; st > 0; st >>= 1) {
-                unsigned okey; int osrc;
-                if (st >= 64) {
-                    skey[tid] = key; ssrc[tid] = src;
-                    __syncthreads();
-                    okey = skey[tid ^ st]; osrc = ssrc[tid ^ st];
-                    __syncthreads();
-                } else { okey = (unsigned)__shfl_xor((int)key, st); osrc = __shfl_xor(src, st); }
-                const bool take_min = ((tid & st) == 0) == ((tid & k) == 0);
-                if (take_min ? okey < key : okey > key) { key = okey; src = osrc; }
+                for (int st = k >> 1; st > 0; st >>= 1) {
+                    unsigned other;
+                    if (st >= 64) {
+                        skey[tid] = kv;
+                        __syncthreads();
+                        other = skey[tid ^ st];
+                        __syncthreads();
+                    } else other = (unsigned)__shfl_xor((int)kv, st);
+                    const bool take_min = ((tid & st) == 0) == ((tid & k) == 0);
+                    const unsigned lo = kv < other ? kv : other, hi = kv < other ? other : kv;
+                    kv = take_min ? lo : hi;
+                }
+            }
+            src = (int)(kv & (unsigned)((1 << LANE_BITS) - 1));
+        } else {
+            unsigned key = tid < nu ? (unsigned)ra.x : 0x80000000u + (unsigned)tid;
+#pragma unroll
+            for (int k = 2; k <= LANES; k <<= 1) {
+#pragma unroll
+                for (int st = k >> 1; st > 0; st >>= 1) {
+                    unsigned okey; int osrc;
+                    if (st >= 64) {
+                        skey[tid] = key; ssrc[tid] = src;
+                        __syncthreads();
+                        okey = skey[tid ^ st]; osrc = ssrc[tid ^ st];
+                        __syncthreads();
+                    } else { okey = (unsigned)__shfl_xor((int)key, st); osrc = __shfl_xor(src, st); }
+                    const bool take_min = ((tid & st) == 0) == ((tid & k) == 0);
+                    if (take_min ? okey < key : okey > key) { key = okey; src = osrc; }
+                }
             }
         }
         // (staging: six words per lane, in the words the hash table takes next)
@@ -768,7 +792,10 @@ static __global__ void __launch_bounds__(T) k_build_bin(BinBuildView v)
     // (manifolds) the unit's joints as the joint list has them: asked for here, looked at after the colouring
     phx_contact_joint q0{}, q1{};
     if (from_manifolds && live && !mismatch) { q0 = v.joints[j]; if (mate >= 0) q1 = v.joints[mate]; }
-    for (int i = tid; i < HT; i += LANES) { ht_key[i] = -1; ht_val[i] = 0x7fffffff; }
+    for (int i = tid; i < HT / 4; i += LANES) {          // (16 bytes per store)
+        reinterpret_cast<int4*>(ht_key)[i] = make_int4(-1, -1, -1, -1);
+        reinterpret_cast<int4*>(ht_val)[i] = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+    }
     __syncthreads();
     if (live) {
         for (int s = 0; s < 2; ++s) {                   // insert, keep the earliest occurrence position 2*tid+s

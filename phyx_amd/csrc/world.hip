@@ -20,6 +20,7 @@
 namespace phx {
 
 static inline int wgrid(int n) { return std::max(1, std::min(div_up(n, 256), 4096)); }
+constexpr int PRELABEL_EARLY_MANIFOLDS = 400000;      // worlds from this size on queue the side stream's share of the schedule rebuild before the joint match (refresh_contact_joints)
 
 class World {
 public:
@@ -324,6 +325,10 @@ int World::refresh_contact_joints()                                         // r
             PHX_HIP(hipMemsetAsync(joint_seen_.p, 0, joint_seen_.cap * sizeof(unsigned), stream_));
             joint_epoch_ = 1;
         }
+        // (the side stream's share of the rebuild is queued BEHIND the match and its scans in a small world — the host needs ~30 us for its
+        //  eight launches, more than those kernels run, and the GPU would idle — but IN FRONT of them in a large one, whose match alone runs
+        //  longer than that: at 1M boxes the side stream's 140 us were the critical path of the step, started 100 us after they could have)
+        if (nm >= PRELABEL_EARLY_MANIFOLDS) PHX_TRY(solver_.prelabel_components((const float4*)mpos_.p, nb(), (const phx_manifold*)d_manifolds_.p, nm));
         if (nm) {
             hipLaunchKernelGGL(k_joints_match, dim3(wgrid(nm)), dim3(256), 0, stream_, (const phx_manifold*)d_manifolds_.p, nm, (const phx_contact_point*)d_cps_.p,
                                d_joints_.p, joint_seen_.p, joint_epoch_, flags_.p);
