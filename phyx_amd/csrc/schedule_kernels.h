@@ -176,10 +176,15 @@ struct RootFlagLoad {
 // memory was fine while every column was its own island, but once a settling scene has merged into one island every
 // wave fired at the SAME counter: 1e4 same-address device atomics were 115 us of this 13 us kernel.
 constexpr int JC_T = 1024, JC_TABLE = 2048;
-struct CompCountTable { int key[JC_TABLE]; unsigned cnt[JC_TABLE], units[JC_TABLE]; };
+// (round 6: the table remembers which slots it handed out — `used`, in the order they were claimed — so that the flush visits those and
+//  resets them on the way, instead of every pass over 1024 items clearing and scanning all 2048 slots: at 1M boxes the clearing and
+//  scanning WAS the kernel — 55 us for a count whose loads take 15.  `nused` has one counter per pass parity: the flush of pass k
+//  resets the one pass k + 1 counts with, between its two barriers, when pass k - 1's readers are all through.)
+struct CompCountTable { int key[JC_TABLE]; unsigned cnt[JC_TABLE], units[JC_TABLE]; int used[JC_T]; int nused[2]; };
 __device__ __forceinline__ void comp_count_clear(CompCountTable& t)
 {
     for (int i = threadIdx.x; i < JC_TABLE; i += JC_T) { t.key[i] = -1; t.cnt[i] = 0; t.units[i] = 0; }
+    if (threadIdx.x < 2) t.nused[threadIdx.x] = 0;
     __syncthreads();
 }
 // every lane adds (1 + extra_joint joints, is_unit units) to component `mine` (< 0: nothing)
@@ -189,12 +194,13 @@ __device__ __forceinline__ void comp_count_clear(CompCountTable& t)
 //  to dozens of components and the leader loop — one serial round of LDS atomics per distinct component — was most of this
 //  kernel's 18 us at cfg 2.  Three rounds take care of waves with a few components, merged worlds included; whoever is left
 //  inserts for himself, all at once: different components, different slots.)
-__device__ __forceinline__ void comp_count_add(CompCountTable& t, int mine, bool extra_joint, bool is_unit)
+__device__ __forceinline__ void comp_count_add(CompCountTable& t, int pass, int mine, bool extra_joint, bool is_unit)
 {
     auto insert = [&](int comp, unsigned jn, unsigned un) {
         unsigned h = ((unsigned)comp * 2654435761u) >> 21;                             // 11 bits
         for (;; h = (h + 1) & (JC_TABLE - 1)) {                                        // <= JC_T distinct keys in a table of 2 * JC_T
             const int seen = atomicCAS(&t.key[h], -1, comp);
+            if (seen == -1) t.used[atomicAdd(&t.nused[pass & 1], 1)] = (int)h;         // (claimed: at most one claim per distinct key, <= JC_T of them)
             if (seen == -1 || seen == comp) { atomicAdd(&t.cnt[h], jn); if (un) atomicAdd(&t.units[h], un); break; }
         }
     };
@@ -210,11 +216,16 @@ __device__ __forceinline__ void comp_count_add(CompCountTable& t, int mine, bool
     }
     if ((todo >> (threadIdx.x & 63)) & 1ull) insert(mine, extra_joint ? 2u : 1u, is_unit ? 1u : 0u);
 }
-__device__ __forceinline__ void comp_count_flush(CompCountTable& t, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
+__device__ __forceinline__ void comp_count_flush(CompCountTable& t, int pass, unsigned* __restrict__ comp_size, unsigned* __restrict__ comp_units)
 {
     __syncthreads();
-    for (int i = threadIdx.x; i < JC_TABLE; i += JC_T)
-        if (t.key[i] >= 0) { atomicAdd(&comp_size[t.key[i]], t.cnt[i]); if (t.units[i]) atomicAdd(&comp_units[t.key[i]], t.units[i]); }
+    const int n = t.nused[pass & 1];
+    for (int i = threadIdx.x; i < n; i += JC_T) {
+        const int h = t.used[i];
+        atomicAdd(&comp_size[t.key[h]], t.cnt[h]); if (t.units[h]) atomicAdd(&comp_units[t.key[h]], t.units[h]);
+        t.key[h] = -1; t.cnt[h] = 0; t.units[h] = 0;
+    }
+    if (threadIdx.x == 0) t.nused[(pass & 1) ^ 1] = 0;
     __syncthreads();
 }
 
@@ -226,8 +237,9 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
     // (`unconverged`, may be null: raised if some joint's two dynamic bodies still carry different labels — a caller that skipped
     //  the hook round which only confirms convergence, solver.hip's speculative build, finds out here instead)
     __shared__ CompCountTable table;
-    for (int j0 = blockIdx.x * blockDim.x; j0 < nj; j0 += gridDim.x * blockDim.x) {       // uniform trip count per workgroup
-        comp_count_clear(table);
+    comp_count_clear(table);
+    int pass = 0;
+    for (int j0 = blockIdx.x * blockDim.x; j0 < nj; j0 += gridDim.x * blockDim.x, ++pass) {       // uniform trip count per workgroup
         const int j = j0 + (int)threadIdx.x;
         int mine = -1;
         unsigned lead_one = 0;
@@ -246,8 +258,8 @@ static __global__ void __launch_bounds__(JC_T) k_joint_components(const phx_cont
             joint_comp[j] = comp;
             mine = comp; lead_one = leads ? 1u : 0u;
         }
-        comp_count_add(table, mine, false, lead_one != 0);
-        comp_count_flush(table, comp_size, comp_units);
+        comp_count_add(table, pass, mine, false, lead_one != 0);
+        comp_count_flush(table, pass, comp_size, comp_units);
     }
 }
 
@@ -262,8 +274,9 @@ static __global__ void __launch_bounds__(JC_T) k_manifold_components(const phx_m
                                                                      unsigned* __restrict__ comp_units, int* __restrict__ flags)
 {
     __shared__ CompCountTable table;
-    for (int i0 = blockIdx.x * blockDim.x; i0 < nm; i0 += gridDim.x * blockDim.x) {
-        comp_count_clear(table);
+    comp_count_clear(table);
+    int pass = 0;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < nm; i0 += gridDim.x * blockDim.x, ++pass) {
         const int i = i0 + (int)threadIdx.x;
         int mine = -1;
         unsigned points = 0;
@@ -277,8 +290,8 @@ static __global__ void __launch_bounds__(JC_T) k_manifold_components(const phx_m
                 else atomicOr(flags, 1);
             }
         }
-        comp_count_add(table, mine, points == 2u, true);
-        comp_count_flush(table, comp_size, comp_units);
+        comp_count_add(table, pass, mine, points == 2u, true);
+        comp_count_flush(table, pass, comp_size, comp_units);
     }
 }
 

@@ -184,6 +184,7 @@ private:
         bool speculate = true;            // PHX_NO_SPECULATION=1 clears it
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
+        bool no_jp_defer = false;         // PHX_NO_JP_DEFER=1: the HBM group's colouring walk looks at its frontier sizes between the rounds (A/B, tests)
         bool no_prelabel = false;         // PHX_NO_PRELABEL=1: the World's rebuilds take their components from the joints (A/B, tests)
         bool force_big = false;           // PHX_ISL_SHAPE=big: the roomier workgroup shape whether or not a component needs it (measurements)
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
@@ -270,6 +271,7 @@ private:
                           : PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, P, P + 1, ki0, ki};
     }
     int jp_rounds_guess_ = 0;
+    unsigned jp_deferred_misses_ = 0;      // builds whose deferred look at the frontier found it not emptied (they were repeated the long way)
     // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;

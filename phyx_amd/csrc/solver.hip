@@ -61,6 +61,7 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     o.speculate = !on("PHX_NO_SPECULATION");
     o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
     o.no_prelabel = on("PHX_NO_PRELABEL");
+    o.no_jp_defer = on("PHX_NO_JP_DEFER");
     { const char* sh = getenv("PHX_ISL_SHAPE"); o.force_big = sh && sh[0] == 'b'; }
     o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
     o.trace_schedule = getenv("PHX_TRACE_SCHEDULE") != nullptr;  // print the schedule builders' laps to stderr

@@ -531,6 +531,15 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         jv.counts = bld_.jp_counts.p; jv.flags = bld_.jp_small.p; jv.hist = reinterpret_cast<unsigned*>(bld_.jp_small.p + 4);
         const unsigned* perm = nullptr;                     // the entries sorted by part (partitioned components only)
         const int parts = parts_total(nb);                    // over both levels (schedule.h)
+        // (round 6: the look at the frontier sizes — a host round trip in the middle of the rebuild — is DEFERRED to the build's last
+        //  readback when the previous build knows how many rounds the walk needs: that many + 2 are queued, the rest of the build
+        //  behind them, and only if the frontier turns out not to have emptied is the group built again with the look in between)
+        unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0, h_nstatic = 0;
+        int h_flags[3] = {0, 0, 0};                            // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI0; [2] KI1
+        for (int attempt = 0;; ++attempt) {
+        const bool defer_frontier = attempt == 0 && jp_rounds_guess_ > 0 && !trace && !opt_.no_jp_defer;
+        std::vector<int> deferred_sizes;
+        int deferred_rounds = 0;
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
         // priority, successor links and predecessor counts
         hipLaunchKernelGGL(k_jp_clear, dim3(grid_for(std::max(nb + 1, ncomp_total + 1))), dim3(256), 0, stream_, jv, JP_ROUNDS_MAX + 1);
@@ -563,7 +572,13 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         }
         // the rounds: as many as the previous build needed (+2) before the first look at the frontier, then in small batches
         int round = 0;
-        for (bool done = false; !done;) {
+        if (defer_frontier) {
+            deferred_rounds = std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX);
+            for (; round < deferred_rounds; ++round)
+                hipLaunchKernelGGL(k_jp_front, dim3(JP_SUBLISTS * std::max(1, std::min(div_up(rest, JP_FRONT_T * JP_ITEMS * JP_SUBLISTS), 64))), dim3(JP_FRONT_T), 0, stream_, jv, round, (const unsigned*)bld_.jp_list[round & 1].p, bld_.jp_list[(round + 1) & 1].p);
+            deferred_sizes.assign(((size_t)deferred_rounds + 1) * JP_SUBLISTS, 0);
+        }
+        for (bool done = defer_frontier; !done;) {
             const int batch = round == 0 ? std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX) : JP_BATCH;
             if (round + batch > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }           // pathological dependency chain: host builder
             for (int k = 0; k < batch; ++k, ++round)
@@ -600,7 +615,6 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         PHX_TRY(device_radix_sort_pairs(bld_.jp_keys[1].p, bld_.jp_vals[1].p, bld_.jp_keys[0].p, bld_.jp_vals[0].p, rest, 8, bld_.sort_hist.p, bld_.sort_scan, stream_, &where2));
         hipLaunchKernelGGL(k_jp_place, dim3(grid_for(rest)), dim3(256), 0, stream_, jv, (const unsigned*)bld_.jp_keys[where2 ^ 1].p, (const unsigned*)bld_.jp_vals[where2 ^ 1].p,
                            hbm_.order.p + lds_slots, lds_slots, perm ? reinterpret_cast<int*>(parts_.ranges.p) : (int*)nullptr);
-        unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0;
         PHX_TRY(rb_.add(h_hist, hist, sizeof h_hist, stream_));
         PHX_TRY(rb_.add(&h_touched, bld_.jp_touched.p + nb, sizeof h_touched, stream_));
         // static slots (only the HBM path indexes the global static-tag tables)
@@ -610,12 +624,27 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         hipLaunchKernelGGL(k_static_flags, dim3(grid_for(nb + 1)), dim3(256), 0, stream_, (const unsigned char*)bld_.cc_static.p, nb, sflags);
         PHX_TRY(device_exclusive_scan(sflags, nb + 1, nullptr, bld_.sort_scan, stream_));
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)bld_.cc_static.p, (const unsigned*)sflags, nb, hbm_.static_slot.p);
-        unsigned h_nstatic = 0;
-        int h_flags[3] = {0, 0, 0};                            // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI0; [2] KI1
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
         PHX_TRY(rb_.add(h_flags, bld_.jp_small.p, sizeof h_flags, stream_));
+        if (defer_frontier) {
+            PHX_TRY(with_fingerprint());
+            PHX_TRY(rb_.add(deferred_sizes.data(), bld_.jp_counts.p, deferred_sizes.size() * sizeof(int), stream_));
+        }
         PHX_TRY(rb_.wait(stream_));
+        if (defer_frontier) {
+            if (h_flags[0] & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
+            if (h_flags[0] & 4) { *fallback = true; return PHX_OK; }                           // a body in thousands of joints: host builder
+            bool emptied = false;
+            for (int k = 0; k <= deferred_rounds && !emptied; ++k) {
+                int n = 0;
+                for (int q = 0; q < JP_SUBLISTS; ++q) n += deferred_sizes[(size_t)k * JP_SUBLISTS + q];
+                if (n == 0) { emptied = true; jp_rounds_guess_ = k; }
+            }
+            if (!emptied) { ++jp_deferred_misses_; jp_rounds_guess_ = deferred_rounds; continue; }      // (uncoloured entries went through the choice: what it flagged means nothing)
+        }
         if (h_flags[0] & 2) { *fallback = true; return PHX_OK; }
+        break;
+        }
         sc.hbm_interior_classes = h_flags[1] + h_flags[2]; sc.hbm_interior_classes0 = h_flags[1];
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
