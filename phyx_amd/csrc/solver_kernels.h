@@ -514,6 +514,108 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
 }
 
 
+// ---- the same sweep of a level's parts with the NEXT class's constants requested a class ahead (round 6, level 0) ------------------------
+// k_solve_parts' class step was an HBM round trip: the step's loads are requested when the step begins (12 classes x ~1.6 us were the
+// launch).  Here lane t locates its unit of class c + 1 and requests its constants BEFORE it sweeps its unit of class c; the barrier
+// between two steps waits for the LDS traffic only (parts_lds_barrier), so the requests stay in flight across it.  What made earlier
+// attempts at this slower: the class tables read by vector loads in the loop (a `vmcnt(0)` per class for two table
+// rows: here they are staged in LDS once), register copies of the requested values at the loop's back edge (a wait for them right
+// behind the barrier: here two explicit register sets take turns) and a loop over units beyond the lanes in the class step (the
+// compiler drains the counter in front of it: an interior class of a part is body-disjoint inside the part's PART_BODIES bodies, so
+// it has at most PART_BODIES / 2 = PARTS_T units and there is nothing beyond the lanes).
+__device__ __forceinline__ void parts_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+static_assert(PART_BODIES / 2 <= PARTS_T, "a lane per unit of a class");
+
+struct PartUnit { HbmJoint q0, q1; int s0, s1; bool have; };
+
+// the body with BOTH halves decided at compile time: the displacement half's run-time gate (dead after the first sweep of a resting pile)
+// is taken once, by the kernel below — a request under a branch, even a uniform one, would be waited for where the branches join
+template <bool DO_IMP, bool DO_DISP>
+__device__ __forceinline__ void parts_ahead_body(const SolverView& v, const PartsView& pv, int iter, float4* s_imp, float4* s_disp, const int4* s_tab, const int4* s_rg,
+                                                 int base, int nclass)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < PART_BODIES; i += PARTS_T) {
+        const int g = base + i;
+        if (g < 0 || g >= v.nb) continue;
+        if (DO_IMP) s_imp[i] = v.sb_imp[g];
+        if (DO_DISP) s_disp[i] = v.sb_disp[g];
+    }
+    __syncthreads();
+    bool any_imp = false, any_disp = false;
+    // lane t's unit of the level's k-th class: located (n2 units with a follower, then the single ones) and requested.  EVERY lane requests
+    // something in every step, under no branch — a lane without a unit the class's first, a unit without a follower its leader's row, a
+    // step beyond the last class the last class again: requests under a branch make the compiler wait, where the branches join, as if
+    // they had not been made (`vmcnt(0)` in front of the sweep: the request a class ahead was waited for in the same step).
+    auto request = [&](int k, PartUnit& r) {
+        const int kk = min(k, nclass - 1);
+        const int4 tab = s_tab[kk], rg = s_rg[kk];
+        const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;
+        r.have = k < nclass && tid < n;
+        const int u = r.have ? tid : 0;
+        const bool has2 = u < n2;
+        const int s0 = has2 ? rg.x + u : rg.z + (u - n2);      // (a class with no unit in this part: slot 0 — some joint's row, read and dropped)
+        const int s1 = tab.x + tab.y + (s0 - tab.x);
+        r.q0 = hbm_load(v, s0, DO_IMP, DO_DISP, false);
+        r.q1 = hbm_load(v, has2 ? s1 : s0, DO_IMP, DO_DISP, true);
+        r.s0 = s0; r.s1 = has2 ? s1 : -1;
+    };
+    auto sweep = [&](PartUnit& r, int c) {
+        if (!r.have) return;
+        const int b1 = (r.q0.k.y - base) & (PART_BODIES - 1), b2 = (r.q0.k.z - base) & (PART_BODIES - 1);      // (masked: a stale schedule may meet other joints, solver.h)
+        float4 B1 = make_float4(0.f, 0.f, 0.f, 0.f), B2 = B1, D1 = B1, D2 = B1;
+        if (DO_IMP) { B1 = s_imp[b1]; B2 = s_imp[b2]; }
+        if (DO_DISP) { D1 = s_disp[b1]; D2 = s_disp[b2]; }
+        const float im1 = r.q0.c.y, ii1 = r.q0.c.z, im2 = r.q0.c.w, ii2 = __int_as_float(r.q0.k.x);
+        bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
+        solve_one(v, r.s0, r.q0, c, iter, DO_IMP, DO_DISP, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        if (r.s1 >= 0)
+            solve_one(v, r.s1, r.q1, c, iter, DO_IMP, DO_DISP, B1, B2, D1, D2, im1, ii1, im2, ii2, false, false, -1, false, false, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        if (DO_IMP) { if (dirty_imp) { s_imp[b1] = B1; s_imp[b2] = B2; } }
+        if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
+    };
+    // (ONE class ahead, two register sets taking turns.  Two ahead — three sets, 112 registers — measured slower: 17.2 against 16.3 us per
+    //  launch in the settled 200k world, the plain form 19.8.)
+    PartUnit a{}, b{};
+    request(0, a);
+    for (int k = 0; k < nclass; k += 2) {
+        request(k + 1, b);
+        sweep(a, pv.c0 + k);
+        parts_lds_barrier();
+        if (k + 1 >= nclass) break;
+        request(k + 2, a);
+        sweep(b, pv.c0 + k + 1);
+        parts_lds_barrier();
+    }
+    for (int i = tid; i < PART_BODIES; i += PARTS_T) {
+        const int g = base + i;
+        if (g < 0 || g >= v.nb) continue;
+        if (DO_IMP) v.sb_imp[g] = s_imp[i];
+        if (DO_DISP) v.sb_disp[g] = s_disp[i];
+    }
+    if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
+    if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
+}
+
+template <bool DO_IMP, bool DO_DISP>
+static __global__ void __launch_bounds__(PARTS_T) k_solve_parts_ahead(SolverView v, PartsView pv, int iter)
+{
+    __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
+    __shared__ float4 s_disp[DO_DISP ? PART_BODIES : 1];
+    __shared__ int4 s_tab[PARTS_CLASS_STRIDE], s_rg[PARTS_CLASS_STRIDE];
+    const int part = pv.first_part + (int)blockIdx.x, tid = threadIdx.x;
+    if (pv.part_begin[part] == pv.part_begin[part + 1]) return;      // nothing of a partitioned component in this part
+    const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
+    if (!DO_IMP && !disp_on) return;
+    const int base = part_first_body(part, v.nb);
+    const int nclass = min(pv.c1 - pv.c0, PARTS_CLASS_STRIDE);
+    if (nclass <= 0) return;
+    if (tid < nclass) { s_tab[tid] = pv.class_tab[pv.c0 + tid]; s_rg[tid] = pv.ranges[(size_t)part * PARTS_CLASS_STRIDE + pv.c0 + tid]; }
+    // (the tables are published by the body's first barrier, behind its load of the part's bodies)
+    if (DO_DISP && disp_on) parts_ahead_body<DO_IMP, true>(v, pv, iter, s_imp, s_disp, s_tab, s_rg, base, nclass);
+    else if (DO_IMP)        parts_ahead_body<true, false>(v, pv, iter, s_imp, s_disp, s_tab, s_rg, base, nclass);
+}
+
 // PreStepJoints of the interior classes, the same way (k_prestep's arithmetic and order)
 static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, PartsView pv)
 {
