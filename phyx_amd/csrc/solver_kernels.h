@@ -443,22 +443,35 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
 {
     __shared__ float4 s_imp[DO_IMP ? PART_BODIES : 1];
     __shared__ float4 s_disp[DO_DISP ? PART_BODIES : 1];
+    // (round 6: the level's rows of the class tables staged in LDS with the part's bodies — read from memory in the class loop they were a
+    //  round trip per class, and twice that in the level-1 launch, whose lanes first walk the classes to find their unit: 8.4 us for a few
+    //  dozen units per part)
+    __shared__ int4 s_tab[PARTS_CLASS_STRIDE], s_rg[PARTS_CLASS_STRIDE];
     const int part = pv.first_part + (int)blockIdx.x, tid = threadIdx.x;
-    if (pv.part_begin[part] == pv.part_begin[part + 1]) return;      // nothing of a partitioned component in this part
-    const int4* ranges = pv.ranges + (size_t)part * PARTS_CLASS_STRIDE;
     const bool imp_on = DO_IMP;
     const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
-    if (!imp_on && !disp_on) return;
+    const int nclass = min(pv.c1 - pv.c0, PARTS_CLASS_STRIDE);
     const int base = part_first_body(part, v.nb);           // (level 1: shifted by half a part; its first part starts below body 0)
+    const int units_before = pv.part_begin[part], units_after = pv.part_begin[part + 1];
+    if (tid < nclass) { s_tab[tid] = pv.class_tab[pv.c0 + tid]; s_rg[tid] = pv.ranges[(size_t)part * PARTS_CLASS_STRIDE + pv.c0 + tid]; }
+    for (int i = tid; i < PART_BODIES; i += PARTS_T) {
+        const int g = base + i;
+        if (g < 0 || g >= v.nb) continue;
+        if (DO_IMP) s_imp[i] = v.sb_imp[g];
+        if (DO_DISP) { if (disp_on) s_disp[i] = v.sb_disp[g]; }
+    }
+    if (units_before == units_after) return;                // nothing of a partitioned component in this part
+    if (!imp_on && !disp_on) return;
+    __syncthreads();
     int own_c = -1, own_s0 = 0, own_s1 = -1;
     HbmJoint own_q0{}, own_q1{};
     if (OWN_ONE) {
         int before = 0;
-        for (int c = pv.c0; c < pv.c1 && own_c < 0; ++c) {
-            const int4 tab = pv.class_tab[c], rg = ranges[c];
+        for (int k = 0; k < nclass && own_c < 0; ++k) {
+            const int4 tab = s_tab[k], rg = s_rg[k];
             const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z, u = tid - before;
             if (u < n) {
-                own_c = c;
+                own_c = pv.c0 + k;
                 own_s0 = u < n2 ? rg.x + u : rg.z + (u - n2);
                 own_q0 = hbm_load(v, own_s0, imp_on, disp_on, false);
                 if (u < n2) { own_s1 = tab.x + tab.y + (own_s0 - tab.x); own_q1 = hbm_load(v, own_s1, imp_on, disp_on, true); }
@@ -466,13 +479,6 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
             before += n;
         }
     }
-    for (int i = tid; i < PART_BODIES; i += PARTS_T) {
-        const int g = base + i;
-        if (g < 0 || g >= v.nb) continue;
-        if (DO_IMP) s_imp[i] = v.sb_imp[g];
-        if (DO_DISP) { if (disp_on) s_disp[i] = v.sb_disp[g]; }
-    }
-    __syncthreads();
     bool any_imp = false, any_disp = false;
     auto sweep = [&](int s0, int s1, HbmJoint& q0, HbmJoint& q1, int c) {
         const int b1 = (q0.k.y - base) & (PART_BODIES - 1), b2 = (q0.k.z - base) & (PART_BODIES - 1);      // (masked: a stale schedule may meet other joints, solver.h)
@@ -488,8 +494,9 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts(SolverView v, Pa
         if (DO_DISP) { if (dirty_disp) { s_disp[b1] = D1; s_disp[b2] = D2; } }
     };
     int before = 0;                                         // units of the level's earlier classes in this part
-    for (int c = pv.c0; c < pv.c1; ++c) {
-        const int4 tab = pv.class_tab[c], rg = ranges[c];
+    for (int k = 0; k < nclass; ++k) {
+        const int c = pv.c0 + k;
+        const int4 tab = s_tab[k], rg = s_rg[k];
         const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;      // the part's units of this class: n2 with a follower, then the single ones
         if (OWN_ONE) { if (own_c == c) sweep(own_s0, own_s1, own_q0, own_q1, c); }
         for (int u = OWN_ONE ? max(PARTS_T - before, 0) + tid : tid; u < n; u += PARTS_T) {      // (OWN_ONE: the units no lane owns)
@@ -620,21 +627,24 @@ static __global__ void __launch_bounds__(PARTS_T) k_solve_parts_ahead(SolverView
 static __global__ void __launch_bounds__(PARTS_T) k_prestep_parts(SolverView v, PartsView pv)
 {
     __shared__ float4 s_imp[PART_BODIES];
+    __shared__ int4 s_tab[PARTS_CLASS_STRIDE], s_rg[PARTS_CLASS_STRIDE];      // (the level's rows of the class tables: k_solve_parts)
     const int part = pv.first_part + (int)blockIdx.x;
-    if (pv.part_begin[part] == pv.part_begin[part + 1]) return;
-    const int4* ranges = pv.ranges + (size_t)part * PARTS_CLASS_STRIDE;
+    const int nclass = min(pv.c1 - pv.c0, PARTS_CLASS_STRIDE);
     const int base = part_first_body(part, v.nb);
+    const int units_before = pv.part_begin[part], units_after = pv.part_begin[part + 1];
+    if ((int)threadIdx.x < nclass) { s_tab[threadIdx.x] = pv.class_tab[pv.c0 + threadIdx.x]; s_rg[threadIdx.x] = pv.ranges[(size_t)part * PARTS_CLASS_STRIDE + pv.c0 + threadIdx.x]; }
     for (int i = threadIdx.x; i < PART_BODIES; i += PARTS_T) { const int g = base + i; if (g >= 0 && g < v.nb) s_imp[i] = v.sb_imp[g]; }
+    if (units_before == units_after) return;
     __syncthreads();
-    for (int c = pv.c0; c < pv.c1; ++c) {
-        const int4 tab = pv.class_tab[c], rg = ranges[c];
+    for (int k = 0; k < nclass; ++k) {
+        const int4 tab = s_tab[k], rg = s_rg[k];
         const int n2 = rg.y - rg.x, n = n2 + rg.w - rg.z;
         for (int u = (int)threadIdx.x; u < n; u += PARTS_T) {
             const int s0 = u < n2 ? rg.x + u : rg.z + (u - n2), i = s0 - tab.x;
             const float4 m = v.q2[s0];
-            const int4 k = v.q3[s0];
-            const float im1 = m.y, ii1 = m.z, im2 = m.w, ii2 = __int_as_float(k.x);
-            const int l1 = (k.y - base) & (PART_BODIES - 1), l2 = (k.z - base) & (PART_BODIES - 1);
+            const int4 k3 = v.q3[s0];
+            const float im1 = m.y, ii1 = m.z, im2 = m.w, ii2 = __int_as_float(k3.x);
+            const int l1 = (k3.y - base) & (PART_BODIES - 1), l2 = (k3.z - base) & (PART_BODIES - 1);
             float4 B1 = s_imp[l1], B2 = s_imp[l2];
             prestep_one(v, s0, B1, B2, im1, ii1, im2, ii2, false, false);
             if (i < tab.z) prestep_one(v, tab.x + tab.y + i, B1, B2, im1, ii1, im2, ii2, false, false);
