@@ -98,7 +98,7 @@ def pmc_traffic():
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same script, read side corrected x2 as MI355X_MICROARCH.md §HBM says.
     A pass is only as good as the kernel it profiled: the file records the source fingerprint and the commit it was taken at, and a
     file taken of another island_kernel.h / solver_kernels.h is REFUSED (`stale`) rather than quoted."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
         if os.path.exists(path):
             try:
@@ -731,7 +731,7 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     # measured traffic: ONLY the kernels of one profiled steady update, each weighted by its launches in that update and listed with its
     # time (tools/steady_step_summary.py: kernel trace + the two PMC passes of the same step) — round 4 summed every kernel name in
     # the PMC file, one-off first-update kernels included, and its 'traffic = algorithmic' was a coincidence
-    pm4 = steady_step_file("r05_cfg4_steady_step")
+    pm4 = steady_step_file("r06_cfg4_steady_step") or steady_step_file("r05_cfg4_steady_step")
     bp_rows = [r for r in pm4.get("kernels", []) if r.get("phase") == "broadphase"]
     bp_traffic = sum(r["hbm_bytes"] for r in bp_rows) or None
     bp_us = sum(r["us"] for r in bp_rows) or None
@@ -764,7 +764,7 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
     t0 = time.perf_counter(); r = s5.bench(arrs[0], arrs[1], arrs[2], cfg5, 0, 10); el = time.perf_counter() - t0
     st = s5.stats()
     launch5_us = 1e3 * r.impulse_kernel_ms / max(r.bracketed_launches, 1)
-    pm5 = pmc_file("r05_pmc_traffic_cfg5")
+    pm5 = pmc_file("r06_pmc_traffic_cfg5") or pmc_file("r05_pmc_traffic_cfg5")
     tr5 = next((v for k, v in pm5.get("kernels", {}).items() if "k_solve_islands<512" in k), None)
     alg5 = (BYTES_IMPULSE_VISIT * r.joint_visits + BYTES_DISPLACEMENT_VISIT * st.displacement_iterations * arrs[2].count * 10) / max(r.impulse_launches, 1)
     res["cfg5_500k_tall_50it_fp32"] = {"ms_per_step": 1e3 * el / 10, "joint_visits_per_sec": r.joint_visits / el, "joints": arrs[2].count,

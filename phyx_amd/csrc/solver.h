@@ -184,10 +184,8 @@ private:
         bool speculate = true;            // PHX_NO_SPECULATION=1 clears it
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
-        bool parts_plain = false;         // PHX_PARTS_PLAIN=1: k_solve_parts without the class-ahead requests (A/B)
         bool no_jp_defer = false;         // PHX_NO_JP_DEFER=1: the HBM group's colouring walk looks at its frontier sizes between the rounds (A/B, tests)
         bool no_prelabel = false;         // PHX_NO_PRELABEL=1: the World's rebuilds take their components from the joints (A/B, tests)
-        bool force_big = false;           // PHX_ISL_SHAPE=big: the roomier workgroup shape whether or not a component needs it (measurements)
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
         int isl_wait_polls = 0;           // PHX_ISL_WAIT_POLLS
         static Options from_env();

@@ -62,8 +62,6 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
     o.no_prelabel = on("PHX_NO_PRELABEL");
     o.no_jp_defer = on("PHX_NO_JP_DEFER");
-    o.parts_plain = on("PHX_PARTS_PLAIN");
-    { const char* sh = getenv("PHX_ISL_SHAPE"); o.force_big = sh && sh[0] == 'b'; }
     o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
     o.trace_schedule = getenv("PHX_TRACE_SCHEDULE") != nullptr;  // print the schedule builders' laps to stderr
     return o;
@@ -289,14 +287,10 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
                 for (int level = 0; level < part_levels(); ++level) {
                     const PartsView pv = parts_view(level, v.nb);
                     const dim3 g(pv.parts), b(PARTS_T);
-                    if (level == 0 && !opt_.parts_plain) {      // a part's ~1000 units, class by class, the next class's constants requested a class ahead
+                    if (level == 0) {      // a part's ~1000 units, class by class, the next class's constants requested a class ahead (solver_kernels.h)
                         if (imp && disp) hipLaunchKernelGGL((k_solve_parts_ahead<true, true>), g, b, 0, stream_, v, pv, it);
                         else if (imp)    hipLaunchKernelGGL((k_solve_parts_ahead<true, false>), g, b, 0, stream_, v, pv, it);
                         else             hipLaunchKernelGGL((k_solve_parts_ahead<false, true>), g, b, 0, stream_, v, pv, it);
-                    } else if (level == 0) {
-                        if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true, false>), g, b, 0, stream_, v, pv, it);
-                        else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false, false>), g, b, 0, stream_, v, pv, it);
-                        else             hipLaunchKernelGGL((k_solve_parts<false, true, false>), g, b, 0, stream_, v, pv, it);
                     } else {           // a level-1 part has a few dozen units: a lane owns one, everything requested up front
                         if (imp && disp) hipLaunchKernelGGL((k_solve_parts<true, true, true>), g, b, 0, stream_, v, pv, it);
                         else if (imp)    hipLaunchKernelGGL((k_solve_parts<true, false, true>), g, b, 0, stream_, v, pv, it);

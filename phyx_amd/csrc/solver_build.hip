@@ -132,7 +132,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
         caps.max_units = ISL_T; caps.max_joints = 2 * ISL_T; caps.max_bodies = ISL_B; caps.max_colours = 64;
         LdsCaps big;
         big.max_units = ISL_T_BIG; big.max_joints = 2 * ISL_T_BIG; big.max_bodies = ISL_B_BIG; big.max_colours = 64;
-        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, opt_.force_big ? big : caps, sched_, &big, prio_id.data());
+        build_island_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, caps, sched_, &big, prio_id.data());
     } else {
         build_colour_schedule(b1.data(), b2.data(), nj, is_static.data(), nb, sched_, prio_id.data());
     }
@@ -407,7 +407,6 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     int cap_units = ISL_T, cap_bodies = ISL_B;
     auto fits = [&](int c, int units) { return (int)comp_size[c] <= 2 * units && (int)comp_units[c] <= units; };
     for (int c = 0; c < ncomp; ++c) if (comp_size[c] && !fits(c, ISL_T) && fits(c, ISL_T_BIG)) { cap_units = ISL_T_BIG; cap_bodies = ISL_B_BIG; break; }
-    if (opt_.force_big) { cap_units = ISL_T_BIG; cap_bodies = ISL_B_BIG; }
     sc.lds_lanes = cap_units;
     std::vector<int> bin_of(std::max(ncomp, 1), -1), rank_of(std::max(ncomp, 1), 0);     // rank of a component inside its bin (schedule.h: the colouring candidate is chosen per component)
     {

@@ -16,7 +16,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o main -
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O -o pmc_fetch -- python $R/bench.py $ARGS > $O/bench_pmc_fetch.json 2> $O/pmc_fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O -o pmc_write -- python $R/bench.py $ARGS > $O/bench_pmc_write.json 2> $O/pmc_write.err
 timeout 600 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $O -o world -- python $R/tools/steady.py 12 --no-phase-timing > $O/world_steady.txt 2> $O/world.err
-python $R/tools/timeline.py $O/world_kernel_trace.csv k_build_keys -v > $O/world_step_timeline.txt 2>&1
+python $R/tools/timeline.py $O/world_kernel_trace.csv k_keys_buckets -v > $O/world_step_timeline.txt 2>&1
 ls $O
 head -14 $O/trace_kernel_stats.csv
 head -3 $O/world_step_timeline.txt
