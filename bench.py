@@ -48,7 +48,7 @@ BYTES_DISPLACEMENT_VISIT = 136   # per displacement joint-visi
 # barrier 128.  Round 4 measured what one wave can do (profiles/r04_unit_issue_probe.txt, profiles/r04_sq_islands.json): a wave64
 # issues ONE instruction per ~4 cycles whether or not it depends on the last one, and the working wave of a class step issues
 # ~222 VALU instructions (SQ_INSTS_VALU per group and class step) — so the floor of a class step is that many issue slots.
-# Round 5 (profiles/r05_sq_islands.json): 164 VALU instructions per group and class step, all four waves and the first sweep's
+# Round 5 (profiles/r06_sq_islands.json): 164 VALU instructions per group and class step, all four waves and the first sweep's
 # displacement half included; the working wave of an impulse-only step issues ~112 of them.
 COLOUR_STEP_CHAIN_FLOOR_CYCLES = 64 + 2 * 26 * 4 + 13 + 128
 COLOUR_STEP_VALU_INSTRUCTIONS = 105          # round 5: a class step of the impulse half in fused arithmetic (island_kernel.h half_step)
@@ -378,7 +378,7 @@ def run_bench(args, pdist):
                      "floor_cycles_per_colour_step": COLOUR_STEP_FLOOR_CYCLES,
                      "floor_what": "class step of the one working wave: LDS read 64 + %d VALU instructions x 4 cycles of issue (measured: one wave64 issues an "
                                    "instruction per ~4 cycles dependent or not, profiles/r04_unit_issue_probe.txt; instructions of the hot form of a class step, "
-                                   "island_kernel.h half_step; SQ counters of the whole launch: profiles/r05_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
+                                   "island_kernel.h half_step; SQ counters of the whole launch: profiles/r06_sq_islands.json) + LDS write 13 + barrier 128 cycles" % COLOUR_STEP_VALU_INSTRUCTIONS,
                      "dependent_chain_floor_cycles_round3": COLOUR_STEP_CHAIN_FLOOR_CYCLES}
             try:
                 # wave passes per sweep over all groups, from the host-side statement of the same schedule (phx_schedule_groups: classes
@@ -445,7 +445,7 @@ def run_bench(args, pdist):
             "unit": "joint-visits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "none (one GPU)" if world == 1 else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("cfg2: stack(%d,%d) = %d bodies / %d joints, Single Sloppy island mode, %d+%d iterations, one SolveJoints "
                                     "per step on HBM-resident inputs (bodies in the resident structure-of-arrays layout), schedule cached "
