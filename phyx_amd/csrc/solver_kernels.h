@@ -77,6 +77,12 @@ __device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i
 // of its last kernel in stamps[1] (max).
 __device__ __forceinline__ void solve_stamp_begin(unsigned long long* stamps) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(&stamps[0], (unsigned long long)wall_clock64()); }
 __device__ __forceinline__ void solve_stamp_end(unsigned long long* stamps) { if (threadIdx.x == 0) atomicMax(&stamps[1], (unsigned long long)wall_clock64()); }
+// the same from a wide streaming kernel whose workgroups all end at once: every 32nd workgroup and the last one stamp (all of them firing at
+// the one word were ~25 of k_finish_bodies' 30 us in a 200k-body world: same-address atomics take their turns)
+__device__ __forceinline__ void solve_stamp_end_sparse(unsigned long long* stamps)
+{
+    if (threadIdx.x == 0 && ((blockIdx.x & 31u) == 31u || blockIdx.x == gridDim.x - 1)) atomicMax(&stamps[1], (unsigned long long)wall_clock64());
+}
 
 // ---- PrepareBodies (ref: Solver.cpp:456-480) -----------------------------------------------------
 // `list` = the bodies the HBM group touches (islands solved in LDS read the records directly)
@@ -672,7 +678,7 @@ static __global__ void __launch_bounds__(256) k_finish_joints(SolverView v, int 
 
 static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, const int* __restrict__ list, int count, BodyView bodies)
 {
-    if (*v.fingerprint != v.expected_fingerprint) { solve_stamp_end(v.stamps); return; }
+    if (*v.fingerprint != v.expected_fingerprint) { solve_stamp_end_sparse(v.stamps); return; }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
         const int i = list[k];
         float4 a = v.sb_imp[i], d = v.sb_disp[i];
@@ -680,7 +686,7 @@ static __global__ void __launch_bounds__(256) k_finish_bodies(SolverView v, cons
         bodies.vel[i] = a;
         bodies.dvel[i] = d;
     }
-    solve_stamp_end(v.stamps);
+    solve_stamp_end_sparse(v.stamps);
 }
 
 } // namespace phx
