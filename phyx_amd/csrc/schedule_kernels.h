@@ -149,6 +149,39 @@ static __global__ void __launch_bounds__(256) k_cc_compress(int* parent, int nb,
     }
 }
 
+// The flattening pass in TWO launches (round 6): first every window of CCW_BODIES consecutive bodies jumps its pointers in LDS until each
+// body points at its root or at an ancestor BELOW the window (parent[x] <= x: chains only run downwards; a stacked column is a chain as
+// deep as it is tall), then k_cc_compress walks what is left — a hop per window the chain spans instead of a hop per body.  The kernel
+// boundary is what makes the windows' work visible to each other (eight XCDs, L2s not coherent: inside ONE launch a walk that leaves its
+// window meets the other windows' entries as they were — the single-launch form of this measured no faster than the plain walk).
+constexpr int CCW_T = 256, CCW_BODIES = 256;      // (1024-body windows, four bodies a lane: 10.9 us at cfg 2 where 256-body windows take less — more workgroups in flight)
+static __global__ void __launch_bounds__(CCW_T) k_cc_compress_window(int* parent, int nb)
+{
+    __shared__ int p[CCW_BODIES];
+    __shared__ int changed;
+    const int base = (int)blockIdx.x * CCW_BODIES, tid = threadIdx.x;
+    for (int j = tid; j < CCW_BODIES; j += CCW_T) p[j] = base + j < nb ? parent[base + j] : -1;
+    __syncthreads();
+    static_assert(CCW_BODIES <= 1024, "ten doublings");
+    for (int round = 0; round < 10; ++round) {               // 2^10 >= the window: a chain through every body of it is flat after that many doublings
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        bool any = false;
+        for (int j = tid; j < CCW_BODIES; j += CCW_T) {
+            const int q = p[j];
+            if (q >= base && q != base + j) {                // my parent is in the window and is not me: take its parent (an ancestor of mine)
+                const int r = p[q - base];
+                if (r != q) { p[j] = r; any = true; }        // (r == q: q is a root — I am flat)
+            }
+        }
+        if (any) changed = 1;
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();                                     // (everybody has read the flag before the next round clears it)
+    }
+    for (int j = tid; j < CCW_BODIES; j += CCW_T) if (base + j < nb) parent[base + j] = p[j];
+}
+
 // loader of the 'roots before body i' scan (device_scan.h): 1 for every component root; also zeroes the per-component joint
 // and unit counters that k_joint_components fills next (nb + 1 words)
 struct RootFlagLoad {

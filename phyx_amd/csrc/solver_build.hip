@@ -266,6 +266,7 @@ int DeviceSolver::prelabel_components(const float4* d_mpos, int nb, const phx_ma
     PHX_HIP(hipStreamWaitEvent(side_stream_, ev_pre_fork_, 0));
     hipLaunchKernelGGL(k_cc_init_bodies, dim3(grid_for(nb)), dim3(256), 0, side_stream_, d_mpos, nb, bld_.cc_parent.p, bld_.cc_static.p, bld_.side_flags.p);
     hipLaunchKernelGGL(k_cc_link_manifolds, dim3(grid_for(nm)), dim3(256), 0, side_stream_, d_manifolds, nm, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p);
+    hipLaunchKernelGGL(k_cc_compress_window, dim3(std::max(1, div_up(nb, CCW_BODIES))), dim3(CCW_T), 0, side_stream_, bld_.cc_parent.p, nb);
     hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, side_stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
     PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size_s[set].p, bld_.comp_units_s[set].p}, bld_.cc_flags.p, nb + 1,
                                      reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.prelabel_scan, side_stream_));
@@ -362,6 +363,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     {
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
                            (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
+        hipLaunchKernelGGL(k_cc_compress_window, dim3(std::max(1, div_up(nb, CCW_BODIES))), dim3(CCW_T), 0, stream_, bld_.cc_parent.p, nb);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size().p, bld_.comp_units().p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
@@ -708,6 +710,7 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
         ++full_builds_;
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
                            (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
+        hipLaunchKernelGGL(k_cc_compress_window, dim3(std::max(1, div_up(nb, CCW_BODIES))), dim3(CCW_T), 0, stream_, bld_.cc_parent.p, nb);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size().p, bld_.comp_units().p}, bld_.cc_flags.p, nb + 1,
                                          reinterpret_cast<unsigned*>(bld_.sb_small.p + 1), bld_.sort_scan, stream_));
