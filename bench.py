@@ -716,6 +716,19 @@ def other_configs(phyx_amd, scenes, Configuration, device, cfg2_world, cfg2):
                                  "ms_per_step": 1e3 * float(np.median(t)), "lds_islands": sst.lds_islands, "colours": sst.colour_count,
                                  "interior_classes": ki, "parts": parts, "sweep_launches_per_solve": launches,
                                  "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), cfg2_world.counts()))}
+    # ... and the same world 40 steps later: the pile loosens again (hundreds of loose pieces beside the big island, whose boundary units — bodies
+    # whose neighbours lie far away in the body order — need up to ten small trailing classes; k_solve_tail sweeps those in one launch)
+    for _ in range(38):
+        cfg2_world.Update(1.0 / 60.0, cfg2)
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter(); cfg2_world.Update(1.0 / 60.0, cfg2); cfg2_world.sync(); t.append(time.perf_counter() - t0)
+    sst = cfg2_world.solver.stats()
+    ki, parts, launches = cfg2_world.solver.partition()
+    res["loosened_world_step"] = {"what": "World::Update of the same world at steps 100-104: the big island beside hundreds of workgroup-sized ones",
+                                  "ms_per_step": 1e3 * float(np.median(t)), "lds_islands": sst.lds_islands, "colours": sst.colour_count,
+                                  "interior_classes": ki, "parts": parts, "sweep_launches_per_solve": launches,
+                                  "counts": dict(zip(("bodies", "manifolds", "contact_points", "joints"), cfg2_world.counts()))}
     # cfg 4: 1M boxes, broadphase-heavy
     w4 = phyx_amd.World(device, gravity=-200.0)
     w4.add_scene(scenes.stack(10000, 100))

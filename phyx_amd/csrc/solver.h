@@ -177,6 +177,7 @@ private:
     // the PHX_* knobs (measurement and debugging; README.md lists them)
     struct Options {
         bool no_side_stream = false;      // PHX_NO_SIDE_STREAM=1: everything on the one stream
+        bool no_tail = false;             // PHX_NO_TAIL=1: the HBM group's trailing tiny classes one launch each (k_solve_colour) instead of one workgroup's launch (k_solve_tail)
         bool no_parts = false;            // PHX_NO_PARTS=1: sweep the interior classes one launch each
         bool no_fused_verify = false;     // PHX_NO_FUSED_VERIFY=1: always the hash pass (also set for good once a verified launch timed out)
         bool use_graphs = false;          // PHX_GRAPHS=1
@@ -184,7 +185,6 @@ private:
         bool speculate = true;            // PHX_NO_SPECULATION=1 clears it
         bool no_islands = false;          // PHX_NO_ISLANDS=1
         bool no_spec_bins = false;        // PHX_NO_SPEC_BINS=1
-        bool no_jp_defer = false;         // PHX_NO_JP_DEFER=1: the HBM group's colouring walk looks at its frontier sizes between the rounds (A/B, tests)
         bool no_prelabel = false;         // PHX_NO_PRELABEL=1: the World's rebuilds take their components from the joints (A/B, tests)
         bool trace_schedule = false;      // PHX_TRACE_SCHEDULE
         int isl_wait_polls = 0;           // PHX_ISL_WAIT_POLLS
@@ -260,6 +260,8 @@ private:
     DevBuf<float4> edge_vel_, edge_dvel_, edge_mpos_;      // resident form of the records a C-ABI edge call handed over
     Arrays cur_;                                          // arrays of the solve being queued (view() reads the resident mpos from it)
     int upload_class_tab(const Schedule& sc, int* interior_leaders);
+    int tail_first_class(int from) const;                     // k_solve_tail's share of the HBM group's classes (solver.hip)
+    bool class_tab_ok_ = false;                               // parts_.class_tab describes sched_'s HBM classes
     int upload_part_tables();            // host-built schedules: part_units_ / part_class_begin_ from sched_
     bool parts_in_use() const { return !opt_.no_parts && parts_.count > 0 && sched_.hbm_interior_classes > 0; }
     int part_levels() const { return sched_.hbm_interior_classes > sched_.hbm_interior_classes0 ? 2 : 1; }
@@ -270,7 +272,6 @@ private:
                           : PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, P, P + 1, ki0, ki};
     }
     int jp_rounds_guess_ = 0;
-    unsigned jp_deferred_misses_ = 0;      // builds whose deferred look at the frontier found it not emptied (they were repeated the long way)
     // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;

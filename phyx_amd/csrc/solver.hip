@@ -51,6 +51,7 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
     Options o;
     o.no_side_stream = on("PHX_NO_SIDE_STREAM");          // everything on the one stream (A/B measurements)
+    o.no_tail = on("PHX_NO_TAIL");                        // the trailing tiny classes of the HBM group one launch each (A/B, tests)
     o.no_parts = on("PHX_NO_PARTS");                      // the interior classes of partitioned components one launch each (A/B, tests)
     o.no_fused_verify = on("PHX_NO_FUSED_VERIFY");        // the topology hash pass in front of every solve on a cached schedule
     const char* wp = getenv("PHX_ISL_WAIT_POLLS");        // tests: 0 makes every workgroup of a verified launch give up, so that ISL_COMPLETE runs
@@ -61,7 +62,6 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     o.speculate = !on("PHX_NO_SPECULATION");
     o.no_islands = on("PHX_NO_ISLANDS");                  // ignore island modes, always the HBM colour path
     o.no_prelabel = on("PHX_NO_PRELABEL");
-    o.no_jp_defer = on("PHX_NO_JP_DEFER");
     o.no_spec_bins = on("PHX_NO_SPEC_BINS") || o.use_graphs;      // every rebuild reads the component sizes back and bins them on the host
     o.trace_schedule = getenv("PHX_TRACE_SCHEDULE") != nullptr;  // print the schedule builders' laps to stderr
     return o;
@@ -221,6 +221,18 @@ int DeviceSolver::enqueue_pre(const BodyView& d_bodies, int nb, const phx_contac
     return PHX_OK;
 }
 
+// First class of the HBM group's trailing run of classes of at most TAIL_T units each (at most TAIL_CLASSES_MAX of them), not before class
+// `from`; the class count if the run is shorter than two classes (one class is as well off in its own launch) or the class table is not
+// on the device.
+int DeviceSolver::tail_first_class(int from) const
+{
+    const int ncol = (int)sched_.hbm_class_leaders.size();
+    if (opt_.no_tail || !class_tab_ok_) return ncol;
+    int t = ncol;
+    while (t > from && sched_.hbm_class_leaders[t - 1] <= TAIL_T && ncol - (t - 1) <= TAIL_CLASSES_MAX) --t;
+    return ncol - t >= 2 ? t : ncol;
+}
+
 int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_point* d_cps, phx_contact_joint* d_joints, int nj, int ci, int pi, int mode_override)
 {
     const SolverView v = view();
@@ -300,12 +312,20 @@ int DeviceSolver::enqueue_sweeps(const BodyView& d_bodies, const phx_contact_poi
                 }
                 c0 = sched_.hbm_interior_classes;
             }
-            for (int c = c0; c < ncol; ++c) {
+            const int tail = tail_first_class(c0);             // the trailing run of tiny classes: one launch, one workgroup (k_solve_tail)
+            for (int c = c0; c < tail; ++c) {
                 const int cb = sched_.hbm_colour_offsets[c], ce = sched_.hbm_colour_offsets[c + 1], lead = sched_.hbm_class_leaders[c], foll = ce - cb - lead;
                 const dim3 g(std::max(1, std::min(div_up(lead, SOLVE_BLOCK), 8192))), b(SOLVE_BLOCK);
                 if (imp && disp) hipLaunchKernelGGL((k_solve_colour<true, true>), g, b, 0, stream_, v, cb, lead, foll, c, it);
                 else if (imp)    hipLaunchKernelGGL((k_solve_colour<true, false>), g, b, 0, stream_, v, cb, lead, foll, c, it);
                 else             hipLaunchKernelGGL((k_solve_colour<false, true>), g, b, 0, stream_, v, cb, lead, foll, c, it);
+                ++sweep_launches_;
+            }
+            if (tail < ncol) {
+                const int4* tab = parts_.class_tab.p;
+                if (imp && disp) hipLaunchKernelGGL((k_solve_tail<true, true>), dim3(1), dim3(TAIL_T), 0, stream_, v, tab, tail, ncol - tail, it);
+                else if (imp)    hipLaunchKernelGGL((k_solve_tail<true, false>), dim3(1), dim3(TAIL_T), 0, stream_, v, tab, tail, ncol - tail, it);
+                else             hipLaunchKernelGGL((k_solve_tail<false, true>), dim3(1), dim3(TAIL_T), 0, stream_, v, tab, tail, ncol - tail, it);
                 ++sweep_launches_;
             }
         }

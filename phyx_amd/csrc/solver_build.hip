@@ -67,6 +67,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
     }
 
     tables_pending_ = false;      // (a rebuild: whatever the last speculative build left unfetched on the device is about to be overwritten)
+    class_tab_ok_ = false;        // (... and the HBM group's class table belongs to the schedule that is being replaced)
     // 2. topology changed.  Schedules are built on the device (only component sizes cross PCIe); the host builder below is
     //    the specification and the fallback (bins that exceed the caps, more than 64 colours, ...).
     if (device_builder) {
@@ -96,6 +97,7 @@ int DeviceSolver::ensure_schedule(const float4* d_bodies, int nb, const phx_cont
         }
         sched_.valid = false;
         build_unverified_ = false;                     // (the host builder's schedules need no verification)
+        if (opt_.trace_schedule || getenv("PHX_TRACE_SPEC")) fprintf(stderr, "[schedule] the device builder handed %d joints to the host builder\n", nj);
     }
     const unsigned long long raw = fp;
     fp ^= ((unsigned long long)(unsigned)nj << 32) ^ (unsigned)nb;
@@ -532,15 +534,11 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         jv.counts = bld_.jp_counts.p; jv.flags = bld_.jp_small.p; jv.hist = reinterpret_cast<unsigned*>(bld_.jp_small.p + 4);
         const unsigned* perm = nullptr;                     // the entries sorted by part (partitioned components only)
         const int parts = parts_total(nb);                    // over both levels (schedule.h)
-        // (round 6: the look at the frontier sizes — a host round trip in the middle of the rebuild — is DEFERRED to the build's last
-        //  readback when the previous build knows how many rounds the walk needs: that many + 2 are queued, the rest of the build
-        //  behind them, and only if the frontier turns out not to have emptied is the group built again with the look in between)
         unsigned h_hist[2 * JP_MAX_COLOURS], h_touched = 0, h_nstatic = 0;
         int h_flags[3] = {0, 0, 0};                            // [0] bit 1: the interior + other classes exceed the device builder's 64; [1] KI0; [2] KI1
-        for (int attempt = 0;; ++attempt) {
-        const bool defer_frontier = attempt == 0 && jp_rounds_guess_ > 0 && !trace && !opt_.no_jp_defer;
-        std::vector<int> deferred_sizes;
-        int deferred_rounds = 0;
+        // (round 6 tried to take the look at the frontier sizes below with the build's LAST readback — as many rounds queued as the previous
+        //  build needed, + 2: a plain step was no faster (the host's wait overlaps queued work) and six of 120 steps of the settling 200k world
+        //  needed more rounds than that and were built twice, 0.4 ms each: removed)
         // the dependency graph of the colouring (schedule_kernels.h): entry cache + degrees, lists per dynamic body ordered by
         // priority, successor links and predecessor counts
         hipLaunchKernelGGL(k_jp_clear, dim3(grid_for(std::max(nb + 1, ncomp_total + 1))), dim3(256), 0, stream_, jv, JP_ROUNDS_MAX + 1);
@@ -573,13 +571,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         }
         // the rounds: as many as the previous build needed (+2) before the first look at the frontier, then in small batches
         int round = 0;
-        if (defer_frontier) {
-            deferred_rounds = std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX);
-            for (; round < deferred_rounds; ++round)
-                hipLaunchKernelGGL(k_jp_front, dim3(JP_SUBLISTS * std::max(1, std::min(div_up(rest, JP_FRONT_T * JP_ITEMS * JP_SUBLISTS), 64))), dim3(JP_FRONT_T), 0, stream_, jv, round, (const unsigned*)bld_.jp_list[round & 1].p, bld_.jp_list[(round + 1) & 1].p);
-            deferred_sizes.assign(((size_t)deferred_rounds + 1) * JP_SUBLISTS, 0);
-        }
-        for (bool done = defer_frontier; !done;) {
+        for (bool done = false; !done;) {
             const int batch = round == 0 ? std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX) : JP_BATCH;
             if (round + batch > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }           // pathological dependency chain: host builder
             for (int k = 0; k < batch; ++k, ++round)
@@ -627,25 +619,8 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)bld_.cc_static.p, (const unsigned*)sflags, nb, hbm_.static_slot.p);
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
         PHX_TRY(rb_.add(h_flags, bld_.jp_small.p, sizeof h_flags, stream_));
-        if (defer_frontier) {
-            PHX_TRY(with_fingerprint());
-            PHX_TRY(rb_.add(deferred_sizes.data(), bld_.jp_counts.p, deferred_sizes.size() * sizeof(int), stream_));
-        }
         PHX_TRY(rb_.wait(stream_));
-        if (defer_frontier) {
-            if (h_flags[0] & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
-            if (h_flags[0] & 4) { *fallback = true; return PHX_OK; }                           // a body in thousands of joints: host builder
-            bool emptied = false;
-            for (int k = 0; k <= deferred_rounds && !emptied; ++k) {
-                int n = 0;
-                for (int q = 0; q < JP_SUBLISTS; ++q) n += deferred_sizes[(size_t)k * JP_SUBLISTS + q];
-                if (n == 0) { emptied = true; jp_rounds_guess_ = k; }
-            }
-            if (!emptied) { ++jp_deferred_misses_; jp_rounds_guess_ = deferred_rounds; continue; }      // (uncoloured entries went through the choice: what it flagged means nothing)
-        }
         if (h_flags[0] & 2) { *fallback = true; return PHX_OK; }
-        break;
-        }
         sc.hbm_interior_classes = h_flags[1] + h_flags[2]; sc.hbm_interior_classes0 = h_flags[1];
         nstatic_ = (int)h_nstatic;
         sc.hbm_body_count = (int)h_touched;
@@ -661,11 +636,13 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         sc.group_offsets.push_back(nj);
         // k_solve_parts' tables: the classes' slot layout; the parts' ranges were left by k_jp_place, their unit counts by the sort by part
         parts_.count = 0;
+        {
+            int interior_leaders = 0;
+            PHX_TRY(upload_class_tab(sc, &interior_leaders));      // (k_solve_parts' and k_solve_tail's table)
+        }
         if (sc.hbm_interior_classes > 0) {
             const int ki = sc.hbm_interior_classes;
             if (!perm || ki >= (int)sc.hbm_class_leaders.size() + 1 || ki > JP_MAX_COLOURS) { set_error("interior classes out of range"); return PHX_ERR_STATE; }
-            int interior_leaders = 0;
-            PHX_TRY(upload_class_tab(sc, &interior_leaders));
             parts_.count = parts;
         }
         PHX_TRY(hbm_.sb_imp.reserve(nbs)); PHX_TRY(hbm_.sb_disp.reserve(nbs));
@@ -815,7 +792,8 @@ int DeviceSolver::upload_class_tab(const Schedule& sc, int* interior_leaders)
         if ((int)c < sc.hbm_interior_classes) *interior_leaders = before;
     }
     PHX_TRY(parts_.class_tab.reserve(std::max<size_t>(tab.size(), 64)));
-    PHX_HIP(hipMemcpyAsync(parts_.class_tab.p, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
+    if (!tab.empty()) PHX_HIP(hipMemcpyAsync(parts_.class_tab.p, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, stream_));
+    class_tab_ok_ = true;
     return PHX_OK;
 }
 
@@ -824,9 +802,9 @@ int DeviceSolver::upload_part_tables()
 {
     parts_.count = 0;
     const int ki = sched_.hbm_interior_classes;
-    if (ki <= 0 || sched_.part_begin.empty()) return PHX_OK;      // (more than 64 interior classes: no tables, one launch per class)
     int interior_leaders = 0;
-    PHX_TRY(upload_class_tab(sched_, &interior_leaders));
+    PHX_TRY(upload_class_tab(sched_, &interior_leaders));         // (k_solve_parts' and k_solve_tail's table)
+    if (ki <= 0 || sched_.part_begin.empty()) return PHX_OK;      // (more than 64 interior classes: no tables, one launch per class)
     if (interior_leaders != sched_.part_begin.back()) { set_error("part tables do not match the interior classes"); return PHX_ERR_STATE; }
     const size_t parts = sched_.part_begin.size() - 1;
     PHX_TRY(parts_.ranges.reserve(parts * PARTS_CLASS_STRIDE)); PHX_TRY(parts_.begin.reserve(parts + 2));

@@ -422,6 +422,113 @@ static __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_colour(SolverView 
     if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
 }
 
+// ---- the TAIL of the HBM group's classes in one launch, one workgroup (round 6) ---------------------------------------------------------
+// The last classes of an island too big for a workgroup are tiny — the units of a pile's loose ends and of bodies whose neighbours lie far
+// away in the body order: ten classes of 3 .. 1600 joints each once the settled 200k-box pile loosens again (steps 80+), one launch of
+// k_solve_colour per class and sweep, 4 us + a kernel boundary for a microsecond of work: 60 % of that world's solve.  Here ONE workgroup
+// sweeps the trailing classes of at most TAIL_T units one after the other with a workgroup barrier where the launches had a kernel
+// boundary (one workgroup = one CU = one L1: its own stores are visible to its later loads behind __syncthreads(); the static bodies' tags
+// are atomics at the coherent level and read past the L1 by static_productive) — and, which is what round 3's form of this lacked (it was no
+// faster than the launches: a class cost its two dependent memory round trips wherever it ran), lane t requests the constants of its
+// unit of class c + 1 BEFORE it sweeps its unit of class c, under no branch (k_solve_parts_ahead says why), so a class step is the body
+// gather, the arithmetic and the stores' acknowledgement, not an HBM round trip.  Same arithmetic (solve_one), same slot order: bit-identical
+// to the launches.
+constexpr int TAIL_T = 1024, TAIL_CLASSES_MAX = 64;
+
+struct TailUnit { HbmJoint q0, q1; int s0, s1; bool have; float4 B1, B2, D1, D2; unsigned tag[4]; };
+
+// static_productive() on words already loaded ({sweep iter - 1's, sweep iter's} of the body's slot)
+__device__ __forceinline__ bool static_productive_words(unsigned prev, unsigned cur, int iter, int colour)
+{
+    if (iter == 0) return true;
+    if ((prev >> 16) == (unsigned)iter) return true;
+    return (cur >> 16) == (unsigned)(iter + 1) && (0xFFFFu - (cur & 0xFFFFu)) < (unsigned)colour;
+}
+
+template <bool DO_IMP, bool DO_DISP>
+__device__ __forceinline__ void tail_body(const SolverView& v, const int4* s_tab, int c_first, int nclass, int iter)
+{
+    const int tid = threadIdx.x;
+    bool any_imp = false, any_disp = false;
+    // Every load of a class step is made by every lane under no branch (a lane without a unit takes the class's first unit's, a unit
+    // without a static body the first static slot's words), and in this order: the bodies and tags of the class at hand, THEN the
+    // constants of the next class — the arithmetic waits for the first lot with the second still in flight (the counter is in order).
+    auto request = [&](int k, TailUnit& r) {
+        const int4 tab = s_tab[min(k, nclass - 1)];             // {first slot, leaders, followers, -}: lane t's unit = leader t (+ follower t)
+        r.have = k < nclass && tid < tab.y;
+        const int u = r.have ? tid : 0;
+        const bool has2 = u < tab.z;
+        const int s0 = tab.x + u, s1 = tab.x + tab.y + u;
+        r.q0 = hbm_load(v, s0, DO_IMP, DO_DISP, false);
+        r.q1 = hbm_load(v, has2 ? s1 : s0, DO_IMP, DO_DISP, true);
+        r.s0 = s0; r.s1 = has2 ? s1 : -1;
+    };
+    auto gather = [&](TailUnit& r) {                            // (r's constants have arrived: requested a class ago, behind a barrier since)
+        const int b1 = clamp_index(r.q0.k.y, v.nb), b2 = clamp_index(r.q0.k.z, v.nb), slot = max(r.q0.k.w, 0);
+        r.B1 = r.B2 = r.D1 = r.D2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DO_IMP) { r.B1 = v.sb_imp[b1]; r.B2 = v.sb_imp[b2]; }
+        if (DO_DISP) { r.D1 = v.sb_disp[b1]; r.D2 = v.sb_disp[b2]; }
+        r.tag[0] = r.tag[1] = r.tag[2] = r.tag[3] = 0u;
+        if (DO_IMP) {
+            r.tag[0] = __hip_atomic_load(&v.sw_imp[((iter + 1) & 1) * v.nstatic + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.tag[1] = __hip_atomic_load(&v.sw_imp[(iter & 1) * v.nstatic + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (DO_DISP) {
+            r.tag[2] = __hip_atomic_load(&v.sw_disp[((iter + 1) & 1) * v.nstatic + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.tag[3] = __hip_atomic_load(&v.sw_disp[(iter & 1) * v.nstatic + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto sweep = [&](TailUnit& r, int colour) {                // (k_solve_colour's loop body on requested constants and gathered bodies)
+        if (!r.have) return;
+        const int b1 = r.q0.k.y, b2 = r.q0.k.z, ss = r.q0.k.w;
+        float4 B1 = r.B1, B2 = r.B2, D1 = r.D1, D2 = r.D2;
+        const float im1 = r.q0.c.y, ii1 = r.q0.c.z, im2 = r.q0.c.w, ii2 = __int_as_float(r.q0.k.x);
+        const bool st1 = (im1 == 0.f && ii1 == 0.f), st2 = (im2 == 0.f && ii2 == 0.f);
+        const float4 S1 = B1, S2 = B2, T1 = D1, T2 = D2;
+        bool tag_imp = false, tag_disp = false, dirty_imp = false, dirty_disp = false;
+        const bool sp_imp = DO_IMP && (st1 || st2) && static_productive_words(r.tag[0], r.tag[1], iter, colour);
+        const bool sp_disp = DO_DISP && (st1 || st2) && static_productive_words(r.tag[2], r.tag[3], iter, colour);
+        solve_one(v, r.s0, r.q0, colour, iter, DO_IMP, DO_DISP, B1, B2, D1, D2, im1, ii1, im2, ii2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        if (r.s1 >= 0) {                               // a static body's record is never stored: the follower must see it untouched
+            if (st1) { B1 = S1; D1 = T1; }
+            if (st2) { B2 = S2; D2 = T2; }
+            solve_one(v, r.s1, r.q1, colour, iter, DO_IMP, DO_DISP, B1, B2, D1, D2, im1, ii1, im2, ii2, st1, st2, ss, sp_imp, sp_disp, any_imp, any_disp, tag_imp, tag_disp, dirty_imp, dirty_disp);
+        }
+        if (dirty_imp) { if (!st1) v.sb_imp[b1] = B1; if (!st2) v.sb_imp[b2] = B2; }
+        if (dirty_disp) { if (!st1) v.sb_disp[b1] = D1; if (!st2) v.sb_disp[b2] = D2; }
+        if (DO_IMP) wave_tag_update(v.sw_imp + (iter & 1) * v.nstatic, tag_imp, ss, static_word(iter, colour));
+        if (DO_DISP) wave_tag_update(v.sw_disp + (iter & 1) * v.nstatic, tag_disp, ss, static_word(iter, colour));
+    };
+    TailUnit a{}, b{};
+    request(0, a);
+    for (int k = 0; k < nclass; k += 2) {
+        gather(a);
+        request(k + 1, b);
+        sweep(a, c_first + k);
+        __syncthreads();                                       // (the class's stores and tag atomics are through: the next class may read them)
+        if (k + 1 >= nclass) break;
+        gather(b);
+        request(k + 2, a);
+        sweep(b, c_first + k + 1);
+        __syncthreads();
+    }
+    if (DO_IMP && __any(any_imp) && (threadIdx.x & 63) == 0) v.imp_active[iter] = 1;
+    if (DO_DISP && __any(any_disp) && (threadIdx.x & 63) == 0) v.disp_active[iter] = 1;
+}
+
+// class_tab: the HBM group's class table (solver.h PartsView); classes [c_first, c_first + nclass), each of at most TAIL_T units
+template <bool DO_IMP, bool DO_DISP>
+static __global__ void __launch_bounds__(TAIL_T) k_solve_tail(SolverView v, const int4* __restrict__ class_tab, int c_first, int nclass, int iter)
+{
+    __shared__ int4 s_tab[TAIL_CLASSES_MAX];
+    const bool disp_on = DO_DISP && (iter == 0 || v.disp_active[iter - 1] != 0);
+    if (!DO_IMP && !disp_on) return;
+    if ((int)threadIdx.x < nclass) s_tab[threadIdx.x] = class_tab[c_first + threadIdx.x];
+    __syncthreads();
+    if (DO_DISP && disp_on) tail_body<DO_IMP, true>(v, s_tab, c_first, nclass, iter);
+    else if (DO_IMP)        tail_body<true, false>(v, s_tab, c_first, nclass, iter);
+}
+
 // ---- the interior classes of partitioned components: ONE launch per sweep (schedule.h) ------------------------------------
 // A merged island (a settled pile: 1e5-1e6 joints in one connected component) is swept class by class out of HBM, one launch
 // per class and sweep.  Its interior units — both bodies in one PART of PART_BODIES consecutive indices — occupy the leading

@@ -469,7 +469,8 @@ def test_partitioned_component_is_swept_by_parts(oracle, built_lib, monkeypatch,
     """A connected component of more than 1024 joints (here a brick wall: one island of 1.1e4 joints — the shape of a settled pile)
     is partitioned: units inside one block of 512 bodies get the leading classes of the HBM group and ONE launch per sweep
     sweeps them all (k_solve_parts), the boundary classes stay one launch each.  Device builder == host builder, the fused
-    launch == one launch per class (PHX_NO_PARTS=1), and all of them == the oracle's replay of the exported schedule."""
+    launch == one launch per class (PHX_NO_PARTS=1, with and without k_solve_tail's one launch for the trailing tiny classes), and all of
+    them == the oracle's replay of the exported schedule."""
     import os
     state = presolve_state(scenes.wall(48, 60), 10)
     assert len(state[2]) > 1024
@@ -480,14 +481,17 @@ def test_partitioned_component_is_swept_by_parts(oracle, built_lib, monkeypatch,
     host = phyx_amd.Solver(0)
     monkeypatch.delenv("PHX_SCHEDULE_BUILDER")
     monkeypatch.setenv("PHX_NO_PARTS", "1")
+    tailed = phyx_amd.Solver(0)                 # no parts: every class a launch of its own — but for the trailing tiny ones, which k_solve_tail sweeps in one
+    monkeypatch.setenv("PHX_NO_TAIL", "1")
     plain = phyx_amd.Solver(0)
     monkeypatch.delenv("PHX_NO_PARTS")
+    monkeypatch.delenv("PHX_NO_TAIL")
     gb, gj, sched, _, st = _device_solve(dev, state, cfg)
     ki, parts, launches = dev.partition()
     classes = len(sched.colours) - 1
     assert st.lds_islands == 0 and ki >= 4 and classes - ki >= 1 and parts == 2 * ((len(state[0]) + 511) // 512) + 1      # both levels
     sweeps = max(st.impulse_iterations, st.displacement_iterations)
-    assert launches == max(ci, pi) * (2 + classes - ki)            # one launch per level for the interior classes + one per rest class
+    assert launches <= max(ci, pi) * (2 + classes - ki)            # one launch per level for the interior classes + one per rest class (or fewer: the tail)
     hb, hj, hsched, _, hst = _device_solve(host, state, cfg)
     assert np.array_equal(hsched.order, sched.order) and np.array_equal(hsched.colours, sched.colours) and np.array_equal(hsched.groups, sched.groups)
     assert host.partition()[:2] == (ki, parts)
@@ -497,6 +501,13 @@ def test_partitioned_component_is_swept_by_parts(oracle, built_lib, monkeypatch,
     assert plain.partition() == (ki, 0, max(ci, pi) * classes)
     assert pb.tobytes() == gb.tobytes() and pj.tobytes() == gj.tobytes()
     assert (pst.impulse_iterations, pst.displacement_iterations, pst.joint_visits) == (st.impulse_iterations, st.displacement_iterations, st.joint_visits)
+    # ... and the trailing classes of at most 1024 units in ONE workgroup's launch (k_solve_tail): fewer launches, the same bytes
+    tb, tj, tsched, _, tst = _device_solve(tailed, state, cfg)
+    assert np.array_equal(tsched.order, sched.order) and np.array_equal(tsched.colours, sched.colours)
+    tki, tparts, tlaunches = tailed.partition()
+    assert (tki, tparts) == (ki, 0) and tlaunches < max(ci, pi) * classes and tlaunches % max(ci, pi) == 0
+    assert tb.tobytes() == gb.tobytes() and tj.tobytes() == gj.tobytes()
+    assert (tst.impulse_iterations, tst.displacement_iterations, tst.joint_visits) == (st.impulse_iterations, st.displacement_iterations, st.joint_visits)
     ob_, oj, ost = _oracle_in_device_order(oracle, state, sched, None, cfg, oracle.STAG_COLOUR_SYNC)
     assert gb.tobytes() == ob_.tobytes() and gj.tobytes() == oj.tobytes()
     assert (st.impulse_iterations, st.displacement_iterations) == (ost.impulse_iterations, ost.displacement_iterations) and sweeps > 0
