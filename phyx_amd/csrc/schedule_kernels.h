@@ -1194,6 +1194,63 @@ static __global__ void __launch_bounds__(256) k_jp_seed(JpView v, const unsigned
 constexpr int JP_ITEMS = 1;           // (4 entries per lane was measured slower: a round is latency bound and wants the lanes)
 
 
+// one frontier entry takes its classes under both candidates and releases its successors (s0, s1: the ones it was the last predecessor of)
+__device__ __forceinline__ void jp_colour_entry(const JpView& v, unsigned k, int& comp, unsigned long long& got_a, unsigned long long& got_b, unsigned& s0, unsigned& s1)
+{
+    const uint4 e = v.ent[k];
+    const bool da = !(e.x & JP_STATIC_BIT), db = !(e.y & JP_STATIC_BIT);
+    const unsigned a = e.x & ~JP_STATIC_BIT, b = e.y & ~JP_STATIC_BIT;
+    comp = (int)v.ent_comp[k];
+    unsigned long long m = 0;
+    int c = 0;
+    if (da) m |= v.used[a];
+    if (db) m |= v.used[b];
+    if (!~m) atomicOr(v.flags, 2);
+    else {
+        c = __builtin_ctzll(~m);
+        if (da) v.used[a] |= 1ull << c;
+        if (db) v.used[b] |= 1ull << c;
+        got_a = 1ull << c;
+    }
+    if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
+        unsigned long long mb = 0;
+        if (da) mb |= v.used_b[a];
+        if (db) mb |= v.used_b[b];
+        const int d0 = da ? (int)(v.offset[a + 1] - v.offset[a]) : 0, d1 = db ? (int)(v.offset[b + 1] - v.offset[b]) : 0;
+        const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
+        if (cb < 0) v.bad_b[comp] = 1;
+        else {
+            if (da) v.used_b[a] |= 1ull << cb;
+            if (db) v.used_b[b] |= 1ull << cb;
+            got_b = 1ull << cb;
+            v.colour_b[k] = (unsigned)cb;
+        }
+    }
+    v.colour[k] = (unsigned)c;
+    const uint2 s = v.succ[k];
+    if (s.x != JP_NONE && (atomicSub(&v.pred[s.x], 1u) & 0xFFFFu) == 1u) s0 = s.x;
+    if (s.y != JP_NONE && (atomicSub(&v.pred[s.y], 1u) & 0xFFFFu) == 1u) s1 = s.y;
+}
+
+// 'colours in use' of the components, wave-aggregated: in a merged island every entry of a round belongs to ONE component, and
+// thousands of same-address atomics serialise
+__device__ __forceinline__ void jp_note_colours(const JpView& v, int comp, unsigned long long got_a, unsigned long long got_b)
+{
+    const int lane = threadIdx.x & 63;
+    for (unsigned long long todo = __ballot((got_a | got_b) != 0); todo;) {
+        const int leader = __builtin_ctzll(todo);
+        const int lc = __shfl(comp, leader);
+        const bool mine = (got_a | got_b) != 0 && comp == lc;
+        unsigned long long ra = mine ? got_a : 0ull, rb = mine ? got_b : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { ra |= __shfl_xor(ra, off); rb |= __shfl_xor(rb, off); }
+        if (lane == leader) {
+            if (ra & ~v.seen_a[lc]) atomicOr(&v.seen_a[lc], ra);
+            if (rb & ~v.seen_b[lc]) atomicOr(&v.seen_b[lc], rb);
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
 static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int round, const unsigned* __restrict__ list_in, unsigned* __restrict__ list_out)
 {
     __shared__ int wave_n[JP_FRONT_T / 64];
@@ -1208,64 +1265,13 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
 #pragma unroll
         for (int it = 0; it < JP_ITEMS; ++it) {
             const int i = base + it * (int)blockDim.x + (int)threadIdx.x;
-            unsigned k = 0, s0 = JP_NONE, s1 = JP_NONE;
+            unsigned s0 = JP_NONE, s1 = JP_NONE;
             int comp = 0;
             unsigned long long got_a = 0, got_b = 0;         // the colour bits this entry took under candidates A / B
-            bool mine_now = i < n;
-            if (mine_now) {
-                k = list_in[i];
-            }
-            if (mine_now) {
-                const uint4 e = v.ent[k];
-                const bool da = !(e.x & JP_STATIC_BIT), db = !(e.y & JP_STATIC_BIT);
-                const unsigned a = e.x & ~JP_STATIC_BIT, b = e.y & ~JP_STATIC_BIT;
-                comp = (int)v.ent_comp[k];
-                unsigned long long m = 0;
-                int c = 0;
-                if (da) m |= v.used[a];
-                if (db) m |= v.used[b];
-                if (!~m) atomicOr(v.flags, 2);
-                else {
-                    c = __builtin_ctzll(~m);
-                    if (da) v.used[a] |= 1ull << c;
-                    if (db) v.used[b] |= 1ull << c;
-                    got_a = 1ull << c;
-                }
-                if (comp < v.ncomp && v.comp_size[comp] <= (unsigned)COLOUR_B_MAX_JOINTS) {      // candidate B: the same turn, the two-ended choice
-                    unsigned long long mb = 0;
-                    if (da) mb |= v.used_b[a];
-                    if (db) mb |= v.used_b[b];
-                    const int d0 = da ? (int)(v.offset[a + 1] - v.offset[a]) : 0, d1 = db ? (int)(v.offset[b + 1] - v.offset[b]) : 0;
-                    const int cb = colour_pick_two_ended(mb, d0 > d1 ? d0 : d1, ((a < b ? a : b) & 1u) != 0);
-                    if (cb < 0) v.bad_b[comp] = 1;
-                    else {
-                        if (da) v.used_b[a] |= 1ull << cb;
-                        if (db) v.used_b[b] |= 1ull << cb;
-                        got_b = 1ull << cb;
-                        v.colour_b[k] = (unsigned)cb;
-                    }
-                }
-                v.colour[k] = (unsigned)c;
-                const uint2 s = v.succ[k];
-                if (s.x != JP_NONE && (atomicSub(&v.pred[s.x], 1u) & 0xFFFFu) == 1u) s0 = s.x;
-                if (s.y != JP_NONE && (atomicSub(&v.pred[s.y], 1u) & 0xFFFFu) == 1u) s1 = s.y;
-            }
+            if (i < n) jp_colour_entry(v, list_in[i], comp, got_a, got_b, s0, s1);
             rel[2 * it] = s0; rel[2 * it + 1] = s1;
             released += (s0 != JP_NONE ? 1 : 0) + (s1 != JP_NONE ? 1 : 0);
-            // 'colours in use' of the components, wave-aggregated: in a merged island every entry of a round belongs to ONE
-            // component, and thousands of same-address atomics serialise
-            for (unsigned long long todo = __ballot((got_a | got_b) != 0); todo;) {
-                const int leader = __builtin_ctzll(todo);
-                const int lc = __shfl(comp, leader);
-                const bool mine = (got_a | got_b) != 0 && comp == lc;
-                unsigned long long ra = mine ? got_a : 0ull, rb = mine ? got_b : 0ull;
-                for (int off = 32; off > 0; off >>= 1) { ra |= __shfl_xor(ra, off); rb |= __shfl_xor(rb, off); }
-                if (lane == leader) {
-                    if (ra & ~v.seen_a[lc]) atomicOr(&v.seen_a[lc], ra);
-                    if (rb & ~v.seen_b[lc]) atomicOr(&v.seen_b[lc], rb);
-                }
-                todo &= ~__ballot(mine);
-            }
+            jp_note_colours(v, comp, got_a, got_b);
         }
         // the released successors -> next frontier: exclusive position of this lane's first one inside the workgroup
         int incl = released;
@@ -1284,6 +1290,66 @@ static __global__ void __launch_bounds__(JP_FRONT_T) k_jp_front(JpView v, int ro
         for (int q = 0; q < 2 * JP_ITEMS; ++q) if (rel[q] != JP_NONE) list_out[at++] = rel[q];
         __syncthreads();                                                     // wave_n / block_base are reused by the next trip
     }
+}
+
+// The WHOLE walk in one launch, by one workgroup (round 6): for the few thousand units that are not interior to a part of a partitioned
+// island (its boundary units) or the joints of a small Single-mode world, a round is a microsecond of work behind a launch and the walk is
+// eight to twenty rounds deep — plus the host's look at the frontier sizes in between.  One workgroup walks round after round with a
+// barrier in between (its own stores are visible to its later loads: one CU, one L1; the predecessor counts are atomics at the coherent
+// level) until the frontier is empty, and leaves {rounds, entries walked, 'ran into rounds_max'} for the build's last readback.  Frontier r
+// is read from all JP_SUBLISTS sublists (round 0's come from k_jp_seed) and frontier r + 1 is written to sublist 0 alone — one workgroup
+// needs no atomics to append.  The host takes this path when the previous build walked few entries (solver_build.hip); the classes are
+// k_jp_front's: both call jp_colour_entry, and a frontier's entries share no dynamic body whatever order they are taken in.
+constexpr int JP_WALK_T = 1024;
+constexpr long long JP_WALK_ONE_MAX = 32768;      // entries the previous build walked, at most, for the host to take this path (a trip of the one workgroup is ~1 us)
+static __global__ void __launch_bounds__(JP_WALK_T) k_jp_walk_one(JpView v, int rounds_max, unsigned* __restrict__ list0, unsigned* __restrict__ list1, int* __restrict__ result)
+{
+    __shared__ int pre[JP_SUBLISTS + 1];
+    __shared__ int wave_n[JP_WALK_T / 64];
+    __shared__ int out_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int walked = 0, round = 0;
+    if (tid == 0) out_n = 0;
+    for (; round < rounds_max; ++round) {
+        const unsigned* list_in = (round & 1) ? list1 : list0;
+        unsigned* list_out = ((round & 1) ? list0 : list1);                  // (sublist 0)
+        if (tid == 0) {                                                      // (round 0: k_jp_seed's eight counts; later rounds: what this workgroup appended to sublist 0)
+            int at = 0;
+            for (int q = 0; q < JP_SUBLISTS; ++q) { pre[q] = at; at += round == 0 ? v.counts[q] : (q == 0 ? out_n : 0); }
+            pre[JP_SUBLISTS] = at; out_n = 0;
+        }
+        __syncthreads();
+        const int n = pre[JP_SUBLISTS];
+        if (n == 0) break;                                                   // (workgroup-uniform)
+        walked += n;
+        for (int base = 0; base < n; base += JP_WALK_T) {
+            const int i = base + tid;
+            unsigned s0 = JP_NONE, s1 = JP_NONE;
+            int comp = 0;
+            unsigned long long got_a = 0, got_b = 0;
+            if (i < n) {
+                int q = 0;
+                while (i >= pre[q + 1]) ++q;
+                jp_colour_entry(v, list_in[(size_t)q * v.count + (i - pre[q])], comp, got_a, got_b, s0, s1);
+            }
+            const int released = (s0 != JP_NONE ? 1 : 0) + (s1 != JP_NONE ? 1 : 0);
+            jp_note_colours(v, comp, got_a, got_b);
+            int incl = released;
+            for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+            if (lane == 63) wave_n[wave] = incl;
+            __syncthreads();
+            int at = out_n + incl - released, total = 0;
+            for (int w = 0; w < JP_WALK_T / 64; ++w) { if (w < wave) at += wave_n[w]; total += wave_n[w]; }
+            if (s0 != JP_NONE) list_out[at++] = s0;
+            if (s1 != JP_NONE) list_out[at++] = s1;
+            __syncthreads();                                                 // (everybody has read out_n and wave_n)
+            if (tid == 0) out_n += total;
+        }
+        __syncthreads();
+        if (tid == 0) v.counts[(round + 1) * JP_SUBLISTS] = out_n;          // (the other sublists of round + 1 are empty: k_jp_clear)
+        __syncthreads();
+    }
+    if (tid == 0) { result[0] = round; result[1] = walked; result[2] = round >= rounds_max ? 1 : 0; }
 }
 
 // ---- the interior units of partitioned components, coloured part by part in LDS ----------------------------------------

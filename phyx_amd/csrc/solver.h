@@ -177,6 +177,7 @@ private:
     // the PHX_* knobs (measurement and debugging; README.md lists them)
     struct Options {
         bool no_side_stream = false;      // PHX_NO_SIDE_STREAM=1: everything on the one stream
+        bool no_jp_walk_one = false;      // PHX_NO_JP_WALK_ONE=1: the HBM group's colouring walk always one launch per round (k_jp_front) with the host's look in between
         bool no_tail = false;             // PHX_NO_TAIL=1: the HBM group's trailing tiny classes one launch each (k_solve_colour) instead of one workgroup's launch (k_solve_tail)
         bool no_parts = false;            // PHX_NO_PARTS=1: sweep the interior classes one launch each
         bool no_fused_verify = false;     // PHX_NO_FUSED_VERIFY=1: always the hash pass (also set for good once a verified launch timed out)
@@ -252,6 +253,7 @@ private:
         DevBuf<uint4> jp_ent, jp_adj;
         DevBuf<uint2> jp_succ;
         DevBuf<unsigned> jp_offset, jp_cursor, jp_pred, jp_ent_comp, jp_seed, jp_touched, jp_keys[2], jp_vals[2], jp_degree, jp_colour_b, jp_list[2];
+        DevBuf<int> jp_walk_result;         // k_jp_walk_one: {rounds, entries walked, ran out of rounds}
         DevBuf<unsigned char> jp_bad_b, jp_kind;
         DevBuf<int> jp_small, jp_counts;
     } bld_;
@@ -272,6 +274,7 @@ private:
                           : PartsView{parts_.ranges.p, parts_.begin.p, parts_.class_tab.p, P, P + 1, ki0, ki};
     }
     int jp_rounds_guess_ = 0;
+    long long jp_walk_entries_ = -1;      // entries the last build's colouring walk visited (-1: no build yet): few -> k_jp_walk_one
     // a device-built schedule whose 'did every bin fit' flag has not been read yet (build_schedule_device, collect_stats)
     bool build_unverified_ = false, build_was_unverified_ = false, force_host_builder_ = false, defer_build_check_ = true;
     int unverified_bins_ = 0;

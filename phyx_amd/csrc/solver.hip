@@ -51,6 +51,7 @@ DeviceSolver::Options DeviceSolver::Options::from_env()
     auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
     Options o;
     o.no_side_stream = on("PHX_NO_SIDE_STREAM");          // everything on the one stream (A/B measurements)
+    o.no_jp_walk_one = on("PHX_NO_JP_WALK_ONE");
     o.no_tail = on("PHX_NO_TAIL");                        // the trailing tiny classes of the HBM group one launch each (A/B, tests)
     o.no_parts = on("PHX_NO_PARTS");                      // the interior classes of partitioned components one launch each (A/B, tests)
     o.no_fused_verify = on("PHX_NO_FUSED_VERIFY");        // the topology hash pass in front of every solve on a cached schedule

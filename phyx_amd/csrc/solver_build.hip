@@ -571,7 +571,16 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         }
         // the rounds: as many as the previous build needed (+2) before the first look at the frontier, then in small batches
         int round = 0;
-        for (bool done = false; !done;) {
+        // (round 6: when the previous build walked few entries, ONE workgroup walks all the rounds in one launch and the host never looks at
+        //  the frontier sizes: k_jp_walk_one — its {rounds, entries, 'ran out of rounds'} come back with the build's last readback)
+        const bool walk_one = !trace && !opt_.no_jp_walk_one && jp_walk_entries_ >= 0 && jp_walk_entries_ <= JP_WALK_ONE_MAX;
+        int walk_result[3] = {0, 0, 0};
+        long long walked = 0;
+        if (walk_one) {
+            PHX_TRY(bld_.jp_walk_result.reserve(4));
+            hipLaunchKernelGGL(k_jp_walk_one, dim3(1), dim3(JP_WALK_T), 0, stream_, jv, JP_ROUNDS_MAX, bld_.jp_list[0].p, bld_.jp_list[1].p, bld_.jp_walk_result.p);
+        }
+        for (bool done = walk_one; !done;) {
             const int batch = round == 0 ? std::min(std::max(jp_rounds_guess_ + 2, JP_BATCH), JP_ROUNDS_MAX) : JP_BATCH;
             if (round + batch > JP_ROUNDS_MAX) { *fallback = true; return PHX_OK; }           // pathological dependency chain: host builder
             for (int k = 0; k < batch; ++k, ++round)
@@ -588,6 +597,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
                 int n = 0;
                 for (int q = 0; q < JP_SUBLISTS; ++q) n += sizes[(size_t)k * JP_SUBLISTS + q];
                 if (n == 0) { done = true; jp_rounds_guess_ = round - batch + k; }
+                else if (k < batch) walked += n;                                               // (the batch's last entry is the next batch's first)
             }
         }
         if (trace) fprintf(stderr, "[schedule/gpu] HBM group: %d joints, %d rounds (%d launched)\n", rest, jp_rounds_guess_, round);
@@ -619,7 +629,14 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
         hipLaunchKernelGGL(k_static_slots, dim3(grid_for(nb)), dim3(256), 0, stream_, (const unsigned char*)bld_.cc_static.p, (const unsigned*)sflags, nb, hbm_.static_slot.p);
         PHX_TRY(rb_.add(&h_nstatic, sflags + nb, sizeof h_nstatic, stream_));
         PHX_TRY(rb_.add(h_flags, bld_.jp_small.p, sizeof h_flags, stream_));
+        if (walk_one) { PHX_TRY(with_fingerprint()); PHX_TRY(rb_.add(walk_result, bld_.jp_walk_result.p, sizeof walk_result, stream_)); }
         PHX_TRY(rb_.wait(stream_));
+        if (walk_one) {                                        // what the rounds' loop checks between its batches
+            if (h_flags[0] & 1) { set_error("a joint references a body out of range"); return PHX_ERR_INVALID; }
+            if ((h_flags[0] & 4) || walk_result[2]) { *fallback = true; return PHX_OK; }       // a body in thousands of joints, or a pathological dependency chain: host builder
+            jp_rounds_guess_ = walk_result[0]; walked = walk_result[1];
+        }
+        jp_walk_entries_ = walked;
         if (h_flags[0] & 2) { *fallback = true; return PHX_OK; }
         sc.hbm_interior_classes = h_flags[1] + h_flags[2]; sc.hbm_interior_classes0 = h_flags[1];
         nstatic_ = (int)h_nstatic;

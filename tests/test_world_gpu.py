@@ -668,7 +668,8 @@ def test_debugging_knobs_do_not_change_results(built_lib):
     mechanisms — like the fused launches of partitioned components, the second stream and the in-kernel schedule check: with each of
     them switched off (PHX_NO_MAILBOX, PHX_NO_SPECULATION, PHX_SCHEDULE_BUILDER=host, PHX_NO_SPEC_BINS, PHX_NO_PARTS, PHX_NO_SIDE_STREAM,
     PHX_NO_FUSED_VERIFY, PHX_NO_SPLIT_SORT, PHX_NO_MAIL_CARRIER — the mailbox posts riding in the next kernel's first workgroup —, PHX_NO_TAIL —
-    the HBM group's trailing tiny classes one launch each instead of one workgroup's launch) a world that
+    the HBM group's trailing tiny classes one launch each instead of one workgroup's launch —, PHX_NO_JP_WALK_ONE — its colouring walk one launch per
+    round with the host's look in between instead of one workgroup's launch) a world that
     rebuilds its schedule every step, merges islands and falls back to the host builder (a 90-box clique) must produce the very
     same bytes."""
     import os
@@ -688,7 +689,7 @@ def test_debugging_knobs_do_not_change_results(built_lib):
         assert len(want) == 64
         for knob in ({"PHX_NO_MAILBOX": "1"}, {"PHX_NO_SPECULATION": "1"}, {"PHX_SCHEDULE_BUILDER": "host"}, {"PHX_NO_SPEC_BINS": "1"},
                      {"PHX_NO_PARTS": "1"}, {"PHX_NO_SIDE_STREAM": "1"}, {"PHX_NO_FUSED_VERIFY": "1"}, {"PHX_NO_SPLIT_SORT": "1"}, {"PHX_NO_MAIL_CARRIER": "1"},
-                     {"PHX_NO_PRELABEL": "1"}, {"PHX_NO_TAIL": "1"}):
+                     {"PHX_NO_PRELABEL": "1"}, {"PHX_NO_TAIL": "1"}, {"PHX_NO_JP_WALK_ONE": "1"}):
             assert digest(knob, mode) == want, (knob, mode)
 
 
