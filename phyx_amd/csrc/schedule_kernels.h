@@ -83,6 +83,8 @@ static __global__ void __launch_bounds__(256) k_cc_link(const phx_contact_joint*
         // shallow: in a world merged into one island the flattening pass falls from 41 to 16 us for 11 us more here; on separate
         // stacks the loads only cost (6.6 -> 9.2 us at cfg 2), so the host asks for them when the last schedule had an HBM group.
         // (link + flatten in the settled 200k world by hops: 0: 60 + 40 us, 1: 56 + 34, 2: 57 + 35, 3: 68 + 15, 5: 110 + 13, 8: 113 + 12.)
+        // (round 6: the flattening pass is two launches now, ~20 us whatever the trees look like — the host asks for ONE hop where it asked for
+        //  three: settled step 1.47 - 1.54 -> 1.43 - 1.48 ms, the loosened world's 1.96 - 2.04 -> 1.91 - 1.96; none: in between.)
         for (int hop = 0; hop < hops; ++hop) {
             const int ph = parent[hi], pl = parent[lo];
             if (ph == hi && pl == lo) break;

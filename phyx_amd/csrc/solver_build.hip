@@ -364,7 +364,7 @@ int DeviceSolver::build_schedule_device(const float4* d_bodies, int nb, const ph
     PHX_TRY(bld_.sort_hist.reserve(radix_hist_words(nj)));
     {
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
+                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 1 : 0);
         hipLaunchKernelGGL(k_cc_compress_window, dim3(std::max(1, div_up(nb, CCW_BODIES))), dim3(CCW_T), 0, stream_, bld_.cc_parent.p, nb);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size().p, bld_.comp_units().p}, bld_.cc_flags.p, nb + 1,
@@ -703,7 +703,7 @@ int DeviceSolver::build_bins_speculative(const float4* d_bodies, int nb, const p
     } else {
         ++full_builds_;
         hipLaunchKernelGGL(k_cc_link, dim3(grid_for(nj)), dim3(256), 0, stream_, d_joints, nj, nb, bld_.cc_parent.p, (const unsigned char*)bld_.cc_static.p,
-                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 3 : 0);
+                           (const unsigned long long*)bld_.partner_first.p, bld_.partner_tag, ncp_, bld_.partner.p, sched_.has_hbm_group() ? 1 : 0);
         hipLaunchKernelGGL(k_cc_compress_window, dim3(std::max(1, div_up(nb, CCW_BODIES))), dim3(CCW_T), 0, stream_, bld_.cc_parent.p, nb);
         hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nb)), dim3(256), 0, stream_, bld_.cc_parent.p, nb, bld_.sb_small.p);
         PHX_TRY(device_exclusive_scan_of(RootFlagLoad{(const int*)bld_.cc_parent.p, nb, bld_.comp_size().p, bld_.comp_units().p}, bld_.cc_flags.p, nb + 1,
